@@ -1,0 +1,138 @@
+"""Synthetic BEAR-shaped scenes (datasets are not shipped with the reference).
+
+Geometry follows DiLiGenT-MV as described in SURVEY.md 8(d): 612x512 images, 96
+lights per view, f ~= 3759 px, look-at camera at the middle of [near, far], GL->CV
+pose flip as in stage1/dataloading/dataset.py:56.  Pure torch/numpy; no HIP, no
+oracle imports.  Everything is deterministic in its seed arguments.
+"""
+import hashlib
+import math
+
+import numpy as np
+import torch
+
+STAGE1_BUNNY = {
+    'model': dict(num_layers=8, hidden_dim=256, octaves_pe=6, octaves_pe_views=4, skips=[4],
+                  geometric_init=True, feat_size=256, rescale=1.0),
+    'rendering': dict(type='unisurf', n_max_network_queries=64000, white_background=True, near=2, far=6,
+                      radius=2.0, interval_start=2.0, interval_end=0.1, interval_decay=0.000015,
+                      num_points_in=64, num_points_out=32, ray_marching_steps=256, occ_prob_points=64),
+    'training': dict(type='unisurf', normal_loss=True, normal_after=1000, normal_angle=65,
+                     lambda_normloss=0.05, lambda_mask=1.0, n_training_points=2048, learning_rate=0.0001,
+                     weight_decay=0.0, lambda_l1_rgb=1.0, lambda_normals=0.005),
+}
+
+
+def stage1_cfg(obj='bunny', **over):
+    """stage1/configs/{bunny,bear}.yaml restricted to the hot-path keys.
+    ``over`` uses 'section.key' names, e.g. ``**{'model.hidden_dim': 64}``."""
+    import copy
+    cfg = copy.deepcopy(STAGE1_BUNNY)
+    if obj == 'bear':
+        cfg['rendering'].update(near=28, far=35)
+    for k, v in over.items():
+        sec, key = k.split('.')
+        cfg[sec][key] = v
+    return cfg
+
+
+def look_at_pose(dist, az_deg=30.0, el_deg=20.0):
+    """c2w [4,4] (OpenCV convention: +z forward) looking at the origin from ``dist``."""
+    az, el = math.radians(az_deg), math.radians(el_deg)
+    eye = np.array([dist * math.cos(el) * math.sin(az), dist * math.sin(el), dist * math.cos(el) * math.cos(az)])
+    fwd = -eye / np.linalg.norm(eye)
+    up = np.array([0.0, 1.0, 0.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, eye
+    return torch.from_numpy(c2w)
+
+
+def stage1_camera(cfg, h=512, w=612, focal=None):
+    """(camera_mat [1,4,4], world_mat [1,4,4], scale_mat [1,4,4]) for a synthetic view.
+    The focal length is chosen so the object fills the frame at the camera
+    distance (DiLiGenT-MV BEAR: f ~= 3759 px at distance ~31.5 for 612x512)."""
+    near, far = cfg['rendering']['near'], cfg['rendering']['far']
+    dist = 0.5 * (near + far)
+    if focal is None:
+        # a 0.6-radius object (the geometric-init sphere) spans ~70 % of the image height
+        focal = 0.35 * h * dist / 0.6
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = focal
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    return K[None], look_at_pose(dist)[None], torch.eye(4)[None]
+
+
+def perturb_state_dict(sd, seed, scale=0.03):
+    """Deterministically jitter a freshly initialised state_dict so tests do not
+    run on the degenerate geometric init (zero PE columns, identical rows)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and v.numel() > 1:
+            s = scale * float(v.abs().mean() + 1e-3)
+            out[k] = v + s * torch.randn(v.shape, generator=g, dtype=v.dtype)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def state_dict_digest(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd.keys()):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k].detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def stage1_batch(cfg, h=64, w=80, seed=0):
+    """A synthetic stage-1 data dict (the keys Trainer.process_data_dict reads,
+    stage1/model/training.py:120-139)."""
+    g = torch.Generator().manual_seed(seed)
+    K, c2w, S = stage1_camera(cfg, h=h, w=w)
+    img = torch.rand(1, 3, h, w, generator=g)
+    mask = (torch.rand(1, h, w, generator=g) > 0.3).float()
+    normal = torch.nn.functional.normalize(torch.randn(1, 3, h, w, generator=g), dim=1)
+    normal[:, 2] = normal[:, 2].abs()
+    return {'img': img, 'img.mask': mask, 'img.world_mat': c2w, 'img.camera_mat': K, 'img.scale_mat': S,
+            'img.normal': normal, 'img.norm_mask': (torch.rand(1, h, w, generator=g) > 0.2).float()}
+
+
+def stage2_inputs(n_pixels, n_lights, n_vis, seed=0, surface_frac=0.9, h=512, w=612, device='cpu'):
+    """Synthetic stage-2 model_input / ground_truth (keys of stage2/model/renderer.py:110-125 and
+    stage2/trainer.py:364-392): points U(-0.6,0.6)^3, unit normals, lights in the camera hemisphere."""
+    g = torch.Generator().manual_seed(seed)
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 3759.0
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    pose = look_at_pose(31.5)
+    uv = torch.stack([torch.randint(0, w, (n_pixels,), generator=g).float(),
+                      torch.randint(0, h, (n_pixels,), generator=g).float()], -1)[None]
+    surface_mask = (torch.rand(1, n_pixels, generator=g) < surface_frac)
+    object_mask = surface_mask | (torch.rand(1, n_pixels, generator=g) < 0.05)
+    points = (torch.rand(1, n_pixels, 3, generator=g) * 1.2 - 0.6)
+    normal = torch.nn.functional.normalize(torch.randn(1, n_pixels, 3, generator=g), dim=-1)
+
+    def hemi(n):
+        d = torch.randn(n, 3, generator=g)
+        d = torch.nn.functional.normalize(d, dim=-1)
+        toward_cam = torch.nn.functional.normalize(pose[:3, 3], dim=0)
+        flip = (d @ toward_cam) < 0
+        d[flip] = -d[flip]
+        return d
+
+    inp = {
+        'intrinsics': K[None], 'uv': uv, 'pose': pose[None], 'object_mask': object_mask,
+        'surface_mask': surface_mask, 'points': points, 'normal': normal,
+        'light_direction': hemi(n_lights), 'light_intensity': 2.0 * torch.ones(n_lights, 1),
+        'light_vis_train': hemi(n_vis),
+        'vis_train_gt': (torch.rand(n_vis, n_pixels, generator=g) < 0.7).float(),
+        'visibility': (torch.rand(n_lights, n_pixels, generator=g) < 0.7).float(),
+    }
+    gt = {'rgb': torch.rand(n_lights, n_pixels, 3, generator=g)}
+    if device != 'cpu':
+        inp = {k: v.to(device) for k, v in inp.items()}
+        gt = {k: v.to(device) for k, v in gt.items()}
+    return inp, gt
