@@ -1,0 +1,139 @@
+/*
+ * psnerf_hip.h -- C ABI of libpsnerf_hip.so, the MI355X (gfx950) implementation
+ * of the PS-NeRF hot path.
+ *
+ * The reference (ywq/psnerf) has no native boundary: its hot path is PyTorch
+ * eager code under nn.Module.forward().  These entry points are what a
+ * ctypes/cffi binding on the reference side would call for each torch
+ * expression they replace (citations are relative to /root/reference).  All
+ * pointers are DEVICE pointers to contiguous fp32 (or int32 where stated)
+ * buffers owned by the caller (PyTorch's allocator in our host code); the
+ * library never allocates or frees device memory and keeps no global state.
+ * `stream` is a hipStream_t passed as void* (0 = default stream).  Every
+ * function returns 0 on success or a negative PSN_E_* code; psn_last_error()
+ * returns a thread-local description of the most recent failure.  Kernels are
+ * launched asynchronously on `stream`; no function synchronises the device.
+ */
+#ifndef PSNERF_HIP_H
+#define PSNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSN_OK 0
+#define PSN_E_ARG (-1)     /* bad shape / null pointer / misaligned buffer */
+#define PSN_E_LAUNCH (-2)  /* hipLaunchKernel / hipGetLastError failure */
+#define PSN_E_UNSUPPORTED (-3)
+
+const char* psn_last_error(void);
+int psn_version(void);
+
+/* ------------------------------------------------------------------------
+ * Alpha composite -- stage1/model/rendering.py:196-197,214-216 (and :405-406)
+ *   w_i   = alpha_i * prod_{j<i} (1 - alpha_j + 1e-6)
+ *   rgb   = sum_i w_i c_i (+ 1 - acc if white_bg),   acc = sum_i w_i
+ * alpha [n_rays, n_samples], rgb [n_rays, n_samples, 3] (may be NULL: acc only),
+ * weights [n_rays, n_samples] (saved for backward; may be NULL),
+ * rgb_out [n_rays, 3] (NULL iff rgb NULL), acc_out [n_rays].
+ * n_samples <= 1024.
+ * ---------------------------------------------------------------------- */
+int psn_composite_fwd(const float* alpha, const float* rgb, int64_t n_rays, int n_samples, int white_bg,
+                      float* weights, float* rgb_out, float* acc_out, void* stream);
+/* d_rgb_out [n_rays,3], d_acc_out [n_rays] (may be NULL) -> d_alpha [n_rays,n_samples], d_rgb [n_rays,n_samples,3] */
+int psn_composite_bwd(const float* alpha, const float* rgb, const float* d_rgb_out, const float* d_acc_out,
+                      int64_t n_rays, int n_samples, int white_bg, float* d_alpha, float* d_rgb, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Positional encodings.
+ *   layout 0: stage1 PositionalEncoding (stage1/model/network.py:141-150)
+ *   layout 0 is also stage2 Embedder (stage2/model/embedder.py:6-54): both are
+ *   [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...] with 3-vectors per block.
+ * x [n, 3] -> out [n, out_stride] (first 3+6*n_freqs columns written, the
+ * rest zero-filled up to out_stride).  `scale` multiplies x first (1/rescale).
+ * ---------------------------------------------------------------------- */
+int psn_pe_encode(const float* x, int64_t n, int n_freqs, float scale, float* out, int out_stride, void* stream);
+/* d_out [n, out_stride] -> d_x [n,3] (chain rule through sin/cos; x is re-read) */
+int psn_pe_encode_bwd(const float* x, const float* d_out, int64_t n, int n_freqs, float scale, int out_stride,
+                      float* d_x, void* stream);
+
+/* ------------------------------------------------------------------------
+ * fp32-MFMA GEMM with fused epilogues: the torch.nn.Linear / addmm / mm calls
+ * of stage1/model/network.py:85-106 and stage2/model/renderer.py:17-49 and
+ * their autograd backward.
+ *   C[M,N] = epi( opA(A)[M,K] * opB(B)[K,N] )
+ * trans_a = 0: A is [M,K] row-major (lda);  1: A is stored [K,M] row-major.
+ * trans_b = 0: B is [K,N] row-major (ldb);  1: B is stored [N,K] row-major
+ *              (a torch Linear weight -> y = x W^T is trans_a=0, trans_b=1).
+ * split_k > 1 (only epi NONE/ACCUM): K is cut into split_k slices, partial
+ * tiles go to `workspace` (>= split_k*M*N floats) and are reduced
+ * deterministically by a second kernel.
+ * ---------------------------------------------------------------------- */
+enum {
+    PSN_EPI_NONE = 0,          /* C = acc                                            */
+    PSN_EPI_BIAS = 1,          /* C = acc + bias[n]                                  */
+    PSN_EPI_BIAS_RELU = 2,     /* C = relu(acc + bias[n])                            */
+    PSN_EPI_BIAS_SOFTPLUS = 3, /* C = softplus_100(z), aux_out = sigmoid(100 z), z = acc+bias */
+    PSN_EPI_MUL_AUX = 4,       /* C = acc * aux_in[m,n]                              */
+    PSN_EPI_MUL_POS = 5,       /* C = acc * (aux_in[m,n] > 0)   (ReLU backward)      */
+    PSN_EPI_BIAS_SIGMOID = 6,  /* C = sigmoid(acc + bias[n])                         */
+    PSN_EPI_ACCUM = 7          /* C += acc                                           */
+};
+int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const float* A, int64_t lda, const float* B,
+             int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue, const float* aux_in,
+             int64_t ld_aux_in, float* aux_out, int64_t ld_aux_out, int split_k, float* workspace, void* stream);
+
+/* column sums: out[n] (+)= sum_m X[m,n]  -- bias gradients.  workspace >= 256*N floats */
+int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int accumulate, float* workspace,
+               void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fully fused MLP inference (activations never leave registers).  Replaces the
+ * no-grad network evaluations: stage2 visibility_net over L*Ns rows
+ * (stage2/model/renderer.py:191-200, vis.detach()), stage1 occupancy queries
+ * in ray_marching / secant / light_visibility (stage1/model/rendering.py:
+ * 456-462, 537-540, 394-399).
+ *
+ * Hidden width is fixed at 256 (8 tiles of 32).  A network is described by
+ * PsnMlpDesc; weights are pre-packed into MFMA fragment order by
+ * psn_mlp_pack_layer (one call per layer, into one contiguous buffer).
+ * ---------------------------------------------------------------------- */
+#define PSN_MLP_MAX_LAYERS 12
+enum { PSN_ACT_NONE = 0, PSN_ACT_RELU = 1, PSN_ACT_SOFTPLUS100 = 2 };
+enum { PSN_OUT_NONE = 0, PSN_OUT_SIGMOID = 1, PSN_OUT_OCC = 2 /* sigmoid(-10 x), network.py:125 */ };
+
+typedef struct {
+    int n_kt_in;   /* 32-wide K tiles taken from the input-feature registers (0..4) */
+    int n_kt_act;  /* 32-wide K tiles taken from the previous layer's activations (0 or 8) */
+    int n_mt;      /* 32-wide output tiles: 8 (hidden) or 1 (final) */
+    int act;       /* PSN_ACT_* applied to this layer's output */
+    int64_t w_off; /* float offset of this layer's packed weights */
+    int64_t b_off; /* float offset of this layer's bias (n_mt*32 floats, zero padded) */
+} PsnMlpLayer;
+
+typedef struct {
+    int n_layers;
+    int n_out;    /* real outputs of the final layer (<= 32) */
+    int out_act;  /* PSN_OUT_* */
+    int in_kt_a;  /* K tiles (of 32 floats) per row of feature table A (1..4) */
+    int in_kt_b;  /* K tiles per row of table B (0 = unused); in_kt_a + in_kt_b <= 4 */
+    PsnMlpLayer layers[PSN_MLP_MAX_LAYERS];
+} PsnMlpDesc;
+
+/* Pack a dense, zero-padded row-major weight W[n_mt*32, k_tiles*32] (ldw floats per
+ * row) into `dst` (n_mt*32 * k_tiles*32 floats) in stage order. */
+int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_tiles, float* dst, void* stream);
+
+/* Row q of the virtual input matrix is [ A[(q / a_div) % a_mod, :] | B[(q / b_div) % b_mod, :] ];
+ * tables are row-major with strides in_kt_a*32 / in_kt_b*32 floats, 16-byte aligned.
+ * out [n_rows, n_out]. */
+int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
+                  int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
+                  int64_t n_rows, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSNERF_HIP_H */

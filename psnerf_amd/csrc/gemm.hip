@@ -1,0 +1,307 @@
+// fp32 GEMM on v_mfma_f32_32x32x2_f32 with fused epilogues (training path of every MLP on the hot path).
+// Reference ops replaced: torch.nn.Linear / F.relu / nn.Softplus(beta=100) and their autograd backward
+// in stage1/model/network.py:85-106 and stage2/model/renderer.py:17-49.
+//
+// Workgroup tile 128x128x16, 4 waves in a 2x2 grid, each wave 64x64 = 2x2 MFMA tiles (64 accumulator
+// VGPRs).  Operand tiles are staged k-major in LDS ([16][128+4] floats) so that every MFMA operand read
+// is a conflict-free ds_read_b32 of 32 consecutive floats; the next k-tile is fetched into registers
+// while the current one is multiplied (one barrier per k-tile).  Numerics: exact fp32 fma chain per
+// output element (k-ordered), see MI355X guide "FP32-input MFMA".
+#include "common.h"
+
+namespace psn {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+
+struct GemmArgs {
+    int64_t M;
+    int N, K;
+    const float* A;
+    int64_t lda;
+    const float* B;
+    int64_t ldb;
+    float* C;
+    int64_t ldc;
+    const float* bias;
+    int epi;
+    const float* aux_in;
+    int64_t ld_aux_in;
+    float* aux_out;
+    int64_t ld_aux_out;
+    int k_chunk;  // K range per blockIdx.z (multiple of BK)
+    int tiles_n;
+    int64_t n_tiles;  // tiles_m * tiles_n
+    int a_vec, b_vec;  // 16-byte vector loads allowed
+    int64_t split_stride;  // floats between split-K partial outputs (0 when split_k == 1)
+};
+
+// Stage one 128 x 16 operand tile into registers.  KCONTIG: source rows run along k (row-major [rows][K]);
+// otherwise the source is [K][rows] row-major.
+template <bool KCONTIG>
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t n_rows,
+                                           int k0, int k_end, int vec_ok, int tid, float4 (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int f = tid + 256 * u;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KCONTIG) {
+            int r = f >> 2, kq = (f & 3) * 4;
+            int64_t row = row0 + r;
+            int k = k0 + kq;
+            if (row < n_rows) {
+                const float* p = src + row * ld + k;
+                if (vec_ok && k + 3 < k_end) {
+                    x = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (k + 0 < k_end) x.x = p[0];
+                    if (k + 1 < k_end) x.y = p[1];
+                    if (k + 2 < k_end) x.z = p[2];
+                    if (k + 3 < k_end) x.w = p[3];
+                }
+            }
+        } else {
+            int kk = f >> 5, rq = (f & 31) * 4;
+            int k = k0 + kk;
+            int64_t row = row0 + rq;
+            if (k < k_end) {
+                const float* p = src + (int64_t)k * ld + row;
+                if (vec_ok && row + 3 < n_rows) {
+                    x = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (row + 0 < n_rows) x.x = p[0];
+                    if (row + 1 < n_rows) x.y = p[1];
+                    if (row + 2 < n_rows) x.z = p[2];
+                    if (row + 3 < n_rows) x.w = p[3];
+                }
+            }
+        }
+        v[u] = x;
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, const float4 (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int f = tid + 256 * u;
+        if (KCONTIG) {
+            int r = f >> 2, kq = (f & 3) * 4;
+            lds[(kq + 0) * LDT + r] = v[u].x;
+            lds[(kq + 1) * LDT + r] = v[u].y;
+            lds[(kq + 2) * LDT + r] = v[u].z;
+            lds[(kq + 3) * LDT + r] = v[u].w;
+        } else {
+            int kk = f >> 5, rq = (f & 31) * 4;
+            *reinterpret_cast<float4*>(&lds[kk * LDT + rq]) = v[u];
+        }
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][BK * LDT];  // [buf][A|B]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each XCD a contiguous run of
+    // tile ids so the n-tiles that share an A row-panel hit the same L2 (bijective remap, guide T1).
+    int64_t bid = blockIdx.x, nb = g.n_tiles;
+    int64_t q = nb / 8, r8 = nb % 8, xcd = bid % 8, idx = bid / 8;
+    int64_t t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    const int64_t tm = t / g.tiles_n;
+    const int tn = (int)(t % g.tiles_n);
+    const int64_t m0 = tm * BM;
+    const int n0 = tn * BN;
+    const int k_begin = blockIdx.z * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2], rb[2];
+    fetch_tile<!TA>(g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid, ra);
+    fetch_tile<TB>(g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid, rb);
+    store_tile<!TA>(lds[0][0], tid, ra);
+    store_tile<TB>(lds[0][1], tid, rb);
+    __syncthreads();
+
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool has_next = k0 + BK < k_end;
+        if (has_next) {
+            fetch_tile<!TA>(g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid, ra);
+            fetch_tile<TB>(g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.b_vec, tid, rb);
+        }
+        const float* As = lds[buf][0];
+        const float* Bs = lds[buf][1];
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 2) {
+            float a0 = As[(ks + lh) * LDT + wr * 64 + li];
+            float a1 = As[(ks + lh) * LDT + wr * 64 + 32 + li];
+            float b0 = Bs[(ks + lh) * LDT + wc * 64 + li];
+            float b1 = Bs[(ks + lh) * LDT + wc * 64 + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (has_next) {
+            store_tile<!TA>(lds[buf ^ 1][0], tid, ra);
+            store_tile<TB>(lds[buf ^ 1][1], tid, rb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: lane (j = li, h = lh) holds C[m0 + wr*64 + i*32 + (r&3) + 8*(r>>2) + 4*h][n0 + wc*64 + jt*32 + j]
+    float* Cbase = g.C + (int64_t)blockIdx.z * g.split_stride;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const int n = n0 + wc * 64 + jt * 32 + li;
+        if (n >= g.N) continue;
+        const float bias = (g.bias != nullptr) ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wr * 64 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= g.M) continue;
+                float v = acc[it][jt][r];
+                float* cp = Cbase + m * g.ldc + n;
+                switch (g.epi) {
+                    case PSN_EPI_NONE: *cp = v; break;
+                    case PSN_EPI_BIAS: *cp = v + bias; break;
+                    case PSN_EPI_BIAS_RELU: *cp = fmaxf(v + bias, 0.0f); break;
+                    case PSN_EPI_BIAS_SOFTPLUS: {
+                        float z = v + bias;
+                        *cp = softplus100(z);
+                        if (g.aux_out != nullptr) g.aux_out[m * g.ld_aux_out + n] = sigmoidf_(100.0f * z);
+                        break;
+                    }
+                    case PSN_EPI_MUL_AUX: *cp = v * g.aux_in[m * g.ld_aux_in + n]; break;
+                    case PSN_EPI_MUL_POS: *cp = g.aux_in[m * g.ld_aux_in + n] > 0.0f ? v : 0.0f; break;
+                    case PSN_EPI_BIAS_SIGMOID: *cp = sigmoidf_(v + bias); break;
+                    case PSN_EPI_ACCUM: *cp += v; break;
+                    default: break;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int64_t MN, int N,
+                                                            int64_t ldc, int splits, int accumulate,
+                                                            float* __restrict__ C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < MN; i += (int64_t)gridDim.x * 256) {
+        float s = 0.0f;
+        for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * MN + i];
+        int64_t m = i / N, n = i % N;
+        float* cp = C + m * ldc + n;
+        *cp = accumulate ? (*cp + s) : s;
+    }
+}
+
+// column sums, two stages: partial[b][n] = sum over a row slab, then out[n] = sum_b partial[b][n]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t M, int N,
+                                                             int64_t ldx, int64_t rows_per_block,
+                                                             float* __restrict__ partial) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float s = 0.0f;
+        for (int64_t m = r0; m < r1; ++m) s += X[m * ldx + n];
+        partial[(int64_t)blockIdx.x * N + n] = s;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int N,
+                                                           int accumulate, float* __restrict__ out) {
+    int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.0f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+}  // namespace psn
+
+extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const float* A, int64_t lda,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
+                        const float* aux_in, int64_t ld_aux_in, float* aux_out, int64_t ld_aux_out, int split_k,
+                        float* workspace, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(A && B && C, "gemm: null operand");
+    PSN_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    PSN_CHECK_ARG(epilogue >= 0 && epilogue <= PSN_EPI_ACCUM, "gemm: unknown epilogue %d", epilogue);
+    if ((epilogue == PSN_EPI_MUL_AUX || epilogue == PSN_EPI_MUL_POS)) PSN_CHECK_ARG(aux_in, "gemm: epilogue needs aux_in");
+    if (epilogue >= PSN_EPI_BIAS && epilogue <= PSN_EPI_BIAS_SOFTPLUS) PSN_CHECK_ARG(bias, "gemm: epilogue needs bias");
+    if (epilogue == PSN_EPI_BIAS_SIGMOID) PSN_CHECK_ARG(bias, "gemm: epilogue needs bias");
+    if (split_k < 1) split_k = 1;
+    if (split_k > 1) {
+        PSN_CHECK_ARG(epilogue == PSN_EPI_NONE || epilogue == PSN_EPI_ACCUM, "gemm: split_k only with NONE/ACCUM epilogue");
+        PSN_CHECK_ARG(workspace, "gemm: split_k needs workspace");
+    }
+    if (M == 0) return PSN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.epi = epilogue; g.aux_in = aux_in; g.ld_aux_in = ld_aux_in; g.aux_out = aux_out;
+    g.ld_aux_out = ld_aux_out;
+    int64_t tiles_m = (M + BM - 1) / BM;
+    g.tiles_n = (N + BN - 1) / BN;
+    g.n_tiles = tiles_m * g.tiles_n;
+    PSN_CHECK_ARG(g.n_tiles < (1ll << 31), "gemm: too many tiles");
+    g.a_vec = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0);
+    g.b_vec = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
+    int kc = (K + split_k - 1) / split_k;
+    kc = ((kc + BK - 1) / BK) * BK;
+    split_k = (K + kc - 1) / kc;
+    g.k_chunk = kc;
+    g.split_stride = 0;
+    if (split_k > 1) {
+        g.C = workspace;
+        g.ldc = N;
+        g.split_stride = M * (int64_t)N;
+        g.epi = PSN_EPI_NONE;
+    }
+    dim3 grid((unsigned)g.n_tiles, 1, (unsigned)split_k), block(256);
+    if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, g);
+    else if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, g);
+    else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, st, g);
+    PSN_CHECK_LAUNCH("gemm");
+    if (split_k > 1) {
+        int64_t MN = M * (int64_t)N;
+        int64_t blocks = (MN + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, workspace, MN, N, ldc,
+                           split_k, epilogue == PSN_EPI_ACCUM ? 1 : 0, C);
+        PSN_CHECK_LAUNCH("gemm split-k reduce");
+    }
+    return PSN_OK;
+}
+
+extern "C" int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int accumulate,
+                          float* workspace, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(X && out && workspace, "colsum: null pointer");
+    PSN_CHECK_ARG(N > 0 && M >= 0, "colsum: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    int nblocks = (int)((M + 255) / 256);
+    if (nblocks > 256) nblocks = 256;
+    if (nblocks < 1) nblocks = 1;
+    int64_t rpb = (M + nblocks - 1) / nblocks;
+    if (rpb < 1) rpb = 1;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, st, X, M, N, ldx, rpb, workspace);
+    PSN_CHECK_LAUNCH("colsum partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, nblocks, N,
+                       accumulate, out);
+    PSN_CHECK_LAUNCH("colsum final");
+    return PSN_OK;
+}

@@ -1,0 +1,77 @@
+// Positional encodings: stage1 PositionalEncoding (stage1/model/network.py:141-150, pi factor 1.0) and
+// stage2 Embedder (stage2/model/embedder.py:6-54, log-sampled 2^k bands).  Both produce
+//   [x(3), sin(2^0 x)(3), cos(2^0 x)(3), sin(2^1 x)(3), ...].
+// 2^k scaling is exact in fp32, so the only rounding is sinf/cosf (full-range ocml versions).
+#include "common.h"
+
+namespace psn {
+
+__global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict__ x, int64_t n, int n_freqs,
+                                                        float scale, float* __restrict__ out, int out_stride) {
+    const int64_t total = n * out_stride;
+    const int width = 3 + 6 * n_freqs;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t row = e / out_stride;
+        int col = (int)(e - row * out_stride);
+        float v = 0.0f;
+        if (col < 3) {
+            v = x[row * 3 + col] * scale;
+        } else if (col < width) {
+            int q = col - 3;
+            int f = q / 6, w = q - 6 * f;
+            int c = w % 3;
+            float arg = ldexpf(x[row * 3 + c] * scale, f);
+            v = (w >= 3) ? cosf(arg) : sinf(arg);
+        }
+        out[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void pe_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ d_out,
+                                                            int64_t n, int n_freqs, float scale, int out_stride,
+                                                            float* __restrict__ d_x) {
+    const int64_t total = n * 3;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t row = e / 3;
+        int c = (int)(e - row * 3);
+        const float* g = d_out + row * out_stride;
+        float xs = x[e] * scale;
+        float acc = g[c];
+        for (int f = 0; f < n_freqs; ++f) {
+            float arg = ldexpf(xs, f);
+            float s, co;
+            sincosf(arg, &s, &co);
+            acc += ldexpf(co * g[3 + 6 * f + c] - s * g[3 + 6 * f + 3 + c], f);
+        }
+        d_x[e] = acc * scale;
+    }
+}
+
+}  // namespace psn
+
+extern "C" int psn_pe_encode(const float* x, int64_t n, int n_freqs, float scale, float* out, int out_stride,
+                             void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(x && out, "pe_encode: null pointer");
+    PSN_CHECK_ARG(n_freqs >= 0 && n_freqs <= 16 && out_stride >= 3 + 6 * n_freqs, "pe_encode: n_freqs=%d out_stride=%d", n_freqs, out_stride);
+    if (n <= 0) return PSN_OK;
+    int64_t total = n * out_stride;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(pe_encode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, n_freqs, scale, out, out_stride);
+    PSN_CHECK_LAUNCH("pe_encode");
+    return PSN_OK;
+}
+
+extern "C" int psn_pe_encode_bwd(const float* x, const float* d_out, int64_t n, int n_freqs, float scale, int out_stride,
+                                 float* d_x, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(x && d_out && d_x, "pe_encode_bwd: null pointer");
+    PSN_CHECK_ARG(n_freqs >= 0 && n_freqs <= 16 && out_stride >= 3 + 6 * n_freqs, "pe_encode_bwd: n_freqs=%d out_stride=%d", n_freqs, out_stride);
+    if (n <= 0) return PSN_OK;
+    int64_t blocks = (n * 3 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(pe_encode_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, d_out, n, n_freqs, scale, out_stride, d_x);
+    PSN_CHECK_LAUNCH("pe_encode_bwd");
+    return PSN_OK;
+}

@@ -1,0 +1,121 @@
+"""Host-side packing for the fused 256-wide MLP inference kernel (csrc/mlp_infer.hip).
+
+A network is a list of layers, each reading up to four 32-float tiles of the
+per-row INPUT FEATURES (positional encodings, kept in registers for the whole
+kernel) and/or the 256 activations of the previous layer.  Dense weights are
+re-ordered once per optimiser step into MFMA fragment order by
+``psn_mlp_pack_layer``; this module only assembles the zero-padded dense
+matrices with torch ops (tiny tensors) and fills the ``PsnMlpDesc``.
+"""
+import math
+
+import torch
+
+from . import hip
+
+
+class PackedMLP(object):
+    def __init__(self, desc, w, b):
+        self.desc, self.w, self.b = desc, w, b
+
+    def __call__(self, tab_a, n_rows, a_div=1, a_mod=None, tab_b=None, b_div=1, b_mod=1, out=None):
+        if a_mod is None:
+            a_mod = tab_a.shape[0]
+        return hip.mlp_infer(self.desc, self.w, self.b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=out)
+
+
+def _pad_cols(w, n):
+    return torch.nn.functional.pad(w, (0, n - w.shape[1])) if w.shape[1] < n else w
+
+
+def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device):
+    """layers: list of dicts {w_in: [o, <=in_kt*32] or None, w_act: [o, <=256] or None, bias: [o], act: ACT_*}.
+    Hidden layers have o <= 256 (zero padded), the final layer o = n_out <= 32."""
+    in_cols = (in_kt_a + in_kt_b) * 32
+    desc = hip.PsnMlpDesc()
+    desc.n_layers = len(layers)
+    desc.n_out, desc.out_act, desc.in_kt_a, desc.in_kt_b = n_out, out_act, in_kt_a, in_kt_b
+    assert len(layers) <= hip.MAX_LAYERS
+    w_sizes, dense, biases = [], [], []
+    for li, L in enumerate(layers):
+        last = li == len(layers) - 1
+        n_mt = 1 if last else 8
+        rows = n_mt * 32
+        parts = []
+        n_kt_in = n_kt_act = 0
+        if L.get('w_in') is not None:
+            parts.append(_pad_cols(L['w_in'], in_cols))
+            n_kt_in = in_kt_a + in_kt_b
+        if L.get('w_act') is not None:
+            parts.append(_pad_cols(L['w_act'], 256))
+            n_kt_act = 8
+        W = torch.cat(parts, dim=1)
+        W = torch.nn.functional.pad(W, (0, 0, 0, rows - W.shape[0])).contiguous().float()
+        b = torch.nn.functional.pad(L['bias'].float(), (0, rows - L['bias'].shape[0]))
+        dense.append((W, n_mt, n_kt_in + n_kt_act))
+        biases.append(b)
+        lay = desc.layers[li]
+        lay.n_kt_in, lay.n_kt_act, lay.n_mt, lay.act = n_kt_in, n_kt_act, n_mt, L['act']
+        w_sizes.append(W.numel())
+    w_buf = torch.empty(sum(w_sizes), device=device, dtype=torch.float32)
+    b_buf = torch.cat(biases).contiguous()
+    off = b_off = 0
+    for li, (W, n_mt, k_tiles) in enumerate(dense):
+        desc.layers[li].w_off = off
+        desc.layers[li].b_off = b_off
+        hip.mlp_pack_layer(W, n_mt, k_tiles, w_buf[off:off + W.numel()])
+        off += W.numel()
+        b_off += n_mt * 32
+    return PackedMLP(desc, w_buf, b_buf)
+
+
+def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE):
+    """stage2 Network / Normal_Network (stage2/model/renderer.py:17-49) of width 256: ReLU stack, the
+    input is concatenated AFTER layer ``skip_at``.  Input row = [table A (din_a real cols, padded to
+    a multiple of 32) | table B (din_b)]."""
+    ka = (din_a + 31) // 32
+    kb = (din_b + 31) // 32 if din_b > 0 else 0
+
+    def split_in(w):  # [o, din_a + din_b] -> padded [o, (ka+kb)*32]
+        wa = _pad_cols(w[:, :din_a], ka * 32)
+        if kb == 0:
+            return wa
+        return torch.cat([wa, _pad_cols(w[:, din_a:din_a + din_b], kb * 32)], dim=1)
+
+    layers = []
+    n = len(weights)
+    for li in range(n):
+        W, b = weights[li].detach(), biases[li].detach()
+        act = hip.ACT_RELU if li < n - 1 else hip.ACT_NONE
+        if li == 0:
+            layers.append(dict(w_in=split_in(W), w_act=None, bias=b, act=act))
+        elif li - 1 == skip_at:  # input of this layer is cat[y(256), x]
+            layers.append(dict(w_in=split_in(W[:, 256:]), w_act=W[:, :256], bias=b, act=act))
+        else:
+            layers.append(dict(w_in=None, w_act=W, bias=b, act=act))
+    assert all(L['bias'].shape[0] == 256 for L in layers[:-1]), 'fused path needs 256-wide hidden layers'
+    return pack_layers(layers, ka, kb, weights[-1].shape[0], out_act, weights[0].device)
+
+
+def pack_geo_occupancy(weights, biases, skips, d_pe):
+    """stage1 occupancy-only network (stage1/model/network.py:85-95,124-125): softplus(beta=100)
+    stack, before layer l in ``skips`` the input becomes cat[x, pe]/sqrt(2); only output row 0 of the
+    last layer is evaluated, followed by sigmoid(-10 x)."""
+    ka = (d_pe + 31) // 32
+    layers = []
+    n = len(weights)
+    inv = 1.0 / math.sqrt(2.0)
+    for li in range(n):
+        W, b = weights[li].detach(), biases[li].detach()
+        last = li == n - 1
+        act = hip.ACT_NONE if last else hip.ACT_SOFTPLUS100
+        if last:
+            W, b = W[:1], b[:1]
+        if li == 0:
+            layers.append(dict(w_in=W, w_act=None, bias=b, act=act))
+        elif li in skips:
+            d_x = W.shape[1] - d_pe
+            layers.append(dict(w_in=W[:, d_x:] * inv, w_act=W[:, :d_x] * inv, bias=b, act=act))
+        else:
+            layers.append(dict(w_in=None, w_act=W, bias=b, act=act))
+    return pack_layers(layers, ka, 0, 1, hip.OUT_OCC, weights[0].device)

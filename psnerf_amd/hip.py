@@ -1,0 +1,209 @@
+"""ctypes binding of libpsnerf_hip.so (C ABI in include/psnerf_hip.h).
+
+Importing this module loads the shared library and FAILS LOUDLY if it is
+missing -- there is no CPU or PyTorch fallback on the product path.  Wrappers
+take torch tensors only as carriers of device pointers: they validate
+device / dtype / contiguity, pass ``data_ptr()`` and the current HIP stream,
+and raise RuntimeError with ``psn_last_error()`` on failure.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpsnerf_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'psnerf_amd: %s is missing. Build it with `python -m psnerf_amd.build` (hipcc, gfx950). '
+        'There is no fallback path.' % LIB_PATH)
+_lib = ctypes.CDLL(LIB_PATH)
+
+c_f = ctypes.c_void_p  # device pointers travel as void*
+i64, i32, f32 = ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+MAX_LAYERS = 12
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_SOFTPLUS, EPI_MUL_AUX, EPI_MUL_POS, EPI_BIAS_SIGMOID, EPI_ACCUM = range(8)
+ACT_NONE, ACT_RELU, ACT_SOFTPLUS100 = range(3)
+OUT_NONE, OUT_SIGMOID, OUT_OCC = range(3)
+
+
+class PsnMlpLayer(ctypes.Structure):
+    _fields_ = [('n_kt_in', i32), ('n_kt_act', i32), ('n_mt', i32), ('act', i32), ('w_off', i64), ('b_off', i64)]
+
+
+class PsnMlpDesc(ctypes.Structure):
+    _fields_ = [('n_layers', i32), ('n_out', i32), ('out_act', i32), ('in_kt_a', i32), ('in_kt_b', i32),
+                ('layers', PsnMlpLayer * MAX_LAYERS)]
+
+
+# every exported symbol of include/psnerf_hip.h with its signature
+SIGNATURES = {
+    'psn_last_error': (ctypes.c_char_p, []),
+    'psn_version': (i32, []),
+    'psn_composite_fwd': (i32, [c_f, c_f, i64, i32, i32, c_f, c_f, c_f, c_f]),
+    'psn_composite_bwd': (i32, [c_f, c_f, c_f, c_f, i64, i32, i32, c_f, c_f, c_f]),
+    'psn_pe_encode': (i32, [c_f, i64, i32, f32, c_f, i32, c_f]),
+    'psn_pe_encode_bwd': (i32, [c_f, c_f, i64, i32, f32, i32, c_f, c_f]),
+    'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, i32,
+                       c_f, c_f]),
+    'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
+    'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, c_f, c_f]),
+    'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, i64, c_f, c_f]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(_lib, _name)  # AttributeError here = library out of date: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, _lib.psn_last_error().decode()))
+
+
+def _ptr(t, name, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise RuntimeError('%s: tensor required' % name)
+    if not t.is_cuda:
+        raise RuntimeError('%s: must be a HIP device tensor (the product path has no CPU fallback)' % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError('%s: must be float32, got %s' % (name, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError('%s: must be contiguous' % name)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def version():
+    return _lib.psn_version()
+
+
+# --------------------------------------------------------------------------- composite
+def composite_fwd(alpha, rgb, white_bg, need_weights=True):
+    """alpha [N,S], rgb [N,S,3] or None -> (weights [N,S] or None, rgb_out [N,3] or None, acc [N])."""
+    N, S = alpha.shape
+    weights = torch.empty_like(alpha) if need_weights else None
+    rgb_out = torch.empty(N, 3, device=alpha.device, dtype=torch.float32) if rgb is not None else None
+    acc = torch.empty(N, device=alpha.device, dtype=torch.float32)
+    _check(_lib.psn_composite_fwd(_ptr(alpha, 'alpha'), _ptr(rgb, 'rgb', True), N, S, int(bool(white_bg)),
+                                  _ptr(weights, 'weights', True), _ptr(rgb_out, 'rgb_out', True), _ptr(acc, 'acc'),
+                                  _stream()), 'composite_fwd')
+    return weights, rgb_out, acc
+
+
+def composite_bwd(alpha, rgb, d_rgb_out, d_acc, white_bg):
+    N, S = alpha.shape
+    d_alpha = torch.empty_like(alpha)
+    d_rgb = torch.empty_like(rgb) if rgb is not None else None
+    _check(_lib.psn_composite_bwd(_ptr(alpha, 'alpha'), _ptr(rgb, 'rgb', True), _ptr(d_rgb_out, 'd_rgb_out', True),
+                                  _ptr(d_acc, 'd_acc', True), N, S, int(bool(white_bg)), _ptr(d_alpha, 'd_alpha'),
+                                  _ptr(d_rgb, 'd_rgb', True), _stream()), 'composite_bwd')
+    return d_alpha, d_rgb
+
+
+# --------------------------------------------------------------------------- positional encoding
+def pe_encode(x, n_freqs, out_stride=None, scale=1.0):
+    """x [n,3] -> [n, out_stride] = [x, sin(2^k x), cos(2^k x)]_k, zero padded to out_stride."""
+    n = x.shape[0]
+    width = 3 + 6 * n_freqs
+    out_stride = width if out_stride is None else out_stride
+    out = torch.empty(n, out_stride, device=x.device, dtype=torch.float32)
+    _check(_lib.psn_pe_encode(_ptr(x, 'x'), n, n_freqs, float(scale), _ptr(out, 'out'), out_stride, _stream()),
+           'pe_encode')
+    return out
+
+
+def pe_encode_bwd(x, d_out, n_freqs, scale=1.0):
+    n = x.shape[0]
+    d_x = torch.empty_like(x)
+    _check(_lib.psn_pe_encode_bwd(_ptr(x, 'x'), _ptr(d_out, 'd_out'), n, n_freqs, float(scale), d_out.shape[1],
+                                  _ptr(d_x, 'd_x'), _stream()), 'pe_encode_bwd')
+    return d_x
+
+
+# --------------------------------------------------------------------------- GEMM
+_ws_cache = {}
+
+
+def workspace(n_floats, device):
+    """Per-device scratch buffer (grown on demand, reused across calls on the same stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, 'matrix operand must be row-major with unit column stride'
+    return t.stride(0)
+
+
+def _mat_ptr(t, name):
+    """2-D row-major view (may be a column slice of a wider buffer: ld = stride(0))."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError('%s: must be a float32 HIP tensor' % name)
+    return t.data_ptr()
+
+
+def gemm(A, B, trans_a=False, trans_b=False, bias=None, epi=EPI_NONE, aux_in=None, out=None, aux_out=None,
+         split_k=1):
+    """out[M,N] = epi(op(A) @ op(B)).  A/B/out/aux may be row-major views with a row stride."""
+    if trans_a:
+        K, M = A.shape
+    else:
+        M, K = A.shape
+    if trans_b:
+        N, Kb = B.shape
+    else:
+        Kb, N = B.shape
+    assert K == Kb, 'gemm: inner dimensions differ (%d vs %d)' % (K, Kb)
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    assert out.shape == (M, N)
+    ws = None
+    if split_k > 1:
+        ws = workspace(split_k * M * N, A.device)
+    _check(_lib.psn_gemm(int(trans_a), int(trans_b), M, N, K, _mat_ptr(A, 'A'), _ld(A), _mat_ptr(B, 'B'), _ld(B),
+                         _mat_ptr(out, 'out'), _ld(out), _ptr(bias, 'bias', True), epi,
+                         None if aux_in is None else _mat_ptr(aux_in, 'aux_in'), 0 if aux_in is None else _ld(aux_in),
+                         None if aux_out is None else _mat_ptr(aux_out, 'aux_out'),
+                         0 if aux_out is None else _ld(aux_out), split_k,
+                         None if ws is None else ws.data_ptr(), _stream()), 'gemm')
+    return out
+
+
+def colsum(X, out=None, accumulate=False):
+    M, N = X.shape
+    if out is None:
+        out = torch.empty(N, device=X.device, dtype=torch.float32)
+    ws = workspace(256 * N, X.device)
+    _check(_lib.psn_colsum(_mat_ptr(X, 'X'), M, N, _ld(X), _ptr(out, 'out'), int(accumulate), ws.data_ptr(),
+                           _stream()), 'colsum')
+    return out
+
+
+# --------------------------------------------------------------------------- fused MLP inference
+def mlp_pack_layer(W_dense, n_mt, k_tiles, dst):
+    """W_dense [n_mt*32, k_tiles*32] zero padded, row-major -> dst (flat float view) in stage order."""
+    assert W_dense.shape == (n_mt * 32, k_tiles * 32) and W_dense.is_contiguous()
+    assert dst.numel() == n_mt * k_tiles * 1024
+    _check(_lib.psn_mlp_pack_layer(_ptr(W_dense, 'W'), W_dense.stride(0), n_mt, k_tiles, dst.data_ptr(), _stream()),
+           'mlp_pack_layer')
+
+
+def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None):
+    if out is None:
+        out = torch.empty(n_rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
+    _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
+                              _ptr(tab_a, 'tab_a'), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod, n_rows,
+                              _ptr(out, 'out'), _stream()), 'mlp_infer')
+    return out

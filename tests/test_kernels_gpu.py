@@ -1,0 +1,190 @@
+"""HIP kernels (through the C ABI) against the CPU oracle / golden vectors.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, assert_close, stage1_state_dict, stage2_state_dict, stage1_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize('S', [64, 96, 128])
+def test_composite_golden(cuda, S):
+    from psnerf_amd import hip
+    g = np.load(os.path.join(GOLDEN, 'stage1_composite.npz'))
+    alpha, rgb = T(g['alpha%d' % S], cuda), T(g['rgb%d' % S], cuda)
+    w, out, acc = hip.composite_fwd(alpha, rgb, True)
+    assert_close(w.cpu(), g['w%d' % S], 2e-6, 'w')
+    assert_close(out.cpu(), g['out%d' % S], 2e-6, 'rgb')
+    assert_close(acc.cpu(), g['acc%d' % S], 2e-6, 'acc')
+    da, dc = hip.composite_bwd(alpha, rgb, T(g['c1_%d' % S], cuda), T(g['c2_%d' % S], cuda), True)
+    assert_close(dc.cpu(), g['drgb%d' % S], 2e-6, 'd_rgb')
+    assert_close(da.cpu(), g['dalpha%d' % S], 1e-4, 'd_alpha')  # /t with t ~ 1e-6 on the alpha==1 rows
+
+
+@pytest.mark.parametrize('N,S', [(1, 1), (5, 7), (1000, 63), (333, 65), (4096, 128), (17, 300), (3, 1024)])
+def test_composite_shapes(cuda, N, S):
+    from psnerf_amd import hip
+    from oracle import stage1 as o1
+    g = torch.Generator().manual_seed(N * 1000 + S)
+    alpha = torch.rand(N, S, generator=g, dtype=torch.float64) * 0.3
+    rgb = torch.rand(N, S, 3, generator=g, dtype=torch.float64)
+    a64, c64 = alpha.clone().requires_grad_(True), rgb.clone().requires_grad_(True)
+    w_ref, rgb_ref = o1.alpha_composite(a64, c64)
+    acc_ref = w_ref.sum(-1)
+    c1, c2 = torch.randn(N, 3, generator=g, dtype=torch.float64), torch.randn(N, generator=g, dtype=torch.float64)
+    ((rgb_ref * c1).sum() + (acc_ref * c2).sum()).backward()
+    a32, c32 = alpha.float().to(cuda), rgb.float().to(cuda)
+    w, out, acc = hip.composite_fwd(a32, c32, False)
+    assert_close(w.cpu(), w_ref.detach(), 5e-6, 'w')
+    assert_close(out.cpu(), rgb_ref.detach(), 5e-6, 'rgb')
+    da, dc = hip.composite_bwd(a32, c32, c1.float().to(cuda), c2.float().to(cuda), False)
+    assert_close(dc.cpu(), c64.grad, 5e-6, 'd_rgb')
+    assert_close(da.cpu(), a64.grad, 2e-5, 'd_alpha')
+    # acc-only form (light visibility)
+    w2, none_, acc2 = hip.composite_fwd(a32, None, False, need_weights=False)
+    assert w2 is None and none_ is None
+    assert_close(acc2.cpu(), acc_ref.detach(), 5e-6, 'acc only')
+
+
+def test_composite_known_answers(cuda):
+    from psnerf_amd import hip
+    z = torch.zeros(9, 80, device=cuda)
+    w, rgb, acc = hip.composite_fwd(z, torch.rand(9, 80, 3, device=cuda), True)
+    assert float(acc.abs().max()) == 0 and float((rgb - 1).abs().max()) == 0  # white background
+    o = torch.ones(9, 80, device=cuda)
+    w, rgb, acc = hip.composite_fwd(o, torch.rand(9, 80, 3, device=cuda), False)
+    assert float((w[:, 0] - 1).abs().max()) == 0 and float(w[:, 1:].abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize('n_freqs,stride', [(6, 39), (6, 64), (10, 64), (4, 27), (0, 3)])
+def test_pe(cuda, n_freqs, stride):
+    from psnerf_amd import hip
+    from oracle import stage1 as o1
+    from oracle import stage2 as o2
+    g = torch.Generator().manual_seed(n_freqs)
+    x = (torch.rand(1001, 3, generator=g) * 2 - 1)
+    ref = o1.positional_encoding(x, n_freqs)
+    if n_freqs > 0:
+        assert torch.equal(ref, o2.embed(x, n_freqs))  # both reference encodings coincide
+    out = hip.pe_encode(x.to(cuda), n_freqs, stride).cpu()
+    assert_close(out[:, :ref.shape[1]], ref, 1e-6, 'pe')
+    assert float(out[:, ref.shape[1]:].abs().max() if stride > ref.shape[1] else 0.0) == 0
+    xg = x.double().requires_grad_(True)
+    d_out = torch.randn(1001, stride, generator=g)
+    (o1.positional_encoding(xg, n_freqs) * d_out[:, :ref.shape[1]].double()).sum().backward()
+    dx = hip.pe_encode_bwd(x.to(cuda), d_out.to(cuda), n_freqs).cpu()
+    assert_close(dx, xg.grad, 1e-5, 'pe bwd')
+
+
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 16), (1, 1, 1), (257, 129, 33), (1000, 256, 126), (300, 217, 256),
+                                   (513, 3, 128), (64, 289, 300)])
+def test_gemm_layouts(cuda, ta, tb, M, N, K):
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    ref = (A.double() @ B.double())
+    # asymmetric operands by construction (random) -> catches transposed C writes
+    Ad = (A.t().contiguous() if ta else A).to(cuda)
+    Bd = (B.t().contiguous() if tb else B).to(cuda)
+    out = hip.gemm(Ad, Bd, trans_a=ta, trans_b=tb).cpu()
+    assert_close(out, ref, 2e-6 * max(1, K ** 0.5), 'gemm')
+
+
+def test_gemm_epilogues_and_strides(cuda):
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 700, 256, 126
+    buf = torch.randn(M, 384, generator=g).to(cuda)        # A is a column slice of a wider buffer
+    A = buf[:, 256:256 + K]
+    W = torch.randn(N, K, generator=g).to(cuda)
+    b = torch.randn(N, generator=g).to(cuda)
+    z = (A.double().cpu() @ W.double().cpu().t()) + b.double().cpu()
+    assert_close(hip.gemm(A, W, trans_b=True, bias=b, epi=hip.EPI_BIAS).cpu(), z, 5e-6, 'bias')
+    assert_close(hip.gemm(A, W, trans_b=True, bias=b, epi=hip.EPI_BIAS_RELU).cpu(), z.clamp(min=0), 5e-6, 'relu')
+    assert_close(hip.gemm(A, W, trans_b=True, bias=b, epi=hip.EPI_BIAS_SIGMOID).cpu(), torch.sigmoid(z), 5e-6, 'sigmoid')
+    zs = z * 0.02
+    s_out = torch.empty(M, N, device=cuda)
+    sp = hip.gemm(A, W * 0.02, trans_b=True, bias=b * 0.02, epi=hip.EPI_BIAS_SOFTPLUS, aux_out=s_out).cpu()
+    assert_close(sp, torch.nn.functional.softplus(zs, beta=100, threshold=20), 1e-5, 'softplus')
+    assert_close(s_out.cpu(), torch.sigmoid(100 * zs), 2e-4, 'softplus aux (sigmoid amplifies 100x)')
+    aux = torch.randn(M, N, generator=g).to(cuda)
+    raw = A.double().cpu() @ W.double().cpu().t()
+    assert_close(hip.gemm(A, W, trans_b=True, epi=hip.EPI_MUL_AUX, aux_in=aux).cpu(), raw * aux.double().cpu(), 5e-6, 'mul')
+    assert_close(hip.gemm(A, W, trans_b=True, epi=hip.EPI_MUL_POS, aux_in=aux).cpu(), raw * (aux.cpu() > 0), 5e-6, 'pos')
+    # output into a column slice, accumulate
+    wide = torch.zeros(M, 512, device=cuda)
+    hip.gemm(A, W, trans_b=True, out=wide[:, 100:100 + N])
+    hip.gemm(A, W, trans_b=True, out=wide[:, 100:100 + N], epi=hip.EPI_ACCUM)
+    assert_close(wide[:, 100:100 + N].cpu(), 2 * raw, 5e-6, 'accum')
+    assert float(wide[:, :100].abs().max()) == 0 and float(wide[:, 100 + N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize('split', [1, 3, 16, 64])
+def test_gemm_splitk_weight_grad(cuda, split):
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(split)
+    Q, O, I = 5000, 256, 382
+    dZ = torch.randn(Q, O, generator=g)
+    X = torch.randn(Q, I, generator=g)
+    ref = dZ.double().t() @ X.double()
+    out = hip.gemm(dZ.to(cuda), X.to(cuda), trans_a=True, trans_b=False, split_k=split).cpu()
+    assert_close(out, ref, 1e-5, 'dW')
+    cs = hip.colsum(dZ.to(cuda)).cpu()
+    assert_close(cs, dZ.double().sum(0), 1e-5, 'colsum')
+
+
+def test_fused_visibility_mlp(cuda):
+    """mlp_infer on the stage2 visibility net == oracle MLP (stage2/model/renderer.py:191-200)."""
+    from psnerf_amd import hip, fused
+    from oracle import stage2 as o2
+    conf = o2.bear_conf()
+    net = o2.PSNetwork(conf)
+    net.load_state_dict(stage2_state_dict(conf, seed=31))
+    vn = net.visibility_net
+    g = torch.Generator().manual_seed(8)
+    Ns, L = 333, 7
+    x = torch.rand(Ns, 3, generator=g) * 1.2 - 0.6
+    l = torch.nn.functional.normalize(torch.randn(L, 3, generator=g), dim=-1)
+    with torch.no_grad():
+        inp = torch.cat([o2.embed(x, 10).tile(L, 1), o2.embed(l, 10).repeat_interleave(Ns, dim=0)], -1)
+        ref = vn(inp)
+    packed = fused.pack_relu_mlp([m.weight.to(cuda) for m in vn.linears], [m.bias.to(cuda) for m in vn.linears],
+                                 63, 63, skip_at=4)
+    ta = hip.pe_encode(x.to(cuda), 10, 64)
+    tb = hip.pe_encode(l.to(cuda), 10, 64)
+    out = packed(ta, L * Ns, a_div=1, a_mod=Ns, tab_b=tb, b_div=Ns, b_mod=L)
+    assert out.shape == (L * Ns, 1)
+    assert_close(out.cpu(), ref, 1e-4, 'visibility net')
+
+
+def test_fused_geo_occupancy(cuda):
+    """mlp_infer on the stage1 occupancy net == oracle forward(only_occupancy=True) (network.py:124-125)."""
+    from psnerf_amd import hip, fused
+    from oracle import stage1 as o1
+    cfg = stage1_cfg('bunny')
+    net = o1.NeuralNetwork(cfg)
+    net.load_state_dict(stage1_state_dict(cfg, seed=11))
+    g = torch.Generator().manual_seed(2)
+    p = torch.rand(1000, 3, generator=g) * 2 - 1
+    with torch.no_grad():
+        ref = net(p, only_occupancy=True)
+        logit_ref = net.infer_occ(p)[:, :1]
+    ws = [getattr(net, 'lin%d' % l).weight().detach().to(cuda) for l in range(net.n_geo)]
+    bs = [getattr(net, 'lin%d' % l).bias.detach().to(cuda) for l in range(net.n_geo)]
+    packed = fused.pack_geo_occupancy(ws, bs, net.skips, 39)
+    tab = hip.pe_encode(p.to(cuda), 6, 64)
+    out = packed(tab, 1000)
+    # sigmoid(-10 x) amplifies logit error 2.5x at most; compare on both scales
+    assert_close(out.cpu(), ref, 1e-4, 'occupancy')
+    packed.desc.out_act = hip.OUT_NONE
+    logit = packed(tab, 1000)
+    assert_close(logit.cpu(), logit_ref, 1e-4, 'occupancy logit')
