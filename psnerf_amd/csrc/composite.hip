@@ -168,9 +168,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
             float G = gacc;
             if (rgb != nullptr && s < S) G += gl[3 * s] + gl[3 * s + 1] + gl[3 * s + 2];
             float gw = s < S ? G * w[e] : 0.0f;
-            float incl = wave_incl_sum_rev(gw, lane);
-            float R = incl - gw + tail;
-            tail += __shfl(incl, 0, 64);
+            // exclusive suffix sum computed directly (incl - self would cancel catastrophically when the
+            // own term dominates, e.g. alpha == 1 rows where the result is then divided by t ~ 1e-6)
+            float nxt = __shfl_down(gw, 1, 64);
+            if (lane == 63) nxt = 0.0f;
+            float ex = wave_incl_sum_rev(nxt, lane);
+            float R = ex + tail;
+            tail += __shfl(ex, 0, 64) + __shfl(gw, 0, 64);
             if (s < S) {
                 float t = 1.0f - a[e] + kEps;
                 d_alpha[ray * S + s] = G * T[e] - R / t;
