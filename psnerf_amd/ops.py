@@ -1,0 +1,243 @@
+"""torch.autograd.Function wrappers over the C ABI (psnerf_amd.hip).
+
+PyTorch is used here only as the owner of device memory and the autograd tape;
+every FLOP on the hot path runs in libpsnerf_hip.so.  Each Function implements
+its own backward with the same kernels (no autograd-of-autograd).
+"""
+import torch
+
+from . import fused, hip
+
+
+def _split_k_for(rows):
+    # enough k-slices to fill 256 CUs when the output is a single 256x256 (4-tile) weight gradient
+    return int(max(1, min(256, rows // 1024)))
+
+
+# --------------------------------------------------------------------------- positional encoding
+class PositionalEncoding(torch.autograd.Function):
+    """[x, sin(2^k x), cos(2^k x)]_k zero-padded to ``out_stride`` columns.
+    stage1/model/network.py:141-150 and stage2/model/embedder.py:6-54."""
+
+    @staticmethod
+    def forward(ctx, x, n_freqs, out_stride, scale=1.0):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.n_freqs, ctx.scale = n_freqs, scale
+        return hip.pe_encode(x, n_freqs, out_stride, scale)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x,) = ctx.saved_tensors
+        return hip.pe_encode_bwd(x, d_out.contiguous(), ctx.n_freqs, ctx.scale), None, None, None
+
+
+def positional_encoding(x, n_freqs, out_stride=None, scale=1.0):
+    width = 3 + 6 * n_freqs
+    return PositionalEncoding.apply(x, n_freqs, width if out_stride is None else out_stride, scale)
+
+
+# --------------------------------------------------------------------------- alpha composite
+class AlphaComposite(torch.autograd.Function):
+    """stage1/model/rendering.py:196-197,214-216: returns (rgb [N,3] incl. white background, acc [N], weights)."""
+
+    @staticmethod
+    def forward(ctx, alpha, rgb, white_bg):
+        alpha, rgb = alpha.contiguous(), rgb.contiguous()
+        w, out, acc = hip.composite_fwd(alpha, rgb, white_bg)
+        ctx.save_for_backward(alpha, rgb)
+        ctx.white_bg = white_bg
+        ctx.mark_non_differentiable(w)
+        return out, acc, w
+
+    @staticmethod
+    def backward(ctx, d_out, d_acc, _dw):
+        alpha, rgb = ctx.saved_tensors
+        d_out = torch.zeros(alpha.shape[0], 3, device=alpha.device) if d_out is None else d_out.contiguous()
+        d_acc = None if d_acc is None else d_acc.contiguous()
+        da, dc = hip.composite_bwd(alpha, rgb, d_out, d_acc, ctx.white_bg)
+        return da, dc, None
+
+
+def alpha_composite(alpha, rgb, white_bg):
+    return AlphaComposite.apply(alpha, rgb, white_bg)
+
+
+# --------------------------------------------------------------------------- ReLU MLP (stage2 nets)
+def _padded_weight(W, cols, kp):
+    """Scatter the columns of W [o, k] to positions ``cols`` of a zero [o, kp] matrix."""
+    if cols is None:
+        return W.contiguous()
+    Wp = torch.zeros(W.shape[0], kp, device=W.device, dtype=W.dtype)
+    Wp[:, cols] = W
+    return Wp
+
+
+class ReluMLP(torch.autograd.Function):
+    """stage2 Network / Normal_Network (stage2/model/renderer.py:17-49) for training: Linear+ReLU stack,
+    the input is concatenated after layer ``skip_at``; final layer linear or sigmoid.
+
+    x: [Q, kp] padded input features; ``in_cols`` maps the din real input columns into the kp padded
+    ones (PE tables are padded to multiples of 32/4 floats so every operand is 16-byte aligned).
+    params: W0, b0, W1, b1, ...  (torch Linear layout [out, in])."""
+
+    @staticmethod
+    def forward(ctx, x, in_cols, skip_at, final_sigmoid, *params):
+        n = len(params) // 2
+        Ws, bs = params[0::2], params[1::2]
+        Q, kp = x.shape
+        width = Ws[0].shape[0]
+        need_grad = any(ctx.needs_input_grad)
+        saved_in = []
+        Wps = []
+        h = x
+        for li in range(n):
+            last = li == n - 1
+            if li == 0:
+                Wp = _padded_weight(Ws[0], in_cols, kp)
+            elif li - 1 == skip_at:
+                cols = torch.cat([torch.arange(width, device=x.device), width + in_cols])
+                Wp = _padded_weight(Ws[li], cols, width + kp)
+            else:
+                Wp = Ws[li].contiguous()
+            Wps.append(Wp)
+            saved_in.append(h)
+            if last:
+                out = hip.gemm(h, Wp, trans_b=True, bias=bs[li].contiguous(),
+                               epi=hip.EPI_BIAS_SIGMOID if final_sigmoid else hip.EPI_BIAS)
+            elif li == skip_at:
+                buf = torch.empty(Q, width + kp, device=x.device, dtype=torch.float32)
+                hip.gemm(h, Wp, trans_b=True, bias=bs[li].contiguous(), epi=hip.EPI_BIAS_RELU, out=buf[:, :width])
+                buf[:, width:] = x
+                h = buf
+            else:
+                h = hip.gemm(h, Wp, trans_b=True, bias=bs[li].contiguous(), epi=hip.EPI_BIAS_RELU)
+        if need_grad:
+            ctx.save_for_backward(out, in_cols, *saved_in, *Wps)
+            ctx.n, ctx.skip_at, ctx.final_sigmoid, ctx.width, ctx.kp = n, skip_at, final_sigmoid, width, kp
+            ctx.x_needs = ctx.needs_input_grad[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        n, width, kp = ctx.n, ctx.width, ctx.kp
+        saved = ctx.saved_tensors
+        out, in_cols = saved[0], saved[1]
+        ins, Wps = saved[2:2 + n], saved[2 + n:2 + 2 * n]
+        g = d_out.contiguous()
+        if ctx.final_sigmoid:
+            g = g * out * (1.0 - out)
+        Q = g.shape[0]
+        sk = _split_k_for(Q)
+        grads = [None] * (2 * n)
+        dx = torch.zeros(Q, kp, device=g.device) if ctx.x_needs else None
+        needs = ctx.needs_input_grad[4:]
+        for li in range(n - 1, -1, -1):
+            inp, Wp = ins[li], Wps[li]
+            if needs[2 * li]:
+                dWp = hip.gemm(g, inp, trans_a=True, trans_b=False, split_k=sk)
+                if li == 0:
+                    grads[0] = dWp[:, in_cols] if in_cols is not None else dWp
+                elif li - 1 == ctx.skip_at:
+                    grads[2 * li] = torch.cat([dWp[:, :width], dWp[:, width + in_cols]], dim=1)
+                else:
+                    grads[2 * li] = dWp
+            if needs[2 * li + 1]:
+                grads[2 * li + 1] = hip.colsum(g)
+            if li > 0:
+                if ctx.x_needs and li - 1 == ctx.skip_at:
+                    dx += hip.gemm(g, Wp[:, width:], trans_a=False, trans_b=False)
+                # d(prev hidden) = (g @ W[:, :width]) * relu'(prev)
+                g = hip.gemm(g, Wp[:, :width], trans_a=False, trans_b=False, epi=hip.EPI_MUL_POS,
+                             aux_in=inp[:, :width])
+            elif ctx.x_needs:
+                dx += hip.gemm(g, Wp, trans_a=False, trans_b=False)
+        return (dx, None, None, None) + tuple(grads)
+
+
+def relu_mlp(x, in_cols, skip_at, final_sigmoid, weights, biases):
+    params = []
+    for W, b in zip(weights, biases):
+        params += [W, b]
+    return ReluMLP.apply(x, in_cols, skip_at, final_sigmoid, *params)
+
+
+class FusedPairMLP(torch.autograd.Function):
+    """256-wide ReLU MLP evaluated on the virtual rows [A[q % nA] | B[q // nA]] (light-major flattening of
+    stage2/model/renderer.py:163,193) with the fully fused inference kernel.  Used for the L-light
+    visibility branch, which the reference evaluates with gradients enabled but whose result only
+    enters the loss detached (renderer.py:197, loss.py:82-83).  If a caller does backpropagate into it,
+    backward re-evaluates the rows on the training path."""
+
+    @staticmethod
+    def forward(ctx, tab_a, tab_b, in_cols, skip_at, *params):
+        Ws, bs = params[0::2], params[1::2]
+        nA, nB = tab_a.shape[0], tab_b.shape[0]
+        din_half = in_cols.numel() // 2
+        packed = fused.pack_relu_mlp(list(Ws), list(bs), din_half, din_half, skip_at)
+        out = packed(tab_a, nA * nB, a_div=1, a_mod=nA, tab_b=tab_b, b_div=nA, b_mod=nB)
+        ctx.save_for_backward(tab_a, tab_b, in_cols, *params)
+        ctx.skip_at = skip_at
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        tab_a, tab_b, in_cols = ctx.saved_tensors[:3]
+        params = [p.detach().requires_grad_(True) for p in ctx.saved_tensors[3:]]
+        nA, nB = tab_a.shape[0], tab_b.shape[0]
+        ta = tab_a.detach().requires_grad_(ctx.needs_input_grad[0])
+        tb = tab_b.detach().requires_grad_(ctx.needs_input_grad[1])
+        with torch.enable_grad():
+            x = torch.cat([ta.tile(nB, 1), tb.repeat_interleave(nA, dim=0)], dim=1)
+            out = ReluMLP.apply(x, in_cols, ctx.skip_at, False, *params)
+            wanted = [t for t in [ta, tb] + params if t.requires_grad]
+            got = torch.autograd.grad(out, wanted, d_out, allow_unused=True)
+        it = iter(got)
+        res = []
+        for t in [ta, tb]:
+            res.append(next(it) if t.requires_grad else None)
+        pg = [next(it) for _ in params]
+        return (res[0], res[1], None, None) + tuple(pg)
+
+
+# --------------------------------------------------------------------------- SG shading
+def sg_shade(light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb):
+    """Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n.
+
+    stage2/model/sgbasis.py:16-32 + stage2/model/renderer.py:174-204:
+        h = normalize(l + v);  D_k = exp(lambda_k (h.n - 1));  spec_c = max(sum_k w_{c,k} D_k, 0)
+        rgb = clamp((albedo + spec) * I_l * (l.n) * clamp(vis, 0, 1), 0, 1)      (cos is NOT clamped)
+    light_dir [L,3], view/normal/albedo [Ns,3], weights [Ns,nbasis], light_int [L,1] tensor or float,
+    vis [L*Ns,1] or None.  Returns rgb [L*Ns,3], spec [L*Ns,3 or 1]."""
+    return SGShade.apply(light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb) \
+        if hip_has_sg_shade() else _sg_shade_eager(light_dir, view, normal, albedo, weights, lobe, light_int, vis,
+                                                   specular_rgb)
+
+
+def hip_has_sg_shade():
+    return hasattr(hip, 'sg_shade_fwd')
+
+
+def _sg_shade_eager(light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb):
+    """Broadcast (no tile) restatement with torch device ops -- bring-up path only, replaced by the
+    fused kernel (SGShade) once libpsnerf_hip exports psn_sg_shade_*."""
+    L, Ns = light_dir.shape[0], view.shape[0]
+    nb = lobe.shape[0]
+    l = light_dir[:, None, :]
+    h = torch.nn.functional.normalize(l + view[None], dim=-1)
+    hn = (h * normal[None]).sum(-1, keepdim=True)
+    D = torch.exp(lobe.clamp(min=0) * (hn - 1))
+    if specular_rgb:
+        spec = (weights.view(1, Ns, 3, nb) * D[:, :, None]).sum(-1).clamp(min=0.0)
+    else:
+        spec = (weights[None] * D).sum(-1, keepdim=True).clamp(min=0.0)
+    brdf = albedo[None] + spec
+    cos = (l * normal[None]).sum(-1, keepdim=True)
+    if torch.is_tensor(light_int) and light_int.shape[0] > 1:
+        li = light_int.view(L, 1, 1)
+    else:
+        li = light_int
+    rgb = brdf * li * cos
+    if vis is not None:
+        rgb = rgb * vis.view(L, Ns, 1).clamp(0, 1)
+    return rgb.clamp(0, 1).reshape(L * Ns, 3), spec.reshape(L * Ns, -1)

@@ -1,0 +1,249 @@
+"""Stage-2 model: SVBRDF / normal / visibility MLPs + multi-light shading, with the reference's
+``PSNetwork`` interface (stage2/model/renderer.py:52-266) on top of the HIP kernels.
+
+Drop-in contract: same constructor (a conf tree with get_string/get_int/get_float/
+get_bool), same ``forward(input, albedo_new=None, basis_new=None)`` input/output dictionaries, same
+state_dict keys ({albedo,rough,normal,visibility}_net.linears.{i}.{weight,bias}, sgbasis.lobe).
+
+MI355X mapping:
+  * positional encodings -> psn_pe_encode tables (one row per surface point / per light), padded to 64
+    floats so every row is one aligned MFMA k-tile pair;
+  * albedo / rough / normal nets and the V supervision-light visibility rows -> ops.ReluMLP (fp32-MFMA
+    GEMMs with fused bias+ReLU / ReLU-mask epilogues, split-K weight gradients);
+  * the L shading-light visibility rows (97 % of the FLOPs, no gradient reaches them: renderer.py:197
+    detach + loss.py:82-83) -> ops.FusedPairMLP, the register-resident fused kernel, which never
+    materialises the [L*Ns, 126] input or any activation;
+  * SG shading -> ops.sg_shade (fused forward/backward kernel).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip, ops
+
+PE_STRIDE = 64  # 3 + 6*10 = 63 real columns + 1 zero pad
+
+
+def camera_rays(uv, pose, intrinsics):
+    """stage2/utils/rend_util.py:90-147 (4x4 pose case), device-agnostic."""
+    fx, fy = intrinsics[:, 0, 0], intrinsics[:, 1, 1]
+    cx, cy = intrinsics[:, 0, 2], intrinsics[:, 1, 2]
+    z = torch.ones_like(uv[:, :, 0])
+    x = (uv[:, :, 0] - cx.unsqueeze(-1)) / fx.unsqueeze(-1) * z
+    y = (uv[:, :, 1] - cy.unsqueeze(-1)) / fy.unsqueeze(-1) * z
+    d = torch.einsum('bij,bnj->bni', pose[:, :3, :3], torch.stack((x, y, z), dim=-1))
+    return F.normalize(d, dim=2), pose[:, :3, 3]
+
+
+class MLP(nn.Module):
+    """Network / Normal_Network (renderer.py:17-49).  Parameters live in ``linears`` exactly like the
+    reference; the forward runs on the HIP GEMM path."""
+
+    def __init__(self, din, dout, W, depth, skip_at=(), final='linear'):
+        super().__init__()
+        self.linears = nn.ModuleList(
+            [nn.Linear(din, W)] +
+            [nn.Linear(W + din if i in skip_at else W, W) for i in range(depth - 1)] +
+            [nn.Linear(W, dout)])
+        self.skip_at = list(skip_at)
+        self.final = final
+        self.din, self.width = din, W
+
+    def _skip_index(self):
+        s = [i for i in self.skip_at if 0 <= i < len(self.linears) - 1]
+        assert len(s) <= 1, 'at most one skip connection is supported'
+        return s[0] if s else -100
+
+    def weights(self):
+        return [l.weight for l in self.linears], [l.bias for l in self.linears]
+
+    def forward(self, x_padded, in_cols):
+        Ws, bs = self.weights()
+        return ops.relu_mlp(x_padded, in_cols, self._skip_index(), self.final == 'sigmoid', Ws, bs)
+
+
+class SGBasis(nn.Module):
+    """stage2/model/sgbasis.py:7-32 (parameter container; evaluation is fused in ops.sg_shade)."""
+
+    def __init__(self, nbasis=9, specular_rgb=False):
+        super().__init__()
+        self.nbasis, self.specular_rgb = nbasis, specular_rgb
+        self.lobe = nn.Parameter(torch.tensor([np.exp(i) for i in range(2, 11)], dtype=torch.float32),
+                                 requires_grad=False)
+
+
+class PSNetwork(nn.Module):
+    def __init__(self, conf):
+        super().__init__()
+        self.conf = conf
+        self.render_model = conf.get_string('train.render_model', default='sgbasis')
+        if self.render_model != 'sgbasis':
+            raise NotImplementedError('render_model=%s: only sgbasis is on the accelerated path (SURVEY 8f4)'
+                                      % self.render_model)
+        nbasis = conf.get_int('train.nbasis', default=9)
+        self.specular_rgb = conf.get_bool('train.specular_rgb', default=False)
+        self.sgbasis = SGBasis(nbasis=nbasis, specular_rgb=self.specular_rgb)
+        self.n_freqs = conf.get_int('brdf.net.n_freqs_xyz')
+        dim_emb = 3 + 6 * self.n_freqs
+        assert dim_emb <= PE_STRIDE
+        W, depth = conf.get_int('brdf.net.mlp_width'), conf.get_int('brdf.net.mlp_depth')
+        skip = conf.get_int('brdf.net.mlp_skip_at')
+        self.albedo_net = MLP(dim_emb, 3, W, depth, skip_at=[skip], final='sigmoid')
+        if self.specular_rgb:
+            nbasis *= 3
+        self.rough_net = MLP(dim_emb, nbasis, conf.get_int('brdf.sgnet.mlp_width', 128),
+                             conf.get_int('brdf.sgnet.mlp_depth', 4),
+                             skip_at=[conf.get_int('brdf.sgnet.mlp_skip_at', 2)])
+        self.nbasis = nbasis
+        self.light_int = conf.get_float('brdf.light_intensity', default=4.0)
+        self.shape_pregen = conf.get_bool('train.shape_pregen', default=False)
+        if not self.shape_pregen:
+            raise NotImplementedError('train.shape_pregen=False (the reference leaves surface_points undefined there)')
+        self.xyz_jitter_std = conf.get_float('brdf.net.xyz_jitter_std', default=0)
+        self.normal_mlp = conf.get_bool('train.normal_mlp', default=False)
+        if self.normal_mlp:
+            self.n_freqs_n = conf.get_int('normal.net.n_freqs_xyz')
+            self.normal_net = MLP(3 + 6 * self.n_freqs_n, 3, conf.get_int('normal.net.mlp_width'),
+                                  conf.get_int('normal.net.mlp_depth'),
+                                  skip_at=[conf.get_int('normal.net.mlp_skip_at')])
+            self.normal_joint = conf.get_bool('train.normal_joint', default=False)
+            self.normal_jitter_std = conf.get_float('normal.net.xyz_jitter_std', default=0)
+            if not self.normal_joint:
+                self.normal_net = self.normal_net.eval().requires_grad_(False)
+                self.normal_jitter_std = 0
+        self.visibility = conf.get_bool('train.visibility', default=False)
+        self.light_vis_detach = conf.get_bool('train.light_vis_detach', default=False)
+        if self.visibility:
+            self.visibility_net = MLP(dim_emb * 2, 1, conf.get_int('visibility.net.mlp_width'),
+                                      conf.get_int('visibility.net.mlp_depth'),
+                                      skip_at=[conf.get_int('visibility.net.mlp_skip_at')])
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _pe(self, x, n_freqs):
+        return ops.positional_encoding(x, n_freqs, PE_STRIDE)
+
+    def _cols(self, n_freqs, device, pair=False):
+        d = 3 + 6 * n_freqs
+        c = torch.arange(d, device=device)
+        return torch.cat([c, PE_STRIDE + c]) if pair else c
+
+    def _visibility_rows(self, pe_x, light_dirs, fused_ok):
+        """visibility_net on the light-major rows [pe_x[n] | PE(light[l])], l-major (renderer.py:191-200)."""
+        l_in = light_dirs.detach() if self.light_vis_detach else light_dirs
+        pe_l = self._pe(l_in, self.n_freqs)
+        net = self.visibility_net
+        Ws, bs = net.weights()
+        cols = self._cols(self.n_freqs, pe_x.device, pair=True)
+        if fused_ok and net.width == 256:
+            params = []
+            for W, b in zip(Ws, bs):
+                params += [W, b]
+            return ops.FusedPairMLP.apply(pe_x, pe_l, cols, net._skip_index(), *params)
+        ns, nl = pe_x.shape[0], pe_l.shape[0]
+        x = torch.cat([pe_x.tile(nl, 1), pe_l.repeat_interleave(ns, dim=0)], dim=1)
+        return net(x, cols)
+
+    # -- forward -----------------------------------------------------------------------------------
+    def forward(self, input, albedo_new=None, basis_new=None, noise=None):
+        noise = noise or {}
+        uv, pose, intr = input['uv'], input['pose'], input['intrinsics']
+        object_mask = input['object_mask']
+        device = uv.device
+        ray_dirs, _ = camera_rays(uv, pose, intr)
+        surface_mask, points, normals = input['surface_mask'], input['points'], input['normal']
+        surf = points[surface_mask].contiguous()
+        ns = surf.shape[0]
+
+        out_n = {}
+        if self.normal_mlp:  # renderer.py:127-143
+            normal_pred = torch.ones_like(points)
+            if ns > 0:
+                cols_n = self._cols(self.n_freqs_n, device)
+                normal_pred[surface_mask] = F.normalize(self.normal_net(self._pe(surf, self.n_freqs_n), cols_n), dim=-1)
+                if self.normal_jitter_std > 0:
+                    nz = noise.get('normal')
+                    if nz is None:
+                        nz = torch.normal(0, torch.ones_like(surf) * self.normal_jitter_std)
+                    nj = torch.ones_like(points)
+                    nj[surface_mask] = F.normalize(self.normal_net(self._pe(surf + nz, self.n_freqs_n), cols_n), dim=-1)
+                    out_n['normal_jitter'] = nj
+            out_n['normal_pred'] = normal_pred
+
+        lnum = input['light_direction'].shape[0]
+        rgb_values = torch.ones_like(points).repeat(lnum, 1, 1) if lnum > 1 else torch.ones_like(points)
+        albedo_values = torch.ones_like(points)
+        rough_values = rgb_values.clone()
+        weight_values = torch.zeros(*points.shape[:-1], self.nbasis, device=device)
+        vis_values = rgb_values.clone()
+        jitter = None
+        pe_x = None
+        if ns > 0:
+            normal = normals[surface_mask] if not self.normal_mlp else normal_pred[surface_mask]
+            pts2c = -ray_dirs[surface_mask]
+            mask_l = surface_mask.expand(lnum, -1)
+            light_dir = input['light_direction']
+            cols = self._cols(self.n_freqs, device)
+            pe_x = self._pe(surf, self.n_freqs)
+            albedo = self.albedo_net(pe_x, cols)
+            if albedo_new is not None:
+                albedo = torch.from_numpy(albedo_new).to(device)[None].expand_as(albedo)
+            rough = self.rough_net(pe_x, cols)
+            weights = F.relu(rough)
+            if basis_new is not None:  # material editing (eval.py:233-312)
+                wn = torch.zeros_like(weights)
+                if self.specular_rgb:
+                    wn.view(-1, 3, self.nbasis // 3)[:, :, basis_new] = 2 ** basis_new / 100
+                else:
+                    wn.view(-1, 1, self.nbasis)[:, :, basis_new] = 2 ** basis_new / 100
+                weights = wn.reshape(-1, self.nbasis)
+            weight_values[surface_mask] = weights
+            light_int = input.get('light_intensity', self.light_int)
+            vis = None
+            vis_for_rgb = None
+            if self.visibility:
+                # gradient-free unless a caller backpropagates into output['visibility']
+                vis = self._visibility_rows(pe_x, light_dir, fused_ok=True)  # [L*Ns, 1], light-major
+                detach = self.conf.get_bool('train.vis_rgb_detach', default=False)
+                vis_for_rgb = vis.detach() if detach else vis
+            rgb, spec = ops.sg_shade(light_dir, pts2c, normal, albedo, weights, self.sgbasis.lobe, light_int,
+                                     vis_for_rgb, self.specular_rgb)
+            rgb_values[mask_l] = rgb
+            if vis is not None:
+                vis_values[mask_l] = vis.expand(rgb.shape)
+            albedo_values[surface_mask] = albedo
+            rough_values[mask_l] = spec.expand(-1, 3)
+            if self.xyz_jitter_std > 0:  # renderer.py:211-231
+                nz = noise.get('xyz')
+                if nz is None:
+                    nz = torch.normal(0, torch.ones_like(surf) * self.xyz_jitter_std)
+                pe_j = self._pe(surf + nz, self.n_freqs)
+                aj = torch.ones_like(points)
+                aj[surface_mask] = self.albedo_net(pe_j, cols)
+                rj = torch.ones_like(weight_values)
+                rj[surface_mask] = F.relu(self.rough_net(pe_j, cols))
+                jitter = {'albedo_values': albedo_values, 'albedo_jitter': aj,
+                          'rough_values': weight_values, 'rough_jitter': rj}
+
+        out = {
+            'points': points, 'object_mask': object_mask, 'network_object_mask': surface_mask,
+            'sg_rgb_values': rgb_values, 'normal_values': normals,
+            'sg_diffuse_albedo_values': albedo_values, 'sg_specular_rgb_values': rough_values,
+        }
+        if jitter is not None:
+            out.update(jitter)
+        if self.normal_mlp:
+            out.update(out_n)
+        if self.visibility:
+            out['visibility'] = vis_values
+            if 'vis_train_gt' in input or 'light_vis_train' in input:  # renderer.py:251-262
+                lv = input['light_vis_train']
+                vnum = lv.shape[0]
+                vt = torch.ones_like(points).repeat(vnum, 1, 1) if vnum > 1 else torch.ones_like(points)
+                if ns > 0:
+                    train = torch.is_grad_enabled() and any(p.requires_grad for p in self.visibility_net.parameters())
+                    vis_t = self._visibility_rows(pe_x, lv, fused_ok=not train)
+                    vt[surface_mask.expand(vnum, -1)] = vis_t.expand(-1, 3)
+                out['vis_train'] = vt
+        out['sg_weight'] = weight_values
+        return out

@@ -1,0 +1,144 @@
+"""Stage-2 product path (HIP, through the C ABI) against the golden vectors captured from the
+reference and against the CPU oracle.  Tolerances: 1e-4 relative on outputs / losses (north star),
+1e-3 on parameter-gradient digests (accumulation order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, assert_close, grad_digest, stage2_state_dict, state_dict_digest
+from psnerf_amd.synthetic import stage2_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(net, MainLoss, NormalLoss, inp, gt, phase, noise, dev):
+    if phase == 1:
+        lw = dict(sg_rgb_weight=0, albedo_smooth_weight=0, rough_smooth_weight=0, vis_weight=10)
+        net.albedo_net.eval().requires_grad_(False)
+        net.rough_net.eval().requires_grad_(False)
+    else:
+        lw = dict(sg_rgb_weight=1.0, albedo_smooth_weight=0.05, rough_smooth_weight=0.01, vis_weight=1)
+    inp = {k: v.to(dev) for k, v in inp.items()}
+    gt = {k: v.to(dev) for k, v in gt.items()}
+    ldir = inp['light_direction'].clone().requires_grad_(phase == 2)
+    lint = inp['light_intensity'].clone().requires_grad_(phase == 2)
+    inp['light_direction'] = torch.nn.functional.normalize(ldir, p=2, dim=-1)
+    inp['light_intensity'] = lint
+    out = net(inp, noise={'xyz': noise.to(dev)})
+    t = dict(MainLoss(loss_type='L1', **lw)(out, gt, inp))
+    tn = NormalLoss(1, 0.05)(out)
+    t['normal_loss'] = tn['normal_loss']
+    t['total'] = t['loss'] + tn['loss']
+    t['total'].backward()
+    gr = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    if phase == 2:
+        gr['__light_dir'], gr['__light_int'] = ldir.grad, lint.grad
+    return out, t, gr
+
+
+@pytest.mark.parametrize('L', [1, 10])
+@pytest.mark.parametrize('phase', [1, 2])
+def test_psnetwork_golden(cuda, L, phase):
+    import psnerf_amd.stage2 as s2
+    g = np.load(os.path.join(GOLDEN, 'stage2_psnet_L%d_ph%d.npz' % (L, phase)))
+    conf = s2.bear_conf()
+    from oracle import stage2 as o2
+    sd = stage2_state_dict(o2.bear_conf(), seed=31)
+    assert state_dict_digest(sd) == str(g['sd_digest'])
+    net = s2.PSNetwork(conf)
+    net.load_state_dict(sd)
+    net.to(cuda)
+    inp, gt = stage2_inputs(int(g['N']), L, int(g['V']), seed=int(g['input_seed']))
+    out, t, gr = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, phase, torch.from_numpy(g['nz_xyz']), cuda)
+    for k in g.files:
+        if k.startswith('out_'):
+            assert_close(out[k[4:]].detach().cpu(), g[k], 1e-4, k)
+    for k, v in zip(g['loss_names'], g['loss_vals']):
+        assert_close(float(t[str(k)]), v, 1e-4, str(k))
+    names, norms, projs = grad_digest(gr)
+    assert names == list(g['grad_names'])
+    assert_close(norms, g['grad_norms'], 1e-3, 'grad norms')
+    assert_close(projs, g['grad_projs'], 1e-3, 'grad projs')
+    if phase == 2:
+        assert_close(gr['__light_dir'].cpu(), g['g_light_dir'], 1e-3, 'light dir grad')
+        assert_close(gr['__light_int'].cpu(), g['g_light_int'], 1e-3, 'light int grad')
+
+
+@pytest.mark.parametrize('N,L,V', [(3000, 5, 8), (777, 96, 3), (64, 2, 1)])
+def test_psnetwork_vs_oracle(cuda, N, L, V):
+    """Ragged sizes (not multiples of the 128-row tiles), per-parameter gradients against the oracle."""
+    import psnerf_amd.stage2 as s2
+    from oracle import stage2 as o2
+    sd = stage2_state_dict(o2.bear_conf(), seed=5)
+    onet = o2.PSNetwork(o2.bear_conf())
+    onet.load_state_dict(sd)
+    net = s2.PSNetwork(s2.bear_conf())
+    net.load_state_dict(sd)
+    net.to(cuda)
+    inp, gt = stage2_inputs(N, L, V, seed=N)
+    ns = int(inp['surface_mask'].sum())
+    nz = torch.randn(ns, 3, generator=torch.Generator().manual_seed(1)) * 0.01
+    o_out, o_t, o_g = _run(onet, o2.MainLoss, o2.NormalLoss, inp, gt, 2, nz, 'cpu')
+    out, t, gr = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, 2, nz, cuda)
+    for k in o_out:
+        if torch.is_tensor(o_out[k]) and o_out[k].dtype.is_floating_point:
+            assert_close(out[k].detach().cpu(), o_out[k].detach(), 1e-4, k)
+    for k in o_t:
+        if o_t[k] is not None:
+            assert_close(float(t[k]), float(o_t[k]), 1e-4, k)
+    assert sorted(gr.keys()) == sorted(o_g.keys())
+    for k in o_g:
+        assert_close(gr[k].cpu(), o_g[k], 1e-3, 'grad ' + k)
+
+
+def test_empty_surface(cuda):
+    import psnerf_amd.stage2 as s2
+    net = s2.PSNetwork(s2.bear_conf()).to(cuda)
+    inp, gt = stage2_inputs(100, 3, 2, seed=1, surface_frac=0.0, device=cuda)
+    inp['surface_mask'][:] = False
+    out = net(inp)
+    assert float((out['sg_rgb_values'] - 1).abs().max()) == 0  # dense outputs are pre-filled with ones
+    t = s2.MainLoss(1.0, 'L1', 0.05, 0.01, 1)(out, gt, inp)
+    assert float(t['loss']) == 0
+
+
+def test_train_steps_match_oracle(cuda):
+    """Three optimisation steps across the train_fix switch (iteration 5000): parameters after the
+    steps match the CPU oracle's within fp32 tolerance."""
+    import psnerf_amd.stage2 as s2
+    from oracle import stage2 as o2
+    sd = stage2_state_dict(o2.bear_conf(), seed=9)
+    N, L, V, NL = 600, 6, 4, 40
+    light_init = torch.nn.functional.normalize(torch.randn(NL, 3, generator=torch.Generator().manual_seed(3)), dim=-1)
+    onet = o2.PSNetwork(o2.bear_conf())
+    onet.load_state_dict(sd)
+    ostep = o2.TrainStep(onet, o2.bear_conf(), NL, light_init)
+    net = s2.PSNetwork(s2.bear_conf())
+    net.load_state_dict(sd)
+    net.to(cuda)
+    step = s2.TrainStep(net, s2.bear_conf(), NL, light_init.to(cuda), cuda)
+    ostep.cur_iter = step.cur_iter = 4999
+    for tr in (ostep, step):  # emulate the state train_fix left at iteration 0
+        tr._ori = (1.0, 0.05, 0.01, 1)
+        tr.loss.sg_rgb_weight, tr.loss.albedo_smooth_weight, tr.loss.rough_smooth_weight, tr.loss.vis_weight = 0, 0, 0, 10
+        tr.model.albedo_net.eval().requires_grad_(False)
+        tr.model.rough_net.eval().requires_grad_(False)
+        tr.light_para.requires_grad_(False)
+        tr.light_inten_para.requires_grad_(False)
+    for it in range(3):
+        inp, gt = stage2_inputs(N, L, V, seed=100 + it)
+        l_slt = torch.randperm(NL, generator=torch.Generator().manual_seed(it))[:L]
+        ns = int(inp['surface_mask'].sum())
+        nz = torch.randn(ns, 3, generator=torch.Generator().manual_seed(50 + it)) * 0.01
+        ot, _ = ostep.step(inp, gt, l_slt, noise={'xyz': nz})
+        inp_d = {k: v.to(cuda) for k, v in inp.items()}
+        gt_d = {k: v.to(cuda) for k, v in gt.items()}
+        pt, _ = step.step(inp_d, gt_d, l_slt.to(cuda), noise={'xyz': nz.to(cuda)})
+        assert_close(float(pt['total']), float(ot['total']), 2e-4, 'loss it%d' % it)
+    osd = onet.state_dict()
+    for k, v in net.state_dict().items():
+        assert_close(v.cpu(), osd[k], 2e-3, 'param ' + k)
+    assert_close(step.light_para.weight.detach().cpu(), ostep.light_para.weight.detach(), 1e-4, 'light dirs')
+    assert_close(step.light_inten_para.weight.detach().cpu(), ostep.light_inten_para.weight.detach(), 1e-4, 'light int')
