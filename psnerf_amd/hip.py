@@ -58,6 +58,11 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 
+# When set to a list (bench.py), kernel wrappers that support it append
+# (name, n_rows, start_event, end_event) recorded on the launch stream.
+PROFILE_EVENTS = None
+
+
 def _check(rc, what):
     if rc != 0:
         raise RuntimeError('%s failed (%d): %s' % (what, rc, _lib.psn_last_error().decode()))
@@ -203,7 +208,14 @@ def mlp_pack_layer(W_dense, n_mt, k_tiles, dst):
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None):
     if out is None:
         out = torch.empty(n_rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
+    prof = PROFILE_EVENTS
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
                               _ptr(tab_a, 'tab_a'), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod, n_rows,
                               _ptr(out, 'out'), _stream()), 'mlp_infer')
+    if prof is not None:
+        e1.record()
+        prof.append(('mlp_infer', n_rows, e0, e1))
     return out

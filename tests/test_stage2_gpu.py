@@ -56,7 +56,7 @@ def test_psnetwork_golden(cuda, L, phase):
         if k.startswith('out_'):
             assert_close(out[k[4:]].detach().cpu(), g[k], 1e-4, k)
     for k, v in zip(g['loss_names'], g['loss_vals']):
-        assert_close(float(t[str(k)]), v, 1e-4, str(k))
+        assert_close(float(t[str(k)].detach()), v, 1e-4, str(k))
     names, norms, projs = grad_digest(gr)
     assert names == list(g['grad_names'])
     assert_close(norms, g['grad_norms'], 1e-3, 'grad norms')
@@ -137,8 +137,13 @@ def test_train_steps_match_oracle(cuda):
         gt_d = {k: v.to(cuda) for k, v in gt.items()}
         pt, _ = step.step(inp_d, gt_d, l_slt.to(cuda), noise={'xyz': nz.to(cuda)})
         assert_close(float(pt['total']), float(ot['total']), 2e-4, 'loss it%d' % it)
+    # Adam's first steps move every weight by ~lr*sign(g): elements whose gradient is at the fp32 noise
+    # floor may legitimately step the other way (|delta| <= 2*lr per step), so bound the max by that and
+    # require the bulk (mean abs difference) to agree tightly.
     osd = onet.state_dict()
     for k, v in net.state_dict().items():
-        assert_close(v.cpu(), osd[k], 2e-3, 'param ' + k)
+        d = (v.cpu() - osd[k]).abs()
+        assert float(d.max()) <= 3 * 2 * 5e-4 + 1e-6, 'param %s max diff %.3e' % (k, float(d.max()))
+        assert float(d.mean()) <= 2e-5, 'param %s mean diff %.3e' % (k, float(d.mean()))
     assert_close(step.light_para.weight.detach().cpu(), ostep.light_para.weight.detach(), 1e-4, 'light dirs')
     assert_close(step.light_inten_para.weight.detach().cpu(), ostep.light_inten_para.weight.detach(), 1e-4, 'light int')
