@@ -55,6 +55,10 @@ int psn_composite_bwd(const float* alpha, const float* rgb, const float* d_rgb_o
  * rest zero-filled up to out_stride).  `scale` multiplies x first (1/rescale).
  * ---------------------------------------------------------------------- */
 int psn_pe_encode(const float* x, int64_t n, int n_freqs, float scale, float* out, int out_stride, void* stream);
+/* forward-mode: t [n,3] tangent of x -> d(encoding) [n, out_stride] = J_PE(x) t  (the transpose of
+ * psn_pe_encode_bwd; needed for the backward of the gradient sweep) */
+int psn_pe_encode_jvp(const float* x, const float* t, int64_t n, int n_freqs, float scale, float* out, int out_stride,
+                      void* stream);
 /* d_out [n, out_stride] -> d_x [n,3] (chain rule through sin/cos; x is re-read) */
 int psn_pe_encode_bwd(const float* x, const float* d_out, int64_t n, int n_freqs, float scale, int out_stride,
                       float* d_x, void* stream);
@@ -79,11 +83,17 @@ enum {
     PSN_EPI_MUL_AUX = 4,       /* C = acc * aux_in[m,n]                              */
     PSN_EPI_MUL_POS = 5,       /* C = acc * (aux_in[m,n] > 0)   (ReLU backward)      */
     PSN_EPI_BIAS_SIGMOID = 6,  /* C = sigmoid(acc + bias[n])                         */
-    PSN_EPI_ACCUM = 7          /* C += acc                                           */
+    PSN_EPI_ACCUM = 7,         /* C += acc                                           */
+    PSN_EPI_MUL2 = 8,          /* C = acc * aux_in,  aux_out = acc * aux_in2         */
+    PSN_EPI_SOFTPLUS_BWD = 9,  /* C = s * (acc + 100 * aux_in2 * (1 - s)), s = aux_in:
+                                  d/dz of softplus_100 plus the sigmoid'(100 z) term of the
+                                  gradient-sweep branch (double backward of network.py:108-120) */
+    PSN_EPI_MUL_AUX_RAW = 10   /* C = acc * aux_in,  aux_out = acc                   */
 };
 int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const float* A, int64_t lda, const float* B,
              int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue, const float* aux_in,
-             int64_t ld_aux_in, float* aux_out, int64_t ld_aux_out, int split_k, float* workspace, void* stream);
+             int64_t ld_aux_in, const float* aux_in2, int64_t ld_aux_in2, float* aux_out, int64_t ld_aux_out,
+             int split_k, float* workspace, void* stream);
 
 /* column sums: out[n] (+)= sum_m X[m,n]  -- bias gradients.  workspace >= 256*N floats */
 int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int accumulate, float* workspace,

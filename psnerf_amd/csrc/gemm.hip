@@ -26,6 +26,8 @@ struct GemmArgs {
     int epi;
     const float* aux_in;
     int64_t ld_aux_in;
+    const float* aux_in2;
+    int64_t ld_aux_in2;
     float* aux_out;
     int64_t ld_aux_out;
     int k_chunk;  // K range per blockIdx.z (multiple of BK)
@@ -189,6 +191,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                     case PSN_EPI_MUL_POS: *cp = g.aux_in[m * g.ld_aux_in + n] > 0.0f ? v : 0.0f; break;
                     case PSN_EPI_BIAS_SIGMOID: *cp = sigmoidf_(v + bias); break;
                     case PSN_EPI_ACCUM: *cp += v; break;
+                    case PSN_EPI_MUL2:
+                        *cp = v * g.aux_in[m * g.ld_aux_in + n];
+                        g.aux_out[m * g.ld_aux_out + n] = v * g.aux_in2[m * g.ld_aux_in2 + n];
+                        break;
+                    case PSN_EPI_SOFTPLUS_BWD: {
+                        float s = g.aux_in[m * g.ld_aux_in + n];
+                        *cp = s * (v + 100.0f * g.aux_in2[m * g.ld_aux_in2 + n] * (1.0f - s));
+                        break;
+                    }
+                    case PSN_EPI_MUL_AUX_RAW:
+                        *cp = v * g.aux_in[m * g.ld_aux_in + n];
+                        g.aux_out[m * g.ld_aux_out + n] = v;
+                        break;
                     default: break;
                 }
             }
@@ -233,13 +248,15 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 
 extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const float* A, int64_t lda,
                         const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
-                        const float* aux_in, int64_t ld_aux_in, float* aux_out, int64_t ld_aux_out, int split_k,
-                        float* workspace, void* stream) {
+                        const float* aux_in, int64_t ld_aux_in, const float* aux_in2, int64_t ld_aux_in2,
+                        float* aux_out, int64_t ld_aux_out, int split_k, float* workspace, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(A && B && C, "gemm: null operand");
     PSN_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
-    PSN_CHECK_ARG(epilogue >= 0 && epilogue <= PSN_EPI_ACCUM, "gemm: unknown epilogue %d", epilogue);
-    if ((epilogue == PSN_EPI_MUL_AUX || epilogue == PSN_EPI_MUL_POS)) PSN_CHECK_ARG(aux_in, "gemm: epilogue needs aux_in");
+    PSN_CHECK_ARG(epilogue >= 0 && epilogue <= PSN_EPI_MUL_AUX_RAW, "gemm: unknown epilogue %d", epilogue);
+    if (epilogue == PSN_EPI_MUL_AUX || epilogue == PSN_EPI_MUL_POS || epilogue >= PSN_EPI_MUL2) PSN_CHECK_ARG(aux_in, "gemm: epilogue needs aux_in");
+    if (epilogue == PSN_EPI_MUL2 || epilogue == PSN_EPI_SOFTPLUS_BWD) PSN_CHECK_ARG(aux_in2, "gemm: epilogue needs aux_in2");
+    if (epilogue == PSN_EPI_MUL2 || epilogue == PSN_EPI_MUL_AUX_RAW) PSN_CHECK_ARG(aux_out, "gemm: epilogue needs aux_out");
     if (epilogue >= PSN_EPI_BIAS && epilogue <= PSN_EPI_BIAS_SOFTPLUS) PSN_CHECK_ARG(bias, "gemm: epilogue needs bias");
     if (epilogue == PSN_EPI_BIAS_SIGMOID) PSN_CHECK_ARG(bias, "gemm: epilogue needs bias");
     if (split_k < 1) split_k = 1;
@@ -252,6 +269,7 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.epi = epilogue; g.aux_in = aux_in; g.ld_aux_in = ld_aux_in; g.aux_out = aux_out;
+    g.aux_in2 = aux_in2; g.ld_aux_in2 = ld_aux_in2;
     g.ld_aux_out = ld_aux_out;
     int64_t tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;

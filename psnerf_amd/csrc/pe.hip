@@ -27,6 +27,29 @@ __global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void pe_encode_jvp_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                            int64_t n, int n_freqs, float scale,
+                                                            float* __restrict__ out, int out_stride) {
+    const int64_t total = n * out_stride;
+    const int width = 3 + 6 * n_freqs;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t row = e / out_stride;
+        int col = (int)(e - row * out_stride);
+        float v = 0.0f;
+        if (col < 3) {
+            v = t[row * 3 + col] * scale;
+        } else if (col < width) {
+            int q = col - 3;
+            int f = q / 6, w = q - 6 * f;
+            int c = w % 3;
+            float arg = ldexpf(x[row * 3 + c] * scale, f);
+            float d = (w >= 3) ? -sinf(arg) : cosf(arg);
+            v = ldexpf(d * (t[row * 3 + c] * scale), f);
+        }
+        out[e] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void pe_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ d_out,
                                                             int64_t n, int n_freqs, float scale, int out_stride,
                                                             float* __restrict__ d_x) {
@@ -60,6 +83,20 @@ extern "C" int psn_pe_encode(const float* x, int64_t n, int n_freqs, float scale
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(pe_encode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, n_freqs, scale, out, out_stride);
     PSN_CHECK_LAUNCH("pe_encode");
+    return PSN_OK;
+}
+
+extern "C" int psn_pe_encode_jvp(const float* x, const float* t, int64_t n, int n_freqs, float scale, float* out,
+                                 int out_stride, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(x && t && out, "pe_encode_jvp: null pointer");
+    PSN_CHECK_ARG(n_freqs >= 0 && n_freqs <= 16 && out_stride >= 3 + 6 * n_freqs, "pe_encode_jvp: n_freqs=%d out_stride=%d", n_freqs, out_stride);
+    if (n <= 0) return PSN_OK;
+    int64_t total = n * out_stride;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(pe_encode_jvp_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, t, n, n_freqs, scale, out, out_stride);
+    PSN_CHECK_LAUNCH("pe_encode_jvp");
     return PSN_OK;
 }
 

@@ -24,7 +24,8 @@ c_f = ctypes.c_void_p  # device pointers travel as void*
 i64, i32, f32 = ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
 MAX_LAYERS = 12
-EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_SOFTPLUS, EPI_MUL_AUX, EPI_MUL_POS, EPI_BIAS_SIGMOID, EPI_ACCUM = range(8)
+(EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_SOFTPLUS, EPI_MUL_AUX, EPI_MUL_POS, EPI_BIAS_SIGMOID, EPI_ACCUM,
+ EPI_MUL2, EPI_SOFTPLUS_BWD, EPI_MUL_AUX_RAW) = range(11)
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS100 = range(3)
 OUT_NONE, OUT_SIGMOID, OUT_OCC = range(3)
 
@@ -46,8 +47,9 @@ SIGNATURES = {
     'psn_composite_bwd': (i32, [c_f, c_f, c_f, c_f, i64, i32, i32, c_f, c_f, c_f]),
     'psn_pe_encode': (i32, [c_f, i64, i32, f32, c_f, i32, c_f]),
     'psn_pe_encode_bwd': (i32, [c_f, c_f, i64, i32, f32, i32, c_f, c_f]),
-    'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, i32,
-                       c_f, c_f]),
+    'psn_pe_encode_jvp': (i32, [c_f, c_f, i64, i32, f32, c_f, i32, c_f]),
+    'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, c_f, i64,
+                       i32, c_f, c_f]),
     'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, c_f, c_f]),
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, i64, c_f, c_f]),
@@ -125,6 +127,15 @@ def pe_encode(x, n_freqs, out_stride=None, scale=1.0):
     return out
 
 
+def pe_encode_jvp(x, t, n_freqs, out_stride, scale=1.0):
+    """J_PE(x) t: tangent t [n,3] -> [n, out_stride]."""
+    n = x.shape[0]
+    out = torch.empty(n, out_stride, device=x.device, dtype=torch.float32)
+    _check(_lib.psn_pe_encode_jvp(_ptr(x, 'x'), _ptr(t, 't'), n, n_freqs, float(scale), _ptr(out, 'out'), out_stride,
+                                  _stream()), 'pe_encode_jvp')
+    return out
+
+
 def pe_encode_bwd(x, d_out, n_freqs, scale=1.0):
     n = x.shape[0]
     d_x = torch.empty_like(x)
@@ -160,7 +171,7 @@ def _mat_ptr(t, name):
 
 
 def gemm(A, B, trans_a=False, trans_b=False, bias=None, epi=EPI_NONE, aux_in=None, out=None, aux_out=None,
-         split_k=1):
+         split_k=1, aux_in2=None):
     """out[M,N] = epi(op(A) @ op(B)).  A/B/out/aux may be row-major views with a row stride."""
     if trans_a:
         K, M = A.shape
@@ -180,6 +191,8 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, epi=EPI_NONE, aux_in=Non
     _check(_lib.psn_gemm(int(trans_a), int(trans_b), M, N, K, _mat_ptr(A, 'A'), _ld(A), _mat_ptr(B, 'B'), _ld(B),
                          _mat_ptr(out, 'out'), _ld(out), _ptr(bias, 'bias', True), epi,
                          None if aux_in is None else _mat_ptr(aux_in, 'aux_in'), 0 if aux_in is None else _ld(aux_in),
+                         None if aux_in2 is None else _mat_ptr(aux_in2, 'aux_in2'),
+                         0 if aux_in2 is None else _ld(aux_in2),
                          None if aux_out is None else _mat_ptr(aux_out, 'aux_out'),
                          0 if aux_out is None else _ld(aux_out), split_k,
                          None if ws is None else ws.data_ptr(), _stream()), 'gemm')

@@ -1,0 +1,178 @@
+"""Stage-1 occupancy + appearance field with the reference's ``NeuralNetwork`` interface
+(stage1/model/network.py:7-138) on the HIP kernels.
+
+state_dict keys are the reference's (``lin{l}.{bias,weight_g,weight_v}``, ``lina{l}.*``), so released
+checkpoints load unchanged.  Mapping to kernels:
+  * training / with-graph evaluation  -> ops.GeoField (value pass + reverse-mode spatial-gradient sweep
+    + hand-written double backward, all fp32-MFMA GEMMs) and ops.ReluMLP (appearance net);
+  * no-grad occupancy queries (ray marching, secant, shadow rays) -> the register-resident fused
+    inference kernel (fused.pack_geo_occupancy), re-packed once per optimiser step.
+Weight normalisation (w = g * v / |v|) is evaluated with torch ops on the (tiny) weight tensors so that
+autograd carries dW back to weight_g / weight_v.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import fused, hip, ops
+
+
+class WNLinear(nn.Module):
+    """Parameters of nn.utils.weight_norm(nn.Linear(...)): weight_g [out,1], weight_v [out,in], bias."""
+
+    def __init__(self, weight, bias):
+        super().__init__()
+        self.weight_g = nn.Parameter(weight.norm(2, dim=1, keepdim=True).clone())
+        self.weight_v = nn.Parameter(weight.clone())
+        self.bias = nn.Parameter(bias.clone())
+
+    def weight(self):
+        v = self.weight_v
+        return v * (self.weight_g / v.norm(2, dim=1, keepdim=True))
+
+
+class NeuralNetwork(nn.Module):
+    def __init__(self, cfg_all, **kwargs):
+        super().__init__()
+        cfg = cfg_all['model']
+        hidden = cfg['hidden_dim']
+        self.octaves_pe = cfg['octaves_pe']
+        self.octaves_pe_views = cfg['octaves_pe_views']
+        self.skips = list(cfg['skips'])
+        self.rescale = cfg['rescale']
+        self.feat_size = cfg['feat_size']
+        geometric_init = cfg['geometric_init']
+        bias0 = 0.6
+
+        d_pe = 3 + 6 * self.octaves_pe
+        self.d_pe = d_pe
+        self.d_view = 3 + 6 * self.octaves_pe_views
+        d_app = 3 + self.d_view + 3 + self.feat_size
+        dims = [d_pe] + [hidden] * cfg['num_layers'] + [self.feat_size + 1]
+        self.num_layers = len(dims)
+        self.n_geo = len(dims) - 1
+        for l in range(self.n_geo):
+            d_out = dims[l + 1] - dims[0] if (l + 1) in self.skips else dims[l + 1]
+            lin = nn.Linear(dims[l], d_out)  # consumes the RNG like the reference (network.py:45)
+            if geometric_init:  # sphere initialisation, network.py:47-61
+                with torch.no_grad():
+                    if l == self.n_geo - 1:
+                        nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                        nn.init.constant_(lin.bias, -bias0)
+                    elif self.octaves_pe > 0 and l == 0:
+                        nn.init.constant_(lin.bias, 0.0)
+                        nn.init.constant_(lin.weight[:, 3:], 0.0)
+                        nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(d_out))
+                    elif self.octaves_pe > 0 and l in self.skips:
+                        nn.init.constant_(lin.bias, 0.0)
+                        nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(d_out))
+                        nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
+                    else:
+                        nn.init.constant_(lin.bias, 0.0)
+                        nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(d_out))
+            setattr(self, 'lin%d' % l, WNLinear(lin.weight.detach(), lin.bias.detach()))
+        dims_app = [d_app] + [hidden] * 4 + [3]
+        self.num_layers_app = len(dims_app)
+        self.n_app = len(dims_app) - 1
+        for l in range(self.n_app):
+            lin = nn.Linear(dims_app[l], dims_app[l + 1])
+            setattr(self, 'lina%d' % l, WNLinear(lin.weight.detach(), lin.bias.detach()))
+        self._packed = None
+        self._packed_key = None
+
+    # ---- effective weights ----------------------------------------------------------------------
+    def _geo_params(self):
+        inv = 1.0 / np.sqrt(2)
+        out = []
+        for l in range(self.n_geo):
+            lin = getattr(self, 'lin%d' % l)
+            W = lin.weight()
+            if l in self.skips:
+                W = W * inv  # fold the cat[x, pe]/sqrt(2) of network.py:90-91 into the layer
+            out += [W, lin.bias]
+        return out
+
+    def _app_params(self):
+        Ws, bs = [], []
+        for l in range(self.n_app):
+            lin = getattr(self, 'lina%d' % l)
+            Ws.append(lin.weight())
+            bs.append(lin.bias)
+        return Ws, bs
+
+    def _geo(self, p_flat, with_grad):
+        return ops.GeoField.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad,
+                                  *self._geo_params())
+
+    def _occupancy_packed(self):
+        key = tuple(int(q._version) for q in self.parameters()) + (self.lin0.weight_v.data_ptr(),)
+        if self._packed is None or self._packed_key != key:
+            with torch.no_grad():
+                ps = self._geo_params()
+                # un-fold the 1/sqrt(2): pack_geo_occupancy applies it itself
+                Ws = [getattr(self, 'lin%d' % l).weight() for l in range(self.n_geo)]
+                self._packed = fused.pack_geo_occupancy(Ws, ps[1::2], self.skips, self.d_pe)
+            self._packed_key = key
+        return self._packed
+
+    # ---- reference API ----------------------------------------------------------------------------
+    def infer_occ(self, p):
+        shp = p.shape[:-1]
+        out, _ = self._geo(p.reshape(-1, 3), False)
+        return out.reshape(*shp, -1)
+
+    def gradient(self, p, tflag=True):
+        """d occ_logit / d p -> [Q,1,3] (network.py:108-120).  tflag=False returns a detached result."""
+        flat = p.reshape(-1, 3)
+        if tflag:
+            _, g = self._geo(flat, True)
+        else:
+            with torch.no_grad():
+                _, g = self._geo(flat, True)
+        return g.unsqueeze(1)
+
+    def infer_app(self, points, normals, view_dirs, feature_vectors):
+        x = torch.cat([points, view_dirs, normals.squeeze(-2), feature_vectors], dim=-1)
+        return self._app(x)
+
+    def _app(self, x):
+        d = x.shape[-1]
+        kp = (d + 3) // 4 * 4
+        xp = torch.nn.functional.pad(x.reshape(-1, d), (0, kp - d)).contiguous()
+        Ws, bs = self._app_params()
+        cols = torch.arange(d, device=x.device)
+        y = ops.relu_mlp(xp, cols, -100, False, Ws, bs)
+        return (torch.tanh(y) * 0.5 + 0.5).reshape(*x.shape[:-1], 3)
+
+    def occupancy(self, p_flat):
+        """sigmoid(-10 * logit) for [Q,3] points without a graph: fused register-resident kernel."""
+        packed = self._occupancy_packed()
+        tab = hip.pe_encode(p_flat.contiguous(), self.octaves_pe, 64, 1.0 / self.rescale)
+        return packed(tab, p_flat.shape[0])
+
+    def forward(self, p, ray_d=None, only_occupancy=False, return_logits=False, return_addocc=False, noise=False,
+                **kwargs):
+        shp = p.shape[:-1]
+        flat = p.reshape(-1, 3)
+        if only_occupancy:
+            if not torch.is_grad_enabled() and self.feat_size + 1 > 1 and self._hidden_is_256():
+                return self.occupancy(flat).reshape(*shp, 1)
+            out, _ = self._geo(flat, False)
+            return torch.sigmoid(out[:, :1] * -10.0).reshape(*shp, 1)
+        if ray_d is not None:
+            out, grad = self._geo(flat, True)
+            v = ray_d.reshape(-1, 3)
+            v = v / torch.norm(v, dim=-1, keepdim=True)
+            v_pe = ops.positional_encoding(v, self.octaves_pe_views)
+            rgb = self._app(torch.cat([flat, v_pe, grad, out[:, 1:]], dim=-1)).reshape(*shp, 3)
+            if return_addocc:
+                return rgb, torch.sigmoid(out[:, :1] * -10.0).reshape(*shp, 1)
+            return rgb
+        if return_logits:
+            out, _ = self._geo(flat, False)
+            return (-1 * out[:, :1]).reshape(*shp, 1)
+        return None
+
+    def _hidden_is_256(self):
+        return self.lin1.weight_v.shape[1] == 256 and all(
+            getattr(self, 'lin%d' % l).weight_v.shape[0] in (256, 256 - self.d_pe) for l in range(self.n_geo - 1))
