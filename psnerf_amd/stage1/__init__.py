@@ -1,9 +1,6 @@
 """Stage-1 (UNISURF-style shape + appearance) with the reference's ``model`` package surface
 (stage1/model/__init__.py:1-4)."""
 from .network import NeuralNetwork, WNLinear
-try:
-    from .rendering import Renderer
-    from .losses import Loss
-    from .training import Trainer
-except ImportError:  # during bring-up
-    pass
+from .rendering import Renderer
+from .losses import Loss
+from .training import Trainer

@@ -1,0 +1,49 @@
+"""Stage-1 loss with the reference's interface (stage1/model/losses.py:6-70).  Scalar reductions on
+[N,3] tensors: host-side torch ops.  ``denoms`` lets the data-parallel trainer substitute GLOBAL
+denominators: the reference divides by the batch ray count, the hit count, the
+normal-mask count and the valid-mask count."""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+class Loss(nn.Module):
+    def __init__(self, full_weight, grad_weight, norm_weight=1.0, mask_weight=1.0, device=None):
+        super().__init__()
+        self.full_weight, self.grad_weight = full_weight, grad_weight
+        self.norm_weight, self.mask_weight = norm_weight, mask_weight
+        self.device = device
+        self.global_sum = None  # callable(int) -> int summed over ranks (set by the DP trainer)
+
+    def _g(self, n):
+        return n if self.global_sum is None else self.global_sum(n)
+
+    def forward(self, out_dict, rgb_gt, normal_gt=None, norm_mask=None, mask=None, mask_gt=None, mask_valid=None):
+        rgb, diff_norm, normal = out_dict['rgb'], out_dict['diff_norm'], out_dict.get('normal_pred')
+        dev = rgb.device
+        zero = torch.tensor(0.0, device=dev)
+        rgb_gt = rgb_gt.to(dev)
+        if self.full_weight != 0.0:
+            l_rgb = (rgb - rgb_gt).abs().sum() / float(self._g(rgb.shape[1]))
+        else:
+            l_rgb = zero
+        if diff_norm is not None and self.grad_weight != 0.0:
+            n_hit = self._g(diff_norm.shape[0])
+            l_grad = zero if n_hit == 0 else diff_norm.sum() / float(n_hit)
+        else:
+            l_grad = zero
+        loss = self.full_weight * l_rgb + self.grad_weight * l_grad
+        terms = {'fullrgb_loss': l_rgb, 'grad_loss': l_grad}
+        if normal is not None and normal_gt is not None:
+            cnt = self._g(int(norm_mask.sum()))
+            if cnt > 0:
+                l_n = (normal[norm_mask] - normal_gt[norm_mask]).abs().sum() / float(cnt)
+                loss = loss + self.norm_weight * l_n
+                terms['normal_loss'] = l_n
+        if mask is not None and mask_gt is not None:
+            cnt = self._g(int(mask_valid.sum()))
+            l_m = F.binary_cross_entropy(mask[mask_valid].clamp(0, 1), mask_gt[mask_valid], reduction='sum') / float(max(cnt, 1))
+            loss = loss + self.mask_weight * l_m
+            terms['mask_loss'] = l_m
+        terms['loss'] = loss
+        return terms

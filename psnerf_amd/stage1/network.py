@@ -100,9 +100,20 @@ class NeuralNetwork(nn.Module):
             bs.append(lin.bias)
         return Ws, bs
 
+    MAX_ROWS = 1 << 18  # rows per GeoField call: bounds the saved activations to ~9 GB of the 288 GB HBM
+
     def _geo(self, p_flat, with_grad):
-        return ops.GeoField.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad,
-                                  *self._geo_params())
+        params = self._geo_params()
+        if p_flat.shape[0] <= self.MAX_ROWS:
+            return ops.GeoField.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad,
+                                      *params)
+        outs, grads = [], []
+        for s in range(0, p_flat.shape[0], self.MAX_ROWS):
+            o, g = ops.GeoField.apply(p_flat[s:s + self.MAX_ROWS], self.octaves_pe, 1.0 / self.rescale,
+                                      tuple(self.skips), with_grad, *params)
+            outs.append(o)
+            grads.append(g)
+        return torch.cat(outs, 0), torch.cat(grads, 0)
 
     def _occupancy_packed(self):
         key = tuple(int(q._version) for q in self.parameters()) + (self.lin0.weight_v.data_ptr(),)

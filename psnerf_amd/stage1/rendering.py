@@ -1,0 +1,289 @@
+"""Stage-1 renderer with the reference's ``Renderer`` interface (stage1/model/rendering.py:9-555,
+minus the phong preview, which is out of scope -- SURVEY 2).
+
+Kernel mapping: every occupancy query without a graph (ray marching, secant refinement, shadow-ray
+light visibility) goes through the fused register-resident MLP kernel; the render samples go through
+ops.GeoField + the appearance MLP; the transmittance composite is the wave-scan kernel
+(ops.alpha_composite / hip.composite_fwd).  Ray set-up, interval sampling and the sign-change search
+are small elementwise torch ops on [N, S] tensors (host-side plumbing).
+
+All random draws can be injected (``noise={'miss','hit','nbr'}``) for parity tests; by default they are
+drawn on the device.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip, ops
+
+MAX_QUERY_ROWS = 1 << 22  # rows per fused-kernel launch (bounds the positional-encoding table to 1 GiB)
+
+
+def camera_origin(n_points, world_mat):
+    """stage1/model/common.py:205-207."""
+    return world_mat[:, :3, -1].unsqueeze(1).repeat(1, n_points, 1)
+
+
+def pixel_rays(pixels, camera_mat, world_mat):
+    """stage1/model/common.py:210-226 -- both pixel axes are divided by fx = K[0,0,0] (reference quirk)."""
+    q = (pixels - camera_mat[0, :2, 2]) / camera_mat[0, 0, 0]
+    q = torch.cat([q, torch.ones_like(q[..., :1])], dim=2)
+    return torch.einsum('bij,bnj->bni', world_mat[:, :3, :3], q)
+
+
+def sphere_intersection(cam_loc, ray_dirs, r=1.0):
+    """stage1/model/rendering.py:576-596."""
+    n_img, n_pix, _ = ray_dirs.shape
+    b = torch.bmm(ray_dirs, cam_loc.unsqueeze(-1)).squeeze(-1).reshape(-1)
+    under = b ** 2 - (cam_loc.norm(2, 1).reshape(-1, 1).expand(n_img, n_pix).reshape(-1) ** 2 - r ** 2)
+    hit = under > 0
+    root = torch.sqrt(under.clamp(min=0))
+    out = torch.stack([-root - b, root - b], dim=-1)
+    out = torch.where(hit.unsqueeze(-1), out, torch.zeros_like(out))
+    return out.reshape(n_img, n_pix, 2).clamp_min(0.0), hit.reshape(n_img, n_pix)
+
+
+def finite_mask(t):
+    return (t.abs() != np.inf) & ~torch.isnan(t)
+
+
+class Renderer(nn.Module):
+    def __init__(self, model, cfg_all, device=None, **kwargs):
+        super().__init__()
+        cfg = cfg_all['rendering']
+        self._device = device
+        self.depth_range = [cfg['near'], cfg['far']]
+        self.n_max_network_queries = cfg['n_max_network_queries']
+        self.white_background = cfg['white_background']
+        self.cfg = cfg
+        self.model = model.to(device) if device is not None else model
+
+    def forward(self, pixels, camera_mat, world_mat, scale_mat, rendering_technique, add_noise=True, eval_=False,
+                it=0, visibility=False, light_dir=None, noise=None):
+        if rendering_technique == 'unisurf':
+            return self.unisurf(pixels, camera_mat, world_mat, scale_mat, it=it, add_noise=add_noise, eval_=eval_,
+                                noise=noise)
+        if rendering_technique == 'shape_extract':
+            return self.shape_extract(pixels, camera_mat, world_mat, scale_mat, it=it, visibility=visibility,
+                                      light_dir=light_dir)
+        if rendering_technique == 'phong_renderer':
+            raise NotImplementedError('phong_renderer is a visualisation preview (out of scope, SURVEY 2)')
+        raise ValueError('Choose unisurf or shape_extract')
+
+    # ---- occupancy queries without a graph -------------------------------------------------------
+    def _occ(self, pts):
+        """sigmoid(-10 logit) for [Q,3] points, fused kernel, chunked."""
+        outs = []
+        for s in range(0, pts.shape[0], MAX_QUERY_ROWS):
+            outs.append(self.model.occupancy(pts[s:s + MAX_QUERY_ROWS]))
+        return torch.cat(outs, 0) if len(outs) != 1 else outs[0]
+
+    # ---- stage1/model/rendering.py:410-523 -------------------------------------------------------
+    @torch.no_grad()
+    def ray_marching(self, ray0, ray_direction, model=None, c=None, tau=0.5, n_steps=(128, 129), n_secant_steps=8,
+                     depth_range=(25, 40), max_points=3500000, rad=1.0, clip=False):
+        B, N, _ = ray0.shape
+        dev = ray0.device
+        n_steps = int(n_steps[0])  # the reference draws randint(n, n+1): a constant
+        far = sphere_intersection(ray0[:, 0], ray_direction, r=rad)[0][..., 1]
+        t = torch.linspace(0, 1, steps=n_steps, device=dev).view(1, 1, n_steps, 1)
+        d_prop = depth_range[0] * (1.0 - t) + far.view(1, -1, 1, 1) * t
+        p_prop = ray0.unsqueeze(2) + ray_direction.unsqueeze(2) * d_prop
+        val = (self._occ(p_prop.reshape(-1, 3)) - tau).view(B, N, n_steps)
+        if clip:
+            val[(p_prop > 1).any(-1)] = -1
+            val[(p_prop < -1).any(-1)] = -1
+        first_free = val[:, :, 0] < 0
+        sgn = torch.cat([torch.sign(val[:, :, :-1] * val[:, :, 1:]), torch.ones(B, N, 1, device=dev)], dim=-1)
+        cost = sgn * torch.arange(n_steps, 0, -1, device=dev).float()
+        values, idx = torch.min(cost, -1)
+        has_change = values < 0
+        from_free = torch.gather(val, 2, idx.unsqueeze(-1)).squeeze(-1) < 0
+        mask = has_change & from_free & first_free
+        dflat = d_prop.expand(B, N, n_steps, 1).reshape(B, N, n_steps)
+        idx2 = torch.clamp(idx + 1, max=n_steps - 1)
+        d_low = torch.gather(dflat, 2, idx.unsqueeze(-1)).squeeze(-1)[mask]
+        f_low = torch.gather(val, 2, idx.unsqueeze(-1)).squeeze(-1)[mask]
+        d_high = torch.gather(dflat, 2, idx2.unsqueeze(-1)).squeeze(-1)[mask]
+        f_high = torch.gather(val, 2, idx2.unsqueeze(-1)).squeeze(-1)[mask]
+        d_pred = self.secant(f_low, f_high, d_low, d_high, n_secant_steps, ray0[mask], ray_direction[mask], tau)
+        out = torch.ones(B, N, device=dev)
+        out[mask] = d_pred
+        out[mask == 0] = np.inf
+        out[first_free == 0] = 0
+        return out
+
+    # ---- stage1/model/rendering.py:525-555 -------------------------------------------------------
+    @torch.no_grad()
+    def secant(self, f_low, f_high, d_low, d_high, n_secant_steps, ray0_masked, ray_direction_masked, tau, it=0):
+        d_pred = -f_low * (d_high - d_low) / (f_high - f_low) + d_low
+        if d_pred.numel() == 0:
+            return d_pred
+        for _ in range(n_secant_steps):
+            p_mid = ray0_masked + d_pred.unsqueeze(-1) * ray_direction_masked
+            f_mid = self._occ(p_mid)[..., 0] - tau
+            lo = f_mid < 0
+            d_low = torch.where(lo, d_pred, d_low)
+            f_low = torch.where(lo, f_mid, f_low)
+            d_high = torch.where(lo, d_high, d_pred)
+            f_high = torch.where(lo, f_high, f_mid)
+            d_pred = -f_low * (d_high - d_low) / (f_high - f_low) + d_low
+        return d_pred
+
+    def _surface(self, pixels, camera_mat, world_mat, ray_steps):
+        """Shared prologue of unisurf / shape_extract (rendering.py:67-108, 311-340)."""
+        B, N, _ = pixels.shape
+        cam = camera_origin(N, world_mat)
+        rays = pixel_rays(pixels, camera_mat, world_mat)
+        rays = rays / rays.norm(2, 2).unsqueeze(-1)
+        d_i = self.ray_marching(cam, rays, n_steps=[int(ray_steps), int(ray_steps) + 1], n_secant_steps=8,
+                                rad=self.cfg['radius'], depth_range=self.depth_range)
+        zero_occ = d_i == 0
+        ok = finite_mask(d_i)
+        dists = torch.where(ok, d_i, torch.ones_like(d_i))
+        dists = torch.where(zero_occ, torch.zeros_like(dists), dists)
+        obj_mask = (ok & ~zero_occ)[0]
+        dists = dists[0]
+        cam = cam.reshape(-1, 3)
+        rays = rays.reshape(-1, 3)
+        points = (cam + rays * dists.unsqueeze(-1)).view(-1, 3)
+        return cam, rays, dists, obj_mask, points
+
+    # ---- stage1/model/rendering.py:50-226 --------------------------------------------------------
+    def unisurf(self, pixels, camera_mat, world_mat, scale_mat, add_noise=False, it=100000, eval_=False, noise=None):
+        noise = noise or {}
+        B, N, _ = pixels.shape
+        dev = pixels.device
+        cfg = self.cfg
+        steps, steps_out = cfg['num_points_in'], cfg['num_points_out']
+        near = float(self.depth_range[0])
+
+        cam0 = camera_origin(N, world_mat)
+        rays0 = pixel_rays(pixels, camera_mat, world_mat)
+        rays0 = rays0 / rays0.norm(2, 2).unsqueeze(-1)
+        isect, _ = sphere_intersection(cam0[:, 0], rays0, r=cfg['radius'])
+        cam, rays, dists, obj_mask, points = self._surface(pixels, camera_mat, world_mat, cfg['ray_marching_steps'])
+        isect = isect.reshape(-1, 2).clone()
+        isect[:, 0] = 0.0
+
+        d_hit = dists[obj_mask]
+        far_hit = isect[obj_mask][:, 1]
+        delta = float(torch.max(cfg['interval_start'] * torch.exp(-1 * cfg['interval_decay'] * it * torch.ones(1)),
+                                cfg['interval_end'] * torch.ones(1)))  # fp32 like rendering.py:116-117
+        dnp = d_hit - delta
+        dfp = d_hit + delta
+        near_t = torch.tensor(near, device=dev)
+        dnp = torch.where(dnp < near_t, near_t, dnp)
+        dfp = torch.where(dfp > far_hit, far_hit, dfp)
+        full_steps = steps + steps_out if (bool((dnp != 0.0).all()) and it > 5000) else steps
+
+        def jitter(d, key):
+            mid = 0.5 * (d[:, :, 1:] + d[:, :, :-1])
+            hi = torch.cat([mid, d[:, :, -1:]], dim=-1)
+            lo = torch.cat([d[:, :, :1], mid], dim=-1)
+            nz = noise.get(key)
+            if nz is None:
+                nz = torch.rand(B, d.shape[1], full_steps, device=dev)
+            return lo + (hi - lo) * nz.to(dev)
+
+        far_miss = isect[~obj_mask][:, 1]
+        u = torch.linspace(0.0, 1.0, steps=full_steps, device=dev).view(1, 1, -1)
+        d2 = near * (1.0 - u) + far_miss.view(1, -1, 1) * u
+        if add_noise:
+            d2 = jitter(d2, 'miss')
+        p_miss = cam[~obj_mask].unsqueeze(-2) + rays[~obj_mask].unsqueeze(-2) * d2[0].unsqueeze(-1)
+
+        u = torch.linspace(0.0, 1.0, steps=steps, device=dev).view(1, 1, -1)
+        d_in = dnp.view(1, -1, 1) * (1.0 - u) + dfp.view(1, -1, 1) * u
+        if full_steps != steps:
+            u = torch.linspace(0.0, 1.0, steps=steps_out, device=dev).view(1, 1, -1)
+            d_out = near * (1.0 - u) + dnp.view(1, -1, 1) * u
+            d1, _ = torch.sort(torch.cat([d_out, d_in], dim=-1), dim=-1)
+        else:
+            d1 = d_in
+        if add_noise:
+            d1 = jitter(d1, 'hit')
+        p_hit = cam[obj_mask].unsqueeze(-2) + rays[obj_mask].unsqueeze(-2) * d1[0].unsqueeze(-1)
+
+        p_fg = torch.zeros(B * N, full_steps, 3, device=dev)
+        p_fg[~obj_mask] = p_miss
+        p_fg[obj_mask] = p_hit
+        p_fg = p_fg.reshape(-1, 3)
+        view = (-1 * rays).unsqueeze(-2).expand(-1, full_steps, -1).reshape(-1, 3)
+
+        rgb, alpha = self.model(p_fg, view, return_addocc=True)  # one launch chain; no 64000-point chunking needed
+        rgb = rgb.reshape(B * N, full_steps, 3)
+        alpha = alpha.reshape(B * N, full_steps)
+        rgb_values, acc, _w = ops.alpha_composite(alpha, rgb, bool(self.white_background))
+
+        surf = points[obj_mask]
+        n_surf = surf.shape[0]
+        if not eval_:
+            nz = noise.get('nbr')
+            if nz is None:
+                nz = torch.rand_like(surf)
+            pp = torch.cat([surf, surf + (nz.to(dev) - 0.5) * 0.01], dim=0)
+        else:
+            pp = surf
+        norm_pred = torch.zeros(B * N, 3, device=dev)
+        diff_norm = None
+        if n_surf > 0:
+            g = self.model.gradient(pp)[:, 0, :]
+            nrm = g / (g.norm(2, dim=1).unsqueeze(-1) + 10 ** (-5))
+            norm_pred[obj_mask] = nrm[:n_surf]
+            if not eval_:
+                diff_norm = torch.norm(nrm[:n_surf] - nrm[n_surf:], dim=-1)
+        elif not eval_:
+            diff_norm = torch.zeros(0, device=dev)
+        return {
+            'rgb': rgb_values.reshape(B, -1, 3),
+            'mask_pred': obj_mask,
+            'diff_norm': diff_norm,
+            'normal_pred': norm_pred.reshape(B, -1, 3),
+            'acc_map': acc.reshape(B, -1),
+        }
+
+    # ---- stage1/model/rendering.py:297-376 -------------------------------------------------------
+    @torch.no_grad()
+    def shape_extract(self, pixels, camera_mat, world_mat, scale_mat, it=100000, visibility=False, light_dir=None):
+        B, N, _ = pixels.shape
+        dev = pixels.device
+        self.model.eval()
+        cam, rays, dists, obj_mask, points = self._surface(pixels, camera_mat, world_mat, 512)
+        surf = points[obj_mask]
+        normal = torch.zeros(B * N, 3, device=dev)
+        if len(surf) > 0:
+            g = torch.cat([self.model.gradient(ps, tflag=False)[:, 0, :] for ps in torch.split(surf, 1000000, dim=0)], 0)
+            normal[obj_mask] = F.normalize(g, dim=-1)
+        out = {'mask': obj_mask.reshape(B, -1), 'normal': normal.reshape(B, -1, 3), 'points': points.reshape(B, -1, 3)}
+        if visibility and light_dir is not None:
+            vis = torch.ones(light_dir.shape[0], N, device=dev)
+            if len(surf) > 0:
+                chunks = [self.light_visibility(surf=surf, light_dir=light_dir[s:s + 96])
+                          for s in range(0, len(light_dir), 96)]
+                vis[obj_mask[None].expand_as(vis)] = torch.cat(chunks, dim=0)
+            out['visibility'] = vis
+        return out
+
+    # ---- stage1/model/rendering.py:378-408 -------------------------------------------------------
+    @torch.no_grad()
+    def light_visibility(self, surf=None, light_dir=None, lnear=0.1, lfar=3.5, tau=0.5, n_steps=128,
+                         max_points=3500000):
+        """Shadow-ray transmittance from every surface point toward every light: 1 - acc, [L*Ns]."""
+        dev = surf.device
+        L, Ns = light_dir.shape[0], surf.shape[0]
+        t = torch.linspace(0, 1, steps=n_steps, device=dev).view(1, n_steps, 1)
+        d = lnear * (1.0 - t) + lfar * t
+        per_light = Ns * n_steps
+        lights_per_chunk = max(1, MAX_QUERY_ROWS // max(per_light, 1))
+        outs = []
+        for l0 in range(0, L, lights_per_chunk):
+            ld = light_dir[l0:l0 + lights_per_chunk]
+            p = surf[None, :, None, :] + ld[:, None, None, :] * d[None]  # [l, Ns, S, 3]
+            alpha = self._occ(p.reshape(-1, 3)).view(-1, n_steps)
+            inside = torch.logical_and((p <= 1.1).all(dim=-1), (p >= -1.1).all(dim=-1)).view(-1, n_steps)
+            alpha = torch.where(inside, alpha, torch.zeros_like(alpha)).contiguous()
+            _, _, acc = hip.composite_fwd(alpha, None, False, need_weights=False)
+            outs.append(1 - acc)
+        return torch.cat(outs, 0)

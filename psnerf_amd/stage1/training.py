@@ -1,0 +1,78 @@
+"""Stage-1 train step with the reference's ``Trainer`` interface (stage1/model/training.py:20-60,
+120-198; visualisation is out of scope).  Under data parallelism every rank renders a slice of the
+sampled pixels of the same view and the gradients are summed with one flat-bucket all-reduce."""
+import numpy as np
+import torch
+
+from ..dist import DataParallel
+from .losses import Loss
+
+
+def gather_pixels(img, pix):
+    """stage1/model/common.py:172-202: nearest grid_sample with the reference's 2p/w - 1 scaling."""
+    _, _, h, w = img.shape
+    p = pix.clone().detach()
+    p[:, :, 0] = 2.0 * p[:, :, 0] / w - 1
+    p[:, :, 1] = 2.0 * p[:, :, 1] / h - 1
+    v = torch.nn.functional.grid_sample(img, p.unsqueeze(1), mode='nearest', align_corners=True)
+    return v.squeeze(2).detach().permute(0, 2, 1)
+
+
+class Trainer(object):
+    def __init__(self, model, optimizer, cfg_all, device=None, dp=None, **kwargs):
+        cfg = cfg_all['training']
+        self.model, self.optimizer, self.device, self.cfg = model, optimizer, device, cfg
+        self.n_training_points = cfg['n_training_points']
+        self.normal_loss = cfg.get('normal_loss', False)
+        self.normal_after = cfg.get('normal_after', -1)
+        self.angle = cfg.get('normal_angle', None)
+        self.mask_loss = cfg.get('mask_loss', False)
+        self.rendering_technique = cfg['type']
+        self.loss = Loss(cfg['lambda_l1_rgb'], cfg['lambda_normals'], cfg.get('lambda_normloss', 1.0),
+                         cfg.get('lambda_mask', 1.0), device=device)
+        self.dp = dp if dp is not None else DataParallel(device)
+        if self.dp.enabled:
+            self.loss.global_sum = self.dp.global_sum_int
+
+    def train_step(self, data, it=None, pix=None, noise=None):
+        self.model.train()
+        self.optimizer.zero_grad()
+        terms = self.compute_loss(data, it=it, pix=pix, noise=noise)
+        terms['loss'].backward()
+        self.dp.allreduce_grads([p for p in self.model.parameters() if p.requires_grad])
+        self.optimizer.step()
+        return terms
+
+    def compute_loss(self, data, eval_mode=False, it=None, pix=None, noise=None):
+        dev = self.device
+        img = data['img'].to(dev)
+        B, _, h, w = img.shape
+        mask_img = data.get('img.mask', torch.ones(B, h, w)).unsqueeze(1).to(dev)
+        world_mat, camera_mat, scale_mat = (data['img.world_mat'].to(dev), data['img.camera_mat'].to(dev),
+                                            data['img.scale_mat'].to(dev))
+        normal = data.get('img.normal').to(dev) if self.normal_loss else None
+        norm_mask = data.get('img.norm_mask').unsqueeze(1).to(dev) if self.normal_loss else None
+        mask_valid = data.get('img.mask_valid', torch.ones(B, h, w)).unsqueeze(1).to(dev)
+        if pix is None:  # stage1/model/common.py:32-36: x then y, CPU randint
+            n = int(self.n_training_points)
+            px = torch.randint(0, w, size=(B, n, 1)).float()
+            py = torch.randint(0, h, size=(B, n, 1)).float()
+            pix = torch.cat([px, py], dim=-1)
+        pix = self.dp.shard_rays(pix.to(dev)) if self.dp.enabled else pix.to(dev)
+        mask_gt = gather_pixels(mask_img, pix).bool().reshape(B, -1).to(torch.float32)
+        mask_valid = gather_pixels(mask_valid * 1.0, pix).bool().reshape(B, -1)
+        norm_mask_gt = gather_pixels(norm_mask, pix).bool().squeeze(-1) if self.normal_loss else None
+        out = self.model(pix, camera_mat, world_mat, scale_mat, self.rendering_technique, it=it, eval_=eval_mode,
+                         noise=noise)
+        rgb_gt = gather_pixels(img, pix)
+        normal_gt = None
+        if self.normal_loss and it >= self.normal_after:
+            normal_gt = gather_pixels(normal, pix)
+            if self.angle is not None:
+                norm_mask_gt[normal_gt[..., -1] < np.cos(np.deg2rad(self.angle))] = False
+            flip = torch.tensor([[[1, -1, -1]]], dtype=torch.float32, device=dev)
+            normal_gt = torch.einsum('bij,bnj->bni', world_mat[:, :3, :3] * flip, normal_gt)
+        mask_pred = out.get('acc_map')
+        if not self.mask_loss:
+            mask_gt = None
+        return self.loss(out, rgb_gt, normal_gt, norm_mask_gt, mask_pred, mask_gt, mask_valid)
