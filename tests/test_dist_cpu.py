@@ -1,0 +1,110 @@
+"""Data-parallel path on CPU: two gloo ranks (world_size 2) vs one process.
+
+The product kernels need a GPU, so the COMPUTE in these tests is the CPU oracle (test infrastructure);
+what is under test is psnerf_amd.dist + the DP-aware losses: pixel sharding, global loss
+denominators, the single flat-bucket all-reduce incl. the sparse light-table gradients.  The summed
+rank gradients must equal the single-process gradients."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.helpers import ROOT
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from psnerf_amd import dist as pdist
+    pdist.init_from_env(backend='gloo')
+    torch.set_num_threads(2)
+    from oracle import stage2 as o2
+    from psnerf_amd.stage2.loss import MainLoss, NormalLoss
+    from psnerf_amd.synthetic import stage2_inputs
+    from tests.helpers import stage2_state_dict
+    dp = pdist.DataParallel(torch.device('cpu'))
+    assert dp.enabled and dp.world == world
+    conf = o2.bear_conf()
+    net = o2.PSNetwork(conf)
+    net.load_state_dict(stage2_state_dict(conf, seed=3))
+    N, L, V, NL = 301, 3, 2, 10  # odd N: ragged shards
+    inp, gt = stage2_inputs(N, L, V, seed=6)
+    nz_full = torch.randn(int(inp['surface_mask'].sum()), 3, generator=torch.Generator().manual_seed(1)) * 0.01
+    light_para = torch.nn.Embedding(NL, 3, sparse=True)
+    light_int = torch.nn.Embedding(NL, 1, sparse=True)
+    torch.manual_seed(0)
+    light_para.weight.data.copy_(torch.nn.functional.normalize(torch.randn(NL, 3), dim=-1))
+    torch.nn.init.constant_(light_int.weight, 2.0)
+    l_slt = torch.tensor([7, 2, 5])
+    mi, g = dp.shard_stage2(inp, gt)
+    lo, hi = dp.slice_bounds(N)
+    # the jitter noise rows of this rank's surface pixels
+    surf_idx = torch.cumsum(inp['surface_mask'][0].long(), 0) - 1
+    sel = inp['surface_mask'][0][lo:hi]
+    nz = nz_full[surf_idx[lo:hi][sel]]
+    mi['light_direction'] = torch.nn.functional.normalize(light_para(l_slt), p=2, dim=-1)
+    mi['light_intensity'] = light_int(l_slt)
+    out = net(mi, noise={'xyz': nz})
+    ml, nl = MainLoss(1.0, 'L1', 0.05, 0.01, 1), NormalLoss(1, 0.05)
+    ml.global_count = nl.global_count = dp.global_count
+    loss = ml(out, g, mi)['loss'] + nl(out)['loss']
+    loss.backward()
+    dp.allreduce_grads(list(net.parameters()), [light_para.weight, light_int.weight])
+    if rank == 0:
+        torch.save({'grads': {k: p.grad for k, p in net.named_parameters()},
+                    'light': light_para.weight.grad.to_dense(), 'lint': light_int.weight.grad.to_dense()}, tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_single_process(tmp_path):
+    from oracle import stage2 as o2
+    from psnerf_amd.synthetic import stage2_inputs
+    from tests.helpers import stage2_state_dict, assert_close
+    tmp = str(tmp_path / 'dp.pt')
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, tmp), nprocs=2, join=True)
+    got = torch.load(tmp)
+    # single-process reference
+    conf = o2.bear_conf()
+    net = o2.PSNetwork(conf)
+    net.load_state_dict(stage2_state_dict(conf, seed=3))
+    N, L, V, NL = 301, 3, 2, 10
+    inp, gt = stage2_inputs(N, L, V, seed=6)
+    nz_full = torch.randn(int(inp['surface_mask'].sum()), 3, generator=torch.Generator().manual_seed(1)) * 0.01
+    light_para = torch.nn.Embedding(NL, 3, sparse=True)
+    light_int = torch.nn.Embedding(NL, 1, sparse=True)
+    torch.manual_seed(0)
+    light_para.weight.data.copy_(torch.nn.functional.normalize(torch.randn(NL, 3), dim=-1))
+    torch.nn.init.constant_(light_int.weight, 2.0)
+    l_slt = torch.tensor([7, 2, 5])
+    inp['light_direction'] = torch.nn.functional.normalize(light_para(l_slt), p=2, dim=-1)
+    inp['light_intensity'] = light_int(l_slt)
+    out = net(inp, noise={'xyz': nz_full})
+    loss = o2.MainLoss(1.0, 'L1', 0.05, 0.01, 1)(out, gt, inp)['loss'] + o2.NormalLoss(1, 0.05)(out)['loss']
+    loss.backward()
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            assert got['grads'][k] is None
+            continue
+        assert_close(got['grads'][k], p.grad, 2e-5, 'dp grad ' + k)
+    assert_close(got['light'], light_para.weight.grad.to_dense(), 2e-5, 'dp light-dir grad')
+    assert_close(got['lint'], light_int.weight.grad.to_dense(), 2e-5, 'dp light-intensity grad')
+
+
+def test_slice_bounds_cover_everything_once():
+    from psnerf_amd.dist import DataParallel
+    dp = DataParallel()
+    for world in (1, 2, 3, 8):
+        dp.world = world
+        for n in (0, 1, 7, 64, 1001):
+            seen = []
+            for r in range(world):
+                dp.rank = r
+                lo, hi = dp.slice_bounds(n)
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
