@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Secondary measurement: stage-1 BEAR train step (BASELINE configs[1]): 4096 rays x 128 samples
+(96 inner + 32 outer, it > 5000), 256 march steps + 8 secant, geometric-init weights, one MI355X.
+Prints one JSON line (ray-samples/s = N_rays * S / step time).  `--cpu` also times the oracle."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rays', type=int, default=4096)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--cpu', action='store_true')
+    args = ap.parse_args()
+    import torch
+    from psnerf_amd.synthetic import stage1_cfg, stage1_batch
+    cfg = stage1_cfg('bear', **{'rendering.num_points_in': 96, 'rendering.num_points_out': 32,
+                                'training.n_training_points': args.rays})
+    it = 6000
+    S = 128
+    h, w = 512, 612
+    batch = stage1_batch(cfg, h=h, w=w, seed=0)
+    out = {}
+    if torch.cuda.is_available():
+        from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+        dev = torch.device('cuda:0')
+        torch.manual_seed(42)
+        net = NeuralNetwork(cfg)
+        ren = Renderer(net, cfg, device=dev)
+        tr = Trainer(ren, torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=dev)
+        batch_d = {k: v.to(dev) for k, v in batch.items()}
+        for _ in range(args.warmup):
+            terms = tr.train_step(batch_d, it=it)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            terms = tr.train_step(batch_d, it=it)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        out = {'metric': 'ray-samples/sec (train step) on BEAR stage1', 'value': args.rays * S / dt,
+               'unit': 'ray-samples/s', 'ms_per_step': dt * 1e3, 'rays': args.rays, 'samples': S,
+               'loss': float(terms['loss'].detach()), 'dtype': 'f32', 'data': 'synthetic'}
+    if args.cpu:
+        from oracle import stage1 as o1
+        n_cpu = 256
+        cfg_c = stage1_cfg('bear', **{'rendering.num_points_in': 96, 'rendering.num_points_out': 32,
+                                      'training.n_training_points': n_cpu})
+        torch.manual_seed(42)
+        onet = o1.NeuralNetwork(cfg_c)
+        otr = o1.Trainer(o1.Renderer(onet, cfg_c), torch.optim.Adam(onet.parameters(), lr=1e-4), cfg_c)
+        otr.train_step(batch, it=it)
+        t0 = time.time()
+        otr.train_step(batch, it=it)
+        dt = time.time() - t0
+        out['cpu_baseline'] = {'value': n_cpu * S / dt, 'unit': 'ray-samples/s', 'cores': torch.get_num_threads(),
+                               'kind': 'port', 'sample': 'oracle stage1 step, %d rays x %d, %.2f s' % (n_cpu, S, dt)}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
