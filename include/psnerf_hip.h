@@ -95,7 +95,7 @@ int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const float* A, 
              int64_t ld_aux_in, const float* aux_in2, int64_t ld_aux_in2, float* aux_out, int64_t ld_aux_out,
              int split_k, float* workspace, void* stream);
 
-/* column sums: out[n] (+)= sum_m X[m,n]  -- bias gradients.  workspace >= 256*N floats */
+/* column sums: out[n] (+)= sum_m X[m,n]  -- bias gradients.  workspace >= 2048*N floats */
 int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int accumulate, float* workspace,
                void* stream);
 

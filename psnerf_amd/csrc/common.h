@@ -29,11 +29,47 @@ void set_error(const char* fmt, ...);
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float softplus100(float z) {
-    // torch.nn.Softplus(beta=100, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta
-    float bz = z * 100.0f;
-    return bz > 20.0f ? z : log1pf(expf(bz)) / 100.0f;
+// exp(-|t|) with a Cody-Waite split of the exp2 argument: v_exp_f32 is ~1 ulp on 2^x, the split keeps
+// the product |t|*log2(e) exact to ~2^-48, so u is accurate to ~2 ulp for |t| <= 100.
+__device__ __forceinline__ float exp_neg_abs(float at) {
+    const float L2E_HI = 1.44269502162933349609375f;    // (float) log2(e)
+    const float L2E_LO = 1.925963033500011e-8f;          // log2(e) - L2E_HI
+    float hi = -at * L2E_HI;
+    float lo = fmaf(-at, L2E_HI, -hi);
+    lo = fmaf(-at, L2E_LO, lo);
+    float u = __builtin_amdgcn_exp2f(hi);
+    return fmaf(u, lo * 0.693147182464599609375f, u);
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// log1p(u) for u in [0, 1]: short alternating series below 1/16 (no cancellation in 1+u), otherwise
+// log2(1+u)*ln2 with the classic (u - ((1+u)-1))/(1+u) rounding correction.
+__device__ __forceinline__ float log1p_unit(float u) {
+    float ser = u * (1.0f - u * (0.5f - u * (0.333333343f - u * (0.25f - u * (0.2f - u * (0.166666672f - u * 0.142857149f))))));
+    float w = 1.0f + u;
+    float big = fmaf(__builtin_amdgcn_logf(w), 0.693147182464599609375f, (u - (w - 1.0f)) / w);
+    return u < 0.0625f ? ser : big;
+}
+
+// torch.nn.Softplus(beta=100, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta, evaluated as
+// max(x,0) + log1p(exp(-|beta x|))/beta (identical in exact arithmetic, no overflow, ~25 instructions).
+// Also returns s = sigmoid(beta*x) = d softplus / dx from the same exponential.
+__device__ __forceinline__ void softplus100_sig(float z, float& sp, float& s) {
+    float t = z * 100.0f;
+    float u = exp_neg_abs(fabsf(t));
+    float l = log1p_unit(u);
+    float r = 1.0f / (1.0f + u);
+    s = t >= 0.0f ? r : u * r;
+    sp = t > 20.0f ? z : (fmaxf(t, 0.0f) + l) / 100.0f;
+}
+__device__ __forceinline__ float softplus100(float z) {
+    float sp, s;
+    softplus100_sig(z, sp, s);
+    return sp;
+}
+__device__ __forceinline__ float sigmoidf_(float x) {
+    float u = exp_neg_abs(fabsf(x));
+    float r = 1.0f / (1.0f + u);
+    return x >= 0.0f ? r : u * r;
+}
 
 }  // namespace psn

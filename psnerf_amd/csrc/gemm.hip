@@ -11,7 +11,8 @@
 
 namespace psn {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4, EPI_LD = 68;
+static_assert(4 * 32 * EPI_LD >= 4 * BK * LDT, "epilogue staging must cover the operand tiles");
 
 struct GemmArgs {
     int64_t M;
@@ -34,6 +35,7 @@ struct GemmArgs {
     int tiles_n;
     int64_t n_tiles;  // tiles_m * tiles_n
     int a_vec, b_vec;  // 16-byte vector loads allowed
+    int c_vec, auxin_vec, auxin2_vec, auxout_vec;  // 16-byte vector epilogue accesses allowed
     int64_t split_stride;  // floats between split-K partial outputs (0 when split_k == 1)
 };
 
@@ -101,7 +103,9 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, con
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][BK * LDT];  // [buf][A|B]
+    // operand tiles [buf][A|B][BK*LDT]; re-used by the epilogue as 4 wave-private [32][EPI_LD] staging tiles
+    __shared__ __attribute__((aligned(16))) float lds_raw[4 * 32 * EPI_LD];
+    float (*lds)[2][BK * LDT] = reinterpret_cast<float (*)[2][BK * LDT]>(lds_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -162,52 +166,90 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         buf ^= 1;
     }
 
-    // epilogue: lane (j = li, h = lh) holds C[m0 + wr*64 + i*32 + (r&3) + 8*(r>>2) + 4*h][n0 + wc*64 + jt*32 + j]
+    // epilogue.  Lane (j = li, h = lh) holds C[m0 + wr*64 + it*32 + (r&3) + 8*(r>>2) + 4*h][n0 + wc*64 + jt*32 + j].
+    // Each wave transposes one 32 x 64 half of its tile through a private LDS tile and then walks it in
+    // float4 row segments (16 lanes = one 256 B row piece): coalesced 16-byte loads/stores for C and the
+    // aux operands, and a small rolled loop so the fused epilogue math does not inflate register use.
     float* Cbase = g.C + (int64_t)blockIdx.z * g.split_stride;
+    float* et = lds_raw + wave * (32 * EPI_LD);
+    const int c4 = (lane & 15) * 4;          // column (within the wave's 64) of this lane's float4
+    const int nbase = n0 + wc * 64 + c4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias != nullptr) {
+        if (nbase + 0 < g.N) bias4.x = g.bias[nbase + 0];
+        if (nbase + 1 < g.N) bias4.y = g.bias[nbase + 1];
+        if (nbase + 2 < g.N) bias4.z = g.bias[nbase + 2];
+        if (nbase + 3 < g.N) bias4.w = g.bias[nbase + 3];
+    }
+    const bool full4 = nbase + 3 < g.N;
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-        const int n = n0 + wc * 64 + jt * 32 + li;
-        if (n >= g.N) continue;
-        const float bias = (g.bias != nullptr) ? g.bias[n] : 0.0f;
+    for (int it = 0; it < 2; ++it) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wr * 64 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= g.M) continue;
-                float v = acc[it][jt][r];
-                float* cp = Cbase + m * g.ldc + n;
-                switch (g.epi) {
-                    case PSN_EPI_NONE: *cp = v; break;
-                    case PSN_EPI_BIAS: *cp = v + bias; break;
-                    case PSN_EPI_BIAS_RELU: *cp = fmaxf(v + bias, 0.0f); break;
-                    case PSN_EPI_BIAS_SOFTPLUS: {
-                        float z = v + bias;
-                        *cp = softplus100(z);
-                        if (g.aux_out != nullptr) g.aux_out[m * g.ld_aux_out + n] = sigmoidf_(100.0f * z);
-                        break;
-                    }
-                    case PSN_EPI_MUL_AUX: *cp = v * g.aux_in[m * g.ld_aux_in + n]; break;
-                    case PSN_EPI_MUL_POS: *cp = g.aux_in[m * g.ld_aux_in + n] > 0.0f ? v : 0.0f; break;
-                    case PSN_EPI_BIAS_SIGMOID: *cp = sigmoidf_(v + bias); break;
-                    case PSN_EPI_ACCUM: *cp += v; break;
-                    case PSN_EPI_MUL2:
-                        *cp = v * g.aux_in[m * g.ld_aux_in + n];
-                        g.aux_out[m * g.ld_aux_out + n] = v * g.aux_in2[m * g.ld_aux_in2 + n];
-                        break;
-                    case PSN_EPI_SOFTPLUS_BWD: {
-                        float s = g.aux_in[m * g.ld_aux_in + n];
-                        *cp = s * (v + 100.0f * g.aux_in2[m * g.ld_aux_in2 + n] * (1.0f - s));
-                        break;
-                    }
-                    case PSN_EPI_MUL_AUX_RAW:
-                        *cp = v * g.aux_in[m * g.ld_aux_in + n];
-                        g.aux_out[m * g.ld_aux_out + n] = v;
-                        break;
+            for (int r = 0; r < 16; ++r)
+                et[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LD + jt * 32 + li] = acc[it][jt][r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            const int row = (lane >> 4) + 4 * i;
+            const int64_t m = m0 + wr * 64 + it * 32 + row;
+            if (m >= g.M || nbase >= g.N) continue;
+            float4 v = *reinterpret_cast<const float4*>(&et[row * EPI_LD + c4]);
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            const float bb[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+            float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f}, o2[4] = {0.f, 0.f, 0.f, 0.f};
+            float cin[4] = {0.f, 0.f, 0.f, 0.f};
+            const int epi = g.epi;
+            const bool need_a1 = epi == PSN_EPI_MUL_AUX || epi == PSN_EPI_MUL_POS || epi >= PSN_EPI_MUL2;
+            const bool need_a2 = epi == PSN_EPI_MUL2 || epi == PSN_EPI_SOFTPLUS_BWD;
+            const bool has_o2 = (epi == PSN_EPI_BIAS_SOFTPLUS && g.aux_out != nullptr) || epi == PSN_EPI_MUL2 ||
+                                epi == PSN_EPI_MUL_AUX_RAW;
+            float* cp = Cbase + m * g.ldc + nbase;
+            if (need_a1) {
+                const float* ap = g.aux_in + m * g.ld_aux_in + nbase;
+                if (full4 && g.auxin_vec) { float4 t = *reinterpret_cast<const float4*>(ap); a1[0] = t.x; a1[1] = t.y; a1[2] = t.z; a1[3] = t.w; }
+                else { for (int e = 0; e < 4; ++e) if (nbase + e < g.N) a1[e] = ap[e]; }
+            }
+            if (need_a2) {
+                const float* ap = g.aux_in2 + m * g.ld_aux_in2 + nbase;
+                if (full4 && g.auxin2_vec) { float4 t = *reinterpret_cast<const float4*>(ap); a2[0] = t.x; a2[1] = t.y; a2[2] = t.z; a2[3] = t.w; }
+                else { for (int e = 0; e < 4; ++e) if (nbase + e < g.N) a2[e] = ap[e]; }
+            }
+            if (epi == PSN_EPI_ACCUM) {
+                if (full4 && g.c_vec) { float4 t = *reinterpret_cast<const float4*>(cp); cin[0] = t.x; cin[1] = t.y; cin[2] = t.z; cin[3] = t.w; }
+                else { for (int e = 0; e < 4; ++e) if (nbase + e < g.N) cin[e] = cp[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = vv[e];
+                switch (epi) {
+                    case PSN_EPI_NONE: break;
+                    case PSN_EPI_BIAS: x = x + bb[e]; break;
+                    case PSN_EPI_BIAS_RELU: x = fmaxf(x + bb[e], 0.0f); break;
+                    case PSN_EPI_BIAS_SOFTPLUS: { float sp, sg; softplus100_sig(x + bb[e], sp, sg); x = sp; o2[e] = sg; break; }
+                    case PSN_EPI_MUL_AUX: x = x * a1[e]; break;
+                    case PSN_EPI_MUL_POS: x = a1[e] > 0.0f ? x : 0.0f; break;
+                    case PSN_EPI_BIAS_SIGMOID: x = sigmoidf_(x + bb[e]); break;
+                    case PSN_EPI_ACCUM: x = cin[e] + x; break;
+                    case PSN_EPI_MUL2: o2[e] = x * a2[e]; x = x * a1[e]; break;
+                    case PSN_EPI_SOFTPLUS_BWD: x = a1[e] * (x + 100.0f * a2[e] * (1.0f - a1[e])); break;
+                    case PSN_EPI_MUL_AUX_RAW: o2[e] = x; x = x * a1[e]; break;
                     default: break;
                 }
+                vv[e] = x;
+            }
+            if (full4 && g.c_vec) *reinterpret_cast<float4*>(cp) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            else { for (int e = 0; e < 4; ++e) if (nbase + e < g.N) cp[e] = vv[e]; }
+            if (has_o2) {
+                float* op = g.aux_out + m * g.ld_aux_out + nbase;
+                if (full4 && g.auxout_vec) *reinterpret_cast<float4*>(op) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                else { for (int e = 0; e < 4; ++e) if (nbase + e < g.N) op[e] = o2[e]; }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -277,6 +319,9 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
     PSN_CHECK_ARG(g.n_tiles < (1ll << 31), "gemm: too many tiles");
     g.a_vec = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0);
     g.b_vec = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
+    g.auxin_vec = aux_in && (((uintptr_t)aux_in & 15) == 0) && (ld_aux_in % 4 == 0);
+    g.auxin2_vec = aux_in2 && (((uintptr_t)aux_in2 & 15) == 0) && (ld_aux_in2 % 4 == 0);
+    g.auxout_vec = aux_out && (((uintptr_t)aux_out & 15) == 0) && (ld_aux_out % 4 == 0);
     int kc = (K + split_k - 1) / split_k;
     kc = ((kc + BK - 1) / BK) * BK;
     split_k = (K + kc - 1) / kc;
@@ -288,6 +333,7 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
         g.split_stride = M * (int64_t)N;
         g.epi = PSN_EPI_NONE;
     }
+    g.c_vec = (((uintptr_t)g.C & 15) == 0) && (g.ldc % 4 == 0) && (g.split_stride % 4 == 0);
     dim3 grid((unsigned)g.n_tiles, 1, (unsigned)split_k), block(256);
     if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, g);
     else if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, g);
@@ -311,8 +357,8 @@ extern "C" int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* 
     PSN_CHECK_ARG(X && out && workspace, "colsum: null pointer");
     PSN_CHECK_ARG(N > 0 && M >= 0, "colsum: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    int nblocks = (int)((M + 255) / 256);
-    if (nblocks > 256) nblocks = 256;
+    int nblocks = (int)((M + 127) / 128);
+    if (nblocks > 2048) nblocks = 2048;
     if (nblocks < 1) nblocks = 1;
     int64_t rpb = (M + nblocks - 1) / nblocks;
     if (rpb < 1) rpb = 1;

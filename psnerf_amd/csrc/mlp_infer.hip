@@ -114,73 +114,95 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_kernel(InferArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) act[mt][r] = 0.f;
 
+    // Hidden layers (8 output tiles) run in this loop; the final layer (1 output tile) is peeled off
+    // below so that the accumulators never meet a control-flow merge between differently shaped code
+    // paths (which makes hipcc shuttle all 128 accumulator registers between VGPRs and AGPRs per stage).
     int gstage = 0;  // global stage counter -> LDS buffer parity
-    for (int li = 0; li < n_layers; ++li) {
-        const PsnMlpLayer L = g.d.layers[li];
-        const int n_st = L.n_kt_in + L.n_kt_act;
-        const int stage_floats = L.n_mt * 1024;
-        const float* wl_g = g.w + L.w_off;
-        // bias -> accumulator init
-        {
-            const float* bp = g.b + L.b_off;
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
-                if (mt < L.n_mt) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float4 bv = *reinterpret_cast<const float4*>(bp + mt * 32 + 8 * q + 4 * lh);
-                        acc[mt][4 * q + 0] = bv.x;
-                        acc[mt][4 * q + 1] = bv.y;
-                        acc[mt][4 * q + 2] = bv.z;
-                        acc[mt][4 * q + 3] = bv.w;
-                    }
-                }
-            }
-        }
-        // stage s of this layer; the data for (li, s) was requested one stage earlier
-#define PSN_STAGE(BSRC, S_IDX)                                                                              \
+
+#define PSN_STAGE(NMT, BSRC, S_IDX)                                                                         \
     {                                                                                                       \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's LDS-DMA pieces have landed */        \
         __syncthreads(); /* every wave's pieces landed; the other buffer is no longer being read */         \
         const int s_ = (S_IDX);                                                                             \
         float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
         if (s_ + 1 < n_st) {                                                                                \
-            stage_load(wl_g + (int64_t)(s_ + 1) * stage_floats, nxt, 4 * L.n_mt, wave, lane);               \
+            stage_load(wl_g + (int64_t)(s_ + 1) * stage_floats, nxt, 4 * (NMT), wave, lane);                \
         } else if (li + 1 < n_layers) {                                                                     \
             const PsnMlpLayer& Ln = g.d.layers[li + 1];                                                     \
             stage_load(g.w + Ln.w_off, nxt, 4 * Ln.n_mt, wave, lane);                                       \
         }                                                                                                   \
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);             \
-        if (L.n_mt == 8) stage_compute<8>(acc, BSRC, wl, lane);                                             \
-        else stage_compute<1>(acc, BSRC, wl, lane);                                                         \
+        stage_compute<NMT>(acc, BSRC, wl, lane);                                                            \
         ++gstage;                                                                                           \
     }
-        // K tiles from the input features first, then from the previous activations (matches the packer)
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            if (kt < L.n_kt_in) PSN_STAGE(xin[kt], kt)
-        }
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            if (kt < L.n_kt_act) PSN_STAGE(act[kt], L.n_kt_in + kt)
-        }
-#undef PSN_STAGE
-        // activation: accumulators become the next layer's B operands
-        if (li + 1 < n_layers) {
+
+    int li = 0;
+    for (; li < n_layers - 1; ++li) {
+        const PsnMlpLayer L = g.d.layers[li];
+        const int n_st = L.n_kt_in + L.n_kt_act;
+        const int stage_floats = 8 * 1024;
+        const float* wl_g = g.w + L.w_off;
+        {  // bias -> accumulator init
+            const float* bp = g.b + L.b_off;
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float z = acc[mt][r];
-                    float a;
-                    if (L.act == PSN_ACT_RELU) a = fmaxf(z, 0.0f);
-                    else if (L.act == PSN_ACT_SOFTPLUS100) a = softplus100(z);
-                    else a = z;
-                    act[mt][r] = a;
+                for (int q = 0; q < 4; ++q) {
+                    float4 bv = *reinterpret_cast<const float4*>(bp + mt * 32 + 8 * q + 4 * lh);
+                    acc[mt][4 * q + 0] = bv.x;
+                    acc[mt][4 * q + 1] = bv.y;
+                    acc[mt][4 * q + 2] = bv.z;
+                    acc[mt][4 * q + 3] = bv.w;
                 }
             }
         }
+        // K tiles from the input features first, then from the previous activations (matches the packer)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < L.n_kt_in) PSN_STAGE(8, xin[kt], kt)
+        }
+        if (L.n_kt_act > 0) {
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) PSN_STAGE(8, act[kt], L.n_kt_in + kt)
+        }
+        // activation: accumulators become the next layer's B operands
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float z = acc[mt][r];
+                float a;
+                if (L.act == PSN_ACT_RELU) a = fmaxf(z, 0.0f);
+                else if (L.act == PSN_ACT_SOFTPLUS100) a = softplus100(z);
+                else a = z;
+                act[mt][r] = a;
+            }
+        }
     }
+    {   // final layer: one output tile
+        const PsnMlpLayer L = g.d.layers[li];
+        const int n_st = L.n_kt_in + L.n_kt_act;
+        const int stage_floats = 1024;
+        const float* wl_g = g.w + L.w_off;
+        const float* bp = g.b + L.b_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 bv = *reinterpret_cast<const float4*>(bp + 8 * q + 4 * lh);
+            acc[0][4 * q + 0] = bv.x;
+            acc[0][4 * q + 1] = bv.y;
+            acc[0][4 * q + 2] = bv.z;
+            acc[0][4 * q + 3] = bv.w;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < L.n_kt_in) PSN_STAGE(1, xin[kt], kt)
+        }
+        if (L.n_kt_act > 0) {
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) PSN_STAGE(1, act[kt], L.n_kt_in + kt)
+        }
+    }
+#undef PSN_STAGE
 
     // ---- output: final layer has one m-tile; feature f = (r&3) + 8*(r>>2) + 4*h ------------------
     if (row < g.n_rows) {

@@ -203,7 +203,7 @@ def colsum(X, out=None, accumulate=False):
     M, N = X.shape
     if out is None:
         out = torch.empty(N, device=X.device, dtype=torch.float32)
-    ws = workspace(256 * N, X.device)
+    ws = workspace(2048 * N, X.device)
     _check(_lib.psn_colsum(_mat_ptr(X, 'X'), M, N, _ld(X), _ptr(out, 'out'), int(accumulate), ws.data_ptr(),
                            _stream()), 'colsum')
     return out
