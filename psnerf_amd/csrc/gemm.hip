@@ -34,6 +34,7 @@ struct GemmArgs {
     int k_chunk;  // K range per blockIdx.z (multiple of BK)
     int tiles_n;
     int64_t n_tiles;  // tiles_m * tiles_n
+    int split_k;
     int a_vec, b_vec;  // 16-byte vector loads allowed
     int c_vec, auxin_vec, auxin2_vec, auxout_vec;  // 16-byte vector epilogue accesses allowed
     int64_t split_stride;  // floats between split-K partial outputs (0 when split_k == 1)
@@ -111,16 +112,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each XCD a contiguous run of
-    // tile ids so the n-tiles that share an A row-panel hit the same L2 (bijective remap, guide T1).
-    int64_t bid = blockIdx.x, nb = g.n_tiles;
+    // XCD-aware work order.  The dispatcher places block b on XCD b % 8 (per-XCD L2s).  Work items are
+    // numbered split-major / tile-minor and each XCD gets a contiguous run of them, so the tiles that share
+    // an operand panel -- the n-tiles of one A row-panel, or all output tiles of one split-K slice (which
+    // stream the same K-chunk of both operands) -- run on the same L2 at about the same time.  Bijective
+    // remap (guide T1) over the 1-D grid of n_tiles * split_k blocks.
+    const int64_t nb = g.n_tiles * (int64_t)g.split_k;
+    int64_t bid = blockIdx.x;
     int64_t q = nb / 8, r8 = nb % 8, xcd = bid % 8, idx = bid / 8;
-    int64_t t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    int64_t w = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    const int split = (int)(w / g.n_tiles);
+    const int64_t t = w % g.n_tiles;
     const int64_t tm = t / g.tiles_n;
     const int tn = (int)(t % g.tiles_n);
     const int64_t m0 = tm * BM;
     const int n0 = tn * BN;
-    const int k_begin = blockIdx.z * g.k_chunk;
+    const int k_begin = split * g.k_chunk;
     const int k_end = min(g.K, k_begin + g.k_chunk);
 
     floatx16 acc[2][2];
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // Each wave transposes one 32 x 64 half of its tile through a private LDS tile and then walks it in
     // float4 row segments (16 lanes = one 256 B row piece): coalesced 16-byte loads/stores for C and the
     // aux operands, and a small rolled loop so the fused epilogue math does not inflate register use.
-    float* Cbase = g.C + (int64_t)blockIdx.z * g.split_stride;
+    float* Cbase = g.C + (int64_t)split * g.split_stride;
     float* et = lds_raw + wave * (32 * EPI_LD);
     const int c4 = (lane & 15) * 4;          // column (within the wave's 64) of this lane's float4
     const int nbase = n0 + wc * 64 + c4;
@@ -279,11 +286,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int N,
                                                            int accumulate, float* __restrict__ out) {
-    int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[4];
+    const int n = blockIdx.x;
     float s = 0.0f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * N + n];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        out[n] = accumulate ? out[n] + tot : tot;
+    }
 }
 
 }  // namespace psn
@@ -334,7 +348,9 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
         g.epi = PSN_EPI_NONE;
     }
     g.c_vec = (((uintptr_t)g.C & 15) == 0) && (g.ldc % 4 == 0) && (g.split_stride % 4 == 0);
-    dim3 grid((unsigned)g.n_tiles, 1, (unsigned)split_k), block(256);
+    g.split_k = split_k;
+    PSN_CHECK_ARG(g.n_tiles * split_k < (1ll << 31), "gemm: too many blocks");
+    dim3 grid((unsigned)(g.n_tiles * split_k)), block(256);
     if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, g);
     else if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, g);
     else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, st, g);
@@ -364,7 +380,7 @@ extern "C" int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* 
     if (rpb < 1) rpb = 1;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, st, X, M, N, ldx, rpb, workspace);
     PSN_CHECK_LAUNCH("colsum partial");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, nblocks, N,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(N), dim3(256), 0, st, workspace, nblocks, N,
                        accumulate, out);
     PSN_CHECK_LAUNCH("colsum final");
     return PSN_OK;

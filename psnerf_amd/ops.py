@@ -9,9 +9,12 @@ import torch
 from . import fused, hip
 
 
-def _split_k_for(rows):
-    # enough k-slices to fill 256 CUs when the output is a single 256x256 (4-tile) weight gradient
-    return int(max(1, min(256, rows // 1024)))
+def _split_k_for(rows, out_rows=256, out_cols=256):
+    """Split-K factor for a weight-gradient GEMM [out_rows, rows] x [rows, out_cols]: enough K slices that
+    (output tiles x slices) fills the 256 CUs a few times over, but at least 256 rows per slice."""
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    want = max(1, 1024 // tiles)
+    return int(max(1, min(want, rows // 256)))
 
 
 # --------------------------------------------------------------------------- positional encoding
@@ -128,14 +131,14 @@ class ReluMLP(torch.autograd.Function):
         if ctx.final_sigmoid:
             g = g * out * (1.0 - out)
         Q = g.shape[0]
-        sk = _split_k_for(Q)
         grads = [None] * (2 * n)
         dx = torch.zeros(Q, kp, device=g.device) if ctx.x_needs else None
         needs = ctx.needs_input_grad[4:]
         for li in range(n - 1, -1, -1):
             inp, Wp = ins[li], Wps[li]
             if needs[2 * li]:
-                dWp = hip.gemm(g, inp, trans_a=True, trans_b=False, split_k=sk)
+                dWp = hip.gemm(g, inp, trans_a=True, trans_b=False,
+                               split_k=_split_k_for(Q, g.shape[1], inp.shape[1]))
                 if li == 0:
                     grads[0] = dWp[:, in_cols] if in_cols is not None else dWp
                 elif li - 1 == ctx.skip_at:
@@ -338,13 +341,13 @@ class GeoField(torch.autograd.Function):
         S = sv[2 + 2 * n:2 + 3 * n - 1]
         Q = p.shape[0]
         dev = p.device
-        sk = _split_k_for(Q)
         dW = [None] * n
         db = [None] * n
         sweep = ctx.with_grad and d_grad is not None
         dS = [None] * (n - 1)
 
         def add_dW(l, a_t, b_mat):  # dW[l] (+)= a_t^T @ b_mat
+            sk = _split_k_for(Q, a_t.shape[1], b_mat.shape[1])
             if dW[l] is None:
                 dW[l] = hip.gemm(a_t, b_mat, trans_a=True, split_k=sk)
             else:
