@@ -121,6 +121,8 @@ typedef struct {
     int act;       /* PSN_ACT_* applied to this layer's output */
     int64_t w_off; /* float offset of this layer's packed weights */
     int64_t b_off; /* float offset of this layer's bias (n_mt*32 floats, zero padded) */
+    int64_t init_off; /* >= 0: the accumulator additionally starts from init_a[ia, init_off + f] + init_b[ib, init_off + f]
+                         (per-row precomputed partial products of this layer's input-feature block); -1: unused */
 } PsnMlpLayer;
 
 typedef struct {
@@ -129,6 +131,7 @@ typedef struct {
     int out_act;  /* PSN_OUT_* */
     int in_kt_a;  /* K tiles (of 32 floats) per row of feature table A (1..4) */
     int in_kt_b;  /* K tiles per row of table B (0 = unused); in_kt_a + in_kt_b <= 4 */
+    int init_stride; /* floats per row of the init tables (multiple of 256), 0 if no layer uses init_off */
     PsnMlpLayer layers[PSN_MLP_MAX_LAYERS];
 } PsnMlpDesc;
 
@@ -138,10 +141,14 @@ int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_tiles, float
 
 /* Row q of the virtual input matrix is [ A[(q / a_div) % a_mod, :] | B[(q / b_div) % b_mod, :] ];
  * tables are row-major with strides in_kt_a*32 / in_kt_b*32 floats, 16-byte aligned.
+ * Because a layer that reads the input block is linear in it, W_in [A_row | B_row] = W_a A_row + W_b B_row
+ * can be precomputed once per table row instead of once per (A,B) pair: init_a / init_b
+ * ([rows, init_stride], indexed like tab_a / tab_b; init_b may be NULL) hold those partial products and the
+ * layers with init_off >= 0 start their accumulators from them (tab_a may then be NULL if no layer has n_kt_in > 0).
  * out [n_rows, n_out]. */
 int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                   int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
-                  int64_t n_rows, float* out, void* stream);
+                  const float* init_a, const float* init_b, int64_t n_rows, float* out, void* stream);
 
 #ifdef __cplusplus
 }

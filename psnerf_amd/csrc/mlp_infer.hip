@@ -6,17 +6,21 @@
 //                                           :394-399 light_visibility; network.py:124-125)
 //
 // Formulation: per layer OUT^T[features, points] = W[features, K] * ACT^T[K, points] on
-// v_mfma_f32_32x32x2_f32.  One wave owns 32 points (the MFMA N dimension = lane & 31); a lane holds
-// 128 of the 256 features of its point in registers, in exactly the MFMA C/D layout
-//     feature(mt, r, h) = 32*mt + (r & 3) + 8*(r >> 2) + 4*h,    h = lane >> 5.
+// v_mfma_f32_16x16x4_f32.  One wave owns 16 points (the MFMA N dimension = lane & 15); a lane holds 64 of
+// the 256 features of its point in registers, in exactly the MFMA C/D layout
+//     feature(mt, r, g) = 16*mt + 4*g + r,    g = lane >> 4,  r = 0..3,  mt = 0..15.
 // Because K may be visited in any order as long as A and B agree, the D registers of layer l are fed
-// straight back as the B operand of layer l+1 (k-step (kt, r) consumes register act[kt][r], whose two
-// lane halves hold features 32kt+(r&3)+8(r>>2)+{0,4}); the weights are pre-packed to match
-// (psn_mlp_pack_layer), so there is no transpose, no LDS round trip and no HBM traffic for
-// activations.  Weights (L2-resident, <= 2.6 MB) stream through LDS in 32 KB stages by LDS-DMA
-// (global_load_lds_dwordx4), double buffered, shared by the 4 waves of the workgroup.
+// straight back as the B operand of layer l+1 (k-step (kt, r) consumes register act[kt][r], whose four
+// lane groups hold features 16kt + 4g + r); the weights are pre-packed to match (psn_mlp_pack_layer), so
+// there is no transpose, no LDS round trip and no HBM traffic for activations.
 //
-// Roofline: MFMA-bound.  Per stage and wave: 128 MFMAs (8192 cycles) vs 32 ds_read_b128.
+// Workgroup = 8 waves = 128 points, 2 waves per SIMD (<= 256 VGPRs each): while one wave of a SIMD is parked
+// at the per-stage barrier or issuing its LDS-DMA, the other keeps the matrix pipe busy (the first
+// 32x32x2 / 1-wave-per-SIMD version measured 73 % MFMA-busy with 15 % of wave cycles parked).
+// Weights (L2-resident, <= 2.6 MB) stream through LDS in 32 KB stages (32 input features x 256 outputs)
+// by LDS-DMA (global_load_lds_dwordx4), double buffered, shared by the 8 waves.
+//
+// Roofline: MFMA-bound.  Per stage and wave: 128 MFMAs (4096 cycles) vs 32 ds_read_b128.
 #include "common.h"
 
 namespace psn {
@@ -29,110 +33,113 @@ struct InferArgs {
     int64_t a_div, a_mod;
     const float* tb;
     int64_t b_div, b_mod;
+    const float* init_a;
+    const float* init_b;
     int64_t n_rows;
     float* out;
 };
 
-constexpr int kStageFloats = 8 * 4 * 64 * 4;  // 8 m-tiles x 4 rho x 64 lanes x float4 = 32 KB
+constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
+constexpr int kWaves = 4;  // per workgroup; two workgroups share a CU (2 waves per SIMD, out of phase)
 
-// One k-tile (32 input features = 16 MFMA k-steps) against NMT output tiles.
+// One 32-feature k-tile (two 16-feature register tiles b0, b1 = 8 MFMA k-steps) against NMT output tiles of 16.
 template <int NMT>
-__device__ __forceinline__ void stage_compute(floatx16 (&acc)[8], const floatx16& bsrc, const float4* __restrict__ wl,
-                                              int lane) {
+__device__ __forceinline__ void stage_compute(floatx4 (&acc)[16], const floatx4& b0, const floatx4& b1,
+                                              const float4* __restrict__ wl, int lane) {
 #pragma unroll
-    for (int rho = 0; rho < 4; ++rho) {
-        float4 a[NMT];
+    for (int e = 0; e < 2; ++e) {
+        const floatx4& bs = e ? b1 : b0;
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) a[mt] = wl[(rho * NMT + mt) * 64 + lane];
+        for (int m0 = 0; m0 < NMT; m0 += 8) {
+            constexpr int G = NMT < 8 ? NMT : 8;
+            float4 a[G];
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bsrc[4 * rho + 0], acc[mt], 0, 0, 0);
+            for (int m = 0; m < G; ++m) a[m] = wl[(e * NMT + m0 + m) * 64 + lane];
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bsrc[4 * rho + 1], acc[mt], 0, 0, 0);
+            for (int m = 0; m < G; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, bs[0], acc[m0 + m], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bsrc[4 * rho + 2], acc[mt], 0, 0, 0);
+            for (int m = 0; m < G; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, bs[1], acc[m0 + m], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bsrc[4 * rho + 3], acc[mt], 0, 0, 0);
+            for (int m = 0; m < G; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, bs[2], acc[m0 + m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < G; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, bs[3], acc[m0 + m], 0, 0, 0);
+        }
     }
 }
 
-// LDS-DMA one stage (n_blocks x 1 KB) of packed weights; the 4 waves split the blocks.
+// LDS-DMA one stage (n_blocks x 1 KB) of packed weights; the 8 waves split the blocks.
 __device__ __forceinline__ void stage_load(const float* __restrict__ gsrc, float* lds_dst, int n_blocks, int wave,
                                            int lane) {
-    for (int blk = wave; blk < n_blocks; blk += 4) {
+    for (int blk = wave; blk < n_blocks; blk += kWaves) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + blk * 256 + lane * 4),
                                          (__attribute__((address_space(3))) void*)(lds_dst + blk * 256), 16, 0, 0);
     }
 }
 
-__global__ __launch_bounds__(256, 1) void mlp_infer_kernel(InferArgs g) {
+__global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int lj = lane & 31, lh = lane >> 5;
-    const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + lj;
+    const int lj = lane & 15, lg = lane >> 4;
+    const int64_t row = (int64_t)blockIdx.x * (kWaves * 16) + wave * 16 + lj;
     const int64_t rowc = row < g.n_rows ? row : g.n_rows - 1;
-
-    // ---- schedule bookkeeping: flat list of stages over all layers -------------------------------
     const int n_layers = g.d.n_layers;
-    // prefetch stage 0 of layer 0
-    {
-        const PsnMlpLayer& L0 = g.d.layers[0];
+
+    {  // prefetch the first weight stage (layer 0 may be evaluated entirely through the init tables)
+        const int l0 = (g.d.layers[0].n_kt_in + g.d.layers[0].n_kt_act > 0) ? 0 : 1;
+        const PsnMlpLayer& L0 = g.d.layers[l0];
         stage_load(g.w + L0.w_off, smem, 4 * L0.n_mt, wave, lane);
     }
 
-    // ---- input features -> registers (MFMA B-operand layout) ------------------------------------
-    floatx16 xin[4];
+    // ---- input features -> registers (MFMA B-operand layout): 16-feature tile t, register r = feature 16t+4g+r
+    floatx4 xin[8];
+    const int64_t ia = (rowc / g.a_div) % g.a_mod;
+    const int64_t ib = (rowc / g.b_div) % g.b_mod;
+    const float* init_a_row = g.init_a != nullptr ? g.init_a + ia * (int64_t)g.d.init_stride : nullptr;
+    const float* init_b_row = g.init_b != nullptr ? g.init_b + ib * (int64_t)g.d.init_stride : nullptr;
     {
-        const int64_t ia = (rowc / g.a_div) % g.a_mod;
-        const float* pa = g.ta + ia * (int64_t)(g.d.in_kt_a * 32);
-        const float* pb = nullptr;
-        if (g.d.in_kt_b > 0) {
-            const int64_t ib = (rowc / g.b_div) % g.b_mod;
-            pb = g.tb + ib * (int64_t)(g.d.in_kt_b * 32);
-        }
+        const float* pa = g.ta != nullptr ? g.ta + ia * (int64_t)(g.d.in_kt_a * 32) : nullptr;
+        const float* pb = (g.d.in_kt_b > 0 && g.tb != nullptr) ? g.tb + ib * (int64_t)(g.d.in_kt_b * 32) : nullptr;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int t = 0; t < 8; ++t) {
             const float* src = nullptr;
-            if (kt < g.d.in_kt_a) src = pa + kt * 32;
-            else if (kt < g.d.in_kt_a + g.d.in_kt_b) src = pb + (kt - g.d.in_kt_a) * 32;
-#pragma unroll
-            for (int rho = 0; rho < 4; ++rho) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (src != nullptr) v = *reinterpret_cast<const float4*>(src + 8 * rho + 4 * lh);
-                xin[kt][4 * rho + 0] = v.x;
-                xin[kt][4 * rho + 1] = v.y;
-                xin[kt][4 * rho + 2] = v.z;
-                xin[kt][4 * rho + 3] = v.w;
-            }
+            if (t < 2 * g.d.in_kt_a) src = pa != nullptr ? pa + t * 16 : nullptr;
+            else if (t < 2 * (g.d.in_kt_a + g.d.in_kt_b)) src = pb != nullptr ? pb + (t - 2 * g.d.in_kt_a) * 16 : nullptr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src != nullptr) v = *reinterpret_cast<const float4*>(src + 4 * lg);
+            xin[t][0] = v.x;
+            xin[t][1] = v.y;
+            xin[t][2] = v.z;
+            xin[t][3] = v.w;
         }
     }
 
-    floatx16 act[8];
-    floatx16 acc[8];
+    floatx4 act[16];
+    floatx4 acc[16];
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < 16; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) act[mt][r] = 0.f;
+        for (int r = 0; r < 4; ++r) act[mt][r] = 0.f;
 
-    // Hidden layers (8 output tiles) run in this loop; the final layer (1 output tile) is peeled off
-    // below so that the accumulators never meet a control-flow merge between differently shaped code
-    // paths (which makes hipcc shuttle all 128 accumulator registers between VGPRs and AGPRs per stage).
+    // Hidden layers (16 output tiles) run in the loop; the final layer (2 output tiles) is peeled off below so
+    // that the accumulators never meet a control-flow merge between differently shaped code paths (which
+    // makes hipcc shuttle every accumulator register between VGPRs and AGPRs per stage).
     int gstage = 0;  // global stage counter -> LDS buffer parity
 
-#define PSN_STAGE(NMT, BSRC, S_IDX)                                                                         \
+#define PSN_STAGE(NMT, B0, B1, S_IDX)                                                                       \
     {                                                                                                       \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's LDS-DMA pieces have landed */        \
         __syncthreads(); /* every wave's pieces landed; the other buffer is no longer being read */         \
         const int s_ = (S_IDX);                                                                             \
         float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
         if (s_ + 1 < n_st) {                                                                                \
-            stage_load(wl_g + (int64_t)(s_ + 1) * stage_floats, nxt, 4 * (NMT), wave, lane);                \
+            stage_load(wl_g + (int64_t)(s_ + 1) * stage_floats, nxt, 2 * (NMT), wave, lane);                \
         } else if (li + 1 < n_layers) {                                                                     \
             const PsnMlpLayer& Ln = g.d.layers[li + 1];                                                     \
             stage_load(g.w + Ln.w_off, nxt, 4 * Ln.n_mt, wave, lane);                                       \
         }                                                                                                   \
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);             \
-        stage_compute<NMT>(acc, BSRC, wl, lane);                                                            \
+        stage_compute<NMT>(acc, B0, B1, wl, lane);                                                          \
         ++gstage;                                                                                           \
     }
 
@@ -145,31 +152,50 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_kernel(InferArgs g) {
         {  // bias -> accumulator init
             const float* bp = g.b + L.b_off;
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
+            for (int mt = 0; mt < 16; ++mt) {
+                float4 bv = *reinterpret_cast<const float4*>(bp + mt * 16 + 4 * lg);
+                acc[mt][0] = bv.x;
+                acc[mt][1] = bv.y;
+                acc[mt][2] = bv.z;
+                acc[mt][3] = bv.w;
+            }
+            if (L.init_off >= 0) {  // per-row precomputed partial products of the input-feature block
+                if (init_a_row != nullptr) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 bv = *reinterpret_cast<const float4*>(bp + mt * 32 + 8 * q + 4 * lh);
-                    acc[mt][4 * q + 0] = bv.x;
-                    acc[mt][4 * q + 1] = bv.y;
-                    acc[mt][4 * q + 2] = bv.z;
-                    acc[mt][4 * q + 3] = bv.w;
+                    for (int mt = 0; mt < 16; ++mt) {
+                        float4 u = *reinterpret_cast<const float4*>(init_a_row + L.init_off + mt * 16 + 4 * lg);
+                        acc[mt][0] += u.x;
+                        acc[mt][1] += u.y;
+                        acc[mt][2] += u.z;
+                        acc[mt][3] += u.w;
+                    }
+                }
+                if (init_b_row != nullptr) {
+#pragma unroll
+                    for (int mt = 0; mt < 16; ++mt) {
+                        float4 u = *reinterpret_cast<const float4*>(init_b_row + L.init_off + mt * 16 + 4 * lg);
+                        acc[mt][0] += u.x;
+                        acc[mt][1] += u.y;
+                        acc[mt][2] += u.z;
+                        acc[mt][3] += u.w;
+                    }
                 }
             }
         }
         // K tiles from the input features first, then from the previous activations (matches the packer)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (kt < L.n_kt_in) PSN_STAGE(8, xin[kt], kt)
+            if (kt < L.n_kt_in) PSN_STAGE(16, xin[2 * kt], xin[2 * kt + 1], kt)
         }
         if (L.n_kt_act > 0) {
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) PSN_STAGE(8, act[kt], L.n_kt_in + kt)
+            for (int kt = 0; kt < 8; ++kt) PSN_STAGE(16, act[2 * kt], act[2 * kt + 1], L.n_kt_in + kt)
         }
         // activation: accumulators become the next layer's B operands
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 0; mt < 16; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 4; ++r) {
                 float z = acc[mt][r];
                 float a;
                 if (L.act == PSN_ACT_RELU) a = fmaxf(z, 0.0f);
@@ -179,62 +205,66 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_kernel(InferArgs g) {
             }
         }
     }
-    {   // final layer: one output tile
+    {  // final layer: 32 (padded) outputs = two 16-wide tiles
         const PsnMlpLayer L = g.d.layers[li];
         const int n_st = L.n_kt_in + L.n_kt_act;
         const int stage_floats = 1024;
         const float* wl_g = g.w + L.w_off;
         const float* bp = g.b + L.b_off;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 bv = *reinterpret_cast<const float4*>(bp + 8 * q + 4 * lh);
-            acc[0][4 * q + 0] = bv.x;
-            acc[0][4 * q + 1] = bv.y;
-            acc[0][4 * q + 2] = bv.z;
-            acc[0][4 * q + 3] = bv.w;
+        for (int mt = 0; mt < 2; ++mt) {
+            float4 bv = *reinterpret_cast<const float4*>(bp + mt * 16 + 4 * lg);
+            acc[mt][0] = bv.x;
+            acc[mt][1] = bv.y;
+            acc[mt][2] = bv.z;
+            acc[mt][3] = bv.w;
         }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (kt < L.n_kt_in) PSN_STAGE(1, xin[kt], kt)
+            if (kt < L.n_kt_in) PSN_STAGE(2, xin[2 * kt], xin[2 * kt + 1], kt)
         }
         if (L.n_kt_act > 0) {
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) PSN_STAGE(1, act[kt], L.n_kt_in + kt)
+            for (int kt = 0; kt < 8; ++kt) PSN_STAGE(2, act[2 * kt], act[2 * kt + 1], L.n_kt_in + kt)
         }
     }
 #undef PSN_STAGE
 
-    // ---- output: final layer has one m-tile; feature f = (r&3) + 8*(r>>2) + 4*h ------------------
+    // ---- output: feature f = 16*mt + 4*g + r of the final layer ---------------------------------
     if (row < g.n_rows) {
         const int n_out = g.d.n_out;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (f < n_out) {
-                float v = acc[0][r];
-                if (g.d.out_act == PSN_OUT_SIGMOID) v = sigmoidf_(v);
-                else if (g.d.out_act == PSN_OUT_OCC) v = sigmoidf_(v * -10.0f);
-                g.out[row * n_out + f] = v;
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * mt + 4 * lg + r;
+                if (f < n_out) {
+                    float v = acc[mt][r];
+                    if (g.d.out_act == PSN_OUT_SIGMOID) v = sigmoidf_(v);
+                    else if (g.d.out_act == PSN_OUT_OCC) v = sigmoidf_(v * -10.0f);
+                    g.out[row * n_out + f] = v;
+                }
             }
         }
     }
 }
 
-// Dense zero-padded W[n_mt*32][k_tiles*32] -> stage order [kt][rho][mt][lane][4]:
-//   lane (i = lane & 31, h = lane >> 5), component c  <-  W[32*mt + i][32*kt + 8*rho + 4*h + c]
+// Dense zero-padded W[n_mt*32][k_tiles*32] -> stage order [kt32][e(2)][mt16][lane][4]:
+//   lane (i = lane & 15, g = lane >> 4), component c  <-  W[16*mt16 + i][32*kt32 + 16*e + 4*g + c]
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__ W, int64_t ldw, int n_mt, int k_tiles,
                                                        float* __restrict__ dst) {
+    const int nmt16 = 2 * n_mt;
     const int64_t total = (int64_t)n_mt * k_tiles * 1024;  // floats
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         int c = (int)(e & 3);
         int lane = (int)((e >> 2) & 63);
         int64_t blk = e >> 8;
-        int mt = (int)(blk % n_mt);
-        int64_t t = blk / n_mt;
-        int rho = (int)(t & 3);
-        int kt = (int)(t >> 2);
-        int i = lane & 31, h = lane >> 5;
-        dst[e] = W[(int64_t)(32 * mt + i) * ldw + 32 * kt + 8 * rho + 4 * h + c];
+        int per_stage = 2 * nmt16;
+        int kt = (int)(blk / per_stage);
+        int bi = (int)(blk % per_stage);
+        int half = bi / nmt16, mt = bi % nmt16;
+        int i = lane & 15, gq = lane >> 4;
+        dst[e] = W[(int64_t)(16 * mt + i) * ldw + 32 * kt + 16 * half + 4 * gq + c];
     }
 }
 
@@ -254,13 +284,20 @@ extern "C" int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_t
 
 extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                              int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
-                             int64_t n_rows, float* out, void* stream) {
+                             const float* init_a, const float* init_b, int64_t n_rows, float* out, void* stream) {
     using namespace psn;
-    PSN_CHECK_ARG(desc && packed_w && packed_b && tab_a && out, "mlp_infer: null pointer");
+    PSN_CHECK_ARG(desc && packed_w && packed_b && out, "mlp_infer: null pointer");
     const PsnMlpDesc& d = *desc;
     PSN_CHECK_ARG(d.n_layers >= 1 && d.n_layers <= PSN_MLP_MAX_LAYERS, "mlp_infer: n_layers=%d", d.n_layers);
-    PSN_CHECK_ARG(d.in_kt_a >= 1 && d.in_kt_b >= 0 && d.in_kt_a + d.in_kt_b <= 4, "mlp_infer: input tiles %d+%d", d.in_kt_a, d.in_kt_b);
-    PSN_CHECK_ARG(d.in_kt_b == 0 || tab_b, "mlp_infer: table B missing");
+    PSN_CHECK_ARG(d.in_kt_a >= 0 && d.in_kt_b >= 0 && d.in_kt_a + d.in_kt_b <= 4, "mlp_infer: input tiles %d+%d", d.in_kt_a, d.in_kt_b);
+    bool uses_in = false, uses_init = false;
+    for (int l = 0; l < d.n_layers; ++l) {
+        uses_in = uses_in || d.layers[l].n_kt_in > 0;
+        uses_init = uses_init || d.layers[l].init_off >= 0;
+    }
+    PSN_CHECK_ARG(!uses_in || (tab_a && d.in_kt_a >= 1 && (d.in_kt_b == 0 || tab_b)), "mlp_infer: input table missing");
+    PSN_CHECK_ARG(!uses_init || (init_a && d.init_stride >= 256 && d.init_stride % 4 == 0), "mlp_infer: init table missing");
+    PSN_CHECK_ARG((((uintptr_t)init_a | (uintptr_t)init_b) & 15) == 0, "mlp_infer: init tables must be 16-byte aligned");
     PSN_CHECK_ARG(d.n_out >= 1 && d.n_out <= 32, "mlp_infer: n_out=%d", d.n_out);
     PSN_CHECK_ARG(a_div >= 1 && a_mod >= 1 && (d.in_kt_b == 0 || (b_div >= 1 && b_mod >= 1)), "mlp_infer: bad index map");
     PSN_CHECK_ARG((((uintptr_t)tab_a | (uintptr_t)tab_b | (uintptr_t)packed_w | (uintptr_t)packed_b) & 15) == 0,
@@ -272,16 +309,19 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         PSN_CHECK_ARG(L.n_kt_in >= 0 && L.n_kt_in <= d.in_kt_a + d.in_kt_b, "mlp_infer: layer %d n_kt_in=%d", l, L.n_kt_in);
         PSN_CHECK_ARG(L.n_kt_act == 0 || L.n_kt_act == 8, "mlp_infer: layer %d n_kt_act=%d", l, L.n_kt_act);
         PSN_CHECK_ARG(l > 0 || L.n_kt_act == 0, "mlp_infer: layer 0 cannot read activations");
-        PSN_CHECK_ARG(L.n_kt_in + L.n_kt_act >= 1, "mlp_infer: layer %d has no input", l);
+        PSN_CHECK_ARG(L.n_kt_in + L.n_kt_act >= 1 || (l == 0 && L.init_off >= 0 && d.n_layers > 1), "mlp_infer: layer %d has no input", l);
+        PSN_CHECK_ARG(L.init_off < 0 || (!last && L.init_off + 256 <= d.init_stride && L.init_off % 4 == 0), "mlp_infer: layer %d bad init_off", l);
         PSN_CHECK_ARG((L.w_off % 4) == 0 && (L.b_off % 4) == 0, "mlp_infer: layer %d offsets must be multiples of 4 floats", l);
     }
     if (n_rows <= 0) return PSN_OK;
     InferArgs a;
     a.d = d; a.w = packed_w; a.b = packed_b; a.ta = tab_a; a.a_div = a_div; a.a_mod = a_mod;
     a.tb = tab_b; a.b_div = b_div > 0 ? b_div : 1; a.b_mod = b_mod > 0 ? b_mod : 1; a.n_rows = n_rows; a.out = out;
-    int64_t blocks = (n_rows + 127) / 128;
+    a.init_a = init_a; a.init_b = init_b;
+    const int rows_per_block = kWaves * 16;
+    int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer: too many rows");
-    hipLaunchKernelGGL(mlp_infer_kernel, dim3((unsigned)blocks), dim3(256), 2 * kStageFloats * sizeof(float),
+    hipLaunchKernelGGL(mlp_infer_kernel, dim3((unsigned)blocks), dim3(kWaves * 64), 2 * kStageFloats * sizeof(float),
                        (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer");
     return PSN_OK;

@@ -1,10 +1,21 @@
 """Host-side packing for the fused 256-wide MLP inference kernel (csrc/mlp_infer.hip).
 
-A network is a list of layers, each reading up to four 32-float tiles of the
-per-row INPUT FEATURES (positional encodings, kept in registers for the whole
-kernel) and/or the 256 activations of the previous layer.  Dense weights are
-re-ordered once per optimiser step into MFMA fragment order by
-``psn_mlp_pack_layer``; this module only assembles the zero-padded dense
+A network is a list of layers, each reading the 256 activations of the previous
+layer and/or the per-row INPUT FEATURES (positional encodings).  The input
+block can be consumed in two ways:
+
+* as MFMA k-tiles (``w_in``): up to four 32-float tiles kept in registers for
+  the whole kernel (used by the stage-1 occupancy net, whose query points are
+  all distinct);
+* as precomputed partial products (``init``): because the layer is linear in
+  its input block, W_in [A_row | B_row] = W_a A_row + W_b B_row is evaluated
+  ONCE per table row by two small GEMMs and the kernel starts the layer's
+  accumulators from U[a] + V[b].  For the stage-2 visibility net the rows are
+  all (surface point, light) pairs, so this removes layer 0 and the input half
+  of the skip layer from the per-pair work (12 % of the MFMAs).
+
+Dense weights are re-ordered once per optimiser step into MFMA fragment order
+by ``psn_mlp_pack_layer``; this module only assembles the zero-padded dense
 matrices with torch ops (tiny tensors) and fills the ``PsnMlpDesc``.
 """
 import math
@@ -15,13 +26,25 @@ from . import hip
 
 
 class PackedMLP(object):
-    def __init__(self, desc, w, b):
+    def __init__(self, desc, w, b, init_wa=None, init_wb=None, init_bias=None):
         self.desc, self.w, self.b = desc, w, b
+        # stacked input-block weights of the layers evaluated through init tables
+        self.init_wa, self.init_wb, self.init_bias = init_wa, init_wb, init_bias
 
     def __call__(self, tab_a, n_rows, a_div=1, a_mod=None, tab_b=None, b_div=1, b_mod=1, out=None):
         if a_mod is None:
             a_mod = tab_a.shape[0]
-        return hip.mlp_infer(self.desc, self.w, self.b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=out)
+        init_a = init_b = None
+        if self.init_wa is not None:
+            # U = A W_a^T (+ bias when there is no B table), V = B W_b^T + bias
+            if self.init_wb is None:
+                init_a = hip.gemm(tab_a, self.init_wa, trans_b=True, bias=self.init_bias, epi=hip.EPI_BIAS)
+            else:
+                init_a = hip.gemm(tab_a, self.init_wa, trans_b=True)
+                init_b = hip.gemm(tab_b, self.init_wb, trans_b=True, bias=self.init_bias, epi=hip.EPI_BIAS)
+        uses_in = any(self.desc.layers[i].n_kt_in > 0 for i in range(self.desc.n_layers))
+        return hip.mlp_infer(self.desc, self.w, self.b, tab_a if uses_in else None, a_div, a_mod,
+                             tab_b if uses_in else None, b_div, b_mod, n_rows, out=out, init_a=init_a, init_b=init_b)
 
 
 def _pad_cols(w, n):
@@ -29,32 +52,47 @@ def _pad_cols(w, n):
 
 
 def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device):
-    """layers: list of dicts {w_in: [o, <=in_kt*32] or None, w_act: [o, <=256] or None, bias: [o], act: ACT_*}.
-    Hidden layers have o <= 256 (zero padded), the final layer o = n_out <= 32."""
+    """layers: list of dicts {w_in | init_a/init_b, w_act, bias, act}.
+    w_in: [o, <=in_kt*32] consumed as MFMA k-tiles; init_a [o, in_kt_a*32] / init_b [o, in_kt_b*32]: the same
+    block evaluated through precomputed tables instead.  Hidden layers have o <= 256 (zero padded), the final
+    layer o = n_out <= 32."""
     in_cols = (in_kt_a + in_kt_b) * 32
     desc = hip.PsnMlpDesc()
     desc.n_layers = len(layers)
     desc.n_out, desc.out_act, desc.in_kt_a, desc.in_kt_b = n_out, out_act, in_kt_a, in_kt_b
     assert len(layers) <= hip.MAX_LAYERS
     w_sizes, dense, biases = [], [], []
+    init_wa, init_wb, init_bias = [], [], []
     for li, L in enumerate(layers):
         last = li == len(layers) - 1
         n_mt = 1 if last else 8
         rows = n_mt * 32
         parts = []
         n_kt_in = n_kt_act = 0
+        lay = desc.layers[li]
+        lay.init_off = -1
+        bias = torch.nn.functional.pad(L['bias'].float(), (0, rows - L['bias'].shape[0]))
+        if L.get('init_a') is not None:
+            assert not last
+            lay.init_off = 256 * len(init_wa)
+            init_wa.append(torch.nn.functional.pad(_pad_cols(L['init_a'], in_kt_a * 32), (0, 0, 0, 256 - L['init_a'].shape[0])))
+            if L.get('init_b') is not None:
+                init_wb.append(torch.nn.functional.pad(_pad_cols(L['init_b'], in_kt_b * 32), (0, 0, 0, 256 - L['init_b'].shape[0])))
+            init_bias.append(bias)  # folded into the init table
+            bias = torch.zeros_like(bias)
         if L.get('w_in') is not None:
             parts.append(_pad_cols(L['w_in'], in_cols))
             n_kt_in = in_kt_a + in_kt_b
         if L.get('w_act') is not None:
             parts.append(_pad_cols(L['w_act'], 256))
             n_kt_act = 8
-        W = torch.cat(parts, dim=1)
-        W = torch.nn.functional.pad(W, (0, 0, 0, rows - W.shape[0])).contiguous().float()
-        b = torch.nn.functional.pad(L['bias'].float(), (0, rows - L['bias'].shape[0]))
+        if parts:
+            W = torch.cat(parts, dim=1)
+            W = torch.nn.functional.pad(W, (0, 0, 0, rows - W.shape[0])).contiguous().float()
+        else:
+            W = torch.zeros(0, device=device)  # layer fully evaluated through the init tables: no weight stages
         dense.append((W, n_mt, n_kt_in + n_kt_act))
-        biases.append(b)
-        lay = desc.layers[li]
+        biases.append(bias)
         lay.n_kt_in, lay.n_kt_act, lay.n_mt, lay.act = n_kt_in, n_kt_act, n_mt, L['act']
         w_sizes.append(W.numel())
     w_buf = torch.empty(sum(w_sizes), device=device, dtype=torch.float32)
@@ -63,16 +101,23 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device):
     for li, (W, n_mt, k_tiles) in enumerate(dense):
         desc.layers[li].w_off = off
         desc.layers[li].b_off = b_off
-        hip.mlp_pack_layer(W, n_mt, k_tiles, w_buf[off:off + W.numel()])
+        if k_tiles > 0:
+            hip.mlp_pack_layer(W, n_mt, k_tiles, w_buf[off:off + W.numel()])
         off += W.numel()
         b_off += n_mt * 32
+    desc.init_stride = 256 * len(init_wa)
+    if init_wa:
+        return PackedMLP(desc, w_buf, b_buf, torch.cat(init_wa).contiguous().float(),
+                         torch.cat(init_wb).contiguous().float() if init_wb else None,
+                         torch.cat(init_bias).contiguous())
     return PackedMLP(desc, w_buf, b_buf)
 
 
-def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE):
+def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, precompute=True):
     """stage2 Network / Normal_Network (stage2/model/renderer.py:17-49) of width 256: ReLU stack, the
     input is concatenated AFTER layer ``skip_at``.  Input row = [table A (din_a real cols, padded to
-    a multiple of 32) | table B (din_b)]."""
+    a multiple of 32) | table B (din_b)].  precompute=True evaluates the input block of layer 0 and of the
+    skip layer through per-row init tables (see module docstring)."""
     ka = (din_a + 31) // 32
     kb = (din_b + 31) // 32 if din_b > 0 else 0
 
@@ -82,17 +127,22 @@ def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE):
             return wa
         return torch.cat([wa, _pad_cols(w[:, din_a:din_a + din_b], kb * 32)], dim=1)
 
+    def in_block(W):
+        if precompute:
+            return dict(init_a=W[:, :din_a], init_b=W[:, din_a:din_a + din_b] if kb else None)
+        return dict(w_in=split_in(W))
+
     layers = []
     n = len(weights)
     for li in range(n):
         W, b = weights[li].detach(), biases[li].detach()
         act = hip.ACT_RELU if li < n - 1 else hip.ACT_NONE
         if li == 0:
-            layers.append(dict(w_in=split_in(W), w_act=None, bias=b, act=act))
+            layers.append(dict(w_act=None, bias=b, act=act, **in_block(W)))
         elif li - 1 == skip_at:  # input of this layer is cat[y(256), x]
-            layers.append(dict(w_in=split_in(W[:, 256:]), w_act=W[:, :256], bias=b, act=act))
+            layers.append(dict(w_act=W[:, :256], bias=b, act=act, **in_block(W[:, 256:])))
         else:
-            layers.append(dict(w_in=None, w_act=W, bias=b, act=act))
+            layers.append(dict(w_act=W, bias=b, act=act))
     assert all(L['bias'].shape[0] == 256 for L in layers[:-1]), 'fused path needs 256-wide hidden layers'
     return pack_layers(layers, ka, kb, weights[-1].shape[0], out_act, weights[0].device)
 
@@ -100,7 +150,8 @@ def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE):
 def pack_geo_occupancy(weights, biases, skips, d_pe):
     """stage1 occupancy-only network (stage1/model/network.py:85-95,124-125): softplus(beta=100)
     stack, before layer l in ``skips`` the input becomes cat[x, pe]/sqrt(2); only output row 0 of the
-    last layer is evaluated, followed by sigmoid(-10 x)."""
+    last layer is evaluated, followed by sigmoid(-10 x).  Every query point is distinct, so the input
+    block stays on the MFMA k-tile path."""
     ka = (d_pe + 31) // 32
     layers = []
     n = len(weights)

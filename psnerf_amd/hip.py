@@ -31,12 +31,13 @@ OUT_NONE, OUT_SIGMOID, OUT_OCC = range(3)
 
 
 class PsnMlpLayer(ctypes.Structure):
-    _fields_ = [('n_kt_in', i32), ('n_kt_act', i32), ('n_mt', i32), ('act', i32), ('w_off', i64), ('b_off', i64)]
+    _fields_ = [('n_kt_in', i32), ('n_kt_act', i32), ('n_mt', i32), ('act', i32), ('w_off', i64), ('b_off', i64),
+                ('init_off', i64)]
 
 
 class PsnMlpDesc(ctypes.Structure):
     _fields_ = [('n_layers', i32), ('n_out', i32), ('out_act', i32), ('in_kt_a', i32), ('in_kt_b', i32),
-                ('layers', PsnMlpLayer * MAX_LAYERS)]
+                ('init_stride', i32), ('layers', PsnMlpLayer * MAX_LAYERS)]
 
 
 # every exported symbol of include/psnerf_hip.h with its signature
@@ -52,7 +53,7 @@ SIGNATURES = {
                        i32, c_f, c_f]),
     'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, c_f, c_f]),
-    'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, i64, c_f, c_f]),
+    'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f, i64, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library out of date: fail loudly
@@ -218,7 +219,8 @@ def mlp_pack_layer(W_dense, n_mt, k_tiles, dst):
            'mlp_pack_layer')
 
 
-def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None):
+def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
+              init_b=None):
     if out is None:
         out = torch.empty(n_rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
     prof = PROFILE_EVENTS
@@ -226,7 +228,8 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
-                              _ptr(tab_a, 'tab_a'), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod, n_rows,
+                              _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,
+                              _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), n_rows,
                               _ptr(out, 'out'), _stream()), 'mlp_infer')
     if prof is not None:
         e1.record()

@@ -31,8 +31,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from psnerf_amd import hip
-    assert ctypes.sizeof(hip.PsnMlpLayer) == 32
-    assert ctypes.sizeof(hip.PsnMlpDesc) == 24 + 12 * 32
+    assert ctypes.sizeof(hip.PsnMlpLayer) == 40
+    assert ctypes.sizeof(hip.PsnMlpDesc) == 24 + 12 * 40
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only check')

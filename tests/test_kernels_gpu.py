@@ -163,7 +163,11 @@ def test_fused_visibility_mlp(cuda):
     tb = hip.pe_encode(l.to(cuda), 10, 64)
     out = packed(ta, L * Ns, a_div=1, a_mod=Ns, tab_b=tb, b_div=Ns, b_mod=L)
     assert out.shape == (L * Ns, 1)
-    assert_close(out.cpu(), ref, 1e-4, 'visibility net')
+    assert_close(out.cpu(), ref, 1e-4, 'visibility net (input block through init tables)')
+    packed2 = fused.pack_relu_mlp([m.weight.to(cuda) for m in vn.linears], [m.bias.to(cuda) for m in vn.linears],
+                                  63, 63, skip_at=4, precompute=False)
+    out2 = packed2(ta, L * Ns, a_div=1, a_mod=Ns, tab_b=tb, b_div=Ns, b_mod=L)
+    assert_close(out2.cpu(), ref, 1e-4, 'visibility net (input block as MFMA k-tiles)')
 
 
 def test_fused_geo_occupancy(cuda):
