@@ -150,6 +150,28 @@ int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* pa
                   int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                   const float* init_a, const float* init_b, int64_t n_rows, float* out, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n:
+ * stage2/model/sgbasis.py:16-32 + stage2/model/renderer.py:174-204
+ *   h = normalize(l + v); D_k = exp(max(lobe_k,0) (h.n - 1)); spec_c = max(sum_k w_{c,k} D_k, 0)
+ *   rgb = clamp((albedo + spec) * I_l * (l.n) * clamp(vis,0,1), 0, 1)
+ * light_dir [L,3]; view/normal/albedo [Ns,3]; weights [Ns, 3*nb] (specular_rgb, channel-major as
+ * sgbasis.py:27 view(-1,3,nb)) or [Ns, nb]; lobe [nb<=9]; light_int [L] or NULL (then light_int_scalar);
+ * vis [L*Ns] or NULL.  rgb [L*Ns,3]; spec [L*Ns,3] (specular_rgb) or [L*Ns].
+ * Backward: g_rgb [L*Ns,3], g_spec like spec or NULL -> d_albedo [Ns,3], d_weights like weights,
+ * d_normal [Ns,3], d_vis [L*Ns] or NULL, d_light_dir [L,3], d_light_int [L] or NULL;
+ * workspace >= ceil(Ns/256)*L*4 floats.
+ * ---------------------------------------------------------------------- */
+int psn_sg_shade_fwd(const float* light_dir, const float* view, const float* normal, const float* albedo,
+                     const float* weights, const float* lobe, const float* light_int, float light_int_scalar,
+                     const float* vis, int L, int64_t Ns, int nb, int specular_rgb, float* rgb, float* spec,
+                     void* stream);
+int psn_sg_shade_bwd(const float* light_dir, const float* view, const float* normal, const float* albedo,
+                     const float* weights, const float* lobe, const float* light_int, float light_int_scalar,
+                     const float* vis, int L, int64_t Ns, int nb, int specular_rgb, const float* g_rgb,
+                     const float* g_spec, float* d_albedo, float* d_weights, float* d_normal, float* d_vis,
+                     float* d_light_dir, float* d_light_int, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,9 @@ SIGNATURES = {
                        i32, c_f, c_f]),
     'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, c_f, c_f]),
+    'psn_sg_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f]),
+    'psn_sg_shade_bwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f, c_f,
+                               c_f, c_f, c_f, c_f, c_f, c_f]),
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f, i64, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
@@ -235,3 +238,37 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
         e1.record()
         prof.append(('mlp_infer', n_rows, e0, e1))
     return out
+
+
+# --------------------------------------------------------------------------- SG shading
+def sg_shade_fwd(light_dir, view, normal, albedo, weights, lobe, light_int, light_int_scalar, vis, specular_rgb):
+    L, Ns, nb = light_dir.shape[0], view.shape[0], lobe.shape[0]
+    rgb = torch.empty(L * Ns, 3, device=view.device, dtype=torch.float32)
+    spec = torch.empty(L * Ns, 3 if specular_rgb else 1, device=view.device, dtype=torch.float32)
+    _check(_lib.psn_sg_shade_fwd(_ptr(light_dir, 'light_dir'), _ptr(view, 'view'), _ptr(normal, 'normal'),
+                                 _ptr(albedo, 'albedo'), _ptr(weights, 'weights'), _ptr(lobe, 'lobe'),
+                                 _ptr(light_int, 'light_int', True), float(light_int_scalar), _ptr(vis, 'vis', True),
+                                 L, Ns, nb, int(bool(specular_rgb)), _ptr(rgb, 'rgb'), _ptr(spec, 'spec'), _stream()),
+           'sg_shade_fwd')
+    return rgb, spec
+
+
+def sg_shade_bwd(light_dir, view, normal, albedo, weights, lobe, light_int, light_int_scalar, vis, specular_rgb,
+                 g_rgb, g_spec, want_vis):
+    L, Ns, nb = light_dir.shape[0], view.shape[0], lobe.shape[0]
+    dev = view.device
+    d_albedo = torch.empty(Ns, 3, device=dev)
+    d_weights = torch.empty_like(weights)
+    d_normal = torch.empty(Ns, 3, device=dev)
+    d_vis = torch.empty(L * Ns, device=dev) if want_vis else None
+    d_ldir = torch.empty(L, 3, device=dev)
+    d_lint = torch.empty(L, device=dev) if light_int is not None else None
+    ws = workspace(((Ns + 255) // 256) * L * 4, dev)
+    _check(_lib.psn_sg_shade_bwd(_ptr(light_dir, 'light_dir'), _ptr(view, 'view'), _ptr(normal, 'normal'),
+                                 _ptr(albedo, 'albedo'), _ptr(weights, 'weights'), _ptr(lobe, 'lobe'),
+                                 _ptr(light_int, 'light_int', True), float(light_int_scalar), _ptr(vis, 'vis', True),
+                                 L, Ns, nb, int(bool(specular_rgb)), _ptr(g_rgb, 'g_rgb'), _ptr(g_spec, 'g_spec', True),
+                                 _ptr(d_albedo, 'd_albedo'), _ptr(d_weights, 'd_weights'), _ptr(d_normal, 'd_normal'),
+                                 _ptr(d_vis, 'd_vis', True), _ptr(d_ldir, 'd_ldir'), _ptr(d_lint, 'd_lint', True),
+                                 ws.data_ptr(), _stream()), 'sg_shade_bwd')
+    return d_albedo, d_weights, d_normal, d_vis, d_ldir, d_lint

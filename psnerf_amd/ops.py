@@ -205,196 +205,58 @@ class FusedPairMLP(torch.autograd.Function):
 
 # --------------------------------------------------------------------------- SG shading
 def sg_shade(light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb):
-    """Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n.
+    """Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n (csrc/shade.hip).
 
     stage2/model/sgbasis.py:16-32 + stage2/model/renderer.py:174-204:
         h = normalize(l + v);  D_k = exp(lambda_k (h.n - 1));  spec_c = max(sum_k w_{c,k} D_k, 0)
         rgb = clamp((albedo + spec) * I_l * (l.n) * clamp(vis, 0, 1), 0, 1)      (cos is NOT clamped)
     light_dir [L,3], view/normal/albedo [Ns,3], weights [Ns,nbasis], light_int [L,1] tensor or float,
     vis [L*Ns,1] or None.  Returns rgb [L*Ns,3], spec [L*Ns,3 or 1]."""
-    return SGShade.apply(light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb) \
-        if hip_has_sg_shade() else _sg_shade_eager(light_dir, view, normal, albedo, weights, lobe, light_int, vis,
-                                                   specular_rgb)
+    return SGShade.apply(light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb)
 
 
-def hip_has_sg_shade():
-    return hasattr(hip, 'sg_shade_fwd')
-
-
-def _sg_shade_eager(light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb):
-    """Broadcast (no tile) restatement with torch device ops -- bring-up path only, replaced by the
-    fused kernel (SGShade) once libpsnerf_hip exports psn_sg_shade_*."""
-    L, Ns = light_dir.shape[0], view.shape[0]
-    nb = lobe.shape[0]
-    l = light_dir[:, None, :]
-    h = torch.nn.functional.normalize(l + view[None], dim=-1)
-    hn = (h * normal[None]).sum(-1, keepdim=True)
-    D = torch.exp(lobe.clamp(min=0) * (hn - 1))
-    if specular_rgb:
-        spec = (weights.view(1, Ns, 3, nb) * D[:, :, None]).sum(-1).clamp(min=0.0)
-    else:
-        spec = (weights[None] * D).sum(-1, keepdim=True).clamp(min=0.0)
-    brdf = albedo[None] + spec
-    cos = (l * normal[None]).sum(-1, keepdim=True)
-    if torch.is_tensor(light_int) and light_int.shape[0] > 1:
-        li = light_int.view(L, 1, 1)
-    else:
-        li = light_int
-    rgb = brdf * li * cos
-    if vis is not None:
-        rgb = rgb * vis.view(L, Ns, 1).clamp(0, 1)
-    return rgb.clamp(0, 1).reshape(L * Ns, 3), spec.reshape(L * Ns, -1)
-
-
-# --------------------------------------------------------------------------- stage-1 geometry field
-def _buf(rows, cols, device):
-    """[rows, cols] view of a buffer whose row stride is a multiple of 4 floats (16-byte aligned rows)."""
-    pad = (cols + 3) // 4 * 4
-    return torch.empty(rows, pad, device=device, dtype=torch.float32)[:, :cols]
-
-
-class GeoField(torch.autograd.Function):
-    """Occupancy ("geo") MLP of stage1/model/network.py:85-95 together with its spatial gradient
-    (network.py:108-120), in ONE differentiable op:
-
-        out  [Q, F+1] = infer_occ(p)          (logit = out[:, 0], features = out[:, 1:])
-        grad [Q, 3]   = d out[:, 0] / d p     (what autograd.grad(..., create_graph=True) returns)
-
-    The reference obtains ``grad`` by running infer_occ a second time and calling autograd with
-    create_graph=True, so training differentiates through a gradient (double backward through nine
-    weight-normed softplus(beta=100) layers).  Here the reverse sweep that produces ``grad`` is written
-    out as explicit GEMMs (r_l = (r_{l+1} * sigmoid(100 z_l)) W_l), and backward() is the hand-derived
-    adjoint of BOTH passes -- no autograd-of-autograd, and infer_occ runs once instead of twice.
-
-    Inputs: p [Q,3]; n_octaves; scale (= 1/rescale); skips (layers whose input is cat[x, pe]; the
-    1/sqrt(2) is folded into those layers' weights by the caller); with_grad; then W_0, b_0, W_1, ...
-    as EFFECTIVE dense weights (weight-norm is applied by the caller with torch ops on the tiny weight
-    tensors, so autograd maps dW back to weight_g / weight_v).
-    Points are never differentiated on the reference's training path (sample depths are detached,
-    rendering.py:88-101), so no gradient is returned for p."""
+class SGShade(torch.autograd.Function):
+    """Fused SG shading (csrc/shade.hip); backward recomputes the forward and returns gradients for the light
+    directions / intensities, normals, albedo, SG weights and (if it was not detached) the visibility."""
 
     @staticmethod
-    def forward(ctx, p, n_octaves, scale, skips, with_grad, *params):
-        Ws, bs = [w.contiguous() for w in params[0::2]], [b.contiguous() for b in params[1::2]]
-        n = len(Ws)
-        p = p.contiguous()
-        Q = p.shape[0]
-        dev = p.device
-        d_pe = 3 + 6 * n_octaves
-        kp = (d_pe + 3) // 4 * 4
-        H = Ws[1].shape[1]
-        pe = hip.pe_encode(p, n_octaves, kp, scale)
-        W0p = torch.nn.functional.pad(Ws[0], (0, kp - d_pe)).contiguous()
-        A, S = [None] * n, [None] * (n - 1)
-        A[0] = pe
-        for l in range(n - 1):
-            o = Ws[l].shape[0]
-            if (l + 1) in skips:
-                nxt = torch.empty(Q, o + d_pe, device=dev, dtype=torch.float32)
-                dst = nxt[:, :o]
-                nxt[:, o:] = pe[:, :d_pe]
+    def forward(ctx, light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb):
+        li_t, li_s = None, 0.0
+        if torch.is_tensor(light_int):
+            if light_int.numel() > 1:
+                li_t = light_int.reshape(-1).contiguous()
             else:
-                nxt = _buf(Q, o, dev)
-                dst = nxt
-            S[l] = _buf(Q, o, dev)
-            hip.gemm(A[l], W0p if l == 0 else Ws[l], trans_b=True, bias=bs[l], epi=hip.EPI_BIAS_SOFTPLUS, out=dst,
-                     aux_out=S[l])
-            A[l + 1] = nxt
-        out = hip.gemm(A[n - 1], Ws[n - 1], trans_b=True, bias=bs[n - 1], epi=hip.EPI_BIAS)
-        grad = None
-        U, R = [None] * (n - 1), [None] * n
-        if with_grad:
-            w_last = Ws[n - 1][0:1, :]  # d logit / d a_{n-1}, the same row for every point
-            U[n - 2] = S[n - 2] * w_last
-            d_pe_acc = None
-            for l in range(n - 2, 0, -1):
-                in_a = Ws[l].shape[1] - d_pe if l in skips else Ws[l].shape[1]
-                R[l] = _buf(Q, in_a, dev)
-                U[l - 1] = _buf(Q, in_a, dev)
-                hip.gemm(U[l], Ws[l][:, :in_a], epi=hip.EPI_MUL_AUX_RAW, aux_in=S[l - 1], out=U[l - 1], aux_out=R[l])
-                if l in skips:
-                    g_skip = hip.gemm(U[l], Ws[l][:, in_a:])
-                    d_pe_acc = g_skip if d_pe_acc is None else d_pe_acc + g_skip
-            d_pe_t = hip.gemm(U[0], W0p)  # [Q, kp]
-            if d_pe_acc is not None:
-                d_pe_t[:, :d_pe] += d_pe_acc
-            grad = hip.pe_encode_bwd(p, d_pe_t, n_octaves, scale)
-        if any(ctx.needs_input_grad):
-            ctx.n, ctx.skips, ctx.with_grad, ctx.d_pe, ctx.kp = n, list(skips), with_grad, d_pe, kp
-            ctx.n_octaves, ctx.scale = n_octaves, scale
-            keep = [p, W0p] + Ws + A + S
-            if with_grad:
-                keep += U + R[1:n - 1]
-            ctx.save_for_backward(*keep)
-        if grad is None:
-            grad = torch.zeros(Q, 3, device=dev)
-            ctx.mark_non_differentiable(grad)
-        return out, grad
+                li_t = light_int.reshape(-1).expand(light_dir.shape[0]).contiguous()
+        else:
+            li_s = float(light_int)
+        ctx.set_materialize_grads(False)
+        vis_f = None if vis is None else vis.reshape(-1).contiguous()
+        args = (light_dir.contiguous(), view.contiguous(), normal.contiguous(), albedo.contiguous(),
+                weights.contiguous(), lobe.contiguous())
+        rgb, spec = hip.sg_shade_fwd(*args, li_t, li_s, vis_f, specular_rgb)
+        ctx.save_for_backward(*args, *([li_t] if li_t is not None else []), *([vis_f] if vis_f is not None else []))
+        ctx.has_li, ctx.has_vis, ctx.li_s, ctx.specular_rgb = li_t is not None, vis_f is not None, li_s, specular_rgb
+        ctx.li_shape = light_int.shape if torch.is_tensor(light_int) else None
+        ctx.vis_shape = None if vis is None else vis.shape
+        return rgb, spec
 
     @staticmethod
-    def backward(ctx, d_out, d_grad):
-        n, skips, d_pe, kp = ctx.n, ctx.skips, ctx.d_pe, ctx.kp
+    def backward(ctx, g_rgb, g_spec):
         sv = list(ctx.saved_tensors)
-        p, W0p = sv[0], sv[1]
-        Ws = sv[2:2 + n]
-        A = sv[2 + n:2 + 2 * n]
-        S = sv[2 + 2 * n:2 + 3 * n - 1]
-        Q = p.shape[0]
-        dev = p.device
-        dW = [None] * n
-        db = [None] * n
-        sweep = ctx.with_grad and d_grad is not None
-        dS = [None] * (n - 1)
-
-        def add_dW(l, a_t, b_mat):  # dW[l] (+)= a_t^T @ b_mat
-            sk = _split_k_for(Q, a_t.shape[1], b_mat.shape[1])
-            if dW[l] is None:
-                dW[l] = hip.gemm(a_t, b_mat, trans_a=True, split_k=sk)
-            else:
-                hip.gemm(a_t, b_mat, trans_a=True, split_k=sk, out=dW[l], epi=hip.EPI_ACCUM)
-
-        if sweep:
-            base = 2 + 3 * n - 1
-            U = sv[base:base + n - 1]
-            R = [None] + sv[base + n - 1:base + n - 1 + (n - 2)] + [None]  # R[1..n-2]
-            dd_pe = hip.pe_encode_jvp(p, d_grad.contiguous(), ctx.n_octaves, kp, ctx.scale)  # dL/d(d_pe)
-            w_last = Ws[n - 1][0:1, :]
-            dR = dd_pe  # dL/dR[0]
-            for l in range(n - 1):
-                Wl = W0p if l == 0 else Ws[l]
-                o = Wl.shape[0]
-                r_next = R[l + 1] if l + 1 <= n - 2 else w_last.expand(Q, -1)  # stride-0 rows for the last layer
-                if (l + 1) in skips:  # the adjoint of R[l+1] is [a-part | pe-part]; build it in one buffer
-                    nxt = torch.empty(Q, o + d_pe, device=dev, dtype=torch.float32)
-                    dst = nxt[:, :o]
-                    nxt[:, o:] = dd_pe[:, :d_pe]
-                else:
-                    nxt = _buf(Q, o, dev)
-                    dst = nxt
-                dS[l] = _buf(Q, o, dev)
-                # du = dR @ W_l^T ;  dR[l+1](a-part) = du * S_l ;  dS_l = du * R[l+1]
-                hip.gemm(dR, Wl, trans_b=True, epi=hip.EPI_MUL2, aux_in=S[l], aux_in2=r_next, out=dst, aux_out=dS[l])
-                add_dW(l, U[l], dR)
-                dR = nxt
-            # R[n-1] is row 0 of the last layer broadcast over points
-            dW[n - 1] = torch.zeros_like(Ws[n - 1])
-            dW[n - 1][0] = hip.colsum(dR)
-
-        g = d_out.contiguous()
-        add_dW(n - 1, g, A[n - 1])
-        db[n - 1] = hip.colsum(g)
-        for l in range(n - 1, 0, -1):
-            in_a = Ws[l].shape[1] - d_pe if l in skips else Ws[l].shape[1]
-            g_prev = _buf(Q, in_a, dev)
-            if sweep:
-                hip.gemm(g, Ws[l][:, :in_a], epi=hip.EPI_SOFTPLUS_BWD, aux_in=S[l - 1], aux_in2=dS[l - 1], out=g_prev)
-            else:
-                hip.gemm(g, Ws[l][:, :in_a], epi=hip.EPI_MUL_AUX, aux_in=S[l - 1], out=g_prev)
-            g = g_prev
-            add_dW(l - 1, g, A[l - 1])
-            db[l - 1] = hip.colsum(g)
-        dW[0] = dW[0][:, :d_pe]
-        grads = []
-        for l in range(n):
-            grads += [dW[l], db[l]]
-        return (None, None, None, None, None) + tuple(grads)
+        light_dir, view, normal, albedo, weights, lobe = sv[:6]
+        k = 6
+        li_t = sv[k] if ctx.has_li else None
+        k += 1 if ctx.has_li else 0
+        vis_f = sv[k] if ctx.has_vis else None
+        want_vis = ctx.has_vis and ctx.needs_input_grad[7]
+        g_spec_c = None if g_spec is None else g_spec.contiguous()
+        if g_rgb is None:
+            g_rgb = torch.zeros(light_dir.shape[0] * view.shape[0], 3, device=view.device)
+        d_alb, d_w, d_n, d_vis, d_ld, d_li = hip.sg_shade_bwd(light_dir, view, normal, albedo, weights, lobe, li_t,
+                                                              ctx.li_s, vis_f, ctx.specular_rgb, g_rgb.contiguous(),
+                                                              g_spec_c, want_vis)
+        if d_li is not None:
+            d_li = d_li.sum().reshape(ctx.li_shape) if int(torch.tensor(ctx.li_shape).prod()) == 1 else d_li.reshape(ctx.li_shape)
+        if d_vis is not None:
+            d_vis = d_vis.reshape(ctx.vis_shape)
+        return d_ld, None, d_n, d_alb, d_w, None, d_li, d_vis, None
