@@ -2,17 +2,19 @@
 // Reference ops replaced: torch.nn.Linear / F.relu / nn.Softplus(beta=100) and their autograd backward
 // in stage1/model/network.py:85-106 and stage2/model/renderer.py:17-49.
 //
-// Workgroup tile 128x128x16, 4 waves in a 2x2 grid, each wave 64x64 = 2x2 MFMA tiles (64 accumulator
-// VGPRs).  Operand tiles are staged k-major in LDS ([16][128+4] floats) so that every MFMA operand read
-// is a conflict-free ds_read_b32 of 32 consecutive floats; the next k-tile is fetched into registers
-// while the current one is multiplied (one barrier per k-tile).  Numerics: exact fp32 fma chain per
-// output element (k-ordered), see MI355X guide "FP32-input MFMA".
+// Workgroup tile 128 x BN x 16 with BN = 256 (default) or 128 (narrow outputs), 4 waves in a 2x2 grid, each
+// wave 64 x BN/2 = 2 x NT MFMA tiles.  fp32 MFMA has so little arithmetic per operand byte that a 128x128
+// tile needs ~8.7 B/clk/CU of global loads at MFMA peak -- the measured per-CU streaming limit (~10 B/clk) --
+// and PMC showed 35-53 % MFMA-busy for it; the 256-wide tile reads each activation row-panel once and halves
+// the bytes per flop.  Operand tiles are staged k-major in LDS ([16][rows+4] floats) so that every MFMA
+// operand read is a conflict-free ds_read_b32 of 32 consecutive floats; the next k-tile is fetched into
+// registers while the current one is multiplied (one barrier per k-tile).  Numerics: exact fp32 fma chain
+// per output element (k-ordered), see MI355X guide "FP32-input MFMA".
 #include "common.h"
 
 namespace psn {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4, EPI_LD = 68;
-static_assert(4 * 32 * EPI_LD >= 4 * BK * LDT, "epilogue staging must cover the operand tiles");
+constexpr int BM = 128, BK = 16, LDA = BM + 4, EPI_LD = 68;
 
 struct GemmArgs {
     int64_t M;
@@ -42,11 +44,11 @@ struct GemmArgs {
 
 // Stage one 128 x 16 operand tile into registers.  KCONTIG: source rows run along k (row-major [rows][K]);
 // otherwise the source is [K][rows] row-major.
-template <bool KCONTIG>
+template <bool KCONTIG, int ROWS>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t n_rows,
-                                           int k0, int k_end, int vec_ok, int tid, float4 (&v)[2]) {
+                                           int k0, int k_end, int vec_ok, int tid, float4 (&v)[ROWS / 64]) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < ROWS / 64; ++u) {
         int f = tid + 256 * u;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KCONTIG) {
@@ -65,7 +67,7 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ src, int64_
                 }
             }
         } else {
-            int kk = f >> 5, rq = (f & 31) * 4;
+            int kk = f / (ROWS / 4), rq = (f % (ROWS / 4)) * 4;
             int k = k0 + kk;
             int64_t row = row0 + rq;
             if (k < k_end) {
@@ -84,29 +86,32 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ src, int64_
     }
 }
 
-template <bool KCONTIG>
-__device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, const float4 (&v)[2]) {
+template <bool KCONTIG, int ROWS>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, const float4 (&v)[ROWS / 64]) {
+    constexpr int LD = ROWS + 4;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < ROWS / 64; ++u) {
         int f = tid + 256 * u;
         if (KCONTIG) {
             int r = f >> 2, kq = (f & 3) * 4;
-            lds[(kq + 0) * LDT + r] = v[u].x;
-            lds[(kq + 1) * LDT + r] = v[u].y;
-            lds[(kq + 2) * LDT + r] = v[u].z;
-            lds[(kq + 3) * LDT + r] = v[u].w;
+            lds[(kq + 0) * LD + r] = v[u].x;
+            lds[(kq + 1) * LD + r] = v[u].y;
+            lds[(kq + 2) * LD + r] = v[u].z;
+            lds[(kq + 3) * LD + r] = v[u].w;
         } else {
-            int kk = f >> 5, rq = (f & 31) * 4;
-            *reinterpret_cast<float4*>(&lds[kk * LDT + rq]) = v[u];
+            int kk = f / (ROWS / 4), rq = (f % (ROWS / 4)) * 4;
+            *reinterpret_cast<float4*>(&lds[kk * LD + rq]) = v[u];
         }
     }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int NT>  // NT = 32-column MFMA tiles per wave in N: BN = 64 * NT
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    // operand tiles [buf][A|B][BK*LDT]; re-used by the epilogue as 4 wave-private [32][EPI_LD] staging tiles
-    __shared__ __attribute__((aligned(16))) float lds_raw[4 * 32 * EPI_LD];
-    float (*lds)[2][BK * LDT] = reinterpret_cast<float (*)[2][BK * LDT]>(lds_raw);
+    constexpr int BN = 64 * NT, LDB = BN + 4;
+    constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB, BUF_FLOATS = A_FLOATS + B_FLOATS;
+    constexpr int LDS_FLOATS = 2 * BUF_FLOATS > 4 * 32 * EPI_LD ? 2 * BUF_FLOATS : 4 * 32 * EPI_LD;
+    // operand tiles [buf]{A[BK][LDA], B[BK][LDB]}; re-used by the epilogue as 4 wave-private [32][EPI_LD] tiles
+    __shared__ __attribute__((aligned(16))) float lds_raw[LDS_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -130,48 +135,62 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int k_begin = split * g.k_chunk;
     const int k_end = min(g.K, k_begin + g.k_chunk);
 
-    floatx16 acc[2][2];
+    floatx16 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[2], rb[2];
-    fetch_tile<!TA>(g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid, ra);
-    fetch_tile<TB>(g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid, rb);
-    store_tile<!TA>(lds[0][0], tid, ra);
-    store_tile<TB>(lds[0][1], tid, rb);
-    __syncthreads();
-
-    int buf = 0;
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        const bool has_next = k0 + BK < k_end;
-        if (has_next) {
-            fetch_tile<!TA>(g.A, g.lda, m0, g.M, k0 + BK, k_end, g.a_vec, tid, ra);
-            fetch_tile<TB>(g.B, g.ldb, n0, g.N, k0 + BK, k_end, g.b_vec, tid, rb);
-        }
-        const float* As = lds[buf][0];
-        const float* Bs = lds[buf][1];
-#pragma unroll
-        for (int ks = 0; ks < BK; ks += 2) {
-            float a0 = As[(ks + lh) * LDT + wr * 64 + li];
-            float a1 = As[(ks + lh) * LDT + wr * 64 + 32 + li];
-            float b0 = Bs[(ks + lh) * LDT + wc * 64 + li];
-            float b1 = Bs[(ks + lh) * LDT + wc * 64 + 32 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (has_next) {
-            store_tile<!TA>(lds[buf ^ 1][0], tid, ra);
-            store_tile<TB>(lds[buf ^ 1][1], tid, rb);
-        }
-        __syncthreads();
-        buf ^= 1;
+    // Register-staged double buffering: while tile t is multiplied out of LDS buffer t&1, tile t+1 is fetched
+    // into registers and written to the other buffer after the MFMA stream (one barrier per k-tile).
+    float4 ra0[2], rb0[BN / 64];
+    const int nt = (k_end - k_begin + BK - 1) / BK;
+#define PSN_FETCH(T)                                                                                    \
+    fetch_tile<!TA, BM>(g.A, g.lda, m0, g.M, k_begin + (T) * BK, k_end, g.a_vec, tid, ra0);               \
+    fetch_tile<TB, BN>(g.B, g.ldb, n0, g.N, k_begin + (T) * BK, k_end, g.b_vec, tid, rb0);
+#define PSN_STORE(BUF)                                                   \
+    store_tile<!TA, BM>(lds_raw + (BUF) * BUF_FLOATS, tid, ra0);         \
+    store_tile<TB, BN>(lds_raw + (BUF) * BUF_FLOATS + A_FLOATS, tid, rb0);
+// MFMA operands of k-step j+1 are read from LDS while the MFMAs of step j execute (two register sets, order
+// given to the scheduler with sched_group_barrier); hipcc otherwise re-uses one operand register set per k-step
+// and serialises {ds_read, s_waitcnt lgkmcnt(0), MFMAs}.
+#define PSN_COMPUTE(BUF)                                                                         \
+    {                                                                                            \
+        const float* As = lds_raw + (BUF) * BUF_FLOATS;                                          \
+        const float* Bs = As + A_FLOATS;                                                         \
+        float pa[8][2], pb[8][NT];                                                               \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                          \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) pa[j][i] = As[(2 * j + lh) * LDA + wr * 64 + i * 32 + li];             \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n) pb[j][n] = Bs[(2 * j + lh) * LDB + wc * (32 * NT) + n * 32 + li];     \
+        }                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                            \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                        \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n)                                   \
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j][i], pb[j][n], acc[i][n], 0, 0, 0);                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, (2 + NT) / 2, 0);                            \
+        _Pragma("unroll") for (int j = 0; j < 7; ++j) {                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, (2 + NT) / 2, 0);                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);                              \
+        }                                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);                                  \
     }
+    PSN_FETCH(0)
+    PSN_STORE(0)
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) { PSN_FETCH(t + 1) }
+        __builtin_amdgcn_sched_barrier(0);  // global loads are issued BEFORE the pinned MFMA / LDS-read stream
+        PSN_COMPUTE(buf)
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nt) { PSN_STORE(buf ^ 1) }
+        __syncthreads();
+    }
+#undef PSN_FETCH
+#undef PSN_STORE
+#undef PSN_COMPUTE
 
     // epilogue.  Lane (j = li, h = lh) holds C[m0 + wr*64 + it*32 + (r&3) + 8*(r>>2) + 4*h][n0 + wc*64 + jt*32 + j].
     // Each wave transposes one 32 x 64 half of its tile through a private LDS tile and then walks it in
@@ -179,8 +198,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // aux operands, and a small rolled loop so the fused epilogue math does not inflate register use.
     float* Cbase = g.C + (int64_t)split * g.split_stride;
     float* et = lds_raw + wave * (32 * EPI_LD);
-    const int c4 = (lane & 15) * 4;          // column (within the wave's 64) of this lane's float4
-    const int nbase = n0 + wc * 64 + c4;
+    const int c4 = (lane & 15) * 4;          // column (within a 64-column group) of this lane's float4
+#pragma unroll
+    for (int cg = 0; cg < NT / 2; ++cg) {    // 64-column groups of the wave's tile
+    const int nbase = n0 + wc * (32 * NT) + cg * 64 + c4;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias != nullptr) {
         if (nbase + 0 < g.N) bias4.x = g.bias[nbase + 0];
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                et[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LD + jt * 32 + li] = acc[it][jt][r];
+                et[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LD + jt * 32 + li] = acc[it][2 * cg + jt][r];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
@@ -258,6 +279,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    }  // cg
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int64_t MN, int N,
@@ -328,7 +350,12 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
     g.aux_in2 = aux_in2; g.ld_aux_in2 = ld_aux_in2;
     g.ld_aux_out = ld_aux_out;
     int64_t tiles_m = (M + BM - 1) / BM;
-    g.tiles_n = (N + BN - 1) / BN;
+    // 256-column tiles read each A row-panel once (measured +0-5 % on the Q x 256 x 256 layer GEMMs) but halve the
+    // workgroup count; keep them only when the grid still covers the 256 CUs several times over.
+    const int64_t tiles_m_ = (M + BM - 1) / BM;
+    int bn = N > 128 ? 256 : 128;
+    if (bn == 256 && tiles_m_ * ((N + 255) / 256) * (split_k < 1 ? 1 : split_k) < 2048) bn = 128;
+    g.tiles_n = (N + bn - 1) / bn;
     g.n_tiles = tiles_m * g.tiles_n;
     PSN_CHECK_ARG(g.n_tiles < (1ll << 31), "gemm: too many tiles");
     g.a_vec = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0);
@@ -351,10 +378,14 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
     g.split_k = split_k;
     PSN_CHECK_ARG(g.n_tiles * split_k < (1ll << 31), "gemm: too many blocks");
     dim3 grid((unsigned)(g.n_tiles * split_k)), block(256);
-    if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, g);
-    else if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, g);
-    else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, st, g);
+#define PSN_LAUNCH(TA_, TB_)                                                                          \
+    if (bn == 256) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 4>), grid, block, 0, st, g);             \
+    else hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 2>), grid, block, 0, st, g);
+    if (!trans_a && trans_b) { PSN_LAUNCH(false, true) }
+    else if (!trans_a && !trans_b) { PSN_LAUNCH(false, false) }
+    else if (trans_a && !trans_b) { PSN_LAUNCH(true, false) }
+    else { PSN_LAUNCH(true, true) }
+#undef PSN_LAUNCH
     PSN_CHECK_LAUNCH("gemm");
     if (split_k > 1) {
         int64_t MN = M * (int64_t)N;

@@ -260,3 +260,157 @@ class SGShade(torch.autograd.Function):
         if d_vis is not None:
             d_vis = d_vis.reshape(ctx.vis_shape)
         return d_ld, None, d_n, d_alb, d_w, None, d_li, d_vis, None
+
+
+# --------------------------------------------------------------------------- stage-1 geometry field
+def _buf(rows, cols, device):
+    """[rows, cols] view of a buffer whose row stride is a multiple of 4 floats (16-byte aligned rows)."""
+    pad = (cols + 3) // 4 * 4
+    return torch.empty(rows, pad, device=device, dtype=torch.float32)[:, :cols]
+
+
+class GeoField(torch.autograd.Function):
+    """Occupancy ("geo") MLP of stage1/model/network.py:85-95 together with its spatial gradient
+    (network.py:108-120), in ONE differentiable op:
+
+        out  [Q, F+1] = infer_occ(p)          (logit = out[:, 0], features = out[:, 1:])
+        grad [Q, 3]   = d out[:, 0] / d p     (what autograd.grad(..., create_graph=True) returns)
+
+    The reference obtains ``grad`` by running infer_occ a second time and calling autograd with
+    create_graph=True, so training differentiates through a gradient (double backward through nine
+    weight-normed softplus(beta=100) layers).  Here the reverse sweep that produces ``grad`` is written
+    out as explicit GEMMs (r_l = (r_{l+1} * sigmoid(100 z_l)) W_l), and backward() is the hand-derived
+    adjoint of BOTH passes -- no autograd-of-autograd, and infer_occ runs once instead of twice.
+
+    Inputs: p [Q,3]; n_octaves; scale (= 1/rescale); skips (layers whose input is cat[x, pe]; the
+    1/sqrt(2) is folded into those layers' weights by the caller); with_grad; then W_0, b_0, W_1, ...
+    as EFFECTIVE dense weights (weight-norm is applied by the caller with torch ops on the tiny weight
+    tensors, so autograd maps dW back to weight_g / weight_v).
+    Points are never differentiated on the reference's training path (sample depths are detached,
+    rendering.py:88-101), so no gradient is returned for p."""
+
+    @staticmethod
+    def forward(ctx, p, n_octaves, scale, skips, with_grad, *params):
+        Ws, bs = [w.contiguous() for w in params[0::2]], [b.contiguous() for b in params[1::2]]
+        n = len(Ws)
+        p = p.contiguous()
+        Q = p.shape[0]
+        dev = p.device
+        d_pe = 3 + 6 * n_octaves
+        kp = (d_pe + 3) // 4 * 4
+        H = Ws[1].shape[1]
+        pe = hip.pe_encode(p, n_octaves, kp, scale)
+        W0p = torch.nn.functional.pad(Ws[0], (0, kp - d_pe)).contiguous()
+        A, S = [None] * n, [None] * (n - 1)
+        A[0] = pe
+        for l in range(n - 1):
+            o = Ws[l].shape[0]
+            if (l + 1) in skips:
+                nxt = torch.empty(Q, o + d_pe, device=dev, dtype=torch.float32)
+                dst = nxt[:, :o]
+                nxt[:, o:] = pe[:, :d_pe]
+            else:
+                nxt = _buf(Q, o, dev)
+                dst = nxt
+            S[l] = _buf(Q, o, dev)
+            hip.gemm(A[l], W0p if l == 0 else Ws[l], trans_b=True, bias=bs[l], epi=hip.EPI_BIAS_SOFTPLUS, out=dst,
+                     aux_out=S[l])
+            A[l + 1] = nxt
+        out = hip.gemm(A[n - 1], Ws[n - 1], trans_b=True, bias=bs[n - 1], epi=hip.EPI_BIAS)
+        grad = None
+        U, R = [None] * (n - 1), [None] * n
+        if with_grad:
+            w_last = Ws[n - 1][0:1, :]  # d logit / d a_{n-1}, the same row for every point
+            U[n - 2] = S[n - 2] * w_last
+            d_pe_acc = None
+            for l in range(n - 2, 0, -1):
+                in_a = Ws[l].shape[1] - d_pe if l in skips else Ws[l].shape[1]
+                R[l] = _buf(Q, in_a, dev)
+                U[l - 1] = _buf(Q, in_a, dev)
+                hip.gemm(U[l], Ws[l][:, :in_a], epi=hip.EPI_MUL_AUX_RAW, aux_in=S[l - 1], out=U[l - 1], aux_out=R[l])
+                if l in skips:
+                    g_skip = hip.gemm(U[l], Ws[l][:, in_a:])
+                    d_pe_acc = g_skip if d_pe_acc is None else d_pe_acc + g_skip
+            d_pe_t = hip.gemm(U[0], W0p)  # [Q, kp]
+            if d_pe_acc is not None:
+                d_pe_t[:, :d_pe] += d_pe_acc
+            grad = hip.pe_encode_bwd(p, d_pe_t, n_octaves, scale)
+        if any(ctx.needs_input_grad):
+            ctx.n, ctx.skips, ctx.with_grad, ctx.d_pe, ctx.kp = n, list(skips), with_grad, d_pe, kp
+            ctx.n_octaves, ctx.scale = n_octaves, scale
+            keep = [p, W0p] + Ws + A + S
+            if with_grad:
+                keep += U + R[1:n - 1]
+            ctx.save_for_backward(*keep)
+        if grad is None:
+            grad = torch.zeros(Q, 3, device=dev)
+            ctx.mark_non_differentiable(grad)
+        return out, grad
+
+    @staticmethod
+    def backward(ctx, d_out, d_grad):
+        n, skips, d_pe, kp = ctx.n, ctx.skips, ctx.d_pe, ctx.kp
+        sv = list(ctx.saved_tensors)
+        p, W0p = sv[0], sv[1]
+        Ws = sv[2:2 + n]
+        A = sv[2 + n:2 + 2 * n]
+        S = sv[2 + 2 * n:2 + 3 * n - 1]
+        Q = p.shape[0]
+        dev = p.device
+        dW = [None] * n
+        db = [None] * n
+        sweep = ctx.with_grad and d_grad is not None
+        dS = [None] * (n - 1)
+
+        def add_dW(l, a_t, b_mat):  # dW[l] (+)= a_t^T @ b_mat
+            sk = _split_k_for(Q, a_t.shape[1], b_mat.shape[1])
+            if dW[l] is None:
+                dW[l] = hip.gemm(a_t, b_mat, trans_a=True, split_k=sk)
+            else:
+                hip.gemm(a_t, b_mat, trans_a=True, split_k=sk, out=dW[l], epi=hip.EPI_ACCUM)
+
+        if sweep:
+            base = 2 + 3 * n - 1
+            U = sv[base:base + n - 1]
+            R = [None] + sv[base + n - 1:base + n - 1 + (n - 2)] + [None]  # R[1..n-2]
+            dd_pe = hip.pe_encode_jvp(p, d_grad.contiguous(), ctx.n_octaves, kp, ctx.scale)  # dL/d(d_pe)
+            w_last = Ws[n - 1][0:1, :]
+            dR = dd_pe  # dL/dR[0]
+            for l in range(n - 1):
+                Wl = W0p if l == 0 else Ws[l]
+                o = Wl.shape[0]
+                r_next = R[l + 1] if l + 1 <= n - 2 else w_last.expand(Q, -1)  # stride-0 rows for the last layer
+                if (l + 1) in skips:  # the adjoint of R[l+1] is [a-part | pe-part]; build it in one buffer
+                    nxt = torch.empty(Q, o + d_pe, device=dev, dtype=torch.float32)
+                    dst = nxt[:, :o]
+                    nxt[:, o:] = dd_pe[:, :d_pe]
+                else:
+                    nxt = _buf(Q, o, dev)
+                    dst = nxt
+                dS[l] = _buf(Q, o, dev)
+                # du = dR @ W_l^T ;  dR[l+1](a-part) = du * S_l ;  dS_l = du * R[l+1]
+                hip.gemm(dR, Wl, trans_b=True, epi=hip.EPI_MUL2, aux_in=S[l], aux_in2=r_next, out=dst, aux_out=dS[l])
+                add_dW(l, U[l], dR)
+                dR = nxt
+            # R[n-1] is row 0 of the last layer broadcast over points
+            dW[n - 1] = torch.zeros_like(Ws[n - 1])
+            dW[n - 1][0] = hip.colsum(dR)
+
+        g = d_out.contiguous()
+        add_dW(n - 1, g, A[n - 1])
+        db[n - 1] = hip.colsum(g)
+        for l in range(n - 1, 0, -1):
+            in_a = Ws[l].shape[1] - d_pe if l in skips else Ws[l].shape[1]
+            g_prev = _buf(Q, in_a, dev)
+            if sweep:
+                hip.gemm(g, Ws[l][:, :in_a], epi=hip.EPI_SOFTPLUS_BWD, aux_in=S[l - 1], aux_in2=dS[l - 1], out=g_prev)
+            else:
+                hip.gemm(g, Ws[l][:, :in_a], epi=hip.EPI_MUL_AUX, aux_in=S[l - 1], out=g_prev)
+            g = g_prev
+            add_dW(l - 1, g, A[l - 1])
+            db[l - 1] = hip.colsum(g)
+        dW[0] = dW[0][:, :d_pe]
+        grads = []
+        for l in range(n):
+            grads += [dW[l], db[l]]
+        return (None, None, None, None, None) + tuple(grads)
