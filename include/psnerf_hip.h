@@ -172,6 +172,20 @@ int psn_sg_shade_bwd(const float* light_dir, const float* view, const float* nor
                      const float* g_spec, float* d_albedo, float* d_weights, float* d_normal, float* d_vis,
                      float* d_light_dir, float* d_light_int, float* workspace, void* stream);
 
+/* ------------------------------------------------------------------------
+ * GGX microfacet shading (train.render_model = microfacet): stage2/model/microfacet.py:35-114 followed by
+ * stage2/model/renderer.py:187-204, same row layout as psn_sg_shade_*.  rough [Ns] (sigmoid output of rough_net),
+ * f0 = brdf.fresnel_f0.  rgb [L*Ns,3].  Backward: d_albedo [Ns,3], d_rough [Ns], d_normal [Ns,3], d_vis [L*Ns] or
+ * NULL, d_light_dir [L,3], d_light_int [L] or NULL; workspace >= ceil(Ns/256)*L*4 floats.
+ * ---------------------------------------------------------------------- */
+int psn_mf_shade_fwd(const float* light_dir, const float* view, const float* normal, const float* albedo,
+                     const float* rough, const float* light_int, float light_int_scalar, float f0, const float* vis,
+                     int L, int64_t Ns, float* rgb, void* stream);
+int psn_mf_shade_bwd(const float* light_dir, const float* view, const float* normal, const float* albedo,
+                     const float* rough, const float* light_int, float light_int_scalar, float f0, const float* vis,
+                     int L, int64_t Ns, const float* g_rgb, float* d_albedo, float* d_rough, float* d_normal,
+                     float* d_vis, float* d_light_dir, float* d_light_int, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,9 @@ SIGNATURES = {
     'psn_sg_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f]),
     'psn_sg_shade_bwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f, c_f,
                                c_f, c_f, c_f, c_f, c_f, c_f]),
+    'psn_mf_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, f32, f32, c_f, i32, i64, c_f, c_f]),
+    'psn_mf_shade_bwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, f32, f32, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f, c_f,
+                               c_f, c_f, c_f]),
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f, i64, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
@@ -272,3 +275,33 @@ def sg_shade_bwd(light_dir, view, normal, albedo, weights, lobe, light_int, ligh
                                  _ptr(d_vis, 'd_vis', True), _ptr(d_ldir, 'd_ldir'), _ptr(d_lint, 'd_lint', True),
                                  ws.data_ptr(), _stream()), 'sg_shade_bwd')
     return d_albedo, d_weights, d_normal, d_vis, d_ldir, d_lint
+
+
+# --------------------------------------------------------------------------- GGX microfacet shading
+def mf_shade_fwd(light_dir, view, normal, albedo, rough, light_int, light_int_scalar, f0, vis):
+    L, Ns = light_dir.shape[0], view.shape[0]
+    rgb = torch.empty(L * Ns, 3, device=view.device, dtype=torch.float32)
+    _check(_lib.psn_mf_shade_fwd(_ptr(light_dir, 'light_dir'), _ptr(view, 'view'), _ptr(normal, 'normal'),
+                                 _ptr(albedo, 'albedo'), _ptr(rough, 'rough'), _ptr(light_int, 'light_int', True),
+                                 float(light_int_scalar), float(f0), _ptr(vis, 'vis', True), L, Ns, _ptr(rgb, 'rgb'),
+                                 _stream()), 'mf_shade_fwd')
+    return rgb
+
+
+def mf_shade_bwd(light_dir, view, normal, albedo, rough, light_int, light_int_scalar, f0, vis, g_rgb, want_vis):
+    L, Ns = light_dir.shape[0], view.shape[0]
+    dev = view.device
+    d_albedo = torch.empty(Ns, 3, device=dev)
+    d_rough = torch.empty(Ns, device=dev)
+    d_normal = torch.empty(Ns, 3, device=dev)
+    d_vis = torch.empty(L * Ns, device=dev) if want_vis else None
+    d_ldir = torch.empty(L, 3, device=dev)
+    d_lint = torch.empty(L, device=dev) if light_int is not None else None
+    ws = workspace(((Ns + 255) // 256) * L * 4, dev)
+    _check(_lib.psn_mf_shade_bwd(_ptr(light_dir, 'light_dir'), _ptr(view, 'view'), _ptr(normal, 'normal'),
+                                 _ptr(albedo, 'albedo'), _ptr(rough, 'rough'), _ptr(light_int, 'light_int', True),
+                                 float(light_int_scalar), float(f0), _ptr(vis, 'vis', True), L, Ns, _ptr(g_rgb, 'g_rgb'),
+                                 _ptr(d_albedo, 'd_albedo'), _ptr(d_rough, 'd_rough'), _ptr(d_normal, 'd_normal'),
+                                 _ptr(d_vis, 'd_vis', True), _ptr(d_ldir, 'd_ldir'), _ptr(d_lint, 'd_lint', True),
+                                 ws.data_ptr(), _stream()), 'mf_shade_bwd')
+    return d_albedo, d_rough, d_normal, d_vis, d_ldir, d_lint

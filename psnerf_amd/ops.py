@@ -414,3 +414,52 @@ class GeoField(torch.autograd.Function):
         for l in range(n):
             grads += [dW[l], db[l]]
         return (None, None, None, None, None) + tuple(grads)
+
+
+# --------------------------------------------------------------------------- GGX microfacet shading
+class MFShade(torch.autograd.Function):
+    """train.render_model = microfacet: stage2/model/microfacet.py:35-114 + renderer.py:187-204, fused
+    (csrc/shade.hip).  rough [Ns,1] is the sigmoid output of rough_net; returns rgb [L*Ns,3]."""
+
+    @staticmethod
+    def forward(ctx, light_dir, view, normal, albedo, rough, light_int, vis, f0):
+        li_t, li_s = None, 0.0
+        if torch.is_tensor(light_int):
+            li_t = light_int.reshape(-1).expand(light_dir.shape[0]).contiguous() if light_int.numel() == 1 \
+                else light_int.reshape(-1).contiguous()
+        else:
+            li_s = float(light_int)
+        vis_f = None if vis is None else vis.reshape(-1).contiguous()
+        args = (light_dir.contiguous(), view.contiguous(), normal.contiguous(), albedo.contiguous(),
+                rough.reshape(-1).contiguous())
+        rgb = hip.mf_shade_fwd(*args, li_t, li_s, f0, vis_f)
+        ctx.save_for_backward(*args, *([li_t] if li_t is not None else []), *([vis_f] if vis_f is not None else []))
+        ctx.has_li, ctx.has_vis, ctx.li_s, ctx.f0 = li_t is not None, vis_f is not None, li_s, f0
+        ctx.li_shape = light_int.shape if torch.is_tensor(light_int) else None
+        ctx.vis_shape = None if vis is None else vis.shape
+        ctx.rough_shape = rough.shape
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        sv = list(ctx.saved_tensors)
+        light_dir, view, normal, albedo, rough = sv[:5]
+        k = 5
+        li_t = sv[k] if ctx.has_li else None
+        k += 1 if ctx.has_li else 0
+        vis_f = sv[k] if ctx.has_vis else None
+        want_vis = ctx.has_vis and ctx.needs_input_grad[6]
+        d_alb, d_r, d_n, d_vis, d_ld, d_li = hip.mf_shade_bwd(light_dir, view, normal, albedo, rough, li_t, ctx.li_s,
+                                                              ctx.f0, vis_f, g_rgb.contiguous(), want_vis)
+        if d_li is not None:
+            n_li = 1
+            for d in ctx.li_shape:
+                n_li *= d
+            d_li = d_li.sum().reshape(ctx.li_shape) if n_li == 1 else d_li.reshape(ctx.li_shape)
+        if d_vis is not None:
+            d_vis = d_vis.reshape(ctx.vis_shape)
+        return d_ld, None, d_n, d_alb, d_r.reshape(ctx.rough_shape), d_li, d_vis, None
+
+
+def mf_shade(light_dir, view, normal, albedo, rough, light_int, vis, f0):
+    return MFShade.apply(light_dir, view, normal, albedo, rough, light_int, vis, f0)

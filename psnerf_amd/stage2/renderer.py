@@ -78,24 +78,28 @@ class PSNetwork(nn.Module):
         super().__init__()
         self.conf = conf
         self.render_model = conf.get_string('train.render_model', default='sgbasis')
-        if self.render_model != 'sgbasis':
-            raise NotImplementedError('render_model=%s: only sgbasis is on the accelerated path (SURVEY 8f4)'
-                                      % self.render_model)
-        nbasis = conf.get_int('train.nbasis', default=9)
-        self.specular_rgb = conf.get_bool('train.specular_rgb', default=False)
-        self.sgbasis = SGBasis(nbasis=nbasis, specular_rgb=self.specular_rgb)
+        if self.render_model not in ('sgbasis', 'microfacet'):
+            raise ValueError('unknown train.render_model %r' % self.render_model)
         self.n_freqs = conf.get_int('brdf.net.n_freqs_xyz')
         dim_emb = 3 + 6 * self.n_freqs
         assert dim_emb <= PE_STRIDE
         W, depth = conf.get_int('brdf.net.mlp_width'), conf.get_int('brdf.net.mlp_depth')
         skip = conf.get_int('brdf.net.mlp_skip_at')
-        self.albedo_net = MLP(dim_emb, 3, W, depth, skip_at=[skip], final='sigmoid')
-        if self.specular_rgb:
-            nbasis *= 3
-        self.rough_net = MLP(dim_emb, nbasis, conf.get_int('brdf.sgnet.mlp_width', 128),
-                             conf.get_int('brdf.sgnet.mlp_depth', 4),
-                             skip_at=[conf.get_int('brdf.sgnet.mlp_skip_at', 2)])
-        self.nbasis = nbasis
+        if self.render_model == 'microfacet':  # renderer.py:62-63,74-75
+            self.f0 = conf.get_float('brdf.fresnel_f0', default=0.05)
+            self.albedo_net = MLP(dim_emb, 3, W, depth, skip_at=[skip], final='sigmoid')
+            self.rough_net = MLP(dim_emb, 1, W, depth, skip_at=[skip], final='sigmoid')
+        else:
+            nbasis = conf.get_int('train.nbasis', default=9)
+            self.specular_rgb = conf.get_bool('train.specular_rgb', default=False)
+            self.sgbasis = SGBasis(nbasis=nbasis, specular_rgb=self.specular_rgb)
+            self.albedo_net = MLP(dim_emb, 3, W, depth, skip_at=[skip], final='sigmoid')
+            if self.specular_rgb:
+                nbasis *= 3
+            self.rough_net = MLP(dim_emb, nbasis, conf.get_int('brdf.sgnet.mlp_width', 128),
+                                 conf.get_int('brdf.sgnet.mlp_depth', 4),
+                                 skip_at=[conf.get_int('brdf.sgnet.mlp_skip_at', 2)])
+            self.nbasis = nbasis
         self.light_int = conf.get_float('brdf.light_intensity', default=4.0)
         self.shape_pregen = conf.get_bool('train.shape_pregen', default=False)
         if not self.shape_pregen:
@@ -170,11 +174,12 @@ class PSNetwork(nn.Module):
                     out_n['normal_jitter'] = nj
             out_n['normal_pred'] = normal_pred
 
+        sg = self.render_model == 'sgbasis'
         lnum = input['light_direction'].shape[0]
         rgb_values = torch.ones_like(points).repeat(lnum, 1, 1) if lnum > 1 else torch.ones_like(points)
         albedo_values = torch.ones_like(points)
-        rough_values = rgb_values.clone()
-        weight_values = torch.zeros(*points.shape[:-1], self.nbasis, device=device)
+        rough_values = rgb_values.clone() if sg else torch.ones_like(points)
+        weight_values = torch.zeros(*points.shape[:-1], self.nbasis, device=device) if sg else None
         vis_values = rgb_values.clone()
         jitter = None
         pe_x = None
@@ -189,15 +194,16 @@ class PSNetwork(nn.Module):
             if albedo_new is not None:
                 albedo = torch.from_numpy(albedo_new).to(device)[None].expand_as(albedo)
             rough = self.rough_net(pe_x, cols)
-            weights = F.relu(rough)
-            if basis_new is not None:  # material editing (eval.py:233-312)
-                wn = torch.zeros_like(weights)
-                if self.specular_rgb:
-                    wn.view(-1, 3, self.nbasis // 3)[:, :, basis_new] = 2 ** basis_new / 100
-                else:
-                    wn.view(-1, 1, self.nbasis)[:, :, basis_new] = 2 ** basis_new / 100
-                weights = wn.reshape(-1, self.nbasis)
-            weight_values[surface_mask] = weights
+            if sg:
+                weights = F.relu(rough)
+                if basis_new is not None:  # material editing (eval.py:233-312)
+                    wn = torch.zeros_like(weights)
+                    if self.specular_rgb:
+                        wn.view(-1, 3, self.nbasis // 3)[:, :, basis_new] = 2 ** basis_new / 100
+                    else:
+                        wn.view(-1, 1, self.nbasis)[:, :, basis_new] = 2 ** basis_new / 100
+                    weights = wn.reshape(-1, self.nbasis)
+                weight_values[surface_mask] = weights
             light_int = input.get('light_intensity', self.light_int)
             vis = None
             vis_for_rgb = None
@@ -206,13 +212,19 @@ class PSNetwork(nn.Module):
                 vis = self._visibility_rows(pe_x, light_dir, fused_ok=True)  # [L*Ns, 1], light-major
                 detach = self.conf.get_bool('train.vis_rgb_detach', default=False)
                 vis_for_rgb = vis.detach() if detach else vis
-            rgb, spec = ops.sg_shade(light_dir, pts2c, normal, albedo, weights, self.sgbasis.lobe, light_int,
-                                     vis_for_rgb, self.specular_rgb)
+            if sg:
+                rgb, spec = ops.sg_shade(light_dir, pts2c, normal, albedo, weights, self.sgbasis.lobe, light_int,
+                                         vis_for_rgb, self.specular_rgb)
+            else:
+                rgb = ops.mf_shade(light_dir, pts2c, normal, albedo, rough, light_int, vis_for_rgb, self.f0)
             rgb_values[mask_l] = rgb
             if vis is not None:
                 vis_values[mask_l] = vis.expand(rgb.shape)
             albedo_values[surface_mask] = albedo
-            rough_values[mask_l] = spec.expand(-1, 3)
+            if sg:
+                rough_values[mask_l] = spec.expand(-1, 3)
+            else:
+                rough_values[surface_mask] = rough.expand(-1, 3)
             if self.xyz_jitter_std > 0:  # renderer.py:211-231
                 nz = noise.get('xyz')
                 if nz is None:
@@ -220,10 +232,16 @@ class PSNetwork(nn.Module):
                 pe_j = self._pe(surf + nz, self.n_freqs)
                 aj = torch.ones_like(points)
                 aj[surface_mask] = self.albedo_net(pe_j, cols)
-                rj = torch.ones_like(weight_values)
-                rj[surface_mask] = F.relu(self.rough_net(pe_j, cols))
+                if sg:
+                    rj = torch.ones_like(weight_values)
+                    rj[surface_mask] = F.relu(self.rough_net(pe_j, cols))
+                    r_ori = weight_values
+                else:
+                    rj = torch.ones_like(points)
+                    rj[surface_mask] = self.rough_net(pe_j, cols).expand(-1, 3)
+                    r_ori = rough_values
                 jitter = {'albedo_values': albedo_values, 'albedo_jitter': aj,
-                          'rough_values': weight_values, 'rough_jitter': rj}
+                          'rough_values': r_ori, 'rough_jitter': rj}
 
         out = {
             'points': points, 'object_mask': object_mask, 'network_object_mask': surface_mask,
@@ -245,5 +263,6 @@ class PSNetwork(nn.Module):
                     vis_t = self._visibility_rows(pe_x, lv, fused_ok=not train)
                     vt[surface_mask.expand(vnum, -1)] = vis_t.expand(-1, 3)
                 out['vis_train'] = vt
-        out['sg_weight'] = weight_values
+        if sg:
+            out['sg_weight'] = weight_values
         return out

@@ -176,3 +176,30 @@ def test_stage2_psnetwork(L, phase):
     assert names == list(g['grad_names'])
     assert_close(norms, g['grad_norms'], 2e-5, 'grad norms')
     assert_close(projs, g['grad_projs'], 1e-4, 'grad projs')
+
+
+def test_stage2_psnetwork_microfacet():
+    g = load('stage2_psnet_microfacet.npz')
+    conf = o2.bear_conf(**{'train.render_model': 'microfacet'})
+    sd = stage2_state_dict(conf, seed=33)
+    assert state_dict_digest(sd) == str(g['sd_digest'])
+    net = o2.PSNetwork(conf)
+    net.load_state_dict(sd)
+    inp, gt = stage2_inputs(int(g['N']), int(g['L']), int(g['V']), seed=int(g['input_seed']))
+    ldir = inp['light_direction'].clone().requires_grad_(True)
+    lint = inp['light_intensity'].clone().requires_grad_(True)
+    inp['light_direction'] = torch.nn.functional.normalize(ldir, p=2, dim=-1)
+    inp['light_intensity'] = lint
+    out = net(inp, noise={'xyz': T(g['nz_xyz'])})
+    for k in g.files:
+        if k.startswith('out_'):
+            assert_close(out[k[4:]].detach(), g[k], 2e-6, k)
+    t = dict(o2.MainLoss(loss_type='L1', sg_rgb_weight=1.0, albedo_smooth_weight=0.05, rough_smooth_weight=0.01,
+                         vis_weight=1)(out, gt, inp))
+    tn = o2.NormalLoss(1, 0.05)(out)
+    t['normal_loss'] = tn['normal_loss']
+    t['total'] = t['loss'] + tn['loss']
+    for k, v in zip(g['loss_names'], g['loss_vals']):
+        assert_close(float(t[str(k)]), v, 2e-6, str(k))
+    t['total'].backward()
+    assert_close(ldir.grad, g['g_light_dir'], 1e-5, 'light dir grad')

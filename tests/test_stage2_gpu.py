@@ -147,3 +147,28 @@ def test_train_steps_match_oracle(cuda):
         assert float(d.mean()) <= 2e-5, 'param %s mean diff %.3e' % (k, float(d.mean()))
     assert_close(step.light_para.weight.detach().cpu(), ostep.light_para.weight.detach(), 1e-4, 'light dirs')
     assert_close(step.light_inten_para.weight.detach().cpu(), ostep.light_inten_para.weight.detach(), 1e-4, 'light int')
+
+
+def test_psnetwork_microfacet_golden(cuda):
+    """train.render_model = microfacet (GGX, stage2/model/microfacet.py) through the fused mf_shade kernel."""
+    import psnerf_amd.stage2 as s2
+    from oracle import stage2 as o2
+    g = np.load(os.path.join(GOLDEN, 'stage2_psnet_microfacet.npz'))
+    sd = stage2_state_dict(o2.bear_conf(**{'train.render_model': 'microfacet'}), seed=33)
+    assert state_dict_digest(sd) == str(g['sd_digest'])
+    net = s2.PSNetwork(s2.bear_conf(**{'train.render_model': 'microfacet'}))
+    net.load_state_dict(sd)
+    net.to(cuda)
+    inp, gt = stage2_inputs(int(g['N']), int(g['L']), int(g['V']), seed=int(g['input_seed']))
+    out, t, gr = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, 2, torch.from_numpy(g['nz_xyz']), cuda)
+    for k in g.files:
+        if k.startswith('out_'):
+            assert_close(out[k[4:]].detach().cpu(), g[k], 1e-4, k)
+    for k, v in zip(g['loss_names'], g['loss_vals']):
+        assert_close(float(t[str(k)].detach()), v, 1e-4, str(k))
+    names, norms, projs = grad_digest(gr)
+    assert names == list(g['grad_names'])
+    assert_close(norms, g['grad_norms'], 1e-3, 'grad norms')
+    assert_close(projs, g['grad_projs'], 2e-3, 'grad projs')
+    assert_close(gr['__light_dir'].cpu(), g['g_light_dir'], 1e-3, 'light dir grad')
+    assert_close(gr['__light_int'].cpu(), g['g_light_int'], 1e-3, 'light int grad')

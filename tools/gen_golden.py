@@ -263,6 +263,51 @@ def gen_stage2():
     np.savez_compressed(os.path.join(GOLDEN, 'stage2_brdf.npz'), v=np_(v), n=np_(nn_), l=np_(l), albedo=np_(alb),
                         weights=np_(wts), brdf=np_(rb), spec=np_(rs), rough=np_(rough), l2=np_(l2), mf=np_(mf_r))
 
+    # ---- GGX microfacet render model (train.render_model = microfacet), full PSNetwork + losses + grads
+    conf_m = o2.bear_conf(**{'train.render_model': 'microfacet'})
+    sd_m = stage2_state_dict(conf_m, seed=33)
+    rnet, onet = RPS(conf_m), o2.PSNetwork(conf_m)
+    rnet.load_state_dict(sd_m)
+    onet.load_state_dict(sd_m)
+    N, L, V = 384, 6, 4
+    inp, gt = stage2_inputs(N, L, V, seed=52)
+    ns = int(inp['surface_mask'].sum())
+    torch.manual_seed(78)
+    nz = torch.normal(0, torch.ones(ns, 3) * 0.01)
+    res = []
+    for net, Main, Norm, kw in ((rnet, RMain, RNormal, {}), (onet, o2.MainLoss, o2.NormalLoss, {'noise': {'xyz': nz}})):
+        i2 = {k: v.clone() for k, v in inp.items()}
+        ldir = i2['light_direction'].clone().requires_grad_(True)
+        lint = i2['light_intensity'].clone().requires_grad_(True)
+        i2['light_direction'] = torch.nn.functional.normalize(ldir, p=2, dim=-1)
+        i2['light_intensity'] = lint
+        torch.manual_seed(78)
+        out = net(i2, **kw)
+        t = Main(loss_type='L1', sg_rgb_weight=1.0, albedo_smooth_weight=0.05, rough_smooth_weight=0.01, vis_weight=1)(out, gt, i2)
+        tn = Norm(1, 0.05)(out)
+        total = t['loss'] + tn['loss']
+        total.backward()
+        gr = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+        gr['__light_dir'], gr['__light_int'] = ldir.grad, lint.grad
+        res.append((out, dict(t, total=total, normal_loss=tn['normal_loss']), gr))
+    keys = [k for k in res[0][0] if torch.is_tensor(res[0][0][k]) and res[0][0][k].dtype.is_floating_point]
+    for k in keys:
+        check('microfacet %s' % k, res[1][0][k], res[0][0][k], 2e-6)
+    for k in res[0][1]:
+        if res[0][1][k] is not None:
+            check('microfacet loss %s' % k, res[1][1][k], res[0][1][k], 2e-6)
+    names, norms, projs = grad_digest(res[0][2])
+    _, onorms, oprojs = grad_digest(res[1][2])
+    check('microfacet grad norms', onorms, norms, 2e-5)
+    check('microfacet grad projs', oprojs, projs, 1e-4)
+    lk = sorted(k for k in res[0][1] if res[0][1][k] is not None)
+    np.savez_compressed(
+        os.path.join(GOLDEN, 'stage2_psnet_microfacet.npz'), sd_digest=state_dict_digest(sd_m), N=N, L=L, V=V,
+        input_seed=52, nz_xyz=np_(nz), loss_names=np.array(lk), loss_vals=np.array([float(res[0][1][k]) for k in lk]),
+        grad_names=np.array(names), grad_norms=norms, grad_projs=projs,
+        g_light_dir=np_(res[0][2]['__light_dir']), g_light_int=np_(res[0][2]['__light_int']),
+        **{('out_' + k): np_(res[0][0][k]) for k in keys})
+
     conf = o2.bear_conf()
     sd = stage2_state_dict(conf, seed=31)
     for L in (1, 10):
