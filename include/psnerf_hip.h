@@ -156,14 +156,15 @@ int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* pa
  *   h = normalize(l + v); D_k = exp(max(lobe_k,0) (h.n - 1)); spec_c = max(sum_k w_{c,k} D_k, 0)
  *   rgb = clamp((albedo + spec) * I_l * (l.n) * clamp(vis,0,1), 0, 1)
  * light_dir [L,3]; view/normal/albedo [Ns,3]; weights [Ns, 3*nb] (specular_rgb, channel-major as
- * sgbasis.py:27 view(-1,3,nb)) or [Ns, nb]; lobe [nb<=9]; light_int [L] or NULL (then light_int_scalar);
+ * sgbasis.py:27 view(-1,3,nb)) or [Ns, nb]; lobe [nb<=9]; light_int [L, int_ch] or NULL (then light_int_scalar),
+ * int_ch = 1, or 3 for RGB environment-map lights (stage2/eval.py:200; forward only);
  * vis [L*Ns] or NULL.  rgb [L*Ns,3]; spec [L*Ns,3] (specular_rgb) or [L*Ns].
  * Backward: g_rgb [L*Ns,3], g_spec like spec or NULL -> d_albedo [Ns,3], d_weights like weights,
  * d_normal [Ns,3], d_vis [L*Ns] or NULL, d_light_dir [L,3], d_light_int [L] or NULL;
  * workspace >= ceil(Ns/256)*L*4 floats.
  * ---------------------------------------------------------------------- */
 int psn_sg_shade_fwd(const float* light_dir, const float* view, const float* normal, const float* albedo,
-                     const float* weights, const float* lobe, const float* light_int, float light_int_scalar,
+                     const float* weights, const float* lobe, const float* light_int, int int_ch, float light_int_scalar,
                      const float* vis, int L, int64_t Ns, int nb, int specular_rgb, float* rgb, float* spec,
                      void* stream);
 int psn_sg_shade_bwd(const float* light_dir, const float* view, const float* normal, const float* albedo,

@@ -21,7 +21,8 @@ struct ShadeArgs {
     const float* albedo;      // [Ns,3]
     const float* weights;     // [Ns, nw] (nw = 3*nb if specular_rgb else nb), already relu'd
     const float* lobe;        // [nb]
-    const float* light_int;   // [L] or nullptr (scalar below)
+    const float* light_int;   // [L, int_ch] or nullptr (scalar below); int_ch = 3 for RGB envmap lights (eval.py:200)
+    int int_ch;
     float light_int_scalar;
     const float* vis;         // [L*Ns] or nullptr
     int L, nb, specular_rgb;
@@ -62,11 +63,11 @@ __device__ __forceinline__ void load_point(const ShadeArgs& a, int64_t n, bool o
 
 // forward pieces for one (light, point); returns pre-clamp rgb and everything the backward needs
 struct Fwd {
-    float h[3], inv_norm, hn, D[kMaxBasis], s[3], brdf[3], cosv, vcl, I, pre[3];
+    float h[3], inv_norm, hn, D[kMaxBasis], s[3], brdf[3], cosv, vcl, I[3], pre[3];
 };
 
-__device__ __forceinline__ void shade_one(const ShadeArgs& a, const PointCtx& p, const float l[3], float I, float vis,
-                                          bool has_vis, Fwd& f) {
+__device__ __forceinline__ void shade_one(const ShadeArgs& a, const PointCtx& p, const float l[3], const float I[3],
+                                          float vis, bool has_vis, Fwd& f) {
     float u0 = l[0] + p.v[0], u1 = l[1] + p.v[1], u2 = l[2] + p.v[2];
     float nrm = sqrtf(u0 * u0 + u1 * u1 + u2 * u2);
     float den = fmaxf(nrm, 1e-12f);  // F.normalize eps
@@ -90,11 +91,11 @@ __device__ __forceinline__ void shade_one(const ShadeArgs& a, const PointCtx& p,
     f.s[2] = a.specular_rgb ? s2 : s0;
     f.cosv = l[0] * p.n[0] + l[1] * p.n[1] + l[2] * p.n[2];
     f.vcl = has_vis ? fminf(fmaxf(vis, 0.0f), 1.0f) : 1.0f;
-    f.I = I;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+        f.I[c] = I[c];
         f.brdf[c] = p.alb[c] + fmaxf(f.s[c], 0.0f);
-        float x = f.brdf[c] * I * f.cosv;
+        float x = f.brdf[c] * I[c] * f.cosv;
         if (has_vis) x = x * f.vcl;
         f.pre[c] = x;
     }
@@ -109,7 +110,10 @@ __global__ __launch_bounds__(256) void sg_shade_fwd_kernel(ShadeArgs a, float* _
     const int sc = a.specular_rgb ? 3 : 1;
     for (int l = 0; l < a.L; ++l) {
         float ld[3] = {a.light_dir[l * 3 + 0], a.light_dir[l * 3 + 1], a.light_dir[l * 3 + 2]};
-        float I = a.light_int != nullptr ? a.light_int[l] : a.light_int_scalar;
+        float I[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            I[c] = a.light_int != nullptr ? a.light_int[l * a.int_ch + (a.int_ch == 3 ? c : 0)] : a.light_int_scalar;
         const int64_t row = (int64_t)l * a.Ns + n;
         float vis = (has_vis && ok) ? a.vis[row] : 1.0f;
         Fwd f;
@@ -150,7 +154,10 @@ __global__ __launch_bounds__(256) void sg_shade_bwd_kernel(ShadeArgs a, const fl
 
     for (int l = 0; l < a.L; ++l) {
         float ld[3] = {a.light_dir[l * 3 + 0], a.light_dir[l * 3 + 1], a.light_dir[l * 3 + 2]};
-        float I = a.light_int != nullptr ? a.light_int[l] : a.light_int_scalar;
+        float I[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            I[c] = a.light_int != nullptr ? a.light_int[l * a.int_ch + (a.int_ch == 3 ? c : 0)] : a.light_int_scalar;
         const int64_t row = (int64_t)l * a.Ns + n;
         float vis = (has_vis && ok) ? a.vis[row] : 1.0f;
         Fwd f;
@@ -161,10 +168,10 @@ __global__ __launch_bounds__(256) void sg_shade_bwd_kernel(ShadeArgs a, const fl
             for (int c = 0; c < 3; ++c) {
                 float g = g_rgb[row * 3 + c];
                 float gp = (f.pre[c] >= 0.0f && f.pre[c] <= 1.0f) ? g : 0.0f;  // clamp(0,1) backward (inclusive)
-                float dbrdf = gp * I * f.cosv * f.vcl;
+                float dbrdf = gp * I[c] * f.cosv * f.vcl;
                 dI += gp * f.brdf[c] * f.cosv * f.vcl;
-                dcos += gp * f.brdf[c] * I * f.vcl;
-                dvcl += gp * f.brdf[c] * I * f.cosv;
+                dcos += gp * f.brdf[c] * I[c] * f.vcl;
+                dvcl += gp * f.brdf[c] * I[c] * f.cosv;
                 dalb[c] += dbrdf;
                 float dspec = dbrdf;
                 if (g_spec != nullptr) dspec += a.specular_rgb ? g_spec[row * 3 + c] : (c == 0 ? g_spec[row] : 0.0f);
@@ -519,12 +526,13 @@ __global__ __launch_bounds__(256) void mf_shade_bwd_kernel(MfArgs a, const float
 }
 
 static int fill_args(ShadeArgs& a, const float* light_dir, const float* view, const float* normal, const float* albedo,
-                     const float* weights, const float* lobe, const float* light_int, float light_int_scalar,
+                     const float* weights, const float* lobe, const float* light_int, int int_ch, float light_int_scalar,
                      const float* vis, int L, int64_t Ns, int nb, int specular_rgb) {
     PSN_CHECK_ARG(light_dir && view && normal && albedo && weights && lobe, "sg_shade: null pointer");
     PSN_CHECK_ARG(L >= 1 && Ns >= 0 && nb >= 1 && nb <= kMaxBasis, "sg_shade: L=%d nb=%d", L, nb);
     a.light_dir = light_dir; a.view = view; a.normal = normal; a.albedo = albedo; a.weights = weights; a.lobe = lobe;
-    a.light_int = light_int; a.light_int_scalar = light_int_scalar; a.vis = vis; a.L = L; a.Ns = Ns; a.nb = nb;
+    PSN_CHECK_ARG(int_ch == 1 || int_ch == 3, "sg_shade: light intensity must have 1 or 3 channels");
+    a.light_int = light_int; a.int_ch = int_ch; a.light_int_scalar = light_int_scalar; a.vis = vis; a.L = L; a.Ns = Ns; a.nb = nb;
     a.specular_rgb = specular_rgb ? 1 : 0;
     return PSN_OK;
 }
@@ -532,12 +540,12 @@ static int fill_args(ShadeArgs& a, const float* light_dir, const float* view, co
 }  // namespace psn
 
 extern "C" int psn_sg_shade_fwd(const float* light_dir, const float* view, const float* normal, const float* albedo,
-                                const float* weights, const float* lobe, const float* light_int,
+                                const float* weights, const float* lobe, const float* light_int, int int_ch,
                                 float light_int_scalar, const float* vis, int L, int64_t Ns, int nb, int specular_rgb,
                                 float* rgb, float* spec, void* stream) {
     using namespace psn;
     ShadeArgs a;
-    int rc = fill_args(a, light_dir, view, normal, albedo, weights, lobe, light_int, light_int_scalar, vis, L, Ns, nb, specular_rgb);
+    int rc = fill_args(a, light_dir, view, normal, albedo, weights, lobe, light_int, int_ch, light_int_scalar, vis, L, Ns, nb, specular_rgb);
     if (rc) return rc;
     PSN_CHECK_ARG(rgb && spec, "sg_shade_fwd: null output");
     if (Ns == 0) return PSN_OK;
@@ -554,7 +562,7 @@ extern "C" int psn_sg_shade_bwd(const float* light_dir, const float* view, const
                                 float* workspace, void* stream) {
     using namespace psn;
     ShadeArgs a;
-    int rc = fill_args(a, light_dir, view, normal, albedo, weights, lobe, light_int, light_int_scalar, vis, L, Ns, nb, specular_rgb);
+    int rc = fill_args(a, light_dir, view, normal, albedo, weights, lobe, light_int, 1, light_int_scalar, vis, L, Ns, nb, specular_rgb);
     if (rc) return rc;
     PSN_CHECK_ARG(g_rgb && d_albedo && d_weights && d_normal && d_light_dir && workspace, "sg_shade_bwd: null pointer");
     if (Ns == 0) return PSN_OK;

@@ -53,7 +53,7 @@ SIGNATURES = {
                        i32, c_f, c_f]),
     'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, c_f, c_f]),
-    'psn_sg_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f]),
+    'psn_sg_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f]),
     'psn_sg_shade_bwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f, c_f,
                                c_f, c_f, c_f, c_f, c_f, c_f]),
     'psn_mf_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, f32, f32, c_f, i32, i64, c_f, c_f]),
@@ -250,7 +250,9 @@ def sg_shade_fwd(light_dir, view, normal, albedo, weights, lobe, light_int, ligh
     spec = torch.empty(L * Ns, 3 if specular_rgb else 1, device=view.device, dtype=torch.float32)
     _check(_lib.psn_sg_shade_fwd(_ptr(light_dir, 'light_dir'), _ptr(view, 'view'), _ptr(normal, 'normal'),
                                  _ptr(albedo, 'albedo'), _ptr(weights, 'weights'), _ptr(lobe, 'lobe'),
-                                 _ptr(light_int, 'light_int', True), float(light_int_scalar), _ptr(vis, 'vis', True),
+                                 _ptr(light_int, 'light_int', True),
+                                 1 if light_int is None or light_int.dim() == 1 else light_int.shape[1],
+                                 float(light_int_scalar), _ptr(vis, 'vis', True),
                                  L, Ns, nb, int(bool(specular_rgb)), _ptr(rgb, 'rgb'), _ptr(spec, 'spec'), _stream()),
            'sg_shade_fwd')
     return rgb, spec

@@ -222,8 +222,14 @@ class SGShade(torch.autograd.Function):
     @staticmethod
     def forward(ctx, light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb):
         li_t, li_s = None, 0.0
+        rgb_lights = False
         if torch.is_tensor(light_int):
-            if light_int.numel() > 1:
+            if light_int.dim() == 2 and light_int.shape[1] == 3:  # RGB environment lights (stage2/eval.py:200)
+                if any(ctx.needs_input_grad):
+                    raise RuntimeError('sg_shade: RGB light intensities are supported on the forward-only path')
+                li_t = light_int.contiguous()
+                rgb_lights = True
+            elif light_int.numel() > 1:
                 li_t = light_int.reshape(-1).contiguous()
             else:
                 li_t = light_int.reshape(-1).expand(light_dir.shape[0]).contiguous()

@@ -1,0 +1,101 @@
+"""Environment-map relighting (forward-only reuse of the stage-2 path): SURVEY 8(f1).
+
+Reference: stage2/eval.py:99-112 (16 x 32 lat-long light grid), :173-231 (light batches x pixel chunks,
+sum over lights WITHOUT solid-angle weights, clip), stage2/utils/eval_utils.py:61-99 (gen_light_xyz),
+stage2/utils/general.py:23-52 (split_input / merge_output).  Environment maps are taken as arrays
+([h, 2h, 3] float, already resized); an .npy path is accepted (cv2 / OpenEXR are not dependencies).
+
+On MI355X the 1024-pixel chunking of the reference is unnecessary (activations never reach HBM in the fused
+visibility kernel), so ``pixel_chunk`` defaults to the whole image; the helpers keep the reference's
+signatures for callers that still split.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def gen_light_xyz(envmap_h, envmap_w, envmap_radius=1e2):
+    """Lat-long light directions and solid angles (eval_utils.py:61-99, sph2cart :255-296)."""
+    lat_step = np.pi / (envmap_h + 2)
+    lng_step = 2 * np.pi / (envmap_w + 2)
+    lats = np.linspace(np.pi / 2 - lat_step, -np.pi / 2 + lat_step, envmap_h)
+    lngs = np.linspace(np.pi - lng_step, -np.pi + lng_step, envmap_w)
+    lngs, lats = np.meshgrid(lngs, lats)
+    r = envmap_radius * np.ones_like(lats)
+    xyz = np.stack((r * np.cos(lats) * np.cos(lngs), r * np.cos(lats) * np.sin(lngs), r * np.sin(lats)), axis=-1)
+    sin_colat = np.sin(np.pi / 2 - lats)
+    areas = 4 * np.pi * sin_colat / np.sum(sin_colat)
+    return xyz.reshape(envmap_h, envmap_w, 3), areas
+
+
+def load_light(path_or_array, light_h=None):
+    """[h, 2h, 3] float32 environment map from an array or .npy file; block-averaged down to light_h rows."""
+    arr = np.load(path_or_array) if isinstance(path_or_array, str) else np.asarray(path_or_array)
+    arr = arr.astype(np.float32)
+    if light_h and arr.shape[0] != light_h:
+        t = torch.from_numpy(arr).permute(2, 0, 1)[None]
+        arr = F.interpolate(t, size=(light_h, 2 * light_h), mode='bilinear', align_corners=False)[0].permute(1, 2, 0).numpy()
+    return arr
+
+
+PIXEL_KEYS = ('uv', 'object_mask', 'gt_normal', 'normal', 'depth', 'points', 'surface_mask', 'visibility')
+
+
+def split_input(model_input, total_pixels, n_pixels=1024):
+    """general.py:23-37 (device-agnostic)."""
+    dev = model_input['uv'].device
+    out = []
+    for idx in torch.split(torch.arange(total_pixels, device=dev), n_pixels, dim=0):
+        data = dict(model_input)
+        for k in PIXEL_KEYS:
+            if k in model_input:
+                data[k] = torch.index_select(model_input[k], 1, idx)
+        out.append(data)
+    return out
+
+
+def merge_output(res, total_pixels, batch_size):
+    """general.py:39-52."""
+    merged = {}
+    for k in res[0]:
+        if res[0][k] is None:
+            continue
+        if res[0][k].dim() < 3:
+            merged[k] = torch.cat([r[k].reshape(batch_size, -1, 1) for r in res], 1).reshape(batch_size * total_pixels)
+        else:
+            merged[k] = torch.cat([r[k].reshape(*r[k].shape[:-2], -1, r[k].shape[-1]) for r in res], -2) \
+                .reshape(-1, res[0][k].shape[-1])
+    return merged
+
+
+@torch.no_grad()
+def render_envmap(model, model_input, env_light, light_h=16, light_batch=64, pixel_chunk=None, envmap_scale=1.0,
+                  visibility=False):
+    """Relit image of one view: sum over the light_h x 2 light_h environment lights (eval.py:199-218).
+
+    model_input: uv [1,N,2], intrinsics, pose, object_mask, normal, points, surface_mask (no lights).
+    env_light: [light_h, 2*light_h, 3].  Returns rgb [N,3] (clipped to [0,1]) and, if requested, the
+    light-averaged visibility [N,3]."""
+    dev = model_input['uv'].device
+    n_pix = model_input['uv'].shape[1]
+    lxyz, _areas = gen_light_xyz(light_h, 2 * light_h, envmap_radius=1)
+    lxyz = torch.from_numpy(lxyz.reshape(-1, 3)).float().to(dev)
+    env = torch.as_tensor(np.asarray(env_light, dtype=np.float32).reshape(-1, 3) * envmap_scale, device=dev)
+    rgb_sum = torch.zeros(n_pix, 3, device=dev)
+    vis_sum = torch.zeros(n_pix, 3, device=dev)
+    n_lights = lxyz.shape[0]
+    for l0 in range(0, n_lights, light_batch):
+        mi = dict(model_input)
+        mi['light_direction'] = F.normalize(lxyz[l0:l0 + light_batch], p=2, dim=-1)
+        mi['light_intensity'] = env[l0:l0 + light_batch].contiguous()
+        chunks = [mi] if pixel_chunk is None else split_input(mi, n_pix, pixel_chunk)
+        p0 = 0
+        for s in chunks:
+            out = model(s)
+            n = s['uv'].shape[1]
+            rgb_sum[p0:p0 + n] += out['sg_rgb_values'].reshape(-1, n, 3).sum(0)
+            if visibility:
+                vis_sum[p0:p0 + n] += out.get('visibility', torch.ones_like(out['sg_rgb_values'])).reshape(-1, n, 3).sum(0)
+            p0 += n
+    rgb = rgb_sum.clamp(0, 1)
+    return (rgb, vis_sum / n_lights) if visibility else rgb

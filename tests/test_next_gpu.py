@@ -1,0 +1,104 @@
+"""envmap relight eval, stage1->stage2 hand-off, checkpoint compatibility (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close, stage1_state_dict, stage2_state_dict, stage1_cfg
+from psnerf_amd.synthetic import stage2_inputs, stage1_camera
+
+pytestmark = pytest.mark.gpu
+
+
+def test_envmap_relight_vs_oracle(cuda):
+    """16x32-style lat-long relighting (here 4x8 lights) with RGB light intensities, summed over lights."""
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.stage2 import relight
+    from oracle import stage2 as o2
+    sd = stage2_state_dict(o2.bear_conf(), seed=12)
+    onet = o2.PSNetwork(o2.bear_conf())
+    onet.load_state_dict(sd)
+    net = s2.PSNetwork(s2.bear_conf())
+    net.load_state_dict(sd)
+    net.to(cuda).eval()
+    N, lh = 700, 4
+    inp, _ = stage2_inputs(N, 1, 1, seed=3)
+    base = {k: inp[k] for k in ('uv', 'intrinsics', 'pose', 'object_mask', 'normal', 'points', 'surface_mask')}
+    env = np.random.RandomState(0).rand(lh, 2 * lh, 3).astype(np.float32) * 0.2
+    lxyz, _ = relight.gen_light_xyz(lh, 2 * lh, envmap_radius=1)
+    with torch.no_grad():
+        ref = torch.zeros(N, 3)
+        mi = dict(base)
+        mi['light_direction'] = torch.nn.functional.normalize(torch.from_numpy(lxyz.reshape(-1, 3)).float(), dim=-1)
+        mi['light_intensity'] = torch.from_numpy(env.reshape(-1, 3))
+        ref = onet(mi)['sg_rgb_values'].sum(0).clamp(0, 1)
+    base_d = {k: v.to(cuda) for k, v in base.items()}
+    out = relight.render_envmap(net, base_d, env, light_h=lh, light_batch=5)
+    assert_close(out.cpu(), ref, 1e-4, 'relit rgb')
+    out2, vis = relight.render_envmap(net, base_d, env, light_h=lh, light_batch=32, pixel_chunk=256, visibility=True)
+    assert_close(out2.cpu(), ref, 1e-4, 'relit rgb (chunked)')
+    assert vis.shape == (N, 3)
+
+
+def test_handoff_roundtrip_and_checkpoints(cuda, tmp_path):
+    """stage-1 shape export in the reference's npy layout, read back as stage-2 inputs; stage-1 / stage-2
+    checkpoints in the reference's file formats."""
+    from psnerf_amd import handoff, checkpoints
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer
+    import psnerf_amd.stage2 as s2
+    from oracle import stage1 as o1
+    cfg = stage1_cfg('bunny')
+    net = NeuralNetwork(cfg)
+    net.load_state_dict(stage1_state_dict(cfg, seed=11))
+    ren = Renderer(net, cfg, device=cuda)
+    h = w = 24
+    K, c2w, S = stage1_camera(cfg, h=h, w=w)
+    ldir = torch.nn.functional.normalize(torch.randn(3, 3, generator=torch.Generator().manual_seed(0)), dim=-1)
+    pdir = torch.nn.functional.normalize(torch.randn(2, 3, generator=torch.Generator().manual_seed(1)), dim=-1)
+    out_dir = str(tmp_path / 'shape')
+    mask = handoff.export_view(ren, K.to(cuda), c2w.to(cuda), S.to(cuda), h, w, out_dir, 3, light_dir=ldir.to(cuda),
+                               vis_plus_dir=pdir.to(cuda), chunk=200)
+    assert mask.shape == (h, w) and mask.any()
+    view = handoff.load_view(out_dir, 3)
+    assert view['points'].shape == (1, h * w, 3) and view['surface_mask'].shape == (1, h * w)
+    assert view['visibility'].shape == (3, h * w) and view['vis_plus'].shape == (2, h * w)
+    assert_close(view['vis_plus_light'], pdir, 1e-6, 'vis_plus dirs')
+    # the oracle's shape_extract on the same pixel grid, mapped through the reference's to_hw
+    onet = o1.NeuralNetwork(cfg)
+    onet.load_state_dict(stage1_state_dict(cfg, seed=11))
+    pix = handoff.arange_pixels(h, w, 'cpu').float()
+    o = o1.Renderer(onet, cfg)(pix, K, c2w, S, 'shape_extract', visibility=True, light_dir=torch.cat([ldir, pdir]))
+    assert_close(view['points'].reshape(h, w, 3), handoff.to_hw(o['points'], h, w), 1e-4, 'points')
+    assert np.array_equal(view['surface_mask'].reshape(h, w).numpy(), handoff.to_hw(o['mask'], h, w)[..., 0].numpy())
+    v_ref = o['visibility'][:3].numpy().reshape(3, h, w).transpose(0, 2, 1).reshape(3, -1)
+    assert_close(view['visibility'], v_ref, 1e-4, 'visibility')
+
+    # stage-1 checkpoint file (reference format) round trip
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    io = checkpoints.CheckpointIO(str(tmp_path / 'models'), model=net, optimizer=opt)
+    io.save('model.pt', epoch_it=3, it=1234, loss_val_best=0.5)
+    raw = torch.load(str(tmp_path / 'models' / 'model.pt'))
+    assert set(raw.keys()) == {'model', 'optimizer', 'epoch_it', 'it', 'loss_val_best'}
+    onet2 = o1.NeuralNetwork(cfg)
+    onet2.load_state_dict(raw['model'])  # a reference-keyed module loads our file
+    net2 = NeuralNetwork(cfg)
+    io2 = checkpoints.CheckpointIO(str(tmp_path / 'models'), model=net2)
+    scalars = io2.load('model.pt')
+    assert scalars['it'] == 1234 and scalars['epoch_it'] == 3
+    with pytest.raises(FileExistsError):
+        io2.load('missing.pt')
+    # stage-2 directory layout round trip
+    conf = s2.bear_conf()
+    m = s2.PSNetwork(conf).to(cuda)
+    step = s2.TrainStep(m, conf, 8, torch.nn.functional.normalize(torch.randn(8, 3), dim=-1).to(cuda), cuda)
+    ck = str(tmp_path / 'ckpt')
+    checkpoints.save_stage2(step, ck, epoch=7)
+    for sub in ('ModelParameters', 'SGOptimizerParameters', 'SGSchedulerParameters', 'OptimizerLightParameters', 'LightParameters'):
+        assert os.path.exists(os.path.join(ck, sub, '7.pth')) and os.path.exists(os.path.join(ck, sub, 'latest.pth'))
+    m2 = s2.PSNetwork(conf).to(cuda)
+    step2 = s2.TrainStep(m2, conf, 8, torch.zeros(8, 3).to(cuda), cuda)
+    assert checkpoints.load_stage2(step2, ck, 'latest') == 7
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert torch.equal(step.light_para.weight, step2.light_para.weight)
