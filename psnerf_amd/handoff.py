@@ -53,19 +53,19 @@ def export_view(renderer, camera_mat, world_mat, scale_mat, h, w, out_dir, view_
     for sub in ('points', 'normal', 'mask', 'visibility', 'vis_plus'):
         os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
     mask_all = to_hw(torch.cat(masks, dim=1), h, w).cpu().numpy()[..., 0]
-    np.save(os.path.join(out_dir, 'points', name), to_hw(torch.cat(points, dim=1), h, w).cpu().numpy().astype(np.float32))
-    np.save(os.path.join(out_dir, 'normal', name), to_hw(torch.cat(normals, dim=1), h, w).cpu().numpy().astype(np.float32))
-    np.save(os.path.join(out_dir, 'mask', name), mask_all.astype(bool))
+    np.save(os.path.join(out_dir, 'points', name), np.ascontiguousarray(to_hw(torch.cat(points, dim=1), h, w).cpu().numpy().astype(np.float32)))
+    np.save(os.path.join(out_dir, 'normal', name), np.ascontiguousarray(to_hw(torch.cat(normals, dim=1), h, w).cpu().numpy().astype(np.float32)))
+    np.save(os.path.join(out_dir, 'mask', name), np.ascontiguousarray(mask_all.astype(bool)))
     if lights is not None:
         v = torch.cat(vis, dim=1).cpu().numpy()
         # NOTE reference quirk reproduced verbatim (shape_extract.py:157): reshape(L, h, w).transpose(0, 2, 1) on
         # the x-major pixel list.  It equals the correct un-flattening only for square images.
         np.save(os.path.join(out_dir, 'visibility', name),
-                v[:n_ori].reshape(n_ori, h, w).transpose(0, 2, 1).astype(np.float32))
+                np.ascontiguousarray(v[:n_ori].reshape(n_ori, h, w).transpose(0, 2, 1).astype(np.float32)))
         if vis_plus_dir is not None:
             n_plus = vis_plus_dir.shape[0]
             np.save(os.path.join(out_dir, 'vis_plus', name),
-                    v[n_ori:].reshape(n_plus, h, w).transpose(0, 2, 1).astype(np.float32))
+                    np.ascontiguousarray(v[n_ori:].reshape(n_plus, h, w).transpose(0, 2, 1).astype(np.float32)))
             jpath = os.path.join(out_dir, 'vis_plus', 'light_dir.json')
             table = json.load(open(jpath)) if os.path.exists(jpath) else {}
             table['view_{:02d}'.format(view_id)] = vis_plus_dir.cpu().numpy().astype(np.float32).tolist()
@@ -80,9 +80,9 @@ def load_view(shape_dir, view_id, device='cpu', with_visibility=True):
     name = 'view_{:02d}.npy'.format(view_id)
     pts = np.load(os.path.join(shape_dir, 'points', name))
     out = {
-        'points': torch.from_numpy(pts.astype(np.float32)).view(1, -1, 3).to(device),
-        'normal': torch.from_numpy(np.load(os.path.join(shape_dir, 'normal', name)).astype(np.float32)).view(1, -1, 3).to(device),
-        'surface_mask': torch.from_numpy(np.load(os.path.join(shape_dir, 'mask', name))).view(1, -1).to(device),
+        'points': torch.from_numpy(pts.astype(np.float32)).reshape(1, -1, 3).to(device),
+        'normal': torch.from_numpy(np.load(os.path.join(shape_dir, 'normal', name)).astype(np.float32)).reshape(1, -1, 3).to(device),
+        'surface_mask': torch.from_numpy(np.load(os.path.join(shape_dir, 'mask', name))).reshape(1, -1).to(device),
         'img_res': list(pts.shape[:2]),
     }
     vpath = os.path.join(shape_dir, 'visibility', name)
