@@ -150,43 +150,54 @@ class PSNetwork(nn.Module):
 
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, input, albedo_new=None, basis_new=None, noise=None):
+        """Same inputs / outputs as the reference forward (renderer.py:110-266).  The reference gathers and
+        scatters with boolean masks (``x[surface_mask]``, ``dense[mask.expand(L,-1)] = v``), each of which costs a
+        nonzero() + host sync on a GPU; here the surface index list is computed once and every gather / scatter
+        is an index_select / index_copy with it (identical element order: ascending pixel index, light-major)."""
         noise = noise or {}
         uv, pose, intr = input['uv'], input['pose'], input['intrinsics']
         object_mask = input['object_mask']
         device = uv.device
         ray_dirs, _ = camera_rays(uv, pose, intr)
         surface_mask, points, normals = input['surface_mask'], input['points'], input['normal']
-        surf = points[surface_mask].contiguous()
-        ns = surf.shape[0]
+        idx = surface_mask[0].nonzero(as_tuple=True)[0]  # the one data-dependent sync of the forward
+        ns = idx.shape[0]
 
+        def gather(t):  # [1,N,C] -> [Ns,C]
+            return t[0].index_select(0, idx)
+
+        def scatter(dense, rows):  # dense [B,N,C] (constant fill), rows [B*Ns,C] light-major -> dense with rows at idx
+            return dense.index_copy(1, idx, rows.reshape(dense.shape[0], ns, rows.shape[-1]))
+
+        surf = gather(points).contiguous()
         out_n = {}
+        normal_s = None
         if self.normal_mlp:  # renderer.py:127-143
             normal_pred = torch.ones_like(points)
             if ns > 0:
                 cols_n = self._cols(self.n_freqs_n, device)
-                normal_pred[surface_mask] = F.normalize(self.normal_net(self._pe(surf, self.n_freqs_n), cols_n), dim=-1)
+                normal_s = F.normalize(self.normal_net(self._pe(surf, self.n_freqs_n), cols_n), dim=-1)
+                normal_pred = scatter(normal_pred, normal_s)
                 if self.normal_jitter_std > 0:
                     nz = noise.get('normal')
                     if nz is None:
                         nz = torch.normal(0, torch.ones_like(surf) * self.normal_jitter_std)
-                    nj = torch.ones_like(points)
-                    nj[surface_mask] = F.normalize(self.normal_net(self._pe(surf + nz, self.n_freqs_n), cols_n), dim=-1)
-                    out_n['normal_jitter'] = nj
+                    nj = F.normalize(self.normal_net(self._pe(surf + nz, self.n_freqs_n), cols_n), dim=-1)
+                    out_n['normal_jitter'] = scatter(torch.ones_like(points), nj)
             out_n['normal_pred'] = normal_pred
 
         sg = self.render_model == 'sgbasis'
         lnum = input['light_direction'].shape[0]
         rgb_values = torch.ones_like(points).repeat(lnum, 1, 1) if lnum > 1 else torch.ones_like(points)
         albedo_values = torch.ones_like(points)
-        rough_values = rgb_values.clone() if sg else torch.ones_like(points)
+        rough_values = torch.ones_like(rgb_values) if sg else torch.ones_like(points)
         weight_values = torch.zeros(*points.shape[:-1], self.nbasis, device=device) if sg else None
-        vis_values = rgb_values.clone()
+        vis_values = torch.ones_like(rgb_values)
         jitter = None
         pe_x = None
         if ns > 0:
-            normal = normals[surface_mask] if not self.normal_mlp else normal_pred[surface_mask]
-            pts2c = -ray_dirs[surface_mask]
-            mask_l = surface_mask.expand(lnum, -1)
+            normal = gather(normals) if not self.normal_mlp else normal_s
+            pts2c = -gather(ray_dirs)
             light_dir = input['light_direction']
             cols = self._cols(self.n_freqs, device)
             pe_x = self._pe(surf, self.n_freqs)
@@ -203,7 +214,7 @@ class PSNetwork(nn.Module):
                     else:
                         wn.view(-1, 1, self.nbasis)[:, :, basis_new] = 2 ** basis_new / 100
                     weights = wn.reshape(-1, self.nbasis)
-                weight_values[surface_mask] = weights
+                weight_values = scatter(weight_values, weights)
             light_int = input.get('light_intensity', self.light_int)
             vis = None
             vis_for_rgb = None
@@ -217,28 +228,25 @@ class PSNetwork(nn.Module):
                                          vis_for_rgb, self.specular_rgb)
             else:
                 rgb = ops.mf_shade(light_dir, pts2c, normal, albedo, rough, light_int, vis_for_rgb, self.f0)
-            rgb_values[mask_l] = rgb
+            rgb_values = scatter(rgb_values, rgb)
             if vis is not None:
-                vis_values[mask_l] = vis.expand(rgb.shape)
-            albedo_values[surface_mask] = albedo
+                vis_values = scatter(vis_values, vis.expand(rgb.shape))
+            albedo_values = scatter(albedo_values, albedo)
             if sg:
-                rough_values[mask_l] = spec.expand(-1, 3)
+                rough_values = scatter(rough_values, spec.expand(-1, 3))
             else:
-                rough_values[surface_mask] = rough.expand(-1, 3)
+                rough_values = scatter(rough_values, rough.expand(-1, 3))
             if self.xyz_jitter_std > 0:  # renderer.py:211-231
                 nz = noise.get('xyz')
                 if nz is None:
                     nz = torch.normal(0, torch.ones_like(surf) * self.xyz_jitter_std)
                 pe_j = self._pe(surf + nz, self.n_freqs)
-                aj = torch.ones_like(points)
-                aj[surface_mask] = self.albedo_net(pe_j, cols)
+                aj = scatter(torch.ones_like(points), self.albedo_net(pe_j, cols))
                 if sg:
-                    rj = torch.ones_like(weight_values)
-                    rj[surface_mask] = F.relu(self.rough_net(pe_j, cols))
+                    rj = scatter(torch.ones_like(weight_values), F.relu(self.rough_net(pe_j, cols)))
                     r_ori = weight_values
                 else:
-                    rj = torch.ones_like(points)
-                    rj[surface_mask] = self.rough_net(pe_j, cols).expand(-1, 3)
+                    rj = scatter(torch.ones_like(points), self.rough_net(pe_j, cols).expand(-1, 3))
                     r_ori = rough_values
                 jitter = {'albedo_values': albedo_values, 'albedo_jitter': aj,
                           'rough_values': r_ori, 'rough_jitter': rj}
@@ -261,7 +269,7 @@ class PSNetwork(nn.Module):
                 if ns > 0:
                     train = torch.is_grad_enabled() and any(p.requires_grad for p in self.visibility_net.parameters())
                     vis_t = self._visibility_rows(pe_x, lv, fused_ok=not train)
-                    vt[surface_mask.expand(vnum, -1)] = vis_t.expand(-1, 3)
+                    vt = scatter(vt, vis_t.expand(-1, 3))
                 out['vis_train'] = vt
         if sg:
             out['sg_weight'] = weight_values
