@@ -77,6 +77,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--pixels', type=int, default=N_PIXELS, help='pixels per GPU (default: the benchmark config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo for 1-GPU dry runs)')
+    ap.add_argument('--single-device', action='store_true', help='dry run: every rank uses cuda:0')
     args = ap.parse_args()
 
     import torch
@@ -84,7 +86,9 @@ def main():
     from psnerf_amd import dist as pdist, hip
     from psnerf_amd.synthetic import stage2_inputs
 
-    rank, local, world = pdist.init_from_env()
+    rank, local, world = pdist.init_from_env(backend=args.backend, set_device=not args.single_device)
+    if args.single_device:
+        local = 0
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)' % (args.gpus, world))
     device = torch.device('cuda', local)

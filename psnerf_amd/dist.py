@@ -25,7 +25,6 @@ class DataParallel(object):
         self.world = dist.get_world_size() if self.enabled else 1
         self.rank = dist.get_rank() if self.enabled else 0
         self.device = device
-        self._count_cache = {}
 
     # ---- sharding -------------------------------------------------------------------------------
     def slice_bounds(self, n):
@@ -53,17 +52,15 @@ class DataParallel(object):
 
     # ---- loss denominators ----------------------------------------------------------------------
     def new_step(self):
-        self._count_cache = {}
+        pass
 
     def global_count(self, mask):
-        """Number of True elements of ``mask`` summed over ranks (python int, cached per step)."""
-        key = (mask.data_ptr(), tuple(mask.shape))
-        if key not in self._count_cache:
-            c = mask.sum().to(torch.int64).reshape(1)
-            if self.enabled:
-                dist.all_reduce(c, op=dist.ReduceOp.SUM)
-            self._count_cache[key] = int(c.item())
-        return self._count_cache[key]
+        """Number of True elements of ``mask`` summed over ranks (python int).  Every rank must call this the
+        same number of times per step (it is a collective): callers compute it once and pass the value on."""
+        c = mask.sum().to(torch.int64).reshape(1)
+        if self.enabled:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        return int(c.item())
 
     def global_sum_int(self, value):
         t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
@@ -115,7 +112,7 @@ class DataParallel(object):
             dist.barrier()
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, set_device=True):
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1:
@@ -126,7 +123,7 @@ def init_from_env(backend=None):
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
+    if backend == 'nccl' and set_device:
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -33,11 +33,14 @@ class MainLoss(nn.Module):
     def _img(self, a, b):
         return (a - b).abs() if self.loss_type == 'L1' else (a - b) ** 2
 
-    def forward(self, model_outputs, ground_truth, model_input=None):
+    def forward(self, model_outputs, ground_truth, model_input=None, count=None):
+        """``count``: number of pixels in (network_object_mask & object_mask), summed over ranks under data
+        parallelism; computed here (one host sync) when the caller does not supply it."""
         m, om = model_outputs['network_object_mask'], model_outputs['object_mask']
         mask = m & om  # [1,N]
         dev = mask.device
-        count = int(mask.sum()) if self.global_count is None else self.global_count(mask)
+        if count is None:
+            count = int(mask.sum()) if self.global_count is None else self.global_count(mask)
         zero = torch.tensor(0.0, device=dev)
         rgb_gt = ground_truth['rgb'].to(dev)
         L = rgb_gt.shape[0]
@@ -83,11 +86,12 @@ class NormalLoss(nn.Module):
         self.normal_weight, self.normal_smooth_weight = normal_weight, normal_smooth_weight
         self.global_count = None
 
-    def forward(self, model_outputs):
+    def forward(self, model_outputs, count=None):
         gt = F.normalize(model_outputs['normal_values'], dim=-1)
         mask = model_outputs['network_object_mask'] & model_outputs['object_mask']
         dev = mask.device
-        count = int(mask.sum()) if self.global_count is None else self.global_count(mask)
+        if count is None:
+            count = int(mask.sum()) if self.global_count is None else self.global_count(mask)
         zero = torch.tensor(0.0, device=dev)
         if count == 0:
             n_loss = zero

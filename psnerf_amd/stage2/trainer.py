@@ -72,8 +72,10 @@ class TrainStep(object):
         model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
         model_input['light_intensity'] = self.light_inten_para(l_slt)
         out = self.model(model_input, noise=noise)
-        terms = dict(self.loss(out, ground_truth, model_input))
-        terms_n = self.loss_n(out)
+        # ONE mask count per step (a tiny all-reduce under data parallelism), shared by every loss term
+        count = self.dp.global_count(out['network_object_mask'] & out['object_mask'])
+        terms = dict(self.loss(out, ground_truth, model_input, count=count))
+        terms_n = self.loss_n(out, count=count)
         loss = terms['loss'] + terms_n['loss']
         self.sg_optimizer.zero_grad()
         train_light = self.light_para.weight.requires_grad
