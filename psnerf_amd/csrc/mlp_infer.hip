@@ -37,6 +37,7 @@ struct InferArgs {
     const float* init_b;
     int64_t n_rows;
     float* out;
+    int n_bias;  // floats in the packed bias buffer (copied to LDS once per workgroup)
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -67,17 +68,22 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[16], const floatx4&
     }
 }
 
-// LDS-DMA one stage (n_blocks x 1 KB) of packed weights; the 8 waves split the blocks.
-__device__ __forceinline__ void stage_load(const float* __restrict__ gsrc, float* lds_dst, int n_blocks, int wave,
-                                           int lane) {
-    for (int blk = wave; blk < n_blocks; blk += kWaves) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + blk * 256 + lane * 4),
-                                         (__attribute__((address_space(3))) void*)(lds_dst + blk * 256), 16, 0, 0);
+// LDS-DMA one stage (NBLK x 1 KB) of packed weights; the 4 waves split the blocks (compile-time trip count, no
+// kernarg reloads inside the stage: an s_load there forces s_waitcnt lgkmcnt(0), which also drains the LDS reads).
+template <int NBLK>
+__device__ __forceinline__ void stage_load(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < (NBLK + kWaves - 1) / kWaves; ++i) {
+        const int blk = wave + i * kWaves;
+        if (NBLK % kWaves == 0 || blk < NBLK)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + blk * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(lds_dst + blk * 256), 16, 0, 0);
     }
 }
 
 __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages + all biases
+    float* bias_lds = smem + 2 * kStageFloats;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 15, lg = lane >> 4;
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     {  // prefetch the first weight stage (layer 0 may be evaluated entirely through the init tables)
         const int l0 = (g.d.layers[0].n_kt_in + g.d.layers[0].n_kt_act > 0) ? 0 : 1;
         const PsnMlpLayer& L0 = g.d.layers[l0];
-        stage_load(g.w + L0.w_off, smem, 4 * L0.n_mt, wave, lane);
+        stage_load<32>(g.w + L0.w_off, smem, wave, lane);
     }
 
     // ---- input features -> registers (MFMA B-operand layout): 16-feature tile t, register r = feature 16t+4g+r
@@ -114,6 +120,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         }
     }
 
+    for (int i = tid; i < g.n_bias; i += kWaves * 64) bias_lds[i] = g.b[i];  // visible after the first stage barrier
+
     floatx4 act[16];
     floatx4 acc[16];
 #pragma unroll
@@ -133,10 +141,9 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         const int s_ = (S_IDX);                                                                             \
         float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
         if (s_ + 1 < n_st) {                                                                                \
-            stage_load(wl_g + (int64_t)(s_ + 1) * stage_floats, nxt, 2 * (NMT), wave, lane);                \
-        } else if (li + 1 < n_layers) {                                                                     \
-            const PsnMlpLayer& Ln = g.d.layers[li + 1];                                                     \
-            stage_load(g.w + Ln.w_off, nxt, 4 * Ln.n_mt, wave, lane);                                       \
+            stage_load<2 * (NMT)>(wl_g + (int64_t)(s_ + 1) * stage_floats, nxt, wave, lane);                \
+        } else if (next_w != nullptr) {                                                                     \
+            stage_load<32>(next_w, nxt, wave, lane);                                                        \
         }                                                                                                   \
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);             \
         stage_compute<NMT>(acc, B0, B1, wl, lane);                                                          \
@@ -149,8 +156,10 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         const int n_st = L.n_kt_in + L.n_kt_act;
         const int stage_floats = 8 * 1024;
         const float* wl_g = g.w + L.w_off;
+        const float* next_w = g.w + g.d.layers[li + 1].w_off;  // li + 1 <= n_layers - 1 inside this loop
         {  // bias -> accumulator init
-            const float* bp = g.b + L.b_off;
+            const float* bp = bias_lds + L.b_off;
+            if (li == 0) __syncthreads();  // bias_lds written above
 #pragma unroll
             for (int mt = 0; mt < 16; ++mt) {
                 float4 bv = *reinterpret_cast<const float4*>(bp + mt * 16 + 4 * lg);
@@ -205,12 +214,9 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             }
         }
     }
-    {  // final layer: 32 (padded) outputs = two 16-wide tiles
+    {  // final layer: 32 (padded) outputs = two 16-wide tiles; all 8 k-tiles arrive as ONE 32 KB stage
         const PsnMlpLayer L = g.d.layers[li];
-        const int n_st = L.n_kt_in + L.n_kt_act;
-        const int stage_floats = 1024;
-        const float* wl_g = g.w + L.w_off;
-        const float* bp = g.b + L.b_off;
+        const float* bp = bias_lds + L.b_off;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             float4 bv = *reinterpret_cast<const float4*>(bp + mt * 16 + 4 * lg);
@@ -219,14 +225,11 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             acc[mt][2] = bv.z;
             acc[mt][3] = bv.w;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            if (kt < L.n_kt_in) PSN_STAGE(2, xin[2 * kt], xin[2 * kt + 1], kt)
-        }
-        if (L.n_kt_act > 0) {
-#pragma unroll
-            for (int kt = 0; kt < 8; ++kt) PSN_STAGE(2, act[2 * kt], act[2 * kt + 1], L.n_kt_in + kt)
-        }
+        for (int kt = 0; kt < 8; ++kt) stage_compute<2>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane);
     }
 #undef PSN_STAGE
 
@@ -307,6 +310,8 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         const bool last = l == d.n_layers - 1;
         PSN_CHECK_ARG(L.n_mt == (last ? 1 : 8), "mlp_infer: layer %d n_mt=%d (hidden layers are 256 wide, final <= 32)", l, L.n_mt);
         PSN_CHECK_ARG(L.n_kt_in >= 0 && L.n_kt_in <= d.in_kt_a + d.in_kt_b, "mlp_infer: layer %d n_kt_in=%d", l, L.n_kt_in);
+        PSN_CHECK_ARG(!last || (L.n_kt_in == 0 && L.n_kt_act == 8), "mlp_infer: the final layer reads the 256 activations only");
+        PSN_CHECK_ARG(L.b_off == (int64_t)l * 256, "mlp_infer: biases must be packed back to back (256 floats per hidden layer)");
         PSN_CHECK_ARG(L.n_kt_act == 0 || L.n_kt_act == 8, "mlp_infer: layer %d n_kt_act=%d", l, L.n_kt_act);
         PSN_CHECK_ARG(l > 0 || L.n_kt_act == 0, "mlp_infer: layer 0 cannot read activations");
         PSN_CHECK_ARG(L.n_kt_in + L.n_kt_act >= 1 || (l == 0 && L.init_off >= 0 && d.n_layers > 1), "mlp_infer: layer %d has no input", l);
@@ -318,10 +323,11 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     a.d = d; a.w = packed_w; a.b = packed_b; a.ta = tab_a; a.a_div = a_div; a.a_mod = a_mod;
     a.tb = tab_b; a.b_div = b_div > 0 ? b_div : 1; a.b_mod = b_mod > 0 ? b_mod : 1; a.n_rows = n_rows; a.out = out;
     a.init_a = init_a; a.init_b = init_b;
+    a.n_bias = (d.n_layers - 1) * 256 + 32;
     const int rows_per_block = kWaves * 16;
     int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer: too many rows");
-    hipLaunchKernelGGL(mlp_infer_kernel, dim3((unsigned)blocks), dim3(kWaves * 64), 2 * kStageFloats * sizeof(float),
+    hipLaunchKernelGGL(mlp_infer_kernel, dim3((unsigned)blocks), dim3(kWaves * 64), (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float),
                        (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer");
     return PSN_OK;
