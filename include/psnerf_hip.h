@@ -145,10 +145,15 @@ int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_tiles, float
  * can be precomputed once per table row instead of once per (A,B) pair: init_a / init_b
  * ([rows, init_stride], indexed like tab_a / tab_b; init_b may be NULL) hold those partial products and the
  * layers with init_off >= 0 start their accumulators from them (tab_a may then be NULL if no layer has n_kt_in > 0).
+ * save_ptrs (HOST array of n_layers-1 device pointers, entries or the array itself may be NULL): for rows >=
+ * save_row0 the post-activation output of hidden layer l is also written row-major to save_ptrs[l]
+ * [n_rows - save_row0, 256] -- the training rows of stage2/model/renderer.py:251-262 ride along with the
+ * gradient-free rows and leave exactly what their backward pass needs.
  * out [n_rows, n_out]. */
 int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                   int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
-                  const float* init_a, const float* init_b, int64_t n_rows, float* out, void* stream);
+                  const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
+                  int64_t n_rows, float* out, void* stream);
 
 /* ------------------------------------------------------------------------
  * Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n:

@@ -38,6 +38,8 @@ struct InferArgs {
     int64_t n_rows;
     float* out;
     int n_bias;  // floats in the packed bias buffer (copied to LDS once per workgroup)
+    float* save[PSN_MLP_MAX_LAYERS];  // per hidden layer: row-major [n_rows - save_row0, 256] activation dump, or nullptr
+    int64_t save_row0;                // rows >= save_row0 are dumped (training rows ride along with inference rows)
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -133,10 +135,14 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     // that the accumulators never meet a control-flow merge between differently shaped code paths (which
     // makes hipcc shuttle every accumulator register between VGPRs and AGPRs per stage).
     int gstage = 0;  // global stage counter -> LDS buffer parity
+    bool pending_dump = false;  // 16 activation-dump stores were issued after the last LDS-DMA batch
+    const bool dump_row = row < g.n_rows && row >= g.save_row0;
 
 #define PSN_STAGE(NMT, B0, B1, S_IDX)                                                                       \
     {                                                                                                       \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's LDS-DMA pieces have landed */        \
+        /* this wave's LDS-DMA pieces have landed; activation dumps issued after them may stay in flight */ \
+        if (pending_dump) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); pending_dump = false; }      \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
         __syncthreads(); /* every wave's pieces landed; the other buffer is no longer being read */         \
         const int s_ = (S_IDX);                                                                             \
         float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
@@ -213,6 +219,17 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                 act[mt][r] = a;
             }
         }
+        // training rows: dump this layer's activations row-major for the backward pass.  The 16 stores are
+        // issued behind the already-requested next weight stage and complete under the next layer's MFMAs.
+        if (g.save[li] != nullptr) {
+            if (dump_row) {
+                float* dst = g.save[li] + (row - g.save_row0) * 256 + 4 * lg;
+#pragma unroll
+                for (int mt = 0; mt < 16; ++mt)
+                    *reinterpret_cast<float4*>(dst + mt * 16) = make_float4(act[mt][0], act[mt][1], act[mt][2], act[mt][3]);
+            }
+            pending_dump = true;
+        }
     }
     {  // final layer: 32 (padded) outputs = two 16-wide tiles; all 8 k-tiles arrive as ONE 32 KB stage
         const PsnMlpLayer L = g.d.layers[li];
@@ -225,7 +242,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             acc[mt][2] = bv.z;
             acc[mt][3] = bv.w;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (pending_dump) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
 #pragma unroll
@@ -287,7 +305,8 @@ extern "C" int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_t
 
 extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                              int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
-                             const float* init_a, const float* init_b, int64_t n_rows, float* out, void* stream) {
+                             const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
+                             int64_t n_rows, float* out, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(desc && packed_w && packed_b && out, "mlp_infer: null pointer");
     const PsnMlpDesc& d = *desc;
@@ -324,6 +343,9 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     a.tb = tab_b; a.b_div = b_div > 0 ? b_div : 1; a.b_mod = b_mod > 0 ? b_mod : 1; a.n_rows = n_rows; a.out = out;
     a.init_a = init_a; a.init_b = init_b;
     a.n_bias = (d.n_layers - 1) * 256 + 32;
+    for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) a.save[l] = (save_ptrs != nullptr && l < d.n_layers - 1) ? save_ptrs[l] : nullptr;
+    a.save_row0 = save_row0;
+    for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) PSN_CHECK_ARG((((uintptr_t)a.save[l]) & 15) == 0, "mlp_infer: save buffers must be 16-byte aligned");
     const int rows_per_block = kWaves * 16;
     int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer: too many rows");

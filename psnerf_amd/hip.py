@@ -59,7 +59,8 @@ SIGNATURES = {
     'psn_mf_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, f32, f32, c_f, i32, i64, c_f, c_f]),
     'psn_mf_shade_bwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, f32, f32, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f, c_f,
                                c_f, c_f, c_f]),
-    'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f, i64, c_f, c_f]),
+    'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
+                            ctypes.POINTER(ctypes.c_void_p), i64, i64, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library out of date: fail loudly
@@ -226,16 +227,22 @@ def mlp_pack_layer(W_dense, n_mt, k_tiles, dst):
 
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
-              init_b=None):
+              init_b=None, save=None, save_row0=0):
+    """save: list (one entry per hidden layer, None allowed) of [n_rows - save_row0, 256] tensors that receive the
+    post-activation outputs of the rows >= save_row0."""
     if out is None:
         out = torch.empty(n_rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
+    save_arr = None
+    if save is not None:
+        assert len(save) == desc.n_layers - 1
+        save_arr = (ctypes.c_void_p * len(save))(*[None if t is None else _ptr(t, 'save') for t in save])
     prof = PROFILE_EVENTS
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
                               _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,
-                              _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), n_rows,
+                              _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), save_arr, save_row0, n_rows,
                               _ptr(out, 'out'), _stream()), 'mlp_infer')
     if prof is not None:
         e1.record()

@@ -469,3 +469,75 @@ class MFShade(torch.autograd.Function):
 
 def mf_shade(light_dir, view, normal, albedo, rough, light_int, vis, f0):
     return MFShade.apply(light_dir, view, normal, albedo, rough, light_int, vis, f0)
+
+
+# --------------------------------------------------------------------------- visibility net: shading + supervision rows
+class VisibilityPair(torch.autograd.Function):
+    """stage-2 visibility_net on BOTH row groups of a training step in one fused launch:
+         rows [0, L*Ns)          shading lights  (renderer.py:191-200; enter the loss detached, :197)
+         rows [L*Ns, (L+V)*Ns)   supervision lights 'vis_train' (renderer.py:251-262; trained by vis_loss)
+    The supervision rows ride along with the gradient-free rows through the register-resident kernel, which
+    dumps their hidden activations (row-major) for the backward pass; the backward is the usual ReLU chain on
+    the fp32-MFMA GEMMs.  The layers that read the input block [PE(x_n) | PE(l_v)] use its separability:
+    dW_x = (sum_v dz[v])^T PE(x), dW_l = (sum_n dz[:, n])^T PE(l) -- an 8x (resp. Ns x) shorter contraction.
+
+    Inputs: pe_x [Ns,64], pe_l [L+V,64] (no gradient: points are data, light directions are detached by
+    train.light_vis_detach), n_shade = L, in_cols, skip_at, then W0, b0, ...  Returns (vis [L*Ns,1], vis_t [V*Ns,1])."""
+
+    @staticmethod
+    def forward(ctx, pe_x, pe_l, n_shade, in_cols, skip_at, *params):
+        Ws, bs = params[0::2], params[1::2]
+        Ns, LV = pe_x.shape[0], pe_l.shape[0]
+        V = LV - n_shade
+        n = len(Ws)
+        din_half = in_cols.numel() // 2
+        packed = fused.pack_relu_mlp(list(Ws), list(bs), din_half, din_half, skip_at)
+        need = any(ctx.needs_input_grad[5:])
+        save = [torch.empty(V * Ns, 256, device=pe_x.device) for _ in range(n - 1)] if (need and V > 0) else None
+        out = packed(pe_x, LV * Ns, a_div=1, a_mod=Ns, tab_b=pe_l, b_div=Ns, b_mod=LV, save=save, save_row0=n_shade * Ns)
+        if save is not None:
+            ctx.save_for_backward(pe_x, pe_l[n_shade:], in_cols, *save, *params)
+        ctx.n, ctx.skip_at, ctx.V, ctx.saved = n, skip_at, V, save is not None
+        vis, vis_t = out[:n_shade * Ns], out[n_shade * Ns:]
+        ctx.mark_non_differentiable(vis)
+        return vis, vis_t
+
+    @staticmethod
+    def backward(ctx, _g_vis, g):
+        n, V = ctx.n, ctx.V
+        if not ctx.saved or g is None:
+            return (None,) * (5 + 2 * n)
+        sv = ctx.saved_tensors
+        pe_x, pe_lv, in_cols = sv[0], sv[1], sv[2]
+        H = sv[3:3 + n - 1]                  # post-ReLU outputs of layers 0..n-2
+        Ws = sv[3 + n - 1::2]
+        Ns = pe_x.shape[0]
+        Q = V * Ns
+        half = in_cols.numel() // 2
+        cols_a, cols_b = in_cols[:half], in_cols[half:] - pe_x.shape[1]
+        grads = [None] * (2 * n)
+        g = g.contiguous()
+
+        def in_block_grad(dz):  # d/dW of the [PE(x) | PE(l)] block via separability -> [out, 2*half]
+            d3 = dz.view(V, Ns, -1)
+            gx = hip.gemm(d3.sum(0), pe_x, trans_a=True, split_k=_split_k_for(Ns, dz.shape[1], pe_x.shape[1]))
+            gl = hip.gemm(d3.sum(1), pe_lv, trans_a=True)
+            return torch.cat([gx[:, cols_a], gl[:, cols_b]], dim=1)
+
+        # last layer (out = 1): dW = g^T h, dz = (g w) * relu'(h)
+        grads[2 * (n - 1)] = hip.gemm(g, H[n - 2], trans_a=True, split_k=_split_k_for(Q, 1, 256))
+        grads[2 * (n - 1) + 1] = hip.colsum(g)
+        dz = hip.gemm(g, Ws[n - 1].contiguous(), epi=hip.EPI_MUL_POS, aux_in=H[n - 2])
+        for li in range(n - 2, -1, -1):
+            W = Ws[li]
+            grads[2 * li + 1] = hip.colsum(dz)
+            if li == 0:
+                grads[0] = in_block_grad(dz)
+                break
+            dWh = hip.gemm(dz, H[li - 1], trans_a=True, split_k=_split_k_for(Q, 256, 256))
+            if li - 1 == ctx.skip_at:
+                grads[2 * li] = torch.cat([dWh, in_block_grad(dz)], dim=1)
+            else:
+                grads[2 * li] = dWh
+            dz = hip.gemm(dz, W[:, :256], epi=hip.EPI_MUL_POS, aux_in=H[li - 1])
+        return (None, None, None, None, None) + tuple(grads)

@@ -148,6 +148,17 @@ class PSNetwork(nn.Module):
         x = torch.cat([pe_x.tile(nl, 1), pe_l.repeat_interleave(ns, dim=0)], dim=1)
         return net(x, cols)
 
+    def _visibility_pair(self, pe_x, light_dir, light_vis_train):
+        """(vis [L*Ns,1], vis_train [V*Ns,1]) from one fused launch (ops.VisibilityPair)."""
+        pe_l = self._pe(torch.cat([light_dir.detach(), light_vis_train.detach()], dim=0), self.n_freqs)
+        net = self.visibility_net
+        Ws, bs = net.weights()
+        params = []
+        for W, b in zip(Ws, bs):
+            params += [W, b]
+        cols = self._cols(self.n_freqs, pe_x.device, pair=True)
+        return ops.VisibilityPair.apply(pe_x.detach(), pe_l, light_dir.shape[0], cols, net._skip_index(), *params)
+
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, input, albedo_new=None, basis_new=None, noise=None):
         """Same inputs / outputs as the reference forward (renderer.py:110-266).  The reference gathers and
@@ -195,6 +206,7 @@ class PSNetwork(nn.Module):
         vis_values = torch.ones_like(rgb_values)
         jitter = None
         pe_x = None
+        vis_t_pre = None
         if ns > 0:
             normal = gather(normals) if not self.normal_mlp else normal_s
             pts2c = -gather(ray_dirs)
@@ -218,10 +230,18 @@ class PSNetwork(nn.Module):
             light_int = input.get('light_intensity', self.light_int)
             vis = None
             vis_for_rgb = None
+            vis_t_pre = None
             if self.visibility:
-                # gradient-free unless a caller backpropagates into output['visibility']
-                vis = self._visibility_rows(pe_x, light_dir, fused_ok=True)  # [L*Ns, 1], light-major
                 detach = self.conf.get_bool('train.vis_rgb_detach', default=False)
+                lv = input.get('light_vis_train')
+                pair_ok = (lv is not None and detach and self.visibility_net.width == 256 and torch.is_grad_enabled()
+                           and (self.light_vis_detach or not (light_dir.requires_grad or lv.requires_grad)))
+                if pair_ok:
+                    # shading rows and supervision rows in ONE fused launch (the latter dump their activations)
+                    vis, vis_t_pre = self._visibility_pair(pe_x, light_dir, lv)
+                else:
+                    # gradient-free unless a caller backpropagates into output['visibility']
+                    vis = self._visibility_rows(pe_x, light_dir, fused_ok=True)  # [L*Ns, 1], light-major
                 vis_for_rgb = vis.detach() if detach else vis
             if sg:
                 rgb, spec = ops.sg_shade(light_dir, pts2c, normal, albedo, weights, self.sgbasis.lobe, light_int,
@@ -267,8 +287,11 @@ class PSNetwork(nn.Module):
                 vnum = lv.shape[0]
                 vt = torch.ones_like(points).repeat(vnum, 1, 1) if vnum > 1 else torch.ones_like(points)
                 if ns > 0:
-                    train = torch.is_grad_enabled() and any(p.requires_grad for p in self.visibility_net.parameters())
-                    vis_t = self._visibility_rows(pe_x, lv, fused_ok=not train)
+                    if vis_t_pre is not None:
+                        vis_t = vis_t_pre
+                    else:
+                        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.visibility_net.parameters())
+                        vis_t = self._visibility_rows(pe_x, lv, fused_ok=not train)
                     vt = scatter(vt, vis_t.expand(-1, 3))
                 out['vis_train'] = vt
         if sg:
