@@ -40,6 +40,7 @@ struct InferArgs {
     int n_bias;  // floats in the packed bias buffer (copied to LDS once per workgroup)
     float* save[PSN_MLP_MAX_LAYERS];  // per hidden layer: row-major [n_rows - save_row0, 256] activation dump, or nullptr
     int64_t save_row0;                // rows >= save_row0 are dumped (training rows ride along with inference rows)
+    const float* mask[PSN_MLP_MAX_LAYERS];  // PSN_ACT_RELU_MASK: row-major [n_rows, 256] forward activations
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -156,13 +157,14 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         ++gstage;                                                                                           \
     }
 
+    const int n_hidden = g.d.n_out > 0 ? n_layers - 1 : n_layers;  // n_out == 0: no final layer (backward chains)
     int li = 0;
-    for (; li < n_layers - 1; ++li) {
+    for (; li < n_hidden; ++li) {
         const PsnMlpLayer L = g.d.layers[li];
         const int n_st = L.n_kt_in + L.n_kt_act;
         const int stage_floats = 8 * 1024;
         const float* wl_g = g.w + L.w_off;
-        const float* next_w = g.w + g.d.layers[li + 1].w_off;  // li + 1 <= n_layers - 1 inside this loop
+        const float* next_w = li + 1 < n_layers ? g.w + g.d.layers[li + 1].w_off : nullptr;
         {  // bias -> accumulator init
             const float* bp = bias_lds + L.b_off;
             if (li == 0) __syncthreads();  // bias_lds written above
@@ -207,16 +209,29 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             for (int kt = 0; kt < 8; ++kt) PSN_STAGE(16, act[2 * kt], act[2 * kt + 1], L.n_kt_in + kt)
         }
         // activation: accumulators become the next layer's B operands
+        if (L.act == PSN_ACT_RELU_MASK) {
+            // backward chain: d z = d h * relu'(h) with the forward activation h re-read row-major
+            const float* mp = g.mask[li] + rowc * 256 + 4 * lg;
 #pragma unroll
-        for (int mt = 0; mt < 16; ++mt) {
+            for (int mt = 0; mt < 16; ++mt) {
+                float4 m = *reinterpret_cast<const float4*>(mp + mt * 16);
+                act[mt][0] = m.x > 0.0f ? acc[mt][0] : 0.0f;
+                act[mt][1] = m.y > 0.0f ? acc[mt][1] : 0.0f;
+                act[mt][2] = m.z > 0.0f ? acc[mt][2] : 0.0f;
+                act[mt][3] = m.w > 0.0f ? acc[mt][3] : 0.0f;
+            }
+        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float z = acc[mt][r];
-                float a;
-                if (L.act == PSN_ACT_RELU) a = fmaxf(z, 0.0f);
-                else if (L.act == PSN_ACT_SOFTPLUS100) a = softplus100(z);
-                else a = z;
-                act[mt][r] = a;
+            for (int mt = 0; mt < 16; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float z = acc[mt][r];
+                    float a;
+                    if (L.act == PSN_ACT_RELU) a = fmaxf(z, 0.0f);
+                    else if (L.act == PSN_ACT_SOFTPLUS100) a = softplus100(z);
+                    else a = z;
+                    act[mt][r] = a;
+                }
             }
         }
         // training rows: dump this layer's activations row-major for the backward pass.  The 16 stores are
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             pending_dump = true;
         }
     }
-    {  // final layer: 32 (padded) outputs = two 16-wide tiles; all 8 k-tiles arrive as ONE 32 KB stage
+    if (g.d.n_out > 0) {  // final layer: 32 (padded) outputs = two 16-wide tiles; all 8 k-tiles arrive as ONE 32 KB stage
         const PsnMlpLayer L = g.d.layers[li];
         const float* bp = bias_lds + L.b_off;
 #pragma unroll
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
 #undef PSN_STAGE
 
     // ---- output: feature f = 16*mt + 4*g + r of the final layer ---------------------------------
-    if (row < g.n_rows) {
+    if (row < g.n_rows && g.d.n_out > 0) {
         const int n_out = g.d.n_out;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -306,9 +321,9 @@ extern "C" int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_t
 extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                              int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                              const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
-                             int64_t n_rows, float* out, void* stream) {
+                             const float* const* mask_ptrs, int64_t n_rows, float* out, void* stream) {
     using namespace psn;
-    PSN_CHECK_ARG(desc && packed_w && packed_b && out, "mlp_infer: null pointer");
+    PSN_CHECK_ARG(desc && packed_w && packed_b && (out || desc->n_out == 0), "mlp_infer: null pointer");
     const PsnMlpDesc& d = *desc;
     PSN_CHECK_ARG(d.n_layers >= 1 && d.n_layers <= PSN_MLP_MAX_LAYERS, "mlp_infer: n_layers=%d", d.n_layers);
     PSN_CHECK_ARG(d.in_kt_a >= 0 && d.in_kt_b >= 0 && d.in_kt_a + d.in_kt_b <= 4, "mlp_infer: input tiles %d+%d", d.in_kt_a, d.in_kt_b);
@@ -320,13 +335,13 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     PSN_CHECK_ARG(!uses_in || (tab_a && d.in_kt_a >= 1 && (d.in_kt_b == 0 || tab_b)), "mlp_infer: input table missing");
     PSN_CHECK_ARG(!uses_init || (init_a && d.init_stride >= 256 && d.init_stride % 4 == 0), "mlp_infer: init table missing");
     PSN_CHECK_ARG((((uintptr_t)init_a | (uintptr_t)init_b) & 15) == 0, "mlp_infer: init tables must be 16-byte aligned");
-    PSN_CHECK_ARG(d.n_out >= 1 && d.n_out <= 32, "mlp_infer: n_out=%d", d.n_out);
+    PSN_CHECK_ARG(d.n_out >= 0 && d.n_out <= 32, "mlp_infer: n_out=%d", d.n_out);
     PSN_CHECK_ARG(a_div >= 1 && a_mod >= 1 && (d.in_kt_b == 0 || (b_div >= 1 && b_mod >= 1)), "mlp_infer: bad index map");
     PSN_CHECK_ARG((((uintptr_t)tab_a | (uintptr_t)tab_b | (uintptr_t)packed_w | (uintptr_t)packed_b) & 15) == 0,
                   "mlp_infer: buffers must be 16-byte aligned");
     for (int l = 0; l < d.n_layers; ++l) {
         const PsnMlpLayer& L = d.layers[l];
-        const bool last = l == d.n_layers - 1;
+        const bool last = d.n_out > 0 && l == d.n_layers - 1;
         PSN_CHECK_ARG(L.n_mt == (last ? 1 : 8), "mlp_infer: layer %d n_mt=%d (hidden layers are 256 wide, final <= 32)", l, L.n_mt);
         PSN_CHECK_ARG(L.n_kt_in >= 0 && L.n_kt_in <= d.in_kt_a + d.in_kt_b, "mlp_infer: layer %d n_kt_in=%d", l, L.n_kt_in);
         PSN_CHECK_ARG(!last || (L.n_kt_in == 0 && L.n_kt_act == 8), "mlp_infer: the final layer reads the 256 activations only");
@@ -342,9 +357,13 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     a.d = d; a.w = packed_w; a.b = packed_b; a.ta = tab_a; a.a_div = a_div; a.a_mod = a_mod;
     a.tb = tab_b; a.b_div = b_div > 0 ? b_div : 1; a.b_mod = b_mod > 0 ? b_mod : 1; a.n_rows = n_rows; a.out = out;
     a.init_a = init_a; a.init_b = init_b;
-    a.n_bias = (d.n_layers - 1) * 256 + 32;
-    for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) a.save[l] = (save_ptrs != nullptr && l < d.n_layers - 1) ? save_ptrs[l] : nullptr;
+    a.n_bias = d.n_out > 0 ? (d.n_layers - 1) * 256 + 32 : d.n_layers * 256;
+    for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) a.save[l] = (save_ptrs != nullptr && l < (d.n_out > 0 ? d.n_layers - 1 : d.n_layers)) ? save_ptrs[l] : nullptr;
     a.save_row0 = save_row0;
+    for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) {
+        a.mask[l] = (mask_ptrs != nullptr && l < d.n_layers) ? mask_ptrs[l] : nullptr;
+        if (l < d.n_layers && d.layers[l].act == PSN_ACT_RELU_MASK) PSN_CHECK_ARG(a.mask[l] != nullptr && (((uintptr_t)a.mask[l]) & 15) == 0, "mlp_infer: layer %d needs an aligned mask tensor", l);
+    }
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) PSN_CHECK_ARG((((uintptr_t)a.save[l]) & 15) == 0, "mlp_infer: save buffers must be 16-byte aligned");
     const int rows_per_block = kWaves * 16;
     int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;

@@ -32,11 +32,13 @@ class PackedMLP(object):
         self.init_wa, self.init_wb, self.init_bias = init_wa, init_wb, init_bias
 
     def __call__(self, tab_a, n_rows, a_div=1, a_mod=None, tab_b=None, b_div=1, b_mod=1, out=None, save=None,
-                 save_row0=0):
+                 save_row0=0, mask=None, init_a_direct=None):
         if a_mod is None:
-            a_mod = tab_a.shape[0]
+            a_mod = tab_a.shape[0] if tab_a is not None else n_rows
         init_a = init_b = None
-        if self.init_wa is not None:
+        if init_a_direct is not None:
+            init_a = init_a_direct  # caller-supplied init table (backward chains: d h of the last hidden layer)
+        elif self.init_wa is not None:
             # U = A W_a^T (+ bias when there is no B table), V = B W_b^T + bias
             if self.init_wb is None:
                 init_a = hip.gemm(tab_a, self.init_wa, trans_b=True, bias=self.init_bias, epi=hip.EPI_BIAS)
@@ -46,14 +48,14 @@ class PackedMLP(object):
         uses_in = any(self.desc.layers[i].n_kt_in > 0 for i in range(self.desc.n_layers))
         return hip.mlp_infer(self.desc, self.w, self.b, tab_a if uses_in else None, a_div, a_mod,
                              tab_b if uses_in else None, b_div, b_mod, n_rows, out=out, init_a=init_a, init_b=init_b,
-                             save=save, save_row0=save_row0)
+                             save=save, save_row0=save_row0, mask=mask)
 
 
 def _pad_cols(w, n):
     return torch.nn.functional.pad(w, (0, n - w.shape[1])) if w.shape[1] < n else w
 
 
-def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device):
+def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True):
     """layers: list of dicts {w_in | init_a/init_b, w_act, bias, act}.
     w_in: [o, <=in_kt*32] consumed as MFMA k-tiles; init_a [o, in_kt_a*32] / init_b [o, in_kt_b*32]: the same
     block evaluated through precomputed tables instead.  Hidden layers have o <= 256 (zero padded), the final
@@ -66,7 +68,7 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device):
     w_sizes, dense, biases = [], [], []
     init_wa, init_wb, init_bias = [], [], []
     for li, L in enumerate(layers):
-        last = li == len(layers) - 1
+        last = has_final and li == len(layers) - 1
         n_mt = 1 if last else 8
         rows = n_mt * 32
         parts = []
@@ -172,3 +174,21 @@ def pack_geo_occupancy(weights, biases, skips, d_pe):
         else:
             layers.append(dict(w_in=None, w_act=W, bias=b, act=act))
     return pack_layers(layers, ka, 0, 1, hip.OUT_OCC, weights[0].device)
+
+
+def pack_relu_bwd(weights, skip_at):
+    """Backward (d x) chain of a 256-wide ReLU MLP for the fused kernel: chain layer j computes
+    d h_{l-1} = W_l[:, :256]^T d z_l for l = n-1-j (transposed weight packs, no bias), followed by the ReLU mask of
+    the forward activation h_{l-1} (PSN_ACT_RELU_MASK, masks supplied at call time) and a dump of d z_{l-1}.
+    Chain layer 0 has no weights: it starts from the caller's init table d h_{n-2} = g_out W_{n-1}.
+    Returns a PackedMLP whose call needs init_a_direct, mask=[h_{n-2}, ..., h_0], save=[dz_{n-2}, ..., dz_0]."""
+    n = len(weights)
+    dev = weights[0].device
+    zeros = torch.zeros(256, device=dev)
+    layers = [dict(init_a=torch.zeros(256, 32, device=dev), init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
+    for l in range(n - 2, 0, -1):  # forward layers n-2 .. 1 -> their transposed [in(256), out(256)] blocks
+        layers.append(dict(w_act=weights[l].detach()[:, :256].t().contiguous(), bias=zeros, act=hip.ACT_RELU_MASK))
+    packed = pack_layers(layers, 1, 0, 0, hip.OUT_NONE, dev, has_final=False)
+    packed.init_wa = packed.init_wb = packed.init_bias = None  # the init table is always supplied by the caller
+    packed.desc.init_stride = 256
+    return packed

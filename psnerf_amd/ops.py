@@ -524,12 +524,18 @@ class VisibilityPair(torch.autograd.Function):
             gl = hip.gemm(d3.sum(1), pe_lv, trans_a=True)
             return torch.cat([gx[:, cols_a], gl[:, cols_b]], dim=1)
 
-        # last layer (out = 1): dW = g^T h, dz = (g w) * relu'(h)
+        # last layer (out = 1): dW = g^T h ; d h_{n-2} = g w  (rank-1, feeds the fused backward chain)
         grads[2 * (n - 1)] = hip.gemm(g, H[n - 2], trans_a=True, split_k=_split_k_for(Q, 1, 256))
         grads[2 * (n - 1) + 1] = hip.colsum(g)
-        dz = hip.gemm(g, Ws[n - 1].contiguous(), epi=hip.EPI_MUL_POS, aux_in=H[n - 2])
+        dh_last = hip.gemm(g, Ws[n - 1].contiguous())  # [Q,256]
+        # d z_l = d h_l * relu'(h_l), d h_{l-1} = W_l[:, :256]^T d z_l for l = n-2 .. 0 in ONE register-resident
+        # launch (transposed weight packs, activations re-read as masks, every d z_l dumped for the weight GEMMs)
+        chain = fused.pack_relu_bwd(list(Ws), ctx.skip_at)
+        DZ = [torch.empty(Q, 256, device=g.device) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
+        chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh_last, mask=[H[n - 2 - j] for j in range(n - 1)],
+              save=DZ, save_row0=0)
         for li in range(n - 2, -1, -1):
-            W = Ws[li]
+            dz = DZ[n - 2 - li]
             grads[2 * li + 1] = hip.colsum(dz)
             if li == 0:
                 grads[0] = in_block_grad(dz)
@@ -539,5 +545,4 @@ class VisibilityPair(torch.autograd.Function):
                 grads[2 * li] = torch.cat([dWh, in_block_grad(dz)], dim=1)
             else:
                 grads[2 * li] = dWh
-            dz = hip.gemm(dz, W[:, :256], epi=hip.EPI_MUL_POS, aux_in=H[li - 1])
         return (None, None, None, None, None) + tuple(grads)
