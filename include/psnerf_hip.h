@@ -111,8 +111,20 @@ int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int ac
  * psn_mlp_pack_layer (one call per layer, into one contiguous buffer).
  * ---------------------------------------------------------------------- */
 #define PSN_MLP_MAX_LAYERS 12
-enum { PSN_ACT_NONE = 0, PSN_ACT_RELU = 1, PSN_ACT_SOFTPLUS100 = 2,
-       PSN_ACT_RELU_MASK = 3 /* out = acc * (mask[row, f] > 0): ReLU backward with the saved forward activation */ };
+/* Per-layer activation "programs" of the fused kernel.  z = accumulator; a1 / a2 = optional row-major [n_rows,256]
+ * operands (mask_ptrs / aux2_ptrs); the new activation (and for some codes a second value) can be dumped row-major
+ * (save_ptrs / save2_ptrs).  Forward, backward and gradient-sweep chains of stage1/model/network.py:85-120 and
+ * stage2/model/renderer.py:17-49 are all sequences of these. */
+enum {
+    PSN_ACT_NONE = 0,
+    PSN_ACT_RELU = 1,
+    PSN_ACT_SOFTPLUS100 = 2,   /* act = softplus_100(z);           second = sigmoid(100 z)                  */
+    PSN_ACT_RELU_MASK = 3,     /* act = z * (a1 > 0)               (ReLU backward with the saved activation) */
+    PSN_ACT_MUL_AUX = 4,       /* act = z * a1;                    second = z                               */
+    PSN_ACT_MUL2 = 5,          /* act = z * a1;                    second = z * a2                          */
+    PSN_ACT_SOFTPLUS_BWD = 6,  /* act = a1 * (z + 100 a2 (1 - a1))  (softplus double-backward combine)       */
+    PSN_ACT_HEAD = 7           /* side output: z is dumped, the activations are left untouched              */
+};
 enum { PSN_OUT_NONE = 0, PSN_OUT_SIGMOID = 1, PSN_OUT_OCC = 2 /* sigmoid(-10 x), network.py:125 */ };
 
 typedef struct {
@@ -150,15 +162,16 @@ int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_tiles, float
  * save_row0 the post-activation output of hidden layer l is also written row-major to save_ptrs[l]
  * [n_rows - save_row0, 256] -- the training rows of stage2/model/renderer.py:251-262 ride along with the
  * gradient-free rows and leave exactly what their backward pass needs.
- * mask_ptrs (HOST array of n_layers device pointers or NULL): row-major [n_rows, 256] tensors read by layers whose
- * activation is PSN_ACT_RELU_MASK.  With n_out == 0 there is no final layer and `out` may be NULL: together with
+ * mask_ptrs / aux2_ptrs (HOST arrays of n_layers device pointers or NULL): row-major [n_rows, 256] operands a1 / a2
+ * of the layers' activation programs; save2_ptrs: second dumps (same indexing as save_ptrs).  With n_out == 0 there is no final layer and `out` may be NULL: together with
  * transposed weight packs, an init table holding d h of the last hidden layer, masks = the dumped activations and
  * save_ptrs = the d z outputs this runs the ReLU BACKWARD chain d h_{l-1} = W_l^T (d h_l * relu'(h_l)).
  * out [n_rows, n_out]. */
 int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                   int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                   const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
-                  const float* const* mask_ptrs, int64_t n_rows, float* out, void* stream);
+                  const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
+                  int64_t n_rows, float* out, void* stream);
 
 /* ------------------------------------------------------------------------
  * Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n:

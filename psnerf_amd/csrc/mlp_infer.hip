@@ -40,7 +40,9 @@ struct InferArgs {
     int n_bias;  // floats in the packed bias buffer (copied to LDS once per workgroup)
     float* save[PSN_MLP_MAX_LAYERS];  // per hidden layer: row-major [n_rows - save_row0, 256] activation dump, or nullptr
     int64_t save_row0;                // rows >= save_row0 are dumped (training rows ride along with inference rows)
-    const float* mask[PSN_MLP_MAX_LAYERS];  // PSN_ACT_RELU_MASK: row-major [n_rows, 256] forward activations
+    const float* mask[PSN_MLP_MAX_LAYERS];  // aux1: row-major [n_rows, 256] tensor read by the layer's activation
+    const float* aux2[PSN_MLP_MAX_LAYERS];  // aux2: second row-major operand (PSN_ACT_MUL2 / PSN_ACT_SOFTPLUS_BWD)
+    float* save2[PSN_MLP_MAX_LAYERS];       // second dump (sigmoid of PSN_ACT_SOFTPLUS100, raw acc of MUL_AUX, acc*aux2 of MUL2)
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -84,6 +86,9 @@ __device__ __forceinline__ void stage_load(const float* __restrict__ gsrc, float
     }
 }
 
+// CHAIN = false: lean inference / forward-with-dump path (NONE / RELU / SOFTPLUS100 activations, one dump per layer).
+// CHAIN = true : general per-layer activation programs with row-major operands and two dumps (training chains).
+template <bool CHAIN>
 __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages + all biases
     float* bias_lds = smem + 2 * kStageFloats;
@@ -136,14 +141,16 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     // that the accumulators never meet a control-flow merge between differently shaped code paths (which
     // makes hipcc shuttle every accumulator register between VGPRs and AGPRs per stage).
     int gstage = 0;  // global stage counter -> LDS buffer parity
-    bool pending_dump = false;  // 16 activation-dump stores were issued after the last LDS-DMA batch
+    int pending_dump = 0;  // activation-dump stores (0 / 16 / 32) issued after the last LDS-DMA batch
     const bool dump_row = row < g.n_rows && row >= g.save_row0;
 
 #define PSN_STAGE(NMT, B0, B1, S_IDX)                                                                       \
     {                                                                                                       \
         /* this wave's LDS-DMA pieces have landed; activation dumps issued after them may stay in flight */ \
-        if (pending_dump) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); pending_dump = false; }      \
+        if (pending_dump == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                            \
+        else if (pending_dump == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                      \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+        pending_dump = 0;                                                                                   \
         __syncthreads(); /* every wave's pieces landed; the other buffer is no longer being read */         \
         const int s_ = (S_IDX);                                                                             \
         float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
@@ -208,19 +215,10 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt) PSN_STAGE(16, act[2 * kt], act[2 * kt + 1], L.n_kt_in + kt)
         }
-        // activation: accumulators become the next layer's B operands
-        if (L.act == PSN_ACT_RELU_MASK) {
-            // backward chain: d z = d h * relu'(h) with the forward activation h re-read row-major
-            const float* mp = g.mask[li] + rowc * 256 + 4 * lg;
-#pragma unroll
-            for (int mt = 0; mt < 16; ++mt) {
-                float4 m = *reinterpret_cast<const float4*>(mp + mt * 16);
-                act[mt][0] = m.x > 0.0f ? acc[mt][0] : 0.0f;
-                act[mt][1] = m.y > 0.0f ? acc[mt][1] : 0.0f;
-                act[mt][2] = m.z > 0.0f ? acc[mt][2] : 0.0f;
-                act[mt][3] = m.w > 0.0f ? acc[mt][3] : 0.0f;
-            }
-        } else {
+        // activation: accumulators become the next layer's B operands.  Optional row-major operands (aux1, aux2)
+        // are re-read and optional results (the new activation, a second value) are dumped per layer; the stores
+        // are issued behind the already-requested next weight stage and complete under the next layer's MFMAs.
+        if constexpr (!CHAIN) {
 #pragma unroll
             for (int mt = 0; mt < 16; ++mt) {
 #pragma unroll
@@ -233,17 +231,53 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                     act[mt][r] = a;
                 }
             }
-        }
-        // training rows: dump this layer's activations row-major for the backward pass.  The 16 stores are
-        // issued behind the already-requested next weight stage and complete under the next layer's MFMAs.
-        if (g.save[li] != nullptr) {
-            if (dump_row) {
-                float* dst = g.save[li] + (row - g.save_row0) * 256 + 4 * lg;
+            if (g.save[li] != nullptr) {
+                if (dump_row) {
+                    float* dst = g.save[li] + (row - g.save_row0) * 256 + 4 * lg;
 #pragma unroll
-                for (int mt = 0; mt < 16; ++mt)
-                    *reinterpret_cast<float4*>(dst + mt * 16) = make_float4(act[mt][0], act[mt][1], act[mt][2], act[mt][3]);
+                    for (int mt = 0; mt < 16; ++mt)
+                        *reinterpret_cast<float4*>(dst + mt * 16) = make_float4(act[mt][0], act[mt][1], act[mt][2], act[mt][3]);
+                }
+                pending_dump = 16;
             }
-            pending_dump = true;
+        } else
+        {
+            const float* p1 = g.mask[li] != nullptr ? g.mask[li] + rowc * 256 + 4 * lg : nullptr;
+            const float* p2 = g.aux2[li] != nullptr ? g.aux2[li] + rowc * 256 + 4 * lg : nullptr;
+            float* d1 = (g.save[li] != nullptr && dump_row) ? g.save[li] + (row - g.save_row0) * 256 + 4 * lg : nullptr;
+            float* d2 = (g.save2[li] != nullptr && dump_row) ? g.save2[li] + (row - g.save_row0) * 256 + 4 * lg : nullptr;
+            const int code = L.act;
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) {
+                float z[4] = {acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]};
+                float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f}, o[4], o2[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p1 != nullptr) {
+                    float4 t = *reinterpret_cast<const float4*>(p1 + mt * 16);
+                    a1[0] = t.x; a1[1] = t.y; a1[2] = t.z; a1[3] = t.w;
+                }
+                if (p2 != nullptr) {
+                    float4 t = *reinterpret_cast<const float4*>(p2 + mt * 16);
+                    a2[0] = t.x; a2[1] = t.y; a2[2] = t.z; a2[3] = t.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    switch (code) {
+                        case PSN_ACT_RELU: o[r] = fmaxf(z[r], 0.0f); break;
+                        case PSN_ACT_SOFTPLUS100: softplus100_sig(z[r], o[r], o2[r]); break;
+                        case PSN_ACT_RELU_MASK: o[r] = a1[r] > 0.0f ? z[r] : 0.0f; break;
+                        case PSN_ACT_MUL_AUX: o[r] = z[r] * a1[r]; o2[r] = z[r]; break;
+                        case PSN_ACT_MUL2: o[r] = z[r] * a1[r]; o2[r] = z[r] * a2[r]; break;
+                        case PSN_ACT_SOFTPLUS_BWD: o[r] = a1[r] * (z[r] + 100.0f * a2[r] * (1.0f - a1[r])); break;
+                        default: o[r] = z[r]; break;  // PSN_ACT_NONE, PSN_ACT_HEAD
+                    }
+                }
+                if (d1 != nullptr) *reinterpret_cast<float4*>(d1 + mt * 16) = make_float4(o[0], o[1], o[2], o[3]);
+                if (d2 != nullptr) *reinterpret_cast<float4*>(d2 + mt * 16) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                if (code != PSN_ACT_HEAD) {  // HEAD: a side output (dumped above); the activations stay for the next layer
+                    act[mt][0] = o[0]; act[mt][1] = o[1]; act[mt][2] = o[2]; act[mt][3] = o[3];
+                }
+            }
+            pending_dump = (g.save[li] != nullptr ? 16 : 0) + (g.save2[li] != nullptr ? 16 : 0);
         }
     }
     if (g.d.n_out > 0) {  // final layer: 32 (padded) outputs = two 16-wide tiles; all 8 k-tiles arrive as ONE 32 KB stage
@@ -257,7 +291,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             acc[mt][2] = bv.z;
             acc[mt][3] = bv.w;
         }
-        if (pending_dump) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (pending_dump == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (pending_dump == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
@@ -321,7 +356,8 @@ extern "C" int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_t
 extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                              int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                              const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
-                             const float* const* mask_ptrs, int64_t n_rows, float* out, void* stream) {
+                             const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
+                             int64_t n_rows, float* out, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(desc && packed_w && packed_b && (out || desc->n_out == 0), "mlp_infer: null pointer");
     const PsnMlpDesc& d = *desc;
@@ -361,15 +397,32 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) a.save[l] = (save_ptrs != nullptr && l < (d.n_out > 0 ? d.n_layers - 1 : d.n_layers)) ? save_ptrs[l] : nullptr;
     a.save_row0 = save_row0;
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) {
-        a.mask[l] = (mask_ptrs != nullptr && l < d.n_layers) ? mask_ptrs[l] : nullptr;
-        if (l < d.n_layers && d.layers[l].act == PSN_ACT_RELU_MASK) PSN_CHECK_ARG(a.mask[l] != nullptr && (((uintptr_t)a.mask[l]) & 15) == 0, "mlp_infer: layer %d needs an aligned mask tensor", l);
+        const bool in_range = l < d.n_layers;
+        a.mask[l] = (mask_ptrs != nullptr && in_range) ? mask_ptrs[l] : nullptr;
+        a.aux2[l] = (aux2_ptrs != nullptr && in_range) ? aux2_ptrs[l] : nullptr;
+        a.save2[l] = (save2_ptrs != nullptr && in_range) ? save2_ptrs[l] : nullptr;
+        PSN_CHECK_ARG(((((uintptr_t)a.mask[l]) | ((uintptr_t)a.aux2[l]) | ((uintptr_t)a.save2[l])) & 15) == 0,
+                      "mlp_infer: aux / dump tensors must be 16-byte aligned");
+        if (in_range) {
+            const int act = d.layers[l].act;
+            const bool need1 = act == PSN_ACT_RELU_MASK || act == PSN_ACT_MUL_AUX || act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD;
+            const bool need2 = act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD;
+            PSN_CHECK_ARG(act >= PSN_ACT_NONE && act <= PSN_ACT_HEAD, "mlp_infer: layer %d unknown activation %d", l, act);
+            PSN_CHECK_ARG(!need1 || a.mask[l] != nullptr, "mlp_infer: layer %d needs aux operand 1", l);
+            PSN_CHECK_ARG(!need2 || a.aux2[l] != nullptr, "mlp_infer: layer %d needs aux operand 2", l);
+            PSN_CHECK_ARG(act != PSN_ACT_HEAD || a.save[l] != nullptr, "mlp_infer: a HEAD layer needs a dump tensor");
+        }
     }
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) PSN_CHECK_ARG((((uintptr_t)a.save[l]) & 15) == 0, "mlp_infer: save buffers must be 16-byte aligned");
     const int rows_per_block = kWaves * 16;
     int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer: too many rows");
-    hipLaunchKernelGGL(mlp_infer_kernel, dim3((unsigned)blocks), dim3(kWaves * 64), (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float),
-                       (hipStream_t)stream, a);
+    bool chain = false;
+    for (int l = 0; l < d.n_layers; ++l)
+        chain = chain || d.layers[l].act > PSN_ACT_SOFTPLUS100 || a.save2[l] != nullptr || a.mask[l] != nullptr || a.aux2[l] != nullptr;
+    const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
+    if (chain) hipLaunchKernelGGL(mlp_infer_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(mlp_infer_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer");
     return PSN_OK;
 }

@@ -32,7 +32,7 @@ class PackedMLP(object):
         self.init_wa, self.init_wb, self.init_bias = init_wa, init_wb, init_bias
 
     def __call__(self, tab_a, n_rows, a_div=1, a_mod=None, tab_b=None, b_div=1, b_mod=1, out=None, save=None,
-                 save_row0=0, mask=None, init_a_direct=None):
+                 save_row0=0, mask=None, init_a_direct=None, aux2=None, save2=None):
         if a_mod is None:
             a_mod = tab_a.shape[0] if tab_a is not None else n_rows
         init_a = init_b = None
@@ -48,7 +48,7 @@ class PackedMLP(object):
         uses_in = any(self.desc.layers[i].n_kt_in > 0 for i in range(self.desc.n_layers))
         return hip.mlp_infer(self.desc, self.w, self.b, tab_a if uses_in else None, a_div, a_mod,
                              tab_b if uses_in else None, b_div, b_mod, n_rows, out=out, init_a=init_a, init_b=init_b,
-                             save=save, save_row0=save_row0, mask=mask)
+                             save=save, save_row0=save_row0, mask=mask, aux2=aux2, save2=save2)
 
 
 def _pad_cols(w, n):

@@ -26,7 +26,8 @@ i64, i32, f32 = ctypes.c_int64, ctypes.c_int, ctypes.c_float
 MAX_LAYERS = 12
 (EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_SOFTPLUS, EPI_MUL_AUX, EPI_MUL_POS, EPI_BIAS_SIGMOID, EPI_ACCUM,
  EPI_MUL2, EPI_SOFTPLUS_BWD, EPI_MUL_AUX_RAW) = range(11)
-ACT_NONE, ACT_RELU, ACT_SOFTPLUS100, ACT_RELU_MASK = range(4)
+(ACT_NONE, ACT_RELU, ACT_SOFTPLUS100, ACT_RELU_MASK, ACT_MUL_AUX, ACT_MUL2, ACT_SOFTPLUS_BWD,
+ ACT_HEAD) = range(8)
 OUT_NONE, OUT_SIGMOID, OUT_OCC = range(3)
 
 
@@ -60,7 +61,8 @@ SIGNATURES = {
     'psn_mf_shade_bwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, f32, f32, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f, c_f,
                                c_f, c_f, c_f]),
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
-                            ctypes.POINTER(ctypes.c_void_p), i64, ctypes.POINTER(ctypes.c_void_p), i64, c_f, c_f]),
+                            ctypes.POINTER(ctypes.c_void_p), i64, ctypes.POINTER(ctypes.c_void_p),
+                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), i64, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library out of date: fail loudly
@@ -227,16 +229,21 @@ def mlp_pack_layer(W_dense, n_mt, k_tiles, dst):
 
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
-              init_b=None, save=None, save_row0=0, mask=None):
+              init_b=None, save=None, save_row0=0, mask=None, aux2=None, save2=None):
     """save: list (one entry per hidden layer, None allowed) of [n_rows - save_row0, 256] tensors that receive the
     post-activation outputs of the rows >= save_row0."""
     if out is None and desc.n_out > 0:
         out = torch.empty(n_rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
     n_hidden = desc.n_layers - 1 if desc.n_out > 0 else desc.n_layers
-    mask_arr = None
-    if mask is not None:
-        assert len(mask) == desc.n_layers
-        mask_arr = (ctypes.c_void_p * len(mask))(*[None if t is None else _ptr(t, 'mask') for t in mask])
+    def ptr_array(lst, n, name):
+        if lst is None:
+            return None
+        assert len(lst) == n, '%s: expected %d entries' % (name, n)
+        return (ctypes.c_void_p * n)(*[None if t is None else _ptr(t, name) for t in lst])
+
+    mask_arr = ptr_array(mask, desc.n_layers, 'mask')
+    aux2_arr = ptr_array(aux2, desc.n_layers, 'aux2')
+    save2_arr = ptr_array(save2, desc.n_layers, 'save2')
     save_arr = None
     if save is not None:
         assert len(save) == n_hidden
@@ -248,7 +255,7 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
     _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
                               _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,
                               _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), save_arr, save_row0, mask_arr,
-                              n_rows, _ptr(out, 'out', True), _stream()), 'mlp_infer')
+                              aux2_arr, save2_arr, n_rows, _ptr(out, 'out', True), _stream()), 'mlp_infer')
     if prof is not None:
         e1.record()
         prof.append(('mlp_infer', n_rows, e0, e1))
