@@ -166,12 +166,13 @@ int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_tiles, float
  * of the layers' activation programs; save2_ptrs: second dumps (same indexing as save_ptrs).  With n_out == 0 there is no final layer and `out` may be NULL: together with
  * transposed weight packs, an init table holding d h of the last hidden layer, masks = the dumped activations and
  * save_ptrs = the d z outputs this runs the ReLU BACKWARD chain d h_{l-1} = W_l^T (d h_l * relu'(h_l)).
+ * act_init (or NULL): row-major [n_rows, 256] initial activations, so that layer 0 may already read them.
  * out [n_rows, n_out]. */
 int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                   int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                   const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
                   const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
-                  int64_t n_rows, float* out, void* stream);
+                  const float* act_init, int64_t n_rows, float* out, void* stream);
 
 /* ------------------------------------------------------------------------
  * Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n:

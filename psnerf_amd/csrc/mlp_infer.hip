@@ -43,6 +43,7 @@ struct InferArgs {
     const float* mask[PSN_MLP_MAX_LAYERS];  // aux1: row-major [n_rows, 256] tensor read by the layer's activation
     const float* aux2[PSN_MLP_MAX_LAYERS];  // aux2: second row-major operand (PSN_ACT_MUL2 / PSN_ACT_SOFTPLUS_BWD)
     float* save2[PSN_MLP_MAX_LAYERS];       // second dump (sigmoid of PSN_ACT_SOFTPLUS100, raw acc of MUL_AUX, acc*aux2 of MUL2)
+    const float* act_init;                  // optional row-major [n_rows, 256] initial activations (chains that start from a tensor)
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -136,6 +137,16 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     for (int mt = 0; mt < 16; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) act[mt][r] = 0.f;
+    if constexpr (CHAIN) {
+        if (g.act_init != nullptr) {
+            const float* ap = g.act_init + rowc * 256 + 4 * lg;
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) {
+                float4 t = *reinterpret_cast<const float4*>(ap + mt * 16);
+                act[mt][0] = t.x; act[mt][1] = t.y; act[mt][2] = t.z; act[mt][3] = t.w;
+            }
+        }
+    }
 
     // Hidden layers (16 output tiles) run in the loop; the final layer (2 output tiles) is peeled off below so
     // that the accumulators never meet a control-flow merge between differently shaped code paths (which
@@ -357,7 +368,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
                              int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                              const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
                              const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
-                             int64_t n_rows, float* out, void* stream) {
+                             const float* act_init, int64_t n_rows, float* out, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(desc && packed_w && packed_b && (out || desc->n_out == 0), "mlp_infer: null pointer");
     const PsnMlpDesc& d = *desc;
@@ -383,7 +394,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         PSN_CHECK_ARG(!last || (L.n_kt_in == 0 && L.n_kt_act == 8), "mlp_infer: the final layer reads the 256 activations only");
         PSN_CHECK_ARG(L.b_off == (int64_t)l * 256, "mlp_infer: biases must be packed back to back (256 floats per hidden layer)");
         PSN_CHECK_ARG(L.n_kt_act == 0 || L.n_kt_act == 8, "mlp_infer: layer %d n_kt_act=%d", l, L.n_kt_act);
-        PSN_CHECK_ARG(l > 0 || L.n_kt_act == 0, "mlp_infer: layer 0 cannot read activations");
+        PSN_CHECK_ARG(l > 0 || L.n_kt_act == 0 || act_init != nullptr, "mlp_infer: layer 0 cannot read activations without act_init");
         PSN_CHECK_ARG(L.n_kt_in + L.n_kt_act >= 1 || (l == 0 && L.init_off >= 0 && d.n_layers > 1), "mlp_infer: layer %d has no input", l);
         PSN_CHECK_ARG(L.init_off < 0 || (!last && L.init_off + 256 <= d.init_stride && L.init_off % 4 == 0), "mlp_infer: layer %d bad init_off", l);
         PSN_CHECK_ARG((L.w_off % 4) == 0 && (L.b_off % 4) == 0, "mlp_infer: layer %d offsets must be multiples of 4 floats", l);
@@ -417,7 +428,9 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     const int rows_per_block = kWaves * 16;
     int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer: too many rows");
-    bool chain = false;
+    a.act_init = act_init;
+    PSN_CHECK_ARG((((uintptr_t)act_init) & 15) == 0, "mlp_infer: act_init must be 16-byte aligned");
+    bool chain = act_init != nullptr;
     for (int l = 0; l < d.n_layers; ++l)
         chain = chain || d.layers[l].act > PSN_ACT_SOFTPLUS100 || a.save2[l] != nullptr || a.mask[l] != nullptr || a.aux2[l] != nullptr;
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);

@@ -32,7 +32,7 @@ class PackedMLP(object):
         self.init_wa, self.init_wb, self.init_bias = init_wa, init_wb, init_bias
 
     def __call__(self, tab_a, n_rows, a_div=1, a_mod=None, tab_b=None, b_div=1, b_mod=1, out=None, save=None,
-                 save_row0=0, mask=None, init_a_direct=None, aux2=None, save2=None):
+                 save_row0=0, mask=None, init_a_direct=None, aux2=None, save2=None, act_init=None):
         if a_mod is None:
             a_mod = tab_a.shape[0] if tab_a is not None else n_rows
         init_a = init_b = None
@@ -48,7 +48,7 @@ class PackedMLP(object):
         uses_in = any(self.desc.layers[i].n_kt_in > 0 for i in range(self.desc.n_layers))
         return hip.mlp_infer(self.desc, self.w, self.b, tab_a if uses_in else None, a_div, a_mod,
                              tab_b if uses_in else None, b_div, b_mod, n_rows, out=out, init_a=init_a, init_b=init_b,
-                             save=save, save_row0=save_row0, mask=mask, aux2=aux2, save2=save2)
+                             save=save, save_row0=save_row0, mask=mask, aux2=aux2, save2=save2, act_init=act_init)
 
 
 def _pad_cols(w, n):
@@ -192,3 +192,62 @@ def pack_relu_bwd(weights, skip_at):
     packed.init_wa = packed.init_wb = packed.init_bias = None  # the init table is always supplied by the caller
     packed.desc.init_stride = 256
     return packed
+
+
+# --------------------------------------------------------------------------- stage-1 geometry-field chains
+def _t(w):
+    return w.detach().t().contiguous()
+
+
+def pack_geo_chains(weights, biases, skips, d_pe):
+    """The four fused chains of ops.GeoFieldFused for the 256-wide softplus geometry network
+    (stage1/model/network.py:85-120); ``weights`` are the EFFECTIVE dense matrices with the 1/sqrt(2) of the skip
+    layer already folded in.  Returns dict(fwd, sweep, sweep_bwd, value_bwd, value_bwd_nosweep) of PackedMLP."""
+    n = len(weights)
+    assert len(skips) == 1 and weights[1].shape[1] == 256 and weights[n - 1].shape[0] == 257
+    sk = skips[0]
+    dev = weights[0].device
+    W = [w.detach() for w in weights]
+    b = [x.detach() for x in biases]
+    zeros = torch.zeros(256, device=dev)
+    ka = (d_pe + 31) // 32
+    d_a = W[sk].shape[1] - d_pe  # width of the activation part of the skip layer's input (217)
+
+    def fwd_in(l):  # how forward layer l consumes its input
+        if l == 0:
+            return dict(w_in=W[0], w_act=None)
+        if l == sk:
+            return dict(w_in=W[l][:, d_a:], w_act=W[l][:, :d_a])
+        return dict(w_in=None, w_act=W[l])
+
+    # F1: value pass, dumps a_{l+1} and sigmoid(100 z_l); HEAD = 256 features, final = occupancy logit
+    layers = [dict(bias=b[l], act=hip.ACT_SOFTPLUS100, **fwd_in(l)) for l in range(n - 1)]
+    layers.append(dict(w_in=None, w_act=W[n - 1][1:], bias=b[n - 1][1:], act=hip.ACT_HEAD))
+    layers.append(dict(w_in=None, w_act=W[n - 1][:1], bias=b[n - 1][:1], act=hip.ACT_NONE))
+    fwd = pack_layers(layers, ka, 0, 1, hip.OUT_NONE, dev)
+
+    # F2: reverse sweep r_l = (r_{l+1} * s_l) W_l, starting from row 0 of the last layer (init table with one row)
+    layers = [dict(init_a=torch.zeros(256, ka * 32, device=dev), init_b=None, w_act=None, bias=zeros, act=hip.ACT_MUL_AUX)]
+    for l in range(n - 2, 0, -1):
+        layers.append(dict(w_act=_t(W[l]), bias=zeros, act=hip.ACT_MUL_AUX))
+    layers.append(dict(w_act=_t(W[0]), bias=zeros, act=hip.ACT_HEAD))
+    sweep = pack_layers(layers, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
+    sweep.init_wa = sweep.init_wb = sweep.init_bias = None
+    sweep.desc.init_stride = 256
+
+    # B1: adjoint of the sweep: du_l = dR_l W_l^T ; dR_{l+1} = du_l * s_l ; dS_l = du_l * R_{l+1}
+    layers = [dict(bias=zeros, act=hip.ACT_MUL2, **fwd_in(l)) for l in range(n - 1)]
+    sweep_bwd = pack_layers(layers, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
+
+    # B2: adjoint of the value pass: da_l = W_l^T dz_l ; dz_{l-1} = s (da + 100 dS (1 - s))   [or s * da without sweep]
+    def value_bwd(act):
+        ls = [dict(init_a=torch.zeros(256, ka * 32, device=dev), init_b=None, w_act=_t(W[n - 1][1:]), bias=zeros, act=act)]
+        for l in range(n - 2, 0, -1):
+            ls.append(dict(w_act=_t(W[l]), bias=zeros, act=act))
+        pk = pack_layers(ls, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
+        pk.init_wa = pk.init_wb = pk.init_bias = None
+        pk.desc.init_stride = 256
+        return pk
+
+    return dict(fwd=fwd, sweep=sweep, sweep_bwd=sweep_bwd, value_bwd=value_bwd(hip.ACT_SOFTPLUS_BWD),
+                value_bwd_nosweep=value_bwd(hip.ACT_MUL_AUX), d_a=d_a)

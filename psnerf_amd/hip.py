@@ -62,7 +62,7 @@ SIGNATURES = {
                                c_f, c_f, c_f]),
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
                             ctypes.POINTER(ctypes.c_void_p), i64, ctypes.POINTER(ctypes.c_void_p),
-                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), i64, c_f, c_f]),
+                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f, i64, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library out of date: fail loudly
@@ -229,7 +229,7 @@ def mlp_pack_layer(W_dense, n_mt, k_tiles, dst):
 
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
-              init_b=None, save=None, save_row0=0, mask=None, aux2=None, save2=None):
+              init_b=None, save=None, save_row0=0, mask=None, aux2=None, save2=None, act_init=None):
     """save: list (one entry per hidden layer, None allowed) of [n_rows - save_row0, 256] tensors that receive the
     post-activation outputs of the rows >= save_row0."""
     if out is None and desc.n_out > 0:
@@ -255,7 +255,7 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
     _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
                               _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,
                               _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), save_arr, save_row0, mask_arr,
-                              aux2_arr, save2_arr, n_rows, _ptr(out, 'out', True), _stream()), 'mlp_infer')
+                              aux2_arr, save2_arr, _ptr(act_init, 'act_init', True), n_rows, _ptr(out, 'out', True), _stream()), 'mlp_infer')
     if prof is not None:
         e1.record()
         prof.append(('mlp_infer', n_rows, e0, e1))

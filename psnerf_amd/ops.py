@@ -546,3 +546,120 @@ class VisibilityPair(torch.autograd.Function):
             else:
                 grads[2 * li] = dWh
         return (None, None, None, None, None) + tuple(grads)
+
+
+# --------------------------------------------------------------------------- stage-1 geometry field, fused chains
+class GeoFieldFused(torch.autograd.Function):
+    """Same function as GeoField (occupancy logit, 256 features and d logit / d p of the stage-1 geometry MLP, with a
+    hand-derived backward through both the value pass and the gradient sweep), but every layer-to-layer chain runs
+    in the register-resident fused kernel (csrc/mlp_infer.hip, chain variant): four launches per call --
+    value pass, reverse sweep, adjoint of the sweep, adjoint of the value pass -- whose per-layer dumps feed the
+    split-K weight-gradient GEMMs.  The Linear / softplus / elementwise traffic of 34 GEMM launches never
+    round-trips through HBM as GEMM operands.  256-wide networks with one skip layer only (fallback: GeoField).
+
+    Returns (logit [Q,1], feat [Q,256], grad [Q,3]).  ``chains`` = fused.pack_geo_chains(...) (cached per step)."""
+
+    @staticmethod
+    def forward(ctx, p, n_octaves, scale, skips, with_grad, chains, *params):
+        Ws = [w for w in params[0::2]]
+        n = len(Ws)
+        p = p.contiguous()
+        Q, dev = p.shape[0], p.device
+        d_pe = 3 + 6 * n_octaves
+        d_a = chains['d_a']
+        sk = skips[0]
+        pe = hip.pe_encode(p, n_octaves, 64, scale)  # [Q,64] xin table (39 real columns)
+        A = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]   # A[l] = softplus output of layer l = input of l+1
+        S = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]
+        feat = torch.empty(Q, 256, device=dev)
+        logit = chains['fwd'](pe, Q, save=A + [feat], save2=S + [None, None])
+        A[sk - 1][:, d_a:] = pe[:, :d_pe]  # the skip layer's input is [a (217) | pe (39)]: complete the dumped tile
+        grad = None
+        U = R = None
+        if with_grad:
+            U = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]   # U[l] = R[l+1] * S[l]
+            R = [None] + [torch.empty(Q, 256, device=dev) for _ in range(n - 2)]  # R[l], l = 1..n-2 (raw sweep values)
+            r0 = torch.empty(Q, 256, device=dev)
+            w_row = Ws[n - 1][0:1, :].contiguous()
+            chains['sweep'](None, Q, a_div=1, a_mod=1, init_a_direct=w_row,
+                            mask=[S[n - 2 - j] for j in range(n - 1)] + [None],
+                            save=[U[n - 2 - j] for j in range(n - 1)] + [r0],
+                            save2=[None] + [R[n - 1 - j] for j in range(1, n - 1)] + [None])
+            d_pe_t = r0[:, :64].contiguous()
+            d_pe_t[:, :d_pe] += R[sk][:, d_a:d_a + d_pe]
+            grad = hip.pe_encode_bwd(p, d_pe_t, n_octaves, scale)
+        if any(ctx.needs_input_grad):
+            ctx.meta = (n, sk, d_pe, d_a, n_octaves, scale, with_grad, chains)
+            keep = [p, pe] + Ws + A + S
+            if with_grad:
+                keep += U + R[1:]
+            ctx.save_for_backward(*keep)
+        if grad is None:
+            grad = torch.zeros(Q, 3, device=dev)
+            ctx.mark_non_differentiable(grad)
+        return logit, feat, grad
+
+    @staticmethod
+    def backward(ctx, d_logit, d_feat, d_grad):
+        n, sk, d_pe, d_a, n_octaves, scale, with_grad, chains = ctx.meta
+        sv = list(ctx.saved_tensors)
+        p, pe = sv[0], sv[1]
+        Ws = sv[2:2 + n]
+        A = sv[2 + n:2 + 2 * n - 1]
+        S = sv[2 + 2 * n - 1:2 + 3 * n - 2]
+        Q, dev = p.shape[0], p.device
+        sweep = with_grad and d_grad is not None
+        d_logit = torch.zeros(Q, 1, device=dev) if d_logit is None else d_logit.contiguous()
+        d_feat = torch.zeros(Q, 256, device=dev) if d_feat is None else d_feat.contiguous()
+        w_row = Ws[n - 1][0:1, :].contiguous()
+        dW = [None] * n
+        db = [None] * n
+
+        def add_dW(l, a_t, b_mat):  # dW[l] (+)= a_t^T @ b_mat
+            skk = _split_k_for(Q, a_t.shape[1], b_mat.shape[1])
+            if dW[l] is None:
+                dW[l] = hip.gemm(a_t, b_mat, trans_a=True, split_k=skk)
+            else:
+                hip.gemm(a_t, b_mat, trans_a=True, split_k=skk, out=dW[l], epi=hip.EPI_ACCUM)
+
+        dS = None
+        if sweep:
+            base = 2 + 3 * n - 2
+            U = sv[base:base + n - 1]
+            R = [None] + sv[base + n - 1:base + n - 1 + (n - 2)]
+            dd_pe = hip.pe_encode_jvp(p, d_grad.contiguous(), n_octaves, 64, scale)  # adjoint of d_pe, [Q,64]
+            dR = [dd_pe] + [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]   # dR[l], l = 0..n-1
+            dS = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]
+            r_last = w_row.expand(Q, 256).contiguous()
+            chains['sweep_bwd'](dd_pe, Q, mask=list(S), aux2=[R[l + 1] for l in range(n - 2)] + [r_last],
+                                save=dR[1:], save2=dS)
+            dR[sk][:, d_a:] = dd_pe[:, :d_pe]  # adjoint of the skip layer's [a | pe] sweep value
+            add_dW(0, U[0], dd_pe[:, :d_pe])
+            for l in range(1, n - 1):
+                add_dW(l, U[l][:, :Ws[l].shape[0]], dR[l][:, :Ws[l].shape[1]])
+            dW[n - 1] = torch.zeros_like(Ws[n - 1])
+            dW[n - 1][0] = hip.colsum(dR[n - 1])
+
+        # adjoint of the value pass
+        dZ = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]  # dZ[l] = d loss / d z_l
+        init = (d_logit * w_row).contiguous()  # [Q,256] rank-1 term of W_last^T d_out
+        key = 'value_bwd' if sweep else 'value_bwd_nosweep'
+        chains[key](None, Q, a_div=1, a_mod=Q, init_a_direct=init, act_init=d_feat,
+                    mask=[S[n - 2 - j] for j in range(n - 1)],
+                    aux2=[dS[n - 2 - j] for j in range(n - 1)] if sweep else None,
+                    save=[dZ[n - 2 - j] for j in range(n - 1)])
+        a_last = A[n - 2]
+        g_last = torch.cat([hip.colsum(d_logit * a_last).unsqueeze(0),
+                            hip.gemm(d_feat, a_last, trans_a=True, split_k=_split_k_for(Q, 256, 256))], dim=0)
+        dW[n - 1] = g_last if dW[n - 1] is None else dW[n - 1] + g_last
+        db[n - 1] = torch.cat([d_logit.sum(0), hip.colsum(d_feat)])
+        add_dW(0, dZ[0][:, :Ws[0].shape[0]], pe[:, :d_pe])
+        db[0] = hip.colsum(dZ[0][:, :Ws[0].shape[0]])
+        for l in range(1, n - 1):
+            o = Ws[l].shape[0]
+            add_dW(l, dZ[l][:, :o], A[l - 1][:, :Ws[l].shape[1]])
+            db[l] = hip.colsum(dZ[l][:, :o])
+        grads = []
+        for l in range(n):
+            grads += [dW[l], db[l]]
+        return (None, None, None, None, None, None) + tuple(grads)

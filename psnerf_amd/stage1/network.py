@@ -79,6 +79,8 @@ class NeuralNetwork(nn.Module):
             setattr(self, 'lina%d' % l, WNLinear(lin.weight.detach(), lin.bias.detach()))
         self._packed = None
         self._packed_key = None
+        self._chains = None
+        self._chains_key = None
 
     # ---- effective weights ----------------------------------------------------------------------
     def _geo_params(self):
@@ -100,20 +102,41 @@ class NeuralNetwork(nn.Module):
             bs.append(lin.bias)
         return Ws, bs
 
+    USE_FUSED_CHAINS = True
     MAX_ROWS = 1 << 18  # rows per GeoField call: bounds the saved activations to ~9 GB of the 288 GB HBM
 
-    def _geo(self, p_flat, with_grad):
+    def _geo_chains(self, params):
+        key = tuple(int(q._version) for q in self.parameters()) + (self.lin0.weight_v.data_ptr(),)
+        if self._chains is None or self._chains_key != key:
+            with torch.no_grad():
+                self._chains = fused.pack_geo_chains(params[0::2], params[1::2], self.skips, self.d_pe)
+            self._chains_key = key
+        return self._chains
+
+    def _geo_call(self, p_flat, with_grad, params, chains):
+        if chains is not None:
+            return ops.GeoFieldFused.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad,
+                                           chains, *params)
+        o, g = ops.GeoField.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad, *params)
+        return o[:, :1], o[:, 1:], g
+
+    def _geo_parts(self, p_flat, with_grad):
+        """(logit [Q,1], features [Q,F], d logit / d p [Q,3]) of the geometry network.  256-wide networks run as
+        fused register-resident chains (ops.GeoFieldFused); other widths fall back to the GEMM sequence."""
         params = self._geo_params()
+        chains = None
+        if self.USE_FUSED_CHAINS and self._hidden_is_256() and len(self.skips) == 1 and self.feat_size == 256 \
+                and self.n_geo <= 10 and self.d_pe <= 64:
+            chains = self._geo_chains(params)
         if p_flat.shape[0] <= self.MAX_ROWS:
-            return ops.GeoField.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad,
-                                      *params)
-        outs, grads = [], []
-        for s in range(0, p_flat.shape[0], self.MAX_ROWS):
-            o, g = ops.GeoField.apply(p_flat[s:s + self.MAX_ROWS], self.octaves_pe, 1.0 / self.rescale,
-                                      tuple(self.skips), with_grad, *params)
-            outs.append(o)
-            grads.append(g)
-        return torch.cat(outs, 0), torch.cat(grads, 0)
+            return self._geo_call(p_flat, with_grad, params, chains)
+        parts = [self._geo_call(p_flat[s:s + self.MAX_ROWS], with_grad, params, chains)
+                 for s in range(0, p_flat.shape[0], self.MAX_ROWS)]
+        return tuple(torch.cat([q[i] for q in parts], 0) for i in range(3))
+
+    def _geo(self, p_flat, with_grad):
+        logit, feat, grad = self._geo_parts(p_flat, with_grad)
+        return torch.cat([logit, feat], dim=1), grad
 
     def _occupancy_packed(self):
         key = tuple(int(q._version) for q in self.parameters()) + (self.lin0.weight_v.data_ptr(),)
@@ -168,20 +191,20 @@ class NeuralNetwork(nn.Module):
         if only_occupancy:
             if not torch.is_grad_enabled() and self.feat_size + 1 > 1 and self._hidden_is_256():
                 return self.occupancy(flat).reshape(*shp, 1)
-            out, _ = self._geo(flat, False)
-            return torch.sigmoid(out[:, :1] * -10.0).reshape(*shp, 1)
+            logit, _, _ = self._geo_parts(flat, False)
+            return torch.sigmoid(logit * -10.0).reshape(*shp, 1)
         if ray_d is not None:
-            out, grad = self._geo(flat, True)
+            logit, feat, grad = self._geo_parts(flat, True)
             v = ray_d.reshape(-1, 3)
             v = v / torch.norm(v, dim=-1, keepdim=True)
             v_pe = ops.positional_encoding(v, self.octaves_pe_views)
-            rgb = self._app(torch.cat([flat, v_pe, grad, out[:, 1:]], dim=-1)).reshape(*shp, 3)
+            rgb = self._app(torch.cat([flat, v_pe, grad, feat], dim=-1)).reshape(*shp, 3)
             if return_addocc:
-                return rgb, torch.sigmoid(out[:, :1] * -10.0).reshape(*shp, 1)
+                return rgb, torch.sigmoid(logit * -10.0).reshape(*shp, 1)
             return rgb
         if return_logits:
-            out, _ = self._geo(flat, False)
-            return (-1 * out[:, :1]).reshape(*shp, 1)
+            logit, _, _ = self._geo_parts(flat, False)
+            return (-1 * logit).reshape(*shp, 1)
         return None
 
     def _hidden_is_256(self):

@@ -48,6 +48,32 @@ def test_network_golden(cuda, tag, over):
     assert_close(projs, g['grad_projs'], 2e-3, 'grad projs')
 
 
+def test_geo_chains_vs_gemm_path(cuda):
+    """The fused register-resident chains (ops.GeoFieldFused) and the GEMM sequence (ops.GeoField) are two
+    implementations of the same double-backward: every parameter gradient must agree."""
+    from psnerf_amd.stage1 import NeuralNetwork
+    g = np.load(os.path.join(GOLDEN, 'stage1_net_h256.npz'))
+    cfg = stage1_cfg('bunny')
+    sd = stage1_state_dict(cfg, seed=11)
+    res = {}
+    for fusedp in (True, False):
+        net = NeuralNetwork(cfg)
+        net.load_state_dict(sd)
+        net.to(cuda)
+        net.USE_FUSED_CHAINS = fusedp
+        p, ray_d = T(g['p'], cuda), T(g['ray_d'], cuda)
+        rgb, alpha = net(p.clone(), ray_d, return_addocc=True)
+        grad = net.gradient(p.clone())[:, 0]
+        loss = (rgb * T(g['c_rgb'], cuda)).sum() + (alpha * T(g['c_alpha'], cuda)).sum() \
+            + (grad * T(g['c_grad'], cuda)).sum() * 0.1
+        loss.backward()
+        res[fusedp] = (rgb.detach().cpu(), grad.detach().cpu(), {k: v.grad.cpu() for k, v in net.named_parameters()})
+    assert_close(res[True][0], res[False][0], 1e-5, 'rgb')
+    assert_close(res[True][1], res[False][1], 1e-4, 'grad')
+    for k in res[True][2]:
+        assert_close(res[True][2][k], res[False][2][k], 1e-3, 'param grad ' + k)
+
+
 def test_network_state_dict_and_init(cuda):
     """Same seed -> same initial weights as the reference (digest captured by tools/gen_golden.py)."""
     from psnerf_amd.stage1 import NeuralNetwork
