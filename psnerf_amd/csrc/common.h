@@ -46,7 +46,8 @@ __device__ __forceinline__ float exp_neg_abs(float at) {
 __device__ __forceinline__ float log1p_unit(float u) {
     float ser = u * (1.0f - u * (0.5f - u * (0.333333343f - u * (0.25f - u * (0.2f - u * (0.166666672f - u * 0.142857149f))))));
     float w = 1.0f + u;
-    float big = fmaf(__builtin_amdgcn_logf(w), 0.693147182464599609375f, (u - (w - 1.0f)) / w);
+    // the correction term is O(2^-24) of the result, a 1-ulp reciprocal is plenty (and keeps the select branch-free)
+    float big = fmaf(__builtin_amdgcn_logf(w), 0.693147182464599609375f, (u - (w - 1.0f)) * __builtin_amdgcn_rcpf(w));
     return u < 0.0625f ? ser : big;
 }
 
@@ -59,7 +60,11 @@ __device__ __forceinline__ void softplus100_sig(float z, float& sp, float& s) {
     float l = log1p_unit(u);
     float r = 1.0f / (1.0f + u);
     s = t >= 0.0f ? r : u * r;
-    sp = t > 20.0f ? z : (fmaxf(t, 0.0f) + l) / 100.0f;
+    // x / 100 correctly rounded without the IEEE division sequence (its length makes hipcc branch around it)
+    float x = fmaxf(t, 0.0f) + l;
+    float q = x * 0.01f;
+    q = fmaf(fmaf(-q, 100.0f, x), 0.01f, q);
+    sp = t > 20.0f ? z : q;
 }
 __device__ __forceinline__ float softplus100(float z) {
     float sp, s;

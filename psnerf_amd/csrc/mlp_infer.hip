@@ -87,6 +87,67 @@ __device__ __forceinline__ void stage_load(const float* __restrict__ gsrc, float
     }
 }
 
+__device__ __forceinline__ floatx4 ld4(const float* p) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    floatx4 v;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    return v;
+}
+__device__ __forceinline__ void st4(float* p, const floatx4& v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+
+// Activation program of one chain layer (CHAIN variant).  The accumulators acc hold z; the result becomes the next
+// layer's B operands (act).  Operand tiles are row-major [n_rows, 256]: p1 / p2 point at this lane's 4 floats of
+// tile 0, tile mt is 16 floats further.  All operand loads of the layer are issued back to back (one exposed
+// latency per layer instead of one per tile) and all dump stores are issued at the end, where they complete under
+// the next layer's MFMAs.  p1 / p2 are non-null whenever CODE needs them (validated on the host).
+template <int CODE>
+__device__ __forceinline__ void chain_activation(floatx4 (&acc)[16], floatx4 (&act)[16], const float* __restrict__ p1,
+                                                 const float* __restrict__ p2, float* __restrict__ d1, float* __restrict__ d2) {
+    constexpr bool kNeed1 = CODE == PSN_ACT_RELU_MASK || CODE == PSN_ACT_MUL_AUX || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD;
+    constexpr bool kNeed2 = CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD;
+    constexpr bool kSecond = CODE == PSN_ACT_SOFTPLUS100 || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_MUL_AUX;
+    floatx4 t1[16], t2[16];
+    if constexpr (kNeed1) {
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) t1[mt] = ld4(p1 + mt * 16);
+    }
+    if constexpr (kNeed2) {
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) t2[mt] = ld4(p2 + mt * 16);
+    }
+    if constexpr (CODE == PSN_ACT_HEAD) {  // side output: dump z, the activations stay for the next layer
+        if (d1 != nullptr) {
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) st4(d1 + mt * 16, acc[mt]);
+        }
+        return;
+    }
+    // One 16-feature tile at a time (interleaving 16 softplus chains spills registers); each tile's results are
+    // stored as soon as they exist, so operand and second-value registers die tile by tile.
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt) {
+        floatx4 o, o2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float z = acc[mt][r];
+            o2[r] = z;
+            if constexpr (CODE == PSN_ACT_RELU) o[r] = fmaxf(z, 0.0f);
+            else if constexpr (CODE == PSN_ACT_SOFTPLUS100) { float a, sg; softplus100_sig(z, a, sg); o[r] = a; o2[r] = sg; }
+            else if constexpr (CODE == PSN_ACT_RELU_MASK) o[r] = t1[mt][r] > 0.0f ? z : 0.0f;
+            else if constexpr (CODE == PSN_ACT_MUL_AUX) o[r] = z * t1[mt][r];
+            else if constexpr (CODE == PSN_ACT_MUL2) { o[r] = z * t1[mt][r]; o2[r] = z * t2[mt][r]; }
+            else if constexpr (CODE == PSN_ACT_SOFTPLUS_BWD) o[r] = t1[mt][r] * (z + 100.0f * t2[mt][r] * (1.0f - t1[mt][r]));
+            else o[r] = z;
+        }
+        act[mt] = o;
+        if (d1 != nullptr) st4(d1 + mt * 16, o);
+        if constexpr (kSecond) {
+            if (d2 != nullptr) st4(d2 + mt * 16, o2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // CHAIN = false: lean inference / forward-with-dump path (NONE / RELU / SOFTPLUS100 activations, one dump per layer).
 // CHAIN = true : general per-layer activation programs with row-major operands and two dumps (training chains).
 template <bool CHAIN>
@@ -112,9 +173,11 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     const int64_t ib = (rowc / g.b_div) % g.b_mod;
     const float* init_a_row = g.init_a != nullptr ? g.init_a + ia * (int64_t)g.d.init_stride : nullptr;
     const float* init_b_row = g.init_b != nullptr ? g.init_b + ib * (int64_t)g.d.init_stride : nullptr;
-    {
-        const float* pa = g.ta != nullptr ? g.ta + ia * (int64_t)(g.d.in_kt_a * 32) : nullptr;
-        const float* pb = (g.d.in_kt_b > 0 && g.tb != nullptr) ? g.tb + ib * (int64_t)(g.d.in_kt_b * 32) : nullptr;
+    const float* pa = g.ta != nullptr ? g.ta + ia * (int64_t)(g.d.in_kt_a * 32) : nullptr;
+    const float* pb = (g.d.in_kt_b > 0 && g.tb != nullptr) ? g.tb + ib * (int64_t)(g.d.in_kt_b * 32) : nullptr;
+    // The lean variant keeps the input features in registers for the whole kernel; the chain variant needs those
+    // registers for its operand tiles and re-reads the (L2-resident) features at each layer that consumes them.
+    auto load_xin = [&]() {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const float* src = nullptr;
@@ -127,7 +190,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             xin[t][2] = v.z;
             xin[t][3] = v.w;
         }
-    }
+    };
+    if constexpr (!CHAIN) load_xin();
 
     for (int i = tid; i < g.n_bias; i += kWaves * 64) bias_lds[i] = g.b[i];  // visible after the first stage barrier
 
@@ -218,6 +282,16 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             }
         }
         // K tiles from the input features first, then from the previous activations (matches the packer)
+        if constexpr (CHAIN) {
+            if (L.n_kt_in > 0) {
+                load_xin();
+            } else {  // a fresh definition: keeps the 32 feature registers dead across the layers that do not use them
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xin[t][r] = 0.f;
+            }
+        }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             if (kt < L.n_kt_in) PSN_STAGE(16, xin[2 * kt], xin[2 * kt + 1], kt)
@@ -257,37 +331,19 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             const float* p2 = g.aux2[li] != nullptr ? g.aux2[li] + rowc * 256 + 4 * lg : nullptr;
             float* d1 = (g.save[li] != nullptr && dump_row) ? g.save[li] + (row - g.save_row0) * 256 + 4 * lg : nullptr;
             float* d2 = (g.save2[li] != nullptr && dump_row) ? g.save2[li] + (row - g.save_row0) * 256 + 4 * lg : nullptr;
-            const int code = L.act;
-#pragma unroll
-            for (int mt = 0; mt < 16; ++mt) {
-                float z[4] = {acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]};
-                float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f}, o[4], o2[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p1 != nullptr) {
-                    float4 t = *reinterpret_cast<const float4*>(p1 + mt * 16);
-                    a1[0] = t.x; a1[1] = t.y; a1[2] = t.z; a1[3] = t.w;
-                }
-                if (p2 != nullptr) {
-                    float4 t = *reinterpret_cast<const float4*>(p2 + mt * 16);
-                    a2[0] = t.x; a2[1] = t.y; a2[2] = t.z; a2[3] = t.w;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    switch (code) {
-                        case PSN_ACT_RELU: o[r] = fmaxf(z[r], 0.0f); break;
-                        case PSN_ACT_SOFTPLUS100: softplus100_sig(z[r], o[r], o2[r]); break;
-                        case PSN_ACT_RELU_MASK: o[r] = a1[r] > 0.0f ? z[r] : 0.0f; break;
-                        case PSN_ACT_MUL_AUX: o[r] = z[r] * a1[r]; o2[r] = z[r]; break;
-                        case PSN_ACT_MUL2: o[r] = z[r] * a1[r]; o2[r] = z[r] * a2[r]; break;
-                        case PSN_ACT_SOFTPLUS_BWD: o[r] = a1[r] * (z[r] + 100.0f * a2[r] * (1.0f - a1[r])); break;
-                        default: o[r] = z[r]; break;  // PSN_ACT_NONE, PSN_ACT_HEAD
-                    }
-                }
-                if (d1 != nullptr) *reinterpret_cast<float4*>(d1 + mt * 16) = make_float4(o[0], o[1], o[2], o[3]);
-                if (d2 != nullptr) *reinterpret_cast<float4*>(d2 + mt * 16) = make_float4(o2[0], o2[1], o2[2], o2[3]);
-                if (code != PSN_ACT_HEAD) {  // HEAD: a side output (dumped above); the activations stay for the next layer
-                    act[mt][0] = o[0]; act[mt][1] = o[1]; act[mt][2] = o[2]; act[mt][3] = o[3];
-                }
+            // one straight-line body per code (operand loads batched up front, results stored tile by tile)
+#define PSN_CASE(C) case C: chain_activation<C>(acc, act, p1, p2, d1, d2); break;
+            switch (L.act) {
+                PSN_CASE(PSN_ACT_RELU)
+                PSN_CASE(PSN_ACT_SOFTPLUS100)
+                PSN_CASE(PSN_ACT_RELU_MASK)
+                PSN_CASE(PSN_ACT_MUL_AUX)
+                PSN_CASE(PSN_ACT_MUL2)
+                PSN_CASE(PSN_ACT_SOFTPLUS_BWD)
+                PSN_CASE(PSN_ACT_HEAD)
+                default: chain_activation<PSN_ACT_NONE>(acc, act, p1, p2, d1, d2); break;
             }
+#undef PSN_CASE
             pending_dump = (g.save[li] != nullptr ? 16 : 0) + (g.save2[li] != nullptr ? 16 : 0);
         }
     }
@@ -434,8 +490,9 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     for (int l = 0; l < d.n_layers; ++l)
         chain = chain || d.layers[l].act > PSN_ACT_SOFTPLUS100 || a.save2[l] != nullptr || a.mask[l] != nullptr || a.aux2[l] != nullptr;
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
-    if (chain) hipLaunchKernelGGL(mlp_infer_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(mlp_infer_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)blocks), block(kWaves * 64);
+    if (chain) hipLaunchKernelGGL(mlp_infer_kernel<true>, grid, block, lds_bytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(mlp_infer_kernel<false>, grid, block, lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer");
     return PSN_OK;
 }
