@@ -304,17 +304,23 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         // are re-read and optional results (the new activation, a second value) are dumped per layer; the stores
         // are issued behind the already-requested next weight stage and complete under the next layer's MFMAs.
         if constexpr (!CHAIN) {
+            // the code is wave-uniform: branch once per layer, never per element (a branch-free softplus inside
+            // the element loop gets if-converted and then runs for the ReLU networks too)
+            if (L.act == PSN_ACT_RELU) {
 #pragma unroll
-            for (int mt = 0; mt < 16; ++mt) {
+                for (int mt = 0; mt < 16; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float z = acc[mt][r];
-                    float a;
-                    if (L.act == PSN_ACT_RELU) a = fmaxf(z, 0.0f);
-                    else if (L.act == PSN_ACT_SOFTPLUS100) a = softplus100(z);
-                    else a = z;
-                    act[mt][r] = a;
+                    for (int r = 0; r < 4; ++r) act[mt][r] = fmaxf(acc[mt][r], 0.0f);
+            } else if (L.act == PSN_ACT_SOFTPLUS100) {
+#pragma unroll
+                for (int mt = 0; mt < 16; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) act[mt][r] = softplus100(acc[mt][r]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 16; ++mt) act[mt] = acc[mt];
             }
             if (g.save[li] != nullptr) {
                 if (dump_row) {
