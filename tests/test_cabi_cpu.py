@@ -98,3 +98,24 @@ def test_state_dict_keys_match_reference_checkpoints():
     for net, n in (('albedo_net', 5), ('rough_net', 3), ('normal_net', 5), ('visibility_net', 9)):
         for i in range(n):
             assert {'%s.linears.%d.weight' % (net, i), '%s.linears.%d.bias' % (net, i)} <= k2
+
+
+def test_host_metrics():
+    """stage2/utils/metrics.py:17-51 semantics: float64, masked, zero vectors -> 90 degrees, identical -> 100 dB."""
+    import numpy as np
+    from psnerf_amd.metrics import MAE, PSNR
+    n1 = np.array([[0, 0, 2.0], [1, 0, 0], [0, 0, 0], [0, 1, 0]], dtype=np.float32)
+    n2 = np.array([[0, 0, 1.0], [0, 1, 0], [0, 0, 1], [0, 1, 1]], dtype=np.float32)
+    mean, err = MAE(n1, n2)
+    # the reference divides by (norm + 1e-5): parallel vectors come out at acos(1 - 1.5e-5) = 0.31 degrees, not 0
+    e0 = np.degrees(np.arccos((2 / (2 + 1e-5)) * (1 / (1 + 1e-5))))
+    np.testing.assert_allclose(err, [e0, 90.0, 90.0, 45.0], atol=2e-3)
+    assert abs(mean - (e0 + 225.0) / 4) < 1e-3
+    mean_m, err_m = MAE(n1, n2, mask=np.array([1, 0, 0, 1]))
+    assert err_m.shape == (2,) and abs(mean_m - (e0 + 45.0) / 2) < 1e-3
+    img = np.full((4, 4, 3), 0.5, dtype=np.float32)
+    assert PSNR(img, img) == 100
+    assert abs(PSNR(img, img + 0.1) - 20.0) < 1e-4
+    m = np.zeros((4, 4)); m[0, 0] = 1
+    img2 = img.copy(); img2[0, 0] += 0.01
+    assert abs(PSNR(img, img2, m) - 40.0) < 1e-3
