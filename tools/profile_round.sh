@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the measurement evidence of a round on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r01h
+# writes gpurun_out/<tag>/{bench_stage2.json, bench_stage1.json, *_kernel_stats.csv, pmc_*.csv};
+# tools/collect_profiles.py then copies / reduces them into profiles/ (tracked).
+# rocprofv3 rules of this pool: the program itself follows `--` (no env / bash hops), counters are collected in
+# their own passes with --kernel-trace only (never with sys / hip / hsa traces).
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+export TMPDIR=/tmp
+cd /tmp
+python3 $R/bench.py > $O/bench_stage2.json 2> $O/bench_stage2.err
+python3 $R/tools/bench_stage1.py > $O/bench_stage1.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps2 -o s2 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+cp $(find /tmp/ps2 -name '*kernel_stats*' | head -1) $O/bench_stage2_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps1 -o s1 -- python3 $R/tools/bench_stage1.py --steps 3 --warmup 1 > /dev/null 2>&1
+cp $(find /tmp/ps1 -name '*kernel_stats*' | head -1) $O/bench_stage1_kernel_stats.csv
+for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    N=$(echo $C | cut -d' ' -f1)
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$N -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+    F=$(find /tmp/pmc_$N -name '*counter_collection*' | head -1)
+    # keep the header and the fused-MLP dispatches only (the full table is large)
+    (head -1 $F; grep mlp_infer_kernel $F) > $O/pmc_$N.csv
+done
+ls -la $O
