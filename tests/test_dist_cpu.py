@@ -108,3 +108,65 @@ def test_slice_bounds_cover_everything_once():
                 lo, hi = dp.slice_bounds(n)
                 seen += list(range(lo, hi))
             assert seen == list(range(n))
+
+
+# ---- stage 1: ray sharding + global denominators of the stage-1 loss -----------------------------------------
+def _stage1_outputs(theta, x):
+    """A tiny differentiable stand-in for the renderer's output dictionary over rays x [1,N,3]: what is under
+    test is the DP plumbing around it (shard_rays, the loss's global denominators, the flat-bucket all-reduce)."""
+    y = x @ theta
+    hit = x[0, :, 0] > 0
+    return {'rgb': torch.sigmoid(y), 'diff_norm': (y[0][hit] ** 2).sum(-1), 'mask_pred': hit,
+            'normal_pred': torch.nn.functional.normalize(y, dim=-1), 'acc_map': torch.sigmoid(y.sum(-1))}
+
+
+def _stage1_case(n=203):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, n, 3, generator=g)
+    x[0, 150:, 0] = -x[0, 150:, 0].abs()  # the second shard gets (almost) no hits: empty diff_norm on one rank
+    rgb_gt = torch.rand(1, n, 3, generator=g)
+    normal_gt = torch.nn.functional.normalize(torch.randn(1, n, 3, generator=g), dim=-1)
+    norm_mask = torch.rand(1, n, generator=g) > 0.4
+    mask_gt = (torch.rand(1, n, generator=g) > 0.5).float()
+    mask_valid = torch.rand(1, n, generator=g) > 0.2
+    theta0 = torch.randn(3, 3, generator=g) * 0.5
+    return x, rgb_gt, normal_gt, norm_mask, mask_gt, mask_valid, theta0
+
+
+def _worker_stage1(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from psnerf_amd import dist as pdist
+    from psnerf_amd.stage1.losses import Loss
+    pdist.init_from_env(backend='gloo')
+    dp = pdist.DataParallel(torch.device('cpu'))
+    x, rgb_gt, normal_gt, norm_mask, mask_gt, mask_valid, theta0 = _stage1_case()
+    theta = theta0.clone().requires_grad_()
+    sh = dp.shard_rays  # every per-ray array is sliced the same way as the sampled pixel list
+    out = _stage1_outputs(theta, sh(x))
+    loss = Loss(1.0, 0.1, 0.5, 0.7)
+    loss.global_sum = dp.global_sum_int
+    terms = loss(out, sh(rgb_gt), sh(normal_gt), sh(norm_mask), out['acc_map'], sh(mask_gt), sh(mask_valid))
+    terms['loss'].backward()
+    dp.allreduce_grads([theta])
+    if rank == 0:
+        torch.save({'grad': theta.grad}, tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stage1_two_rank_loss_gradients(tmp_path):
+    from psnerf_amd.stage1.losses import Loss
+    from tests.helpers import assert_close
+    tmp = str(tmp_path / 'dp1.pt')
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_stage1, args=(2, port, tmp), nprocs=2, join=True)
+    got = torch.load(tmp)
+    x, rgb_gt, normal_gt, norm_mask, mask_gt, mask_valid, theta0 = _stage1_case()
+    theta = theta0.clone().requires_grad_()
+    out = _stage1_outputs(theta, x)
+    terms = Loss(1.0, 0.1, 0.5, 0.7)(out, rgb_gt, normal_gt, norm_mask, out['acc_map'], mask_gt, mask_valid)
+    terms['loss'].backward()
+    assert_close(got['grad'], theta.grad, 2e-5, 'stage-1 dp grad')
