@@ -140,6 +140,15 @@ def test_gemm_splitk_weight_grad(cuda, split):
     assert_close(out, ref, 1e-5, 'dW')
     cs = hip.colsum(dZ.to(cuda)).cpu()
     assert_close(cs, dZ.double().sum(0), 1e-5, 'colsum')
+    if split > 1:
+        # vectorised reduce (N % 4 == 0) with accumulation into a strided view, and the scalar fallback (N = 217)
+        base = torch.randn(O, 380 + 8, generator=g)
+        acc = base.clone().to(cuda)
+        hip.gemm(dZ.to(cuda), X[:, :380].contiguous().to(cuda), trans_a=True, split_k=split, out=acc[:, 4:384], epi=hip.EPI_ACCUM)
+        assert_close(acc[:, 4:384].cpu(), base[:, 4:384].double() + dZ.double().t() @ X[:, :380].double(), 1e-5, 'dW accumulate')
+        assert torch.equal(acc[:, :4].cpu(), base[:, :4]) and torch.equal(acc[:, 384:].cpu(), base[:, 384:])
+        out2 = hip.gemm(dZ.to(cuda), X[:, :217].contiguous().to(cuda), trans_a=True, split_k=split).cpu()
+        assert_close(out2, dZ.double().t() @ X[:, :217].double(), 1e-5, 'dW (N = 217)')
 
 
 def test_fused_visibility_mlp(cuda):
