@@ -74,7 +74,10 @@ int psn_pe_encode_bwd(const float* x, const float* d_out, int64_t n, int n_freqs
  * split_k > 1 (only epi NONE/ACCUM): K is cut into split_k slices, partial
  * tiles go to `workspace` (>= split_k*M*N floats) and are reduced
  * deterministically by a second kernel.
- * ---------------------------------------------------------------------- */
+ * ----------------------------------------------------------------------  * colsum_a (trans_a only, or NULL): receives sum_k A[k, m] for m < M as a by-product of staging the A tiles -- with
+ * A = dZ this is the bias gradient that accompanies the weight gradient dW = dZ^T X (nn.Linear backward), so no
+ * separate pass over dZ is needed.  With split_k > 1 the workspace must hold split_k * M * (N + 1) floats.
+ */
 enum {
     PSN_EPI_NONE = 0,          /* C = acc                                            */
     PSN_EPI_BIAS = 1,          /* C = acc + bias[n]                                  */
@@ -93,7 +96,7 @@ enum {
 int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const float* A, int64_t lda, const float* B,
              int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue, const float* aux_in,
              int64_t ld_aux_in, const float* aux_in2, int64_t ld_aux_in2, float* aux_out, int64_t ld_aux_out,
-             int split_k, float* workspace, void* stream);
+             int split_k, float* workspace, float* colsum_a, void* stream);
 
 /* column sums: out[n] (+)= sum_m X[m,n]  -- bias gradients.  workspace >= 2048*N floats */
 int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int accumulate, float* workspace,

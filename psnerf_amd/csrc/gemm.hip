@@ -40,6 +40,7 @@ struct GemmArgs {
     int a_vec, b_vec;  // 16-byte vector loads allowed
     int c_vec, auxin_vec, auxin2_vec, auxout_vec;  // 16-byte vector epilogue accesses allowed
     int64_t split_stride;  // floats between split-K partial outputs (0 when split_k == 1)
+    float* colsum;          // trans_a only, or nullptr: [split_k][M] sums over k of A[k, m] (bias gradient by-product)
 };
 
 // Stage one 128 x 16 operand tile into registers.  KCONTIG: source rows run along k (row-major [rows][K]);
@@ -147,10 +148,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // into registers and written to the other buffer after the MFMA stream (one barrier per k-tile).
     float4 ra0[2], rb0[BN / 64];
     const int nt = (k_end - k_begin + BK - 1) / BK;
+    // Bias-gradient by-product of dW = dZ^T X: with A = dZ stored [K][M], thread tid always stages the same four
+    // columns m0 + 4 (tid % 32) .. +3 (rows k = tid / 32 and tid / 32 + 8 of every k-tile), so their sum over k is one
+    // float4 per thread; only the n-tile-0 workgroups of each row panel keep it.
+    const bool do_cs = TA && g.colsum != nullptr && tn == 0;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #define PSN_FETCH(T)                                                                                    \
     fetch_tile<!TA, BM>(g.A, g.lda, m0, g.M, k_begin + (T) * BK, k_end, g.a_vec, tid, ra0);               \
     fetch_tile<TB, BN>(g.B, g.ldb, n0, g.N, k_begin + (T) * BK, k_end, g.b_vec, tid, rb0);
 #define PSN_STORE(BUF)                                                   \
+    if (TA && do_cs) {                                                   \
+        cs.x += ra0[0].x + ra0[1].x; cs.y += ra0[0].y + ra0[1].y;        \
+        cs.z += ra0[0].z + ra0[1].z; cs.w += ra0[0].w + ra0[1].w;        \
+    }                                                                    \
     store_tile<!TA, BM>(lds_raw + (BUF) * BUF_FLOATS, tid, ra0);         \
     store_tile<TB, BN>(lds_raw + (BUF) * BUF_FLOATS + A_FLOATS, tid, rb0);
 // MFMA operands of k-step j+1 are read from LDS while the MFMAs of step j execute (two register sets, order
@@ -191,6 +201,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #undef PSN_FETCH
 #undef PSN_STORE
 #undef PSN_COMPUTE
+
+    if (TA && do_cs) {  // fixed-order reduction over the 8 threads that share a column group: deterministic
+        cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64);
+        cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
+        float4* red = reinterpret_cast<float4*>(lds_raw);  // the operand tiles are dead (barrier at the loop end)
+        if (lane < 32) red[wave * 32 + lane] = cs;
+        __syncthreads();
+        if (tid < 32) {
+            float4 a = red[tid], b = red[32 + tid], c = red[64 + tid], d = red[96 + tid];
+            float* dst = g.colsum + (int64_t)split * g.M + m0 + 4 * tid;
+            const float v[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (m0 + 4 * tid + e < g.M) dst[e] = v[e];
+        }
+        __syncthreads();  // the epilogue re-uses the same LDS
+    }
 
     // epilogue.  Lane (j = li, h = lh) holds C[m0 + wr*64 + it*32 + (r&3) + 8*(r>>2) + 4*h][n0 + wc*64 + jt*32 + j].
     // Each wave transposes one 32 x 64 half of its tile through a private LDS tile and then walks it in
@@ -364,9 +391,10 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const float* A, int64_t lda,
                         const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
                         const float* aux_in, int64_t ld_aux_in, const float* aux_in2, int64_t ld_aux_in2,
-                        float* aux_out, int64_t ld_aux_out, int split_k, float* workspace, void* stream) {
+                        float* aux_out, int64_t ld_aux_out, int split_k, float* workspace, float* colsum_a, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(A && B && C, "gemm: null operand");
+    PSN_CHECK_ARG(colsum_a == nullptr || trans_a, "gemm: colsum_a needs trans_a (A stored [K][M])");
     PSN_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
     PSN_CHECK_ARG(epilogue >= 0 && epilogue <= PSN_EPI_MUL_AUX_RAW, "gemm: unknown epilogue %d", epilogue);
     if (epilogue == PSN_EPI_MUL_AUX || epilogue == PSN_EPI_MUL_POS || epilogue >= PSN_EPI_MUL2) PSN_CHECK_ARG(aux_in, "gemm: epilogue needs aux_in");
@@ -413,6 +441,8 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
     }
     g.c_vec = (((uintptr_t)g.C & 15) == 0) && (g.ldc % 4 == 0) && (g.split_stride % 4 == 0);
     g.split_k = split_k;
+    // column sums of A: straight to the caller's buffer, or per-split partials behind the C partials
+    g.colsum = colsum_a == nullptr ? nullptr : (split_k > 1 ? workspace + (int64_t)split_k * M * N : colsum_a);
     PSN_CHECK_ARG(g.n_tiles * split_k < (1ll << 31), "gemm: too many blocks");
     dim3 grid((unsigned)(g.n_tiles * split_k)), block(256);
 #define PSN_LAUNCH(TA_, TB_)                                                                          \
@@ -436,6 +466,11 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, workspace, MN, N, ldc, split_k, acc, C);
         }
         PSN_CHECK_LAUNCH("gemm split-k reduce");
+        if (colsum_a != nullptr) {  // [split_k][M] partial column sums -> colsum_a[M]
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, g.colsum, M, (int)M, M,
+                               split_k, 0, colsum_a);
+            PSN_CHECK_LAUNCH("gemm split-k colsum reduce");
+        }
     }
     return PSN_OK;
 }

@@ -51,7 +51,7 @@ SIGNATURES = {
     'psn_pe_encode_bwd': (i32, [c_f, c_f, i64, i32, f32, i32, c_f, c_f]),
     'psn_pe_encode_jvp': (i32, [c_f, c_f, i64, i32, f32, c_f, i32, c_f]),
     'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, c_f, i64,
-                       i32, c_f, c_f]),
+                       i32, c_f, c_f, c_f]),
     'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, c_f, c_f]),
     'psn_sg_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f]),
@@ -181,8 +181,9 @@ def _mat_ptr(t, name):
 
 
 def gemm(A, B, trans_a=False, trans_b=False, bias=None, epi=EPI_NONE, aux_in=None, out=None, aux_out=None,
-         split_k=1, aux_in2=None):
-    """out[M,N] = epi(op(A) @ op(B)).  A/B/out/aux may be row-major views with a row stride."""
+         split_k=1, aux_in2=None, colsum_a=None):
+    """out[M,N] = epi(op(A) @ op(B)).  A/B/out/aux may be row-major views with a row stride.
+    colsum_a (trans_a only): [M] tensor that receives the column sums of A (= the bias gradient when A = dZ)."""
     if trans_a:
         K, M = A.shape
     else:
@@ -197,7 +198,7 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, epi=EPI_NONE, aux_in=Non
     assert out.shape == (M, N)
     ws = None
     if split_k > 1:
-        ws = workspace(split_k * M * N, A.device)
+        ws = workspace(split_k * M * (N + 1), A.device)
     _check(_lib.psn_gemm(int(trans_a), int(trans_b), M, N, K, _mat_ptr(A, 'A'), _ld(A), _mat_ptr(B, 'B'), _ld(B),
                          _mat_ptr(out, 'out'), _ld(out), _ptr(bias, 'bias', True), epi,
                          None if aux_in is None else _mat_ptr(aux_in, 'aux_in'), 0 if aux_in is None else _ld(aux_in),
@@ -205,7 +206,7 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, epi=EPI_NONE, aux_in=Non
                          0 if aux_in2 is None else _ld(aux_in2),
                          None if aux_out is None else _mat_ptr(aux_out, 'aux_out'),
                          0 if aux_out is None else _ld(aux_out), split_k,
-                         None if ws is None else ws.data_ptr(), _stream()), 'gemm')
+                         None if ws is None else ws.data_ptr(), _ptr(colsum_a, 'colsum_a', True), _stream()), 'gemm')
     return out
 
 

@@ -136,16 +136,21 @@ class ReluMLP(torch.autograd.Function):
         needs = ctx.needs_input_grad[4:]
         for li in range(n - 1, -1, -1):
             inp, Wp = ins[li], Wps[li]
+            db_done = False
             if needs[2 * li]:
+                db = torch.empty(g.shape[1], device=g.device) if needs[2 * li + 1] else None
                 dWp = hip.gemm(g, inp, trans_a=True, trans_b=False,
-                               split_k=_split_k_for(Q, g.shape[1], inp.shape[1]))
+                               split_k=_split_k_for(Q, g.shape[1], inp.shape[1]), colsum_a=db)  # bias grad = by-product
+                if db is not None:
+                    grads[2 * li + 1] = db
+                    db_done = True
                 if li == 0:
                     grads[0] = dWp[:, in_cols] if in_cols is not None else dWp
                 elif li - 1 == ctx.skip_at:
                     grads[2 * li] = torch.cat([dWp[:, :width], dWp[:, width + in_cols]], dim=1)
                 else:
                     grads[2 * li] = dWp
-            if needs[2 * li + 1]:
+            if needs[2 * li + 1] and not db_done:
                 grads[2 * li + 1] = hip.colsum(g)
             if li > 0:
                 if ctx.x_needs and li - 1 == ctx.skip_at:
@@ -368,12 +373,15 @@ class GeoField(torch.autograd.Function):
         sweep = ctx.with_grad and d_grad is not None
         dS = [None] * (n - 1)
 
-        def add_dW(l, a_t, b_mat):  # dW[l] (+)= a_t^T @ b_mat
+        def add_dW(l, a_t, b_mat, with_bias=False):  # dW[l] (+)= a_t^T @ b_mat ; db[l] = column sums of a_t
             sk = _split_k_for(Q, a_t.shape[1], b_mat.shape[1])
+            cs = torch.empty(a_t.shape[1], device=dev) if with_bias else None
             if dW[l] is None:
-                dW[l] = hip.gemm(a_t, b_mat, trans_a=True, split_k=sk)
+                dW[l] = hip.gemm(a_t, b_mat, trans_a=True, split_k=sk, colsum_a=cs)
             else:
-                hip.gemm(a_t, b_mat, trans_a=True, split_k=sk, out=dW[l], epi=hip.EPI_ACCUM)
+                hip.gemm(a_t, b_mat, trans_a=True, split_k=sk, out=dW[l], epi=hip.EPI_ACCUM, colsum_a=cs)
+            if with_bias:
+                db[l] = cs
 
         if sweep:
             base = 2 + 3 * n - 1
@@ -403,8 +411,7 @@ class GeoField(torch.autograd.Function):
             dW[n - 1][0] = hip.colsum(dR)
 
         g = d_out.contiguous()
-        add_dW(n - 1, g, A[n - 1])
-        db[n - 1] = hip.colsum(g)
+        add_dW(n - 1, g, A[n - 1], with_bias=True)
         for l in range(n - 1, 0, -1):
             in_a = Ws[l].shape[1] - d_pe if l in skips else Ws[l].shape[1]
             g_prev = _buf(Q, in_a, dev)
@@ -413,8 +420,7 @@ class GeoField(torch.autograd.Function):
             else:
                 hip.gemm(g, Ws[l][:, :in_a], epi=hip.EPI_MUL_AUX, aux_in=S[l - 1], out=g_prev)
             g = g_prev
-            add_dW(l - 1, g, A[l - 1])
-            db[l - 1] = hip.colsum(g)
+            add_dW(l - 1, g, A[l - 1], with_bias=True)
         dW[0] = dW[0][:, :d_pe]
         grads = []
         for l in range(n):
@@ -536,11 +542,13 @@ class VisibilityPair(torch.autograd.Function):
               save=DZ, save_row0=0)
         for li in range(n - 2, -1, -1):
             dz = DZ[n - 2 - li]
-            grads[2 * li + 1] = hip.colsum(dz)
             if li == 0:
+                grads[1] = hip.colsum(dz)
                 grads[0] = in_block_grad(dz)
                 break
-            dWh = hip.gemm(dz, H[li - 1], trans_a=True, split_k=_split_k_for(Q, 256, 256))
+            db = torch.empty(256, device=g.device)
+            dWh = hip.gemm(dz, H[li - 1], trans_a=True, split_k=_split_k_for(Q, 256, 256), colsum_a=db)
+            grads[2 * li + 1] = db
             if li - 1 == ctx.skip_at:
                 grads[2 * li] = torch.cat([dWh, in_block_grad(dz)], dim=1)
             else:
@@ -615,12 +623,15 @@ class GeoFieldFused(torch.autograd.Function):
         dW = [None] * n
         db = [None] * n
 
-        def add_dW(l, a_t, b_mat):  # dW[l] (+)= a_t^T @ b_mat
+        def add_dW(l, a_t, b_mat, with_bias=False):  # dW[l] (+)= a_t^T @ b_mat ; db[l] = column sums of a_t
             skk = _split_k_for(Q, a_t.shape[1], b_mat.shape[1])
+            cs = torch.empty(a_t.shape[1], device=dev) if with_bias else None
             if dW[l] is None:
-                dW[l] = hip.gemm(a_t, b_mat, trans_a=True, split_k=skk)
+                dW[l] = hip.gemm(a_t, b_mat, trans_a=True, split_k=skk, colsum_a=cs)
             else:
-                hip.gemm(a_t, b_mat, trans_a=True, split_k=skk, out=dW[l], epi=hip.EPI_ACCUM)
+                hip.gemm(a_t, b_mat, trans_a=True, split_k=skk, out=dW[l], epi=hip.EPI_ACCUM, colsum_a=cs)
+            if with_bias:
+                db[l] = cs
 
         dS = None
         if sweep:
@@ -653,12 +664,10 @@ class GeoFieldFused(torch.autograd.Function):
                             hip.gemm(d_feat, a_last, trans_a=True, split_k=_split_k_for(Q, 256, 256))], dim=0)
         dW[n - 1] = g_last if dW[n - 1] is None else dW[n - 1] + g_last
         db[n - 1] = torch.cat([d_logit.sum(0), hip.colsum(d_feat)])
-        add_dW(0, dZ[0][:, :Ws[0].shape[0]], pe[:, :d_pe])
-        db[0] = hip.colsum(dZ[0][:, :Ws[0].shape[0]])
+        add_dW(0, dZ[0][:, :Ws[0].shape[0]], pe[:, :d_pe], with_bias=True)
         for l in range(1, n - 1):
             o = Ws[l].shape[0]
-            add_dW(l, dZ[l][:, :o], A[l - 1][:, :Ws[l].shape[1]])
-            db[l] = hip.colsum(dZ[l][:, :o])
+            add_dW(l, dZ[l][:, :o], A[l - 1][:, :Ws[l].shape[1]], with_bias=True)
         grads = []
         for l in range(n):
             grads += [dW[l], db[l]]

@@ -56,7 +56,7 @@ def test_argument_validation_needs_no_gpu():
     lib = hip._lib
     rc = lib.psn_composite_fwd(None, None, 4, 8, 1, None, None, None, None)
     assert rc == -1 and b'null' in lib.psn_last_error()
-    rc = lib.psn_gemm(0, 1, 4, 0, 4, 1, 4, 1, 4, 1, 4, None, 0, None, 0, None, 0, None, 0, 1, None, None)
+    rc = lib.psn_gemm(0, 1, 4, 0, 4, 1, 4, 1, 4, 1, 4, None, 0, None, 0, None, 0, None, 0, 1, None, None, None)
     assert rc == -1 and b'bad shape' in lib.psn_last_error()
 
 

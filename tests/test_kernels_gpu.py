@@ -140,6 +140,13 @@ def test_gemm_splitk_weight_grad(cuda, split):
     assert_close(out, ref, 1e-5, 'dW')
     cs = hip.colsum(dZ.to(cuda)).cpu()
     assert_close(cs, dZ.double().sum(0), 1e-5, 'colsum')
+    # bias gradient as a by-product of the weight-gradient GEMM (column sums of A), ragged M and strided A
+    for cols in (256, 217, 1):
+        cs2 = torch.empty(cols, device=cuda)
+        a_view = dZ.to(cuda)[:, :cols]
+        out3 = hip.gemm(a_view, X.to(cuda), trans_a=True, split_k=split, colsum_a=cs2).cpu()
+        assert_close(out3, dZ[:, :cols].double().t() @ X.double(), 1e-5, 'dW with colsum (%d)' % cols)
+        assert_close(cs2.cpu(), dZ[:, :cols].double().sum(0), 1e-5, 'colsum by-product (%d)' % cols)
     if split > 1:
         # vectorised reduce (N % 4 == 0) with accumulation into a strided view, and the scalar fallback (N = 217)
         base = torch.randn(O, 380 + 8, generator=g)
