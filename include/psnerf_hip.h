@@ -98,6 +98,26 @@ int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const float* A, 
              int64_t ld_aux_in, const float* aux_in2, int64_t ld_aux_in2, float* aux_out, int64_t ld_aux_out,
              int split_k, float* workspace, float* colsum_a, void* stream);
 
+/* Grouped weight gradients of one backward pass (nn.Linear backward of every layer of a network at once):
+ *   C_i [M_i, N_i] (+)= A_i^T B_i (+ A2_i^T B2_i),    colsum_a_i [M_i] = column sums of A_i      for i < n_items
+ * with A_i = dZ_i [K, M_i], B_i = the layer input [K, N_i] (row-major, row strides lda / ldb), all sharing K = the
+ * number of rows of the pass.  One launch over all items + one reduction launch; split_k slices of K per product.
+ * The optional second product covers a layer that is used twice (stage1/model/network.py:108-120: value pass and
+ * gradient sweep share the weights).  n_items <= 12.  workspace: sum over items of
+ * n_products * split_k * M * N + split_k * M floats (+ 8 floats of padding per item). */
+typedef struct {
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    const float* A2; int64_t lda2;   /* NULL: single product */
+    const float* B2; int64_t ldb2;
+    float* C; int64_t ldc;
+    int M, N;
+    int accumulate;                  /* 0: C = ..., 1: C += ... */
+    float* colsum_a;                 /* NULL or [M] */
+} PsnGemmTnItem;
+int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
+                        int64_t workspace_floats, void* stream);
+
 /* column sums: out[n] (+)= sum_m X[m,n]  -- bias gradients.  workspace >= 2048*N floats */
 int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int accumulate, float* workspace,
                void* stream);

@@ -41,6 +41,13 @@ struct GemmArgs {
     int c_vec, auxin_vec, auxin2_vec, auxout_vec;  // 16-byte vector epilogue accesses allowed
     int64_t split_stride;  // floats between split-K partial outputs (0 when split_k == 1)
     float* colsum;          // trans_a only, or nullptr: [split_k][M] sums over k of A[k, m] (bias gradient by-product)
+    // optional second product accumulated into the same C (grouped weight gradients: C = A^T B + A2^T B2): the splits
+    // seg_splits .. split_k-1 run over (A2, B2); seg_splits == split_k when there is no second segment
+    const float* A2;
+    int64_t lda2;
+    const float* B2;
+    int64_t ldb2;
+    int seg_splits;
 };
 
 // Stage one 128 x 16 operand tile into registers.  KCONTIG: source rows run along k (row-major [rows][K]);
@@ -106,13 +113,19 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, con
     }
 }
 
-template <bool TA, bool TB, int NT>  // NT = 32-column MFMA tiles per wave in N: BN = 64 * NT
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    constexpr int BN = 64 * NT, LDB = BN + 4;
-    constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB, BUF_FLOATS = A_FLOATS + B_FLOATS;
-    constexpr int LDS_FLOATS = 2 * BUF_FLOATS > 4 * 32 * EPI_LD ? 2 * BUF_FLOATS : 4 * 32 * EPI_LD;
+template <int NT>
+struct GemmLds {
+    static constexpr int BN = 64 * NT, LDB = BN + 4;
+    static constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB, BUF_FLOATS = A_FLOATS + B_FLOATS;
     // operand tiles [buf]{A[BK][LDA], B[BK][LDB]}; re-used by the epilogue as 4 wave-private [32][EPI_LD] tiles
-    __shared__ __attribute__((aligned(16))) float lds_raw[LDS_FLOATS];
+    static constexpr int FLOATS = 2 * BUF_FLOATS > 4 * 32 * EPI_LD ? 2 * BUF_FLOATS : 4 * 32 * EPI_LD;
+};
+
+// One workgroup = one (output tile, split-K slice) work item `bid` of the problem g.
+template <bool TA, bool TB, int NT>  // NT = 32-column MFMA tiles per wave in N: BN = 64 * NT
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t bid, float* lds_raw) {
+    constexpr int BN = GemmLds<NT>::BN, LDB = GemmLds<NT>::LDB;
+    constexpr int A_FLOATS = GemmLds<NT>::A_FLOATS, BUF_FLOATS = GemmLds<NT>::BUF_FLOATS;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -124,7 +137,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // stream the same K-chunk of both operands) -- run on the same L2 at about the same time.  Bijective
     // remap (guide T1) over the 1-D grid of n_tiles * split_k blocks.
     const int64_t nb = g.n_tiles * (int64_t)g.split_k;
-    int64_t bid = blockIdx.x;
     int64_t q = nb / 8, r8 = nb % 8, xcd = bid % 8, idx = bid / 8;
     int64_t w = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
     const int split = (int)(w / g.n_tiles);
@@ -133,7 +145,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int tn = (int)(t % g.tiles_n);
     const int64_t m0 = tm * BM;
     const int n0 = tn * BN;
-    const int k_begin = split * g.k_chunk;
+    const bool seg2 = split >= g.seg_splits;  // second (A2, B2) product of a grouped weight gradient
+    const float* Ap = seg2 ? g.A2 : g.A;
+    const float* Bp = seg2 ? g.B2 : g.B;
+    const int64_t lda = seg2 ? g.lda2 : g.lda, ldb = seg2 ? g.ldb2 : g.ldb;
+    const int k_begin = (seg2 ? split - g.seg_splits : split) * g.k_chunk;
     const int k_end = min(g.K, k_begin + g.k_chunk);
 
     floatx16 acc[2][NT];
@@ -151,11 +167,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // Bias-gradient by-product of dW = dZ^T X: with A = dZ stored [K][M], thread tid always stages the same four
     // columns m0 + 4 (tid % 32) .. +3 (rows k = tid / 32 and tid / 32 + 8 of every k-tile), so their sum over k is one
     // float4 per thread; only the n-tile-0 workgroups of each row panel keep it.
-    const bool do_cs = TA && g.colsum != nullptr && tn == 0;
+    const bool do_cs = TA && g.colsum != nullptr && tn == 0 && !seg2;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #define PSN_FETCH(T)                                                                                    \
-    fetch_tile<!TA, BM>(g.A, g.lda, m0, g.M, k_begin + (T) * BK, k_end, g.a_vec, tid, ra0);               \
-    fetch_tile<TB, BN>(g.B, g.ldb, n0, g.N, k_begin + (T) * BK, k_end, g.b_vec, tid, rb0);
+    fetch_tile<!TA, BM>(Ap, lda, m0, g.M, k_begin + (T) * BK, k_end, g.a_vec, tid, ra0);               \
+    fetch_tile<TB, BN>(Bp, ldb, n0, g.N, k_begin + (T) * BK, k_end, g.b_vec, tid, rb0);
 #define PSN_STORE(BUF)                                                   \
     if (TA && do_cs) {                                                   \
         cs.x += ra0[0].x + ra0[1].x; cs.y += ra0[0].y + ra0[1].y;        \
@@ -309,6 +325,99 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }  // cg
 }
 
+template <bool TA, bool TB, int NT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds_raw[GemmLds<NT>::FLOATS];
+    gemm_tile<TA, TB, NT>(g, blockIdx.x, lds_raw);
+}
+
+// Grouped weight gradients: up to kMaxGroup independent C_i = A_i^T B_i (+ A2_i^T B2_i) problems that share K (the row
+// count of one backward pass) in ONE launch.  A single 256 x 256 gradient has only four output tiles, so on its own it
+// needs ~128 split-K slices to fill 256 CUs and then spends as long reducing 128 partial tiles as multiplying; sixteen
+// of them together fill the chip with 8 slices each.  Block ranges are padded to multiples of 8 so that the XCD-aware
+// work order of gemm_tile stays aligned with the hardware's block -> XCD round robin.
+constexpr int kMaxGroup = 12;
+struct GroupedArgs {
+    int n;
+    int64_t block_start[kMaxGroup + 1];
+    GemmArgs g[kMaxGroup];
+};
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(GroupedArgs gg) {
+    __shared__ __attribute__((aligned(16))) float lds_raw[GemmLds<2>::FLOATS];
+    int i = 0;
+    while (i + 1 < gg.n && (int64_t)blockIdx.x >= gg.block_start[i + 1]) ++i;
+    const GemmArgs g = gg.g[i];
+    const int64_t bid = (int64_t)blockIdx.x - gg.block_start[i];
+    if (bid >= g.n_tiles * (int64_t)g.split_k) return;  // padding block
+    gemm_tile<true, false, 2>(g, bid, lds_raw);
+}
+
+struct ReduceItem {
+    const float* ws;       // [splits][M*N] partial outputs
+    const float* cs_ws;    // [cs_splits][M] partial column sums or nullptr
+    float* C;
+    float* colsum;
+    int64_t MN, ldc;
+    int N, M, splits, cs_splits, accumulate, vec;
+    int blocks;            // blocks that reduce C; the following ceil(M/256) blocks reduce the column sums
+};
+struct GroupedReduceArgs {
+    ReduceItem it[kMaxGroup];
+};
+__global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupedReduceArgs ra) {
+    const ReduceItem r = ra.it[blockIdx.y];
+    __shared__ float4 red[8][32];
+    const int b = blockIdx.x;
+    if (b < r.blocks) {
+        if (r.vec) {  // same scheme as splitk_reduce_vec_kernel
+            const int tx = threadIdx.x & 31, tz = threadIdx.x >> 5;
+            const int64_t i = ((int64_t)b * 32 + tx) * 4;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < r.MN) {
+                const int per = (r.splits + 7) / 8;
+                const int z0 = tz * per, z1 = min(r.splits, z0 + per);
+#pragma unroll 8
+                for (int z = z0; z < z1; ++z) {
+                    const float4 v = *reinterpret_cast<const float4*>(r.ws + (int64_t)z * r.MN + i);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            }
+            red[tz][tx] = s;
+            __syncthreads();
+            if (tz == 0 && i < r.MN) {
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    const float4 v = red[k][tx];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                const int64_t m = i / r.N, n = i % r.N;
+                float4* cp = reinterpret_cast<float4*>(r.C + m * r.ldc + n);
+                if (r.accumulate) {
+                    const float4 c = *cp;
+                    s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+                }
+                *cp = s;
+            }
+        } else {
+            const int64_t i = (int64_t)b * 256 + threadIdx.x;
+            if (i < r.MN) {
+                float s = 0.0f;
+                for (int z = 0; z < r.splits; ++z) s += r.ws[(int64_t)z * r.MN + i];
+                const int64_t m = i / r.N, n = i % r.N;
+                float* cp = r.C + m * r.ldc + n;
+                *cp = r.accumulate ? (*cp + s) : s;
+            }
+        }
+    } else if (r.colsum != nullptr) {
+        const int64_t m = (int64_t)(b - r.blocks) * 256 + threadIdx.x;
+        if (m < r.M) {
+            float s = 0.0f;
+            for (int z = 0; z < r.cs_splits; ++z) s += r.cs_ws[(int64_t)z * r.M + m];
+            r.colsum[m] = s;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int64_t MN, int N,
                                                             int64_t ldc, int splits, int accumulate,
                                                             float* __restrict__ C) {
@@ -443,6 +552,7 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
     g.split_k = split_k;
     // column sums of A: straight to the caller's buffer, or per-split partials behind the C partials
     g.colsum = colsum_a == nullptr ? nullptr : (split_k > 1 ? workspace + (int64_t)split_k * M * N : colsum_a);
+    g.A2 = nullptr; g.B2 = nullptr; g.lda2 = g.ldb2 = 0; g.seg_splits = split_k;
     PSN_CHECK_ARG(g.n_tiles * split_k < (1ll << 31), "gemm: too many blocks");
     dim3 grid((unsigned)(g.n_tiles * split_k)), block(256);
 #define PSN_LAUNCH(TA_, TB_)                                                                          \
@@ -472,6 +582,69 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
             PSN_CHECK_LAUNCH("gemm split-k colsum reduce");
         }
     }
+    return PSN_OK;
+}
+
+extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
+                                   int64_t workspace_floats, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(items && n_items >= 1 && n_items <= kMaxGroup, "gemm_tn_grouped: n_items=%d (1..%d)", n_items, kMaxGroup);
+    PSN_CHECK_ARG(K > 0 && K < (1ll << 31) && workspace, "gemm_tn_grouped: bad K or null workspace");
+    if (split_k < 1) split_k = 1;
+    int kc = (int)((K + split_k - 1) / split_k);
+    kc = ((kc + BK - 1) / BK) * BK;
+    split_k = (int)((K + kc - 1) / kc);
+    GroupedArgs gg;
+    GroupedReduceArgs ra;
+    gg.n = n_items;
+    int64_t blocks = 0, ws_off = 0;
+    int max_rblocks = 1;
+    for (int i = 0; i < n_items; ++i) {
+        const PsnGemmTnItem& it = items[i];
+        PSN_CHECK_ARG(it.A && it.B && it.C && it.M > 0 && it.N > 0, "gemm_tn_grouped: item %d has a null operand or empty shape", i);
+        PSN_CHECK_ARG((it.A2 == nullptr) == (it.B2 == nullptr), "gemm_tn_grouped: item %d needs both A2 and B2", i);
+        const int n_seg = it.A2 ? 2 : 1;
+        GemmArgs& g = gg.g[i];
+        g.M = it.M; g.N = it.N; g.K = (int)K; g.A = it.A; g.lda = it.lda; g.B = it.B; g.ldb = it.ldb;
+        g.A2 = it.A2; g.lda2 = it.lda2; g.B2 = it.B2; g.ldb2 = it.ldb2;
+        g.bias = nullptr; g.epi = PSN_EPI_NONE; g.aux_in = g.aux_in2 = nullptr; g.aux_out = nullptr;
+        g.ld_aux_in = g.ld_aux_in2 = g.ld_aux_out = 0;
+        g.tiles_n = (it.N + 127) / 128;
+        g.n_tiles = (int64_t)((it.M + BM - 1) / BM) * g.tiles_n;
+        g.k_chunk = kc;
+        g.split_k = split_k * n_seg;
+        g.seg_splits = split_k;
+        g.a_vec = (((uintptr_t)it.A & 15) == 0) && (it.lda % 4 == 0) && (!it.A2 || ((((uintptr_t)it.A2 & 15) == 0) && (it.lda2 % 4 == 0)));
+        g.b_vec = (((uintptr_t)it.B & 15) == 0) && (it.ldb % 4 == 0) && (!it.B2 || ((((uintptr_t)it.B2 & 15) == 0) && (it.ldb2 % 4 == 0)));
+        g.auxin_vec = g.auxin2_vec = g.auxout_vec = 0;
+        const int64_t MN = (int64_t)it.M * it.N;
+        g.C = workspace + ws_off;
+        g.ldc = it.N;
+        g.split_stride = MN;
+        g.c_vec = ((ws_off % 4) == 0) && (it.N % 4 == 0) && (MN % 4 == 0) && (((uintptr_t)workspace & 15) == 0);
+        ws_off += MN * g.split_k;
+        ws_off = (ws_off + 3) / 4 * 4;
+        g.colsum = it.colsum_a ? workspace + ws_off : nullptr;
+        ReduceItem& r = ra.it[i];
+        r.ws = g.C; r.cs_ws = g.colsum; r.C = it.C; r.colsum = it.colsum_a; r.MN = MN; r.ldc = it.ldc; r.N = it.N; r.M = it.M;
+        r.splits = g.split_k; r.cs_splits = split_k; r.accumulate = it.accumulate ? 1 : 0;
+        r.vec = g.c_vec && (it.ldc % 4 == 0) && (((uintptr_t)it.C & 15) == 0);
+        r.blocks = (int)(r.vec ? (MN + 127) / 128 : (MN + 255) / 256);
+        const int rb = r.blocks + (it.colsum_a ? (it.M + 255) / 256 : 0);
+        if (rb > max_rblocks) max_rblocks = rb;
+        if (it.colsum_a) ws_off += (int64_t)split_k * it.M;
+        ws_off = (ws_off + 3) / 4 * 4;
+        gg.block_start[i] = blocks;
+        blocks += (g.n_tiles * g.split_k + 7) / 8 * 8;
+    }
+    gg.block_start[n_items] = blocks;
+    PSN_CHECK_ARG(ws_off <= workspace_floats, "gemm_tn_grouped: workspace too small (%lld floats needed)", (long long)ws_off);
+    PSN_CHECK_ARG(blocks < (1ll << 31), "gemm_tn_grouped: too many blocks");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gg);
+    PSN_CHECK_LAUNCH("gemm_tn_grouped");
+    hipLaunchKernelGGL(grouped_reduce_kernel, dim3((unsigned)max_rblocks, (unsigned)n_items), dim3(256), 0, st, ra);
+    PSN_CHECK_LAUNCH("gemm_tn_grouped reduce");
     return PSN_OK;
 }
 

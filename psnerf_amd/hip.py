@@ -41,6 +41,15 @@ class PsnMlpDesc(ctypes.Structure):
                 ('init_stride', i32), ('layers', PsnMlpLayer * MAX_LAYERS)]
 
 
+class PsnGemmTnItem(ctypes.Structure):
+    _fields_ = [('A', ctypes.c_void_p), ('lda', i64), ('B', ctypes.c_void_p), ('ldb', i64),
+                ('A2', ctypes.c_void_p), ('lda2', i64), ('B2', ctypes.c_void_p), ('ldb2', i64),
+                ('C', ctypes.c_void_p), ('ldc', i64), ('M', i32), ('N', i32), ('accumulate', i32),
+                ('colsum_a', ctypes.c_void_p)]
+
+
+MAX_GROUP = 12
+
 # every exported symbol of include/psnerf_hip.h with its signature
 SIGNATURES = {
     'psn_last_error': (ctypes.c_char_p, []),
@@ -52,6 +61,7 @@ SIGNATURES = {
     'psn_pe_encode_jvp': (i32, [c_f, c_f, i64, i32, f32, c_f, i32, c_f]),
     'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, c_f, i64,
                        i32, c_f, c_f, c_f]),
+    'psn_gemm_tn_grouped': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
     'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, c_f, c_f]),
     'psn_sg_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f]),
@@ -208,6 +218,45 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, epi=EPI_NONE, aux_in=Non
                          0 if aux_out is None else _ld(aux_out), split_k,
                          None if ws is None else ws.data_ptr(), _ptr(colsum_a, 'colsum_a', True), _stream()), 'gemm')
     return out
+
+
+def gemm_tn_grouped(items, split_k):
+    """Weight gradients of one backward pass in one launch.  items: list of dicts with A [K,M], B [K,N] (row-major
+    views, row stride allowed), optional A2 / B2 (second product summed into the same result), optional out [M,N]
+    (+ accumulate=True) and colsum (True -> the column sums of A are returned too).  Returns [(C, colsum or None)]."""
+    res = []
+    K = items[0]['A'].shape[0]
+    dev = items[0]['A'].device
+    for c0 in range(0, len(items), MAX_GROUP):
+        chunk = items[c0:c0 + MAX_GROUP]
+        arr = (PsnGemmTnItem * len(chunk))()
+        need = 0
+        keep = []
+        for i, it in enumerate(chunk):
+            A, B = it['A'], it['B']
+            assert A.shape[0] == K and B.shape[0] == K, 'gemm_tn_grouped: all products share K'
+            M, N = A.shape[1], B.shape[1]
+            C = it.get('out')
+            if C is None:
+                C = torch.empty(M, N, device=dev, dtype=torch.float32)
+            assert C.shape == (M, N)
+            cs = torch.empty(M, device=dev, dtype=torch.float32) if it.get('colsum') else None
+            A2, B2 = it.get('A2'), it.get('B2')
+            e = arr[i]
+            e.A, e.lda, e.B, e.ldb = _mat_ptr(A, 'A'), _ld(A), _mat_ptr(B, 'B'), _ld(B)
+            if A2 is not None:
+                assert A2.shape == A.shape and B2.shape == B.shape
+                e.A2, e.lda2, e.B2, e.ldb2 = _mat_ptr(A2, 'A2'), _ld(A2), _mat_ptr(B2, 'B2'), _ld(B2)
+            e.C, e.ldc, e.M, e.N = _mat_ptr(C, 'out'), _ld(C), M, N
+            e.accumulate = int(bool(it.get('accumulate')))
+            e.colsum_a = None if cs is None else cs.data_ptr()
+            need += (2 if A2 is not None else 1) * split_k * M * N + split_k * M + 16
+            keep.append((C, cs))
+        ws = workspace(need, dev)
+        _check(_lib.psn_gemm_tn_grouped(len(chunk), ctypes.addressof(arr), K, split_k, ws.data_ptr(), ws.numel(), _stream()),
+               'gemm_tn_grouped')
+        res += keep
+    return res
 
 
 def colsum(X, out=None, accumulate=False):

@@ -134,23 +134,13 @@ class ReluMLP(torch.autograd.Function):
         grads = [None] * (2 * n)
         dx = torch.zeros(Q, kp, device=g.device) if ctx.x_needs else None
         needs = ctx.needs_input_grad[4:]
+        items, item_layer = [], []
         for li in range(n - 1, -1, -1):
             inp, Wp = ins[li], Wps[li]
-            db_done = False
-            if needs[2 * li]:
-                db = torch.empty(g.shape[1], device=g.device) if needs[2 * li + 1] else None
-                dWp = hip.gemm(g, inp, trans_a=True, trans_b=False,
-                               split_k=_split_k_for(Q, g.shape[1], inp.shape[1]), colsum_a=db)  # bias grad = by-product
-                if db is not None:
-                    grads[2 * li + 1] = db
-                    db_done = True
-                if li == 0:
-                    grads[0] = dWp[:, in_cols] if in_cols is not None else dWp
-                elif li - 1 == ctx.skip_at:
-                    grads[2 * li] = torch.cat([dWp[:, :width], dWp[:, width + in_cols]], dim=1)
-                else:
-                    grads[2 * li] = dWp
-            if needs[2 * li + 1] and not db_done:
+            if needs[2 * li]:  # dW (and db as its by-product): deferred, all layers go out as one grouped launch
+                items.append(dict(A=g, B=inp, colsum=bool(needs[2 * li + 1])))
+                item_layer.append(li)
+            elif needs[2 * li + 1]:
                 grads[2 * li + 1] = hip.colsum(g)
             if li > 0:
                 if ctx.x_needs and li - 1 == ctx.skip_at:
@@ -160,7 +150,28 @@ class ReluMLP(torch.autograd.Function):
                              aux_in=inp[:, :width])
             elif ctx.x_needs:
                 dx += hip.gemm(g, Wp, trans_a=False, trans_b=False)
+        if items:
+            for li, (dWp, db) in zip(item_layer, hip.gemm_tn_grouped(items, _grouped_split(items, Q))):
+                if db is not None:
+                    grads[2 * li + 1] = db
+                if li == 0:
+                    grads[0] = dWp[:, in_cols] if in_cols is not None else dWp
+                elif li - 1 == ctx.skip_at:
+                    grads[2 * li] = torch.cat([dWp[:, :width], dWp[:, width + in_cols]], dim=1)
+                else:
+                    grads[2 * li] = dWp
         return (dx, None, None, None) + tuple(grads)
+
+
+def _grouped_split(items, K):
+    """Split-K slices per product for a grouped weight-gradient launch: enough (tile, slice) work items to cover
+    the 256 CUs about four times, but K-chunks of at least 512 rows."""
+    work = 0
+    for it in items:
+        tiles = ((it['A'].shape[1] + 127) // 128) * ((it['B'].shape[1] + 127) // 128)
+        work += tiles * (2 if it.get('A2') is not None else 1)
+    want = max(1, (1024 + work - 1) // max(work, 1))
+    return int(max(1, min(want, K // 512 if K >= 512 else 1, 256)))
 
 
 def relu_mlp(x, in_cols, skip_at, final_sigmoid, weights, biases):
@@ -540,19 +551,16 @@ class VisibilityPair(torch.autograd.Function):
         DZ = [torch.empty(Q, 256, device=g.device) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
         chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh_last, mask=[H[n - 2 - j] for j in range(n - 1)],
               save=DZ, save_row0=0)
-        for li in range(n - 2, -1, -1):
-            dz = DZ[n - 2 - li]
-            if li == 0:
-                grads[1] = hip.colsum(dz)
-                grads[0] = in_block_grad(dz)
-                break
-            db = torch.empty(256, device=g.device)
-            dWh = hip.gemm(dz, H[li - 1], trans_a=True, split_k=_split_k_for(Q, 256, 256), colsum_a=db)
+        items = [dict(A=DZ[n - 2 - li], B=H[li - 1], colsum=True) for li in range(n - 2, 0, -1)]
+        res = hip.gemm_tn_grouped(items, _grouped_split(items, Q)) if items else []
+        for li, (dWh, db) in zip(range(n - 2, 0, -1), res):
             grads[2 * li + 1] = db
             if li - 1 == ctx.skip_at:
-                grads[2 * li] = torch.cat([dWh, in_block_grad(dz)], dim=1)
+                grads[2 * li] = torch.cat([dWh, in_block_grad(DZ[n - 2 - li])], dim=1)
             else:
                 grads[2 * li] = dWh
+        grads[1] = hip.colsum(DZ[n - 2])
+        grads[0] = in_block_grad(DZ[n - 2])
         return (None, None, None, None, None) + tuple(grads)
 
 
@@ -623,16 +631,6 @@ class GeoFieldFused(torch.autograd.Function):
         dW = [None] * n
         db = [None] * n
 
-        def add_dW(l, a_t, b_mat, with_bias=False):  # dW[l] (+)= a_t^T @ b_mat ; db[l] = column sums of a_t
-            skk = _split_k_for(Q, a_t.shape[1], b_mat.shape[1])
-            cs = torch.empty(a_t.shape[1], device=dev) if with_bias else None
-            if dW[l] is None:
-                dW[l] = hip.gemm(a_t, b_mat, trans_a=True, split_k=skk, colsum_a=cs)
-            else:
-                hip.gemm(a_t, b_mat, trans_a=True, split_k=skk, out=dW[l], epi=hip.EPI_ACCUM, colsum_a=cs)
-            if with_bias:
-                db[l] = cs
-
         dS = None
         if sweep:
             base = 2 + 3 * n - 2
@@ -645,11 +643,6 @@ class GeoFieldFused(torch.autograd.Function):
             chains['sweep_bwd'](dd_pe, Q, mask=list(S), aux2=[R[l + 1] for l in range(n - 2)] + [r_last],
                                 save=dR[1:], save2=dS)
             dR[sk][:, d_a:] = dd_pe[:, :d_pe]  # adjoint of the skip layer's [a | pe] sweep value
-            add_dW(0, U[0], dd_pe[:, :d_pe])
-            for l in range(1, n - 1):
-                add_dW(l, U[l][:, :Ws[l].shape[0]], dR[l][:, :Ws[l].shape[1]])
-            dW[n - 1] = torch.zeros_like(Ws[n - 1])
-            dW[n - 1][0] = hip.colsum(dR[n - 1])
 
         # adjoint of the value pass
         dZ = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]  # dZ[l] = d loss / d z_l
@@ -659,15 +652,25 @@ class GeoFieldFused(torch.autograd.Function):
                     mask=[S[n - 2 - j] for j in range(n - 1)],
                     aux2=[dS[n - 2 - j] for j in range(n - 1)] if sweep else None,
                     save=[dZ[n - 2 - j] for j in range(n - 1)])
+        # Every weight gradient of the call in ONE grouped launch: dW_l = dZ_l^T A_{l-1} (+ U_l^T dR_l from the sweep),
+        # the bias gradients are the column sums of dZ_l, a by-product of staging the A tiles.
         a_last = A[n - 2]
-        g_last = torch.cat([hip.colsum(d_logit * a_last).unsqueeze(0),
-                            hip.gemm(d_feat, a_last, trans_a=True, split_k=_split_k_for(Q, 256, 256))], dim=0)
-        dW[n - 1] = g_last if dW[n - 1] is None else dW[n - 1] + g_last
-        db[n - 1] = torch.cat([d_logit.sum(0), hip.colsum(d_feat)])
-        add_dW(0, dZ[0][:, :Ws[0].shape[0]], pe[:, :d_pe], with_bias=True)
-        for l in range(1, n - 1):
-            o = Ws[l].shape[0]
-            add_dW(l, dZ[l][:, :o], A[l - 1][:, :Ws[l].shape[1]], with_bias=True)
+        items = []
+        for l in range(n - 1):
+            o, i_w = Ws[l].shape[0], Ws[l].shape[1]
+            it = dict(A=dZ[l][:, :o], B=pe[:, :d_pe] if l == 0 else A[l - 1][:, :i_w], colsum=True)
+            if sweep:
+                it['A2'], it['B2'] = U[l][:, :o], dd_pe[:, :d_pe] if l == 0 else dR[l][:, :i_w]
+            items.append(it)
+        items.append(dict(A=d_feat, B=a_last, colsum=True))
+        res = hip.gemm_tn_grouped(items, _grouped_split(items, Q))
+        for l in range(n - 1):
+            dW[l], db[l] = res[l]
+        row0 = hip.colsum(d_logit * a_last)
+        if sweep:
+            row0 = row0 + hip.colsum(dR[n - 1])
+        dW[n - 1] = torch.cat([row0.unsqueeze(0), res[n - 1][0]], dim=0)
+        db[n - 1] = torch.cat([d_logit.sum(0), res[n - 1][1]])
         grads = []
         for l in range(n):
             grads += [dW[l], db[l]]

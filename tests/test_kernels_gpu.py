@@ -158,6 +158,45 @@ def test_gemm_splitk_weight_grad(cuda, split):
         assert_close(out2, dZ.double().t() @ X[:, :217].double(), 1e-5, 'dW (N = 217)')
 
 
+@pytest.mark.parametrize('Q,split', [(5000, 4), (1234, 1), (40000, 16)])
+def test_gemm_tn_grouped(cuda, Q, split):
+    """All weight gradients of a backward pass in one launch: ragged shapes, strided views, two-product items
+    (value pass + gradient sweep of a shared layer), accumulation, bias-gradient by-products."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(Q)
+    dZ = [torch.randn(Q, 256, generator=g) for _ in range(4)]
+    X = [torch.randn(Q, 256, generator=g) for _ in range(4)]
+    pe = torch.randn(Q, 64, generator=g)
+    base = torch.randn(256, 256, generator=g)
+    d = lambda t: t.to(cuda)
+    dZd, Xd, ped = [d(t) for t in dZ], [d(t) for t in X], d(pe)
+    acc = d(base.clone())
+    items = [
+        dict(A=dZd[0], B=Xd[0], colsum=True),
+        dict(A=dZd[1][:, :217], B=Xd[1], colsum=True),                      # ragged M, strided A
+        dict(A=dZd[2], B=ped[:, :39], colsum=True),                         # N = 39, strided B
+        dict(A=dZd[3], B=Xd[3], A2=dZd[0], B2=Xd[1], colsum=True),          # two products into one gradient
+        dict(A=dZd[1], B=Xd[2], out=acc, accumulate=True),                  # accumulate into an existing tensor
+        dict(A=dZd[2][:, :1], B=Xd[0]),                                     # M = 1
+    ]
+    res = hip.gemm_tn_grouped(items, split)
+    D = lambda t: t.double()
+    refs = [D(dZ[0]).t() @ D(X[0]), D(dZ[1][:, :217]).t() @ D(X[1]), D(dZ[2]).t() @ D(pe[:, :39]),
+            D(dZ[3]).t() @ D(X[3]) + D(dZ[0]).t() @ D(X[1]), D(base) + D(dZ[1]).t() @ D(X[2]), D(dZ[2][:, :1]).t() @ D(X[0])]
+    cs_refs = [D(dZ[0]).sum(0), D(dZ[1][:, :217]).sum(0), D(dZ[2]).sum(0), D(dZ[3]).sum(0), None, None]
+    for i, ((C, cs), ref, cref) in enumerate(zip(res, refs, cs_refs)):
+        assert_close(C.cpu(), ref, 1e-5, 'grouped dW %d' % i)
+        if cref is None:
+            assert cs is None
+        else:
+            assert_close(cs.cpu(), cref, 1e-5, 'grouped colsum %d' % i)
+    # same results as the one-at-a-time path, and deterministic
+    one = hip.gemm(dZd[0], Xd[0], trans_a=True, split_k=split)
+    assert_close(res[0][0].cpu(), one.cpu(), 1e-6, 'grouped vs single')
+    res2 = hip.gemm_tn_grouped(items[:4], split)
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(res[:4], res2))
+
+
 def test_fused_visibility_mlp(cuda):
     """mlp_infer on the stage2 visibility net == oracle MLP (stage2/model/renderer.py:191-200)."""
     from psnerf_amd import hip, fused
