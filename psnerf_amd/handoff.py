@@ -96,3 +96,71 @@ def load_view(shape_dir, view_id, device='cpu', with_visibility=True):
         table = json.load(open(os.path.join(shape_dir, 'vis_plus', 'light_dir.json')))
         out['vis_plus_light'] = torch.tensor(np.array(table['view_{:02d}'.format(view_id)], dtype=np.float32)).to(device)
     return out
+
+
+class ViewSampler(object):
+    """The per-item sampling of stage2/datasets/dataset.py:137-199 (multi_light layout) over views that are already
+    in memory: ``views[v]`` = load_view(...) dictionaries, ``images[v]`` [L_v, h*w, 3], ``object_masks[v]`` [h*w] bool,
+    ``light_direction[v]`` [L_v, 3], ``poses[v]`` [4,4], ``intrinsics`` [4,4].  Image decoding (PNG, imageio) stays
+    outside: this is the wire format between the two accelerated stages, not the file I/O.
+
+    Per item: a fresh subset of ``light_bs`` lights (np.random.choice without replacement, dataset.py:149-151) and,
+    when ``n_pixels`` is set, ``n_pixels`` in-mask pixels (dataset.py:182-195).  The draws use the global
+    ``np.random`` stream in the reference's order (lights, then pixels) unless ``rng`` is given, so a seeded run
+    samples exactly what the reference samples."""
+
+    def __init__(self, views, images, object_masks, light_direction, poses, intrinsics, light_bs, n_pixels=None,
+                 sample_in_mask=True, vis_loss=True, split='train', gt_normal=None, rng=None):
+        self.views, self.images, self.object_masks = views, images, object_masks
+        self.light_direction, self.poses, self.intrinsics = light_direction, poses, intrinsics
+        self.light_bs, self.n_pixels, self.sample_in_mask = light_bs, n_pixels, sample_in_mask
+        self.vis_loss, self.split, self.gt_normal = vis_loss, split, gt_normal
+        self.rng = rng if rng is not None else np.random
+        self.img_res = views[0]['img_res']
+        self.total_pixels = self.img_res[0] * self.img_res[1]
+        self.sampling_idx = None if n_pixels is None else torch.zeros(n_pixels, dtype=torch.long)
+
+    def __len__(self):
+        return len(self.views)
+
+    def uv_grid(self):
+        h, w = self.img_res
+        uv = np.mgrid[0:h, 0:w].astype(np.int32)
+        uv = torch.from_numpy(np.flip(uv, axis=0).copy()).float()  # (x, y) order, dataset.py:138-140
+        return uv.reshape(2, -1).transpose(1, 0)
+
+    def __getitem__(self, idx):
+        v = self.views[idx]
+        n_l = self.light_direction[idx].shape[0]
+        if self.split == 'train' and n_l >= self.light_bs:
+            lidx = torch.tensor(self.rng.choice(np.arange(n_l), self.light_bs, replace=False)).long()
+        else:
+            lidx = torch.arange(n_l).long()
+        omask = self.object_masks[idx]
+        uv = self.uv_grid()
+        sample = {'object_mask': omask, 'uv': uv, 'vidx': torch.tensor(idx), 'intrinsics': self.intrinsics, 'lidx': lidx,
+                  'normal': v['normal'][0], 'points': v['points'][0], 'surface_mask': v['surface_mask'][0],
+                  'light_direction': self.light_direction[idx][lidx]}
+        if self.gt_normal is not None:
+            sample['gt_normal'] = self.gt_normal[idx]
+        if self.vis_loss:
+            sample['visibility'] = v['visibility'][lidx]
+        img = self.images[idx][lidx] * omask[None, :, None]
+        ground_truth = {'rgb': img}
+        if self.sampling_idx is not None:
+            if self.sample_in_mask:
+                pick = np.arange(self.total_pixels)[omask.numpy()]
+                self.sampling_idx = torch.tensor(self.rng.choice(pick, min(self.sampling_idx.shape[0], pick.shape[0]),
+                                                                 replace=False)).long()
+            s = self.sampling_idx
+            ground_truth['rgb'] = img[:, s, :]
+            sample['object_mask'] = omask[s]
+            sample['uv'] = uv[s, :]
+            for k in ('normal', 'points'):
+                sample[k] = sample[k][s, :]
+            sample['surface_mask'] = sample['surface_mask'][s]
+            if self.vis_loss:
+                sample['visibility'] = sample['visibility'][:, s]
+            sample['sampling_idx'] = s.clone()
+        sample['pose'] = self.poses[idx]
+        return idx, sample, ground_truth

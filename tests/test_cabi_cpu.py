@@ -119,3 +119,38 @@ def test_host_metrics():
     m = np.zeros((4, 4)); m[0, 0] = 1
     img2 = img.copy(); img2[0, 0] += 0.01
     assert abs(PSNR(img, img2, m) - 40.0) < 1e-3
+
+
+def test_view_sampler_matches_reference_sampling_order(tmp_path):
+    """stage2/datasets/dataset.py:137-199 on in-memory views: dictionary layout, (x, y) uv grid, light subset then
+    in-mask pixel subset drawn from np.random in the reference's order."""
+    import numpy as np
+    import torch
+    from psnerf_amd.handoff import ViewSampler
+    h, w, L = 6, 8, 10
+    g = torch.Generator().manual_seed(0)
+    view = {'points': torch.randn(1, h * w, 3, generator=g), 'normal': torch.randn(1, h * w, 3, generator=g),
+            'surface_mask': torch.rand(1, h * w, generator=g) > 0.3, 'visibility': torch.rand(L, h * w, generator=g),
+            'img_res': [h, w]}
+    omask = torch.rand(h * w, generator=g) > 0.25
+    imgs = torch.rand(L, h * w, 3, generator=g)
+    ldir = torch.randn(L, 3, generator=g)
+    ds = ViewSampler([view], [imgs], [omask], [ldir], [torch.eye(4)], torch.eye(4), light_bs=4, n_pixels=12)
+    np.random.seed(123)
+    idx, sample, gt = ds[0]
+    np.random.seed(123)
+    lidx = np.random.choice(np.arange(L), 4, replace=False)
+    pick = np.arange(h * w)[omask.numpy()]
+    sidx = np.random.choice(pick, 12, replace=False)
+    assert idx == 0 and sample['lidx'].tolist() == lidx.tolist() and sample['sampling_idx'].tolist() == sidx.tolist()
+    assert bool(omask[sample['sampling_idx']].all()) and bool(sample['object_mask'].all())
+    assert torch.equal(sample['light_direction'], ldir[lidx])
+    assert torch.equal(sample['visibility'], view['visibility'][lidx][:, sidx])
+    assert torch.equal(gt['rgb'], (imgs[lidx] * omask[None, :, None])[:, sidx])
+    assert torch.equal(sample['points'], view['points'][0][sidx]) and sample['surface_mask'].shape == (12,)
+    # uv = (x, y): pixel k of the row-major h*w flattening sits at x = k % w, y = k // w
+    assert sample['uv'].tolist() == [[float(k % w), float(k // w)] for k in sidx.tolist()]
+    # eval split / fewer lights than light_bs: all lights in order, whole image when n_pixels is None
+    ds2 = ViewSampler([view], [imgs], [omask], [ldir], [torch.eye(4)], torch.eye(4), light_bs=4, split='test')
+    _, s2, g2 = ds2[0]
+    assert s2['lidx'].tolist() == list(range(L)) and g2['rgb'].shape == (L, h * w, 3) and 'sampling_idx' not in s2
