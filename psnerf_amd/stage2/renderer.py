@@ -148,8 +148,7 @@ class PSNetwork(nn.Module):
         x = torch.cat([pe_x.tile(nl, 1), pe_l.repeat_interleave(ns, dim=0)], dim=1)
         return net(x, cols)
 
-    def _visibility_pair(self, pe_x, light_dir, light_vis_train):
-        """(vis [L*Ns,1], vis_train [V*Ns,1]) from one fused launch (ops.VisibilityPair)."""
+    def _visibility_pair_args(self, pe_x, light_dir, light_vis_train):
         pe_l = self._pe(torch.cat([light_dir.detach(), light_vis_train.detach()], dim=0), self.n_freqs)
         net = self.visibility_net
         Ws, bs = net.weights()
@@ -157,7 +156,21 @@ class PSNetwork(nn.Module):
         for W, b in zip(Ws, bs):
             params += [W, b]
         cols = self._cols(self.n_freqs, pe_x.device, pair=True)
-        return ops.VisibilityPair.apply(pe_x.detach(), pe_l, light_dir.shape[0], cols, net._skip_index(), *params)
+        return pe_x.detach(), pe_l, light_dir.shape[0], cols, net._skip_index(), params
+
+    def _visibility_pair_launch(self, pe_x, light_dir, light_vis_train):
+        """Issue the fused launch now, attach the autograd node later (ops.VisibilityPair.launch)."""
+        a = self._visibility_pair_args(pe_x, light_dir, light_vis_train)
+        need = any(p.requires_grad for p in a[5])
+        return a, ops.VisibilityPair.launch(a[0], a[1], a[2], a[3], a[4], [p.detach() for p in a[5]], need)
+
+    def _visibility_pair(self, pe_x, light_dir, light_vis_train, launched=None):
+        """(vis [L*Ns,1], vis_train [V*Ns,1]) from one fused launch (ops.VisibilityPair)."""
+        if launched is not None:
+            a, pre = launched
+        else:
+            a, pre = self._visibility_pair_args(pe_x, light_dir, light_vis_train), None
+        return ops.VisibilityPair.apply(a[0], a[1], a[2], a[3], a[4], pre, *a[5])
 
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, input, albedo_new=None, basis_new=None, noise=None):
@@ -183,6 +196,20 @@ class PSNetwork(nn.Module):
         surf = gather(points).contiguous()
         out_n = {}
         normal_s = None
+        # The fused visibility launch is 60 % of the step and depends only on the surface points and the light
+        # directions: issue it FIRST, so the GPU is busy while the host queues the small BRDF / normal-net launches
+        # (they then run back to back behind it instead of each waiting for its own launch latency).  Its autograd
+        # node is attached at the reference's position in the graph, further down.
+        pe_x = None
+        vis_pair = None
+        if ns > 0 and self.visibility:
+            lv0 = input.get('light_vis_train')
+            ld0 = input['light_direction']
+            if (lv0 is not None and self.conf.get_bool('train.vis_rgb_detach', default=False)
+                    and self.visibility_net.width == 256 and torch.is_grad_enabled()
+                    and (self.light_vis_detach or not (ld0.requires_grad or lv0.requires_grad))):
+                pe_x = self._pe(surf, self.n_freqs)
+                vis_pair = self._visibility_pair_launch(pe_x, ld0, lv0)
         if self.normal_mlp:  # renderer.py:127-143
             normal_pred = torch.ones_like(points)
             if ns > 0:
@@ -205,14 +232,14 @@ class PSNetwork(nn.Module):
         weight_values = torch.zeros(*points.shape[:-1], self.nbasis, device=device) if sg else None
         vis_values = torch.ones_like(rgb_values)
         jitter = None
-        pe_x = None
         vis_t_pre = None
         if ns > 0:
             normal = gather(normals) if not self.normal_mlp else normal_s
             pts2c = -gather(ray_dirs)
             light_dir = input['light_direction']
             cols = self._cols(self.n_freqs, device)
-            pe_x = self._pe(surf, self.n_freqs)
+            if pe_x is None:
+                pe_x = self._pe(surf, self.n_freqs)
             albedo = self.albedo_net(pe_x, cols)
             if albedo_new is not None:
                 albedo = torch.from_numpy(albedo_new).to(device)[None].expand_as(albedo)
@@ -238,7 +265,7 @@ class PSNetwork(nn.Module):
                            and (self.light_vis_detach or not (light_dir.requires_grad or lv.requires_grad)))
                 if pair_ok:
                     # shading rows and supervision rows in ONE fused launch (the latter dump their activations)
-                    vis, vis_t_pre = self._visibility_pair(pe_x, light_dir, lv)
+                    vis, vis_t_pre = self._visibility_pair(pe_x, light_dir, lv, launched=vis_pair)
                 else:
                     # gradient-free unless a caller backpropagates into output['visibility']
                     vis = self._visibility_rows(pe_x, light_dir, fused_ok=True)  # [L*Ns, 1], light-major
