@@ -103,7 +103,7 @@ class NeuralNetwork(nn.Module):
         return Ws, bs
 
     USE_FUSED_CHAINS = True
-    MAX_ROWS = 1 << 18  # rows per GeoField call: bounds the saved activations to ~9 GB of the 288 GB HBM
+    MAX_ROWS = 1 << 20  # rows per GeoField call: bounds the saved activations to ~50 GB of the 288 GB HBM
 
     def _geo_chains(self, params):
         key = tuple(int(q._version) for q in self.parameters()) + (self.lin0.weight_v.data_ptr(),)

@@ -95,6 +95,7 @@ def test_stage1_benchmark_size_properties(cuda):
     sd = stage1_state_dict(cfg, seed=11)
     net = NeuralNetwork(cfg)
     net.load_state_dict(sd)
+    net.MAX_ROWS = 1 << 18  # force two chunks of the geometry-field chains (the default holds 2^20 rows per call)
     ren = Renderer(net, cfg, device=cuda)
     h, w = 96, 128
     K, c2w, S = stage1_camera(cfg, h=h, w=w)
