@@ -247,3 +247,73 @@ def test_fused_geo_occupancy(cuda):
     packed.desc.out_act = hip.OUT_NONE
     logit = packed(tab, 1000)
     assert_close(logit.cpu(), logit_ref, 1e-4, 'occupancy logit')
+
+
+def test_mlp_chain_activation_programs(cuda):
+    """Every per-layer activation program of the chain engine (psn_mlp_infer with operands and dumps) against a
+    float64 restatement: ragged row count, input-feature k-tiles, two operands, two dumps, HEAD side outputs."""
+    from psnerf_amd import hip, fused
+    g = torch.Generator().manual_seed(0)
+    Q = 1000
+    rn = lambda *sh: torch.randn(*sh, generator=g)
+    x = rn(Q, 64)
+    W = [rn(256, 64) * 0.1] + [rn(256, 256) * 0.06 for _ in range(6)]
+    Wx2 = rn(256, 64) * 0.1
+    Wf = rn(3, 256) * 0.06
+    b = [rn(256) * 0.05 for _ in range(7)]
+    bf = rn(3) * 0.05
+    m1, m2, q2, t4, h5 = rn(Q, 256), rn(Q, 256), rn(Q, 256), rn(Q, 256) * 0.01, rn(Q, 256)
+    s4 = torch.rand(Q, 256, generator=g)
+    layers = [
+        dict(w_in=W[0], w_act=None, bias=b[0], act=hip.ACT_SOFTPLUS100),
+        dict(w_in=None, w_act=W[1], bias=b[1], act=hip.ACT_MUL_AUX),
+        dict(w_in=Wx2, w_act=W[2], bias=b[2], act=hip.ACT_MUL2),
+        dict(w_in=None, w_act=W[3], bias=b[3], act=hip.ACT_HEAD),
+        dict(w_in=None, w_act=W[4], bias=b[4], act=hip.ACT_SOFTPLUS_BWD),
+        dict(w_in=None, w_act=W[5], bias=b[5], act=hip.ACT_RELU_MASK),
+        dict(w_in=None, w_act=W[6], bias=b[6], act=hip.ACT_RELU),
+        dict(w_in=None, w_act=Wf, bias=bf, act=hip.ACT_NONE),
+    ]
+    d = lambda t: None if t is None else t.to(cuda)
+    packed = fused.pack_layers([{k: (d(v) if torch.is_tensor(v) else v) for k, v in L.items()} for L in layers],
+                               2, 0, 3, hip.OUT_NONE, cuda)
+    save = [torch.empty(Q, 256, device=cuda) for _ in range(7)]
+    save2 = [torch.empty(Q, 256, device=cuda) if i in (0, 1, 2) else None for i in range(7)] + [None]
+    out = packed(d(x), Q, save=save, save2=save2,
+                 mask=[None, d(m1), d(m2), None, d(s4), d(h5), None, None],
+                 aux2=[None, None, d(q2), None, d(t4), None, None, None])
+    D = lambda t: t.double()
+    xd = D(x)
+    z0 = xd @ D(W[0]).t() + D(b[0])
+    a0 = torch.nn.functional.softplus(z0, beta=100)
+    z1 = a0 @ D(W[1]).t() + D(b[1])
+    a1 = z1 * D(m1)
+    z2 = a1 @ D(W[2]).t() + xd @ D(Wx2).t() + D(b[2])
+    a2 = z2 * D(m2)
+    z3 = a2 @ D(W[3]).t() + D(b[3])
+    z4 = a2 @ D(W[4]).t() + D(b[4])            # HEAD leaves the activations of layer 2 in place
+    a4 = D(s4) * (z4 + 100.0 * D(t4) * (1.0 - D(s4)))
+    z5 = a4 @ D(W[5]).t() + D(b[5])
+    a5 = torch.where(D(h5) > 0, z5, torch.zeros_like(z5))
+    a6 = torch.relu(a5 @ D(W[6]).t() + D(b[6]))
+    ref_out = a6 @ D(Wf).t() + D(bf)
+    for name, got, ref in [('a0', save[0], a0), ('sigmoid(100 z0)', save2[0], torch.sigmoid(100 * z0)), ('a1', save[1], a1),
+                           ('raw z1', save2[1], z1), ('a2', save[2], a2), ('z2 * q2', save2[2], z2 * D(q2)), ('head z3', save[3], z3),
+                           ('a4', save[4], a4), ('a5', save[5], a5), ('a6', save[6], a6), ('out', out, ref_out)]:
+        assert_close(got.cpu(), ref, 2e-5, 'chain program: ' + name)
+
+    # a chain without final layer that starts from a tensor (act_init) plus a per-row init table
+    act0, init = rn(Q, 256), rn(Q, 256)
+    zeros = torch.zeros(256)
+    ls = [dict(init_a=torch.zeros(256, 64), init_b=None, w_act=W[1], bias=zeros, act=hip.ACT_RELU_MASK),
+          dict(w_act=W[2], bias=zeros, act=hip.ACT_NONE)]
+    pk = fused.pack_layers([{k: (d(v) if torch.is_tensor(v) else v) for k, v in L.items()} for L in ls], 2, 0, 0,
+                           hip.OUT_NONE, cuda, has_final=False)
+    pk.init_wa = pk.init_wb = pk.init_bias = None
+    pk.desc.init_stride = 256
+    dumps = [torch.empty(Q, 256, device=cuda) for _ in range(2)]
+    pk(None, Q, a_div=1, a_mod=Q, init_a_direct=d(init), act_init=d(act0), mask=[d(h5), None], save=dumps)
+    r0 = D(act0) @ D(W[1]).t() + D(init)
+    r0 = torch.where(D(h5) > 0, r0, torch.zeros_like(r0))
+    assert_close(dumps[0].cpu(), r0, 2e-5, 'act_init + init table')
+    assert_close(dumps[1].cpu(), r0 @ D(W[2]).t(), 2e-5, 'second chain layer')
