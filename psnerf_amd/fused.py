@@ -251,3 +251,31 @@ def pack_geo_chains(weights, biases, skips, d_pe):
 
     return dict(fwd=fwd, sweep=sweep, sweep_bwd=sweep_bwd, value_bwd=value_bwd(hip.ACT_SOFTPLUS_BWD),
                 value_bwd_nosweep=value_bwd(hip.ACT_MUL_AUX), d_a=d_a)
+
+
+def pack_app_chains(weights, biases, d_x):
+    """stage1 appearance network (stage1/model/network.py:98-106, 128-138): ReLU MLP [d_x + 256] -> 256 x (n-1) -> 3
+    whose input is cat[x (points, view encoding, normal: d_x <= 64 columns), 256 geometry features].  The features
+    enter the first layer as the chain's initial activations (act_init), x as input-feature k-tiles.
+    Returns dict(fwd, bwd): fwd dumps the hidden activations, bwd = ReLU backward chain over transposed packs that
+    ends with a HEAD layer producing d features."""
+    n = len(weights)
+    dev = weights[0].device
+    W = [w.detach() for w in weights]
+    b = [x.detach() for x in biases]
+    assert W[0].shape[1] == d_x + 256 and all(w.shape == (256, 256) for w in W[1:n - 1]) and d_x <= 64
+    ka = (d_x + 31) // 32
+    zeros = torch.zeros(256, device=dev)
+    layers = [dict(w_in=W[0][:, :d_x], w_act=W[0][:, d_x:], bias=b[0], act=hip.ACT_RELU)]
+    for l in range(1, n - 1):
+        layers.append(dict(w_in=None, w_act=W[l], bias=b[l], act=hip.ACT_RELU))
+    layers.append(dict(w_in=None, w_act=W[n - 1], bias=b[n - 1], act=hip.ACT_NONE))
+    fwd = pack_layers(layers, ka, 0, W[n - 1].shape[0], hip.OUT_NONE, dev)
+    ls = [dict(init_a=torch.zeros(256, ka * 32, device=dev), init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
+    for l in range(n - 2, 0, -1):
+        ls.append(dict(w_act=_t(W[l]), bias=zeros, act=hip.ACT_RELU_MASK))
+    ls.append(dict(w_act=_t(W[0][:, d_x:]), bias=zeros, act=hip.ACT_HEAD))
+    bwd = pack_layers(ls, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
+    bwd.init_wa = bwd.init_wb = bwd.init_bias = None
+    bwd.desc.init_stride = 256
+    return dict(fwd=fwd, bwd=bwd)

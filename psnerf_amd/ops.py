@@ -690,3 +690,51 @@ class GeoFieldFused(torch.autograd.Function):
         for l in range(n):
             grads += [dW[l], db[l]]
         return (None, None, None, None, None, None) + tuple(grads)
+
+
+# --------------------------------------------------------------------------- stage-1 appearance network, fused chains
+class AppNetFused(torch.autograd.Function):
+    """stage1 appearance MLP (network.py:98-106) on cat[x, features] without materialising the 289-wide input:
+    the 256 geometry features are the chain's initial activations, x = [point, view encoding, normal] rides in the
+    64-wide input-feature table.  One forward launch (hidden activations dumped) and one backward launch (ReLU
+    chain over transposed packs, HEAD = d features), then one grouped weight-gradient launch.
+    Inputs: x [Q,64] (d_x real columns, no gradient), normal [Q,3] (= columns d_x-3.. of x; receives a gradient),
+    feat [Q,256].  Returns the pre-activation colour [Q,3]."""
+
+    @staticmethod
+    def forward(ctx, x, normal, feat, d_x, chains, *params):
+        n = len(params) // 2
+        Q = x.shape[0]
+        feat = feat.contiguous()
+        need = any(ctx.needs_input_grad)
+        H = [torch.empty(Q, 256, device=x.device) for _ in range(n - 1)] if need else None
+        out = chains['fwd'](x, Q, act_init=feat, save=H)
+        if need:
+            ctx.save_for_backward(x, feat, *H, *params[0::2])
+            ctx.meta = (n, d_x, chains)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, d_x, chains = ctx.meta
+        sv = ctx.saved_tensors
+        x, feat = sv[0], sv[1]
+        H = sv[2:2 + n - 1]
+        Ws = sv[2 + n - 1:]
+        Q, dev = x.shape[0], x.device
+        g = g.contiguous()
+        dh = hip.gemm(g, Ws[n - 1].contiguous())  # [Q,256]
+        DZ = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
+        d_feat = torch.empty(Q, 256, device=dev)
+        chains['bwd'](None, Q, a_div=1, a_mod=Q, init_a_direct=dh, mask=[H[n - 2 - j] for j in range(n - 1)] + [None],
+                      save=DZ + [d_feat])
+        dz0 = DZ[n - 2]
+        d_normal = hip.gemm(dz0, Ws[0][:, d_x - 3:d_x].contiguous())  # [Q,3]
+        items = [dict(A=dz0, B=x[:, :d_x], colsum=True), dict(A=dz0, B=feat)]
+        items += [dict(A=DZ[n - 2 - l], B=H[l - 1], colsum=True) for l in range(1, n - 1)]
+        items.append(dict(A=g, B=H[n - 2], colsum=True))
+        res = hip.gemm_tn_grouped(items, _grouped_split(items, Q))
+        grads = [torch.cat([res[0][0], res[1][0]], dim=1), res[0][1]]
+        for l in range(1, n):
+            grads += [res[l + 1][0], res[l + 1][1]]
+        return (None, d_normal, d_feat, None, None) + tuple(grads)

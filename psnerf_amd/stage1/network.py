@@ -81,6 +81,8 @@ class NeuralNetwork(nn.Module):
         self._packed_key = None
         self._chains = None
         self._chains_key = None
+        self._app_packed = None
+        self._app_key = None
 
     # ---- effective weights ----------------------------------------------------------------------
     def _geo_params(self):
@@ -169,6 +171,32 @@ class NeuralNetwork(nn.Module):
         x = torch.cat([points, view_dirs, normals.squeeze(-2), feature_vectors], dim=-1)
         return self._app(x)
 
+    def _app_chains(self, Ws, bs, d_x):
+        key = tuple(int(q._version) for q in self.parameters()) + (self.lina0.weight_v.data_ptr(),)
+        if self._app_packed is None or self._app_key != key:
+            with torch.no_grad():
+                self._app_packed = fused.pack_app_chains(Ws, bs, d_x)
+            self._app_key = key
+        return self._app_packed
+
+    def _app_parts(self, points, v_pe, normal, feat):
+        """Colour from (point, view encoding, normal, geometry features) = infer_app without the 289-wide concat:
+        256-wide networks run as fused chains (ops.AppNetFused)."""
+        d_x = 3 + self.d_view + 3
+        Ws, bs = self._app_params()
+        if not (self.USE_FUSED_CHAINS and self.feat_size == 256 and d_x <= 64 and Ws[0].shape[0] == 256
+                and all(w.shape == (256, 256) for w in Ws[1:-1]) and self.n_app <= 10):
+            return self._app(torch.cat([points, v_pe, normal, feat], dim=-1))
+        x = torch.zeros(points.shape[0], 64, device=points.device)
+        x[:, :3] = points
+        x[:, 3:3 + self.d_view] = v_pe
+        x[:, d_x - 3:d_x] = normal.detach()
+        params = []
+        for W, b in zip(Ws, bs):
+            params += [W, b]
+        y = ops.AppNetFused.apply(x, normal, feat, d_x, self._app_chains(Ws, bs, d_x), *params)
+        return torch.tanh(y) * 0.5 + 0.5
+
     def _app(self, x):
         d = x.shape[-1]
         kp = (d + 3) // 4 * 4
@@ -198,7 +226,7 @@ class NeuralNetwork(nn.Module):
             v = ray_d.reshape(-1, 3)
             v = v / torch.norm(v, dim=-1, keepdim=True)
             v_pe = ops.positional_encoding(v, self.octaves_pe_views)
-            rgb = self._app(torch.cat([flat, v_pe, grad, feat], dim=-1)).reshape(*shp, 3)
+            rgb = self._app_parts(flat, v_pe, grad, feat).reshape(*shp, 3)
             if return_addocc:
                 return rgb, torch.sigmoid(logit * -10.0).reshape(*shp, 1)
             return rgb
