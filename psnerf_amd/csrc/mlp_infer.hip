@@ -50,26 +50,63 @@ constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
 constexpr int kWaves = 4;  // per workgroup; two workgroups share a CU (2 waves per SIMD, out of phase)
 
 // One 32-feature k-tile (two 16-feature register tiles b0, b1 = 8 MFMA k-steps) against NMT output tiles of 16.
+// The weight fragments of a group of 8 output tiles (8 ds_read_b128 = 8 KB per wave) feed 32 MFMAs.  Two register
+// sets: the reads of group g+1 are issued at the START of group g's MFMA stream (1024 MFMA cycles ahead).  With a
+// single set hipcc can only issue them behind the last six MFMAs (192 cycles), which does not cover the LDS queueing
+// when the eight waves of a CU, barrier-aligned, all ask for their 8 KB at the same moment (PMC: matrix pipe 83 % busy).
 template <int NMT>
 __device__ __forceinline__ void stage_compute(floatx4 (&acc)[16], const floatx4& b0, const floatx4& b1,
                                               const float4* __restrict__ wl, int lane) {
+    if constexpr (NMT == 16) {
+        float4 a[2][8];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const floatx4& bs = e ? b1 : b0;
+        for (int m = 0; m < 8; ++m) a[0][m] = wl[m * 64 + lane];
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // the first group's reads (exposed once per stage)
 #pragma unroll
-        for (int m0 = 0; m0 < NMT; m0 += 8) {
-            constexpr int G = NMT < 8 ? NMT : 8;
-            float4 a[G];
+        for (int g = 0; g < 4; ++g) {
+            const int e = g >> 1, m0 = (g & 1) * 8;
+            const floatx4& bs = e ? b1 : b0;
+            if (g < 3) {
+                const int e1 = (g + 1) >> 1, m1 = ((g + 1) & 1) * 8;
 #pragma unroll
-            for (int m = 0; m < G; ++m) a[m] = wl[(e * NMT + m0 + m) * 64 + lane];
+                for (int m = 0; m < 8; ++m) a[(g + 1) & 1][m] = wl[(e1 * 16 + m1 + m) * 64 + lane];
+            }
+            const float4(&ag)[8] = a[g & 1];
 #pragma unroll
-            for (int m = 0; m < G; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, bs[0], acc[m0 + m], 0, 0, 0);
+            for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].x, bs[0], acc[m0 + m], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < G; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, bs[1], acc[m0 + m], 0, 0, 0);
+            for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].y, bs[1], acc[m0 + m], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < G; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, bs[2], acc[m0 + m], 0, 0, 0);
+            for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].z, bs[2], acc[m0 + m], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < G; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, bs[3], acc[m0 + m], 0, 0, 0);
+            for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].w, bs[3], acc[m0 + m], 0, 0, 0);
+            // pin the order: this group's 8 prefetch reads spread over its first 8 MFMAs, then the other 24 MFMAs
+            if (g < 3) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const floatx4& bs = e ? b1 : b0;
+            float4 a[NMT];
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) a[m] = wl[(e * NMT + m) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, bs[0], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, bs[1], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, bs[2], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, bs[3], acc[m], 0, 0, 0);
         }
     }
 }
@@ -81,9 +118,11 @@ __device__ __forceinline__ void stage_load(const float* __restrict__ gsrc, float
 #pragma unroll
     for (int i = 0; i < (NBLK + kWaves - 1) / kWaves; ++i) {
         const int blk = wave + i * kWaves;
-        if (NBLK % kWaves == 0 || blk < NBLK)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + blk * 256 + lane * 4),
+        if (NBLK % kWaves == 0 || blk < NBLK) {
+            const char* base = reinterpret_cast<const char*>(gsrc + blk * 256);  // uniform (SGPR pair) + 32-bit lane offset
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (unsigned)(lane * 16)),
                                              (__attribute__((address_space(3))) void*)(lds_dst + blk * 256), 16, 0, 0);
+        }
     }
 }
 
@@ -155,7 +194,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages + all biases
     float* bias_lds = smem + 2 * kStageFloats;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: keeps the LDS-DMA bases in SGPRs
     const int lj = lane & 15, lg = lane >> 4;
     const int64_t row = (int64_t)blockIdx.x * (kWaves * 16) + wave * 16 + lj;
     const int64_t rowc = row < g.n_rows ? row : g.n_rows - 1;
@@ -168,16 +208,15 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     }
 
     // ---- input features -> registers (MFMA B-operand layout): 16-feature tile t, register r = feature 16t+4g+r
-    floatx4 xin[8];
     const int64_t ia = (rowc / g.a_div) % g.a_mod;
     const int64_t ib = (rowc / g.b_div) % g.b_mod;
     const float* init_a_row = g.init_a != nullptr ? g.init_a + ia * (int64_t)g.d.init_stride : nullptr;
     const float* init_b_row = g.init_b != nullptr ? g.init_b + ib * (int64_t)g.d.init_stride : nullptr;
     const float* pa = g.ta != nullptr ? g.ta + ia * (int64_t)(g.d.in_kt_a * 32) : nullptr;
     const float* pb = (g.d.in_kt_b > 0 && g.tb != nullptr) ? g.tb + ib * (int64_t)(g.d.in_kt_b * 32) : nullptr;
-    // The lean variant keeps the input features in registers for the whole kernel; the chain variant needs those
-    // registers for its operand tiles and re-reads the (L2-resident) features at each layer that consumes them.
-    auto load_xin = [&]() {
+    // The (L2-resident) input features are re-read at each layer that consumes them: keeping them in registers for
+    // the whole kernel would cost the 32 VGPRs that the second weight-fragment set of stage_compute needs.
+    auto load_xin = [&](floatx4 (&xin)[8]) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const float* src = nullptr;
@@ -191,7 +230,6 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             xin[t][3] = v.w;
         }
     };
-    if constexpr (!CHAIN) load_xin();
 
     for (int i = tid; i < g.n_bias; i += kWaves * 64) bias_lds[i] = g.b[i];  // visible after the first stage barrier
 
@@ -281,24 +319,20 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                 }
             }
         }
-        // K tiles from the input features first, then from the previous activations (matches the packer)
-        if constexpr (CHAIN) {
-            if (L.n_kt_in > 0) {
-                load_xin();
-            } else {  // a fresh definition: keeps the 32 feature registers dead across the layers that do not use them
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xin[t][r] = 0.f;
-            }
-        }
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            if (kt < L.n_kt_in) PSN_STAGE(16, xin[2 * kt], xin[2 * kt + 1], kt)
-        }
+        // K tiles from the previous activations first, then from the input features (matches the packer): once the
+        // activation tiles are consumed their 64 registers are dead, so the (L2-resident) input features are only
+        // fetched then -- the two operand sets never compete for registers with the double-buffered weight fragments.
         if (L.n_kt_act > 0) {
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) PSN_STAGE(16, act[2 * kt], act[2 * kt + 1], L.n_kt_in + kt)
+            for (int kt = 0; kt < 8; ++kt) PSN_STAGE(16, act[2 * kt], act[2 * kt + 1], kt)
+        }
+        if (L.n_kt_in > 0) {
+            floatx4 xin[8];
+            load_xin(xin);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt < L.n_kt_in) PSN_STAGE(16, xin[2 * kt], xin[2 * kt + 1], L.n_kt_act + kt)
+            }
         }
         // activation: accumulators become the next layer's B operands.  Optional row-major operands (aux1, aux2)
         // are re-read and optional results (the new activation, a second value) are dumped per layer; the stores

@@ -84,12 +84,12 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
                 init_wb.append(torch.nn.functional.pad(_pad_cols(L['init_b'], in_kt_b * 32), (0, 0, 0, 256 - L['init_b'].shape[0])))
             init_bias.append(bias)  # folded into the init table
             bias = torch.zeros_like(bias)
+        if L.get('w_act') is not None:  # K order of the packed layer: activation tiles first, input-feature tiles last
+            parts.append(_pad_cols(L['w_act'], 256))
+            n_kt_act = 8
         if L.get('w_in') is not None:
             parts.append(_pad_cols(L['w_in'], in_cols))
             n_kt_in = in_kt_a + in_kt_b
-        if L.get('w_act') is not None:
-            parts.append(_pad_cols(L['w_act'], 256))
-            n_kt_act = 8
         if parts:
             W = torch.cat(parts, dim=1)
             W = torch.nn.functional.pad(W, (0, 0, 0, rows - W.shape[0])).contiguous().float()
