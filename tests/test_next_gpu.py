@@ -102,3 +102,26 @@ def test_handoff_roundtrip_and_checkpoints(cuda, tmp_path):
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
     assert torch.equal(step.light_para.weight, step2.light_para.weight)
+
+
+def test_material_editing_vs_oracle(cuda):
+    """eval.py:233-312: re-render with a replaced albedo (``albedo_new``) and with a single specular basis lobe
+    switched on (``basis_new``); forward only, against the oracle."""
+    import psnerf_amd.stage2 as s2
+    from oracle import stage2 as o2
+    sd = stage2_state_dict(o2.bear_conf(), seed=21)
+    onet = o2.PSNetwork(o2.bear_conf())
+    onet.load_state_dict(sd)
+    net = s2.PSNetwork(s2.bear_conf())
+    net.load_state_dict(sd)
+    net.to(cuda).eval()
+    N, L = 500, 6
+    inp, _ = stage2_inputs(N, L, 1, seed=9)
+    inp_d = {k: v.to(cuda) for k, v in inp.items()}
+    albedo_new = np.array([0.8, 0.3, 0.1], dtype=np.float32)
+    for kw in (dict(albedo_new=albedo_new), dict(basis_new=3), dict(albedo_new=albedo_new, basis_new=7)):
+        with torch.no_grad():
+            ref = onet(inp, **kw)
+            out = net(inp_d, **kw)
+        for k in ('sg_rgb_values', 'sg_diffuse_albedo_values', 'sg_specular_rgb_values', 'sg_weight'):
+            assert_close(out[k].cpu(), ref[k], 1e-4, '%s with %s' % (k, sorted(kw)))
