@@ -1,9 +1,13 @@
-// Fully fused MLP inference for 256-wide networks: activations never leave registers.
+// Fully fused 256-wide MLP engine: activations never leave registers.
 //
-// Replaces the no-grad network evaluations of the reference:
-//   stage2 visibility_net over L*Ns rows   (stage2/model/renderer.py:191-200; vis.detach() at :197)
-//   stage1 occupancy-only queries          (stage1/model/rendering.py:456-462 march, :537-540 secant,
-//                                           :394-399 light_visibility; network.py:124-125)
+// Lean variant (mlp_infer_kernel<false>) -- the no-grad network evaluations of the reference, optionally leaving the
+// hidden activations of a row range behind for a later backward pass:
+//   stage2 visibility_net over (L + V)*Ns rows  (stage2/model/renderer.py:191-200, 251-262; vis.detach() at :197)
+//   stage1 occupancy-only queries               (stage1/model/rendering.py:456-462 march, :537-540 secant,
+//                                                :394-399 light_visibility; network.py:124-125)
+// Chain variant (mlp_infer_kernel<true>) -- the same pipeline with a per-layer activation PROGRAM (row-major
+// operands, dumps, side outputs): forward-with-dumps, ReLU backward, the stage-1 gradient sweep
+// (network.py:108-120 under create_graph=True) and the adjoints of both, see include/psnerf_hip.h PSN_ACT_*.
 //
 // Formulation: per layer OUT^T[features, points] = W[features, K] * ACT^T[K, points] on
 // v_mfma_f32_16x16x4_f32.  One wave owns 16 points (the MFMA N dimension = lane & 15); a lane holds 64 of
@@ -14,13 +18,15 @@
 // lane groups hold features 16kt + 4g + r); the weights are pre-packed to match (psn_mlp_pack_layer), so
 // there is no transpose, no LDS round trip and no HBM traffic for activations.
 //
-// Workgroup = 8 waves = 128 points, 2 waves per SIMD (<= 256 VGPRs each): while one wave of a SIMD is parked
-// at the per-stage barrier or issuing its LDS-DMA, the other keeps the matrix pipe busy (the first
-// 32x32x2 / 1-wave-per-SIMD version measured 73 % MFMA-busy with 15 % of wave cycles parked).
+// Workgroup = 4 waves = 64 points; two workgroups share a CU (2 waves per SIMD, <= 256 VGPRs each): while one
+// wave of a SIMD is parked at the per-stage barrier, issuing its LDS-DMA or running its activation program, the
+// other keeps the matrix pipe busy (the first 32x32x2 / 1-wave-per-SIMD version measured 73 % MFMA-busy; an
+// 8-wave workgroup per CU is no faster: the stage barrier then couples all eight waves).
 // Weights (L2-resident, <= 2.6 MB) stream through LDS in 32 KB stages (32 input features x 256 outputs)
-// by LDS-DMA (global_load_lds_dwordx4), double buffered, shared by the 8 waves.
+// by LDS-DMA (global_load_lds_dwordx4), double buffered, shared by the 4 waves; biases sit in LDS.
 //
-// Roofline: MFMA-bound.  Per stage and wave: 128 MFMAs (4096 cycles) vs 32 ds_read_b128.
+// Roofline: MFMA-bound.  Per stage and wave: 128 MFMAs (4096 cycles) vs 32 ds_read_b128.  Measured (lean variant,
+// visibility net): 0.90 of the dense fp32-MFMA peak algorithmic, matrix pipe 83 % busy at 2.30 GHz.
 #include "common.h"
 
 namespace psn {
