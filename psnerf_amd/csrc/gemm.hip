@@ -2,14 +2,17 @@
 // Reference ops replaced: torch.nn.Linear / F.relu / nn.Softplus(beta=100) and their autograd backward
 // in stage1/model/network.py:85-106 and stage2/model/renderer.py:17-49.
 //
-// Workgroup tile 128 x BN x 16 with BN = 256 (default) or 128 (narrow outputs), 4 waves in a 2x2 grid, each
-// wave 64 x BN/2 = 2 x NT MFMA tiles.  fp32 MFMA has so little arithmetic per operand byte that a 128x128
+// Workgroup tile 128 x BN x 16 with BN = 128 or 256 (256 only when the grid still covers the chip several times
+// over, see psn_gemm), 4 waves in a 2x2 grid, each wave 64 x BN/2 = 2 x NT MFMA tiles.  fp32 MFMA has so little arithmetic per operand byte that a 128x128
 // tile needs ~8.7 B/clk/CU of global loads at MFMA peak -- the measured per-CU streaming limit (~10 B/clk) --
 // and PMC showed 35-53 % MFMA-busy for it; the 256-wide tile reads each activation row-panel once and halves
 // the bytes per flop.  Operand tiles are staged k-major in LDS ([16][rows+4] floats) so that every MFMA
 // operand read is a conflict-free ds_read_b32 of 32 consecutive floats; the next k-tile is fetched into
 // registers while the current one is multiplied (one barrier per k-tile).  Numerics: exact fp32 fma chain
 // per output element (k-ordered), see MI355X guide "FP32-input MFMA".
+//
+// Weight gradients (dW = dZ^T X, K = rows of the pass) use deterministic split-K; psn_gemm_tn_grouped runs all of
+// them for one backward pass in a single launch and returns the bias gradients (column sums of dZ) as a by-product.
 #include "common.h"
 
 namespace psn {

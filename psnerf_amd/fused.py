@@ -4,9 +4,9 @@ A network is a list of layers, each reading the 256 activations of the previous
 layer and/or the per-row INPUT FEATURES (positional encodings).  The input
 block can be consumed in two ways:
 
-* as MFMA k-tiles (``w_in``): up to four 32-float tiles kept in registers for
-  the whole kernel (used by the stage-1 occupancy net, whose query points are
-  all distinct);
+* as MFMA k-tiles (``w_in``): up to four 32-float tiles, fetched into registers
+  by each layer that consumes them, after its activation k-tiles (used by the
+  stage-1 networks, whose query points are all distinct);
 * as precomputed partial products (``init``): because the layer is linear in
   its input block, W_in [A_row | B_row] = W_a A_row + W_b B_row is evaluated
   ONCE per table row by two small GEMMs and the kernel starts the layer's
