@@ -355,6 +355,156 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(GroupedArgs gg) {
     gemm_tile<true, false, 2>(g, bid, lds_raw);
 }
 
+// Branch-free staging of one 16 x 256 operand tile of the one-tile-per-workgroup kernel (source [K][rows], row-major,
+// 16-byte aligned, ld % 4 == 0): addresses are clamped into the allocation and out-of-range elements zeroed with
+// selects, so all loads of a k-tile sit in one basic block and the waits on them can be counted (vmcnt(N)) instead of
+// draining the queue -- the condition for keeping two tiles in flight.
+__device__ __forceinline__ void fetch_tile256(const float* __restrict__ src, int64_t ld, int k0, int k_end, int tid,
+                                              float4 (&v)[4]) {
+    const int rqc = min((tid & 63) * 4, (int)ld - 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int kc = min(k0 + (tid >> 6) + 4 * u, k_end - 1);
+        v[u] = *reinterpret_cast<const float4*>(src + (int64_t)kc * ld + rqc);
+    }
+}
+// ... the zeroing happens when the tile is written to LDS (two k-tiles later), never right behind the loads
+__device__ __forceinline__ void mask_tile256(int n_rows, int k0, int k_end, int tid, float4 (&v)[4]) {
+    const int rq = (tid & 63) * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool kin = k0 + (tid >> 6) + 4 * u < k_end;
+        v[u].x = (kin && rq + 0 < n_rows) ? v[u].x : 0.f;
+        v[u].y = (kin && rq + 1 < n_rows) ? v[u].y : 0.f;
+        v[u].z = (kin && rq + 2 < n_rows) ? v[u].z : 0.f;
+        v[u].w = (kin && rq + 3 < n_rows) ? v[u].w : 0.f;
+    }
+}
+
+// ---- weight gradients with ONE 256 x 256 tile per workgroup ----------------------------------------------------------
+// dW = dZ^T X with M, N <= 256: a workgroup owns the whole output for one K slice, so every operand row is read from
+// L2 exactly once (the 128 x 128 tiles above read each twice and sit at the per-CU streaming limit).  4 waves in a
+// 2 x 2 grid, each 128 x 128 = 4 x 4 MFMA tiles (256 accumulator registers, one wave per SIMD); per 16-row k-tile a
+// wave issues 128 MFMAs (8192 cycles) against 64 ds_read_b32, 8 staged float4 loads and one barrier.
+constexpr int T256 = 256, T256_LD = T256 + 4, T256_BUF = 2 * BK * T256_LD;
+__global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs gg) {
+    extern __shared__ __attribute__((aligned(16))) float lds256[];  // 2 x {A[16][260], B[16][260]}
+    int gi = 0;
+    while (gi + 1 < gg.n && (int64_t)blockIdx.x >= gg.block_start[gi + 1]) ++gi;
+    const GemmArgs g = gg.g[gi];
+    const int split = (int)((int64_t)blockIdx.x - gg.block_start[gi]);
+    if (split >= g.split_k) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const bool seg2 = split >= g.seg_splits;
+    const float* Ap = seg2 ? g.A2 : g.A;
+    const float* Bp = seg2 ? g.B2 : g.B;
+    const int64_t lda = seg2 ? g.lda2 : g.lda, ldb = seg2 ? g.ldb2 : g.ldb;
+    const int k_begin = (seg2 ? split - g.seg_splits : split) * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int nt = (k_end - k_begin + BK - 1) / BK;
+
+    floatx16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+    // Two register sets: the operand rows of k-tiles t+2 and t+3 are in flight while tile t is multiplied.  With one
+    // workgroup per CU and nothing re-used between workgroups, HBM has to deliver ~2.3 TB/s for the matrix pipe to stay
+    // busy; a single 32 KB tile in flight per CU (8 MB on the chip) only sustains about half of that.
+    float4 ra[2][4], rb[2][4];
+    const bool do_cs = g.colsum != nullptr && !seg2;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#define T_FETCH(T, S)                                                                            \
+    fetch_tile256(Ap, lda, k_begin + (T) * BK, k_end, tid, ra[S]);                               \
+    fetch_tile256(Bp, ldb, k_begin + (T) * BK, k_end, tid, rb[S]);
+#define T_STORE(BUF, S, T)                                                                       \
+    mask_tile256((int)g.M, k_begin + (T) * BK, k_end, tid, ra[S]);                               \
+    mask_tile256(g.N, k_begin + (T) * BK, k_end, tid, rb[S]);                                    \
+    if (do_cs) {                                                                                 \
+        cs.x += (ra[S][0].x + ra[S][1].x) + (ra[S][2].x + ra[S][3].x); cs.y += (ra[S][0].y + ra[S][1].y) + (ra[S][2].y + ra[S][3].y); \
+        cs.z += (ra[S][0].z + ra[S][1].z) + (ra[S][2].z + ra[S][3].z); cs.w += (ra[S][0].w + ra[S][1].w) + (ra[S][2].w + ra[S][3].w); \
+    }                                                                                            \
+    store_tile<false, T256>(lds256 + (BUF) * T256_BUF, tid, ra[S]);                              \
+    store_tile<false, T256>(lds256 + (BUF) * T256_BUF + BK * T256_LD, tid, rb[S]);
+#define T_COMPUTE(BUF)                                                                           \
+    {                                                                                            \
+        const float* As = lds256 + (BUF) * T256_BUF + wr * 128 + li;                             \
+        const float* Bs = lds256 + (BUF) * T256_BUF + BK * T256_LD + wc * 128 + li;              \
+        float pa[2][4], pb[2][4];                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) pa[0][i] = As[lh * T256_LD + i * 32];      \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) pb[0][n] = Bs[lh * T256_LD + n * 32];      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                       \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                          \
+            if (j < 7) {                                                                         \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) pa[(j + 1) & 1][i] = As[(2 * j + 2 + lh) * T256_LD + i * 32]; \
+                _Pragma("unroll") for (int n = 0; n < 4; ++n) pb[(j + 1) & 1][n] = Bs[(2 * j + 2 + lh) * T256_LD + n * 32]; \
+            }                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                _Pragma("unroll") for (int n = 0; n < 4; ++n)                                    \
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j & 1][i], pb[j & 1][n], acc[i][n], 0, 0, 0); \
+            if (j < 7) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                  \
+        }                                                                                        \
+    }
+    // one wave per SIMD: nothing else hides the LDS latency, so T_COMPUTE requests the operands of k-pair j+1 before
+    // the 16 MFMAs of k-pair j are issued (two register sets, order pinned for the scheduler)
+#define T_STEP(T, S)                                                                             \
+    {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        T_COMPUTE((T) & 1)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        T_STORE(((T) + 1) & 1, S, (T) + 1) /* past the end: clamped loads, zeroed by the mask */  \
+        T_FETCH((T) + 3, S)                                                                      \
+        __syncthreads();                                                                         \
+    }
+    T_FETCH(0, 0)
+    T_STORE(0, 0, 0)
+    T_FETCH(1, 0)
+    T_FETCH(2, 1)
+    __syncthreads();
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {  // no control flow around the MFMA blocks: 256 accumulators must not meet a merge
+        T_STEP(t, 0)
+        T_STEP(t + 1, 1)
+    }
+    if (t < nt) T_STEP(t, 0)
+#undef T_STEP
+#undef T_COMPUTE
+#undef T_FETCH
+#undef T_STORE
+    if (do_cs) {  // thread tid staged columns 4 (tid % 64) .. +3 (rows tid / 64 + 4u of every k-tile): reduce over the 4 waves
+        float4* red = reinterpret_cast<float4*>(lds256);
+        red[wave * 64 + lane] = cs;
+        __syncthreads();
+        if (tid < 64) {
+            const float4 a = red[tid], b = red[64 + tid], c = red[128 + tid], d = red[192 + tid];
+            const float v[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+            float* dst = g.colsum + (int64_t)split * g.M + 4 * tid;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * tid + e < g.M) dst[e] = v[e];
+        }
+    }
+    // partial tile -> workspace.  Lane (li, lh) holds C[wr*128 + i*32 + (r&3) + 8*(r>>2) + 4*lh][wc*128 + n*32 + li].
+    float* Cw = g.C + (int64_t)split * g.split_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int col = wc * 128 + n * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.M && col < g.N) Cw[(int64_t)row * g.N + col] = acc[i][n][r];
+            }
+        }
+}
+
 struct ReduceItem {
     const float* ws;       // [splits][M*N] partial outputs
     const float* cs_ws;    // [cs_splits][M] partial column sums or nullptr
@@ -597,26 +747,48 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
     int kc = (int)((K + split_k - 1) / split_k);
     kc = ((kc + BK - 1) / BK) * BK;
     split_k = (int)((K + kc - 1) / kc);
-    GroupedArgs gg;
-    GroupedReduceArgs ra;
-    gg.n = n_items;
-    int64_t blocks = 0, ws_off = 0;
-    int max_rblocks = 1;
+    // Products with 128 < M, N <= 256 (the hidden-layer gradients) take the one-tile-per-workgroup kernel: exactly one
+    // workgroup per (product, K slice), one workgroup per CU, so the slice count is chosen to fill 256 CUs once.
+    int big_products = 0;
     for (int i = 0; i < n_items; ++i) {
         const PsnGemmTnItem& it = items[i];
         PSN_CHECK_ARG(it.A && it.B && it.C && it.M > 0 && it.N > 0, "gemm_tn_grouped: item %d has a null operand or empty shape", i);
         PSN_CHECK_ARG((it.A2 == nullptr) == (it.B2 == nullptr), "gemm_tn_grouped: item %d needs both A2 and B2", i);
+        const bool vec = (((uintptr_t)it.A | (uintptr_t)it.B | (uintptr_t)it.A2 | (uintptr_t)it.B2) & 15) == 0 && it.lda % 4 == 0 &&
+                         it.ldb % 4 == 0 && it.lda >= 4 && it.ldb >= 4 && (!it.A2 || (it.lda2 % 4 == 0 && it.ldb2 % 4 == 0 && it.lda2 >= 4 && it.ldb2 >= 4));
+        if (vec && it.M > 128 && it.N > 128 && it.M <= T256 && it.N <= T256) big_products += it.A2 ? 2 : 1;
+    }
+    int split_big = 1, kc_big = 0;
+    if (big_products > 0) {
+        int64_t want = 256 / big_products;
+        if (want < 1) want = 1;
+        if (want > K / 256) want = K / 256 > 0 ? K / 256 : 1;
+        kc_big = (int)((K + want - 1) / want);
+        kc_big = ((kc_big + BK - 1) / BK) * BK;
+        split_big = (int)((K + kc_big - 1) / kc_big);
+    }
+    GroupedArgs gg, gb;
+    GroupedReduceArgs ra;
+    gg.n = gb.n = 0;
+    int64_t blocks = 0, blocks_big = 0, ws_off = 0;
+    int max_rblocks = 1;
+    for (int i = 0; i < n_items; ++i) {
+        const PsnGemmTnItem& it = items[i];
         const int n_seg = it.A2 ? 2 : 1;
-        GemmArgs& g = gg.g[i];
+        const bool vec = (((uintptr_t)it.A | (uintptr_t)it.B | (uintptr_t)it.A2 | (uintptr_t)it.B2) & 15) == 0 && it.lda % 4 == 0 &&
+                         it.ldb % 4 == 0 && it.lda >= 4 && it.ldb >= 4 && (!it.A2 || (it.lda2 % 4 == 0 && it.ldb2 % 4 == 0 && it.lda2 >= 4 && it.ldb2 >= 4));
+        const bool big = vec && it.M > 128 && it.N > 128 && it.M <= T256 && it.N <= T256;
+        const int sk = big ? split_big : split_k;
+        GemmArgs& g = big ? gb.g[gb.n] : gg.g[gg.n];
         g.M = it.M; g.N = it.N; g.K = (int)K; g.A = it.A; g.lda = it.lda; g.B = it.B; g.ldb = it.ldb;
         g.A2 = it.A2; g.lda2 = it.lda2; g.B2 = it.B2; g.ldb2 = it.ldb2;
         g.bias = nullptr; g.epi = PSN_EPI_NONE; g.aux_in = g.aux_in2 = nullptr; g.aux_out = nullptr;
         g.ld_aux_in = g.ld_aux_in2 = g.ld_aux_out = 0;
-        g.tiles_n = (it.N + 127) / 128;
-        g.n_tiles = (int64_t)((it.M + BM - 1) / BM) * g.tiles_n;
-        g.k_chunk = kc;
-        g.split_k = split_k * n_seg;
-        g.seg_splits = split_k;
+        g.tiles_n = big ? 1 : (it.N + 127) / 128;
+        g.n_tiles = big ? 1 : (int64_t)((it.M + BM - 1) / BM) * g.tiles_n;
+        g.k_chunk = big ? kc_big : kc;
+        g.split_k = sk * n_seg;
+        g.seg_splits = sk;
         g.a_vec = (((uintptr_t)it.A & 15) == 0) && (it.lda % 4 == 0) && (!it.A2 || ((((uintptr_t)it.A2 & 15) == 0) && (it.lda2 % 4 == 0)));
         g.b_vec = (((uintptr_t)it.B & 15) == 0) && (it.ldb % 4 == 0) && (!it.B2 || ((((uintptr_t)it.B2 & 15) == 0) && (it.ldb2 % 4 == 0)));
         g.auxin_vec = g.auxin2_vec = g.auxout_vec = 0;
@@ -630,22 +802,34 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         g.colsum = it.colsum_a ? workspace + ws_off : nullptr;
         ReduceItem& r = ra.it[i];
         r.ws = g.C; r.cs_ws = g.colsum; r.C = it.C; r.colsum = it.colsum_a; r.MN = MN; r.ldc = it.ldc; r.N = it.N; r.M = it.M;
-        r.splits = g.split_k; r.cs_splits = split_k; r.accumulate = it.accumulate ? 1 : 0;
+        r.splits = g.split_k; r.cs_splits = sk; r.accumulate = it.accumulate ? 1 : 0;
         r.vec = g.c_vec && (it.ldc % 4 == 0) && (((uintptr_t)it.C & 15) == 0);
         r.blocks = (int)(r.vec ? (MN + 127) / 128 : (MN + 255) / 256);
         const int rb = r.blocks + (it.colsum_a ? (it.M + 255) / 256 : 0);
         if (rb > max_rblocks) max_rblocks = rb;
-        if (it.colsum_a) ws_off += (int64_t)split_k * it.M;
+        if (it.colsum_a) ws_off += (int64_t)sk * it.M;
         ws_off = (ws_off + 3) / 4 * 4;
-        gg.block_start[i] = blocks;
-        blocks += (g.n_tiles * g.split_k + 7) / 8 * 8;
+        if (big) {
+            gb.block_start[gb.n++] = blocks_big;
+            blocks_big += g.split_k;
+        } else {
+            gg.block_start[gg.n++] = blocks;
+            blocks += (g.n_tiles * g.split_k + 7) / 8 * 8;
+        }
     }
-    gg.block_start[n_items] = blocks;
+    gg.block_start[gg.n] = blocks;
+    gb.block_start[gb.n] = blocks_big;
     PSN_CHECK_ARG(ws_off <= workspace_floats, "gemm_tn_grouped: workspace too small (%lld floats needed)", (long long)ws_off);
-    PSN_CHECK_ARG(blocks < (1ll << 31), "gemm_tn_grouped: too many blocks");
+    PSN_CHECK_ARG(blocks < (1ll << 31) && blocks_big < (1ll << 31), "gemm_tn_grouped: too many blocks");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gg);
-    PSN_CHECK_LAUNCH("gemm_tn_grouped");
+    if (gb.n > 0) {
+        hipLaunchKernelGGL(gemm_tn256_grouped_kernel, dim3((unsigned)blocks_big), dim3(256), T256_BUF * 2 * sizeof(float), st, gb);
+        PSN_CHECK_LAUNCH("gemm_tn_grouped (256 x 256 tiles)");
+    }
+    if (gg.n > 0) {
+        hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gg);
+        PSN_CHECK_LAUNCH("gemm_tn_grouped");
+    }
     hipLaunchKernelGGL(grouped_reduce_kernel, dim3((unsigned)max_rblocks, (unsigned)n_items), dim3(256), 0, st, ra);
     PSN_CHECK_LAUNCH("gemm_tn_grouped reduce");
     return PSN_OK;

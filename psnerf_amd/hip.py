@@ -220,18 +220,45 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, epi=EPI_NONE, aux_in=Non
     return out
 
 
-def gemm_tn_grouped(items, split_k):
+def _tn_is_big(it):
+    """Products that psn_gemm_tn_grouped sends to its one-256x256-tile-per-workgroup kernel."""
+    def ok(t):
+        return t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(0) >= 4)
+    return (128 < it['A'].shape[1] <= 256 and 128 < it['B'].shape[1] <= 256
+            and all(ok(it.get(k)) for k in ('A', 'B', 'A2', 'B2')))
+
+
+def gemm_tn_grouped(items, split_k=None):
     """Weight gradients of one backward pass in one launch.  items: list of dicts with A [K,M], B [K,N] (row-major
     views, row stride allowed), optional A2 / B2 (second product summed into the same result), optional out [M,N]
-    (+ accumulate=True) and colsum (True -> the column sums of A are returned too).  Returns [(C, colsum or None)]."""
+    (+ accumulate=True) and colsum (True -> the column sums of A are returned too).  Returns [(C, colsum or None)].
+    split_k = K slices per product of the 128 x 128-tile path (default: enough (tile, slice) work items to cover the
+    256 CUs about four times with K chunks of at least 512 rows); the 256 x 256-tile path picks its own."""
     res = []
     K = items[0]['A'].shape[0]
     dev = items[0]['A'].device
+    if split_k is None:
+        work = 0
+        for it in items:
+            if not _tn_is_big(it):
+                tiles = ((it['A'].shape[1] + 127) // 128) * ((it['B'].shape[1] + 127) // 128)
+                work += tiles * (2 if it.get('A2') is not None else 1)
+        want = max(1, (1024 + work - 1) // max(work, 1))
+        split_k = int(max(1, min(want, K // 512 if K >= 512 else 1, 256)))
     for c0 in range(0, len(items), MAX_GROUP):
         chunk = items[c0:c0 + MAX_GROUP]
         arr = (PsnGemmTnItem * len(chunk))()
         need = 0
         keep = []
+        # slices per product of the one-tile-per-workgroup path (mirrors psn_gemm_tn_grouped, which re-checks the size)
+        is_big = _tn_is_big
+        n_big = sum((2 if it.get('A2') is not None else 1) for it in chunk if is_big(it))
+        split_big = 1
+        if n_big:
+            want = max(1, min(256 // n_big, K // 256 if K >= 256 else 1))
+            kc = -(-K // want)
+            kc = (kc + 15) // 16 * 16
+            split_big = -(-K // kc)
         for i, it in enumerate(chunk):
             A, B = it['A'], it['B']
             assert A.shape[0] == K and B.shape[0] == K, 'gemm_tn_grouped: all products share K'
@@ -250,7 +277,8 @@ def gemm_tn_grouped(items, split_k):
             e.C, e.ldc, e.M, e.N = _mat_ptr(C, 'out'), _ld(C), M, N
             e.accumulate = int(bool(it.get('accumulate')))
             e.colsum_a = None if cs is None else cs.data_ptr()
-            need += (2 if A2 is not None else 1) * split_k * M * N + split_k * M + 16
+            sk = max(split_k, split_big) if is_big(it) else split_k
+            need += (2 if A2 is not None else 1) * sk * M * N + sk * M + 16
             keep.append((C, cs))
         ws = workspace(need, dev)
         _check(_lib.psn_gemm_tn_grouped(len(chunk), ctypes.addressof(arr), K, split_k, ws.data_ptr(), ws.numel(), _stream()),

@@ -151,7 +151,7 @@ class ReluMLP(torch.autograd.Function):
             elif ctx.x_needs:
                 dx += hip.gemm(g, Wp, trans_a=False, trans_b=False)
         if items:
-            for li, (dWp, db) in zip(item_layer, hip.gemm_tn_grouped(items, _grouped_split(items, Q))):
+            for li, (dWp, db) in zip(item_layer, hip.gemm_tn_grouped(items)):
                 if db is not None:
                     grads[2 * li + 1] = db
                 if li == 0:
@@ -161,17 +161,6 @@ class ReluMLP(torch.autograd.Function):
                 else:
                     grads[2 * li] = dWp
         return (dx, None, None, None) + tuple(grads)
-
-
-def _grouped_split(items, K):
-    """Split-K slices per product for a grouped weight-gradient launch: enough (tile, slice) work items to cover
-    the 256 CUs about four times, but K-chunks of at least 512 rows."""
-    work = 0
-    for it in items:
-        tiles = ((it['A'].shape[1] + 127) // 128) * ((it['B'].shape[1] + 127) // 128)
-        work += tiles * (2 if it.get('A2') is not None else 1)
-    want = max(1, (1024 + work - 1) // max(work, 1))
-    return int(max(1, min(want, K // 512 if K >= 512 else 1, 256)))
 
 
 def relu_mlp(x, in_cols, skip_at, final_sigmoid, weights, biases):
@@ -567,7 +556,7 @@ class VisibilityPair(torch.autograd.Function):
         chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh_last, mask=[H[n - 2 - j] for j in range(n - 1)],
               save=DZ, save_row0=0)
         items = [dict(A=DZ[n - 2 - li], B=H[li - 1], colsum=True) for li in range(n - 2, 0, -1)]
-        res = hip.gemm_tn_grouped(items, _grouped_split(items, Q)) if items else []
+        res = hip.gemm_tn_grouped(items) if items else []
         for li, (dWh, db) in zip(range(n - 2, 0, -1), res):
             grads[2 * li + 1] = db
             if li - 1 == ctx.skip_at:
@@ -678,7 +667,7 @@ class GeoFieldFused(torch.autograd.Function):
                 it['A2'], it['B2'] = U[l][:, :o], dd_pe[:, :d_pe] if l == 0 else dR[l][:, :i_w]
             items.append(it)
         items.append(dict(A=d_feat, B=a_last, colsum=True))
-        res = hip.gemm_tn_grouped(items, _grouped_split(items, Q))
+        res = hip.gemm_tn_grouped(items)
         for l in range(n - 1):
             dW[l], db[l] = res[l]
         row0 = hip.colsum(d_logit * a_last)
@@ -733,7 +722,7 @@ class AppNetFused(torch.autograd.Function):
         items = [dict(A=dz0, B=x[:, :d_x], colsum=True), dict(A=dz0, B=feat)]
         items += [dict(A=DZ[n - 2 - l], B=H[l - 1], colsum=True) for l in range(1, n - 1)]
         items.append(dict(A=g, B=H[n - 2], colsum=True))
-        res = hip.gemm_tn_grouped(items, _grouped_split(items, Q))
+        res = hip.gemm_tn_grouped(items)
         grads = [torch.cat([res[0][0], res[1][0]], dim=1), res[0][1]]
         for l in range(1, n):
             grads += [res[l + 1][0], res[l + 1][1]]

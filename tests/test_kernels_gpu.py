@@ -192,9 +192,9 @@ def test_gemm_tn_grouped(cuda, Q, split):
             assert_close(cs.cpu(), cref, 1e-5, 'grouped colsum %d' % i)
     # same results as the one-at-a-time path, and deterministic
     one = hip.gemm(dZd[0], Xd[0], trans_a=True, split_k=split)
-    assert_close(res[0][0].cpu(), one.cpu(), 1e-6, 'grouped vs single')
-    res2 = hip.gemm_tn_grouped(items[:4], split)
-    assert all(torch.equal(a[0], b[0]) for a, b in zip(res[:4], res2))
+    assert_close(res[0][0].cpu(), one.cpu(), 1e-5, 'grouped vs single')  # different K slicing: rounding only
+    res2 = hip.gemm_tn_grouped(items, split)  # the same grouping again: bit-identical (fixed summation order)
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(res[:4], res2[:4]))
 
 
 def test_fused_visibility_mlp(cuda):
