@@ -197,6 +197,30 @@ def test_gemm_tn_grouped(cuda, Q, split):
     assert all(torch.equal(a[0], b[0]) for a, b in zip(res[:4], res2[:4]))
 
 
+@pytest.mark.parametrize('Q', [7, 100, 4099])
+def test_gemm_tn_grouped_tile256_edges(cuda, Q):
+    """The one-256x256-tile-per-workgroup path (128 < M, N <= 256) on awkward shapes: K smaller than / not a multiple
+    of the 16-row k-tile, operands that are column slices of narrow buffers (row stride < 256), two products."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(Q)
+    A = torch.randn(Q, 132, generator=g)   # M = 130 of a 132-wide buffer
+    B = torch.randn(Q, 200, generator=g)   # N = 200, row stride 200
+    A2 = torch.randn(Q, 256, generator=g)
+    B2 = torch.randn(Q, 204, generator=g)
+    d = lambda t: t.to(cuda)
+    Ad, Bd, A2d, B2d = d(A), d(B), d(A2), d(B2)
+    items = [dict(A=Ad[:, :130], B=Bd, colsum=True),
+             dict(A=A2d[:, :130], B=B2d[:, :200], A2=Ad[:, :130], B2=Bd, colsum=True),
+             dict(A=A2d, B=B2d[:, :129])]
+    res = hip.gemm_tn_grouped(items)
+    D = lambda t: t.double()
+    refs = [D(A[:, :130]).t() @ D(B), D(A2[:, :130]).t() @ D(B2[:, :200]) + D(A[:, :130]).t() @ D(B), D(A2).t() @ D(B2[:, :129])]
+    for i, ((C, cs), ref) in enumerate(zip(res, refs)):
+        assert_close(C.cpu(), ref, 1e-5, 'tile256 dW %d (Q=%d)' % (i, Q))
+    assert_close(res[0][1].cpu(), D(A[:, :130]).sum(0), 1e-5, 'tile256 colsum 0')
+    assert_close(res[1][1].cpu(), D(A2[:, :130]).sum(0), 1e-5, 'tile256 colsum 1')
+
+
 def test_fused_visibility_mlp(cuda):
     """mlp_infer on the stage2 visibility net == oracle MLP (stage2/model/renderer.py:191-200)."""
     from psnerf_amd import hip, fused
