@@ -359,9 +359,11 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(GroupedArgs gg) {
 // 16-byte aligned, ld % 4 == 0): addresses are clamped into the allocation and out-of-range elements zeroed with
 // selects, so all loads of a k-tile sit in one basic block and the waits on them can be counted (vmcnt(N)) instead of
 // draining the queue -- the condition for keeping two tiles in flight.
-__device__ __forceinline__ void fetch_tile256(const float* __restrict__ src, int64_t ld, int k0, int k_end, int tid,
-                                              float4 (&v)[4]) {
-    const int rqc = min((tid & 63) * 4, (int)ld - 4);
+__device__ __forceinline__ void fetch_tile256(const float* __restrict__ src, int64_t ld, int n_rows, int k0, int k_end,
+                                              int tid, float4 (&v)[4]) {
+    // clamp to the last 4-column group of the logical matrix: with a 16-byte aligned base and ld % 4 == 0 that group
+    // lies inside the row of the underlying buffer even when the operand is a column slice of it
+    const int rqc = min((tid & 63) * 4, ((n_rows - 1) >> 2) << 2);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int kc = min(k0 + (tid >> 6) + 4 * u, k_end - 1);
@@ -420,8 +422,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
     const bool do_cs = g.colsum != nullptr && !seg2;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #define T_FETCH(T, S)                                                                            \
-    fetch_tile256(Ap, lda, k_begin + (T) * BK, k_end, tid, ra[S]);                               \
-    fetch_tile256(Bp, ldb, k_begin + (T) * BK, k_end, tid, rb[S]);
+    fetch_tile256(Ap, lda, (int)g.M, k_begin + (T) * BK, k_end, tid, ra[S]);                     \
+    fetch_tile256(Bp, ldb, g.N, k_begin + (T) * BK, k_end, tid, rb[S]);
 #define T_STORE(BUF, S, T)                                                                       \
     mask_tile256((int)g.M, k_begin + (T) * BK, k_end, tid, ra[S]);                               \
     mask_tile256(g.N, k_begin + (T) * BK, k_end, tid, rb[S]);                                    \
