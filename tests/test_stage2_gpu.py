@@ -91,6 +91,11 @@ def test_psnetwork_vs_oracle(cuda, N, L, V):
     assert sorted(gr.keys()) == sorted(o_g.keys())
     for k in o_g:
         assert_close(gr[k].cpu(), o_g[k], 1e-3, 'grad ' + k)
+    # PSNR parity: the rendering metric of the two implementations against the same ground truth
+    m = inp['surface_mask'][0]
+    p_hip = s2.psnr(out['sg_rgb_values'].detach().cpu()[:, m], gt['rgb'][:, m])
+    p_ref = o2.psnr(o_out['sg_rgb_values'].detach()[:, m], gt['rgb'][:, m])
+    assert abs(p_hip - p_ref) < 1e-3, 'PSNR %.5f dB vs %.5f dB' % (p_hip, p_ref)
 
 
 def test_empty_surface(cuda):
