@@ -261,15 +261,19 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     // makes hipcc shuttle every accumulator register between VGPRs and AGPRs per stage).
     int gstage = 0;  // global stage counter -> LDS buffer parity
     int pending_dump = 0;  // activation-dump stores (0 / 16 / 32) issued after the last LDS-DMA batch
+    int pending_stages = 0;  // stage starts (0 or 1) that may leave `pending_dump` stores in flight
     const bool dump_row = row < g.n_rows && row >= g.save_row0;
+    // A wave none of whose rows is dumped skips the store instructions altogether (s_cbranch_execz), so it must not
+    // leave room for them in its counted waits -- it would then not wait for its LDS-DMA pieces either.
+    const bool wave_dumps = __builtin_amdgcn_ballot_w64(dump_row) != 0;
 
 #define PSN_STAGE(NMT, B0, B1, S_IDX)                                                                       \
     {                                                                                                       \
         /* this wave's LDS-DMA pieces have landed; activation dumps issued after them may stay in flight */ \
-        if (pending_dump == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                            \
-        else if (pending_dump == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                      \
+        if (pending_stages > 0 && pending_dump == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      \
+        else if (pending_stages > 0 && pending_dump == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
-        pending_dump = 0;                                                                                   \
+        if (pending_stages > 0) --pending_stages;                                                           \
         __syncthreads(); /* every wave's pieces landed; the other buffer is no longer being read */         \
         const int s_ = (S_IDX);                                                                             \
         float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
@@ -369,7 +373,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                     for (int mt = 0; mt < 16; ++mt)
                         *reinterpret_cast<float4*>(dst + mt * 16) = make_float4(act[mt][0], act[mt][1], act[mt][2], act[mt][3]);
                 }
-                pending_dump = 16;
+                pending_dump = wave_dumps ? 16 : 0;
+                pending_stages = wave_dumps ? 1 : 0;
             }
         } else
         {
@@ -390,7 +395,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                 default: chain_activation<PSN_ACT_NONE>(acc, act, p1, p2, d1, d2); break;
             }
 #undef PSN_CASE
-            pending_dump = (g.save[li] != nullptr ? 16 : 0) + (g.save2[li] != nullptr ? 16 : 0);
+            pending_dump = wave_dumps ? (g.save[li] != nullptr ? 16 : 0) + (g.save2[li] != nullptr ? 16 : 0) : 0;
+            pending_stages = pending_dump > 0 ? 1 : 0;
         }
     }
     if (g.d.n_out > 0) {  // final layer: 32 (padded) outputs = two 16-wide tiles; all 8 k-tiles arrive as ONE 32 KB stage
@@ -404,8 +410,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             acc[mt][2] = bv.z;
             acc[mt][3] = bv.w;
         }
-        if (pending_dump == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else if (pending_dump == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (pending_stages > 0 && pending_dump == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (pending_stages > 0 && pending_dump == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
@@ -524,6 +530,8 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
             PSN_CHECK_ARG(!need1 || a.mask[l] != nullptr, "mlp_infer: layer %d needs aux operand 1", l);
             PSN_CHECK_ARG(!need2 || a.aux2[l] != nullptr, "mlp_infer: layer %d needs aux operand 2", l);
             PSN_CHECK_ARG(act != PSN_ACT_HEAD || a.save[l] != nullptr, "mlp_infer: a HEAD layer needs a dump tensor");
+            const bool second = act == PSN_ACT_SOFTPLUS100 || act == PSN_ACT_MUL_AUX || act == PSN_ACT_MUL2;
+            PSN_CHECK_ARG(a.save2[l] == nullptr || second, "mlp_infer: layer %d (activation %d) has no second value to dump", l, act);
         }
     }
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) PSN_CHECK_ARG((((uintptr_t)a.save[l]) & 15) == 0, "mlp_infer: save buffers must be 16-byte aligned");
