@@ -60,14 +60,19 @@ constexpr int kWaves = 4;  // per workgroup; two workgroups share a CU (2 waves 
 // sets: the reads of group g+1 are issued at the START of group g's MFMA stream (1024 MFMA cycles ahead).  With a
 // single set hipcc can only issue them behind the last six MFMAs (192 cycles), which does not cover the LDS queueing
 // when the eight waves of a CU, barrier-aligned, all ask for their 8 KB at the same moment (PMC: matrix pipe 83 % busy).
-template <int NMT>
+// `request_next` issues the LDS-DMA of the next weight stage; it is placed BEHIND the first group's fragment reads so
+// that its ~50 issue slots (address arithmetic, M0 updates, 8 global_load_lds) fall into the LDS latency the wave has to
+// sit out anyway, instead of delaying the first MFMA of the stage.
+template <int NMT, typename RequestNext>
 __device__ __forceinline__ void stage_compute(floatx4 (&acc)[16], const floatx4& b0, const floatx4& b1,
-                                              const float4* __restrict__ wl, int lane) {
+                                              const float4* __restrict__ wl, int lane, RequestNext request_next) {
     if constexpr (NMT == 16) {
         float4 a[2][8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) a[0][m] = wl[m * 64 + lane];
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // the first group's reads (exposed once per stage)
+        __builtin_amdgcn_sched_barrier(0);  // the first group's reads are in flight (exposed once per stage) ...
+        request_next();
+        __builtin_amdgcn_sched_barrier(0);  // ... while the next stage is requested
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int e = g >> 1, m0 = (g & 1) * 8;
@@ -99,6 +104,7 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[16], const floatx4&
             }
         }
     } else {
+        request_next();
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const floatx4& bs = e ? b1 : b0;
@@ -277,13 +283,14 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         __syncthreads(); /* every wave's pieces landed; the other buffer is no longer being read */         \
         const int s_ = (S_IDX);                                                                             \
         float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
-        if (s_ + 1 < n_st) {                                                                                \
-            stage_load<2 * (NMT)>(wl_g + (int64_t)(s_ + 1) * stage_floats, nxt, wave, lane);                \
-        } else if (next_w != nullptr) {                                                                     \
-            stage_load<32>(next_w, nxt, wave, lane);                                                        \
-        }                                                                                                   \
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);             \
-        stage_compute<NMT>(acc, B0, B1, wl, lane);                                                          \
+        stage_compute<NMT>(acc, B0, B1, wl, lane, [&]() {                                                   \
+            if (s_ + 1 < n_st) {                                                                            \
+                stage_load<2 * (NMT)>(wl_g + (int64_t)(s_ + 1) * stage_floats, nxt, wave, lane);            \
+            } else if (next_w != nullptr) {                                                                 \
+                stage_load<32>(next_w, nxt, wave, lane);                                                    \
+            }                                                                                               \
+        });                                                                                                 \
         ++gstage;                                                                                           \
     }
 
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         __syncthreads();
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) stage_compute<2>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane);
+        for (int kt = 0; kt < 8; ++kt) stage_compute<2>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane, []() {});
     }
 #undef PSN_STAGE
 
