@@ -240,10 +240,25 @@ class PSNetwork(nn.Module):
             cols = self._cols(self.n_freqs, device)
             if pe_x is None:
                 pe_x = self._pe(surf, self.n_freqs)
-            albedo = self.albedo_net(pe_x, cols)
+            # The jittered re-evaluation of the BRDF nets (renderer.py:211-231) rides in the same launches as the base
+            # evaluation: rows [0, Ns) = PE(x), rows [Ns, 2 Ns) = PE(x + noise).  Row-wise identical results, half the
+            # (latency-bound, Ns-row) GEMM launches in forward and backward.
+            pe_j = None
+            if self.xyz_jitter_std > 0:
+                nz = noise.get('xyz')
+                if nz is None:
+                    nz = torch.normal(0, torch.ones_like(surf) * self.xyz_jitter_std)
+                pe_j = self._pe(surf + nz, self.n_freqs)
+                pe_both = torch.cat([pe_x, pe_j], dim=0)
+                albedo_both = self.albedo_net(pe_both, cols)
+                rough_both = self.rough_net(pe_both, cols)
+                albedo, albedo_j = albedo_both[:ns], albedo_both[ns:]
+                rough, rough_j = rough_both[:ns], rough_both[ns:]
+            else:
+                albedo = self.albedo_net(pe_x, cols)
+                rough = self.rough_net(pe_x, cols)
             if albedo_new is not None:
                 albedo = torch.from_numpy(albedo_new).to(device)[None].expand_as(albedo)
-            rough = self.rough_net(pe_x, cols)
             if sg:
                 weights = F.relu(rough)
                 if basis_new is not None:  # material editing (eval.py:233-312)
@@ -284,16 +299,12 @@ class PSNetwork(nn.Module):
             else:
                 rough_values = scatter(rough_values, rough.expand(-1, 3))
             if self.xyz_jitter_std > 0:  # renderer.py:211-231
-                nz = noise.get('xyz')
-                if nz is None:
-                    nz = torch.normal(0, torch.ones_like(surf) * self.xyz_jitter_std)
-                pe_j = self._pe(surf + nz, self.n_freqs)
-                aj = scatter(torch.ones_like(points), self.albedo_net(pe_j, cols))
+                aj = scatter(torch.ones_like(points), albedo_j)
                 if sg:
-                    rj = scatter(torch.ones_like(weight_values), F.relu(self.rough_net(pe_j, cols)))
+                    rj = scatter(torch.ones_like(weight_values), F.relu(rough_j))
                     r_ori = weight_values
                 else:
-                    rj = scatter(torch.ones_like(points), self.rough_net(pe_j, cols).expand(-1, 3))
+                    rj = scatter(torch.ones_like(points), rough_j.expand(-1, 3))
                     r_ori = rough_values
                 jitter = {'albedo_values': albedo_values, 'albedo_jitter': aj,
                           'rough_values': r_ori, 'rough_jitter': rj}
