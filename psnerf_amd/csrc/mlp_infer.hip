@@ -63,10 +63,12 @@ constexpr int kWaves = 4;  // per workgroup; two workgroups share a CU (2 waves 
 // `request_next` issues the LDS-DMA of the next weight stage; it is placed BEHIND the first group's fragment reads so
 // that its ~50 issue slots (address arithmetic, M0 updates, 8 global_load_lds) fall into the LDS latency the wave has to
 // sit out anyway, instead of delaying the first MFMA of the stage.
-template <int NMT, typename RequestNext>
-__device__ __forceinline__ void stage_compute(floatx4 (&acc)[16], const floatx4& b0, const floatx4& b1,
+template <int NMT, int NACC, typename RequestNext>
+__device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx4& b0, const floatx4& b1,
                                               const float4* __restrict__ wl, int lane, RequestNext request_next) {
-    if constexpr (NMT == 16) {
+    if constexpr (NMT >= 8) {
+        constexpr int GE = NMT / 8;      // groups of 8 output tiles per 16-feature half of the k-tile
+        constexpr int NG = 2 * GE;
         float4 a[2][8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) a[0][m] = wl[m * 64 + lane];
@@ -74,13 +76,13 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[16], const floatx4&
         request_next();
         __builtin_amdgcn_sched_barrier(0);  // ... while the next stage is requested
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int e = g >> 1, m0 = (g & 1) * 8;
+        for (int g = 0; g < NG; ++g) {
+            const int e = g / GE, m0 = (g % GE) * 8;
             const floatx4& bs = e ? b1 : b0;
-            if (g < 3) {
-                const int e1 = (g + 1) >> 1, m1 = ((g + 1) & 1) * 8;
+            if (g < NG - 1) {
+                const int e1 = (g + 1) / GE, m1 = ((g + 1) % GE) * 8;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) a[(g + 1) & 1][m] = wl[(e1 * 16 + m1 + m) * 64 + lane];
+                for (int m = 0; m < 8; ++m) a[(g + 1) & 1][m] = wl[(e1 * NMT + m1 + m) * 64 + lane];
             }
             const float4(&ag)[8] = a[g & 1];
 #pragma unroll
@@ -92,7 +94,7 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[16], const floatx4&
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].w, bs[3], acc[m0 + m], 0, 0, 0);
             // pin the order: this group's 8 prefetch reads spread over its first 8 MFMAs, then the other 24 MFMAs
-            if (g < 3) {
+            if (g < NG - 1) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -151,32 +153,32 @@ __device__ __forceinline__ void st4(float* p, const floatx4& v) { *reinterpret_c
 // tile 0, tile mt is 16 floats further.  All operand loads of the layer are issued back to back (one exposed
 // latency per layer instead of one per tile) and all dump stores are issued at the end, where they complete under
 // the next layer's MFMAs.  p1 / p2 are non-null whenever CODE needs them (validated on the host).
-template <int CODE>
-__device__ __forceinline__ void chain_activation(floatx4 (&acc)[16], floatx4 (&act)[16], const float* __restrict__ p1,
+template <int CODE, int NMT>
+__device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&act)[NMT], const float* __restrict__ p1,
                                                  const float* __restrict__ p2, float* __restrict__ d1, float* __restrict__ d2) {
     constexpr bool kNeed1 = CODE == PSN_ACT_RELU_MASK || CODE == PSN_ACT_MUL_AUX || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD;
     constexpr bool kNeed2 = CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD;
     constexpr bool kSecond = CODE == PSN_ACT_SOFTPLUS100 || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_MUL_AUX;
-    floatx4 t1[16], t2[16];
+    floatx4 t1[NMT], t2[NMT];
     if constexpr (kNeed1) {
 #pragma unroll
-        for (int mt = 0; mt < 16; ++mt) t1[mt] = ld4(p1 + mt * 16);
+        for (int mt = 0; mt < NMT; ++mt) t1[mt] = ld4(p1 + mt * 16);
     }
     if constexpr (kNeed2) {
 #pragma unroll
-        for (int mt = 0; mt < 16; ++mt) t2[mt] = ld4(p2 + mt * 16);
+        for (int mt = 0; mt < NMT; ++mt) t2[mt] = ld4(p2 + mt * 16);
     }
     if constexpr (CODE == PSN_ACT_HEAD) {  // side output: dump z, the activations stay for the next layer
         if (d1 != nullptr) {
 #pragma unroll
-            for (int mt = 0; mt < 16; ++mt) st4(d1 + mt * 16, acc[mt]);
+            for (int mt = 0; mt < NMT; ++mt) st4(d1 + mt * 16, acc[mt]);
         }
         return;
     }
     // One 16-feature tile at a time (interleaving 16 softplus chains spills registers); each tile's results are
     // stored as soon as they exist, so operand and second-value registers die tile by tile.
 #pragma unroll
-    for (int mt = 0; mt < 16; ++mt) {
+    for (int mt = 0; mt < NMT; ++mt) {
         floatx4 o, o2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -199,10 +201,25 @@ __device__ __forceinline__ void chain_activation(floatx4 (&acc)[16], floatx4 (&a
     }
 }
 
+// Wait until this wave's LDS-DMA pieces have landed while leaving `stores` (0, NMT or 2 NMT) younger dump stores in flight.
+template <int NMT>
+__device__ __forceinline__ void wait_for_weights(int stores) {
+    if (stores == 2 * NMT) {
+        if constexpr (NMT == 16) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else if (stores == NMT) {
+        if constexpr (NMT == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 // CHAIN = false: lean inference / forward-with-dump path (NONE / RELU / SOFTPLUS100 activations, one dump per layer).
 // CHAIN = true : general per-layer activation programs with row-major operands and two dumps (training chains).
-template <bool CHAIN>
+template <bool CHAIN, int NMT>  // NMT = hidden width / 16: 16 (256-wide networks) or 8 (128-wide)
 __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
+    constexpr int W = 16 * NMT;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages + all biases
     float* bias_lds = smem + 2 * kStageFloats;
     const int tid = threadIdx.x;
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     {  // prefetch the first weight stage (layer 0 may be evaluated entirely through the init tables)
         const int l0 = (g.d.layers[0].n_kt_in + g.d.layers[0].n_kt_act > 0) ? 0 : 1;
         const PsnMlpLayer& L0 = g.d.layers[l0];
-        stage_load<32>(g.w + L0.w_off, smem, wave, lane);
+        stage_load<2 * NMT>(g.w + L0.w_off, smem, wave, lane);
     }
 
     // ---- input features -> registers (MFMA B-operand layout): 16-feature tile t, register r = feature 16t+4g+r
@@ -245,17 +262,17 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
 
     for (int i = tid; i < g.n_bias; i += kWaves * 64) bias_lds[i] = g.b[i];  // visible after the first stage barrier
 
-    floatx4 act[16];
-    floatx4 acc[16];
+    floatx4 act[NMT];
+    floatx4 acc[NMT];
 #pragma unroll
-    for (int mt = 0; mt < 16; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) act[mt][r] = 0.f;
     if constexpr (CHAIN) {
         if (g.act_init != nullptr) {
-            const float* ap = g.act_init + rowc * 256 + 4 * lg;
+            const float* ap = g.act_init + rowc * W + 4 * lg;
 #pragma unroll
-            for (int mt = 0; mt < 16; ++mt) {
+            for (int mt = 0; mt < NMT; ++mt) {
                 float4 t = *reinterpret_cast<const float4*>(ap + mt * 16);
                 act[mt][0] = t.x; act[mt][1] = t.y; act[mt][2] = t.z; act[mt][3] = t.w;
             }
@@ -276,19 +293,17 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
 #define PSN_STAGE(NMT, B0, B1, S_IDX)                                                                       \
     {                                                                                                       \
         /* this wave's LDS-DMA pieces have landed; activation dumps issued after them may stay in flight */ \
-        if (pending_stages > 0 && pending_dump == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      \
-        else if (pending_stages > 0 && pending_dump == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+        wait_for_weights<NMT>(pending_stages > 0 ? pending_dump : 0);                                       \
         if (pending_stages > 0) --pending_stages;                                                           \
         __syncthreads(); /* every wave's pieces landed; the other buffer is no longer being read */         \
         const int s_ = (S_IDX);                                                                             \
         float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);             \
-        stage_compute<NMT>(acc, B0, B1, wl, lane, [&]() {                                                   \
+        stage_compute<NMT, NMT>(acc, B0, B1, wl, lane, [&]() {                                                   \
             if (s_ + 1 < n_st) {                                                                            \
                 stage_load<2 * (NMT)>(wl_g + (int64_t)(s_ + 1) * stage_floats, nxt, wave, lane);            \
             } else if (next_w != nullptr) {                                                                 \
-                stage_load<32>(next_w, nxt, wave, lane);                                                    \
+                stage_load<2 * NMT>(next_w, nxt, wave, lane);                                                  \
             }                                                                                               \
         });                                                                                                 \
         ++gstage;                                                                                           \
@@ -299,14 +314,14 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     for (; li < n_hidden; ++li) {
         const PsnMlpLayer L = g.d.layers[li];
         const int n_st = L.n_kt_in + L.n_kt_act;
-        const int stage_floats = 8 * 1024;
+        const int stage_floats = NMT * 512;
         const float* wl_g = g.w + L.w_off;
         const float* next_w = li + 1 < n_layers ? g.w + g.d.layers[li + 1].w_off : nullptr;
         {  // bias -> accumulator init
             const float* bp = bias_lds + L.b_off;
             if (li == 0) __syncthreads();  // bias_lds written above
 #pragma unroll
-            for (int mt = 0; mt < 16; ++mt) {
+            for (int mt = 0; mt < NMT; ++mt) {
                 float4 bv = *reinterpret_cast<const float4*>(bp + mt * 16 + 4 * lg);
                 acc[mt][0] = bv.x;
                 acc[mt][1] = bv.y;
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             if (L.init_off >= 0) {  // per-row precomputed partial products of the input-feature block
                 if (init_a_row != nullptr) {
 #pragma unroll
-                    for (int mt = 0; mt < 16; ++mt) {
+                    for (int mt = 0; mt < NMT; ++mt) {
                         float4 u = *reinterpret_cast<const float4*>(init_a_row + L.init_off + mt * 16 + 4 * lg);
                         acc[mt][0] += u.x;
                         acc[mt][1] += u.y;
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                 }
                 if (init_b_row != nullptr) {
 #pragma unroll
-                    for (int mt = 0; mt < 16; ++mt) {
+                    for (int mt = 0; mt < NMT; ++mt) {
                         float4 u = *reinterpret_cast<const float4*>(init_b_row + L.init_off + mt * 16 + 4 * lg);
                         acc[mt][0] += u.x;
                         acc[mt][1] += u.y;
@@ -341,14 +356,14 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         // fetched then -- the two operand sets never compete for registers with the double-buffered weight fragments.
         if (L.n_kt_act > 0) {
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) PSN_STAGE(16, act[2 * kt], act[2 * kt + 1], kt)
+            for (int kt = 0; kt < NMT / 2; ++kt) PSN_STAGE(NMT, act[2 * kt], act[2 * kt + 1], kt)
         }
         if (L.n_kt_in > 0) {
             floatx4 xin[8];
             load_xin(xin);
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                if (kt < L.n_kt_in) PSN_STAGE(16, xin[2 * kt], xin[2 * kt + 1], L.n_kt_act + kt)
+                if (kt < L.n_kt_in) PSN_STAGE(NMT, xin[2 * kt], xin[2 * kt + 1], L.n_kt_act + kt)
             }
         }
         // activation: accumulators become the next layer's B operands.  Optional row-major operands (aux1, aux2)
@@ -359,38 +374,38 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             // the element loop gets if-converted and then runs for the ReLU networks too)
             if (L.act == PSN_ACT_RELU) {
 #pragma unroll
-                for (int mt = 0; mt < 16; ++mt)
+                for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) act[mt][r] = fmaxf(acc[mt][r], 0.0f);
             } else if (L.act == PSN_ACT_SOFTPLUS100) {
 #pragma unroll
-                for (int mt = 0; mt < 16; ++mt) {
+                for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) act[mt][r] = softplus100(acc[mt][r]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
-                for (int mt = 0; mt < 16; ++mt) act[mt] = acc[mt];
+                for (int mt = 0; mt < NMT; ++mt) act[mt] = acc[mt];
             }
             if (g.save[li] != nullptr) {
                 if (dump_row) {
-                    float* dst = g.save[li] + (row - g.save_row0) * 256 + 4 * lg;
+                    float* dst = g.save[li] + (row - g.save_row0) * W + 4 * lg;
 #pragma unroll
-                    for (int mt = 0; mt < 16; ++mt)
+                    for (int mt = 0; mt < NMT; ++mt)
                         *reinterpret_cast<float4*>(dst + mt * 16) = make_float4(act[mt][0], act[mt][1], act[mt][2], act[mt][3]);
                 }
-                pending_dump = wave_dumps ? 16 : 0;
+                pending_dump = wave_dumps ? NMT : 0;
                 pending_stages = wave_dumps ? 1 : 0;
             }
         } else
         {
-            const float* p1 = g.mask[li] != nullptr ? g.mask[li] + rowc * 256 + 4 * lg : nullptr;
-            const float* p2 = g.aux2[li] != nullptr ? g.aux2[li] + rowc * 256 + 4 * lg : nullptr;
-            float* d1 = (g.save[li] != nullptr && dump_row) ? g.save[li] + (row - g.save_row0) * 256 + 4 * lg : nullptr;
-            float* d2 = (g.save2[li] != nullptr && dump_row) ? g.save2[li] + (row - g.save_row0) * 256 + 4 * lg : nullptr;
+            const float* p1 = g.mask[li] != nullptr ? g.mask[li] + rowc * W + 4 * lg : nullptr;
+            const float* p2 = g.aux2[li] != nullptr ? g.aux2[li] + rowc * W + 4 * lg : nullptr;
+            float* d1 = (g.save[li] != nullptr && dump_row) ? g.save[li] + (row - g.save_row0) * W + 4 * lg : nullptr;
+            float* d2 = (g.save2[li] != nullptr && dump_row) ? g.save2[li] + (row - g.save_row0) * W + 4 * lg : nullptr;
             // one straight-line body per code (operand loads batched up front, results stored tile by tile)
-#define PSN_CASE(C) case C: chain_activation<C>(acc, act, p1, p2, d1, d2); break;
+#define PSN_CASE(C) case C: chain_activation<C, NMT>(acc, act, p1, p2, d1, d2); break;
             switch (L.act) {
                 PSN_CASE(PSN_ACT_RELU)
                 PSN_CASE(PSN_ACT_SOFTPLUS100)
@@ -399,10 +414,10 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                 PSN_CASE(PSN_ACT_MUL2)
                 PSN_CASE(PSN_ACT_SOFTPLUS_BWD)
                 PSN_CASE(PSN_ACT_HEAD)
-                default: chain_activation<PSN_ACT_NONE>(acc, act, p1, p2, d1, d2); break;
+                default: chain_activation<PSN_ACT_NONE, NMT>(acc, act, p1, p2, d1, d2); break;
             }
 #undef PSN_CASE
-            pending_dump = wave_dumps ? (g.save[li] != nullptr ? 16 : 0) + (g.save2[li] != nullptr ? 16 : 0) : 0;
+            pending_dump = wave_dumps ? (g.save[li] != nullptr ? NMT : 0) + (g.save2[li] != nullptr ? NMT : 0) : 0;
             pending_stages = pending_dump > 0 ? 1 : 0;
         }
     }
@@ -417,13 +432,11 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             acc[mt][2] = bv.z;
             acc[mt][3] = bv.w;
         }
-        if (pending_stages > 0 && pending_dump == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else if (pending_stages > 0 && pending_dump == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_for_weights<NMT>(pending_stages > 0 ? pending_dump : 0);
         __syncthreads();
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) stage_compute<2>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane, []() {});
+        for (int kt = 0; kt < NMT / 2; ++kt) stage_compute<2, NMT>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane, []() {});
     }
 #undef PSN_STAGE
 
@@ -495,23 +508,27 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         uses_init = uses_init || d.layers[l].init_off >= 0;
     }
     PSN_CHECK_ARG(!uses_in || (tab_a && d.in_kt_a >= 1 && (d.in_kt_b == 0 || tab_b)), "mlp_infer: input table missing");
-    PSN_CHECK_ARG(!uses_init || (init_a && d.init_stride >= 256 && d.init_stride % 4 == 0), "mlp_infer: init table missing");
+    PSN_CHECK_ARG(!uses_init || (init_a && d.init_stride >= 128 && d.init_stride % 4 == 0), "mlp_infer: init table missing");
     PSN_CHECK_ARG((((uintptr_t)init_a | (uintptr_t)init_b) & 15) == 0, "mlp_infer: init tables must be 16-byte aligned");
     PSN_CHECK_ARG(d.n_out >= 0 && d.n_out <= 32, "mlp_infer: n_out=%d", d.n_out);
     PSN_CHECK_ARG(a_div >= 1 && a_mod >= 1 && (d.in_kt_b == 0 || (b_div >= 1 && b_mod >= 1)), "mlp_infer: bad index map");
     PSN_CHECK_ARG((((uintptr_t)tab_a | (uintptr_t)tab_b | (uintptr_t)packed_w | (uintptr_t)packed_b) & 15) == 0,
                   "mlp_infer: buffers must be 16-byte aligned");
+    // hidden width: 256 (8 output tiles of 32) or 128 (4), the same for every hidden layer of the network
+    const int hid = (d.n_out > 0 && d.n_layers == 1) ? 8 : d.layers[0].n_mt;
+    PSN_CHECK_ARG(hid == 8 || hid == 4, "mlp_infer: hidden layers must be 256 or 128 wide (n_mt = 8 or 4), got n_mt=%d", hid);
+    const int width = hid * 32;
     for (int l = 0; l < d.n_layers; ++l) {
         const PsnMlpLayer& L = d.layers[l];
         const bool last = d.n_out > 0 && l == d.n_layers - 1;
-        PSN_CHECK_ARG(L.n_mt == (last ? 1 : 8), "mlp_infer: layer %d n_mt=%d (hidden layers are 256 wide, final <= 32)", l, L.n_mt);
+        PSN_CHECK_ARG(L.n_mt == (last ? 1 : hid), "mlp_infer: layer %d n_mt=%d (hidden layers share one width, final <= 32)", l, L.n_mt);
         PSN_CHECK_ARG(L.n_kt_in >= 0 && L.n_kt_in <= d.in_kt_a + d.in_kt_b, "mlp_infer: layer %d n_kt_in=%d", l, L.n_kt_in);
-        PSN_CHECK_ARG(!last || (L.n_kt_in == 0 && L.n_kt_act == 8), "mlp_infer: the final layer reads the 256 activations only");
-        PSN_CHECK_ARG(L.b_off == (int64_t)l * 256, "mlp_infer: biases must be packed back to back (256 floats per hidden layer)");
-        PSN_CHECK_ARG(L.n_kt_act == 0 || L.n_kt_act == 8, "mlp_infer: layer %d n_kt_act=%d", l, L.n_kt_act);
+        PSN_CHECK_ARG(!last || (L.n_kt_in == 0 && L.n_kt_act == hid), "mlp_infer: the final layer reads the hidden activations only");
+        PSN_CHECK_ARG(L.b_off == (int64_t)l * width, "mlp_infer: biases must be packed back to back (one hidden width per layer)");
+        PSN_CHECK_ARG(L.n_kt_act == 0 || L.n_kt_act == hid, "mlp_infer: layer %d n_kt_act=%d", l, L.n_kt_act);
         PSN_CHECK_ARG(l > 0 || L.n_kt_act == 0 || act_init != nullptr, "mlp_infer: layer 0 cannot read activations without act_init");
         PSN_CHECK_ARG(L.n_kt_in + L.n_kt_act >= 1 || (l == 0 && L.init_off >= 0 && d.n_layers > 1), "mlp_infer: layer %d has no input", l);
-        PSN_CHECK_ARG(L.init_off < 0 || (!last && L.init_off + 256 <= d.init_stride && L.init_off % 4 == 0), "mlp_infer: layer %d bad init_off", l);
+        PSN_CHECK_ARG(L.init_off < 0 || (!last && L.init_off + width <= d.init_stride && L.init_off % 4 == 0), "mlp_infer: layer %d bad init_off", l);
         PSN_CHECK_ARG((L.w_off % 4) == 0 && (L.b_off % 4) == 0, "mlp_infer: layer %d offsets must be multiples of 4 floats", l);
     }
     if (n_rows <= 0) return PSN_OK;
@@ -519,7 +536,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     a.d = d; a.w = packed_w; a.b = packed_b; a.ta = tab_a; a.a_div = a_div; a.a_mod = a_mod;
     a.tb = tab_b; a.b_div = b_div > 0 ? b_div : 1; a.b_mod = b_mod > 0 ? b_mod : 1; a.n_rows = n_rows; a.out = out;
     a.init_a = init_a; a.init_b = init_b;
-    a.n_bias = d.n_out > 0 ? (d.n_layers - 1) * 256 + 32 : d.n_layers * 256;
+    a.n_bias = d.n_out > 0 ? (d.n_layers - 1) * width + 32 : d.n_layers * width;
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) a.save[l] = (save_ptrs != nullptr && l < (d.n_out > 0 ? d.n_layers - 1 : d.n_layers)) ? save_ptrs[l] : nullptr;
     a.save_row0 = save_row0;
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) {
@@ -552,8 +569,14 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         chain = chain || d.layers[l].act > PSN_ACT_SOFTPLUS100 || a.save2[l] != nullptr || a.mask[l] != nullptr || a.aux2[l] != nullptr;
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
     const dim3 grid((unsigned)blocks), block(kWaves * 64);
-    if (chain) hipLaunchKernelGGL(mlp_infer_kernel<true>, grid, block, lds_bytes, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(mlp_infer_kernel<false>, grid, block, lds_bytes, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (hid == 8) {
+        if (chain) hipLaunchKernelGGL((mlp_infer_kernel<true, 16>), grid, block, lds_bytes, st, a);
+        else hipLaunchKernelGGL((mlp_infer_kernel<false, 16>), grid, block, lds_bytes, st, a);
+    } else {
+        if (chain) hipLaunchKernelGGL((mlp_infer_kernel<true, 8>), grid, block, lds_bytes, st, a);
+        else hipLaunchKernelGGL((mlp_infer_kernel<false, 8>), grid, block, lds_bytes, st, a);
+    }
     PSN_CHECK_LAUNCH("mlp_infer");
     return PSN_OK;
 }

@@ -55,11 +55,13 @@ def _pad_cols(w, n):
     return torch.nn.functional.pad(w, (0, n - w.shape[1])) if w.shape[1] < n else w
 
 
-def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True):
+def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True, width=256):
     """layers: list of dicts {w_in | init_a/init_b, w_act, bias, act}.
     w_in: [o, <=in_kt*32] consumed as MFMA k-tiles; init_a [o, in_kt_a*32] / init_b [o, in_kt_b*32]: the same
-    block evaluated through precomputed tables instead.  Hidden layers have o <= 256 (zero padded), the final
-    layer o = n_out <= 32."""
+    block evaluated through precomputed tables instead.  Hidden layers have o <= width (zero padded; width = 256 or
+    128, one value per network), the final layer o = n_out <= 32."""
+    assert width in (128, 256)
+    hid = width // 32
     in_cols = (in_kt_a + in_kt_b) * 32
     desc = hip.PsnMlpDesc()
     desc.n_layers = len(layers)
@@ -69,7 +71,7 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     init_wa, init_wb, init_bias = [], [], []
     for li, L in enumerate(layers):
         last = has_final and li == len(layers) - 1
-        n_mt = 1 if last else 8
+        n_mt = 1 if last else hid
         rows = n_mt * 32
         parts = []
         n_kt_in = n_kt_act = 0
@@ -78,15 +80,15 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
         bias = torch.nn.functional.pad(L['bias'].float(), (0, rows - L['bias'].shape[0]))
         if L.get('init_a') is not None:
             assert not last
-            lay.init_off = 256 * len(init_wa)
-            init_wa.append(torch.nn.functional.pad(_pad_cols(L['init_a'], in_kt_a * 32), (0, 0, 0, 256 - L['init_a'].shape[0])))
+            lay.init_off = width * len(init_wa)
+            init_wa.append(torch.nn.functional.pad(_pad_cols(L['init_a'], in_kt_a * 32), (0, 0, 0, width - L['init_a'].shape[0])))
             if L.get('init_b') is not None:
-                init_wb.append(torch.nn.functional.pad(_pad_cols(L['init_b'], in_kt_b * 32), (0, 0, 0, 256 - L['init_b'].shape[0])))
+                init_wb.append(torch.nn.functional.pad(_pad_cols(L['init_b'], in_kt_b * 32), (0, 0, 0, width - L['init_b'].shape[0])))
             init_bias.append(bias)  # folded into the init table
             bias = torch.zeros_like(bias)
         if L.get('w_act') is not None:  # K order of the packed layer: activation tiles first, input-feature tiles last
-            parts.append(_pad_cols(L['w_act'], 256))
-            n_kt_act = 8
+            parts.append(_pad_cols(L['w_act'], width))
+            n_kt_act = hid
         if L.get('w_in') is not None:
             parts.append(_pad_cols(L['w_in'], in_cols))
             n_kt_in = in_kt_a + in_kt_b
@@ -109,7 +111,7 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
             hip.mlp_pack_layer(W, n_mt, k_tiles, w_buf[off:off + W.numel()])
         off += W.numel()
         b_off += n_mt * 32
-    desc.init_stride = 256 * len(init_wa)
+    desc.init_stride = width * len(init_wa)
     if init_wa:
         return PackedMLP(desc, w_buf, b_buf, torch.cat(init_wa).contiguous().float(),
                          torch.cat(init_wb).contiguous().float() if init_wb else None,
@@ -117,7 +119,7 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     return PackedMLP(desc, w_buf, b_buf)
 
 
-def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, precompute=True):
+def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, precompute=True, width=256):
     """stage2 Network / Normal_Network (stage2/model/renderer.py:17-49) of width 256: ReLU stack, the
     input is concatenated AFTER layer ``skip_at``.  Input row = [table A (din_a real cols, padded to
     a multiple of 32) | table B (din_b)].  precompute=True evaluates the input block of layer 0 and of the
@@ -144,11 +146,11 @@ def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, 
         if li == 0:
             layers.append(dict(w_act=None, bias=b, act=act, **in_block(W)))
         elif li - 1 == skip_at:  # input of this layer is cat[y(256), x]
-            layers.append(dict(w_act=W[:, :256], bias=b, act=act, **in_block(W[:, 256:])))
+            layers.append(dict(w_act=W[:, :width], bias=b, act=act, **in_block(W[:, width:])))
         else:
             layers.append(dict(w_act=W, bias=b, act=act))
-    assert all(L['bias'].shape[0] == 256 for L in layers[:-1]), 'fused path needs 256-wide hidden layers'
-    return pack_layers(layers, ka, kb, weights[-1].shape[0], out_act, weights[0].device)
+    assert all(L['bias'].shape[0] == width for L in layers[:-1]), 'fused path: every hidden layer must have the given width'
+    return pack_layers(layers, ka, kb, weights[-1].shape[0], out_act, weights[0].device, width=width)
 
 
 def pack_geo_occupancy(weights, biases, skips, d_pe):
@@ -176,7 +178,7 @@ def pack_geo_occupancy(weights, biases, skips, d_pe):
     return pack_layers(layers, ka, 0, 1, hip.OUT_OCC, weights[0].device)
 
 
-def pack_relu_bwd(weights, skip_at):
+def pack_relu_bwd(weights, skip_at, width=256):
     """Backward (d x) chain of a 256-wide ReLU MLP for the fused kernel: chain layer j computes
     d h_{l-1} = W_l[:, :256]^T d z_l for l = n-1-j (transposed weight packs, no bias), followed by the ReLU mask of
     the forward activation h_{l-1} (PSN_ACT_RELU_MASK, masks supplied at call time) and a dump of d z_{l-1}.
@@ -184,13 +186,13 @@ def pack_relu_bwd(weights, skip_at):
     Returns a PackedMLP whose call needs init_a_direct, mask=[h_{n-2}, ..., h_0], save=[dz_{n-2}, ..., dz_0]."""
     n = len(weights)
     dev = weights[0].device
-    zeros = torch.zeros(256, device=dev)
-    layers = [dict(init_a=torch.zeros(256, 32, device=dev), init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
+    zeros = torch.zeros(width, device=dev)
+    layers = [dict(init_a=torch.zeros(width, 32, device=dev), init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
     for l in range(n - 2, 0, -1):  # forward layers n-2 .. 1 -> their transposed [in(256), out(256)] blocks
-        layers.append(dict(w_act=weights[l].detach()[:, :256].t().contiguous(), bias=zeros, act=hip.ACT_RELU_MASK))
-    packed = pack_layers(layers, 1, 0, 0, hip.OUT_NONE, dev, has_final=False)
+        layers.append(dict(w_act=weights[l].detach()[:, :width].t().contiguous(), bias=zeros, act=hip.ACT_RELU_MASK))
+    packed = pack_layers(layers, 1, 0, 0, hip.OUT_NONE, dev, has_final=False, width=width)
     packed.init_wa = packed.init_wb = packed.init_bias = None  # the init table is always supplied by the caller
-    packed.desc.init_stride = 256
+    packed.desc.init_stride = width
     return packed
 
 

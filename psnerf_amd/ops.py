@@ -727,3 +727,68 @@ class AppNetFused(torch.autograd.Function):
         for l in range(1, n):
             grads += [res[l + 1][0], res[l + 1][1]]
         return (None, d_normal, d_feat, None, None) + tuple(grads)
+
+
+# --------------------------------------------------------------------------- ReLU MLP on encoded points, fused
+class FusedReluNet(torch.autograd.Function):
+    """stage-2 Network / Normal_Network (stage2/model/renderer.py:17-49) of width 128 or 256 on a table of encoded
+    points pe [Q, 64] (din real columns first): ONE register-resident forward launch that leaves the hidden
+    activations behind, ONE backward chain launch (ReLU masks over transposed packs) and one grouped weight-gradient
+    launch -- instead of one GEMM launch per layer and direction on Ns rows, which are all latency-bound.
+    The points are data (no gradient with respect to pe)."""
+
+    @staticmethod
+    def forward(ctx, pe, din, skip_at, final_sigmoid, width, *params):
+        Ws, bs = params[0::2], params[1::2]
+        n = len(Ws)
+        Q = pe.shape[0]
+        packed = fused.pack_relu_mlp(list(Ws), list(bs), din, 0, skip_at,
+                                     out_act=hip.OUT_SIGMOID if final_sigmoid else hip.OUT_NONE, precompute=False, width=width)
+        need = any(ctx.needs_input_grad[5:])
+        H = [torch.empty(Q, width, device=pe.device) for _ in range(n - 1)] if need else None
+        out = packed(pe, Q, save=H)
+        if need:
+            ctx.save_for_backward(pe, out, *H, *Ws)
+            ctx.meta = (n, din, skip_at, final_sigmoid, width)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, din, skip_at, final_sigmoid, width = ctx.meta
+        sv = ctx.saved_tensors
+        pe, out = sv[0], sv[1]
+        H = sv[2:2 + n - 1]
+        Ws = sv[2 + n - 1:]
+        Q, dev = pe.shape[0], pe.device
+        g = g.contiguous()
+        if final_sigmoid:
+            g = g * out * (1.0 - out)
+        dh = hip.gemm(g, Ws[n - 1].contiguous())  # [Q, width]
+        chain = fused.pack_relu_bwd(list(Ws), skip_at, width=width)
+        DZ = [torch.empty(Q, width, device=dev) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
+        chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh, mask=[H[n - 2 - j] for j in range(n - 1)], save=DZ)
+        x_in = pe[:, :din]
+        items = [dict(A=g, B=H[n - 2], colsum=True)]
+        where = [(n - 1, 'w')]
+        for l in range(n - 2, -1, -1):
+            dz = DZ[n - 2 - l]
+            if l == 0:
+                items.append(dict(A=dz, B=x_in, colsum=True))
+                where.append((0, 'w'))
+            else:
+                items.append(dict(A=dz, B=H[l - 1], colsum=True))
+                where.append((l, 'w'))
+                if l - 1 == skip_at:
+                    items.append(dict(A=dz, B=x_in))
+                    where.append((l, 'x'))
+        res = hip.gemm_tn_grouped(items)
+        dW, dWx, db = [None] * n, [None] * n, [None] * n
+        for (l, kind), (C, cs) in zip(where, res):
+            if kind == 'w':
+                dW[l], db[l] = C, cs
+            else:
+                dWx[l] = C
+        grads = []
+        for l in range(n):
+            grads += [dW[l] if dWx[l] is None else torch.cat([dW[l], dWx[l]], dim=1), db[l]]
+        return (None, None, None, None, None) + tuple(grads)
