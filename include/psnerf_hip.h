@@ -171,9 +171,12 @@ typedef struct {
     PsnMlpLayer layers[PSN_MLP_MAX_LAYERS];
 } PsnMlpDesc;
 
-/* Pack a dense, zero-padded row-major weight W[n_mt*32, k_tiles*32] (ldw floats per
- * row) into `dst` (n_mt*32 * k_tiles*32 floats) in stage order. */
-int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_tiles, float* dst, void* stream);
+/* Pack W[rows, cols] (row-major, ldw floats per row; with transpose != 0 the memory holds W^T, i.e. element (r, c) sits
+ * at W[c * ldw + r]), zero-extended to [n_mt*32, k_tiles*32], into `dst` (n_mt*32 * k_tiles*32 floats) in stage order.
+ * A layer whose K dimension consists of several blocks (activations | input features) is packed block by block into
+ * consecutive k-tile ranges of its slot. */
+int psn_mlp_pack_layer(const float* W, int64_t ldw, int rows, int cols, int transpose, int n_mt, int k_tiles, float* dst,
+                       void* stream);
 
 /* Row q of the virtual input matrix is [ A[(q / a_div) % a_mod, :] | B[(q / b_div) % b_mod, :] ];
  * tables are row-major with strides in_kt_a*32 / in_kt_b*32 floats, 16-byte aligned.

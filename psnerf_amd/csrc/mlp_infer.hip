@@ -459,10 +459,11 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     }
 }
 
-// Dense zero-padded W[n_mt*32][k_tiles*32] -> stage order [kt32][e(2)][mt16][lane][4]:
+// W[rows][cols] (or its transpose in memory), zero-extended to [n_mt*32][k_tiles*32] -> stage order
+// [kt32][e(2)][mt16][lane][4]:
 //   lane (i = lane & 15, g = lane >> 4), component c  <-  W[16*mt16 + i][32*kt32 + 16*e + 4*g + c]
-__global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__ W, int64_t ldw, int n_mt, int k_tiles,
-                                                       float* __restrict__ dst) {
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__ W, int64_t ldw, int rows, int cols,
+                                                       int transpose, int n_mt, int k_tiles, float* __restrict__ dst) {
     const int nmt16 = 2 * n_mt;
     const int64_t total = (int64_t)n_mt * k_tiles * 1024;  // floats
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -474,20 +475,26 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__
         int bi = (int)(blk % per_stage);
         int half = bi / nmt16, mt = bi % nmt16;
         int i = lane & 15, gq = lane >> 4;
-        dst[e] = W[(int64_t)(16 * mt + i) * ldw + 32 * kt + 16 * half + 4 * gq + c];
+        const int r = 16 * mt + i, k = 32 * kt + 16 * half + 4 * gq + c;
+        float v = 0.0f;
+        if (r < rows && k < cols) v = transpose ? W[(int64_t)k * ldw + r] : W[(int64_t)r * ldw + k];
+        dst[e] = v;
     }
 }
 
 }  // namespace psn
 
-extern "C" int psn_mlp_pack_layer(const float* W, int64_t ldw, int n_mt, int k_tiles, float* dst, void* stream) {
+extern "C" int psn_mlp_pack_layer(const float* W, int64_t ldw, int rows, int cols, int transpose, int n_mt, int k_tiles,
+                                  float* dst, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(W && dst, "mlp_pack_layer: null pointer");
     PSN_CHECK_ARG(n_mt >= 1 && n_mt <= 8 && k_tiles >= 1 && k_tiles <= 12, "mlp_pack_layer: n_mt=%d k_tiles=%d", n_mt, k_tiles);
-    PSN_CHECK_ARG(ldw >= (int64_t)k_tiles * 32, "mlp_pack_layer: ldw too small");
+    PSN_CHECK_ARG(rows >= 1 && rows <= n_mt * 32 && cols >= 1 && cols <= k_tiles * 32, "mlp_pack_layer: %d x %d does not fit %d x %d",
+                  rows, cols, n_mt * 32, k_tiles * 32);
+    PSN_CHECK_ARG(ldw >= (transpose ? rows : cols), "mlp_pack_layer: ldw too small");
     int64_t total = (int64_t)n_mt * k_tiles * 1024;
     int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, ldw, n_mt, k_tiles, dst);
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, ldw, rows, cols, transpose, n_mt, k_tiles, dst);
     PSN_CHECK_LAUNCH("mlp_pack_layer");
     return PSN_OK;
 }

@@ -55,29 +55,46 @@ def _pad_cols(w, n):
     return torch.nn.functional.pad(w, (0, n - w.shape[1])) if w.shape[1] < n else w
 
 
+class Transposed(object):
+    """Marker for pack_layers: use the transpose of ``w`` (backward chains) without materialising it."""
+
+    def __init__(self, w):
+        self.w = w.detach()
+
+
+def _src(w):
+    """(matrix, transpose flag, logical rows, logical cols) of a weight block handed to pack_layers."""
+    if isinstance(w, Transposed):
+        m = w.w
+        return m, True, m.shape[1], m.shape[0]
+    m = w.detach()
+    return m, False, m.shape[0], m.shape[1]
+
+
 def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True, width=256):
     """layers: list of dicts {w_in | init_a/init_b, w_act, bias, act}.
     w_in: [o, <=in_kt*32] consumed as MFMA k-tiles; init_a [o, in_kt_a*32] / init_b [o, in_kt_b*32]: the same
     block evaluated through precomputed tables instead.  Hidden layers have o <= width (zero padded; width = 256 or
-    128, one value per network), the final layer o = n_out <= 32."""
+    128, one value per network), the final layer o = n_out <= 32.  w_act / w_in may be any row-major view with unit
+    column stride (column slices of a parameter) or Transposed(w): the pack kernel reads them in place and zero-fills
+    the padding, so no padded / concatenated / transposed copies are made on the way."""
     assert width in (128, 256)
     hid = width // 32
-    in_cols = (in_kt_a + in_kt_b) * 32
+    kin = in_kt_a + in_kt_b
     desc = hip.PsnMlpDesc()
     desc.n_layers = len(layers)
     desc.n_out, desc.out_act, desc.in_kt_a, desc.in_kt_b = n_out, out_act, in_kt_a, in_kt_b
     assert len(layers) <= hip.MAX_LAYERS
-    w_sizes, dense, biases = [], [], []
+    plan, biases = [], []
     init_wa, init_wb, init_bias = [], [], []
+    off = b_off = 0
     for li, L in enumerate(layers):
         last = has_final and li == len(layers) - 1
         n_mt = 1 if last else hid
         rows = n_mt * 32
-        parts = []
-        n_kt_in = n_kt_act = 0
         lay = desc.layers[li]
         lay.init_off = -1
-        bias = torch.nn.functional.pad(L['bias'].float(), (0, rows - L['bias'].shape[0]))
+        bias = torch.nn.functional.pad(L['bias'].detach().float(), (0, rows - L['bias'].shape[0]))
         if L.get('init_a') is not None:
             assert not last
             lay.init_off = width * len(init_wa)
@@ -86,31 +103,26 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
                 init_wb.append(torch.nn.functional.pad(_pad_cols(L['init_b'], in_kt_b * 32), (0, 0, 0, width - L['init_b'].shape[0])))
             init_bias.append(bias)  # folded into the init table
             bias = torch.zeros_like(bias)
+        n_kt_in = n_kt_act = 0
+        tile = n_mt * 1024  # floats per 32-feature k-tile of this layer
+        lay.w_off, lay.b_off = off, b_off
         if L.get('w_act') is not None:  # K order of the packed layer: activation tiles first, input-feature tiles last
-            parts.append(_pad_cols(L['w_act'], width))
+            plan.append((L['w_act'], n_mt, hid, off))
             n_kt_act = hid
+            off += hid * tile
         if L.get('w_in') is not None:
-            parts.append(_pad_cols(L['w_in'], in_cols))
-            n_kt_in = in_kt_a + in_kt_b
-        if parts:
-            W = torch.cat(parts, dim=1)
-            W = torch.nn.functional.pad(W, (0, 0, 0, rows - W.shape[0])).contiguous().float()
-        else:
-            W = torch.zeros(0, device=device)  # layer fully evaluated through the init tables: no weight stages
-        dense.append((W, n_mt, n_kt_in + n_kt_act))
+            plan.append((L['w_in'], n_mt, kin, off))
+            n_kt_in = kin
+            off += kin * tile
         biases.append(bias)
         lay.n_kt_in, lay.n_kt_act, lay.n_mt, lay.act = n_kt_in, n_kt_act, n_mt, L['act']
-        w_sizes.append(W.numel())
-    w_buf = torch.empty(sum(w_sizes), device=device, dtype=torch.float32)
+        b_off += rows
+    w_buf = torch.empty(max(off, 4), device=device, dtype=torch.float32)
     b_buf = torch.cat(biases).contiguous()
-    off = b_off = 0
-    for li, (W, n_mt, k_tiles) in enumerate(dense):
-        desc.layers[li].w_off = off
-        desc.layers[li].b_off = b_off
-        if k_tiles > 0:
-            hip.mlp_pack_layer(W, n_mt, k_tiles, w_buf[off:off + W.numel()])
-        off += W.numel()
-        b_off += n_mt * 32
+    for w, n_mt, k_tiles, o in plan:
+        m, tr, r, c = _src(w)
+        assert r <= n_mt * 32 and c <= k_tiles * 32, 'pack_layers: block %dx%d does not fit %dx%d' % (r, c, n_mt * 32, k_tiles * 32)
+        hip.mlp_pack_layer(m if m.dtype == torch.float32 else m.float(), n_mt, k_tiles, w_buf[o:o + n_mt * k_tiles * 1024], transpose=tr)
     desc.init_stride = width * len(init_wa)
     if init_wa:
         return PackedMLP(desc, w_buf, b_buf, torch.cat(init_wa).contiguous().float(),
@@ -127,10 +139,10 @@ def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, 
     ka = (din_a + 31) // 32
     kb = (din_b + 31) // 32 if din_b > 0 else 0
 
-    def split_in(w):  # [o, din_a + din_b] -> padded [o, (ka+kb)*32]
-        wa = _pad_cols(w[:, :din_a], ka * 32)
+    def split_in(w):  # [o, din_a + din_b] -> [o, (ka+kb)*32] (single table: the slice itself, the packer zero-fills)
         if kb == 0:
-            return wa
+            return w[:, :din_a]
+        wa = _pad_cols(w[:, :din_a], ka * 32)
         return torch.cat([wa, _pad_cols(w[:, din_a:din_a + din_b], kb * 32)], dim=1)
 
     def in_block(W):
@@ -189,7 +201,7 @@ def pack_relu_bwd(weights, skip_at, width=256):
     zeros = torch.zeros(width, device=dev)
     layers = [dict(init_a=torch.zeros(width, 32, device=dev), init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
     for l in range(n - 2, 0, -1):  # forward layers n-2 .. 1 -> their transposed [in(256), out(256)] blocks
-        layers.append(dict(w_act=weights[l].detach()[:, :width].t().contiguous(), bias=zeros, act=hip.ACT_RELU_MASK))
+        layers.append(dict(w_act=Transposed(weights[l][:, :width]), bias=zeros, act=hip.ACT_RELU_MASK))
     packed = pack_layers(layers, 1, 0, 0, hip.OUT_NONE, dev, has_final=False, width=width)
     packed.init_wa = packed.init_wb = packed.init_bias = None  # the init table is always supplied by the caller
     packed.desc.init_stride = width
@@ -198,7 +210,7 @@ def pack_relu_bwd(weights, skip_at, width=256):
 
 # --------------------------------------------------------------------------- stage-1 geometry-field chains
 def _t(w):
-    return w.detach().t().contiguous()
+    return Transposed(w)
 
 
 def pack_geo_chains(weights, biases, skips, d_pe):

@@ -63,7 +63,7 @@ SIGNATURES = {
                        i32, c_f, c_f, c_f]),
     'psn_gemm_tn_grouped': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
     'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
-    'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, c_f, c_f]),
+    'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, i32, i32, i32, c_f, c_f]),
     'psn_sg_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f]),
     'psn_sg_shade_bwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f, c_f,
                                c_f, c_f, c_f, c_f, c_f, c_f]),
@@ -298,12 +298,13 @@ def colsum(X, out=None, accumulate=False):
 
 
 # --------------------------------------------------------------------------- fused MLP inference
-def mlp_pack_layer(W_dense, n_mt, k_tiles, dst):
-    """W_dense [n_mt*32, k_tiles*32] zero padded, row-major -> dst (flat float view) in stage order."""
-    assert W_dense.shape == (n_mt * 32, k_tiles * 32) and W_dense.is_contiguous()
-    assert dst.numel() == n_mt * k_tiles * 1024
-    _check(_lib.psn_mlp_pack_layer(_ptr(W_dense, 'W'), W_dense.stride(0), n_mt, k_tiles, dst.data_ptr(), _stream()),
-           'mlp_pack_layer')
+def mlp_pack_layer(W, n_mt, k_tiles, dst, transpose=False):
+    """W: 2-D fp32 device matrix (row-major view, unit column stride); with transpose=True its transpose is packed.
+    Zero-extended to [n_mt*32, k_tiles*32] and written to dst (flat float view) in stage order."""
+    assert W.dim() == 2 and W.stride(1) == 1 and W.is_cuda and W.dtype == torch.float32
+    rows, cols = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
+    _check(_lib.psn_mlp_pack_layer(W.data_ptr(), W.stride(0), rows, cols, int(transpose), n_mt, k_tiles, dst.data_ptr(),
+                                   _stream()), 'mlp_pack_layer')
 
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
