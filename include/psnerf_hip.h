@@ -129,7 +129,7 @@ int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int ac
  * in ray_marching / secant / light_visibility (stage1/model/rendering.py:
  * 456-462, 537-540, 394-399).
  *
- * Hidden width is fixed at 256 (8 tiles of 32).  A network is described by
+ * Hidden width is 256 or 128 (8 or 4 tiles of 32; one width per network).  A network is described by
  * PsnMlpDesc; weights are pre-packed into MFMA fragment order by
  * psn_mlp_pack_layer (one call per layer, into one contiguous buffer).
  * ---------------------------------------------------------------------- */
@@ -152,8 +152,8 @@ enum { PSN_OUT_NONE = 0, PSN_OUT_SIGMOID = 1, PSN_OUT_OCC = 2 /* sigmoid(-10 x),
 
 typedef struct {
     int n_kt_in;   /* 32-wide K tiles taken from the input-feature registers (0..4) */
-    int n_kt_act;  /* 32-wide K tiles taken from the previous layer's activations (0 or 8) */
-    int n_mt;      /* 32-wide output tiles: 8 (hidden) or 1 (final) */
+    int n_kt_act;  /* 32-wide K tiles taken from the previous layer's activations (0 or the hidden n_mt) */
+    int n_mt;      /* 32-wide output tiles: 8 or 4 (hidden: 256- / 128-wide network) or 1 (final) */
     int act;       /* PSN_ACT_* applied to this layer's output */
     int64_t w_off; /* float offset of this layer's packed weights */
     int64_t b_off; /* float offset of this layer's bias (n_mt*32 floats, zero padded) */
@@ -167,7 +167,7 @@ typedef struct {
     int out_act;  /* PSN_OUT_* */
     int in_kt_a;  /* K tiles (of 32 floats) per row of feature table A (1..4) */
     int in_kt_b;  /* K tiles per row of table B (0 = unused); in_kt_a + in_kt_b <= 4 */
-    int init_stride; /* floats per row of the init tables (multiple of 256), 0 if no layer uses init_off */
+    int init_stride; /* floats per row of the init tables (multiple of the hidden width), 0 if no layer uses init_off */
     PsnMlpLayer layers[PSN_MLP_MAX_LAYERS];
 } PsnMlpDesc;
 

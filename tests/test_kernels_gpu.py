@@ -249,6 +249,45 @@ def test_fused_visibility_mlp(cuda):
     assert_close(out2.cpu(), ref, 1e-4, 'visibility net (input block as MFMA k-tiles)')
 
 
+@pytest.mark.parametrize('width', [128, 256])
+def test_fused_relu_net_widths(cuda, width):
+    """ops.FusedReluNet (lean forward with dumps + backward chain + grouped weight gradients) for both hidden widths of
+    the engine against a float64 restatement of stage2/model/renderer.py:17-49: outputs and every parameter gradient,
+    ragged row count, skip connection, sigmoid head."""
+    from psnerf_amd import hip, ops
+    g = torch.Generator().manual_seed(width)
+    Q, din, skip_at = 1000, 63, 2
+    dims_in = [din, width, width, width + din, width]
+    dims_out = [width, width, width, width, 3]
+    Ws = [torch.randn(o, i, generator=g) * (1.2 / i ** 0.5) for i, o in zip(dims_in, dims_out)]
+    bs = [torch.randn(o, generator=g) * 0.05 for o in dims_out]
+    x = torch.rand(Q, 3, generator=g) - 0.5
+    c_out = torch.randn(Q, 3, generator=g)
+    pe = hip.pe_encode(x.to(cuda), 10, 64)
+    params = []
+    for W, b in zip(Ws, bs):
+        params += [W.to(cuda).requires_grad_(), b.to(cuda).requires_grad_()]
+    out = ops.FusedReluNet.apply(pe, din, skip_at, True, width, *params)
+    (out * c_out.to(cuda)).sum().backward()
+    # float64 reference
+    Wd = [W.double().requires_grad_() for W in Ws]
+    bd = [b.double().requires_grad_() for b in bs]
+    xin = pe.cpu().double()[:, :din]
+    h = xin
+    for l in range(5):
+        if l - 1 == skip_at:
+            h = torch.cat([h, xin], dim=1)
+        h = h @ Wd[l].t() + bd[l]
+        if l < 4:
+            h = torch.relu(h)
+    ref = torch.sigmoid(h)
+    (ref * c_out.double()).sum().backward()
+    assert_close(out.detach().cpu(), ref.detach(), 1e-5, 'output')
+    for l in range(5):
+        assert_close(params[2 * l].grad.cpu(), Wd[l].grad, 2e-5, 'dW%d' % l)
+        assert_close(params[2 * l + 1].grad.cpu(), bd[l].grad, 2e-5, 'db%d' % l)
+
+
 def test_fused_geo_occupancy(cuda):
     """mlp_infer on the stage1 occupancy net == oracle forward(only_occupancy=True) (network.py:124-125)."""
     from psnerf_amd import hip, fused
