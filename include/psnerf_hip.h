@@ -129,7 +129,7 @@ int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int ac
  * in ray_marching / secant / light_visibility (stage1/model/rendering.py:
  * 456-462, 537-540, 394-399).
  *
- * Hidden width is 256 or 128 (8 or 4 tiles of 32; one width per network).  A network is described by
+ * Hidden width is 256, 128 or 64 (8, 4 or 2 tiles of 32; one width per network).  A network is described by
  * PsnMlpDesc; weights are pre-packed into MFMA fragment order by
  * psn_mlp_pack_layer (one call per layer, into one contiguous buffer).
  * ---------------------------------------------------------------------- */
@@ -153,7 +153,7 @@ enum { PSN_OUT_NONE = 0, PSN_OUT_SIGMOID = 1, PSN_OUT_OCC = 2 /* sigmoid(-10 x),
 typedef struct {
     int n_kt_in;   /* 32-wide K tiles taken from the input-feature registers (0..4) */
     int n_kt_act;  /* 32-wide K tiles taken from the previous layer's activations (0 or the hidden n_mt) */
-    int n_mt;      /* 32-wide output tiles: 8 or 4 (hidden: 256- / 128-wide network) or 1 (final) */
+    int n_mt;      /* 32-wide output tiles: 8, 4 or 2 (hidden: 256- / 128- / 64-wide network) or 1 (final) */
     int act;       /* PSN_ACT_* applied to this layer's output */
     int64_t w_off; /* float offset of this layer's packed weights */
     int64_t b_off; /* float offset of this layer's bias (n_mt*32 floats, zero padded) */

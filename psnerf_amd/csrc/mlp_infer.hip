@@ -206,10 +206,12 @@ template <int NMT>
 __device__ __forceinline__ void wait_for_weights(int stores) {
     if (stores == 2 * NMT) {
         if constexpr (NMT == 16) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if constexpr (NMT == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else if (stores == NMT) {
         if constexpr (NMT == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (NMT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -217,7 +219,7 @@ __device__ __forceinline__ void wait_for_weights(int stores) {
 
 // CHAIN = false: lean inference / forward-with-dump path (NONE / RELU / SOFTPLUS100 activations, one dump per layer).
 // CHAIN = true : general per-layer activation programs with row-major operands and two dumps (training chains).
-template <bool CHAIN, int NMT>  // NMT = hidden width / 16: 16 (256-wide networks) or 8 (128-wide)
+template <bool CHAIN, int NMT>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
 __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     constexpr int W = 16 * NMT;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages + all biases
@@ -515,7 +517,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         uses_init = uses_init || d.layers[l].init_off >= 0;
     }
     PSN_CHECK_ARG(!uses_in || (tab_a && d.in_kt_a >= 1 && (d.in_kt_b == 0 || tab_b)), "mlp_infer: input table missing");
-    PSN_CHECK_ARG(!uses_init || (init_a && d.init_stride >= 128 && d.init_stride % 4 == 0), "mlp_infer: init table missing");
+    PSN_CHECK_ARG(!uses_init || (init_a && d.init_stride >= 64 && d.init_stride % 4 == 0), "mlp_infer: init table missing");
     PSN_CHECK_ARG((((uintptr_t)init_a | (uintptr_t)init_b) & 15) == 0, "mlp_infer: init tables must be 16-byte aligned");
     PSN_CHECK_ARG(d.n_out >= 0 && d.n_out <= 32, "mlp_infer: n_out=%d", d.n_out);
     PSN_CHECK_ARG(a_div >= 1 && a_mod >= 1 && (d.in_kt_b == 0 || (b_div >= 1 && b_mod >= 1)), "mlp_infer: bad index map");
@@ -523,7 +525,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
                   "mlp_infer: buffers must be 16-byte aligned");
     // hidden width: 256 (8 output tiles of 32) or 128 (4), the same for every hidden layer of the network
     const int hid = (d.n_out > 0 && d.n_layers == 1) ? 8 : d.layers[0].n_mt;
-    PSN_CHECK_ARG(hid == 8 || hid == 4, "mlp_infer: hidden layers must be 256 or 128 wide (n_mt = 8 or 4), got n_mt=%d", hid);
+    PSN_CHECK_ARG(hid == 8 || hid == 4 || hid == 2, "mlp_infer: hidden layers must be 256, 128 or 64 wide (n_mt = 8, 4, 2), got n_mt=%d", hid);
     const int width = hid * 32;
     for (int l = 0; l < d.n_layers; ++l) {
         const PsnMlpLayer& L = d.layers[l];
@@ -580,9 +582,12 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     if (hid == 8) {
         if (chain) hipLaunchKernelGGL((mlp_infer_kernel<true, 16>), grid, block, lds_bytes, st, a);
         else hipLaunchKernelGGL((mlp_infer_kernel<false, 16>), grid, block, lds_bytes, st, a);
-    } else {
+    } else if (hid == 4) {
         if (chain) hipLaunchKernelGGL((mlp_infer_kernel<true, 8>), grid, block, lds_bytes, st, a);
         else hipLaunchKernelGGL((mlp_infer_kernel<false, 8>), grid, block, lds_bytes, st, a);
+    } else {
+        if (chain) hipLaunchKernelGGL((mlp_infer_kernel<true, 4>), grid, block, lds_bytes, st, a);
+        else hipLaunchKernelGGL((mlp_infer_kernel<false, 4>), grid, block, lds_bytes, st, a);
     }
     PSN_CHECK_LAUNCH("mlp_infer");
     return PSN_OK;

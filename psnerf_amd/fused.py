@@ -78,7 +78,7 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     128, one value per network), the final layer o = n_out <= 32.  w_act / w_in may be any row-major view with unit
     column stride (column slices of a parameter) or Transposed(w): the pack kernel reads them in place and zero-fills
     the padding, so no padded / concatenated / transposed copies are made on the way."""
-    assert width in (128, 256)
+    assert width in (64, 128, 256)
     hid = width // 32
     kin = in_kt_a + in_kt_b
     desc = hip.PsnMlpDesc()

@@ -58,11 +58,11 @@ class MLP(nn.Module):
     def weights(self):
         return [l.weight for l in self.linears], [l.bias for l in self.linears]
 
-    FUSED = True  # 128 / 256-wide networks on encoded points run in the register-resident kernel (ops.FusedReluNet)
+    FUSED = True  # 64 / 128 / 256-wide networks on encoded points run in the register-resident kernel (ops.FusedReluNet)
 
     def _fusable(self, x_padded, in_cols):
         Ws = [l.weight for l in self.linears]
-        return (self.FUSED and self.width in (128, 256) and x_padded.shape[1] == 64 and not x_padded.requires_grad
+        return (self.FUSED and self.width in (64, 128, 256) and x_padded.shape[1] == 64 and not x_padded.requires_grad
                 and in_cols.numel() == self.din <= 64 and Ws[-1].shape[0] <= 32 and len(Ws) <= 11
                 and all(w.shape[0] == self.width for w in Ws[:-1]))
 

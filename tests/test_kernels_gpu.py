@@ -249,7 +249,7 @@ def test_fused_visibility_mlp(cuda):
     assert_close(out2.cpu(), ref, 1e-4, 'visibility net (input block as MFMA k-tiles)')
 
 
-@pytest.mark.parametrize('width', [128, 256])
+@pytest.mark.parametrize('width', [64, 128, 256])
 def test_fused_relu_net_widths(cuda, width):
     """ops.FusedReluNet (lean forward with dumps + backward chain + grouped weight gradients) for both hidden widths of
     the engine against a float64 restatement of stage2/model/renderer.py:17-49: outputs and every parameter gradient,
