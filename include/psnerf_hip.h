@@ -114,6 +114,9 @@ typedef struct {
     int M, N;
     int accumulate;                  /* 0: C = ..., 1: C += ... */
     float* colsum_a;                 /* NULL or [M] */
+    int64_t b_div, b_mod;            /* b_div > 0: B is a TABLE and row k of the product reads its row (k / b_div) % b_mod
+                                        (the virtual input rows of psn_mlp_infer: d W_in of a layer whose input block
+                                        repeats per light or per point, summed over all K rows without expanding it) */
 } PsnGemmTnItem;
 int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
                         int64_t workspace_floats, void* stream);

@@ -51,13 +51,15 @@ struct GemmArgs {
     const float* B2;
     int64_t ldb2;
     int seg_splits;
+    int b_div, b_mod;  // b_div > 0 (trans_a, !trans_b only): row k of B is table row (k / b_div) % b_mod
 };
 
 // Stage one 128 x 16 operand tile into registers.  KCONTIG: source rows run along k (row-major [rows][K]);
 // otherwise the source is [K][rows] row-major.
 template <bool KCONTIG, int ROWS>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t n_rows,
-                                           int k0, int k_end, int vec_ok, int tid, float4 (&v)[ROWS / 64]) {
+                                           int k0, int k_end, int vec_ok, int tid, float4 (&v)[ROWS / 64],
+                                           int k_div = 0, int k_mod = 0) {
 #pragma unroll
     for (int u = 0; u < ROWS / 64; ++u) {
         int f = tid + 256 * u;
@@ -82,7 +84,10 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ src, int64_
             int k = k0 + kk;
             int64_t row = row0 + rq;
             if (k < k_end) {
-                const float* p = src + (int64_t)k * ld + row;
+                // k_div > 0: the operand is a TABLE indexed like the fused kernel's (k / k_div) % k_mod (weight
+                // gradients of an input block whose rows repeat per light or per point)
+                const int ks = k_div > 0 ? (k / k_div) % k_mod : k;
+                const float* p = src + (int64_t)ks * ld + row;
                 if (vec_ok && row + 3 < n_rows) {
                     x = *reinterpret_cast<const float4*>(p);
                 } else {
@@ -174,7 +179,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t bid, float*
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #define PSN_FETCH(T)                                                                                    \
     fetch_tile<!TA, BM>(Ap, lda, m0, g.M, k_begin + (T) * BK, k_end, g.a_vec, tid, ra0);               \
-    fetch_tile<TB, BN>(Bp, ldb, n0, g.N, k_begin + (T) * BK, k_end, g.b_vec, tid, rb0);
+    fetch_tile<TB, BN>(Bp, ldb, n0, g.N, k_begin + (T) * BK, k_end, g.b_vec, tid, rb0, g.b_div, g.b_mod);
 #define PSN_STORE(BUF)                                                   \
     if (TA && do_cs) {                                                   \
         cs.x += ra0[0].x + ra0[1].x; cs.y += ra0[0].y + ra0[1].y;        \
@@ -707,7 +712,7 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
     g.split_k = split_k;
     // column sums of A: straight to the caller's buffer, or per-split partials behind the C partials
     g.colsum = colsum_a == nullptr ? nullptr : (split_k > 1 ? workspace + (int64_t)split_k * M * N : colsum_a);
-    g.A2 = nullptr; g.B2 = nullptr; g.lda2 = g.ldb2 = 0; g.seg_splits = split_k;
+    g.A2 = nullptr; g.B2 = nullptr; g.lda2 = g.ldb2 = 0; g.seg_splits = split_k; g.b_div = g.b_mod = 0;
     PSN_CHECK_ARG(g.n_tiles * split_k < (1ll << 31), "gemm: too many blocks");
     dim3 grid((unsigned)(g.n_tiles * split_k)), block(256);
 #define PSN_LAUNCH(TA_, TB_)                                                                          \
@@ -758,7 +763,8 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         PSN_CHECK_ARG((it.A2 == nullptr) == (it.B2 == nullptr), "gemm_tn_grouped: item %d needs both A2 and B2", i);
         const bool vec = (((uintptr_t)it.A | (uintptr_t)it.B | (uintptr_t)it.A2 | (uintptr_t)it.B2) & 15) == 0 && it.lda % 4 == 0 &&
                          it.ldb % 4 == 0 && it.lda >= 4 && it.ldb >= 4 && (!it.A2 || (it.lda2 % 4 == 0 && it.ldb2 % 4 == 0 && it.lda2 >= 4 && it.ldb2 >= 4));
-        if (vec && it.M > 128 && it.N > 128 && it.M <= T256 && it.N <= T256) big_products += it.A2 ? 2 : 1;
+        if (vec && it.b_div == 0 && it.M > 128 && it.N > 128 && it.M <= T256 && it.N <= T256) big_products += it.A2 ? 2 : 1;
+        PSN_CHECK_ARG(it.b_div == 0 || (it.b_div > 0 && it.b_mod > 0 && !it.A2), "gemm_tn_grouped: item %d bad table mapping", i);
     }
     int split_big = 1, kc_big = 0;
     if (big_products > 0) {
@@ -779,11 +785,12 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         const int n_seg = it.A2 ? 2 : 1;
         const bool vec = (((uintptr_t)it.A | (uintptr_t)it.B | (uintptr_t)it.A2 | (uintptr_t)it.B2) & 15) == 0 && it.lda % 4 == 0 &&
                          it.ldb % 4 == 0 && it.lda >= 4 && it.ldb >= 4 && (!it.A2 || (it.lda2 % 4 == 0 && it.ldb2 % 4 == 0 && it.lda2 >= 4 && it.ldb2 >= 4));
-        const bool big = vec && it.M > 128 && it.N > 128 && it.M <= T256 && it.N <= T256;
+        const bool big = vec && it.b_div == 0 && it.M > 128 && it.N > 128 && it.M <= T256 && it.N <= T256;
         const int sk = big ? split_big : split_k;
         GemmArgs& g = big ? gb.g[gb.n] : gg.g[gg.n];
         g.M = it.M; g.N = it.N; g.K = (int)K; g.A = it.A; g.lda = it.lda; g.B = it.B; g.ldb = it.ldb;
         g.A2 = it.A2; g.lda2 = it.lda2; g.B2 = it.B2; g.ldb2 = it.ldb2;
+        g.b_div = (int)it.b_div; g.b_mod = (int)it.b_mod;
         g.bias = nullptr; g.epi = PSN_EPI_NONE; g.aux_in = g.aux_in2 = nullptr; g.aux_out = nullptr;
         g.ld_aux_in = g.ld_aux_in2 = g.ld_aux_out = 0;
         g.tiles_n = big ? 1 : (it.N + 127) / 128;

@@ -45,7 +45,7 @@ class PsnGemmTnItem(ctypes.Structure):
     _fields_ = [('A', ctypes.c_void_p), ('lda', i64), ('B', ctypes.c_void_p), ('ldb', i64),
                 ('A2', ctypes.c_void_p), ('lda2', i64), ('B2', ctypes.c_void_p), ('ldb2', i64),
                 ('C', ctypes.c_void_p), ('ldc', i64), ('M', i32), ('N', i32), ('accumulate', i32),
-                ('colsum_a', ctypes.c_void_p)]
+                ('colsum_a', ctypes.c_void_p), ('b_div', i64), ('b_mod', i64)]
 
 
 MAX_GROUP = 12
@@ -224,7 +224,7 @@ def _tn_is_big(it):
     """Products that psn_gemm_tn_grouped sends to its one-256x256-tile-per-workgroup kernel."""
     def ok(t):
         return t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(0) >= 4)
-    return (128 < it['A'].shape[1] <= 256 and 128 < it['B'].shape[1] <= 256
+    return (not it.get('b_div') and not it.get('b_mod') and 128 < it['A'].shape[1] <= 256 and 128 < it['B'].shape[1] <= 256
             and all(ok(it.get(k)) for k in ('A', 'B', 'A2', 'B2')))
 
 
@@ -261,7 +261,12 @@ def gemm_tn_grouped(items, split_k=None):
             split_big = -(-K // kc)
         for i, it in enumerate(chunk):
             A, B = it['A'], it['B']
-            assert A.shape[0] == K and B.shape[0] == K, 'gemm_tn_grouped: all products share K'
+            b_div, b_mod = int(it.get('b_div', 0)), int(it.get('b_mod', 0))
+            if b_div or b_mod:  # B is a table: row k of the product reads B[(k // b_div) % b_mod]
+                b_div, b_mod = max(b_div, 1), (b_mod if b_mod else B.shape[0])
+                assert A.shape[0] == K and b_mod <= B.shape[0] and it.get('A2') is None
+            else:
+                assert A.shape[0] == K and B.shape[0] == K, 'gemm_tn_grouped: all products share K'
             M, N = A.shape[1], B.shape[1]
             C = it.get('out')
             if C is None:
@@ -276,6 +281,7 @@ def gemm_tn_grouped(items, split_k=None):
                 e.A2, e.lda2, e.B2, e.ldb2 = _mat_ptr(A2, 'A2'), _ld(A2), _mat_ptr(B2, 'B2'), _ld(B2)
             e.C, e.ldc, e.M, e.N = _mat_ptr(C, 'out'), _ld(C), M, N
             e.accumulate = int(bool(it.get('accumulate')))
+            e.b_div, e.b_mod = b_div, b_mod
             e.colsum_a = None if cs is None else cs.data_ptr()
             sk = max(split_k, split_big) if is_big(it) else split_k
             need += (2 if A2 is not None else 1) * sk * M * N + sk * M + 16

@@ -491,7 +491,7 @@ class VisibilityPair(torch.autograd.Function):
     train.light_vis_detach), n_shade = L, in_cols, skip_at, then W0, b0, ...  Returns (vis [L*Ns,1], vis_t [V*Ns,1])."""
 
     @staticmethod
-    def launch(pe_x, pe_l, n_shade, in_cols, skip_at, params, need_grad):
+    def launch(pe_x, pe_l, n_shade, in_cols, skip_at, params, need_grad, packed=None):
         """The fused launch itself, separable from the autograd node: the renderer issues it at the very start of
         the forward pass (it is 60 % of the step and depends on nothing but points and lights) and attaches the
         node later with ``apply(..., pre, *params)``, so that the node keeps a LATE position in the graph and its
@@ -502,7 +502,8 @@ class VisibilityPair(torch.autograd.Function):
         n = len(Ws)
         din_half = in_cols.numel() // 2
         with torch.no_grad():
-            packed = fused.pack_relu_mlp(list(Ws), list(bs), din_half, din_half, skip_at)
+            if packed is None:
+                packed = fused.pack_relu_mlp(list(Ws), list(bs), din_half, din_half, skip_at)
             save = [torch.empty(V * Ns, 256, device=pe_x.device) for _ in range(n - 1)] if (need_grad and V > 0) else None
             out = packed(pe_x, LV * Ns, a_div=1, a_mod=Ns, tab_b=pe_l, b_div=Ns, b_mod=LV, save=save, save_row0=n_shade * Ns)
         return out, save
@@ -539,15 +540,7 @@ class VisibilityPair(torch.autograd.Function):
         grads = [None] * (2 * n)
         g = g.contiguous()
 
-        def in_block_grad(dz):  # d/dW of the [PE(x) | PE(l)] block via separability -> [out, 2*half]
-            d3 = dz.view(V, Ns, -1)
-            gx = hip.gemm(d3.sum(0), pe_x, trans_a=True, split_k=_split_k_for(Ns, dz.shape[1], pe_x.shape[1]))
-            gl = hip.gemm(d3.sum(1), pe_lv, trans_a=True)
-            return torch.cat([gx[:, cols_a], gl[:, cols_b]], dim=1)
-
         # last layer (out = 1): dW = g^T h ; d h_{n-2} = g w  (rank-1, feeds the fused backward chain)
-        grads[2 * (n - 1)] = hip.gemm(g, H[n - 2], trans_a=True, split_k=_split_k_for(Q, 1, 256))
-        grads[2 * (n - 1) + 1] = hip.colsum(g)
         dh_last = hip.gemm(g, Ws[n - 1].contiguous())  # [Q,256]
         # d z_l = d h_l * relu'(h_l), d h_{l-1} = W_l[:, :256]^T d z_l for l = n-2 .. 0 in ONE register-resident
         # launch (transposed weight packs, activations re-read as masks, every d z_l dumped for the weight GEMMs)
@@ -555,16 +548,30 @@ class VisibilityPair(torch.autograd.Function):
         DZ = [torch.empty(Q, 256, device=g.device) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
         chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh_last, mask=[H[n - 2 - j] for j in range(n - 1)],
               save=DZ, save_row0=0)
-        items = [dict(A=DZ[n - 2 - li], B=H[li - 1], colsum=True) for li in range(n - 2, 0, -1)]
-        res = hip.gemm_tn_grouped(items) if items else []
-        for li, (dWh, db) in zip(range(n - 2, 0, -1), res):
-            grads[2 * li + 1] = db
-            if li - 1 == ctx.skip_at:
-                grads[2 * li] = torch.cat([dWh, in_block_grad(DZ[n - 2 - li])], dim=1)
-            else:
-                grads[2 * li] = dWh
-        grads[1] = hip.colsum(DZ[n - 2])
-        grads[0] = in_block_grad(DZ[n - 2])
+        # Every weight gradient in one grouped launch.  The input block [PE(x_n) | PE(l_v)] of row k = v Ns + n is never
+        # expanded: its two halves are TABLES read as pe_x[k % Ns] and pe_lv[k // Ns] by the GEMM itself.
+        items = [dict(A=g, B=H[n - 2], colsum=True)]
+        where = [(n - 1, 'w')]
+        for li in range(n - 2, -1, -1):
+            dz = DZ[n - 2 - li]
+            if li > 0:
+                items.append(dict(A=dz, B=H[li - 1], colsum=True))
+                where.append((li, 'w'))
+            if li == 0 or li - 1 == ctx.skip_at:
+                items.append(dict(A=dz, B=pe_x, b_div=1, b_mod=Ns, colsum=(li == 0)))
+                where.append((li, 'x'))
+                items.append(dict(A=dz, B=pe_lv, b_div=Ns, b_mod=V))
+                where.append((li, 'l'))
+        parts = {}
+        for (li, kind), (C, cs) in zip(where, hip.gemm_tn_grouped(items)):
+            parts[(li, kind)] = C
+            if cs is not None:
+                grads[2 * li + 1] = cs
+        for li in range(n):
+            blocks = [parts[(li, 'w')]] if (li, 'w') in parts else []
+            if (li, 'x') in parts:
+                blocks += [parts[(li, 'x')][:, cols_a], parts[(li, 'l')][:, cols_b]]
+            grads[2 * li] = blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=1)
         return (None, None, None, None, None, None) + tuple(grads)
 
 
@@ -738,13 +745,20 @@ class FusedReluNet(torch.autograd.Function):
     The points are data (no gradient with respect to pe)."""
 
     @staticmethod
-    def forward(ctx, pe, din, skip_at, final_sigmoid, width, *params):
+    def pack(Ws, bs, din, skip_at, final_sigmoid, width):
+        """Forward weight pack; callers may build it ahead of time (it only depends on the parameters)."""
+        with torch.no_grad():
+            return fused.pack_relu_mlp(list(Ws), list(bs), din, 0, skip_at,
+                                       out_act=hip.OUT_SIGMOID if final_sigmoid else hip.OUT_NONE, precompute=False, width=width)
+
+    @staticmethod
+    def forward(ctx, pe, din, skip_at, final_sigmoid, width, packed, *params):
         Ws, bs = params[0::2], params[1::2]
         n = len(Ws)
         Q = pe.shape[0]
-        packed = fused.pack_relu_mlp(list(Ws), list(bs), din, 0, skip_at,
-                                     out_act=hip.OUT_SIGMOID if final_sigmoid else hip.OUT_NONE, precompute=False, width=width)
-        need = any(ctx.needs_input_grad[5:])
+        if packed is None:
+            packed = FusedReluNet.pack(Ws, bs, din, skip_at, final_sigmoid, width)
+        need = any(ctx.needs_input_grad[6:])
         H = [torch.empty(Q, width, device=pe.device) for _ in range(n - 1)] if need else None
         out = packed(pe, Q, save=H)
         if need:
@@ -791,4 +805,4 @@ class FusedReluNet(torch.autograd.Function):
         grads = []
         for l in range(n):
             grads += [dW[l] if dWx[l] is None else torch.cat([dW[l], dWx[l]], dim=1), db[l]]
-        return (None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None) + tuple(grads)

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import hip, ops
+from .. import fused, hip, ops
 
 PE_STRIDE = 64  # 3 + 6*10 = 63 real columns + 1 zero pad
 
@@ -66,13 +66,27 @@ class MLP(nn.Module):
                 and in_cols.numel() == self.din <= 64 and Ws[-1].shape[0] <= 32 and len(Ws) <= 11
                 and all(w.shape[0] == self.width for w in Ws[:-1]))
 
+    def prepack(self):
+        """The forward weight pack, rebuilt only when the parameters changed since the last call (evaluation loops and
+        the two evaluations of a training step share it)."""
+        if not (self.FUSED and self.width in (64, 128, 256) and self.din <= 64 and self.linears[-1].weight.shape[0] <= 32
+                and all(l.weight.shape[0] == self.width for l in list(self.linears)[:-1]) and self.linears[0].weight.is_cuda):
+            return None
+        key = tuple(int(p._version) for p in self.parameters()) + (self.linears[0].weight.data_ptr(),)
+        if getattr(self, '_pack_key', None) != key:
+            Ws, bs = self.weights()
+            self._pack = ops.FusedReluNet.pack(Ws, bs, self.din, self._skip_index(), self.final == 'sigmoid', self.width)
+            self._pack_key = key
+        return self._pack
+
     def forward(self, x_padded, in_cols):
         Ws, bs = self.weights()
         if self._fusable(x_padded, in_cols):
             params = []
             for W, b in zip(Ws, bs):
                 params += [W, b]
-            return ops.FusedReluNet.apply(x_padded, self.din, self._skip_index(), self.final == 'sigmoid', self.width, *params)
+            return ops.FusedReluNet.apply(x_padded, self.din, self._skip_index(), self.final == 'sigmoid', self.width,
+                                          self.prepack(), *params)
         return ops.relu_mlp(x_padded, in_cols, self._skip_index(), self.final == 'sigmoid', Ws, bs)
 
 
@@ -171,11 +185,26 @@ class PSNetwork(nn.Module):
         cols = self._cols(self.n_freqs, pe_x.device, pair=True)
         return pe_x.detach(), pe_l, light_dir.shape[0], cols, net._skip_index(), params
 
+    def _visibility_prepack(self):
+        """Packed visibility-net weights (input block through init tables), rebuilt only when the parameters changed."""
+        net = self.visibility_net
+        if net.width != 256 or not net.linears[0].weight.is_cuda:
+            return None
+        key = tuple(int(p._version) for p in net.parameters()) + (net.linears[0].weight.data_ptr(),)
+        if getattr(self, '_vis_pack_key', None) != key:
+            Ws, bs = net.weights()
+            half = 3 + 6 * self.n_freqs
+            with torch.no_grad():
+                self._vis_pack = fused.pack_relu_mlp(list(Ws), list(bs), half, half, net._skip_index())
+            self._vis_pack_key = key
+        return self._vis_pack
+
     def _visibility_pair_launch(self, pe_x, light_dir, light_vis_train):
         """Issue the fused launch now, attach the autograd node later (ops.VisibilityPair.launch)."""
         a = self._visibility_pair_args(pe_x, light_dir, light_vis_train)
         need = any(p.requires_grad for p in a[5])
-        return a, ops.VisibilityPair.launch(a[0], a[1], a[2], a[3], a[4], [p.detach() for p in a[5]], need)
+        return a, ops.VisibilityPair.launch(a[0], a[1], a[2], a[3], a[4], [p.detach() for p in a[5]], need,
+                                            packed=self._visibility_prepack())
 
     def _visibility_pair(self, pe_x, light_dir, light_vis_train, launched=None):
         """(vis [L*Ns,1], vis_train [V*Ns,1]) from one fused launch (ops.VisibilityPair)."""

@@ -197,6 +197,26 @@ def test_gemm_tn_grouped(cuda, Q, split):
     assert all(torch.equal(a[0], b[0]) for a, b in zip(res[:4], res2[:4]))
 
 
+def test_gemm_tn_grouped_table_operand(cuda):
+    """B given as a TABLE indexed (k // b_div) % b_mod: the weight gradient of an input block that repeats per light /
+    per point (rows k = v * Ns + n of the visibility supervision set) without expanding it."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(3)
+    Ns, V = 777, 5
+    Q = Ns * V
+    dz = torch.randn(Q, 256, generator=g)
+    pe_x, pe_l = torch.randn(Ns, 64, generator=g), torch.randn(V, 64, generator=g)
+    d = lambda t: t.to(cuda)
+    res = hip.gemm_tn_grouped([dict(A=d(dz), B=d(pe_x), b_div=1, b_mod=Ns, colsum=True),
+                               dict(A=d(dz), B=d(pe_l), b_div=Ns, b_mod=V),
+                               dict(A=d(dz), B=d(dz))])
+    D = lambda t: t.double()
+    assert_close(res[0][0].cpu(), D(dz).t() @ D(pe_x).repeat(V, 1), 1e-5, 'table operand (k % Ns)')
+    assert_close(res[1][0].cpu(), D(dz).t() @ D(pe_l).repeat_interleave(Ns, dim=0), 1e-5, 'table operand (k // Ns)')
+    assert_close(res[0][1].cpu(), D(dz).sum(0), 1e-5, 'colsum')
+    assert_close(res[2][0].cpu(), D(dz).t() @ D(dz), 1e-5, 'plain item in the same group')
+
+
 @pytest.mark.parametrize('Q', [7, 100, 4099])
 def test_gemm_tn_grouped_tile256_edges(cuda, Q):
     """The one-256x256-tile-per-workgroup path (128 < M, N <= 256) on awkward shapes: K smaller than / not a multiple
@@ -267,7 +287,7 @@ def test_fused_relu_net_widths(cuda, width):
     params = []
     for W, b in zip(Ws, bs):
         params += [W.to(cuda).requires_grad_(), b.to(cuda).requires_grad_()]
-    out = ops.FusedReluNet.apply(pe, din, skip_at, True, width, *params)
+    out = ops.FusedReluNet.apply(pe, din, skip_at, True, width, None, *params)
     (out * c_out.to(cuda)).sum().backward()
     # float64 reference
     Wd = [W.double().requires_grad_() for W in Ws]
