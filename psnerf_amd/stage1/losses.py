@@ -21,7 +21,7 @@ class Loss(nn.Module):
     def forward(self, out_dict, rgb_gt, normal_gt=None, norm_mask=None, mask=None, mask_gt=None, mask_valid=None):
         rgb, diff_norm, normal = out_dict['rgb'], out_dict['diff_norm'], out_dict.get('normal_pred')
         dev = rgb.device
-        zero = torch.tensor(0.0, device=dev)
+        zero = torch.zeros((), device=dev)  # a fill kernel: torch.tensor(0.0, device=...) is a pageable H2D copy = a stream sync
         rgb_gt = rgb_gt.to(dev)
         if self.full_weight != 0.0:
             l_rgb = (rgb - rgb_gt).abs().sum() / float(self._g(rgb.shape[1]))

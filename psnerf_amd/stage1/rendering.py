@@ -173,7 +173,7 @@ class Renderer(nn.Module):
                                 cfg['interval_end'] * torch.ones(1)))  # fp32 like rendering.py:116-117
         dnp = d_hit - delta
         dfp = d_hit + delta
-        near_t = torch.tensor(near, device=dev)
+        near_t = torch.full((), near, device=dev)
         dnp = torch.where(dnp < near_t, near_t, dnp)
         dfp = torch.where(dfp > far_hit, far_hit, dfp)
         full_steps = steps + steps_out if (bool((dnp != 0.0).all()) and it > 5000) else steps

@@ -70,7 +70,8 @@ class Trainer(object):
             normal_gt = gather_pixels(normal, pix)
             if self.angle is not None:
                 norm_mask_gt[normal_gt[..., -1] < np.cos(np.deg2rad(self.angle))] = False
-            flip = torch.tensor([[[1, -1, -1]]], dtype=torch.float32, device=dev)
+            flip = torch.ones(1, 1, 3, device=dev)
+            flip[..., 1:] = -1.0  # (1, -1, -1) without a host-to-device copy
             normal_gt = torch.einsum('bij,bnj->bni', world_mat[:, :3, :3] * flip, normal_gt)
         mask_pred = out.get('acc_map')
         if not self.mask_loss:

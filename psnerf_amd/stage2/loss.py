@@ -41,7 +41,7 @@ class MainLoss(nn.Module):
         dev = mask.device
         if count is None:
             count = int(mask.sum()) if self.global_count is None else self.global_count(mask)
-        zero = torch.tensor(0.0, device=dev)
+        zero = torch.zeros((), device=dev)  # a fill kernel: torch.tensor(0.0, device=...) is a pageable H2D copy = a stream sync
         rgb_gt = ground_truth['rgb'].to(dev)
         L = rgb_gt.shape[0]
         if count == 0:
@@ -92,7 +92,7 @@ class NormalLoss(nn.Module):
         dev = mask.device
         if count is None:
             count = int(mask.sum()) if self.global_count is None else self.global_count(mask)
-        zero = torch.tensor(0.0, device=dev)
+        zero = torch.zeros((), device=dev)  # a fill kernel: torch.tensor(0.0, device=...) is a pageable H2D copy = a stream sync
         if count == 0:
             n_loss = zero
         else:

@@ -261,7 +261,7 @@ class PSNetwork(nn.Module):
                 if self.normal_jitter_std > 0:
                     nz = noise.get('normal')
                     if nz is None:
-                        nz = torch.normal(0, torch.ones_like(surf) * self.normal_jitter_std)
+                        nz = torch.randn_like(surf) * self.normal_jitter_std  # = torch.normal(0, std) without its host-side std >= 0 check
                     nj = F.normalize(self.normal_net(self._pe(surf + nz, self.n_freqs_n), cols_n), dim=-1)
                     out_n['normal_jitter'] = scatter(torch.ones_like(points), nj)
             out_n['normal_pred'] = normal_pred
@@ -289,7 +289,7 @@ class PSNetwork(nn.Module):
             if self.xyz_jitter_std > 0:
                 nz = noise.get('xyz')
                 if nz is None:
-                    nz = torch.normal(0, torch.ones_like(surf) * self.xyz_jitter_std)
+                    nz = torch.randn_like(surf) * self.xyz_jitter_std  # = torch.normal(0, std) without its host-side std >= 0 check
                 pe_j = self._pe(surf + nz, self.n_freqs)
                 pe_both = torch.cat([pe_x, pe_j], dim=0)
                 albedo_both = self.albedo_net(pe_both, cols)

@@ -71,9 +71,12 @@ class TrainStep(object):
         model_input = dict(model_input)
         model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
         model_input['light_intensity'] = self.light_inten_para(l_slt)
+        # ONE mask count per step (a tiny all-reduce under data parallelism), shared by every loss term.  Both masks
+        # are inputs (the model passes them through as 'network_object_mask' / 'object_mask'), so the count -- a host
+        # synchronisation -- is taken BEFORE the forward pass: afterwards the host runs ahead of the GPU through
+        # forward, losses and backward instead of stalling behind the 22 ms visibility launch.
+        count = self.dp.global_count(model_input['surface_mask'] & model_input['object_mask'])
         out = self.model(model_input, noise=noise)
-        # ONE mask count per step (a tiny all-reduce under data parallelism), shared by every loss term
-        count = self.dp.global_count(out['network_object_mask'] & out['object_mask'])
         terms = dict(self.loss(out, ground_truth, model_input, count=count))
         terms_n = self.loss_n(out, count=count)
         loss = terms['loss'] + terms_n['loss']
