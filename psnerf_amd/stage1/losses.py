@@ -18,7 +18,11 @@ class Loss(nn.Module):
     def _g(self, n):
         return n if self.global_sum is None else self.global_sum(n)
 
-    def forward(self, out_dict, rgb_gt, normal_gt=None, norm_mask=None, mask=None, mask_gt=None, mask_valid=None):
+    def forward(self, out_dict, rgb_gt, normal_gt=None, norm_mask=None, mask=None, mask_gt=None, mask_valid=None,
+                norm_count=None, valid_count=None):
+        """``norm_count`` / ``valid_count``: local counts of ``norm_mask`` / ``mask_valid`` when the caller already has
+        them (both masks are inputs: the trainer counts them BEFORE the network call so that no host synchronisation
+        sits between forward and backward)."""
         rgb, diff_norm, normal = out_dict['rgb'], out_dict['diff_norm'], out_dict.get('normal_pred')
         dev = rgb.device
         zero = torch.zeros((), device=dev)  # a fill kernel: torch.tensor(0.0, device=...) is a pageable H2D copy = a stream sync
@@ -35,14 +39,16 @@ class Loss(nn.Module):
         loss = self.full_weight * l_rgb + self.grad_weight * l_grad
         terms = {'fullrgb_loss': l_rgb, 'grad_loss': l_grad}
         if normal is not None and normal_gt is not None:
-            cnt = self._g(int(norm_mask.sum()))
+            cnt = self._g(int(norm_mask.sum()) if norm_count is None else norm_count)
             if cnt > 0:
-                l_n = (normal[norm_mask] - normal_gt[norm_mask]).abs().sum() / float(cnt)
+                # masked sum instead of the reference's boolean gathers (each a nonzero + host synchronisation)
+                l_n = ((normal - normal_gt).abs() * norm_mask.unsqueeze(-1).to(normal.dtype)).sum() / float(cnt)
                 loss = loss + self.norm_weight * l_n
                 terms['normal_loss'] = l_n
         if mask is not None and mask_gt is not None:
-            cnt = self._g(int(mask_valid.sum()))
-            l_m = F.binary_cross_entropy(mask[mask_valid].clamp(0, 1), mask_gt[mask_valid], reduction='sum') / float(max(cnt, 1))
+            cnt = self._g(int(mask_valid.sum()) if valid_count is None else valid_count)
+            bce = F.binary_cross_entropy(mask.clamp(0, 1), mask_gt, reduction='none')  # log terms are clamped at -100: finite
+            l_m = (bce * mask_valid.to(bce.dtype)).sum() / float(max(cnt, 1))
             loss = loss + self.mask_weight * l_m
             terms['mask_loss'] = l_m
         terms['loss'] = loss

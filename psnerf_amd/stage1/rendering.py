@@ -212,11 +212,8 @@ class Renderer(nn.Module):
         p_fg = p_fg.reshape(-1, 3)
         view = (-1 * rays).unsqueeze(-2).expand(-1, full_steps, -1).reshape(-1, 3)
 
-        rgb, alpha = self.model(p_fg, view, return_addocc=True)  # one launch chain; no 64000-point chunking needed
-        rgb = rgb.reshape(B * N, full_steps, 3)
-        alpha = alpha.reshape(B * N, full_steps)
-        rgb_values, acc, _w = ops.alpha_composite(alpha, rgb, bool(self.white_background))
-
+        # The surface-point gather is a boolean index (a host synchronisation): take it BEFORE the big network call is
+        # queued, so that the host keeps running ahead of the GPU afterwards (same RNG order: the model call draws nothing).
         surf = points[obj_mask]
         n_surf = surf.shape[0]
         if not eval_:
@@ -226,6 +223,11 @@ class Renderer(nn.Module):
             pp = torch.cat([surf, surf + (nz.to(dev) - 0.5) * 0.01], dim=0)
         else:
             pp = surf
+
+        rgb, alpha = self.model(p_fg, view, return_addocc=True)  # one launch chain; no 64000-point chunking needed
+        rgb = rgb.reshape(B * N, full_steps, 3)
+        alpha = alpha.reshape(B * N, full_steps)
+        rgb_values, acc, _w = ops.alpha_composite(alpha, rgb, bool(self.white_background))
         norm_pred = torch.zeros(B * N, 3, device=dev)
         diff_norm = None
         if n_surf > 0:

@@ -62,8 +62,9 @@ class Trainer(object):
         mask_gt = gather_pixels(mask_img, pix).bool().reshape(B, -1).to(torch.float32)
         mask_valid = gather_pixels(mask_valid * 1.0, pix).bool().reshape(B, -1)
         norm_mask_gt = gather_pixels(norm_mask, pix).bool().squeeze(-1) if self.normal_loss else None
-        out = self.model(pix, camera_mat, world_mat, scale_mat, self.rendering_technique, it=it, eval_=eval_mode,
-                         noise=noise)
+        # everything that depends on the data only -- ground-truth gathers, masks and their COUNTS (host
+        # synchronisations) -- comes before the network call; afterwards the host runs ahead of the GPU through the
+        # forward chains, the loss and the backward pass
         rgb_gt = gather_pixels(img, pix)
         normal_gt = None
         if self.normal_loss and it >= self.normal_after:
@@ -73,7 +74,12 @@ class Trainer(object):
             flip = torch.ones(1, 1, 3, device=dev)
             flip[..., 1:] = -1.0  # (1, -1, -1) without a host-to-device copy
             normal_gt = torch.einsum('bij,bnj->bni', world_mat[:, :3, :3] * flip, normal_gt)
+        norm_count = int(norm_mask_gt.sum()) if normal_gt is not None else None
+        valid_count = int(mask_valid.sum()) if self.mask_loss else None
+        out = self.model(pix, camera_mat, world_mat, scale_mat, self.rendering_technique, it=it, eval_=eval_mode,
+                         noise=noise)
         mask_pred = out.get('acc_map')
         if not self.mask_loss:
             mask_gt = None
-        return self.loss(out, rgb_gt, normal_gt, norm_mask_gt, mask_pred, mask_gt, mask_valid)
+        return self.loss(out, rgb_gt, normal_gt, norm_mask_gt, mask_pred, mask_gt, mask_valid,
+                         norm_count=norm_count, valid_count=valid_count)
