@@ -167,8 +167,12 @@ class Renderer(nn.Module):
         isect = isect.reshape(-1, 2).clone()
         isect[:, 0] = 0.0
 
-        d_hit = dists[obj_mask]
-        far_hit = isect[obj_mask][:, 1]
+        # hit / miss ray lists ONCE (two nonzero() = the data-dependent host synchronisations of this function); every
+        # gather / scatter below is an index op with them instead of a boolean mask (each of which would sync again)
+        hit_idx = obj_mask.nonzero(as_tuple=True)[0]
+        miss_idx = (~obj_mask).nonzero(as_tuple=True)[0]
+        d_hit = dists[hit_idx]
+        far_hit = isect[hit_idx][:, 1]
         delta = float(torch.max(cfg['interval_start'] * torch.exp(-1 * cfg['interval_decay'] * it * torch.ones(1)),
                                 cfg['interval_end'] * torch.ones(1)))  # fp32 like rendering.py:116-117
         dnp = d_hit - delta
@@ -187,12 +191,12 @@ class Renderer(nn.Module):
                 nz = torch.rand(B, d.shape[1], full_steps, device=dev)
             return lo + (hi - lo) * nz.to(dev)
 
-        far_miss = isect[~obj_mask][:, 1]
+        far_miss = isect[miss_idx][:, 1]
         u = torch.linspace(0.0, 1.0, steps=full_steps, device=dev).view(1, 1, -1)
         d2 = near * (1.0 - u) + far_miss.view(1, -1, 1) * u
         if add_noise:
             d2 = jitter(d2, 'miss')
-        p_miss = cam[~obj_mask].unsqueeze(-2) + rays[~obj_mask].unsqueeze(-2) * d2[0].unsqueeze(-1)
+        p_miss = cam[miss_idx].unsqueeze(-2) + rays[miss_idx].unsqueeze(-2) * d2[0].unsqueeze(-1)
 
         u = torch.linspace(0.0, 1.0, steps=steps, device=dev).view(1, 1, -1)
         d_in = dnp.view(1, -1, 1) * (1.0 - u) + dfp.view(1, -1, 1) * u
@@ -204,17 +208,16 @@ class Renderer(nn.Module):
             d1 = d_in
         if add_noise:
             d1 = jitter(d1, 'hit')
-        p_hit = cam[obj_mask].unsqueeze(-2) + rays[obj_mask].unsqueeze(-2) * d1[0].unsqueeze(-1)
+        p_hit = cam[hit_idx].unsqueeze(-2) + rays[hit_idx].unsqueeze(-2) * d1[0].unsqueeze(-1)
 
         p_fg = torch.zeros(B * N, full_steps, 3, device=dev)
-        p_fg[~obj_mask] = p_miss
-        p_fg[obj_mask] = p_hit
+        p_fg[miss_idx] = p_miss
+        p_fg[hit_idx] = p_hit
         p_fg = p_fg.reshape(-1, 3)
         view = (-1 * rays).unsqueeze(-2).expand(-1, full_steps, -1).reshape(-1, 3)
 
-        # The surface-point gather is a boolean index (a host synchronisation): take it BEFORE the big network call is
-        # queued, so that the host keeps running ahead of the GPU afterwards (same RNG order: the model call draws nothing).
-        surf = points[obj_mask]
+        # (same RNG order as the reference: the model call below draws nothing)
+        surf = points[hit_idx]
         n_surf = surf.shape[0]
         if not eval_:
             nz = noise.get('nbr')
@@ -233,7 +236,7 @@ class Renderer(nn.Module):
         if n_surf > 0:
             g = self.model.gradient(pp)[:, 0, :]
             nrm = g / (g.norm(2, dim=1).unsqueeze(-1) + 10 ** (-5))
-            norm_pred[obj_mask] = nrm[:n_surf]
+            norm_pred[hit_idx] = nrm[:n_surf]
             if not eval_:
                 diff_norm = torch.norm(nrm[:n_surf] - nrm[n_surf:], dim=-1)
         elif not eval_:
