@@ -83,6 +83,13 @@ class Renderer(nn.Module):
     @torch.no_grad()
     def ray_marching(self, ray0, ray_direction, model=None, c=None, tau=0.5, n_steps=(128, 129), n_secant_steps=8,
                      depth_range=(25, 40), max_points=3500000, rad=1.0, clip=False):
+        state = self._march_launch(ray0, ray_direction, tau, n_steps, depth_range, rad, clip)
+        return self._march_finish(state, n_secant_steps)
+
+    @torch.no_grad()
+    def _march_launch(self, ray0, ray_direction, tau, n_steps, depth_range, rad, clip):
+        """First half of ray_marching (rendering.py:410-480): everything up to the first-crossing mask -- all of it
+        asynchronous device work (the 256-step occupancy sweep is one fused launch), no host synchronisation."""
         B, N, _ = ray0.shape
         dev = ray0.device
         n_steps = int(n_steps[0])  # the reference draws randint(n, n+1): a constant
@@ -103,16 +110,24 @@ class Renderer(nn.Module):
         mask = has_change & from_free & first_free
         dflat = d_prop.expand(B, N, n_steps, 1).reshape(B, N, n_steps)
         idx2 = torch.clamp(idx + 1, max=n_steps - 1)
-        d_low = torch.gather(dflat, 2, idx.unsqueeze(-1)).squeeze(-1)[mask]
-        f_low = torch.gather(val, 2, idx.unsqueeze(-1)).squeeze(-1)[mask]
-        d_high = torch.gather(dflat, 2, idx2.unsqueeze(-1)).squeeze(-1)[mask]
-        f_high = torch.gather(val, 2, idx2.unsqueeze(-1)).squeeze(-1)[mask]
-        d_pred = self.secant(f_low, f_high, d_low, d_high, n_secant_steps, ray0[mask], ray_direction[mask], tau)
-        out = torch.ones(B, N, device=dev)
-        out[mask] = d_pred
-        out[mask == 0] = np.inf
-        out[first_free == 0] = 0
-        return out
+        gat = lambda src, i: torch.gather(src, 2, i.unsqueeze(-1)).reshape(-1)
+        return dict(ray0=ray0, ray_direction=ray_direction, tau=tau, mask=mask, first_free=first_free,
+                    d_low=gat(dflat, idx), f_low=gat(val, idx), d_high=gat(dflat, idx2), f_high=gat(val, idx2))
+
+    @torch.no_grad()
+    def _march_finish(self, st, n_secant_steps):
+        """Second half: ONE nonzero() (the data-dependent host synchronisation of the march) gives the list of rays
+        with a free -> occupied crossing; every gather / scatter below is an index op with it (rendering.py:480-520)."""
+        ray0, ray_direction, mask = st['ray0'], st['ray_direction'], st['mask']
+        B, N, _ = ray0.shape
+        dev = ray0.device
+        mi = mask.reshape(-1).nonzero(as_tuple=True)[0]
+        d_pred = self.secant(st['f_low'][mi], st['f_high'][mi], st['d_low'][mi], st['d_high'][mi], n_secant_steps,
+                             ray0.reshape(-1, 3)[mi], ray_direction.reshape(-1, 3)[mi], st['tau'])
+        out = torch.full((B * N,), float('inf'), device=dev)
+        out[mi] = d_pred
+        out = out.view(B, N)
+        return torch.where(st['first_free'], out, torch.zeros_like(out))
 
     # ---- stage1/model/rendering.py:525-555 -------------------------------------------------------
     @torch.no_grad()
@@ -131,14 +146,32 @@ class Renderer(nn.Module):
             d_pred = -f_low * (d_high - d_low) / (f_high - f_low) + d_low
         return d_pred
 
-    def _surface(self, pixels, camera_mat, world_mat, ray_steps):
-        """Shared prologue of unisurf / shape_extract (rendering.py:67-108, 311-340)."""
+    def _surface_launch(self, pixels, camera_mat, world_mat, ray_steps):
         B, N, _ = pixels.shape
         cam = camera_origin(N, world_mat)
         rays = pixel_rays(pixels, camera_mat, world_mat)
         rays = rays / rays.norm(2, 2).unsqueeze(-1)
-        d_i = self.ray_marching(cam, rays, n_steps=[int(ray_steps), int(ray_steps) + 1], n_secant_steps=8,
-                                rad=self.cfg['radius'], depth_range=self.depth_range)
+        state = self._march_launch(cam, rays, 0.5, [int(ray_steps), int(ray_steps) + 1], self.depth_range,
+                                   self.cfg['radius'], False)
+        return cam, rays, state
+
+    @torch.no_grad()
+    def prefetch_surface(self, pixels, camera_mat, world_mat):
+        """Queue the ray-march sweep for ``pixels`` now; the next forward() with the SAME pixel tensor picks it up.  The
+        trainer calls this before its data-only host work (ground-truth gathers, mask counts), which then overlaps
+        with the 10 ms sweep instead of preceding it."""
+        steps = int(self.cfg['ray_marching_steps'])
+        self._pref = (pixels, steps, self._surface_launch(pixels, camera_mat, world_mat, steps))
+
+    def _surface(self, pixels, camera_mat, world_mat, ray_steps):
+        """Shared prologue of unisurf / shape_extract (rendering.py:67-108, 311-340)."""
+        B, N, _ = pixels.shape
+        pref, self._pref = getattr(self, '_pref', None), None
+        if pref is not None and pref[0] is pixels and pref[1] == int(ray_steps):
+            cam, rays, state = pref[2]  # requested earlier by prefetch_surface: the sweep is already running
+        else:
+            cam, rays, state = self._surface_launch(pixels, camera_mat, world_mat, ray_steps)
+        d_i = self._march_finish(state, 8)
         zero_occ = d_i == 0
         ok = finite_mask(d_i)
         dists = torch.where(ok, d_i, torch.ones_like(d_i))

@@ -59,6 +59,8 @@ class Trainer(object):
             py = torch.randint(0, h, size=(B, n, 1)).float()
             pix = torch.cat([px, py], dim=-1)
         pix = self.dp.shard_rays(pix.to(dev)) if self.dp.enabled else pix.to(dev)
+        if self.rendering_technique == 'unisurf' and hasattr(self.model, 'prefetch_surface'):
+            self.model.prefetch_surface(pix, camera_mat, world_mat)  # the ray-march sweep runs under the host work below
         mask_gt = gather_pixels(mask_img, pix).bool().reshape(B, -1).to(torch.float32)
         mask_valid = gather_pixels(mask_valid * 1.0, pix).bool().reshape(B, -1)
         norm_mask_gt = gather_pixels(norm_mask, pix).bool().squeeze(-1) if self.normal_loss else None
