@@ -41,7 +41,7 @@ def main():
     busy = counter_rows(os.path.join(src, 'pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv'))
 
     def dominant(rows, counter):  # the forward launch = the largest value among the lean-kernel dispatches
-        vals = [v[counter] for (d, k), v in rows.items() if 'mlp_infer_kernel<false>' in k and counter in v]
+        vals = [v[counter] for (d, k), v in rows.items() if 'mlp_infer_kernel<false' in k and counter in v]
         return max(vals) if vals else None
 
     f_kb, w_kb = dominant(fetch, 'FETCH_SIZE'), dominant(write, 'WRITE_SIZE')
@@ -52,7 +52,7 @@ def main():
                     'MI355X_MICROARCH.md (HBM section) gfx950 FETCH_SIZE tallies 128-B fabric requests as 64 B for wide '
                     '16 B/lane reads, so the read side is doubled; WRITE_SIZE is taken as reported (uncalibrated); '
                     'Infinity-Cache hits are included in both.',
-        'kernel': 'psn::mlp_infer_kernel<false>',
+        'kernel': 'psn::mlp_infer_kernel<false, 16>',
         'rows_per_launch': bench['config']['surface_pixels_total'] * (bench['config']['lights'] + bench['config']['vis_lights']),
         'FETCH_SIZE_KB_raw': f_kb, 'WRITE_SIZE_KB_raw': w_kb,
     }
@@ -62,7 +62,7 @@ def main():
     res['algorithmic_bytes_per_launch'] = int((L + V) * ns * (4096 + 4) + V * ns * 9 * 1024)
     res['algorithmic_bytes_note'] = ('per row 2 x 2 KB init-table rows (U[point], V[light]; L2 / Infinity-Cache hits for all but the '
                                      'first use) + 4 B output; the V*Ns supervised rows also dump 9 x 1 KB of activations')
-    mb = [(v.get('SQ_VALU_MFMA_BUSY_CYCLES'), v.get('GRBM_GUI_ACTIVE')) for (d, k), v in busy.items() if 'mlp_infer_kernel<false>' in k]
+    mb = [(v.get('SQ_VALU_MFMA_BUSY_CYCLES'), v.get('GRBM_GUI_ACTIVE')) for (d, k), v in busy.items() if 'mlp_infer_kernel<false' in k]
     mb = [x for x in mb if x[0] and x[1]]
     if mb:
         b, g = max(mb, key=lambda x: x[0])

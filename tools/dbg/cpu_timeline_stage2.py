@@ -45,8 +45,10 @@ mark('losses issued')
 self.sg_optimizer.zero_grad(); self.light_optimizer.zero_grad()
 loss.backward()
 mark('backward issued')
-self.sg_optimizer.step(); self.light_optimizer.step()
-mark('optimizers issued')
+self.sg_optimizer.step()
+mark('Adam issued')
+self.light_optimizer.step()
+mark('SparseAdam issued')
 torch.cuda.synchronize()
 mark('GPU done')
 t0 = T[0][1]
