@@ -126,6 +126,20 @@ int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int ac
                void* stream);
 
 /* ------------------------------------------------------------------------
+ * Points along rays.  Replaces the depth-profile arithmetic of stage1/model/rendering.py:110-176 (interval
+ * sampling around the surface, outer samples after iteration 5000, free-space sampling of rays that miss,
+ * stratified jitter) and :431-436 (the ray-march sweep), bit-identically for the same u tables and noise.
+ *   origin, dir [N,3]; dist [N] (surface depth of hit rays, NULL otherwise); far [N] (sphere exit depth)
+ *   idx [n] int64: the rays of this group = rows of out [N, c0+c1, 3] that are written (NULL: rays 0..n-1)
+ *   hit = 0: d = near (1 - u0) + far u0.   hit = 1: [dnp, dfp] = [max(dist - delta, near), min(dist + delta, far)]
+ *   sampled with u0 (c1 == 0), or [near, dnp] with u0 followed by [dnp, dfp] with u1.
+ *   u*, omu* = linspace(0, 1, c) and 1 - linspace; noise [n, c0+c1] in [0,1) or NULL (no jitter).
+ * ---------------------------------------------------------------------- */
+int psn_sample_points(const float* origin, const float* dir, const float* dist, const float* far, const int64_t* idx,
+                      int64_t n, int hit, float near, float delta, const float* u0, const float* omu0, int c0,
+                      const float* u1, const float* omu1, int c1, const float* noise, float* out, void* stream);
+
+/* ------------------------------------------------------------------------
  * Fully fused MLP inference (activations never leave registers).  Replaces the
  * no-grad network evaluations: stage2 visibility_net over L*Ns rows
  * (stage2/model/renderer.py:191-200, vis.detach()), stage1 occupancy queries

@@ -63,6 +63,7 @@ SIGNATURES = {
                        i32, c_f, c_f, c_f]),
     'psn_gemm_tn_grouped': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
     'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
+    'psn_sample_points': (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, i32, i32, i32, c_f, c_f]),
     'psn_sg_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f]),
     'psn_sg_shade_bwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f, c_f,
@@ -162,6 +163,23 @@ def pe_encode_bwd(x, d_out, n_freqs, scale=1.0):
     _check(_lib.psn_pe_encode_bwd(_ptr(x, 'x'), _ptr(d_out, 'd_out'), n, n_freqs, float(scale), d_out.shape[1],
                                   _ptr(d_x, 'd_x'), _stream()), 'pe_encode_bwd')
     return d_x
+
+
+def sample_points(origin, direction, far, out, hit, near, u0, idx=None, dist=None, delta=0.0, u1=None, noise=None):
+    """Fill rows ``idx`` (all rows if None) of out [N,S,3] with origin + direction * depth profile (psn_sample_points).
+    u0 / u1: (linspace(0,1,c), 1 - linspace) pairs of device tensors."""
+    n = origin.shape[0] if idx is None else idx.shape[0]
+    c0 = u0[0].numel()
+    c1 = 0 if u1 is None else u1[0].numel()
+    assert out.shape[1] == c0 + c1 and out.is_contiguous() and (idx is None or idx.dtype == torch.int64)
+    if noise is not None:
+        assert noise.numel() == n * (c0 + c1)
+    _check(_lib.psn_sample_points(_ptr(origin, 'origin'), _ptr(direction, 'direction'), _ptr(dist, 'dist', True), _ptr(far, 'far'),
+                                  None if idx is None else idx.data_ptr(), n, int(bool(hit)), float(near), float(delta),
+                                  _ptr(u0[0], 'u0'), _ptr(u0[1], 'omu0'), c0,
+                                  None if u1 is None else _ptr(u1[0], 'u1'), None if u1 is None else _ptr(u1[1], 'omu1'), c1,
+                                  _ptr(noise, 'noise', True), _ptr(out, 'out'), _stream()), 'sample_points')
+    return out
 
 
 # --------------------------------------------------------------------------- GEMM

@@ -71,6 +71,15 @@ class Renderer(nn.Module):
             raise NotImplementedError('phong_renderer is a visualisation preview (out of scope, SURVEY 2)')
         raise ValueError('Choose unisurf or shape_extract')
 
+    def _u(self, n, dev):
+        """(linspace(0, 1, n), 1 - linspace(0, 1, n)) on the device, cached: the tables of csrc/sample.hip."""
+        cache = self.__dict__.setdefault('_u_cache', {})
+        key = (int(n), str(dev))
+        if key not in cache:
+            u = torch.linspace(0.0, 1.0, steps=int(n), device=dev)
+            cache[key] = (u.contiguous(), (1.0 - u).contiguous())
+        return cache[key]
+
     # ---- occupancy queries without a graph -------------------------------------------------------
     def _occ(self, pts):
         """sigmoid(-10 logit) for [Q,3] points, fused kernel, chunked."""
@@ -93,14 +102,17 @@ class Renderer(nn.Module):
         B, N, _ = ray0.shape
         dev = ray0.device
         n_steps = int(n_steps[0])  # the reference draws randint(n, n+1): a constant
-        far = sphere_intersection(ray0[:, 0], ray_direction, r=rad)[0][..., 1]
-        t = torch.linspace(0, 1, steps=n_steps, device=dev).view(1, 1, n_steps, 1)
-        d_prop = depth_range[0] * (1.0 - t) + far.view(1, -1, 1, 1) * t
-        p_prop = ray0.unsqueeze(2) + ray_direction.unsqueeze(2) * d_prop
+        far = sphere_intersection(ray0[:, 0], ray_direction, r=rad)[0][..., 1].contiguous()
+        # sweep points ray0 + dir * (near (1 - t) + far t), t = linspace(0, 1, n_steps): one launch (csrc/sample.hip)
+        u = self._u(n_steps, dev)
+        p_prop = torch.empty(B * N, n_steps, 3, device=dev)
+        hip.sample_points(ray0.reshape(-1, 3).contiguous(), ray_direction.reshape(-1, 3).contiguous(),
+                          far.reshape(-1), p_prop, False, float(depth_range[0]), u)
         val = (self._occ(p_prop.reshape(-1, 3)) - tau).view(B, N, n_steps)
         if clip:
-            val[(p_prop > 1).any(-1)] = -1
-            val[(p_prop < -1).any(-1)] = -1
+            pp4 = p_prop.view(B, N, n_steps, 3)
+            val[(pp4 > 1).any(-1)] = -1
+            val[(pp4 < -1).any(-1)] = -1
         first_free = val[:, :, 0] < 0
         sgn = torch.cat([torch.sign(val[:, :, :-1] * val[:, :, 1:]), torch.ones(B, N, 1, device=dev)], dim=-1)
         cost = sgn * torch.arange(n_steps, 0, -1, device=dev).float()
@@ -108,11 +120,11 @@ class Renderer(nn.Module):
         has_change = values < 0
         from_free = torch.gather(val, 2, idx.unsqueeze(-1)).squeeze(-1) < 0
         mask = has_change & from_free & first_free
-        dflat = d_prop.expand(B, N, n_steps, 1).reshape(B, N, n_steps)
         idx2 = torch.clamp(idx + 1, max=n_steps - 1)
         gat = lambda src, i: torch.gather(src, 2, i.unsqueeze(-1)).reshape(-1)
-        return dict(ray0=ray0, ray_direction=ray_direction, tau=tau, mask=mask, first_free=first_free,
-                    d_low=gat(dflat, idx), f_low=gat(val, idx), d_high=gat(dflat, idx2), f_high=gat(val, idx2))
+        depth = lambda i: (float(depth_range[0]) * u[1][i] + far * u[0][i]).reshape(-1)  # the sweep depth number i
+        return dict(ray0=ray0, ray_direction=ray_direction, tau=tau, mask=mask, first_free=first_free, far=far,
+                    d_low=depth(idx), f_low=gat(val, idx), d_high=depth(idx2), f_high=gat(val, idx2))
 
     @torch.no_grad()
     def _march_finish(self, st, n_secant_steps):
@@ -181,6 +193,7 @@ class Renderer(nn.Module):
         cam = cam.reshape(-1, 3)
         rays = rays.reshape(-1, 3)
         points = (cam + rays * dists.unsqueeze(-1)).view(-1, 3)
+        self._last_far = state['far'].reshape(-1)  # sphere exit depth per ray (rendering.py:576-596), reused by unisurf
         return cam, rays, dists, obj_mask, points
 
     # ---- stage1/model/rendering.py:50-226 --------------------------------------------------------
@@ -192,60 +205,40 @@ class Renderer(nn.Module):
         steps, steps_out = cfg['num_points_in'], cfg['num_points_out']
         near = float(self.depth_range[0])
 
-        cam0 = camera_origin(N, world_mat)
-        rays0 = pixel_rays(pixels, camera_mat, world_mat)
-        rays0 = rays0 / rays0.norm(2, 2).unsqueeze(-1)
-        isect, _ = sphere_intersection(cam0[:, 0], rays0, r=cfg['radius'])
         cam, rays, dists, obj_mask, points = self._surface(pixels, camera_mat, world_mat, cfg['ray_marching_steps'])
-        isect = isect.reshape(-1, 2).clone()
-        isect[:, 0] = 0.0
+        far = self._last_far  # = sphere_intersection(cam, rays, r)[..., 1], already computed for the sweep
 
         # hit / miss ray lists ONCE (two nonzero() = the data-dependent host synchronisations of this function); every
         # gather / scatter below is an index op with them instead of a boolean mask (each of which would sync again)
         hit_idx = obj_mask.nonzero(as_tuple=True)[0]
         miss_idx = (~obj_mask).nonzero(as_tuple=True)[0]
-        d_hit = dists[hit_idx]
-        far_hit = isect[hit_idx][:, 1]
         delta = float(torch.max(cfg['interval_start'] * torch.exp(-1 * cfg['interval_decay'] * it * torch.ones(1)),
                                 cfg['interval_end'] * torch.ones(1)))  # fp32 like rendering.py:116-117
-        dnp = d_hit - delta
-        dfp = d_hit + delta
-        near_t = torch.full((), near, device=dev)
-        dnp = torch.where(dnp < near_t, near_t, dnp)
-        dfp = torch.where(dfp > far_hit, far_hit, dfp)
-        full_steps = steps + steps_out if (bool((dnp != 0.0).all()) and it > 5000) else steps
+        if near > 0:
+            nonzero_dnp = True  # dnp = max(d - delta, near) >= near > 0: the reference's (dnp != 0).all() holds
+        else:
+            dnp_t = dists[hit_idx] - delta
+            nonzero_dnp = bool((torch.where(dnp_t < near, torch.full_like(dnp_t, near), dnp_t) != 0.0).all())
+        full_steps = steps + steps_out if (nonzero_dnp and it > 5000) else steps
 
-        def jitter(d, key):
-            mid = 0.5 * (d[:, :, 1:] + d[:, :, :-1])
-            hi = torch.cat([mid, d[:, :, -1:]], dim=-1)
-            lo = torch.cat([d[:, :, :1], mid], dim=-1)
+        def draw(key, n_rays):  # stratified-jitter noise in the reference's draw order (miss rays, then hit rays)
+            if not add_noise:
+                return None
             nz = noise.get(key)
             if nz is None:
-                nz = torch.rand(B, d.shape[1], full_steps, device=dev)
-            return lo + (hi - lo) * nz.to(dev)
+                nz = torch.rand(B, n_rays, full_steps, device=dev)
+            return nz.to(dev).reshape(-1).contiguous()
 
-        far_miss = isect[miss_idx][:, 1]
-        u = torch.linspace(0.0, 1.0, steps=full_steps, device=dev).view(1, 1, -1)
-        d2 = near * (1.0 - u) + far_miss.view(1, -1, 1) * u
-        if add_noise:
-            d2 = jitter(d2, 'miss')
-        p_miss = cam[miss_idx].unsqueeze(-2) + rays[miss_idx].unsqueeze(-2) * d2[0].unsqueeze(-1)
-
-        u = torch.linspace(0.0, 1.0, steps=steps, device=dev).view(1, 1, -1)
-        d_in = dnp.view(1, -1, 1) * (1.0 - u) + dfp.view(1, -1, 1) * u
+        # depth profiles, jitter and points of both ray groups: two launches of csrc/sample.hip (rendering.py:110-176)
+        p_fg = torch.empty(B * N, full_steps, 3, device=dev)
+        hip.sample_points(cam, rays, far, p_fg, False, near, self._u(full_steps, dev), idx=miss_idx,
+                          noise=draw('miss', miss_idx.shape[0]))
         if full_steps != steps:
-            u = torch.linspace(0.0, 1.0, steps=steps_out, device=dev).view(1, 1, -1)
-            d_out = near * (1.0 - u) + dnp.view(1, -1, 1) * u
-            d1, _ = torch.sort(torch.cat([d_out, d_in], dim=-1), dim=-1)
+            hip.sample_points(cam, rays, far, p_fg, True, near, self._u(steps_out, dev), idx=hit_idx, dist=dists, delta=delta,
+                              u1=self._u(steps, dev), noise=draw('hit', hit_idx.shape[0]))
         else:
-            d1 = d_in
-        if add_noise:
-            d1 = jitter(d1, 'hit')
-        p_hit = cam[hit_idx].unsqueeze(-2) + rays[hit_idx].unsqueeze(-2) * d1[0].unsqueeze(-1)
-
-        p_fg = torch.zeros(B * N, full_steps, 3, device=dev)
-        p_fg[miss_idx] = p_miss
-        p_fg[hit_idx] = p_hit
+            hip.sample_points(cam, rays, far, p_fg, True, near, self._u(steps, dev), idx=hit_idx, dist=dists, delta=delta,
+                              noise=draw('hit', hit_idx.shape[0]))
         p_fg = p_fg.reshape(-1, 3)
         view = (-1 * rays).unsqueeze(-2).expand(-1, full_steps, -1).reshape(-1, 3)
 
