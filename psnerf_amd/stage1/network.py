@@ -122,6 +122,24 @@ class NeuralNetwork(nn.Module):
         o, g = ops.GeoField.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad, *params)
         return o[:, :1], o[:, 1:], g
 
+    @torch.no_grad()
+    def prepack(self, occupancy=False, chains=False):
+        """Build the weight packs that depend on nothing but the parameters, ahead of their first use: the occupancy
+        pack right after an optimiser step (queued behind the backward pass), the chain packs while the host waits for
+        the ray-march sweep.  All of them are cached by parameter version, so the later calls find them ready."""
+        if not self.lin0.weight_v.is_cuda:
+            return
+        if occupancy and self._hidden_is_256():
+            self._occupancy_packed()
+        if chains and self.USE_FUSED_CHAINS:
+            if self._hidden_is_256() and len(self.skips) == 1 and self.feat_size == 256 and self.n_geo <= 10 and self.d_pe <= 64:
+                self._geo_chains(self._geo_params())
+            Ws, bs = self._app_params()
+            d_x = 3 + self.d_view + 3
+            if (self.feat_size == 256 and d_x <= 64 and Ws[0].shape[0] == 256
+                    and all(w.shape == (256, 256) for w in Ws[1:-1]) and self.n_app <= 10):
+                self._app_chains(Ws, bs, d_x)
+
     def _geo_parts(self, p_flat, with_grad):
         """(logit [Q,1], features [Q,F], d logit / d p [Q,3]) of the geometry network.  256-wide networks run as
         fused register-resident chains (ops.GeoFieldFused); other widths fall back to the GEMM sequence."""

@@ -174,6 +174,8 @@ class Renderer(nn.Module):
         with the 10 ms sweep instead of preceding it."""
         steps = int(self.cfg['ray_marching_steps'])
         self._pref = (pixels, steps, self._surface_launch(pixels, camera_mat, world_mat, steps))
+        if hasattr(self.model, 'prepack'):
+            self.model.prepack(chains=True)  # the host has ~10 ms to spare while the sweep runs
 
     def _surface(self, pixels, camera_mat, world_mat, ray_steps):
         """Shared prologue of unisurf / shape_extract (rendering.py:67-108, 311-340)."""

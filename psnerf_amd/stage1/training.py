@@ -41,6 +41,9 @@ class Trainer(object):
         terms['loss'].backward()
         self.dp.allreduce_grads([p for p in self.model.parameters() if p.requires_grad])
         self.optimizer.step()
+        net = getattr(self.model, 'model', None)
+        if hasattr(net, 'prepack'):
+            net.prepack(occupancy=True)  # the next step's ray march starts with this pack: queue it behind the backward
         return terms
 
     def compute_loss(self, data, eval_mode=False, it=None, pix=None, noise=None):
