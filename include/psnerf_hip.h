@@ -117,6 +117,9 @@ typedef struct {
     int64_t b_div, b_mod;            /* b_div > 0: B is a TABLE and row k of the product reads its row (k / b_div) % b_mod
                                         (the virtual input rows of psn_mlp_infer: d W_in of a layer whose input block
                                         repeats per light or per point, summed over all K rows without expanding it) */
+    const float* B_tab2; int64_t ldb_tab2;   /* optional second table (needs b_div > 0): the columns b_split .. N-1 of the */
+    int64_t b2_div, b2_mod;                  /* virtual B come from B_tab2[(k / b2_div) % b2_mod, n - b_split]           */
+    int b_split;                             /* multiple of 4; N = b_split + columns taken from B_tab2                    */
 } PsnGemmTnItem;
 int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
                         int64_t workspace_floats, void* stream);

@@ -52,6 +52,9 @@ struct GemmArgs {
     int64_t ldb2;
     int seg_splits;
     int b_div, b_mod;  // b_div > 0 (trans_a, !trans_b only): row k of B is table row (k / b_div) % b_mod
+    const float* Bt2;  // optional second table for the columns >= b_split (own row stride and index map)
+    int64_t ldbt2;
+    int b2_div, b2_mod, b_split;
 };
 
 // Stage one 128 x 16 operand tile into registers.  KCONTIG: source rows run along k (row-major [rows][K]);
@@ -59,7 +62,8 @@ struct GemmArgs {
 template <bool KCONTIG, int ROWS>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t n_rows,
                                            int k0, int k_end, int vec_ok, int tid, float4 (&v)[ROWS / 64],
-                                           int k_div = 0, int k_mod = 0) {
+                                           int k_div = 0, int k_mod = 0, const float* __restrict__ src2 = nullptr,
+                                           int64_t ld2 = 0, int k_div2 = 0, int k_mod2 = 0, int col_split = 0) {
 #pragma unroll
     for (int u = 0; u < ROWS / 64; ++u) {
         int f = tid + 256 * u;
@@ -86,8 +90,12 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ src, int64_
             if (k < k_end) {
                 // k_div > 0: the operand is a TABLE indexed like the fused kernel's (k / k_div) % k_mod (weight
                 // gradients of an input block whose rows repeat per light or per point)
-                const int ks = k_div > 0 ? (k / k_div) % k_mod : k;
-                const float* p = src + (int64_t)ks * ld + row;
+                // col_split > 0: the columns from col_split on come from a SECOND table with its own index map (the two
+                // halves [PE(x_n) | PE(l_v)] of one input block, side by side in one product)
+                const bool second = col_split > 0 && row >= col_split;
+                const int kd = second ? k_div2 : k_div, km = second ? k_mod2 : k_mod;
+                const int ks = kd > 0 ? (k / kd) % km : k;
+                const float* p = second ? src2 + (int64_t)ks * ld2 + (row - col_split) : src + (int64_t)ks * ld + row;
                 if (vec_ok && row + 3 < n_rows) {
                     x = *reinterpret_cast<const float4*>(p);
                 } else {
@@ -179,7 +187,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t bid, float*
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #define PSN_FETCH(T)                                                                                    \
     fetch_tile<!TA, BM>(Ap, lda, m0, g.M, k_begin + (T) * BK, k_end, g.a_vec, tid, ra0);               \
-    fetch_tile<TB, BN>(Bp, ldb, n0, g.N, k_begin + (T) * BK, k_end, g.b_vec, tid, rb0, g.b_div, g.b_mod);
+    fetch_tile<TB, BN>(Bp, ldb, n0, g.N, k_begin + (T) * BK, k_end, g.b_vec, tid, rb0, g.b_div, g.b_mod, g.Bt2, g.ldbt2,   \
+                       g.b2_div, g.b2_mod, g.b_split);
 #define PSN_STORE(BUF)                                                   \
     if (TA && do_cs) {                                                   \
         cs.x += ra0[0].x + ra0[1].x; cs.y += ra0[0].y + ra0[1].y;        \
@@ -712,7 +721,7 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
     g.split_k = split_k;
     // column sums of A: straight to the caller's buffer, or per-split partials behind the C partials
     g.colsum = colsum_a == nullptr ? nullptr : (split_k > 1 ? workspace + (int64_t)split_k * M * N : colsum_a);
-    g.A2 = nullptr; g.B2 = nullptr; g.lda2 = g.ldb2 = 0; g.seg_splits = split_k; g.b_div = g.b_mod = 0;
+    g.A2 = nullptr; g.B2 = nullptr; g.lda2 = g.ldb2 = 0; g.seg_splits = split_k; g.b_div = g.b_mod = 0; g.Bt2 = nullptr; g.ldbt2 = 0; g.b2_div = g.b2_mod = g.b_split = 0;
     PSN_CHECK_ARG(g.n_tiles * split_k < (1ll << 31), "gemm: too many blocks");
     dim3 grid((unsigned)(g.n_tiles * split_k)), block(256);
 #define PSN_LAUNCH(TA_, TB_)                                                                          \
@@ -765,6 +774,8 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
                          it.ldb % 4 == 0 && it.lda >= 4 && it.ldb >= 4 && (!it.A2 || (it.lda2 % 4 == 0 && it.ldb2 % 4 == 0 && it.lda2 >= 4 && it.ldb2 >= 4));
         if (vec && it.b_div == 0 && it.M > 128 && it.N > 128 && it.M <= T256 && it.N <= T256) big_products += it.A2 ? 2 : 1;
         PSN_CHECK_ARG(it.b_div == 0 || (it.b_div > 0 && it.b_mod > 0 && !it.A2), "gemm_tn_grouped: item %d bad table mapping", i);
+        PSN_CHECK_ARG(it.B_tab2 == nullptr || (it.b_div > 0 && it.b2_div > 0 && it.b2_mod > 0 && it.b_split > 0 && it.b_split % 4 == 0 &&
+                                                it.b_split < it.N), "gemm_tn_grouped: item %d bad second table", i);
     }
     int split_big = 1, kc_big = 0;
     if (big_products > 0) {
@@ -791,6 +802,7 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         g.M = it.M; g.N = it.N; g.K = (int)K; g.A = it.A; g.lda = it.lda; g.B = it.B; g.ldb = it.ldb;
         g.A2 = it.A2; g.lda2 = it.lda2; g.B2 = it.B2; g.ldb2 = it.ldb2;
         g.b_div = (int)it.b_div; g.b_mod = (int)it.b_mod;
+        g.Bt2 = it.B_tab2; g.ldbt2 = it.ldb_tab2; g.b2_div = (int)it.b2_div; g.b2_mod = (int)it.b2_mod; g.b_split = it.b_split;
         g.bias = nullptr; g.epi = PSN_EPI_NONE; g.aux_in = g.aux_in2 = nullptr; g.aux_out = nullptr;
         g.ld_aux_in = g.ld_aux_in2 = g.ld_aux_out = 0;
         g.tiles_n = big ? 1 : (it.N + 127) / 128;
@@ -799,7 +811,8 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         g.split_k = sk * n_seg;
         g.seg_splits = sk;
         g.a_vec = (((uintptr_t)it.A & 15) == 0) && (it.lda % 4 == 0) && (!it.A2 || ((((uintptr_t)it.A2 & 15) == 0) && (it.lda2 % 4 == 0)));
-        g.b_vec = (((uintptr_t)it.B & 15) == 0) && (it.ldb % 4 == 0) && (!it.B2 || ((((uintptr_t)it.B2 & 15) == 0) && (it.ldb2 % 4 == 0)));
+        g.b_vec = (((uintptr_t)it.B & 15) == 0) && (it.ldb % 4 == 0) && (!it.B2 || ((((uintptr_t)it.B2 & 15) == 0) && (it.ldb2 % 4 == 0))) &&
+                  (!it.B_tab2 || ((((uintptr_t)it.B_tab2 & 15) == 0) && (it.ldb_tab2 % 4 == 0)));
         g.auxin_vec = g.auxin2_vec = g.auxout_vec = 0;
         const int64_t MN = (int64_t)it.M * it.N;
         g.C = workspace + ws_off;

@@ -45,7 +45,8 @@ class PsnGemmTnItem(ctypes.Structure):
     _fields_ = [('A', ctypes.c_void_p), ('lda', i64), ('B', ctypes.c_void_p), ('ldb', i64),
                 ('A2', ctypes.c_void_p), ('lda2', i64), ('B2', ctypes.c_void_p), ('ldb2', i64),
                 ('C', ctypes.c_void_p), ('ldc', i64), ('M', i32), ('N', i32), ('accumulate', i32),
-                ('colsum_a', ctypes.c_void_p), ('b_div', i64), ('b_mod', i64)]
+                ('colsum_a', ctypes.c_void_p), ('b_div', i64), ('b_mod', i64),
+                ('B_tab2', ctypes.c_void_p), ('ldb_tab2', i64), ('b2_div', i64), ('b2_mod', i64), ('b_split', i32)]
 
 
 MAX_GROUP = 12
@@ -286,6 +287,10 @@ def gemm_tn_grouped(items, split_k=None):
             else:
                 assert A.shape[0] == K and B.shape[0] == K, 'gemm_tn_grouped: all products share K'
             M, N = A.shape[1], B.shape[1]
+            Bt2 = it.get('B_tab2')
+            if Bt2 is not None:  # second table side by side: columns N .. N + Bt2.shape[1] - 1 of the virtual operand
+                assert N % 4 == 0 and int(it.get('b2_div', 0)) > 0
+                N += Bt2.shape[1]
             C = it.get('out')
             if C is None:
                 C = torch.empty(M, N, device=dev, dtype=torch.float32)
@@ -300,6 +305,9 @@ def gemm_tn_grouped(items, split_k=None):
             e.C, e.ldc, e.M, e.N = _mat_ptr(C, 'out'), _ld(C), M, N
             e.accumulate = int(bool(it.get('accumulate')))
             e.b_div, e.b_mod = b_div, b_mod
+            if Bt2 is not None:
+                e.B_tab2, e.ldb_tab2 = _mat_ptr(Bt2, 'B_tab2'), _ld(Bt2)
+                e.b2_div, e.b2_mod, e.b_split = int(it['b2_div']), int(it.get('b2_mod', Bt2.shape[0])), B.shape[1]
             e.colsum_a = None if cs is None else cs.data_ptr()
             sk = max(split_k, split_big) if is_big(it) else split_k
             need += (2 if A2 is not None else 1) * sk * M * N + sk * M + 16

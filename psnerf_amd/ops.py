@@ -549,7 +549,8 @@ class VisibilityPair(torch.autograd.Function):
         chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh_last, mask=[H[n - 2 - j] for j in range(n - 1)],
               save=DZ, save_row0=0)
         # Every weight gradient in one grouped launch.  The input block [PE(x_n) | PE(l_v)] of row k = v Ns + n is never
-        # expanded: its two halves are TABLES read as pe_x[k % Ns] and pe_lv[k // Ns] by the GEMM itself.
+        # expanded: its two halves are TABLES read as pe_x[k % Ns] and pe_lv[k // Ns] by the GEMM itself, side by side in
+        # one 128-column product.
         items = [dict(A=g, B=H[n - 2], colsum=True)]
         where = [(n - 1, 'w')]
         for li in range(n - 2, -1, -1):
@@ -558,10 +559,8 @@ class VisibilityPair(torch.autograd.Function):
                 items.append(dict(A=dz, B=H[li - 1], colsum=True))
                 where.append((li, 'w'))
             if li == 0 or li - 1 == ctx.skip_at:
-                items.append(dict(A=dz, B=pe_x, b_div=1, b_mod=Ns, colsum=(li == 0)))
-                where.append((li, 'x'))
-                items.append(dict(A=dz, B=pe_lv, b_div=Ns, b_mod=V))
-                where.append((li, 'l'))
+                items.append(dict(A=dz, B=pe_x, b_div=1, b_mod=Ns, B_tab2=pe_lv, b2_div=Ns, b2_mod=V, colsum=(li == 0)))
+                where.append((li, 'xl'))
         parts = {}
         for (li, kind), (C, cs) in zip(where, hip.gemm_tn_grouped(items)):
             parts[(li, kind)] = C
@@ -569,8 +568,8 @@ class VisibilityPair(torch.autograd.Function):
                 grads[2 * li + 1] = cs
         for li in range(n):
             blocks = [parts[(li, 'w')]] if (li, 'w') in parts else []
-            if (li, 'x') in parts:
-                blocks += [parts[(li, 'x')][:, cols_a], parts[(li, 'l')][:, cols_b]]
+            if (li, 'xl') in parts:  # columns [0, 64) = d W_x (table pe_x), [64, 128) = d W_l (table pe_lv)
+                blocks += [parts[(li, 'xl')][:, cols_a], parts[(li, 'xl')][:, pe_x.shape[1] + cols_b]]
             grads[2 * li] = blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=1)
         return (None, None, None, None, None, None) + tuple(grads)
 

@@ -215,6 +215,12 @@ def test_gemm_tn_grouped_table_operand(cuda):
     assert_close(res[1][0].cpu(), D(dz).t() @ D(pe_l).repeat_interleave(Ns, dim=0), 1e-5, 'table operand (k // Ns)')
     assert_close(res[0][1].cpu(), D(dz).sum(0), 1e-5, 'colsum')
     assert_close(res[2][0].cpu(), D(dz).t() @ D(dz), 1e-5, 'plain item in the same group')
+    # both tables side by side in one 128-column product
+    both = hip.gemm_tn_grouped([dict(A=d(dz), B=d(pe_x), b_div=1, b_mod=Ns, B_tab2=d(pe_l), b2_div=Ns, b2_mod=V, colsum=True)])[0]
+    assert both[0].shape == (256, 128)
+    assert_close(both[0][:, :64].cpu(), D(dz).t() @ D(pe_x).repeat(V, 1), 1e-5, 'two tables: first')
+    assert_close(both[0][:, 64:].cpu(), D(dz).t() @ D(pe_l).repeat_interleave(Ns, dim=0), 1e-5, 'two tables: second')
+    assert_close(both[1].cpu(), D(dz).sum(0), 1e-5, 'two tables: colsum')
 
 
 @pytest.mark.parametrize('Q', [7, 100, 4099])
