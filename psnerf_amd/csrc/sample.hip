@@ -4,8 +4,8 @@
 //   miss rays / ray-march sweep  (rendering.py:150-162, 431-436):  d = near (1 - u) + far_n u,  u = linspace(0, 1, S)
 //   hit rays                     (rendering.py:110-149, 163-176):  interval [dnp, dfp] = [max(d_n - delta, near),
 //                                  min(d_n + delta, far_n)] with `steps` samples, preceded (it > 5000) by `steps_out`
-//                                  samples of [near, dnp]; the reference sorts the concatenation, which is the identity
-//                                  because every outer depth <= dnp <= every inner depth
+//                                  samples of [near, dnp]; the reference sorts the concatenation: the identity unless
+//                                  an interval collapses, see the kernel
 //   jitter                       (rendering.py:133-141):  d_i <- lo_i + (hi_i - lo_i) noise_i, mid-point bounds
 //   points                       p = origin_n + direction_n d
 // HBM-bound: 12 S bytes written per ray (+ 4 S of noise read).  Arithmetic mirrors the reference's op order (products
@@ -55,10 +55,36 @@ __global__ __launch_bounds__(256) void sample_points_kernel(SampleArgs a) {
     } else {
         lo0 = a.near; hi0 = a.far[ray];
     }
-    float d = profile_depth(a, s, lo0, hi0, lo1, hi1);
+    // The reference SORTS the concatenated outer + inner depths (rendering.py:129).  That is the identity whenever the
+    // sequence is non-decreasing -- always, except when an interval collapses (surface within delta of the near plane:
+    // near (1 - u) + near u wobbles by an ulp) -- so the sequence is scanned once and only a non-monotonic ray pays for
+    // a rank-based selection of its sorted depths.
+    bool mono = true;
+    if (a.c1 > 0) {
+        float prev = profile_depth(a, 0, lo0, hi0, lo1, hi1);
+        for (int i = 1; i < S; ++i) {
+            const float cur = profile_depth(a, i, lo0, hi0, lo1, hi1);
+            mono = mono && (cur >= prev);
+            prev = cur;
+        }
+    }
+    auto depth_at = [&](int pos) -> float {
+        if (mono) return profile_depth(a, pos, lo0, hi0, lo1, hi1);
+        for (int j = 0; j < S; ++j) {  // the element whose (stable) rank is pos
+            const float vj = profile_depth(a, j, lo0, hi0, lo1, hi1);
+            int rank = 0;
+            for (int i = 0; i < S; ++i) {
+                const float vi = profile_depth(a, i, lo0, hi0, lo1, hi1);
+                rank += (vi < vj || (vi == vj && i < j)) ? 1 : 0;
+            }
+            if (rank == pos) return vj;
+        }
+        return profile_depth(a, pos, lo0, hi0, lo1, hi1);
+    };
+    float d = depth_at(s);
     if (a.noise != nullptr) {
-        const float dm = s > 0 ? profile_depth(a, s - 1, lo0, hi0, lo1, hi1) : d;
-        const float dp = s + 1 < S ? profile_depth(a, s + 1, lo0, hi0, lo1, hi1) : d;
+        const float dm = s > 0 ? depth_at(s - 1) : d;
+        const float dp = s + 1 < S ? depth_at(s + 1) : d;
         const float lo = s > 0 ? 0.5f * (d + dm) : d;
         const float hi = s + 1 < S ? 0.5f * (dp + d) : d;
         d = lo + (hi - lo) * a.noise[r * S + s];

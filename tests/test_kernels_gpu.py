@@ -406,3 +406,57 @@ def test_mlp_chain_activation_programs(cuda):
     r0 = torch.where(D(h5) > 0, r0, torch.zeros_like(r0))
     assert_close(dumps[0].cpu(), r0, 2e-5, 'act_init + init table')
     assert_close(dumps[1].cpu(), r0 @ D(W[2]).t(), 2e-5, 'second chain layer')
+
+
+@pytest.mark.parametrize('with_outer,with_noise', [(False, False), (True, True), (False, True)])
+def test_sample_points_bit_exact(cuda, with_outer, with_noise):
+    """psn_sample_points against the torch formulation of stage1/model/rendering.py:110-176 (the reference's op order):
+    bit-identical depths / points for hit rays (inner interval, optional outer samples) and miss rays, with and without
+    stratified jitter, rows selected through index lists."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(11)
+    N, steps, steps_out, near, delta = 777, 64, 32, 28.0, 0.35
+    S = steps + steps_out if with_outer else steps
+    cam = torch.randn(N, 3, generator=g).to(cuda)
+    rays = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(cuda)
+    far = (33.0 + torch.rand(N, generator=g)).to(cuda)
+    dist = (29.0 + 3.0 * torch.rand(N, generator=g)).to(cuda)
+    dist[:5] = near + 0.1  # dnp clamps to near
+    hit = (torch.rand(N, generator=g) < 0.6).to(cuda)
+    hit_idx, miss_idx = hit.nonzero(as_tuple=True)[0], (~hit).nonzero(as_tuple=True)[0]
+    nz_m = torch.rand(miss_idx.numel(), S, generator=g).to(cuda) if with_noise else None
+    nz_h = torch.rand(hit_idx.numel(), S, generator=g).to(cuda) if with_noise else None
+    U = lambda n: (torch.linspace(0.0, 1.0, steps=n, device=cuda), 1.0 - torch.linspace(0.0, 1.0, steps=n, device=cuda))
+    out = torch.zeros(N, S, 3, device=cuda)
+    hip.sample_points(cam, rays, far, out, False, near, U(S), idx=miss_idx, noise=nz_m)
+    if with_outer:
+        hip.sample_points(cam, rays, far, out, True, near, U(steps_out), idx=hit_idx, dist=dist, delta=delta, u1=U(steps), noise=nz_h)
+    else:
+        hip.sample_points(cam, rays, far, out, True, near, U(steps), idx=hit_idx, dist=dist, delta=delta, noise=nz_h)
+
+    def jitter(d, nz):
+        mid = 0.5 * (d[:, 1:] + d[:, :-1])
+        hi = torch.cat([mid, d[:, -1:]], dim=-1)
+        lo = torch.cat([d[:, :1], mid], dim=-1)
+        return lo + (hi - lo) * nz
+
+    u = torch.linspace(0.0, 1.0, steps=S, device=cuda).view(1, -1)
+    d2 = near * (1.0 - u) + far[miss_idx].view(-1, 1) * u
+    if with_noise:
+        d2 = jitter(d2, nz_m)
+    ref = torch.zeros(N, S, 3, device=cuda)
+    ref[miss_idx] = cam[miss_idx].unsqueeze(-2) + rays[miss_idx].unsqueeze(-2) * d2.unsqueeze(-1)
+    dh, fh = dist[hit_idx], far[hit_idx]
+    dnp, dfp = dh - delta, dh + delta
+    dnp = torch.where(dnp < near, torch.full_like(dnp, near), dnp)
+    dfp = torch.where(dfp > fh, fh, dfp)
+    u = torch.linspace(0.0, 1.0, steps=steps, device=cuda).view(1, -1)
+    d1 = dnp.view(-1, 1) * (1.0 - u) + dfp.view(-1, 1) * u
+    if with_outer:
+        uo = torch.linspace(0.0, 1.0, steps=steps_out, device=cuda).view(1, -1)
+        d_out = near * (1.0 - uo) + dnp.view(-1, 1) * uo
+        d1, _ = torch.sort(torch.cat([d_out, d1], dim=-1), dim=-1)
+    if with_noise:
+        d1 = jitter(d1, nz_h)
+    ref[hit_idx] = cam[hit_idx].unsqueeze(-2) + rays[hit_idx].unsqueeze(-2) * d1.unsqueeze(-1)
+    assert torch.equal(out, ref), 'max |diff| = %g' % float((out - ref).abs().max())
