@@ -221,6 +221,44 @@ int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* pa
                   const float* act_init, int64_t n_rows, float* out, void* stream);
 
 /* ------------------------------------------------------------------------
+ * bf16 inference engine (evaluation / relighting only; BASELINE config 5 "bf16 MFMA path ... envmap relight eval"):
+ * the 256-wide ReLU networks of stage2/model/renderer.py:34-49 on v_mfma_f32_32x32x16_bf16 -- weights, input
+ * features and post-ReLU activations rounded to bf16 (RNE), fp32 accumulation, fp32 output.  Replaces the no-grad
+ * evaluation of visibility_net in stage2/eval.py:199-218 (via renderer.py:191-200) when the caller opts in; training
+ * and every parity-gated path use psn_mlp_infer (exact fp32).
+ *
+ * Network: n_hidden hidden layers of width 256 with ReLU; layer 0 reads the input block only, layer l >= 1 reads the
+ * previous activations and, if has_in[l], the input block again (skip connection cat[y, x]); a final layer with
+ * n_out <= 32 outputs followed by out_act.  The input block of row q is
+ * [ A[(q / a_div) % a_mod, 0:64] | B[(q / b_div) % b_mod, 0:64] ] with bf16 tables of 64 columns (128-byte rows).
+ *
+ * Weight stream (bf16, one contiguous buffer, in execution order), each piece written by psn_mlp_pack_bf16:
+ *   layer 0:      input block k-steps 0..7 [W_a | W_b] natural order, 1 bias k-step            (72 KB)
+ *   layer l >= 1: activation k-steps 0..7 (permuted), 1 bias k-step (72 KB); activation k-steps 8..15 (64 KB);
+ *                 if has_in[l]: input block k-steps 0..7 (64 KB)
+ *   final:        activation k-steps 0..15 with n_ot = 1 (16 KB); its bias is added in fp32 from final_bias[32].
+ * A k-step covers 16 K indices; a bias k-step is the [256, 2] matrix (bf16(b), b - bf16(b)) packed in natural order.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_hidden;
+    int32_t n_out;
+    int32_t out_act; /* PSN_OUT_* */
+    int32_t reserved;
+    uint8_t has_in[PSN_MLP_MAX_LAYERS + 4];
+} PsnBf16Desc;
+
+/* k-steps [ks0, ks0 + n_ks) of W[rows, cols] (row-major fp32, ldw floats per row, zero-extended) for n_ot output tiles
+ * of 32 (8 = hidden layer, 1 = final layer) -> dst[n_ks][n_ot][64 lanes][8] bf16.  permuted != 0: K follows the
+ * register layout of the previous layer's activations; 0: natural order (input block, bias columns). */
+int psn_mlp_pack_bf16(const float* W, int64_t ldw, int rows, int cols, int permuted, int n_ot, int ks0, int n_ks,
+                      uint16_t* dst, void* stream);
+
+/* out [n_rows, n_out] fp32.  tab_b may be NULL (input block = table A only).  All device buffers 16-byte aligned. */
+int psn_mlp_infer_bf16(const PsnBf16Desc* desc, const uint16_t* packed_w, const float* final_bias, const uint16_t* tab_a,
+                       int64_t a_div, int64_t a_mod, const uint16_t* tab_b, int64_t b_div, int64_t b_mod, int64_t n_rows,
+                       float* out, void* stream);
+
+/* ------------------------------------------------------------------------
  * Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n:
  * stage2/model/sgbasis.py:16-32 + stage2/model/renderer.py:174-204
  *   h = normalize(l + v); D_k = exp(max(lobe_k,0) (h.n - 1)); spec_c = max(sum_k w_{c,k} D_k, 0)

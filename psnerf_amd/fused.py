@@ -165,6 +165,70 @@ def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, 
     return pack_layers(layers, ka, kb, weights[-1].shape[0], out_act, weights[0].device, width=width)
 
 
+class PackedBf16(object):
+    """A 256-wide ReLU network packed for the bf16 inference engine (csrc/mlp_infer_bf16.hip)."""
+
+    def __init__(self, desc, w, final_bias):
+        self.desc, self.w, self.final_bias = desc, w, final_bias
+
+    def __call__(self, tab_a, n_rows, a_div=1, a_mod=None, tab_b=None, b_div=1, b_mod=1, out=None):
+        """tab_a / tab_b: [n, 64] bfloat16 feature tables (the two halves of the input block)."""
+        if a_mod is None:
+            a_mod = tab_a.shape[0]
+        return hip.mlp_infer_bf16(self.desc, self.w, self.final_bias, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=out)
+
+
+def pack_relu_mlp_bf16(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE):
+    """stage2 Network (stage2/model/renderer.py:34-49) of width 256 for the bf16 engine: the input row is
+    [table A (din_a <= 64 real columns) | table B (din_b <= 64)], concatenated again AFTER layer ``skip_at``.
+    Weight stream layout: include/psnerf_hip.h (psn_mlp_infer_bf16)."""
+    n = len(weights)
+    dev = weights[0].device
+    assert n - 1 <= hip.MAX_LAYERS and din_a <= 64 and din_b <= 64
+    assert all(w.shape[0] == 256 for w in weights[:-1]) and weights[-1].shape[0] <= 32
+    desc = hip.PsnBf16Desc()
+    desc.n_hidden, desc.n_out, desc.out_act = n - 1, weights[-1].shape[0], out_act
+    KS = 8 * 512  # bf16 elements per k-step of a hidden layer
+    sizes = []
+    for li in range(n - 1):
+        has_in = li == 0 or li - 1 == skip_at
+        desc.has_in[li] = int(has_in)
+        sizes.append(9 * KS if li == 0 else (17 + (8 if has_in else 0)) * KS)
+    buf = torch.empty(sum(sizes) + 16 * 512, device=dev, dtype=torch.bfloat16)
+
+    def bias_cols(b):
+        b = b.detach().float()
+        hi = b.to(torch.bfloat16).float()
+        return torch.stack([hi, b - hi], dim=1).contiguous()
+
+    def pack_in(W_in, dst):  # [256, din_a + din_b] -> 4 k-steps of table A, 4 of table B
+        hip.mlp_pack_bf16(W_in[:, :din_a], False, 8, 0, 4, dst[:4 * KS])
+        if din_b > 0:
+            hip.mlp_pack_bf16(W_in[:, din_a:din_a + din_b], False, 8, 0, 4, dst[4 * KS:8 * KS])
+        else:
+            dst[4 * KS:8 * KS].zero_()
+
+    off = 0
+    for li in range(n - 1):
+        W = weights[li].detach().float()
+        dst = buf[off:off + sizes[li]]
+        if li == 0:
+            pack_in(W, dst)
+            hip.mlp_pack_bf16(bias_cols(biases[li]), False, 8, 0, 1, dst[8 * KS:9 * KS])
+        else:
+            W_act = W[:, :256]
+            hip.mlp_pack_bf16(W_act, True, 8, 0, 8, dst[:8 * KS])
+            hip.mlp_pack_bf16(bias_cols(biases[li]), False, 8, 0, 1, dst[8 * KS:9 * KS])
+            hip.mlp_pack_bf16(W_act, True, 8, 8, 8, dst[9 * KS:17 * KS])
+            if desc.has_in[li]:
+                pack_in(W[:, 256:], dst[17 * KS:])
+        off += sizes[li]
+    hip.mlp_pack_bf16(weights[-1].detach().float(), True, 1, 0, 16, buf[off:])
+    fb = torch.zeros(32, device=dev)
+    fb[:weights[-1].shape[0]] = biases[-1].detach().float()
+    return PackedBf16(desc, buf, fb)
+
+
 def pack_geo_occupancy(weights, biases, skips, d_pe):
     """stage1 occupancy-only network (stage1/model/network.py:85-95,124-125): softplus(beta=100)
     stack, before layer l in ``skips`` the input becomes cat[x, pe]/sqrt(2); only output row 0 of the

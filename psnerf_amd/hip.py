@@ -41,6 +41,11 @@ class PsnMlpDesc(ctypes.Structure):
                 ('init_stride', i32), ('layers', PsnMlpLayer * MAX_LAYERS)]
 
 
+class PsnBf16Desc(ctypes.Structure):
+    _fields_ = [('n_hidden', i32), ('n_out', i32), ('out_act', i32), ('reserved', i32),
+                ('has_in', ctypes.c_uint8 * (MAX_LAYERS + 4))]
+
+
 class PsnGemmTnItem(ctypes.Structure):
     _fields_ = [('A', ctypes.c_void_p), ('lda', i64), ('B', ctypes.c_void_p), ('ldb', i64),
                 ('A2', ctypes.c_void_p), ('lda2', i64), ('B2', ctypes.c_void_p), ('ldb2', i64),
@@ -75,6 +80,8 @@ SIGNATURES = {
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
                             ctypes.POINTER(ctypes.c_void_p), i64, ctypes.POINTER(ctypes.c_void_p),
                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f, i64, c_f, c_f]),
+    'psn_mlp_pack_bf16': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
+    'psn_mlp_infer_bf16': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, i64, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library out of date: fail loudly
@@ -370,6 +377,42 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
     if prof is not None:
         e1.record()
         prof.append(('mlp_infer', n_rows, e0, e1))
+    return out
+
+
+# --------------------------------------------------------------------------- bf16 inference engine (evaluation only)
+def mlp_pack_bf16(W, permuted, n_ot, ks0, n_ks, dst):
+    """k-steps [ks0, ks0 + n_ks) of the fp32 matrix W (row-major view) -> dst (flat bfloat16 view, n_ks*n_ot*512
+    elements) in fragment order of the bf16 engine."""
+    assert W.dim() == 2 and W.stride(1) == 1 and W.is_cuda and W.dtype == torch.float32
+    assert dst.dtype == torch.bfloat16 and dst.is_contiguous() and dst.numel() == n_ks * n_ot * 512
+    _check(_lib.psn_mlp_pack_bf16(W.data_ptr(), W.stride(0), W.shape[0], W.shape[1], int(permuted), n_ot, ks0, n_ks,
+                                  dst.data_ptr(), _stream()), 'mlp_pack_bf16')
+
+
+def _bf16_table(t, name):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == 64):
+        raise RuntimeError('%s: must be a contiguous [n, 64] bfloat16 HIP tensor' % name)
+    return t.data_ptr()
+
+
+def mlp_infer_bf16(desc, packed_w, final_bias, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None):
+    if out is None:
+        out = torch.empty(n_rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
+    assert packed_w.dtype == torch.bfloat16 and packed_w.is_cuda and packed_w.is_contiguous()
+    assert final_bias.numel() == 32
+    prof = PROFILE_EVENTS
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _check(_lib.psn_mlp_infer_bf16(ctypes.byref(desc), packed_w.data_ptr(), _ptr(final_bias, 'final_bias'),
+                                   _bf16_table(tab_a, 'tab_a'), a_div, a_mod, _bf16_table(tab_b, 'tab_b'), b_div, b_mod,
+                                   n_rows, _ptr(out, 'out'), _stream()), 'mlp_infer_bf16')
+    if prof is not None:
+        e1.record()
+        prof.append(('mlp_infer_bf16', n_rows, e0, e1))
     return out
 
 

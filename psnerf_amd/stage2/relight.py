@@ -70,12 +70,20 @@ def merge_output(res, total_pixels, batch_size):
 
 @torch.no_grad()
 def render_envmap(model, model_input, env_light, light_h=16, light_batch=64, pixel_chunk=None, envmap_scale=1.0,
-                  visibility=False):
+                  visibility=False, precision=None):
     """Relit image of one view: sum over the light_h x 2 light_h environment lights (eval.py:199-218).
 
     model_input: uv [1,N,2], intrinsics, pose, object_mask, normal, points, surface_mask (no lights).
     env_light: [light_h, 2*light_h, 3].  Returns rgb [N,3] (clipped to [0,1]) and, if requested, the
-    light-averaged visibility [N,3]."""
+    light-averaged visibility [N,3].  precision='bf16' evaluates visibility_net on the bf16 MFMA engine for this
+    call (PSNetwork.inference_precision; default: the model's current setting, 'fp32')."""
+    if precision is not None:
+        saved = model.inference_precision
+        model.inference_precision = precision
+        try:
+            return render_envmap(model, model_input, env_light, light_h, light_batch, pixel_chunk, envmap_scale, visibility)
+        finally:
+            model.inference_precision = saved
     dev = model_input['uv'].device
     n_pix = model_input['uv'].shape[1]
     lxyz, _areas = gen_light_xyz(light_h, 2 * light_h, envmap_radius=1)

@@ -143,6 +143,9 @@ class PSNetwork(nn.Module):
             if not self.normal_joint:
                 self.normal_net = self.normal_net.eval().requires_grad_(False)
                 self.normal_jitter_std = 0
+        # 'fp32' (default, exact) or 'bf16': gradient-free visibility_net evaluations (evaluation / relighting,
+        # stage2/eval.py:199-218) on the bf16 MFMA engine.  Never used while gradients are enabled.
+        self.inference_precision = 'fp32'
         self.visibility = conf.get_bool('train.visibility', default=False)
         self.light_vis_detach = conf.get_bool('train.light_vis_detach', default=False)
         if self.visibility:
@@ -166,6 +169,12 @@ class PSNetwork(nn.Module):
         net = self.visibility_net
         Ws, bs = net.weights()
         cols = self._cols(self.n_freqs, pe_x.device, pair=True)
+        if (fused_ok and net.width == 256 and self.inference_precision == 'bf16' and not torch.is_grad_enabled()
+                and len(Ws) <= 12 and pe_x.is_cuda):
+            # opt-in bf16 MFMA engine (evaluation / relighting only; csrc/mlp_infer_bf16.hip)
+            ns, nl = pe_x.shape[0], pe_l.shape[0]
+            return self._visibility_prepack_bf16()(pe_x.to(torch.bfloat16), ns * nl, a_div=1, a_mod=ns,
+                                                   tab_b=pe_l.to(torch.bfloat16), b_div=ns, b_mod=nl)
         if fused_ok and net.width == 256:
             params = []
             for W, b in zip(Ws, bs):
@@ -198,6 +207,19 @@ class PSNetwork(nn.Module):
                 self._vis_pack = fused.pack_relu_mlp(list(Ws), list(bs), half, half, net._skip_index())
             self._vis_pack_key = key
         return self._vis_pack
+
+    def _visibility_prepack_bf16(self):
+        """visibility-net weights in the fragment order of the bf16 engine, rebuilt only when the parameters changed."""
+        net = self.visibility_net
+        key = tuple(int(p._version) for p in net.parameters()) + (net.linears[0].weight.data_ptr(),)
+        if getattr(self, '_vis_pack16_key', None) != key:
+            Ws, bs = net.weights()
+            half = 3 + 6 * self.n_freqs
+            with torch.no_grad():
+                self._vis_pack16 = fused.pack_relu_mlp_bf16(list(Ws), list(bs), half, half, net._skip_index(),
+                                                            hip.OUT_SIGMOID if net.final == 'sigmoid' else hip.OUT_NONE)
+            self._vis_pack16_key = key
+        return self._vis_pack16
 
     def _visibility_pair_launch(self, pe_x, light_dir, light_vis_train):
         """Issue the fused launch now, attach the autograd node later (ops.VisibilityPair.launch)."""

@@ -1,0 +1,142 @@
+"""bf16 inference engine (csrc/mlp_infer_bf16.hip; BASELINE config 5 "bf16 MFMA path ... envmap relight eval").
+
+Not a parity-gated path: the reference computes in fp32 and every training / parity test uses the exact fp32 engine.
+The checks here pin the bf16 engine (a) against a float64 emulation of exactly its roundings (weights, inputs and
+post-ReLU activations rounded to bf16 RNE, bias as bf16 hi + lo, wide accumulation) -- the only differences left are
+the fp32 accumulation order and the rounding flips it causes (one bf16 ulp of one activation), tolerance 3e-3 on
+O(0.3) logits -- and (b) against the fp32 path at image level: relit images within 0.05 dB PSNR of the fp32 render
+measured against the same ground truth (north star: "rendered PSNR within 0.05 dB")."""
+import numpy as np
+import pytest
+import torch
+
+from psnerf_amd.synthetic import stage2_inputs
+from psnerf_amd import metrics
+from tests.helpers import stage2_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(din_a, din_b, depth, skip_at, n_out, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    din = din_a + din_b
+    Ws, bs = [], []
+    for li in range(depth):
+        fan_in = (din if li == 0 else 256) + (din if li - 1 == skip_at else 0)
+        out = 256 if li < depth - 1 else n_out
+        k = 1.0 / fan_in ** 0.5
+        Ws.append(((torch.rand(out, fan_in, generator=g) * 2 - 1) * k * 1.7).to(dev))
+        bs.append(((torch.rand(out, generator=g) * 2 - 1) * k).to(dev))
+    return Ws, bs
+
+
+def _emulate(Ws, bs, xa, xb, skip_at, out_act):
+    r = lambda t: t.to(torch.bfloat16).double()
+    x = r(xa) if xb is None else torch.cat([r(xa), r(xb)], dim=1)
+    h = None
+    for li in range(len(Ws) - 1):
+        bh = bs[li].to(torch.bfloat16).float()
+        b = bh.double() + r(bs[li] - bh)
+        inp = x if li == 0 else (torch.cat([h, x], dim=1) if li - 1 == skip_at else h)
+        h = r(torch.relu(inp @ r(Ws[li]).t() + b).float())
+    out = h @ r(Ws[-1]).t() + bs[-1].double()
+    if out_act == 1:
+        out = torch.sigmoid(out)
+    elif out_act == 2:
+        out = torch.sigmoid(-10.0 * out)
+    return out.float()
+
+
+def _table(n, d, seed, dev):
+    t = torch.zeros(n, 64, device=dev)
+    t[:, :d] = torch.randn(n, d, generator=torch.Generator().manual_seed(seed)).clamp(-1, 1).to(dev)
+    return t
+
+
+@pytest.mark.parametrize('nA,nB,depth,skip_at,n_out,out_act', [
+    (1000, 7, 8, 3, 1, 0),     # visibility_net shape of bear.conf, ragged tail (7000 rows = 27 workgroups + 88 rows)
+    (1000, 7, 8, 3, 1, 1),
+    (37, 3, 8, 3, 1, 0),       # less than one workgroup
+    (513, 2, 5, 1, 3, 0),      # other depth / skip position, several outputs
+    (300, 4, 4, -100, 32, 2),  # no skip connection, full final tile, occupancy output
+    (256, 1, 2, -100, 1, 0),   # one hidden layer, exactly one workgroup
+])
+def test_bf16_engine_vs_emulation(cuda, nA, nB, depth, skip_at, n_out, out_act):
+    from psnerf_amd import fused
+    Ws, bs = _net(63, 63, depth, skip_at, n_out, seed=depth + n_out, dev=cuda)
+    ta, tb = _table(nA, 63, 1, cuda), _table(nB, 63, 2, cuda)
+    pk = fused.pack_relu_mlp_bf16(Ws, bs, 63, 63, skip_at, out_act)
+    out = pk(ta.to(torch.bfloat16), nA * nB, a_div=1, a_mod=nA, tab_b=tb.to(torch.bfloat16), b_div=nA, b_mod=nB)
+    ref = _emulate(Ws, bs, ta[:, :63].tile(nB, 1), tb[:, :63].repeat_interleave(nA, dim=0), skip_at, out_act)
+    assert out.shape == (nA * nB, n_out)
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < 3e-3
+    # and it is a bf16-accurate evaluation of the fp32 network
+    p32 = fused.pack_relu_mlp(Ws, bs, 63, 63, skip_at, out_act)
+    o32 = p32(ta, nA * nB, a_div=1, a_mod=nA, tab_b=tb, b_div=nA, b_mod=nB)
+    assert (out - o32).abs().max().item() < 2e-2
+
+
+def test_bf16_engine_single_table_and_index_maps(cuda):
+    from psnerf_amd import fused
+    Ws, bs = _net(40, 0, 6, 2, 2, seed=5, dev=cuda)
+    ta = _table(90, 40, 3, cuda)
+    pk = fused.pack_relu_mlp_bf16(Ws, bs, 40, 0, 2, 0)
+    n_rows = 90 * 5 + 13
+    out = pk(ta.to(torch.bfloat16), n_rows, a_div=5, a_mod=90)  # row q reads table row (q // 5) % 90
+    idx = (torch.arange(n_rows, device=cuda) // 5) % 90
+    ref = _emulate(Ws, bs, ta[idx, :40], None, 2, 0)
+    assert (out - ref).abs().max().item() < 3e-3
+
+
+def test_bf16_engine_rejects_bad_arguments(cuda):
+    from psnerf_amd import fused
+    Ws, bs = _net(63, 63, 4, 1, 1, seed=1, dev=cuda)
+    pk = fused.pack_relu_mlp_bf16(Ws, bs, 63, 63, 1, 0)
+    with pytest.raises(RuntimeError):
+        pk(torch.zeros(10, 64, device=cuda), 10)  # fp32 table
+    with pytest.raises(RuntimeError):
+        pk(torch.zeros(10, 32, device=cuda, dtype=torch.bfloat16), 10)  # wrong table width
+
+
+def test_relight_bf16_psnr_parity(cuda):
+    """Envmap relighting (stage2/eval.py:199-218) with visibility_net on the bf16 engine: PSNR against a ground-truth
+    image within 0.05 dB of the fp32 render, and the two renders > 45 dB apart from each other."""
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.stage2 import relight
+    conf = s2.bear_conf()
+    net = s2.PSNetwork(conf)
+    net.load_state_dict(stage2_state_dict(conf, seed=12))
+    net.to(cuda).eval()
+    N, lh = 4096, 8
+    inp, _ = stage2_inputs(N, 1, 1, seed=3)
+    base = {k: inp[k].to(cuda) for k in ('uv', 'intrinsics', 'pose', 'object_mask', 'normal', 'points', 'surface_mask')}
+    env = np.random.RandomState(0).rand(lh, 2 * lh, 3).astype(np.float32) * (4.0 / (lh * 2 * lh))
+    rgb32, vis32 = relight.render_envmap(net, base, env, light_h=lh, light_batch=64, visibility=True)
+    rgb16, vis16 = relight.render_envmap(net, base, env, light_h=lh, light_batch=64, visibility=True, precision='bf16')
+    assert net.inference_precision == 'fp32'  # restored
+    assert not torch.equal(rgb32, rgb16)       # the bf16 engine really ran
+    gt = (rgb32 + 0.03 * torch.randn(rgb32.shape, generator=torch.Generator().manual_seed(0)).to(cuda)).clamp(0, 1)
+    np_ = lambda t: t.cpu().numpy()
+    p32 = metrics.PSNR(np_(rgb32), np_(gt))
+    p16 = metrics.PSNR(np_(rgb16), np_(gt))
+    assert abs(p32 - p16) < 0.05, (p32, p16)
+    assert metrics.PSNR(np_(rgb16), np_(rgb32)) > 45.0
+    assert (vis16 - vis32).abs().max().item() < 2e-2
+
+
+def test_bf16_never_used_with_gradients(cuda):
+    """inference_precision only affects gradient-free evaluations: a training forward is bit-identical."""
+    import psnerf_amd.stage2 as s2
+    conf = s2.bear_conf()
+    net = s2.PSNetwork(conf)
+    net.load_state_dict(stage2_state_dict(conf, seed=12))
+    net.to(cuda).train()
+    inp, _ = stage2_inputs(512, 4, 2, seed=3)
+    inp = {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    torch.manual_seed(0)
+    a = net(inp)['sg_rgb_values']
+    net.inference_precision = 'bf16'
+    torch.manual_seed(0)
+    b = net(inp)['sg_rgb_values']
+    assert torch.equal(a, b)
