@@ -37,10 +37,9 @@ struct Bf16Args {
     const unsigned char* w;
     const float* final_bias;
     const unsigned char* ta;
-    int64_t a_div, a_mod;
     const unsigned char* tb;
-    int64_t b_div, b_mod;
-    int64_t n_rows;
+    unsigned a_div, a_mod, b_div, b_mod;
+    unsigned n_rows;
     float* out;
 };
 
@@ -48,30 +47,38 @@ constexpr int kKsBytes = 8192;               // one k-step of a hidden layer: 8 
 constexpr int kStageBytes = 9 * kKsBytes;    // largest stage: 8 k-steps + the bias k-step
 constexpr int kBfWaves = 4;
 
-// LDS-DMA `nblk` KB of the weight stream; the 4 waves split the 1 KB blocks.
-__device__ __forceinline__ void bf_stage_dma(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int nblk, int wave, int lane) {
+// LDS-DMA 4 x NPW KB of the weight stream: wave w moves the contiguous blocks [w NPW, (w + 1) NPW) of 1 KB each.  Four
+// consecutive blocks share one base (global address and M0) and differ in the instruction offset only, so a stage costs
+// NPW global_load_lds plus ~NPW/4 address / M0 updates, no branches: the scheduler can spread them between MFMAs.
+template <int NPW>
+__device__ __forceinline__ void bf_stage_dma(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int wave, int lane) {
+    const unsigned char* g = gsrc + wave * (NPW * 1024);
+    unsigned char* l = lds_dst + wave * (NPW * 1024);
 #pragma unroll
-    for (int i = 0; i < 18; ++i) {
-        const int blk = wave + i * kBfWaves;
-        if (blk < nblk) {
-            const unsigned char* base = gsrc + blk * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (unsigned)(lane * 16)),
-                                             (__attribute__((address_space(3))) void*)(lds_dst + blk * 1024), 16, 0, 0);
+    for (int j = 0; j < NPW; ++j) {
+        const int grp = j >> 2;
+        const unsigned char* base = g + grp * 4096;
+        auto gp = (const __attribute__((address_space(1))) void*)(base + (unsigned)(lane * 16));
+        auto lp = (__attribute__((address_space(3))) void*)(l + grp * 4096);
+        switch (j & 3) {
+            case 0: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0); break;
+            case 1: __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0); break;
+            case 2: __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0); break;
+            default: __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0); break;
         }
     }
 }
 
 // NKS k-steps of one stage against the 8 output tiles, both row tiles sharing each weight fragment.  Fragments are
 // double buffered per k-step (8 ds_read_b128 = 8 KB per wave, issued at the start of the previous k-step's 16 MFMAs).
-template <int NKS, bool ZERO_C, typename RequestNext>
+template <int NKS, bool ZERO_C, int NPW, typename RequestNext>
 __device__ __forceinline__ void bf_stage_mma(floatx16 (&acc)[2][8], const bf16x8 (&b0)[NKS], const bf16x8 (&b1)[NKS],
                                              const bf16x8* __restrict__ wl, int lane, RequestNext request_next) {
     bf16x8 a[2][8];
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) a[0][ot] = wl[ot * 64 + lane];
-    __builtin_amdgcn_sched_barrier(0);
-    request_next();
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);  // the first k-step's fragments are in flight ...
+    request_next();                     // ... the NPW LDS-DMA requests are spread over the first MFMAs below
     floatx16 zero;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
@@ -86,10 +93,14 @@ __device__ __forceinline__ void bf_stage_mma(floatx16 (&acc)[2][8], const bf16x8
             acc[0][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][ot], b0[ks], (ZERO_C && ks == 0) ? zero : acc[0][ot], 0, 0, 0);
             acc[1][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][ot], b1[ks], (ZERO_C && ks == 0) ? zero : acc[1][ot], 0, 0, 0);
         }
+        // pin the order: per pair of MFMAs one fragment read of the next k-step and (k-steps 0..2) one LDS-DMA request
+        constexpr int kPerKs = 8;
+        const int dma_here = NPW - ks * kPerKs > kPerKs ? kPerKs : (NPW - ks * kPerKs > 0 ? NPW - ks * kPerKs : 0);
         if (ks + 1 < NKS) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (k < dma_here) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
         } else {
@@ -123,29 +134,39 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_bf16_kernel(Bf16Args g) {
     const int n_hidden = g.d.n_hidden;
 
     const unsigned char* wptr = g.w;  // source of the NEXT stage to request
-    bf_stage_dma(wptr, bsmem, 72, wave, lane);  // layer 0 = input block + bias (9 k-steps)
+    bf_stage_dma<18>(wptr, bsmem, wave, lane);  // layer 0 = input block + bias (9 k-steps)
     wptr += 72 * 1024;
 
-    int64_t row[2];
-    const unsigned char* pa[2];
-    const unsigned char* pb[2];
+    // rows and table offsets (n_rows < 2^31 and tables < 4 GB are checked on the host: 32-bit index arithmetic)
+    unsigned row[2], offa[2], offb[2];
+    const bool has_b = g.tb != nullptr;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        row[t] = (int64_t)blockIdx.x * (kBfWaves * 64) + wave * 64 + t * 32 + ln;
-        const int64_t rc = row[t] < g.n_rows ? row[t] : g.n_rows - 1;
-        pa[t] = g.ta + ((rc / g.a_div) % g.a_mod) * 128 + lh * 16;
-        pb[t] = g.tb != nullptr ? g.tb + ((rc / g.b_div) % g.b_mod) * 128 + lh * 16 : nullptr;
+        row[t] = blockIdx.x * (unsigned)(kBfWaves * 64) + wave * 64 + t * 32 + ln;
+        const unsigned rc = row[t] < g.n_rows ? row[t] : g.n_rows - 1;
+        offa[t] = ((rc / g.a_div) % g.a_mod) * 128u + lh * 16;
+        offb[t] = ((rc / g.b_div) % g.b_mod) * 128u + lh * 16;
     }
-    // input block: k-step s < 4 = features [16 s, 16 s + 16) of table A, s >= 4 of table B; the lane takes 8 h .. 8 h + 7
+    // input block: k-step s < 4 = features [16 s, 16 s + 16) of table A, s >= 4 of table B; the lane takes 8 h .. 8 h + 7.
+    // (a missing table B re-reads A and is zeroed afterwards: no divergent load count)
+    const unsigned char* tbp = has_b ? g.tb : g.ta;
     auto load_in = [&](bf16x8 (&bin)[2][8]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                bin[t][s] = *reinterpret_cast<const bf16x8*>(pa[t] + s * 32);
-                intx4 z = {0, 0, 0, 0};
-                bin[t][4 + s] = pb[t] != nullptr ? *reinterpret_cast<const bf16x8*>(pb[t] + s * 32) : __builtin_bit_cast(bf16x8, z);
+                bin[t][s] = *reinterpret_cast<const bf16x8*>(g.ta + offa[t] + s * 32);
+                bin[t][4 + s] = *reinterpret_cast<const bf16x8*>(tbp + (has_b ? offb[t] : offa[t]) + s * 32);
             }
+        }
+    };
+    auto mask_in = [&](bf16x8 (&bin)[2][8]) {
+        if (!has_b) {
+            const intx4 z = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 4; s < 8; ++s) bin[t][s] = __builtin_bit_cast(bf16x8, z);
         }
     };
     bf16x8 bias_b;  // K index 8 h + j: slots 0 and 1 carry the constant 1 (bias hi / lo columns)
@@ -158,16 +179,18 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_bf16_kernel(Bf16Args g) {
     bf16x8 bact[2][16];
     int gstage = 0;
 
-#define BF_STAGE(NKS, ZERO, B0, B1, NEXT_NBLK)                                                          \
-    {                                                                                                   \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
-        __syncthreads();                                                                                \
-        const bf16x8* wl = reinterpret_cast<const bf16x8*>(bsmem + (gstage & 1) * kStageBytes);         \
-        unsigned char* nxt = bsmem + ((gstage + 1) & 1) * kStageBytes;                                  \
-        const int nn_ = (NEXT_NBLK);                                                                    \
-        bf_stage_mma<NKS, ZERO>(acc, B0, B1, wl, lane, [&]() { bf_stage_dma(wptr, nxt, nn_, wave, lane); }); \
-        wptr += nn_ * 1024;                                                                             \
-        ++gstage;                                                                                       \
+    // One stage: wait for this wave's LDS-DMA pieces, barrier, then the
+    // MFMAs with the request for the next stage (4 x NPW KB; NPW = 0: none) spread between them.  ADV = bytes the
+    // weight pointer advances (the true size of the next stage; a request may over-read into the stage after it).
+#define BF_STAGE(NKS, ZERO, B0, B1, NPW, ADV)                                                            \
+    {                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+        __syncthreads();                                                                                 \
+        const bf16x8* wl = reinterpret_cast<const bf16x8*>(bsmem + (gstage & 1) * kStageBytes);          \
+        unsigned char* nxt = bsmem + ((gstage + 1) & 1) * kStageBytes;                                   \
+        bf_stage_mma<NKS, ZERO, NPW>(acc, B0, B1, wl, lane, [&]() { bf_stage_dma<NPW>(wptr, nxt, wave, lane); }); \
+        wptr += (ADV);                                                                                   \
+        ++gstage;                                                                                        \
     }
 #define BF_EPILOGUE()                                                             \
     {                                                                             \
@@ -178,37 +201,38 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_bf16_kernel(Bf16Args g) {
             }                                                                     \
     }
 
-    const int n_final_blk = 16;  // final layer: 16 k-steps x 1 output tile
     {  // layer 0: the input block only
         bf16x8 bin[2][8];
         load_in(bin);
+        mask_in(bin);
         bf16x8 s0[9], s1[9];
 #pragma unroll
         for (int s = 0; s < 8; ++s) { s0[s] = bin[0][s]; s1[s] = bin[1][s]; }
         s0[8] = bias_b; s1[8] = bias_b;
-        BF_STAGE(9, true, s0, s1, n_hidden > 1 ? 72 : n_final_blk)
+        BF_STAGE(9, true, s0, s1, 18, n_hidden > 1 ? 72 * 1024 : 16 * 1024)
         BF_EPILOGUE()
     }
     for (int li = 1; li < n_hidden; ++li) {
         const bool has_in = g.d.has_in[li] != 0;
-        const int first_next = li + 1 < n_hidden ? 72 : n_final_blk;
+        const int first_next = li + 1 < n_hidden ? 72 * 1024 : 16 * 1024;  // next layer's first stage / the final layer
         {
             bf16x8 s0[9], s1[9];
 #pragma unroll
             for (int s = 0; s < 8; ++s) { s0[s] = bact[0][s]; s1[s] = bact[1][s]; }
             s0[8] = bias_b; s1[8] = bias_b;
-            BF_STAGE(9, true, s0, s1, 64)
+            BF_STAGE(9, true, s0, s1, 16, 64 * 1024)
         }
         {
             bf16x8 s0[8], s1[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) { s0[s] = bact[0][8 + s]; s1[s] = bact[1][8 + s]; }
-            BF_STAGE(8, false, s0, s1, has_in ? 64 : first_next)
+            BF_STAGE(8, false, s0, s1, 18, has_in ? 64 * 1024 : first_next)
         }
-        if (has_in) {
+        if (has_in) {  // skip layer: cat[y, x] (fetching x earlier, under the stage above, costs more in spills than it hides)
             bf16x8 bin[2][8];
             load_in(bin);
-            BF_STAGE(8, false, bin[0], bin[1], first_next)
+            mask_in(bin);
+            BF_STAGE(8, false, bin[0], bin[1], 18, first_next)
         }
         BF_EPILOGUE()
     }
@@ -241,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_bf16_kernel(Bf16Args g) {
                         float x = f[t][0][v] + f[t][1][v] + g.final_bias[m];
                         if (g.d.out_act == PSN_OUT_SIGMOID) x = sigmoidf_(x);
                         else if (g.d.out_act == PSN_OUT_OCC) x = sigmoidf_(x * -10.0f);
-                        g.out[row[t] * n_out + m] = x;
+                        g.out[(int64_t)row[t] * n_out + m] = x;
                     }
                 }
             }
@@ -308,9 +332,11 @@ extern "C" int psn_mlp_infer_bf16(const PsnBf16Desc* desc, const uint16_t* packe
     a.final_bias = final_bias;
     a.ta = reinterpret_cast<const unsigned char*>(tab_a);
     a.tb = reinterpret_cast<const unsigned char*>(tab_b);
-    a.a_div = a_div; a.a_mod = a_mod;
-    a.b_div = b_div > 0 ? b_div : 1; a.b_mod = b_mod > 0 ? b_mod : 1;
-    a.n_rows = n_rows;
+    PSN_CHECK_ARG(n_rows < (1ll << 31) && a_div < (1ll << 31) && a_mod <= (1ll << 24) && b_div < (1ll << 31) && b_mod <= (1ll << 24),
+                  "mlp_infer_bf16: 32-bit index arithmetic: n_rows, divisors < 2^31, table rows <= 2^24");
+    a.a_div = (unsigned)a_div; a.a_mod = (unsigned)a_mod;
+    a.b_div = (unsigned)(b_div > 0 ? b_div : 1); a.b_mod = (unsigned)(b_mod > 0 ? b_mod : 1);
+    a.n_rows = (unsigned)n_rows;
     a.out = out;
     const int rows_per_block = kBfWaves * 64;
     const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;

@@ -194,7 +194,8 @@ def pack_relu_mlp_bf16(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_N
         has_in = li == 0 or li - 1 == skip_at
         desc.has_in[li] = int(has_in)
         sizes.append(9 * KS if li == 0 else (17 + (8 if has_in else 0)) * KS)
-    buf = torch.empty(sum(sizes) + 16 * 512, device=dev, dtype=torch.bfloat16)
+    # the kernel always requests a full 72 KB stage: the final layer's 16 KB block is followed by 56 KB of padding
+    buf = torch.zeros(sum(sizes) + 72 * 512, device=dev, dtype=torch.bfloat16)
 
     def bias_cols(b):
         b = b.detach().float()
@@ -223,7 +224,7 @@ def pack_relu_mlp_bf16(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_N
             if desc.has_in[li]:
                 pack_in(W[:, 256:], dst[17 * KS:])
         off += sizes[li]
-    hip.mlp_pack_bf16(weights[-1].detach().float(), True, 1, 0, 16, buf[off:])
+    hip.mlp_pack_bf16(weights[-1].detach().float(), True, 1, 0, 16, buf[off:off + 16 * 512])
     fb = torch.zeros(32, device=dev)
     fb[:weights[-1].shape[0]] = biases[-1].detach().float()
     return PackedBf16(desc, buf, fb)

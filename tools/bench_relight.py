@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Secondary measurement: stage-2 environment-map relighting (BASELINE configs[4] "... bf16 MFMA path ... envmap
+relight eval"; stage2/eval.py:199-218): one BEAR-sized view (612 x 512 pixels, surface fraction 0.9) under a
+16 x 32 lat-long environment map = 512 lights, forward only, random-init bear.conf networks, one MI355X.
+Times relight.render_envmap with visibility_net on the exact fp32 engine and on the opt-in bf16 MFMA engine and
+reports the PSNR between the two renders.  Prints one JSON line (pixel-light samples/s = surface pixels x lights / s)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--height', type=int, default=512)
+    ap.add_argument('--width', type=int, default=612)
+    ap.add_argument('--light-h', type=int, default=16)
+    ap.add_argument('--light-batch', type=int, default=64)
+    ap.add_argument('--repeat', type=int, default=2)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd import hip, metrics
+    from psnerf_amd.stage2 import relight
+    from psnerf_amd.synthetic import stage2_inputs
+    dev = torch.device('cuda:0')
+    torch.manual_seed(42)
+    net = s2.PSNetwork(s2.bear_conf()).to(dev).eval()
+    n_pix = args.height * args.width
+    inp, _ = stage2_inputs(n_pix, 1, 1, seed=0, h=args.height, w=args.width)
+    base = {k: inp[k].to(dev) for k in ('uv', 'intrinsics', 'pose', 'object_mask', 'normal', 'points', 'surface_mask')}
+    n_surf = int(base['surface_mask'].sum())
+    lh = args.light_h
+    n_lights = lh * 2 * lh
+    env = np.random.RandomState(0).rand(lh, 2 * lh, 3).astype(np.float32) * (4.0 / n_lights)
+
+    def run(precision):
+        hip.PROFILE_EVENTS = ev = []
+        rgb = relight.render_envmap(net, base, env, light_h=lh, light_batch=args.light_batch, precision=precision)
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(args.repeat):
+            del ev[:]
+            t0 = time.perf_counter()
+            rgb = relight.render_envmap(net, base, env, light_h=lh, light_batch=args.light_batch, precision=precision)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            name = 'mlp_infer_bf16' if precision == 'bf16' else 'mlp_infer'
+            big = [(n, e0.elapsed_time(e1)) for k, n, e0, e1 in ev if k == name and n >= n_surf * args.light_batch // 2]
+            if best is None or dt < best[0]:
+                best = (dt, sum(n for n, _ in big), sum(ms for _, ms in big))
+        hip.PROFILE_EVENTS = None
+        return rgb, best
+
+    rgb32, (t32, rows32, ms32) = run('fp32')
+    rgb16, (t16, rows16, ms16) = run('bf16')
+    flop_row = 2.0 * (126 * 256 + 5 * 65536 + 382 * 256 + 256)  # visibility_net of bear.conf, per (pixel, light) row
+    out = {
+        'metric': 'pixel-light samples/sec, envmap relight eval on BEAR stage2 (forward only)',
+        'unit': 'samples/s', 'data': 'synthetic', 'n_gpus': 1,
+        'config': {'workload': 'stage2 BEAR view %dx%d, %d surface pixels x %d envmap lights, light_batch %d'
+                               % (args.width, args.height, n_surf, n_lights, args.light_batch)},
+        'fp32': {'value': n_surf * n_lights / t32, 'seconds_per_view': t32, 'visibility_kernel_ms': ms32,
+                 'visibility_kernel_tflops': rows32 * flop_row / ms32 * 1e-9, 'dtype': 'f32'},
+        'bf16': {'value': n_surf * n_lights / t16, 'seconds_per_view': t16, 'visibility_kernel_ms': ms16,
+                 'visibility_kernel_tflops': rows16 * flop_row / ms16 * 1e-9, 'dtype': 'bf16 (fp32 accumulate)',
+                 'mfma_peak_frac': rows16 * flop_row / ms16 * 1e-9 / 2500.0},
+        'speedup': t32 / t16,
+        'psnr_bf16_vs_fp32_db': metrics.PSNR(rgb16.cpu().numpy(), rgb32.cpu().numpy()),
+        'max_abs_diff': float((rgb16 - rgb32).abs().max()),
+    }
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
