@@ -234,8 +234,8 @@ int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* pa
  *
  * Weight stream (bf16, one contiguous buffer, in execution order), each piece written by psn_mlp_pack_bf16:
  *   layer 0:      input block k-steps 0..7 [W_a | W_b] natural order, 1 bias k-step            (72 KB)
- *   layer l >= 1: activation k-steps 0..7 (permuted), 1 bias k-step (72 KB); activation k-steps 8..15 (64 KB);
- *                 if has_in[l]: input block k-steps 0..7 (64 KB)
+ *   layer l >= 1: activation k-steps 0..7 (permuted), 1 bias k-step (72 KB); if has_in[l]: input block k-steps 0..7
+ *                 (64 KB); activation k-steps 8..15 (64 KB)
  *   final:        activation k-steps 0..15 with n_ot = 1 (16 KB); its bias is added in fp32 from final_bias[32].
  *                 The kernel always requests whole 72 KB stages: the buffer must extend (any content) 56 KB past
  *                 the final block.

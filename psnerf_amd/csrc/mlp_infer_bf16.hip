@@ -51,62 +51,24 @@ constexpr int kBfWaves = 4;
 // consecutive blocks share one base (global address and M0) and differ in the instruction offset only, so a stage costs
 // NPW global_load_lds plus ~NPW/4 address / M0 updates, no branches: the scheduler can spread them between MFMAs.
 template <int NPW>
-__device__ __forceinline__ void bf_stage_dma(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int wave, int lane) {
+__device__ __forceinline__ void bf_dma_piece(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int wave, int lane, int j) {
     const unsigned char* g = gsrc + wave * (NPW * 1024);
     unsigned char* l = lds_dst + wave * (NPW * 1024);
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-        const int grp = j >> 2;
-        const unsigned char* base = g + grp * 4096;
-        auto gp = (const __attribute__((address_space(1))) void*)(base + (unsigned)(lane * 16));
-        auto lp = (__attribute__((address_space(3))) void*)(l + grp * 4096);
-        switch (j & 3) {
-            case 0: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0); break;
-            case 1: __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0); break;
-            case 2: __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0); break;
-            default: __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0); break;
-        }
+    const int grp = j >> 2;
+    const unsigned char* base = g + grp * 4096;
+    auto gp = (const __attribute__((address_space(1))) void*)(base + (unsigned)(lane * 16));
+    auto lp = (__attribute__((address_space(3))) void*)(l + grp * 4096);
+    switch (j & 3) {
+        case 0: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0); break;
+        case 1: __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0); break;
+        case 2: __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0); break;
+        default: __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0); break;
     }
 }
-
-// NKS k-steps of one stage against the 8 output tiles, both row tiles sharing each weight fragment.  Fragments are
-// double buffered per k-step (8 ds_read_b128 = 8 KB per wave, issued at the start of the previous k-step's 16 MFMAs).
-template <int NKS, bool ZERO_C, int NPW, typename RequestNext>
-__device__ __forceinline__ void bf_stage_mma(floatx16 (&acc)[2][8], const bf16x8 (&b0)[NKS], const bf16x8 (&b1)[NKS],
-                                             const bf16x8* __restrict__ wl, int lane, RequestNext request_next) {
-    bf16x8 a[2][8];
+template <int NPW>
+__device__ __forceinline__ void bf_stage_dma(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int wave, int lane) {
 #pragma unroll
-    for (int ot = 0; ot < 8; ++ot) a[0][ot] = wl[ot * 64 + lane];
-    __builtin_amdgcn_sched_barrier(0);  // the first k-step's fragments are in flight ...
-    request_next();                     // ... the NPW LDS-DMA requests are spread over the first MFMAs below
-    floatx16 zero;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        if (ks + 1 < NKS) {
-#pragma unroll
-            for (int ot = 0; ot < 8; ++ot) a[(ks + 1) & 1][ot] = wl[((ks + 1) * 8 + ot) * 64 + lane];
-        }
-#pragma unroll
-        for (int ot = 0; ot < 8; ++ot) {
-            acc[0][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][ot], b0[ks], (ZERO_C && ks == 0) ? zero : acc[0][ot], 0, 0, 0);
-            acc[1][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][ot], b1[ks], (ZERO_C && ks == 0) ? zero : acc[1][ot], 0, 0, 0);
-        }
-        // pin the order: per pair of MFMAs one fragment read of the next k-step and (k-steps 0..2) one LDS-DMA request
-        constexpr int kPerKs = 8;
-        const int dma_here = NPW - ks * kPerKs > kPerKs ? kPerKs : (NPW - ks * kPerKs > 0 ? NPW - ks * kPerKs : 0);
-        if (ks + 1 < NKS) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (k < dma_here) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            }
-        } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-        }
-    }
+    for (int j = 0; j < NPW; ++j) bf_dma_piece<NPW>(gsrc, lds_dst, wave, lane, j);
 }
 
 // ReLU + round-to-nearest-even bf16 of accumulator registers [8 qp, 8 qp + 8): the next layer's B operand.
@@ -123,6 +85,87 @@ __device__ __forceinline__ bf16x8 bf_pack_relu(const floatx16& c, int qp) {
         o[i] = __builtin_bit_cast(int, s);
     }
     return __builtin_bit_cast(bf16x8, o);
+}
+
+// Epilogue of output-tile pair q (tiles 2q, 2q+1, both row tiles) = 8 jobs of 16 VALU instructions (8 accumulator
+// reads, 4 cvt, 4 max); job j writes B operand k-step 2 ot + qp of row tile t in place.
+__device__ __forceinline__ void bf_epilogue_job(const floatx16 (&acc)[2][8], bf16x8 (&bact)[2][16], int q, int j) {
+    const int ot = 2 * q + (j >> 2), t = (j >> 1) & 1, qp = j & 1;
+    bact[t][2 * ot + qp] = bf_pack_relu(acc[t][ot], qp);
+}
+
+enum { BF_SRC_ACT_LO = 0, BF_SRC_ACT_HI = 1, BF_SRC_IN = 2, BF_SRC_INB = 3 };  // B operands of a stage (+ bias k-step: ACT_LO, INB)
+enum { BF_EPI_NONE = 0, BF_EPI_FIRST = 1, BF_EPI_LAST = 2 };
+
+// One stage (8 or 9 k-steps) in OUTPUT-TILE-PAIR-major order: pair p = tiles 2p, 2p+1 runs through all k-steps of the
+// stage (4 MFMAs per k-step: 2 tiles x 2 row tiles, so consecutive MFMAs on one accumulator are 4 apart) before
+// pair p+1 starts.  In the LAST stage of a layer pair p is therefore final after (p+1)/4 of the stage, and its
+// epilogue (accumulator -> ReLU -> bf16 B operand, VALU only) is issued in the MFMA gaps of later pairs -- with one
+// wave per SIMD nothing else could hide it:
+//   LAST  stage of layer l  :  P0 | P1 + E(l,0) | P2 + E(l,1) | P3
+//   FIRST stage of layer l+1:  P0 + E(l,2) | P1 + E(l,3) | P2 | P3
+// E(l,0..1) produce k-steps 0..7 (all the FIRST stage reads), E(l,2..3) k-steps 8..15 (read by the second stage), and
+// they read the accumulators of pairs 2, 3 before this stage's P2 / P3 overwrite them.  All writes are in place:
+// a stage never reads the k-steps its jobs write.
+// Weight fragments: 2 ds_read_b128 per k-step, ring of 3 (requested two k-steps = 256 MFMA cycles ahead).
+template <int SRC, int EPI, int NPW, typename RequestPiece>
+__device__ __forceinline__ void bf_stage_mma(floatx16 (&acc)[2][8], bf16x8 (&bact)[2][16], const bf16x8 (&bin)[2][8],
+                                             const bf16x8& bias_b, const bf16x8* __restrict__ wl, int lane,
+                                             RequestPiece request_piece) {
+    constexpr int NKS = (SRC == BF_SRC_ACT_LO || SRC == BF_SRC_INB) ? 9 : 8;
+    constexpr bool ZERO_C = SRC == BF_SRC_ACT_LO || SRC == BF_SRC_INB;  // first stage of its layer
+    constexpr int NSTEP = 4 * NKS;
+    constexpr int DMA_PAIR = EPI == BF_EPI_FIRST ? 2 : 0;  // the pair whose gaps carry the LDS-DMA requests (one without jobs)
+    auto bop = [&](int t, int ks) -> bf16x8 {
+        if constexpr (SRC == BF_SRC_ACT_LO) return ks < 8 ? bact[t][ks] : bias_b;
+        else if constexpr (SRC == BF_SRC_ACT_HI) return bact[t][8 + ks];
+        else if constexpr (SRC == BF_SRC_IN) return bin[t][ks];
+        else return ks < 8 ? bin[t][ks] : bias_b;
+    };
+    auto frag = [&](int step, int o) -> bf16x8 { return wl[((step % NKS) * 8 + 2 * (step / NKS) + o) * 64 + lane]; };
+    bf16x8 a[3][2];
+    a[0][0] = frag(0, 0); a[0][1] = frag(0, 1);
+    a[1][0] = frag(1, 0); a[1][1] = frag(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    floatx16 zero;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+        const int p = step / NKS, ks = step % NKS;
+        const int dma_left = p == DMA_PAIR ? NPW - 4 * ks : 0;  // one request per MFMA of the DMA pair until all NPW are out
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m < dma_left) request_piece(4 * ks + m);
+        if (step + 2 < NSTEP) {
+            a[(step + 2) % 3][0] = frag(step + 2, 0);
+            a[(step + 2) % 3][1] = frag(step + 2, 1);
+        }
+        const bf16x8 b0 = bop(0, ks), b1 = bop(1, ks);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int ot = 2 * p + o;
+            acc[0][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step % 3][o], b0, (ZERO_C && ks == 0) ? zero : acc[0][ot], 0, 0, 0);
+            acc[1][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step % 3][o], b1, (ZERO_C && ks == 0) ? zero : acc[1][ot], 0, 0, 0);
+        }
+        int q = -1;
+        if (EPI == BF_EPI_FIRST && p < 2) q = 2 + p;
+        if (EPI == BF_EPI_LAST && (p == 1 || p == 2)) q = p - 1;
+        const bool job = q >= 0 && ks < 8;
+        if (job) bf_epilogue_job(acc, bact, q, ks);
+        // pin the order of this k-step: 2 fragment reads, then per MFMA 4 epilogue VALU (if any) and, in the DMA pair,
+        // one LDS-DMA request per MFMA until all NPW are out
+        if (step + 2 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (m < dma_left) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (job) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        // region boundary per k-step: the accumulator reads of a job are COPYs until register allocation (no scheduling
+        // group matches them) and would otherwise all float to the top of the stage, ahead of the first MFMA
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 __global__ __launch_bounds__(256, 1) void mlp_infer_bf16_kernel(Bf16Args g) {
@@ -179,63 +222,51 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_bf16_kernel(Bf16Args g) {
     bf16x8 bact[2][16];
     int gstage = 0;
 
-    // One stage: wait for this wave's LDS-DMA pieces, barrier, then the
-    // MFMAs with the request for the next stage (4 x NPW KB; NPW = 0: none) spread between them.  ADV = bytes the
-    // weight pointer advances (the true size of the next stage; a request may over-read into the stage after it).
-#define BF_STAGE(NKS, ZERO, B0, B1, NPW, ADV)                                                            \
+    // One stage: wait for this wave's LDS-DMA pieces, barrier, then the MFMAs with the request for the next stage
+    // (4 x NPW KB) and the epilogue jobs in their gaps.  ADV = bytes the weight pointer advances (the true size of
+    // the next stage; a request may over-read into the stage after it).
+#define BF_STAGE(SRC, EPI, NPW, ADV)                                                                     \
     {                                                                                                    \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
         __syncthreads();                                                                                 \
         const bf16x8* wl = reinterpret_cast<const bf16x8*>(bsmem + (gstage & 1) * kStageBytes);          \
         unsigned char* nxt = bsmem + ((gstage + 1) & 1) * kStageBytes;                                   \
-        bf_stage_mma<NKS, ZERO, NPW>(acc, B0, B1, wl, lane, [&]() { bf_stage_dma<NPW>(wptr, nxt, wave, lane); }); \
+        if ((EPI) == BF_EPI_FIRST) { /* pairs 2, 3 enter the stage in AGPRs: their reads then sit at the jobs, not at the top of the block */ \
+            asm volatile("" : "+a"(acc[0][4]), "+a"(acc[1][4]), "+a"(acc[0][5]), "+a"(acc[1][5]),       \
+                              "+a"(acc[0][6]), "+a"(acc[1][6]), "+a"(acc[0][7]), "+a"(acc[1][7]));      \
+        }                                                                                                \
+        bf_stage_mma<SRC, EPI, NPW>(acc, bact, bin, bias_b, wl, lane, [&](int j_) { bf_dma_piece<NPW>(wptr, nxt, wave, lane, j_); }); \
+        if ((EPI) == BF_EPI_FIRST) { /* k-steps 8..15 are first READ two stages on: without a use here hipcc sinks their epilogue there */ \
+            _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                                            \
+                asm volatile("" :: "v"(bact[t_][8]), "v"(bact[t_][9]), "v"(bact[t_][10]), "v"(bact[t_][11]), \
+                                   "v"(bact[t_][12]), "v"(bact[t_][13]), "v"(bact[t_][14]), "v"(bact[t_][15])); \
+        }                                                                                                \
         wptr += (ADV);                                                                                   \
         ++gstage;                                                                                        \
     }
-#define BF_EPILOGUE()                                                             \
-    {                                                                             \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t)                             \
-            _Pragma("unroll") for (int ot = 0; ot < 8; ++ot) {                    \
-                bact[t][2 * ot] = bf_pack_relu(acc[t][ot], 0);                    \
-                bact[t][2 * ot + 1] = bf_pack_relu(acc[t][ot], 1);                \
-            }                                                                     \
-    }
 
-    {  // layer 0: the input block only
-        bf16x8 bin[2][8];
-        load_in(bin);
-        mask_in(bin);
-        bf16x8 s0[9], s1[9];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) { s0[s] = bin[0][s]; s1[s] = bin[1][s]; }
-        s0[8] = bias_b; s1[8] = bias_b;
-        BF_STAGE(9, true, s0, s1, 18, n_hidden > 1 ? 72 * 1024 : 16 * 1024)
-        BF_EPILOGUE()
-    }
+    bf16x8 bin[2][8];
+    // layer 0: the input block only (its own LAST stage; no previous layer)
+    load_in(bin);
+    mask_in(bin);
+    BF_STAGE(BF_SRC_INB, BF_EPI_LAST, 18, n_hidden > 1 ? 72 * 1024 : 16 * 1024)
     for (int li = 1; li < n_hidden; ++li) {
         const bool has_in = g.d.has_in[li] != 0;
         const int first_next = li + 1 < n_hidden ? 72 * 1024 : 16 * 1024;  // next layer's first stage / the final layer
-        {
-            bf16x8 s0[9], s1[9];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) { s0[s] = bact[0][s]; s1[s] = bact[1][s]; }
-            s0[8] = bias_b; s1[8] = bias_b;
-            BF_STAGE(9, true, s0, s1, 16, 64 * 1024)
-        }
-        {
-            bf16x8 s0[8], s1[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) { s0[s] = bact[0][8 + s]; s1[s] = bact[1][8 + s]; }
-            BF_STAGE(8, false, s0, s1, 18, has_in ? 64 * 1024 : first_next)
-        }
-        if (has_in) {  // skip layer: cat[y, x] (fetching x earlier, under the stage above, costs more in spills than it hides)
-            bf16x8 bin[2][8];
+        BF_STAGE(BF_SRC_ACT_LO, BF_EPI_FIRST, 16, 64 * 1024)
+        if (has_in) {  // skip layer cat[y, x]: the input block goes in the middle, so that every layer ends with the same stage
             load_in(bin);
             mask_in(bin);
-            BF_STAGE(8, false, bin[0], bin[1], 18, first_next)
+            BF_STAGE(BF_SRC_IN, BF_EPI_NONE, 16, 64 * 1024)
         }
-        BF_EPILOGUE()
+        BF_STAGE(BF_SRC_ACT_HI, BF_EPI_LAST, 18, first_next)
     }
+    // the last hidden layer's pairs 2, 3 have no following stage to hide in
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bf_epilogue_job(acc, bact, 2, j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bf_epilogue_job(acc, bact, 3, j);
+#undef BF_STAGE
     // final layer: one output tile (n_out <= 32); two accumulator chains per row tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -271,8 +302,6 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_bf16_kernel(Bf16Args g) {
             }
         }
     }
-#undef BF_STAGE
-#undef BF_EPILOGUE
 }
 
 // W[rows, cols] (row-major, ldw floats per row), zero-extended, k-steps [ks0, ks0 + n_ks) -> [ks][ot][lane][8] bf16:

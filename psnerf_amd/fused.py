@@ -220,9 +220,11 @@ def pack_relu_mlp_bf16(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_N
             W_act = W[:, :256]
             hip.mlp_pack_bf16(W_act, True, 8, 0, 8, dst[:8 * KS])
             hip.mlp_pack_bf16(bias_cols(biases[li]), False, 8, 0, 1, dst[8 * KS:9 * KS])
-            hip.mlp_pack_bf16(W_act, True, 8, 8, 8, dst[9 * KS:17 * KS])
+            hi = 9 * KS
             if desc.has_in[li]:
-                pack_in(W[:, 256:], dst[17 * KS:])
+                pack_in(W[:, 256:], dst[9 * KS:17 * KS])
+                hi = 17 * KS
+            hip.mlp_pack_bf16(W_act, True, 8, 8, 8, dst[hi:hi + 8 * KS])
         off += sizes[li]
     hip.mlp_pack_bf16(weights[-1].detach().float(), True, 1, 0, 16, buf[off:off + 16 * 512])
     fb = torch.zeros(32, device=dev)
