@@ -60,9 +60,10 @@ constexpr int kWaves = 4;  // per workgroup; two workgroups share a CU (2 waves 
 // sets: the reads of group g+1 are issued at the START of group g's MFMA stream (1024 MFMA cycles ahead).  With a
 // single set hipcc can only issue them behind the last six MFMAs (192 cycles), which does not cover the LDS queueing
 // when the eight waves of a CU, barrier-aligned, all ask for their 8 KB at the same moment (PMC: matrix pipe 83 % busy).
-// `request_next` issues the LDS-DMA of the next weight stage; it is placed BEHIND the first group's fragment reads so
-// that its ~50 issue slots (address arithmetic, M0 updates, 8 global_load_lds) fall into the LDS latency the wave has to
-// sit out anyway, instead of delaying the first MFMA of the stage.
+// `request_next(j)` issues LDS-DMA piece j of the next weight stage.  The pieces are requested BEHIND the first group's
+// fragment reads and spread over its first MFMAs (sched_group_barrier): issued as a block ahead of the first MFMA their
+// ~50 issue slots were the largest single loss of the kernel (8 % when measured by removing the stream); a piece's
+// issue fits into the 32-cycle gap of an MFMA.
 template <int NMT, int NACC, typename RequestNext>
 __device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx4& b0, const floatx4& b1,
                                               const float4* __restrict__ wl, int lane, RequestNext request_next) {
@@ -72,9 +73,10 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx
         float4 a[2][8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) a[0][m] = wl[m * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);  // the first group's reads are in flight (exposed once per stage) ...
-        request_next();
-        __builtin_amdgcn_sched_barrier(0);  // ... while the next stage is requested
+        __builtin_amdgcn_sched_barrier(0);  // the first group's reads are in flight (exposed once per stage)
+        constexpr int NPW = NMT / 2;        // LDS-DMA pieces of the next stage per wave: spread over the first MFMAs below
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) request_next(j);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int e = g / GE, m0 = (g % GE) * 8;
@@ -99,6 +101,7 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx
                 for (int k = 0; k < 4; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (g == 0) __builtin_amdgcn_sched_group_barrier(0x020, NPW / 4, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
             } else {
@@ -106,7 +109,8 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx
             }
         }
     } else {
-        request_next();
+#pragma unroll
+        for (int j = 0; j < NMT / 2; ++j) request_next(j);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const floatx4& bs = e ? b1 : b0;
@@ -125,19 +129,29 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx
     }
 }
 
-// LDS-DMA one stage (NBLK x 1 KB) of packed weights; the 4 waves split the blocks (compile-time trip count, no
-// kernarg reloads inside the stage: an s_load there forces s_waitcnt lgkmcnt(0), which also drains the LDS reads).
+// LDS-DMA one stage (NBLK x 1 KB) of packed weights; wave w moves the contiguous blocks [w NBLK/4, (w+1) NBLK/4): four
+// consecutive 1 KB pieces share one base (global address and M0) and differ in the instruction offset only
+// (compile-time trip count, no kernarg reloads inside the stage: an s_load there forces s_waitcnt lgkmcnt(0), which
+// also drains the LDS reads).
+template <int NBLK>
+__device__ __forceinline__ void stage_piece(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane, int j) {
+    constexpr int NPW = NBLK / kWaves;
+    static_assert(NBLK % kWaves == 0, "stage size");
+    const int grp = j >> 2;
+    const char* base = reinterpret_cast<const char*>(gsrc + (wave * NPW + grp * 4) * 256);  // uniform (SGPR pair) + 32-bit lane offset
+    auto gp = (const __attribute__((address_space(1))) void*)(base + (unsigned)(lane * 16));
+    auto lp = (__attribute__((address_space(3))) void*)(lds_dst + (wave * NPW + grp * 4) * 256);
+    switch (j & 3) {
+        case 0: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0); break;
+        case 1: __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0); break;
+        case 2: __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0); break;
+        default: __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0); break;
+    }
+}
 template <int NBLK>
 __device__ __forceinline__ void stage_load(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < (NBLK + kWaves - 1) / kWaves; ++i) {
-        const int blk = wave + i * kWaves;
-        if (NBLK % kWaves == 0 || blk < NBLK) {
-            const char* base = reinterpret_cast<const char*>(gsrc + blk * 256);  // uniform (SGPR pair) + 32-bit lane offset
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (unsigned)(lane * 16)),
-                                             (__attribute__((address_space(3))) void*)(lds_dst + blk * 256), 16, 0, 0);
-        }
-    }
+    for (int j = 0; j < NBLK / kWaves; ++j) stage_piece<NBLK>(gsrc, lds_dst, wave, lane, j);
 }
 
 __device__ __forceinline__ floatx4 ld4(const float* p) {
@@ -301,13 +315,10 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         const int s_ = (S_IDX);                                                                             \
         float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);             \
-        stage_compute<NMT, NMT>(acc, B0, B1, wl, lane, [&]() {                                                   \
-            if (s_ + 1 < n_st) {                                                                            \
-                stage_load<2 * (NMT)>(wl_g + (int64_t)(s_ + 1) * stage_floats, nxt, wave, lane);            \
-            } else if (next_w != nullptr) {                                                                 \
-                stage_load<2 * NMT>(next_w, nxt, wave, lane);                                                  \
-            }                                                                                               \
-        });                                                                                                 \
+        /* branch-free request (a branch would end the scheduling region the pieces are spread over): after the very \
+           last stage the idle buffer receives a copy of the first one */                                   \
+        const float* src_ = s_ + 1 < n_st ? wl_g + (int64_t)(s_ + 1) * stage_floats : (next_w != nullptr ? next_w : g.w); \
+        stage_compute<NMT, NMT>(acc, B0, B1, wl, lane, [&](int j_) { stage_piece<2 * (NMT)>(src_, nxt, wave, lane, j_); }); \
         ++gstage;                                                                                           \
     }
 
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         __syncthreads();
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
 #pragma unroll
-        for (int kt = 0; kt < NMT / 2; ++kt) stage_compute<2, NMT>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane, []() {});
+        for (int kt = 0; kt < NMT / 2; ++kt) stage_compute<2, NMT>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane, [](int) {});
     }
 #undef PSN_STAGE
 
