@@ -59,7 +59,7 @@ def main():
 
     rgb32, (t32, rows32, ms32) = run('fp32')
     rgb16, (t16, rows16, ms16) = run('bf16')
-    flop_row = 2.0 * (126 * 256 + 5 * 65536 + 382 * 256 + 256)  # visibility_net of bear.conf, per (pixel, light) row
+    flop_row = 2.0 * sum(l.weight.numel() for l in net.visibility_net.linears)  # per (pixel, light) row: 523,520 MAC for bear.conf
     out = {
         'metric': 'pixel-light samples/sec, envmap relight eval on BEAR stage2 (forward only)',
         'unit': 'samples/s', 'data': 'synthetic', 'n_gpus': 1,
