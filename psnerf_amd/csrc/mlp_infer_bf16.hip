@@ -1,7 +1,8 @@
 // bf16 inference engine for the 256-wide ReLU networks of stage 2 -- the evaluation / relighting path only
 // (BASELINE config 5: "bf16 MFMA path ... envmap relight eval"; stage2/eval.py:199-218 evaluates visibility_net on
 // 512 environment lights x every surface pixel, no gradients).  Training and every parity-gated path stay on the
-// exact-fp32 engine of mlp_infer.hip; this kernel is opt-in (PSNetwork.inference_precision = 'bf16').
+// exact-fp32 engine of mlp_infer.hip; this kernel is opt-in (PSNetwork.inference_precision = 'bf16'; conf train.vis_bf16
+// for the detached shading rows of a training step).
 //
 // Same idea as the fp32 engine -- activations never leave registers, the D registers of one layer are the B
 // operands of the next through a permuted K order -- re-tiled for v_mfma_f32_32x32x16_bf16 (16x the fp32 rate):
@@ -18,10 +19,12 @@
 // Workgroup = 4 waves = 256 rows, one workgroup per CU (1 wave per SIMD, 512 registers): at 16x the MFMA rate the
 // weight stream, not the matrix pipe, is what has to be amortised -- 256 rows per pass keep it at ~3.8 KB per row
 // from L2 and the fragment reads at a quarter of the LDS bandwidth.  Weights stream through LDS by LDS-DMA in stages
-// of 8-9 k-steps (64 / 72 KB), double buffered.
+// of 8-9 k-steps (64 / 72 KB), double buffered.  With one wave per SIMD nothing hides a block of non-MFMA work, but
+// ~5 single-issue instructions fit into the 32-cycle gap behind each MFMA: stages run output-tile-pair-major and the
+// epilogue of a pair is issued in the gaps of the pairs that follow it (bf_stage_mma).
 //
-// Roofline: MFMA-bound in bf16 (2.5 PFLOP/s dense): per layer and wave 256-272 MFMAs (32 cycles each) against
-// ~640 VALU instructions of epilogue (accumulator reads, cvt, max).
+// Roofline: MFMA-bound in bf16 (2.5 PFLOP/s dense).  Measured: 1.35 PFLOP/s algorithmic on the visibility net of
+// bear.conf (0.54 of the peak), matrix pipe 67 % busy at 2.25 GHz.
 #include "common.h"
 
 namespace psn {

@@ -146,6 +146,10 @@ class PSNetwork(nn.Module):
         # 'fp32' (default, exact) or 'bf16': gradient-free visibility_net evaluations (evaluation / relighting,
         # stage2/eval.py:199-218) on the bf16 MFMA engine.  Never used while gradients are enabled.
         self.inference_precision = 'fp32'
+        # opt-in, NOT the reference's arithmetic (default off; every parity test and the headline benchmark run without
+        # it): during training, the L shading-light visibility rows -- which only enter the loss detached,
+        # renderer.py:197 -- are evaluated on the bf16 engine (max |d| ~ 2e-3 on the visibility value).
+        self.train_vis_bf16 = conf.get_bool('train.vis_bf16', default=False)
         self.visibility = conf.get_bool('train.visibility', default=False)
         self.light_vis_detach = conf.get_bool('train.light_vis_detach', default=False)
         if self.visibility:
@@ -171,10 +175,8 @@ class PSNetwork(nn.Module):
         cols = self._cols(self.n_freqs, pe_x.device, pair=True)
         if (fused_ok and net.width == 256 and self.inference_precision == 'bf16' and not torch.is_grad_enabled()
                 and len(Ws) <= 12 and pe_x.is_cuda):
-            # opt-in bf16 MFMA engine (evaluation / relighting only; csrc/mlp_infer_bf16.hip)
-            ns, nl = pe_x.shape[0], pe_l.shape[0]
-            return self._visibility_prepack_bf16()(pe_x.to(torch.bfloat16), ns * nl, a_div=1, a_mod=ns,
-                                                   tab_b=pe_l.to(torch.bfloat16), b_div=ns, b_mod=nl)
+            # opt-in bf16 MFMA engine (evaluation / relighting; csrc/mlp_infer_bf16.hip)
+            return self._visibility_rows_bf16(pe_x, pe_l)
         if fused_ok and net.width == 256:
             params = []
             for W, b in zip(Ws, bs):
@@ -207,6 +209,13 @@ class PSNetwork(nn.Module):
                 self._vis_pack = fused.pack_relu_mlp(list(Ws), list(bs), half, half, net._skip_index())
             self._vis_pack_key = key
         return self._vis_pack
+
+    @torch.no_grad()
+    def _visibility_rows_bf16(self, pe_x, pe_l):
+        """Gradient-free visibility_net rows (light-major) on the bf16 MFMA engine."""
+        ns, nl = pe_x.shape[0], pe_l.shape[0]
+        return self._visibility_prepack_bf16()(pe_x.to(torch.bfloat16), ns * nl, a_div=1, a_mod=ns,
+                                               tab_b=pe_l.to(torch.bfloat16), b_div=ns, b_mod=nl)
 
     def _visibility_prepack_bf16(self):
         """visibility-net weights in the fragment order of the bf16 engine, rebuilt only when the parameters changed."""
@@ -266,6 +275,7 @@ class PSNetwork(nn.Module):
         # node is attached at the reference's position in the graph, further down.
         pe_x = None
         vis_pair = None
+        vis_bf16 = None
         if ns > 0 and self.visibility:
             lv0 = input.get('light_vis_train')
             ld0 = input['light_direction']
@@ -273,7 +283,13 @@ class PSNetwork(nn.Module):
                     and self.visibility_net.width == 256 and torch.is_grad_enabled()
                     and (self.light_vis_detach or not (ld0.requires_grad or lv0.requires_grad))):
                 pe_x = self._pe(surf, self.n_freqs)
-                vis_pair = self._visibility_pair_launch(pe_x, ld0, lv0)
+                if self.train_vis_bf16:
+                    # opt-in (train.vis_bf16): the L shading rows enter the loss detached (renderer.py:197), so they can
+                    # run on the bf16 engine; the V supervised rows stay on the exact fp32 path with their dumps
+                    vis_bf16 = self._visibility_rows_bf16(pe_x, self._pe(ld0.detach(), self.n_freqs))
+                    vis_pair = self._visibility_pair_launch(pe_x, ld0[:0], lv0)
+                else:
+                    vis_pair = self._visibility_pair_launch(pe_x, ld0, lv0)
         if self.normal_mlp:  # renderer.py:127-143
             normal_pred = torch.ones_like(points)
             if ns > 0:
@@ -344,7 +360,11 @@ class PSNetwork(nn.Module):
                            and (self.light_vis_detach or not (light_dir.requires_grad or lv.requires_grad)))
                 if pair_ok:
                     # shading rows and supervision rows in ONE fused launch (the latter dump their activations)
-                    vis, vis_t_pre = self._visibility_pair(pe_x, light_dir, lv, launched=vis_pair)
+                    if vis_bf16 is not None:
+                        _none, vis_t_pre = self._visibility_pair(pe_x, light_dir[:0], lv, launched=vis_pair)
+                        vis = vis_bf16
+                    else:
+                        vis, vis_t_pre = self._visibility_pair(pe_x, light_dir, lv, launched=vis_pair)
                 else:
                     # gradient-free unless a caller backpropagates into output['visibility']
                     vis = self._visibility_rows(pe_x, light_dir, fused_ok=True)  # [L*Ns, 1], light-major

@@ -140,3 +140,34 @@ def test_bf16_never_used_with_gradients(cuda):
     torch.manual_seed(0)
     b = net(inp)['sg_rgb_values']
     assert torch.equal(a, b)
+
+
+def test_train_vis_bf16_option(cuda):
+    """conf train.vis_bf16 (opt-in, default off): only the detached L shading rows move to the bf16 engine; the
+    supervised visibility rows, every gradient path and the loss structure are unchanged, so the loss terms stay
+    within 1e-4 relative of the fp32 step and vis_loss is bit-identical."""
+    import psnerf_amd.stage2 as s2
+    conf = s2.bear_conf()
+    sd = stage2_state_dict(conf, seed=12)
+    inp, gt = stage2_inputs(1024, 6, 3, seed=3)
+    inp = {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    gt = {k: v.to(cuda) for k, v in gt.items()}
+    res = {}
+    for flag in (False, True):
+        net = s2.PSNetwork(conf)
+        net.load_state_dict(sd)
+        net.to(cuda).train()
+        assert net.train_vis_bf16 is False  # default
+        net.train_vis_bf16 = flag
+        torch.manual_seed(0)
+        out = net(inp)
+        loss = s2.MainLoss(1.0, 'L1', 0.01, 0.01, 1.0)(out, gt, inp)
+        loss['loss'].backward()
+        g = torch.cat([p.grad.flatten() for p in net.parameters() if p.grad is not None])
+        res[flag] = (out, {k: float(v.detach()) for k, v in loss.items()}, g)
+    (o0, l0, g0), (o1, l1, g1) = res[False], res[True]
+    assert not torch.equal(o0['visibility'], o1['visibility'])      # the bf16 engine ran for the shading rows
+    assert torch.equal(o0['vis_train'], o1['vis_train'])            # supervised rows: exact fp32 path
+    assert l0['vis_loss'] == l1['vis_loss']
+    assert abs(l0['sg_rgb_loss'] - l1['sg_rgb_loss']) <= 1e-4 * abs(l0['sg_rgb_loss'])
+    assert float((g1 - g0).norm() / g0.norm()) < 1e-3
