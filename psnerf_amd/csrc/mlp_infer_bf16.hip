@@ -374,14 +374,11 @@ extern "C" int psn_mlp_infer_bf16(const PsnBf16Desc* desc, const uint16_t* packe
     const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer_bf16: too many rows");
     const size_t lds_bytes = 2 * kStageBytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_infer_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) {
-            set_error("mlp_infer_bf16: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
-            return PSN_E_LAUNCH;
-        }
-        attr_set = true;
+    // 144 KB of dynamic LDS need the opt-in attribute; set per call (per-device state, cheap, no static flag to race on)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_infer_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+        set_error("mlp_infer_bf16: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+        return PSN_E_LAUNCH;
     }
     hipLaunchKernelGGL(mlp_infer_bf16_kernel, dim3((unsigned)blocks), dim3(kBfWaves * 64), lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer_bf16");
