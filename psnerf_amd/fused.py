@@ -55,6 +55,14 @@ def _pad_cols(w, n):
     return torch.nn.functional.pad(w, (0, n - w.shape[1])) if w.shape[1] < n else w
 
 
+def _pad_rows(w, n):  # F.pad with nothing to pad still clones: one fill + one copy kernel per call, ~50 per train step
+    return torch.nn.functional.pad(w, (0, 0, 0, n - w.shape[0])) if w.shape[0] < n else w
+
+
+def _pad_vec(b, n):
+    return torch.nn.functional.pad(b, (0, n - b.shape[0])) if b.shape[0] < n else b
+
+
 class Transposed(object):
     """Marker for pack_layers: use the transpose of ``w`` (backward chains) without materialising it."""
 
@@ -94,13 +102,13 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
         rows = n_mt * 32
         lay = desc.layers[li]
         lay.init_off = -1
-        bias = torch.nn.functional.pad(L['bias'].detach().float(), (0, rows - L['bias'].shape[0]))
+        bias = _pad_vec(L['bias'].detach().float(), rows)
         if L.get('init_a') is not None:
             assert not last
             lay.init_off = width * len(init_wa)
-            init_wa.append(torch.nn.functional.pad(_pad_cols(L['init_a'], in_kt_a * 32), (0, 0, 0, width - L['init_a'].shape[0])))
+            init_wa.append(_pad_rows(_pad_cols(L['init_a'], in_kt_a * 32), width))
             if L.get('init_b') is not None:
-                init_wb.append(torch.nn.functional.pad(_pad_cols(L['init_b'], in_kt_b * 32), (0, 0, 0, width - L['init_b'].shape[0])))
+                init_wb.append(_pad_rows(_pad_cols(L['init_b'], in_kt_b * 32), width))
             init_bias.append(bias)  # folded into the init table
             bias = torch.zeros_like(bias)
         n_kt_in = n_kt_act = 0

@@ -7,6 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..dist import DataParallel
+from ..optim import RowSparseAdam
 from .loss import MainLoss, NormalLoss
 
 
@@ -30,12 +31,13 @@ class TrainStep(object):
         gamma = conf.get_float('train.sg_sched_factor', default=0.0)
         self.sg_optimizer = torch.optim.Adam(model.parameters(), lr=conf.get_float('train.sg_learning_rate'))
         self.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.sg_optimizer, list(milestones), gamma=gamma)
-        self.light_para = nn.Embedding(n_lights_total, 3, sparse=True).to(device)
+        # dense gradients + RowSparseAdam = SparseAdam's update of the touched rows without coalesce() (optim.py)
+        self.light_para = nn.Embedding(n_lights_total, 3, sparse=False).to(device)
         self.light_para.weight.data.copy_(light_init)
-        self.light_inten_para = nn.Embedding(n_lights_total, 1, sparse=True).to(device)
+        self.light_inten_para = nn.Embedding(n_lights_total, 1, sparse=False).to(device)
         nn.init.constant_(self.light_inten_para.weight, model.light_int)
         lr_l = conf.get_float('train.light_learning_rate', default=5e-4)
-        self.light_optimizer = torch.optim.SparseAdam(
+        self.light_optimizer = RowSparseAdam(
             [{'params': list(self.light_para.parameters())},
              {'params': list(self.light_inten_para.parameters()),
               'lr': conf.get_float('train.light_inten_lr', default=lr_l)}], lr=lr_l)
@@ -85,11 +87,11 @@ class TrainStep(object):
         if train_light:
             self.light_optimizer.zero_grad()
         loss.backward()
-        self.dp.allreduce_grads([p for p in self.model.parameters() if p.requires_grad],
-                                [self.light_para.weight, self.light_inten_para.weight] if train_light else ())
+        self.dp.allreduce_grads([p for p in self.model.parameters() if p.requires_grad]
+                                + ([self.light_para.weight, self.light_inten_para.weight] if train_light else []))
         self.sg_optimizer.step()
         if train_light:
-            self.light_optimizer.step()
+            self.light_optimizer.step(rows=l_slt)
         self.cur_iter += 1
         self.sg_scheduler.step()
         if train_light:

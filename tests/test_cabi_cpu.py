@@ -154,3 +154,46 @@ def test_view_sampler_matches_reference_sampling_order(tmp_path):
     ds2 = ViewSampler([view], [imgs], [omask], [ldir], [torch.eye(4)], torch.eye(4), light_bs=4, split='test')
     _, s2, g2 = ds2[0]
     assert s2['lidx'].tolist() == list(range(L)) and g2['rgb'].shape == (L, h * w, 3) and 'sampling_idx' not in s2
+
+
+def test_row_sparse_adam_matches_sparse_adam():
+    """psnerf_amd.optim.RowSparseAdam = torch.optim.SparseAdam on the touched rows (stage2/trainer.py:126-168), with
+    sparse (uncoalesced, duplicate rows) and with dense gradients; untouched rows and their moments do not move; the
+    state dict has SparseAdam's layout."""
+    import torch
+    from psnerf_amd.optim import RowSparseAdam
+    g = torch.Generator().manual_seed(0)
+    n, d = 40, 3
+    w0 = torch.randn(n, d, generator=g)
+    ref = torch.nn.Embedding(n, d, sparse=True)
+    a = torch.nn.Embedding(n, d, sparse=True)
+    b = torch.nn.Embedding(n, d, sparse=False)
+    for e in (ref, a, b):
+        e.weight.data.copy_(w0)
+    o_ref = torch.optim.SparseAdam(list(ref.parameters()), lr=5e-3)
+    o_a = RowSparseAdam(list(a.parameters()), lr=5e-3)
+    o_b = RowSparseAdam(list(b.parameters()), lr=5e-3)
+    for it in range(6):
+        rows = torch.randint(0, n, (12,), generator=g)  # with duplicates
+        coef = torch.randn(12, d, generator=g)
+        for e, o in ((ref, o_ref), (a, o_a), (b, o_b)):
+            o.zero_grad()
+            (e(rows) * coef).sum().backward()
+        o_ref.step()
+        o_a.step()
+        o_b.step(rows=rows)
+        assert torch.allclose(a.weight, ref.weight, rtol=0, atol=1e-7), it
+        assert torch.allclose(b.weight, ref.weight, rtol=0, atol=1e-7), it
+        untouched = torch.ones(n, dtype=torch.bool)
+        untouched[rows] = False
+        if it == 0:
+            assert torch.equal(b.weight[untouched], w0[untouched])
+    sa, sr = o_a.state_dict(), o_ref.state_dict()
+    assert set(sa['state'][0].keys()) == set(sr['state'][0].keys()) == {'step', 'exp_avg', 'exp_avg_sq'}
+    assert torch.allclose(sa['state'][0]['exp_avg'], sr['state'][0]['exp_avg'].to_dense() if sr['state'][0]['exp_avg'].is_sparse else sr['state'][0]['exp_avg'], atol=1e-7)
+    o_a.load_state_dict(sr)  # a SparseAdam checkpoint loads
+    import pytest
+    with pytest.raises(RuntimeError):
+        o_b.zero_grad()
+        (b(torch.tensor([1])) * 1.0).sum().backward()
+        o_b.step()  # dense gradient without rows

@@ -1,0 +1,18 @@
+"""torch.profiler view of one stage-2 train step (bench configuration): which aten ops emit the small kernels."""
+import os, sys
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+import torch
+import bench
+from psnerf_amd.synthetic import stage2_inputs
+from torch.profiler import profile, ProfilerActivity
+dev = torch.device('cuda:0')
+step = bench.make_step(dev)
+inp, gt = stage2_inputs(bench.N_PIXELS, bench.N_LIGHTS, bench.N_VIS, seed=100, device=dev)
+l_slt = torch.arange(bench.N_LIGHTS, device=dev) + 96 * 3
+for _ in range(3):
+    step.step(inp, gt, l_slt, train_order=False)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+    step.step(inp, gt, l_slt, train_order=False)
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=60, max_name_column_width=60))
