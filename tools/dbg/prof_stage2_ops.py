@@ -12,7 +12,10 @@ l_slt = torch.arange(bench.N_LIGHTS, device=dev) + 96 * 3
 for _ in range(3):
     step.step(inp, gt, l_slt, train_order=False)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=len(sys.argv) > 1) as prof:
     step.step(inp, gt, l_slt, train_order=False)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=60, max_name_column_width=60))
+if len(sys.argv) > 1:  # group the small aten ops by python call site
+    print(prof.key_averages(group_by_stack_n=4).table(sort_by='cuda_time_total', row_limit=70, max_name_column_width=40, max_src_column_width=110))
+else:
+    print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=60, max_name_column_width=60))
