@@ -221,6 +221,27 @@ int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* pa
                   const float* act_init, int64_t n_rows, float* out, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Weight normalisation of up to PSN_WN_MAX_ITEMS layers in one launch: nn.utils.weight_norm(nn.Linear) as used by every
+ * layer of stage1/model/network.py:37-66 (state_dict keys weight_g [rows,1], weight_v [rows,cols]).
+ *   fwd: w = v * (g / |v|_row) [* scale]       (scale = 1/sqrt(2) folds the cat[x, pe]/sqrt(2) of network.py:90-91)
+ *   bwd: given dw (gradient of the scaled w):  dv, dg
+ * All matrices row-major and dense (row stride = cols).  HOST array of items holding device pointers.
+ * ---------------------------------------------------------------------- */
+#define PSN_WN_MAX_ITEMS 16
+typedef struct {
+    const float* v;   /* [rows, cols] */
+    const float* g;   /* [rows] */
+    float* w;         /* fwd: [rows, cols] output */
+    const float* dw;  /* bwd: [rows, cols] */
+    float* dv;        /* bwd: [rows, cols] output */
+    float* dg;        /* bwd: [rows] output */
+    int rows, cols;
+    float scale;
+} PsnWnItem;
+int psn_weight_norm_fwd(int n_items, const PsnWnItem* items, void* stream);
+int psn_weight_norm_bwd(int n_items, const PsnWnItem* items, void* stream);
+
+/* ------------------------------------------------------------------------
  * bf16 inference engine (evaluation / relighting only; BASELINE config 5 "bf16 MFMA path ... envmap relight eval"):
  * the 256-wide ReLU networks of stage2/model/renderer.py:34-49 on v_mfma_f32_32x32x16_bf16 -- weights, input
  * features and post-ReLU activations rounded to bf16 (RNE), fp32 accumulation, fp32 output.  Replaces the no-grad

@@ -46,6 +46,11 @@ class PsnBf16Desc(ctypes.Structure):
                 ('has_in', ctypes.c_uint8 * (MAX_LAYERS + 4))]
 
 
+class PsnWnItem(ctypes.Structure):
+    _fields_ = [('v', ctypes.c_void_p), ('g', ctypes.c_void_p), ('w', ctypes.c_void_p), ('dw', ctypes.c_void_p),
+                ('dv', ctypes.c_void_p), ('dg', ctypes.c_void_p), ('rows', i32), ('cols', i32), ('scale', f32)]
+
+
 class PsnGemmTnItem(ctypes.Structure):
     _fields_ = [('A', ctypes.c_void_p), ('lda', i64), ('B', ctypes.c_void_p), ('ldb', i64),
                 ('A2', ctypes.c_void_p), ('lda2', i64), ('B2', ctypes.c_void_p), ('ldb2', i64),
@@ -80,6 +85,8 @@ SIGNATURES = {
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
                             ctypes.POINTER(ctypes.c_void_p), i64, ctypes.POINTER(ctypes.c_void_p),
                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f, i64, c_f, c_f]),
+    'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
+    'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_mlp_pack_bf16': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
     'psn_mlp_infer_bf16': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, i64, c_f, c_f]),
 }
@@ -378,6 +385,43 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
         e1.record()
         prof.append(('mlp_infer', n_rows, e0, e1))
     return out
+
+
+# --------------------------------------------------------------------------- weight normalisation
+WN_MAX_ITEMS = 16
+
+
+def weight_norm_fwd(vs, gs, scales):
+    """[v_l * (g_l / |v_l|_row) * scale_l] for all layers in one launch (<= 16 per launch)."""
+    out = [torch.empty_like(v) for v in vs]
+    for c0 in range(0, len(vs), WN_MAX_ITEMS):
+        n = min(WN_MAX_ITEMS, len(vs) - c0)
+        arr = (PsnWnItem * n)()
+        for i in range(n):
+            v, g = vs[c0 + i], gs[c0 + i]
+            assert v.dim() == 2 and g.numel() == v.shape[0]
+            e = arr[i]
+            e.v, e.g, e.w = _ptr(v, 'weight_v'), _ptr(g, 'weight_g'), out[c0 + i].data_ptr()
+            e.rows, e.cols, e.scale = v.shape[0], v.shape[1], float(scales[c0 + i])
+        _check(_lib.psn_weight_norm_fwd(n, ctypes.addressof(arr), _stream()), 'weight_norm_fwd')
+    return out
+
+
+def weight_norm_bwd(vs, gs, scales, dws):
+    """(dv_l, dg_l) of weight_norm_fwd for the output gradients dws (dense, same shapes as vs)."""
+    dvs = [torch.empty_like(v) for v in vs]
+    dgs = [torch.empty_like(g) for g in gs]
+    for c0 in range(0, len(vs), WN_MAX_ITEMS):
+        n = min(WN_MAX_ITEMS, len(vs) - c0)
+        arr = (PsnWnItem * n)()
+        for i in range(n):
+            v, g = vs[c0 + i], gs[c0 + i]
+            e = arr[i]
+            e.v, e.g, e.dw = _ptr(v, 'weight_v'), _ptr(g, 'weight_g'), _ptr(dws[c0 + i], 'dw')
+            e.dv, e.dg = dvs[c0 + i].data_ptr(), dgs[c0 + i].data_ptr()
+            e.rows, e.cols, e.scale = v.shape[0], v.shape[1], float(scales[c0 + i])
+        _check(_lib.psn_weight_norm_bwd(n, ctypes.addressof(arr), _stream()), 'weight_norm_bwd')
+    return dvs, dgs
 
 
 # --------------------------------------------------------------------------- bf16 inference engine (evaluation only)

@@ -208,6 +208,33 @@ class FusedPairMLP(torch.autograd.Function):
         return (res[0], res[1], None, None) + tuple(pg)
 
 
+# --------------------------------------------------------------------------- weight normalisation
+class WeightNormAll(torch.autograd.Function):
+    """Effective matrices of all weight-normalised layers of a network, w_l = v_l (g_l / |v_l|_row) * scale_l
+    (nn.utils.weight_norm as in stage1/model/network.py:37-66), one launch forward and one backward
+    (csrc/weight_norm.hip) instead of ~4 + ~12 torch kernels per layer.
+    apply(scales (tuple of floats), g_0, v_0, g_1, v_1, ...) -> (w_0, w_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, scales, *gv):
+        gs, vs = [t.detach().contiguous() for t in gv[0::2]], [t.detach().contiguous() for t in gv[1::2]]
+        ctx.scales = scales
+        ctx.save_for_backward(*gs, *vs)
+        return tuple(hip.weight_norm_fwd(vs, [g.reshape(-1) for g in gs], scales))
+
+    @staticmethod
+    def backward(ctx, *dws):
+        n = len(ctx.scales)
+        sv = ctx.saved_tensors
+        gs, vs = sv[:n], sv[n:]
+        dws = [torch.zeros_like(v) if d is None else d.contiguous() for d, v in zip(dws, vs)]
+        dvs, dgs = hip.weight_norm_bwd(list(vs), [g.reshape(-1) for g in gs], ctx.scales, dws)
+        out = [None]
+        for g, dg, dv in zip(gs, dgs, dvs):
+            out += [dg.view_as(g), dv]
+        return tuple(out)
+
+
 # --------------------------------------------------------------------------- SG shading
 def sg_shade(light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb):
     """Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n (csrc/shade.hip).

@@ -85,24 +85,28 @@ class NeuralNetwork(nn.Module):
         self._app_key = None
 
     # ---- effective weights ----------------------------------------------------------------------
+    def _effective(self, prefix, n, scales):
+        """Effective matrices of layers ``prefix``0..n-1.  On the GPU all of them come from ONE launch
+        (ops.WeightNormAll, differentiable); elsewhere (state-dict handling on the host) from the torch formula."""
+        lins = [getattr(self, '%s%d' % (prefix, l)) for l in range(n)]
+        if not lins[0].weight_v.is_cuda:
+            return [lin.weight() * s if s != 1.0 else lin.weight() for lin, s in zip(lins, scales)]
+        gv = []
+        for lin in lins:
+            gv += [lin.weight_g, lin.weight_v]
+        return list(ops.WeightNormAll.apply(tuple(scales), *gv))
+
     def _geo_params(self):
-        inv = 1.0 / np.sqrt(2)
+        inv = float(1.0 / np.sqrt(2))  # folds the cat[x, pe]/sqrt(2) of network.py:90-91 into the skip layer
+        Ws = self._effective('lin', self.n_geo, [inv if l in self.skips else 1.0 for l in range(self.n_geo)])
         out = []
         for l in range(self.n_geo):
-            lin = getattr(self, 'lin%d' % l)
-            W = lin.weight()
-            if l in self.skips:
-                W = W * inv  # fold the cat[x, pe]/sqrt(2) of network.py:90-91 into the layer
-            out += [W, lin.bias]
+            out += [Ws[l], getattr(self, 'lin%d' % l).bias]
         return out
 
     def _app_params(self):
-        Ws, bs = [], []
-        for l in range(self.n_app):
-            lin = getattr(self, 'lina%d' % l)
-            Ws.append(lin.weight())
-            bs.append(lin.bias)
-        return Ws, bs
+        Ws = self._effective('lina', self.n_app, [1.0] * self.n_app)
+        return Ws, [getattr(self, 'lina%d' % l).bias for l in range(self.n_app)]
 
     USE_FUSED_CHAINS = True
     MAX_ROWS = 1 << 20  # rows per GeoField call: bounds the saved activations to ~50 GB of the 288 GB HBM
@@ -162,10 +166,10 @@ class NeuralNetwork(nn.Module):
         key = tuple(int(q._version) for q in self.parameters()) + (self.lin0.weight_v.data_ptr(),)
         if self._packed is None or self._packed_key != key:
             with torch.no_grad():
-                ps = self._geo_params()
-                # un-fold the 1/sqrt(2): pack_geo_occupancy applies it itself
-                Ws = [getattr(self, 'lin%d' % l).weight() for l in range(self.n_geo)]
-                self._packed = fused.pack_geo_occupancy(Ws, ps[1::2], self.skips, self.d_pe)
+                # without the 1/sqrt(2) fold: pack_geo_occupancy applies it itself
+                Ws = self._effective('lin', self.n_geo, [1.0] * self.n_geo)
+                bs = [getattr(self, 'lin%d' % l).bias for l in range(self.n_geo)]
+                self._packed = fused.pack_geo_occupancy(Ws, bs, self.skips, self.d_pe)
             self._packed_key = key
         return self._packed
 

@@ -460,3 +460,34 @@ def test_sample_points_bit_exact(cuda, with_outer, with_noise):
         d1 = jitter(d1, nz_h)
     ref[hit_idx] = cam[hit_idx].unsqueeze(-2) + rays[hit_idx].unsqueeze(-2) * d1.unsqueeze(-1)
     assert torch.equal(out, ref), 'max |diff| = %g' % float((out - ref).abs().max())
+
+
+def test_weight_norm_all(cuda):
+    """ops.WeightNormAll (csrc/weight_norm.hip) = v * (g / |v|_row) * scale and its autograd, all layers in one launch
+    (nn.utils.weight_norm of stage1/model/network.py:37-66)."""
+    from psnerf_amd import ops
+    g = torch.Generator().manual_seed(3)
+    shapes = [(256, 39), (256, 256), (217, 256), (256, 256), (257, 256), (3, 256), (1, 5), (70, 289)]
+    scales = (1.0, 1.0, 1.0, float(1 / np.sqrt(2)), 1.0, 1.0, 1.0, 0.5)
+    vs = [torch.randn(s, generator=g).to(cuda).requires_grad_(True) for s in shapes]
+    gs = [(torch.rand(s[0], 1, generator=g) + 0.5).to(cuda).requires_grad_(True) for s in shapes]
+    cot = [torch.randn(s, generator=g).to(cuda) for s in shapes]
+    gv = []
+    for a, b in zip(gs, vs):
+        gv += [a, b]
+    Ws = ops.WeightNormAll.apply(scales, *gv)
+    sum((w * c).sum() for w, c in zip(Ws[:-1], cot[:-1])).backward()  # the last output gets no gradient
+    got = [(v.grad.clone(), a.grad.clone()) for v, a in zip(vs, gs)]
+    for t in vs + gs:
+        t.grad = None
+    ref = [v * (a / v.norm(2, dim=1, keepdim=True)) * s if s != 1.0 else v * (a / v.norm(2, dim=1, keepdim=True))
+           for v, a, s in zip(vs, gs, scales)]
+    sum((w * c).sum() for w, c in zip(ref[:-1], cot[:-1])).backward()
+    for i, (w, r) in enumerate(zip(Ws, ref)):
+        assert_close(w.detach().cpu(), r.detach().cpu(), 2e-6, 'w[%d]' % i)
+    for i, ((dv, dg), v, a) in enumerate(zip(got, vs, gs)):
+        if i == len(vs) - 1:
+            assert float(dv.abs().max()) == 0.0 and float(dg.abs().max()) == 0.0
+        else:
+            assert_close(dv.cpu(), v.grad.cpu(), 2e-5, 'dv[%d]' % i)
+            assert_close(dg.cpu(), a.grad.cpu(), 2e-5, 'dg[%d]' % i)
