@@ -44,65 +44,172 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <int E>  // E = chunks of 64 samples held per lane
+// Forward, blocked layout: lane l owns the E CONSECUTIVE samples l E .. l E + E - 1 of its wave's ray (E = ceil(S / 64)):
+// a sequential product inside the lane, ONE exclusive wave scan over the 64 lane totals, no LDS -- a lane already holds
+// the colours of its own samples (3 E consecutive floats).  The four ray sums (acc, r, g, b) are reduced together in a
+// halving butterfly (7 cross-lane steps instead of 4 x 6).  The previous strided version needed E scans and an LDS
+// round trip per ray and was instruction-bound at 0.44 of the HBM peak.  The rows of the NEXT ray of the wave are
+// requested before the current one is processed (two register sets, loop unrolled by two).
+// streamed once: non-temporal accesses keep the rows out of L2 / Infinity Cache
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 nt_load2(const float* p) {
+    const floatx2 v = __builtin_nontemporal_load(reinterpret_cast<const floatx2*>(p));
+    return make_float2(v[0], v[1]);
+}
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+    const floatx4 v = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store2(float* p, float a, float b) {
+    floatx2 v; v[0] = a; v[1] = b;
+    __builtin_nontemporal_store(v, reinterpret_cast<floatx2*>(p));
+}
+__device__ __forceinline__ void nt_store4(float* p, float a, float b, float c, float d) {
+    floatx4 v; v[0] = a; v[1] = b; v[2] = c; v[3] = d;
+    __builtin_nontemporal_store(v, reinterpret_cast<floatx4*>(p));
+}
+
+template <int E>
+struct RayRegs {
+    float a[E];
+    float c[3 * E];
+};
+
+template <int E, bool VEC>
+__device__ __forceinline__ void fwd_load(RayRegs<E>& r, const float* __restrict__ alpha, const float* __restrict__ rgb,
+                                         int64_t ray, int S, int lane) {
+    const int s0 = lane * E;
+    const float* a_row = alpha + ray * S + s0;
+    const float* c_row = rgb != nullptr ? rgb + (ray * S + s0) * 3 : nullptr;
+    if constexpr (VEC) {  // S % E == 0 and 16-byte aligned base: whole lanes are inside or outside the row
+        if (s0 < S) {
+            if constexpr (E == 2) {
+                const float2 t = nt_load2(a_row);
+                r.a[0] = t.x; r.a[1] = t.y;
+            } else {
+#pragma unroll
+                for (int i = 0; i < E; i += 4) {
+                    const float4 t = nt_load4(a_row + i);
+                    r.a[i] = t.x; r.a[i + 1] = t.y; r.a[i + 2] = t.z; r.a[i + 3] = t.w;
+                }
+            }
+            if (c_row != nullptr) {
+                if constexpr (E == 2) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float2 t = nt_load2(c_row + 2 * i);
+                        r.c[2 * i] = t.x; r.c[2 * i + 1] = t.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 3 * E; i += 4) {
+                        const float4 t = nt_load4(c_row + i);
+                        r.c[i] = t.x; r.c[i + 1] = t.y; r.c[i + 2] = t.z; r.c[i + 3] = t.w;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) r.a[i] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3 * E; ++i) r.c[i] = 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < E; ++i) r.a[i] = s0 + i < S ? a_row[i] : 0.0f;
+        if (c_row != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 3 * E; ++i) r.c[i] = s0 + i / 3 < S ? c_row[i] : 0.0f;
+        }
+    }
+}
+
+// Sums of four per-lane values over the wave: lanes 0 / 16 / 32 / 48 end up with the totals of x0 / x1 / x2 / x3.
+__device__ __forceinline__ float wave_sum4(float x0, float x1, float x2, float x3, int lane) {
+    const bool hi = (lane & 32) != 0;
+    const float k0 = (hi ? x2 : x0) + __shfl_xor(hi ? x0 : x2, 32, 64);
+    const float k1 = (hi ? x3 : x1) + __shfl_xor(hi ? x1 : x3, 32, 64);
+    const bool h16 = (lane & 16) != 0;
+    float v = (h16 ? k1 : k0) + __shfl_xor(h16 ? k0 : k1, 16, 64);
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+template <int E, bool VEC>
+__device__ __forceinline__ void fwd_ray(const RayRegs<E>& r, bool has_rgb, int64_t ray, int S, int white_bg, int lane,
+                                        float* __restrict__ weights, float* __restrict__ rgb_out,
+                                        float* __restrict__ acc_out) {
+    const int s0 = lane * E;
+    float p[E + 1];  // exclusive products inside the lane
+    p[0] = 1.0f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) p[i + 1] = p[i] * (s0 + i < S ? (1.0f - r.a[i] + kEps) : 1.0f);
+    const float incl = wave_incl_prod(p[E], lane);
+    float pre = __shfl_up(incl, 1, 64);
+    if (lane == 0) pre = 1.0f;
+    float w[E];
+    float acc = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        w[i] = r.a[i] * (pre * p[i]);
+        acc += w[i];
+        q0 += w[i] * r.c[3 * i];
+        q1 += w[i] * r.c[3 * i + 1];
+        q2 += w[i] * r.c[3 * i + 2];
+    }
+    if (weights != nullptr) {
+        float* w_row = weights + ray * S + s0;
+        if constexpr (VEC) {
+            if (s0 < S) {
+                if constexpr (E == 2) {
+                    nt_store2(w_row, w[0], w[1]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < E; i += 4) nt_store4(w_row + i, w[i], w[i + 1], w[i + 2], w[i + 3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i)
+                if (s0 + i < S) w_row[i] = w[i];
+        }
+    }
+    if (has_rgb) {
+        const float v = wave_sum4(acc, q0, q1, q2, lane);
+        const float acc_all = __shfl(v, 0, 64);
+        if (lane == 0) acc_out[ray] = v;
+        if ((lane & 15) == 0 && lane != 0) rgb_out[ray * 3 + (lane >> 4) - 1] = v + (white_bg ? (1.0f - acc_all) : 0.0f);
+    } else {
+        acc = wave_sum(acc);
+        if (lane == 0) acc_out[ray] = acc;
+    }
+}
+
+template <int E, bool VEC>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ alpha,
                                                             const float* __restrict__ rgb, int64_t n_rays, int S,
                                                             int white_bg, float* __restrict__ weights,
                                                             float* __restrict__ rgb_out, float* __restrict__ acc_out) {
-    __shared__ float w_lds[kWavesPerBlock][E * 64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float* wl = w_lds[wave];
-    for (int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + wave; ray < n_rays;
-         ray += (int64_t)gridDim.x * kWavesPerBlock) {
-        const float* a_row = alpha + ray * S;
-        float a[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            int s = e * 64 + lane;
-            a[e] = s < S ? a_row[s] : 0.0f;
-        }
-        float carry = 1.0f, acc = 0.0f;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            int s = e * 64 + lane;
-            float t = s < S ? (1.0f - a[e] + kEps) : 1.0f;
-            float incl = wave_incl_prod(t, lane);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0f;
-            float w = a[e] * (excl * carry);
-            carry *= __shfl(incl, 63, 64);
-            acc += w;
-            wl[e * 64 + lane] = w;
-            if (weights != nullptr && s < S) weights[ray * S + s] = w;
-        }
-        acc = wave_sum(acc);
-        if (rgb != nullptr) {
-            // wave-private LDS row: writes above are visible to this wave's reads after the waitcnt
-            wave_lds_sync();
-            const float* c_row = rgb + ray * S * 3;
-            float part0 = 0.f, part1 = 0.f, part2 = 0.f;
-            const int n_flat = 3 * S;
-            for (int k = lane; k < n_flat; k += 64) {
-                float c = c_row[k];
-                int s = k / 3;
-                int ch = k - 3 * s;
-                float p = wl[s] * c;
-                part0 += ch == 0 ? p : 0.f;
-                part1 += ch == 1 ? p : 0.f;
-                part2 += ch == 2 ? p : 0.f;
-            }
-            part0 = wave_sum(part0);
-            part1 = wave_sum(part1);
-            part2 = wave_sum(part2);
-            if (lane == 0) {
-                float bg = white_bg ? (1.0f - acc) : 0.0f;
-                rgb_out[ray * 3 + 0] = part0 + bg;
-                rgb_out[ray * 3 + 1] = part1 + bg;
-                rgb_out[ray * 3 + 2] = part2 + bg;
-            }
-        }
-        if (lane == 0) acc_out[ray] = acc;
+    const bool has_rgb = rgb != nullptr;
+    const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+    int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (ray >= n_rays) return;
+    RayRegs<E> r0, r1;
+    fwd_load<E, VEC>(r0, alpha, rgb, ray, S, lane);
+    while (true) {
+        int64_t nxt = ray + stride;
+        if (nxt < n_rays) fwd_load<E, VEC>(r1, alpha, rgb, nxt, S, lane);
+        fwd_ray<E, VEC>(r0, has_rgb, ray, S, white_bg, lane, weights, rgb_out, acc_out);
+        if (nxt >= n_rays) break;
+        ray = nxt;
+        nxt = ray + stride;
+        if (nxt < n_rays) fwd_load<E, VEC>(r0, alpha, rgb, nxt, S, lane);
+        fwd_ray<E, VEC>(r1, has_rgb, ray, S, white_bg, lane, weights, rgb_out, acc_out);
+        if (nxt >= n_rays) break;
+        ray = nxt;
     }
 }
 
@@ -135,7 +242,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             int s = e * 64 + lane;
-            a[e] = s < S ? a_row[s] : 0.0f;
+            a[e] = s < S ? __builtin_nontemporal_load(a_row + s) : 0.0f;
             float t = s < S ? (1.0f - a[e] + kEps) : 1.0f;
             float incl = wave_incl_prod(t, lane);
             float excl = __shfl_up(incl, 1, 64);
@@ -151,12 +258,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
             const float* c_row = rgb + ray * S * 3;
             float* dc_row = d_rgb + ray * S * 3;
             for (int k = lane; k < n_flat; k += 64) {
-                float c = c_row[k];
+                float c = __builtin_nontemporal_load(c_row + k);
                 int s = k / 3;
                 int ch = k - 3 * s;
                 float g = ch == 0 ? g0 : (ch == 1 ? g1 : g2);
                 gl[k] = g * (c - wb);
-                dc_row[k] = wl[s] * g;
+                __builtin_nontemporal_store(wl[s] * g, dc_row + k);
             }
             wave_lds_sync();
         }
@@ -177,7 +284,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
             tail += __shfl(ex, 0, 64) + __shfl(gw, 0, 64);
             if (s < S) {
                 float t = 1.0f - a[e] + kEps;
-                d_alpha[ray * S + s] = G * T[e] - R / t;
+                __builtin_nontemporal_store(G * T[e] - R / t, d_alpha + ray * S + s);
             }
         }
     }
@@ -188,8 +295,11 @@ static int launch_fwd(const float* alpha, const float* rgb, int64_t n_rays, int 
                       float* rgb_out, float* acc_out, hipStream_t st) {
     int64_t blocks = (n_rays + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(composite_fwd_kernel<E>, dim3((unsigned)blocks), dim3(256), 0, st, alpha, rgb, n_rays, S,
-                       white_bg, weights, rgb_out, acc_out);
+    // vector path: every lane's E samples lie entirely inside or outside the row and all of its accesses are aligned
+    // (E = 2: 8-byte accesses at even sample offsets; E >= 4: 16-byte accesses at multiples of four samples)
+    const bool vec = E >= 2 && S % E == 0 && (((uintptr_t)alpha | (uintptr_t)rgb | (uintptr_t)weights) & 15) == 0;
+    if (vec) hipLaunchKernelGGL((composite_fwd_kernel<E, true>), dim3((unsigned)blocks), dim3(256), 0, st, alpha, rgb, n_rays, S, white_bg, weights, rgb_out, acc_out);
+    else hipLaunchKernelGGL((composite_fwd_kernel<E, false>), dim3((unsigned)blocks), dim3(256), 0, st, alpha, rgb, n_rays, S, white_bg, weights, rgb_out, acc_out);
     PSN_CHECK_LAUNCH("composite_fwd");
     return PSN_OK;
 }
