@@ -2,11 +2,13 @@
 // Reference: stage1/model/rendering.py:196-197 (weights = alpha * cumprod([1, 1-alpha+eps])[:-1]),
 // :197 rgb = sum w c, :214-216 acc = sum w, white background; same formula at :405-406.
 //
-// HBM-bound: forward moves 20*S+16 B/ray, backward 36*S+16 B/ray.
-// One 64-lane wave per ray: lane l owns samples l, l+64, ... (coalesced 256 B rows); the exclusive
-// product scan runs as a 6-step wave scan per 64-sample chunk with a carried prefix; rgb rows (3*S
-// floats, not float4-aligned per sample) are read as flat coalesced dwords and matched with their
-// sample weight through a per-wave LDS row.
+// HBM-bound: forward moves 20*S+16 B/ray, backward 36*S+16 B/ray.  One 64-lane wave per ray.
+// Forward: blocked layout (lane l owns the E = ceil(S/64) consecutive samples l*E .. and their 3*E colour floats),
+// sequential product inside the lane + one exclusive wave scan over the lane totals, no LDS (see composite_fwd_kernel).
+// Backward: strided layout (lane l owns samples l, l+64, ...: coalesced 256 B rows), 6-step wave scans per 64-sample
+// chunk with a carried prefix; rgb rows are read as flat coalesced dwords and matched with their sample weight through
+// a per-wave LDS row.  Measured (2 M rays x 128 samples): forward 4.84 TB/s, backward 5.09 TB/s (0.61 / 0.64 of the
+// 8 TB/s peak; torch's elementwise add reaches 6.1 TB/s on the same box).
 #include "common.h"
 
 namespace psn {
