@@ -60,6 +60,7 @@ def _table(n, d, seed, dev):
     (513, 2, 5, 1, 3, 0),      # other depth / skip position, several outputs
     (300, 4, 4, -100, 32, 2),  # no skip connection, full final tile, occupancy output
     (256, 1, 2, -100, 1, 0),   # one hidden layer, exactly one workgroup
+    (700, 3, 12, 5, 2, 0),     # the deepest network both engines hold (11 hidden layers + final)
 ])
 def test_bf16_engine_vs_emulation(cuda, nA, nB, depth, skip_at, n_out, out_act):
     from psnerf_amd import fused

@@ -491,3 +491,22 @@ def test_weight_norm_all(cuda):
         else:
             assert_close(dv.cpu(), v.grad.cpu(), 2e-5, 'dv[%d]' % i)
             assert_close(dg.cpu(), a.grad.cpu(), 2e-5, 'dg[%d]' % i)
+
+
+def test_weight_norm_more_layers_than_one_launch(cuda):
+    """hip.weight_norm_fwd / _bwd split lists longer than PSN_WN_MAX_ITEMS (16) into several launches."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(5)
+    vs = [torch.randn(8 + i, 5 + 2 * i, generator=g).to(cuda) for i in range(19)]
+    gs = [(torch.rand(v.shape[0], generator=g) + 0.5).to(cuda) for v in vs]
+    sc = [1.0 + 0.1 * (i % 3) for i in range(19)]
+    ws = hip.weight_norm_fwd(vs, gs, sc)
+    dws = [torch.randn(v.shape, generator=g).to(cuda) for v in vs]
+    dvs, dgs = hip.weight_norm_bwd(vs, gs, sc, dws)
+    for v, a, s_, w, dw, dv, dg in zip(vs, gs, sc, ws, dws, dvs, dgs):
+        v64, a64, dw64 = v.double(), a.double(), dw.double()
+        nrm = v64.norm(dim=1, keepdim=True)
+        assert_close(w.cpu(), (v64 * (a64[:, None] / nrm) * s_).float().cpu(), 2e-6, 'w')
+        dot = (dw64 * v64).sum(1, keepdim=True) * s_
+        assert_close(dg.cpu(), (dot / nrm).float().reshape(-1).cpu(), 2e-5, 'dg')
+        assert_close(dv.cpu(), (dw64 * (a64[:, None] / nrm) * s_ - dot * a64[:, None] * v64 / nrm ** 3).float().cpu(), 2e-5, 'dv')
