@@ -28,7 +28,8 @@ def test_composite_golden(cuda, S):
     assert_close(da.cpu(), g['dalpha%d' % S], 1e-4, 'd_alpha')  # /t with t ~ 1e-6 on the alpha==1 rows
 
 
-@pytest.mark.parametrize('N,S', [(1, 1), (5, 7), (1000, 63), (333, 65), (4096, 128), (17, 300), (3, 1024)])
+@pytest.mark.parametrize('N,S', [(1, 1), (5, 7), (1000, 63), (333, 65), (4096, 128), (17, 300), (3, 1024),
+                                 (21, 100), (50, 256), (9, 512), (4, 1000), (70001, 2)])  # vector / scalar row paths, idle lanes
 def test_composite_shapes(cuda, N, S):
     from psnerf_amd import hip
     from oracle import stage1 as o1
