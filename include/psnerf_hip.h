@@ -220,6 +220,13 @@ int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* pa
                   const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
                   const float* act_init, int64_t n_rows, float* out, void* stream);
 
+/* One secant (regula falsi) iteration of the surface refinement, stage1/model/rendering.py:525-555, for n hit rays:
+ * with occ [n] (occupancy at the current d_pred; NULL for the initial step) the bracket (d_low, d_high, f_low, f_high,
+ * all [n], updated in place) moves -- f_mid = occ - tau replaces the end with its sign -- then
+ * d_pred = -f_low (d_high - d_low) / (f_high - f_low) + d_low and, if p_mid != NULL, p_mid [n,3] = origin + d_pred dir. */
+int psn_secant_step(const float* occ, float tau, float* d_pred, float* d_low, float* d_high, float* f_low, float* f_high,
+                    const float* origin, const float* dir, float* p_mid, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------
  * Weight normalisation of up to PSN_WN_MAX_ITEMS layers in one launch: nn.utils.weight_norm(nn.Linear) as used by every
  * layer of stage1/model/network.py:37-66 (state_dict keys weight_g [rows,1], weight_v [rows,cols]).

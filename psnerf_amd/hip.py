@@ -85,6 +85,7 @@ SIGNATURES = {
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
                             ctypes.POINTER(ctypes.c_void_p), i64, ctypes.POINTER(ctypes.c_void_p),
                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f, i64, c_f, c_f]),
+    'psn_secant_step': (i32, [c_f, f32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_mlp_pack_bf16': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
@@ -199,6 +200,14 @@ def sample_points(origin, direction, far, out, hit, near, u0, idx=None, dist=Non
 
 # --------------------------------------------------------------------------- GEMM
 _ws_cache = {}
+
+
+def secant_step(occ, tau, d_pred, d_low, d_high, f_low, f_high, origin, direction, p_mid):
+    """One regula-falsi iteration in place (csrc/sample.hip); occ=None: initial step."""
+    _check(_lib.psn_secant_step(_ptr(occ, 'occ', True), float(tau), _ptr(d_pred, 'd_pred'), _ptr(d_low, 'd_low'),
+                                _ptr(d_high, 'd_high'), _ptr(f_low, 'f_low'), _ptr(f_high, 'f_high'),
+                                _ptr(origin, 'origin', True), _ptr(direction, 'direction', True), _ptr(p_mid, 'p_mid', True),
+                                d_pred.numel(), _stream()), 'secant_step')
 
 
 def workspace(n_floats, device):

@@ -144,6 +144,18 @@ class Renderer(nn.Module):
     # ---- stage1/model/rendering.py:525-555 -------------------------------------------------------
     @torch.no_grad()
     def secant(self, f_low, f_high, d_low, d_high, n_secant_steps, ray0_masked, ray_direction_masked, tau, it=0):
+        if f_low.is_cuda and f_low.numel() > 0:
+            # one launch per iteration for the bracket update, the next estimate and the next query point
+            d_low, d_high, f_low, f_high = (t.contiguous().clone() for t in (d_low, d_high, f_low, f_high))
+            origin, direction = ray0_masked.contiguous(), ray_direction_masked.contiguous()
+            d_pred = torch.empty_like(d_low)
+            p_mid = torch.empty(d_low.shape[0], 3, device=d_low.device)
+            hip.secant_step(None, tau, d_pred, d_low, d_high, f_low, f_high, origin, direction, p_mid)
+            for i in range(n_secant_steps):
+                occ = self._occ(p_mid)[..., 0].contiguous()
+                hip.secant_step(occ, tau, d_pred, d_low, d_high, f_low, f_high, origin, direction,
+                                p_mid if i + 1 < n_secant_steps else None)
+            return d_pred
         d_pred = -f_low * (d_high - d_low) / (f_high - f_low) + d_low
         if d_pred.numel() == 0:
             return d_pred

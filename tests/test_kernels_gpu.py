@@ -511,3 +511,37 @@ def test_weight_norm_more_layers_than_one_launch(cuda):
         dot = (dw64 * v64).sum(1, keepdim=True) * s_
         assert_close(dg.cpu(), (dot / nrm).float().reshape(-1).cpu(), 2e-5, 'dg')
         assert_close(dv.cpu(), (dw64 * (a64[:, None] / nrm) * s_ - dot * a64[:, None] * v64 / nrm ** 3).float().cpu(), 2e-5, 'dv')
+
+
+def test_secant_step_matches_torch_formulation(cuda):
+    """hip.secant_step = one iteration of stage1/model/rendering.py:525-555 (bracket update, next estimate, next query
+    point), bit-identical to the elementwise torch formulation."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(9)
+    n, tau = 1000, 0.5
+    d_low = (torch.rand(n, generator=g) * 2 + 1).to(cuda)
+    d_high = d_low + (torch.rand(n, generator=g) * 0.1 + 1e-3).to(cuda)
+    f_low = -(torch.rand(n, generator=g) * 0.5 + 1e-3).to(cuda)
+    f_high = (torch.rand(n, generator=g) * 0.5 + 1e-3).to(cuda)
+    origin = torch.randn(n, 3, generator=g).to(cuda)
+    direction = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(cuda)
+    ref = dict(d_low=d_low.clone(), d_high=d_high.clone(), f_low=f_low.clone(), f_high=f_high.clone())
+    d_pred = torch.empty(n, device=cuda)
+    p_mid = torch.empty(n, 3, device=cuda)
+    hip.secant_step(None, tau, d_pred, d_low, d_high, f_low, f_high, origin, direction, p_mid)
+    r_pred = -ref['f_low'] * (ref['d_high'] - ref['d_low']) / (ref['f_high'] - ref['f_low']) + ref['d_low']
+    assert torch.equal(d_pred, r_pred)
+    assert torch.equal(p_mid, origin + r_pred.unsqueeze(-1) * direction)
+    for it in range(3):
+        occ = torch.rand(n, generator=g).to(cuda)
+        hip.secant_step(occ, tau, d_pred, d_low, d_high, f_low, f_high, origin, direction, p_mid if it < 2 else None)
+        f_mid = occ - tau
+        lo = f_mid < 0
+        ref['d_low'] = torch.where(lo, r_pred, ref['d_low'])
+        ref['f_low'] = torch.where(lo, f_mid, ref['f_low'])
+        ref['d_high'] = torch.where(lo, ref['d_high'], r_pred)
+        ref['f_high'] = torch.where(lo, ref['f_high'], f_mid)
+        r_pred = -ref['f_low'] * (ref['d_high'] - ref['d_low']) / (ref['f_high'] - ref['f_low']) + ref['d_low']
+        assert torch.equal(d_pred, r_pred), it
+        for k, t in (('d_low', d_low), ('d_high', d_high), ('f_low', f_low), ('f_high', f_high)):
+            assert torch.equal(t, ref[k]), (it, k)
