@@ -378,22 +378,28 @@ __device__ __forceinline__ void fetch_tile256(const float* __restrict__ src, int
     // clamp to the last 4-column group of the logical matrix: with a 16-byte aligned base and ld % 4 == 0 that group
     // lies inside the row of the underlying buffer even when the operand is a column slice of it
     const int rqc = min((tid & 63) * 4, ((n_rows - 1) >> 2) << 2);
+    // the k row of a load is wave-uniform (tid >> 6 = wave): scalar row pointer + one constant lane offset, so the eight
+    // loads of a k-tile cost no vector address arithmetic
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int kc = min(k0 + (tid >> 6) + 4 * u, k_end - 1);
-        v[u] = *reinterpret_cast<const float4*>(src + (int64_t)kc * ld + rqc);
+        const int kc = min(k0 + wave + 4 * u, k_end - 1);
+        const float* row = src + (int64_t)kc * ld;
+        v[u] = *reinterpret_cast<const float4*>(row + rqc);
     }
 }
 // ... the zeroing happens when the tile is written to LDS (two k-tiles later), never right behind the loads
 __device__ __forceinline__ void mask_tile256(int n_rows, int k0, int k_end, int tid, float4 (&v)[4]) {
     const int rq = (tid & 63) * 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool c0 = rq + 0 < n_rows, c1 = rq + 1 < n_rows, c2 = rq + 2 < n_rows, c3 = rq + 3 < n_rows;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const bool kin = k0 + (tid >> 6) + 4 * u < k_end;
-        v[u].x = (kin && rq + 0 < n_rows) ? v[u].x : 0.f;
-        v[u].y = (kin && rq + 1 < n_rows) ? v[u].y : 0.f;
-        v[u].z = (kin && rq + 2 < n_rows) ? v[u].z : 0.f;
-        v[u].w = (kin && rq + 3 < n_rows) ? v[u].w : 0.f;
+        const bool kin = k0 + wave + 4 * u < k_end;  // wave-uniform
+        v[u].x = (kin && c0) ? v[u].x : 0.f;
+        v[u].y = (kin && c1) ? v[u].y : 0.f;
+        v[u].z = (kin && c2) ? v[u].z : 0.f;
+        v[u].w = (kin && c3) ? v[u].w : 0.f;
     }
 }
 
