@@ -92,18 +92,24 @@ def render_envmap(model, model_input, env_light, light_h=16, light_batch=64, pix
     rgb_sum = torch.zeros(n_pix, 3, device=dev)
     vis_sum = torch.zeros(n_pix, 3, device=dev)
     n_lights = lxyz.shape[0]
-    for l0 in range(0, n_lights, light_batch):
-        mi = dict(model_input)
-        mi['light_direction'] = F.normalize(lxyz[l0:l0 + light_batch], p=2, dim=-1)
-        mi['light_intensity'] = env[l0:l0 + light_batch].contiguous()
-        chunks = [mi] if pixel_chunk is None else split_input(mi, n_pix, pixel_chunk)
-        p0 = 0
-        for s in chunks:
-            out = model(s)
-            n = s['uv'].shape[1]
-            rgb_sum[p0:p0 + n] += out['sg_rgb_values'].reshape(-1, n, 3).sum(0)
-            if visibility:
-                vis_sum[p0:p0 + n] += out.get('visibility', torch.ones_like(out['sg_rgb_values'])).reshape(-1, n, 3).sum(0)
-            p0 += n
+    # pixel chunks are cut once and shared by all light batches: the model then computes their light-independent
+    # parts (positional encodings, BRDF and normal nets) once per chunk instead of once per (chunk, light batch)
+    chunks = [dict(model_input)] if pixel_chunk is None else split_input(model_input, n_pix, pixel_chunk)
+    model._eval_cache = {}
+    try:
+        for l0 in range(0, n_lights, light_batch):
+            light_direction = F.normalize(lxyz[l0:l0 + light_batch], p=2, dim=-1)
+            light_intensity = env[l0:l0 + light_batch].contiguous()
+            p0 = 0
+            for s in chunks:
+                s['light_direction'], s['light_intensity'] = light_direction, light_intensity
+                out = model(s)
+                n = s['uv'].shape[1]
+                rgb_sum[p0:p0 + n] += out['sg_rgb_values'].reshape(-1, n, 3).sum(0)
+                if visibility:
+                    vis_sum[p0:p0 + n] += out.get('visibility', torch.ones_like(out['sg_rgb_values'])).reshape(-1, n, 3).sum(0)
+                p0 += n
+    finally:
+        model._eval_cache = None
     rgb = rgb_sum.clamp(0, 1)
     return (rgb, vis_sum / n_lights) if visibility else rgb
