@@ -33,6 +33,8 @@ def test_struct_layout_matches_header():
     from psnerf_amd import hip
     assert ctypes.sizeof(hip.PsnMlpLayer) == 40
     assert ctypes.sizeof(hip.PsnMlpDesc) == 24 + 12 * 40
+    assert ctypes.sizeof(hip.PsnBf16Desc) == 16 + 16          # 4 x int32 + uint8[PSN_MLP_MAX_LAYERS + 4]
+    assert ctypes.sizeof(hip.PsnWnItem) == 64                  # 6 pointers + 2 x int32 + float, padded to 8
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only check')
@@ -58,6 +60,16 @@ def test_argument_validation_needs_no_gpu():
     assert rc == -1 and b'null' in lib.psn_last_error()
     rc = lib.psn_gemm(0, 1, 4, 0, 4, 1, 4, 1, 4, 1, 4, None, 0, None, 0, None, 0, None, 0, 1, None, None, None)
     assert rc == -1 and b'bad shape' in lib.psn_last_error()
+    d = hip.PsnBf16Desc()
+    d.n_hidden, d.n_out = 3, 1
+    rc = lib.psn_mlp_infer_bf16(ctypes.byref(d), None, None, None, 1, 1, None, 1, 1, 10, None, None)
+    assert rc == -1 and b'null' in lib.psn_last_error()
+    rc = lib.psn_weight_norm_fwd(0, None, None)
+    assert rc == -1 and b'n_items' in lib.psn_last_error()
+    rc = lib.psn_secant_step(None, 0.5, None, None, None, None, None, None, None, None, 4, None)
+    assert rc == -1 and b'null' in lib.psn_last_error()
+    rc = lib.psn_mlp_pack_bf16(None, 4, 4, 4, 0, 8, 0, 1, None, None)
+    assert rc == -1 and b'null' in lib.psn_last_error()
 
 
 def test_conf_reader_on_hocon_subset():
