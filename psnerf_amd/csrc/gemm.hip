@@ -453,36 +453,68 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
     }                                                                                            \
     store_tile<false, T256>(lds256 + (BUF) * T256_BUF, tid, ra[S]);                              \
     store_tile<false, T256>(lds256 + (BUF) * T256_BUF + BK * T256_LD, tid, rb[S]);
-#define T_COMPUTE(BUF)                                                                           \
+    // Staging item J (0..7) of a step: one float4 of operand A (J < 4, k row wave + 4 J) or B (k row wave + 4 (J - 4)) of
+    // tile T+1 is masked, added to the column sums (A; same association as T_STORE), written to the other LDS buffer,
+    // and its register receives the same row of tile T+3.  One item rides in the MFMA gaps of each k-pair of T_STEP.
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rq_ = (tid & 63) * 4;
+    const bool am0 = rq_ + 0 < (int)g.M, am1 = rq_ + 1 < (int)g.M, am2 = rq_ + 2 < (int)g.M, am3 = rq_ + 3 < (int)g.M;
+    const bool bm0 = rq_ + 0 < g.N, bm1 = rq_ + 1 < g.N, bm2 = rq_ + 2 < g.N, bm3 = rq_ + 3 < g.N;
+    const int rqa = min(rq_, (((int)g.M - 1) >> 2) << 2), rqb = min(rq_, ((g.N - 1) >> 2) << 2);
+    float4 cs01 = make_float4(0.f, 0.f, 0.f, 0.f), cs2 = cs01;
+#define T_ITEM(BUF, S, T, J)                                                                     \
     {                                                                                            \
-        const float* As = lds256 + (BUF) * T256_BUF + wr * 128 + li;                             \
-        const float* Bs = lds256 + (BUF) * T256_BUF + BK * T256_LD + wc * 128 + li;              \
-        float pa[2][4], pb[2][4];                                                                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) pa[0][i] = As[lh * T256_LD + i * 32];      \
-        _Pragma("unroll") for (int n = 0; n < 4; ++n) pb[0][n] = Bs[lh * T256_LD + n * 32];      \
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                       \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                          \
-            if (j < 7) {                                                                         \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) pa[(j + 1) & 1][i] = As[(2 * j + 2 + lh) * T256_LD + i * 32]; \
-                _Pragma("unroll") for (int n = 0; n < 4; ++n) pb[(j + 1) & 1][n] = Bs[(2 * j + 2 + lh) * T256_LD + n * 32]; \
-            }                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
-                _Pragma("unroll") for (int n = 0; n < 4; ++n)                                    \
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j & 1][i], pb[j & 1][n], acc[i][n], 0, 0, 0); \
-            if (j < 7) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                  \
+        constexpr int u_ = (J) & 3;                                                              \
+        constexpr bool isb_ = (J) >= 4;                                                          \
+        float4& x_ = isb_ ? rb[S][u_] : ra[S][u_];                                               \
+        const bool kin_ = k_begin + ((T) + 1) * BK + wave_u + 4 * u_ < k_end;                    \
+        x_.x = (kin_ && (isb_ ? bm0 : am0)) ? x_.x : 0.f;                                        \
+        x_.y = (kin_ && (isb_ ? bm1 : am1)) ? x_.y : 0.f;                                        \
+        x_.z = (kin_ && (isb_ ? bm2 : am2)) ? x_.z : 0.f;                                        \
+        x_.w = (kin_ && (isb_ ? bm3 : am3)) ? x_.w : 0.f;                                        \
+        if (!isb_ && do_cs) {                                                                    \
+            if (u_ == 0) cs01 = x_;                                                              \
+            else if (u_ == 1) { cs01.x += x_.x; cs01.y += x_.y; cs01.z += x_.z; cs01.w += x_.w; } \
+            else if (u_ == 2) cs2 = x_;                                                          \
+            else { cs.x += cs01.x + (cs2.x + x_.x); cs.y += cs01.y + (cs2.y + x_.y); cs.z += cs01.z + (cs2.z + x_.z); cs.w += cs01.w + (cs2.w + x_.w); } \
         }                                                                                        \
+        *reinterpret_cast<float4*>(lds256 + (BUF) * T256_BUF + (isb_ ? BK * T256_LD : 0) + (wave_u + 4 * u_) * T256_LD + rq_) = x_; \
+        const int kc_ = min(k_begin + ((T) + 3) * BK + wave_u + 4 * u_, k_end - 1);             \
+        x_ = *reinterpret_cast<const float4*>((isb_ ? Bp + (int64_t)kc_ * ldb + rqb : Ap + (int64_t)kc_ * lda + rqa)); \
     }
-    // one wave per SIMD: nothing else hides the LDS latency, so T_COMPUTE requests the operands of k-pair j+1 before
-    // the 16 MFMAs of k-pair j are issued (two register sets, order pinned for the scheduler)
+    // one wave per SIMD: nothing else hides latencies or the staging work, so every k-pair j of a step is its own
+    // scheduling region: operand reads of k-pair j+1 first, then the 16 MFMAs of k-pair j with staging item j in their gaps
 #define T_STEP(T, S)                                                                             \
     {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        T_COMPUTE((T) & 1)                                                                       \
+        const float* As = lds256 + ((T) & 1) * T256_BUF + wr * 128 + li;                         \
+        const float* Bs = lds256 + ((T) & 1) * T256_BUF + BK * T256_LD + wc * 128 + li;          \
+        float pa[2][4], pb[2][4];                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) pa[0][i] = As[lh * T256_LD + i * 32];      \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) pb[0][n] = Bs[lh * T256_LD + n * 32];      \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        T_STORE(((T) + 1) & 1, S, (T) + 1) /* past the end: clamped loads, zeroed by the mask */  \
-        T_FETCH((T) + 3, S)                                                                      \
+        T_PAIR(T, S, 0) T_PAIR(T, S, 1) T_PAIR(T, S, 2) T_PAIR(T, S, 3)                          \
+        T_PAIR(T, S, 4) T_PAIR(T, S, 5) T_PAIR(T, S, 6) T_PAIR(T, S, 7)                          \
         __syncthreads();                                                                         \
+    }
+#define T_PAIR(T, S, J)                                                                          \
+    {                                                                                            \
+        if ((J) < 7) {                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) pa[((J) + 1) & 1][i] = As[(2 * (J) + 2 + lh) * T256_LD + i * 32]; \
+            _Pragma("unroll") for (int n = 0; n < 4; ++n) pb[((J) + 1) & 1][n] = Bs[(2 * (J) + 2 + lh) * T256_LD + n * 32]; \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            _Pragma("unroll") for (int n = 0; n < 4; ++n)                                        \
+                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(J) & 1][i], pb[(J) & 1][n], acc[i][n], 0, 0, 0); \
+        T_ITEM(((T) + 1) & 1, S, T, J)                                                           \
+        if ((J) < 7) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                          \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                   \
+            if (q_ == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                      \
+            if (q_ == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                      \
+        }                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
     }
     T_FETCH(0, 0)
     T_STORE(0, 0, 0)
@@ -496,7 +528,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
     }
     if (t < nt) T_STEP(t, 0)
 #undef T_STEP
-#undef T_COMPUTE
+#undef T_PAIR
+#undef T_ITEM
 #undef T_FETCH
 #undef T_STORE
     if (do_cs) {  // thread tid staged columns 4 (tid % 64) .. +3 (rows tid / 64 + 4u of every k-tile): reduce over the 4 waves
