@@ -29,6 +29,16 @@ void set_error(const char* fmt, ...);
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// max(x, 0) in ONE instruction.  fmaxf(x, 0.0f) on an MFMA result compiles to two (v_max_f32 x, x, x to quiet a
+// possible signalling NaN, then the max; v_med3 / maxnum intrinsics are folded back to the same pair): in the fp32
+// MFMA kernels every vector instruction costs matrix-pipe time, and ReLU runs on every activation.  v_max_f32 itself
+// already returns the non-NaN operand, i.e. 0 for a NaN input, like fmaxf.
+__device__ __forceinline__ float relu1(float x) {
+    float o;
+    asm("v_max_f32 %0, 0, %1" : "=v"(o) : "v"(x));
+    return o;
+}
+
 // exp(-|t|) with a Cody-Waite split of the exp2 argument: v_exp_f32 is ~1 ulp on 2^x, the split keeps
 // the product |t|*log2(e) exact to ~2^-48, so u is accurate to ~2 ulp for |t| <= 100.
 __device__ __forceinline__ float exp_neg_abs(float at) {
@@ -61,7 +71,7 @@ __device__ __forceinline__ void softplus100_sig(float z, float& sp, float& s) {
     float r = 1.0f / (1.0f + u);
     s = t >= 0.0f ? r : u * r;
     // x / 100 correctly rounded without the IEEE division sequence (its length makes hipcc branch around it)
-    float x = fmaxf(t, 0.0f) + l;
+    float x = relu1(t) + l;
     float q = x * 0.01f;
     q = fmaf(fmaf(-q, 100.0f, x), 0.01f, q);
     sp = t > 20.0f ? z : q;

@@ -198,7 +198,7 @@ __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&
         for (int r = 0; r < 4; ++r) {
             const float z = acc[mt][r];
             o2[r] = z;
-            if constexpr (CODE == PSN_ACT_RELU) o[r] = fmaxf(z, 0.0f);
+            if constexpr (CODE == PSN_ACT_RELU) o[r] = relu1(z);
             else if constexpr (CODE == PSN_ACT_SOFTPLUS100) { float a, sg; softplus100_sig(z, a, sg); o[r] = a; o2[r] = sg; }
             else if constexpr (CODE == PSN_ACT_RELU_MASK) o[r] = t1[mt][r] > 0.0f ? z : 0.0f;
             else if constexpr (CODE == PSN_ACT_MUL_AUX) o[r] = z * t1[mt][r];
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) act[mt][r] = fmaxf(acc[mt][r], 0.0f);
+                    for (int r = 0; r < 4; ++r) act[mt][r] = relu1(acc[mt][r]);
             } else if (L.act == PSN_ACT_SOFTPLUS100) {
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) {
