@@ -53,11 +53,18 @@ __device__ __forceinline__ float exp_neg_abs(float at) {
 
 // log1p(u) for u in [0, 1]: short alternating series below 1/16 (no cancellation in 1+u), otherwise
 // log2(1+u)*ln2 with the classic (u - ((1+u)-1))/(1+u) rounding correction.
-__device__ __forceinline__ float log1p_unit(float u) {
-    float ser = u * (1.0f - u * (0.5f - u * (0.333333343f - u * (0.25f - u * (0.2f - u * (0.166666672f - u * 0.142857149f))))));
-    float w = 1.0f + u;
+__device__ __forceinline__ float log1p_unit(float u, float w, float rw) {  // w = 1 + u, rw ~ 1 / w (shared with the sigmoid)
+    // explicit FMAs: 7 instead of 14 rounded operations (every vector instruction costs matrix-pipe time in the fp32
+    // MFMA kernels) and one rounding per step instead of two
+    float p = fmaf(-u, 0.142857149f, 0.166666672f);
+    p = fmaf(-u, p, 0.2f);
+    p = fmaf(-u, p, 0.25f);
+    p = fmaf(-u, p, 0.333333343f);
+    p = fmaf(-u, p, 0.5f);
+    p = fmaf(-u, p, 1.0f);
+    const float ser = u * p;
     // the correction term is O(2^-24) of the result, a 1-ulp reciprocal is plenty (and keeps the select branch-free)
-    float big = fmaf(__builtin_amdgcn_logf(w), 0.693147182464599609375f, (u - (w - 1.0f)) * __builtin_amdgcn_rcpf(w));
+    const float big = fmaf(__builtin_amdgcn_logf(w), 0.693147182464599609375f, (u - (w - 1.0f)) * rw);
     return u < 0.0625f ? ser : big;
 }
 
@@ -67,8 +74,10 @@ __device__ __forceinline__ float log1p_unit(float u) {
 __device__ __forceinline__ void softplus100_sig(float z, float& sp, float& s) {
     float t = z * 100.0f;
     float u = exp_neg_abs(fabsf(t));
-    float l = log1p_unit(u);
-    float r = 1.0f / (1.0f + u);
+    const float w = 1.0f + u;
+    const float rw = __builtin_amdgcn_rcpf(w);     // 1 ulp
+    float l = log1p_unit(u, w, rw);
+    float r = fmaf(fmaf(-w, rw, 1.0f), rw, rw);    // one Newton step: 1 / w to ~0.5 ulp without the IEEE division sequence
     s = t >= 0.0f ? r : u * r;
     // x / 100 correctly rounded without the IEEE division sequence (its length makes hipcc branch around it)
     float x = relu1(t) + l;
