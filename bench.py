@@ -170,7 +170,7 @@ def main():
                     'traffic': traffic, 'avg_launch_ms': round(avg_ms, 3), 'launches': len(durs),
                     'share_of_step': round(avg_ms * len(durs) / args.steps / ms_per_step, 3)}
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # the CPU oracle is timed at N = 1 only (other ranks would idle behind it)
         cpu = cpu_baseline()
     line = {
         'metric': 'ray-samples/sec (train step) on BEAR stage2', 'value': round(value, 1), 'unit': 'ray-samples/s',
