@@ -142,6 +142,9 @@ def main():
         dist.all_reduce(ns, op=dist.ReduceOp.SUM)
     dt = float(t.item())
     ns_total = int(ns.item())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()  # every rank leaves the group cleanly before rank 0 prints
     if rank != 0:
         return
     ms_per_step = dt / args.steps * 1e3
