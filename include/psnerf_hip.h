@@ -198,6 +198,17 @@ typedef struct {
 int psn_mlp_pack_layer(const float* W, int64_t ldw, int rows, int cols, int transpose, int n_mt, int k_tiles, float* dst,
                        void* stream);
 
+/* The same for up to PSN_PACK_MAX_ITEMS blocks in one launch (all layers of a network after an optimiser step).
+ * HOST array of items holding device pointers. */
+#define PSN_PACK_MAX_ITEMS 24
+typedef struct {
+    const float* W;
+    float* dst;
+    int64_t ldw;
+    int rows, cols, transpose, n_mt, k_tiles;
+} PsnPackItem;
+int psn_mlp_pack_layers(int n_items, const PsnPackItem* items, void* stream);
+
 /* Row q of the virtual input matrix is [ A[(q / a_div) % a_mod, :] | B[(q / b_div) % b_mod, :] ];
  * tables are row-major with strides in_kt_a*32 / in_kt_b*32 floats, 16-byte aligned.
  * Because a layer that reads the input block is linear in it, W_in [A_row | B_row] = W_a A_row + W_b B_row

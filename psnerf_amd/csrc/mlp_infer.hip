@@ -495,7 +495,54 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__
     }
 }
 
+// All weight blocks of a network in one launch (a train step re-packs ~40 blocks after every optimiser step; one launch
+// each was ~0.15 ms of launch-bound work).
+struct PackGroupArgs {
+    PsnPackItem it[PSN_PACK_MAX_ITEMS];
+    int64_t start[PSN_PACK_MAX_ITEMS + 1];  // first 256-float chunk of each item
+    int n;
+};
+__global__ __launch_bounds__(256) void mlp_pack_group_kernel(PackGroupArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int64_t)blockIdx.x >= a.start[i + 1]) ++i;
+    const PsnPackItem it = a.it[i];
+    const int64_t e = ((int64_t)blockIdx.x - a.start[i]) * 256 + threadIdx.x;  // items are multiples of 1024 floats
+    const int nmt16 = 2 * it.n_mt;
+    const int c = (int)(e & 3);
+    const int lane = (int)((e >> 2) & 63);
+    const int64_t blk = e >> 8;
+    const int per_stage = 2 * nmt16;
+    const int kt = (int)(blk / per_stage);
+    const int bi = (int)(blk % per_stage);
+    const int half = bi / nmt16, mt = bi % nmt16;
+    const int r = 16 * mt + (lane & 15), k = 32 * kt + 16 * half + 4 * (lane >> 4) + c;
+    float v = 0.0f;
+    if (r < it.rows && k < it.cols) v = it.transpose ? it.W[(int64_t)k * it.ldw + r] : it.W[(int64_t)r * it.ldw + k];
+    it.dst[e] = v;
+}
+
 }  // namespace psn
+
+extern "C" int psn_mlp_pack_layers(int n_items, const PsnPackItem* items, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(items && n_items >= 1 && n_items <= PSN_PACK_MAX_ITEMS, "mlp_pack_layers: n_items=%d", n_items);
+    PackGroupArgs a;
+    a.n = n_items;
+    a.start[0] = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const PsnPackItem& it = items[i];
+        PSN_CHECK_ARG(it.W && it.dst, "mlp_pack_layers: item %d: null pointer", i);
+        PSN_CHECK_ARG(it.n_mt >= 1 && it.n_mt <= 8 && it.k_tiles >= 1 && it.k_tiles <= 12, "mlp_pack_layers: item %d: n_mt=%d k_tiles=%d", i, it.n_mt, it.k_tiles);
+        PSN_CHECK_ARG(it.rows >= 1 && it.rows <= it.n_mt * 32 && it.cols >= 1 && it.cols <= it.k_tiles * 32,
+                      "mlp_pack_layers: item %d: %d x %d does not fit %d x %d", i, it.rows, it.cols, it.n_mt * 32, it.k_tiles * 32);
+        PSN_CHECK_ARG(it.ldw >= (it.transpose ? it.rows : it.cols), "mlp_pack_layers: item %d: ldw too small", i);
+        a.it[i] = it;
+        a.start[i + 1] = a.start[i] + (int64_t)it.n_mt * it.k_tiles * 4;  // n_mt * k_tiles * 1024 floats / 256
+    }
+    hipLaunchKernelGGL(mlp_pack_group_kernel, dim3((unsigned)a.start[n_items]), dim3(256), 0, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("mlp_pack_layers");
+    return PSN_OK;
+}
 
 extern "C" int psn_mlp_pack_layer(const float* W, int64_t ldw, int rows, int cols, int transpose, int n_mt, int k_tiles,
                                   float* dst, void* stream) {

@@ -127,10 +127,12 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
         b_off += rows
     w_buf = torch.empty(max(off, 4), device=device, dtype=torch.float32)
     b_buf = torch.cat(biases).contiguous()
+    group = []
     for w, n_mt, k_tiles, o in plan:
         m, tr, r, c = _src(w)
         assert r <= n_mt * 32 and c <= k_tiles * 32, 'pack_layers: block %dx%d does not fit %dx%d' % (r, c, n_mt * 32, k_tiles * 32)
-        hip.mlp_pack_layer(m if m.dtype == torch.float32 else m.float(), n_mt, k_tiles, w_buf[o:o + n_mt * k_tiles * 1024], transpose=tr)
+        group.append((m if m.dtype == torch.float32 else m.float(), tr, n_mt, k_tiles, w_buf[o:o + n_mt * k_tiles * 1024]))
+    hip.mlp_pack_layers(group)  # every block of the network in one launch
     desc.init_stride = width * len(init_wa)
     if init_wa:
         return PackedMLP(desc, w_buf, b_buf, torch.cat(init_wa).contiguous().float(),

@@ -46,6 +46,11 @@ class PsnBf16Desc(ctypes.Structure):
                 ('has_in', ctypes.c_uint8 * (MAX_LAYERS + 4))]
 
 
+class PsnPackItem(ctypes.Structure):
+    _fields_ = [('W', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('ldw', i64), ('rows', i32), ('cols', i32),
+                ('transpose', i32), ('n_mt', i32), ('k_tiles', i32)]
+
+
 class PsnWnItem(ctypes.Structure):
     _fields_ = [('v', ctypes.c_void_p), ('g', ctypes.c_void_p), ('w', ctypes.c_void_p), ('dw', ctypes.c_void_p),
                 ('dv', ctypes.c_void_p), ('dg', ctypes.c_void_p), ('rows', i32), ('cols', i32), ('scale', f32)]
@@ -76,6 +81,7 @@ SIGNATURES = {
     'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_sample_points': (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, i32, i32, i32, c_f, c_f]),
+    'psn_mlp_pack_layers': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_sg_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f]),
     'psn_sg_shade_bwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f, c_f,
                                c_f, c_f, c_f, c_f, c_f, c_f]),
@@ -360,6 +366,23 @@ def mlp_pack_layer(W, n_mt, k_tiles, dst, transpose=False):
     rows, cols = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
     _check(_lib.psn_mlp_pack_layer(W.data_ptr(), W.stride(0), rows, cols, int(transpose), n_mt, k_tiles, dst.data_ptr(),
                                    _stream()), 'mlp_pack_layer')
+
+
+PACK_MAX_ITEMS = 24
+
+
+def mlp_pack_layers(plan):
+    """plan: list of (W, transpose, n_mt, k_tiles, dst) like mlp_pack_layer, packed in ONE launch per 24 blocks."""
+    for c0 in range(0, len(plan), PACK_MAX_ITEMS):
+        chunk = plan[c0:c0 + PACK_MAX_ITEMS]
+        arr = (PsnPackItem * len(chunk))()
+        for e, (W, transpose, n_mt, k_tiles, dst) in zip(arr, chunk):
+            assert W.dim() == 2 and W.stride(1) == 1 and W.is_cuda and W.dtype == torch.float32
+            assert dst.is_contiguous() and dst.numel() == n_mt * k_tiles * 1024
+            rows, cols = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
+            e.W, e.dst, e.ldw = W.data_ptr(), dst.data_ptr(), W.stride(0)
+            e.rows, e.cols, e.transpose, e.n_mt, e.k_tiles = rows, cols, int(transpose), n_mt, k_tiles
+        _check(_lib.psn_mlp_pack_layers(len(chunk), ctypes.addressof(arr), _stream()), 'mlp_pack_layers')
 
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
