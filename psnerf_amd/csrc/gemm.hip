@@ -57,6 +57,14 @@ struct GemmArgs {
     int b2_div, b2_mod, b_split;
 };
 
+// floor(k / d) for 0 <= k < 2^24, d >= 1: float reciprocal estimate, corrected by at most one.
+__device__ __forceinline__ int fastdiv24(int k, int d) {
+    int q = (int)((float)k * __builtin_amdgcn_rcpf((float)d));
+    const int r = k - q * d;
+    q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    return q;
+}
+
 // Stage one 128 x 16 operand tile into registers.  KCONTIG: source rows run along k (row-major [rows][K]);
 // otherwise the source is [K][rows] row-major.
 template <bool KCONTIG, int ROWS>
@@ -94,7 +102,19 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ src, int64_
                 // halves [PE(x_n) | PE(l_v)] of one input block, side by side in one product)
                 const bool second = col_split > 0 && row >= col_split;
                 const int kd = second ? k_div2 : k_div, km = second ? k_mod2 : k_mod;
-                const int ks = kd > 0 ? (k / kd) % km : k;
+                int ks = k;
+                if (kd > 0) {
+                    // (k / kd) % km without integer division (two of them per load were ~50 vector instructions per
+                    // k-tile, and every one costs matrix-pipe time): float reciprocal + one correction step, exact for
+                    // k < 2^24; km == 0 = the host found the modulo to be the identity ((K - 1) / kd < km)
+                    if (k_end <= (1 << 24)) {
+                        if (kd > 1) ks = fastdiv24(k, kd);
+                        if (km > 0) ks -= fastdiv24(ks, km) * km;
+                    } else {
+                        ks = k / kd;
+                        if (km > 0) ks %= km;
+                    }
+                }
                 const float* p = second ? src2 + (int64_t)ks * ld2 + (row - col_split) : src + (int64_t)ks * ld + row;
                 if (vec_ok && row + 3 < n_rows) {
                     x = *reinterpret_cast<const float4*>(p);
@@ -676,14 +696,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
 }
 
 // column sums, two stages: partial[b][n] = sum over a row slab, then out[n] = sum_b partial[b][n]
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t M, int N,
-                                                             int64_t ldx, int64_t rows_per_block,
+// with row weights w [M]: partial sums of w[m] * X[m][n] (product and sum rounded separately, as the elementwise
+// product followed by a column sum would be): the 1 x N weight gradient of a single-output layer, g^T H, as a
+// bandwidth-bound reduction instead of a 1-row GEMM item that occupies a whole 128-row tile
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                             int64_t M, int N, int64_t ldx, int64_t rows_per_block,
                                                              float* __restrict__ partial) {
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(M, r0 + rows_per_block);
     for (int n = threadIdx.x; n < N; n += 256) {
         float s = 0.0f;
-        for (int64_t m = r0; m < r1; ++m) s += X[m * ldx + n];
+        if (w != nullptr) {
+            for (int64_t m = r0; m < r1; ++m) s += w[m] * X[m * ldx + n];
+        } else {
+            for (int64_t m = r0; m < r1; ++m) s += X[m * ldx + n];
+        }
         partial[(int64_t)blockIdx.x * N + n] = s;
     }
 }
@@ -840,8 +867,10 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         GemmArgs& g = big ? gb.g[gb.n] : gg.g[gg.n];
         g.M = it.M; g.N = it.N; g.K = (int)K; g.A = it.A; g.lda = it.lda; g.B = it.B; g.ldb = it.ldb;
         g.A2 = it.A2; g.lda2 = it.lda2; g.B2 = it.B2; g.ldb2 = it.ldb2;
-        g.b_div = (int)it.b_div; g.b_mod = (int)it.b_mod;
-        g.Bt2 = it.B_tab2; g.ldbt2 = it.ldb_tab2; g.b2_div = (int)it.b2_div; g.b2_mod = (int)it.b2_mod; g.b_split = it.b_split;
+        // a modulo that cannot wrap ((K - 1) / div < mod) is passed as 0 = identity
+        g.b_div = (int)it.b_div; g.b_mod = (it.b_div > 0 && (K - 1) / it.b_div < it.b_mod) ? 0 : (int)it.b_mod;
+        g.Bt2 = it.B_tab2; g.ldbt2 = it.ldb_tab2; g.b2_div = (int)it.b2_div; g.b_split = it.b_split;
+        g.b2_mod = (it.b2_div > 0 && (K - 1) / it.b2_div < it.b2_mod) ? 0 : (int)it.b2_mod;
         g.bias = nullptr; g.epi = PSN_EPI_NONE; g.aux_in = g.aux_in2 = nullptr; g.aux_out = nullptr;
         g.ld_aux_in = g.ld_aux_in2 = g.ld_aux_out = 0;
         g.tiles_n = big ? 1 : (it.N + 127) / 128;
@@ -896,7 +925,7 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
     return PSN_OK;
 }
 
-extern "C" int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* out, int accumulate,
+extern "C" int psn_colsum(const float* X, const float* row_weight, int64_t M, int N, int64_t ldx, float* out, int accumulate,
                           float* workspace, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(X && out && workspace, "colsum: null pointer");
@@ -907,7 +936,7 @@ extern "C" int psn_colsum(const float* X, int64_t M, int N, int64_t ldx, float* 
     if (nblocks < 1) nblocks = 1;
     int64_t rpb = (M + nblocks - 1) / nblocks;
     if (rpb < 1) rpb = 1;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, st, X, M, N, ldx, rpb, workspace);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, st, X, row_weight, M, N, ldx, rpb, workspace);
     PSN_CHECK_LAUNCH("colsum partial");
     hipLaunchKernelGGL(colsum_final_kernel, dim3(N), dim3(256), 0, st, workspace, nblocks, N,
                        accumulate, out);

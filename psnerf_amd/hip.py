@@ -78,7 +78,7 @@ SIGNATURES = {
     'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, c_f, i64,
                        i32, c_f, c_f, c_f]),
     'psn_gemm_tn_grouped': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
-    'psn_colsum': (i32, [c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
+    'psn_colsum': (i32, [c_f, c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_sample_points': (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, i32, i32, i32, c_f, c_f]),
     'psn_mlp_pack_layers': (i32, [i32, ctypes.c_void_p, c_f]),
@@ -348,13 +348,16 @@ def gemm_tn_grouped(items, split_k=None):
     return res
 
 
-def colsum(X, out=None, accumulate=False):
+def colsum(X, out=None, accumulate=False, row_weight=None):
+    """out[n] (+)= sum_m w[m] X[m, n]; row_weight [M] or [M, 1] (None: plain column sums)."""
     M, N = X.shape
     if out is None:
         out = torch.empty(N, device=X.device, dtype=torch.float32)
+    if row_weight is not None:
+        assert row_weight.numel() == M
     ws = workspace(2048 * N, X.device)
-    _check(_lib.psn_colsum(_mat_ptr(X, 'X'), M, N, _ld(X), _ptr(out, 'out'), int(accumulate), ws.data_ptr(),
-                           _stream()), 'colsum')
+    _check(_lib.psn_colsum(_mat_ptr(X, 'X'), _ptr(row_weight, 'row_weight', True), M, N, _ld(X), _ptr(out, 'out'),
+                           int(accumulate), ws.data_ptr(), _stream()), 'colsum')
     return out
 
 

@@ -578,8 +578,12 @@ class VisibilityPair(torch.autograd.Function):
         # Every weight gradient in one grouped launch.  The input block [PE(x_n) | PE(l_v)] of row k = v Ns + n is never
         # expanded: its two halves are TABLES read as pe_x[k % Ns] and pe_lv[k // Ns] by the GEMM itself, side by side in
         # one 128-column product.
-        items = [dict(A=g, B=H[n - 2], colsum=True)]
-        where = [(n - 1, 'w')]
+        # last layer (one output): dW = g^T h as a weighted column sum, db = sum g -- a 1-row GEMM item would occupy a
+        # whole 128-row tile per K slice
+        grads[2 * (n - 1)] = hip.colsum(H[n - 2], row_weight=g).unsqueeze(0)
+        grads[2 * (n - 1) + 1] = g.sum(0)
+        items = []
+        where = []
         for li in range(n - 2, -1, -1):
             dz = DZ[n - 2 - li]
             if li > 0:
@@ -593,7 +597,7 @@ class VisibilityPair(torch.autograd.Function):
             parts[(li, kind)] = C
             if cs is not None:
                 grads[2 * li + 1] = cs
-        for li in range(n):
+        for li in range(n - 1):
             blocks = [parts[(li, 'w')]] if (li, 'w') in parts else []
             if (li, 'xl') in parts:  # columns [0, 64) = d W_x (table pe_x), [64, 128) = d W_l (table pe_lv)
                 blocks += [parts[(li, 'xl')][:, cols_a], parts[(li, 'xl')][:, pe_x.shape[1] + cols_b]]
@@ -703,7 +707,7 @@ class GeoFieldFused(torch.autograd.Function):
         res = hip.gemm_tn_grouped(items)
         for l in range(n - 1):
             dW[l], db[l] = res[l]
-        row0 = hip.colsum(d_logit * a_last)
+        row0 = hip.colsum(a_last, row_weight=d_logit)  # d_logit^T a_last without the [Q,256] product
         if sweep:
             row0 = row0 + hip.colsum(dR[n - 1])
         dW[n - 1] = torch.cat([row0.unsqueeze(0), res[n - 1][0]], dim=0)
