@@ -124,10 +124,11 @@ typedef struct {
 int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
                         int64_t workspace_floats, void* stream);
 
-/* column sums: out[n] (+)= sum_m w[m] X[m,n]  (row_weight = NULL: w = 1) -- bias gradients, and with weights the
- * 1 x N weight gradient g^T H of a single-output layer.  workspace >= 2048*N floats */
-int psn_colsum(const float* X, const float* row_weight, int64_t M, int N, int64_t ldx, float* out, int accumulate,
-               float* workspace, void* stream);
+/* column sums: out[j, n] (+)= sum_m w[m, j] X[m, n] for n_w <= 4 weight columns (row_weight [M, n_w], row stride ldw), or
+ * plain column sums out[n] (+)= sum_m X[m, n] with row_weight = NULL, n_w = 0 -- bias gradients, and with weights the
+ * n_w x N weight gradient g^T H of a layer with few outputs.  workspace >= 2048*N floats */
+int psn_colsum(const float* X, const float* row_weight, int n_w, int64_t ldw, int64_t M, int N, int64_t ldx, float* out,
+               int accumulate, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------
  * Points along rays.  Replaces the depth-profile arithmetic of stage1/model/rendering.py:110-176 (interval

@@ -696,37 +696,48 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
 }
 
 // column sums, two stages: partial[b][n] = sum over a row slab, then out[n] = sum_b partial[b][n]
-// with row weights w [M]: partial sums of w[m] * X[m][n] (product and sum rounded separately, as the elementwise
-// product followed by a column sum would be): the 1 x N weight gradient of a single-output layer, g^T H, as a
-// bandwidth-bound reduction instead of a 1-row GEMM item that occupies a whole 128-row tile
+// with row weights w [M, n_w] (n_w <= 4): partial sums of w[m][j] * X[m][n] (product and sum rounded separately, as the
+// elementwise product followed by a column sum would be): the n_w x N weight gradient g^T H of a layer with n_w <= 4
+// outputs as a bandwidth-bound reduction (X is read once) instead of an n_w-row GEMM item that occupies a whole
+// 128-row tile per K slice
+template <int NW>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, const float* __restrict__ w,
-                                                             int64_t M, int N, int64_t ldx, int64_t rows_per_block,
-                                                             float* __restrict__ partial) {
+                                                             int64_t ldw, int64_t M, int N, int64_t ldx,
+                                                             int64_t rows_per_block, float* __restrict__ partial) {
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(M, r0 + rows_per_block);
     for (int n = threadIdx.x; n < N; n += 256) {
-        float s = 0.0f;
-        if (w != nullptr) {
-            for (int64_t m = r0; m < r1; ++m) s += w[m] * X[m * ldx + n];
-        } else {
+        if (NW == 0) {
+            float s = 0.0f;
             for (int64_t m = r0; m < r1; ++m) s += X[m * ldx + n];
+            partial[(int64_t)blockIdx.x * N + n] = s;
+        } else {
+            float s[NW > 0 ? NW : 1];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) s[j] = 0.0f;
+            for (int64_t m = r0; m < r1; ++m) {
+                const float x = X[m * ldx + n];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) s[j] += w[m * ldw + j] * x;
+            }
+#pragma unroll
+            for (int j = 0; j < NW; ++j) partial[((int64_t)blockIdx.x * NW + j) * N + n] = s[j];
         }
-        partial[(int64_t)blockIdx.x * N + n] = s;
     }
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int N,
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int N, int NW,
                                                            int accumulate, float* __restrict__ out) {
     __shared__ float red[4];
-    const int n = blockIdx.x;
+    const int j = blockIdx.x / N, n = blockIdx.x % N;  // out[j][n]
     float s = 0.0f;
-    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * N + n];
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[((int64_t)b * NW + j) * N + n];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         float tot = (red[0] + red[1]) + (red[2] + red[3]);
-        out[n] = accumulate ? out[n] + tot : tot;
+        out[blockIdx.x] = accumulate ? out[blockIdx.x] + tot : tot;
     }
 }
 
@@ -925,21 +936,29 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
     return PSN_OK;
 }
 
-extern "C" int psn_colsum(const float* X, const float* row_weight, int64_t M, int N, int64_t ldx, float* out, int accumulate,
-                          float* workspace, void* stream) {
+extern "C" int psn_colsum(const float* X, const float* row_weight, int n_w, int64_t ldw, int64_t M, int N, int64_t ldx,
+                          float* out, int accumulate, float* workspace, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(X && out && workspace, "colsum: null pointer");
     PSN_CHECK_ARG(N > 0 && M >= 0, "colsum: bad shape");
+    PSN_CHECK_ARG(row_weight == nullptr ? n_w == 0 : (n_w >= 1 && n_w <= 4 && ldw >= n_w), "colsum: n_w=%d (1..4 with weights, 0 without)", n_w);
     hipStream_t st = (hipStream_t)stream;
+    const int nw1 = n_w > 0 ? n_w : 1;
     int nblocks = (int)((M + 127) / 128);
-    if (nblocks > 2048) nblocks = 2048;
+    if (nblocks > 2048 / nw1) nblocks = 2048 / nw1;  // workspace: 2048 * N floats
     if (nblocks < 1) nblocks = 1;
     int64_t rpb = (M + nblocks - 1) / nblocks;
     if (rpb < 1) rpb = 1;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, st, X, row_weight, M, N, ldx, rpb, workspace);
+    switch (n_w) {
+        case 0: hipLaunchKernelGGL(colsum_partial_kernel<0>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
+        case 1: hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
+        case 2: hipLaunchKernelGGL(colsum_partial_kernel<2>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
+        case 3: hipLaunchKernelGGL(colsum_partial_kernel<3>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
+        default: hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
+    }
     PSN_CHECK_LAUNCH("colsum partial");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(N), dim3(256), 0, st, workspace, nblocks, N,
-                       accumulate, out);
+    // the partial sums of weight column j form an [nblocks, N] matrix with row stride n_w * N: out [n_w, N]
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(N * nw1), dim3(256), 0, st, workspace, nblocks, N, nw1, accumulate, out);
     PSN_CHECK_LAUNCH("colsum final");
     return PSN_OK;
 }

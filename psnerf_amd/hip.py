@@ -78,7 +78,7 @@ SIGNATURES = {
     'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, c_f, i64,
                        i32, c_f, c_f, c_f]),
     'psn_gemm_tn_grouped': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
-    'psn_colsum': (i32, [c_f, c_f, i64, i32, i64, c_f, i32, c_f, c_f]),
+    'psn_colsum': (i32, [c_f, c_f, i32, i64, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_sample_points': (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, i32, i32, i32, c_f, c_f]),
     'psn_mlp_pack_layers': (i32, [i32, ctypes.c_void_p, c_f]),
@@ -349,15 +349,19 @@ def gemm_tn_grouped(items, split_k=None):
 
 
 def colsum(X, out=None, accumulate=False, row_weight=None):
-    """out[n] (+)= sum_m w[m] X[m, n]; row_weight [M] or [M, 1] (None: plain column sums)."""
+    """Plain column sums [N]: out[n] (+)= sum_m X[m, n]; or with row_weight [M, n_w <= 4] (a 1-D [M] counts as one
+    column) the small weight gradient [n_w, N]: out[j, n] (+)= sum_m w[m, j] X[m, n]."""
     M, N = X.shape
-    if out is None:
-        out = torch.empty(N, device=X.device, dtype=torch.float32)
+    n_w, ldw, wp = 0, 0, None
     if row_weight is not None:
-        assert row_weight.numel() == M
+        w2 = row_weight.reshape(M, -1)
+        assert w2.stride(1) == 1 and 1 <= w2.shape[1] <= 4
+        n_w, ldw, wp = w2.shape[1], w2.stride(0), _mat_ptr(w2, 'row_weight')
+    if out is None:
+        out = torch.empty((n_w, N) if n_w else (N,), device=X.device, dtype=torch.float32)
     ws = workspace(2048 * N, X.device)
-    _check(_lib.psn_colsum(_mat_ptr(X, 'X'), _ptr(row_weight, 'row_weight', True), M, N, _ld(X), _ptr(out, 'out'),
-                           int(accumulate), ws.data_ptr(), _stream()), 'colsum')
+    _check(_lib.psn_colsum(_mat_ptr(X, 'X'), wp, n_w, ldw, M, N, _ld(X), out.data_ptr(), int(accumulate), ws.data_ptr(),
+                           _stream()), 'colsum')
     return out
 
 

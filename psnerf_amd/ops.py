@@ -580,7 +580,7 @@ class VisibilityPair(torch.autograd.Function):
         # one 128-column product.
         # last layer (one output): dW = g^T h as a weighted column sum, db = sum g -- a 1-row GEMM item would occupy a
         # whole 128-row tile per K slice
-        grads[2 * (n - 1)] = hip.colsum(H[n - 2], row_weight=g).unsqueeze(0)
+        grads[2 * (n - 1)] = hip.colsum(H[n - 2], row_weight=g)  # [1, 256]
         grads[2 * (n - 1) + 1] = g.sum(0)
         items = []
         where = []
@@ -707,7 +707,7 @@ class GeoFieldFused(torch.autograd.Function):
         res = hip.gemm_tn_grouped(items)
         for l in range(n - 1):
             dW[l], db[l] = res[l]
-        row0 = hip.colsum(a_last, row_weight=d_logit)  # d_logit^T a_last without the [Q,256] product
+        row0 = hip.colsum(a_last, row_weight=d_logit).reshape(-1)  # d_logit^T a_last without the [Q,256] product
         if sweep:
             row0 = row0 + hip.colsum(dR[n - 1])
         dW[n - 1] = torch.cat([row0.unsqueeze(0), res[n - 1][0]], dim=0)
@@ -758,11 +758,12 @@ class AppNetFused(torch.autograd.Function):
         d_normal = hip.gemm(dz0, Ws[0][:, d_x - 3:d_x].contiguous())  # [Q,3]
         items = [dict(A=dz0, B=x[:, :d_x], colsum=True), dict(A=dz0, B=feat)]
         items += [dict(A=DZ[n - 2 - l], B=H[l - 1], colsum=True) for l in range(1, n - 1)]
-        items.append(dict(A=g, B=H[n - 2], colsum=True))
         res = hip.gemm_tn_grouped(items)
         grads = [torch.cat([res[0][0], res[1][0]], dim=1), res[0][1]]
-        for l in range(1, n):
+        for l in range(1, n - 1):
             grads += [res[l + 1][0], res[l + 1][1]]
+        # output layer (3 colours): g^T h as a weighted column sum (a 3-row GEMM item occupies a whole 128-row tile)
+        grads += [hip.colsum(H[n - 2], row_weight=g), g.sum(0)]
         return (None, d_normal, d_feat, None, None) + tuple(grads)
 
 
