@@ -233,6 +233,22 @@ int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* pa
                   const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
                   const float* act_init, int64_t n_rows, float* out, void* stream);
 
+/* Dense per-pixel outputs of the stage-2 model, stage2/model/renderer.py:145-152,204-264: dense [B, N, C] = fill
+ * everywhere except dense[b, idx[r], c] = rows[(b Ns + r) row_stride + c col_stride] (light-major surface rows;
+ * col_stride 0 broadcasts one column, as the reference's .expand(-1, 3) does).  Up to PSN_SCATTER_MAX_ITEMS outputs in one
+ * launch.  inv [N] int32: surface row of a pixel or -1.  psn_gather_rows is the adjoint: rows [B Ns, C] (contiguous,
+ * written) = dense[b, idx[r], c] with idx [Ns] int64 (the `rows` pointer of an item is then the OUTPUT). */
+#define PSN_SCATTER_MAX_ITEMS 16
+typedef struct {
+    const float* rows;
+    float* dense;
+    int64_t row_stride, col_stride;
+    int B, C;
+    float fill;
+} PsnScatterItem;
+int psn_scatter_rows(int n_items, const PsnScatterItem* items, const int* inv, int64_t N, int64_t Ns, void* stream);
+int psn_gather_rows(int n_items, const PsnScatterItem* items, const int64_t* idx, int64_t N, int64_t Ns, void* stream);
+
 /* One secant (regula falsi) iteration of the surface refinement, stage1/model/rendering.py:525-555, for n hit rays:
  * with occ [n] (occupancy at the current d_pred; NULL for the initial step) the bracket (d_low, d_high, f_low, f_high,
  * all [n], updated in place) moves -- f_mid = occ - tau replaces the end with its sign -- then

@@ -112,3 +112,72 @@ extern "C" int psn_pe_encode_bwd(const float* x, const float* d_out, int64_t n, 
     PSN_CHECK_LAUNCH("pe_encode_bwd");
     return PSN_OK;
 }
+
+// ---- dense outputs of the stage-2 model (stage2/model/renderer.py:145-152, 204-264) -----------------------------------
+// The reference returns per-pixel tensors [B, N, C] pre-filled with a constant (1, or 0 for the SG weights) and carrying
+// the surface rows at the pixels of the surface mask.  All of them (up to PSN_SCATTER_MAX_ITEMS per call) are written by
+// ONE launch instead of a fill + an index_copy each; `inv` [N] maps a pixel to its surface row or -1.  HBM-bound.
+namespace psn {
+struct ScatterArgs {
+    PsnScatterItem it[PSN_SCATTER_MAX_ITEMS];
+    int64_t start[PSN_SCATTER_MAX_ITEMS + 1];  // first 256-element chunk of each item
+    const int* inv;
+    const int64_t* idx;
+    int64_t N, Ns;
+    int n;
+};
+__global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int64_t)blockIdx.x >= a.start[i + 1]) ++i;
+    const PsnScatterItem it = a.it[i];
+    const int64_t e = ((int64_t)blockIdx.x - a.start[i]) * 256 + threadIdx.x;  // element of dense [B, N, C]
+    if (e >= (int64_t)it.B * a.N * it.C) return;
+    const int c = (int)(e % it.C);
+    const int64_t bn = e / it.C;
+    const int64_t n = bn % a.N, b = bn / a.N;
+    const int r = a.inv[n];
+    it.dense[e] = r >= 0 ? it.rows[(b * a.Ns + r) * it.row_stride + c * it.col_stride] : it.fill;
+}
+// adjoint: rows_grad[(b Ns + r), c] = dense_grad[b, idx[r], c]
+__global__ __launch_bounds__(256) void gather_rows_kernel(ScatterArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int64_t)blockIdx.x >= a.start[i + 1]) ++i;
+    const PsnScatterItem it = a.it[i];
+    const int64_t e = ((int64_t)blockIdx.x - a.start[i]) * 256 + threadIdx.x;  // element of rows_grad [B Ns, C]
+    if (e >= (int64_t)it.B * a.Ns * it.C) return;
+    const int c = (int)(e % it.C);
+    const int64_t br = e / it.C;
+    const int64_t r = br % a.Ns, b = br / a.Ns;
+    const_cast<float*>(it.rows)[e] = it.dense[(b * a.N + a.idx[r]) * it.C + c];
+}
+
+static int launch_scatter(int n_items, const PsnScatterItem* items, const int* inv, const int64_t* idx, int64_t N, int64_t Ns,
+                          bool gather, void* stream) {
+    PSN_CHECK_ARG(items && n_items >= 1 && n_items <= PSN_SCATTER_MAX_ITEMS, "scatter_rows: n_items=%d", n_items);
+    PSN_CHECK_ARG(gather ? idx != nullptr : inv != nullptr, "scatter_rows: missing index map");
+    PSN_CHECK_ARG(N >= 1 && Ns >= 0, "scatter_rows: bad sizes");
+    ScatterArgs a;
+    a.n = n_items; a.inv = inv; a.idx = idx; a.N = N; a.Ns = Ns;
+    a.start[0] = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const PsnScatterItem& it = items[i];
+        PSN_CHECK_ARG(it.dense && (it.rows || Ns == 0) && it.B >= 1 && it.C >= 1, "scatter_rows: item %d: null pointer or empty shape", i);
+        a.it[i] = it;
+        const int64_t elems = (int64_t)it.B * (gather ? Ns : N) * it.C;
+        a.start[i + 1] = a.start[i] + (elems + 255) / 256;
+    }
+    if (a.start[n_items] == 0) return PSN_OK;
+    PSN_CHECK_ARG(a.start[n_items] < (1ll << 31), "scatter_rows: too many elements");
+    if (gather) hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)a.start[n_items]), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)a.start[n_items]), dim3(256), 0, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH(gather ? "gather_rows" : "scatter_rows");
+    return PSN_OK;
+}
+}  // namespace psn
+
+extern "C" int psn_scatter_rows(int n_items, const PsnScatterItem* items, const int* inv, int64_t N, int64_t Ns, void* stream) {
+    return psn::launch_scatter(n_items, items, inv, nullptr, N, Ns, false, stream);
+}
+extern "C" int psn_gather_rows(int n_items, const PsnScatterItem* items, const int64_t* idx, int64_t N, int64_t Ns, void* stream) {
+    return psn::launch_scatter(n_items, items, nullptr, idx, N, Ns, true, stream);
+}

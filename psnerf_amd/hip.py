@@ -46,6 +46,11 @@ class PsnBf16Desc(ctypes.Structure):
                 ('has_in', ctypes.c_uint8 * (MAX_LAYERS + 4))]
 
 
+class PsnScatterItem(ctypes.Structure):
+    _fields_ = [('rows', ctypes.c_void_p), ('dense', ctypes.c_void_p), ('row_stride', i64), ('col_stride', i64),
+                ('B', i32), ('C', i32), ('fill', f32)]
+
+
 class PsnPackItem(ctypes.Structure):
     _fields_ = [('W', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('ldw', i64), ('rows', i32), ('cols', i32),
                 ('transpose', i32), ('n_mt', i32), ('k_tiles', i32)]
@@ -91,6 +96,8 @@ SIGNATURES = {
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
                             ctypes.POINTER(ctypes.c_void_p), i64, ctypes.POINTER(ctypes.c_void_p),
                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f, i64, c_f, c_f]),
+    'psn_scatter_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
+    'psn_gather_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_secant_step': (i32, [c_f, f32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
@@ -206,6 +213,42 @@ def sample_points(origin, direction, far, out, hit, near, u0, idx=None, dist=Non
 
 # --------------------------------------------------------------------------- GEMM
 _ws_cache = {}
+
+
+SCATTER_MAX_ITEMS = 16
+
+
+def scatter_rows(specs, rows, inv, n_pixels, n_surf):
+    """specs: [(B, C, fill)], rows: matching list of [B*Ns, C] fp32 tensors (any strides, stride-0 columns allowed) ->
+    list of dense [B, N, C] tensors, one launch per 16 outputs."""
+    dev = inv.device
+    dense = [torch.empty(B, n_pixels, C, device=dev, dtype=torch.float32) for B, C, _ in specs]
+    for c0 in range(0, len(specs), SCATTER_MAX_ITEMS):
+        n = min(SCATTER_MAX_ITEMS, len(specs) - c0)
+        arr = (PsnScatterItem * n)()
+        for i in range(n):
+            (B, C, fill), r, e = specs[c0 + i], rows[c0 + i], arr[i]
+            assert r.dtype == torch.float32 and r.is_cuda and r.shape == (B * n_surf, C)
+            e.rows, e.dense = r.data_ptr(), dense[c0 + i].data_ptr()
+            e.row_stride, e.col_stride, e.B, e.C, e.fill = r.stride(0), r.stride(1), B, C, float(fill)
+        assert inv.dtype == torch.int32 and inv.is_contiguous() and inv.numel() == n_pixels
+        _check(_lib.psn_scatter_rows(n, ctypes.addressof(arr), inv.data_ptr(), n_pixels, n_surf, _stream()), 'scatter_rows')
+    return dense
+
+
+def gather_rows(specs, dense_grads, idx, n_pixels, n_surf):
+    """Adjoint of scatter_rows for the given dense gradients (contiguous [B, N, C]) -> list of [B*Ns, C] tensors."""
+    out = [torch.empty(B * n_surf, C, device=idx.device, dtype=torch.float32) for B, C, _ in specs]
+    for c0 in range(0, len(specs), SCATTER_MAX_ITEMS):
+        n = min(SCATTER_MAX_ITEMS, len(specs) - c0)
+        arr = (PsnScatterItem * n)()
+        for i in range(n):
+            (B, C, _), g, e = specs[c0 + i], dense_grads[c0 + i], arr[i]
+            assert g.is_contiguous() and g.shape == (B, n_pixels, C)
+            e.rows, e.dense, e.B, e.C = out[c0 + i].data_ptr(), _ptr(g, 'dense_grad'), B, C
+        assert idx.dtype == torch.int64 and idx.is_contiguous()
+        _check(_lib.psn_gather_rows(n, ctypes.addressof(arr), idx.data_ptr(), n_pixels, n_surf, _stream()), 'gather_rows')
+    return out
 
 
 def secant_step(occ, tau, d_pred, d_low, d_high, f_low, f_high, origin, direction, p_mid):

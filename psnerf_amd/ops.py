@@ -208,6 +208,31 @@ class FusedPairMLP(torch.autograd.Function):
         return (res[0], res[1], None, None) + tuple(pg)
 
 
+# --------------------------------------------------------------------------- dense per-pixel outputs
+class ScatterRows(torch.autograd.Function):
+    """All dense outputs of PSNetwork.forward in one launch: dense_k [B_k, N, C_k] = fill_k everywhere except the surface
+    pixels idx, which carry rows_k [B_k*Ns, C_k] (light-major; stage2/model/renderer.py:145-152, 204-264).
+    apply(idx [Ns] int64, inv [N] int32, specs ((B, C, fill), ...), *rows) -> tuple of dense tensors.  Backward gathers the
+    rows back (one launch for all outputs that received a gradient)."""
+
+    @staticmethod
+    def forward(ctx, idx, inv, specs, *rows):
+        ctx.specs, ctx.n_pix, ctx.ns = specs, inv.numel(), idx.numel()
+        ctx.save_for_backward(idx)
+        return tuple(hip.scatter_rows(list(specs), [r.detach() for r in rows], inv, inv.numel(), idx.numel()))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        idx, = ctx.saved_tensors
+        sel = [k for k, g in enumerate(grads) if g is not None and ctx.needs_input_grad[3 + k]]
+        out = [None] * len(grads)
+        if sel:
+            got = hip.gather_rows([ctx.specs[k] for k in sel], [grads[k].contiguous() for k in sel], idx, ctx.n_pix, ctx.ns)
+            for k, g in zip(sel, got):
+                out[k] = g
+        return (None, None, None) + tuple(out)
+
+
 # --------------------------------------------------------------------------- weight normalisation
 class WeightNormAll(torch.autograd.Function):
     """Effective matrices of all weight-normalised layers of a network, w_l = v_l (g_l / |v_l|_row) * scale_l

@@ -100,6 +100,13 @@ class SGBasis(nn.Module):
                                  requires_grad=False)
 
 
+class _Dense(object):
+    """A dense output [B, N, C] of PSNetwork.forward that has not been written yet (see forward)."""
+
+    def __init__(self, fill, B, C, rows=None):
+        self.fill, self.B, self.C, self.rows = float(fill), int(B), int(C), rows
+
+
 class PSNetwork(nn.Module):
     def __init__(self, conf):
         super().__init__()
@@ -277,8 +284,15 @@ class PSNetwork(nn.Module):
         def gather(t):  # [1,N,C] -> [Ns,C]
             return t[0].index_select(0, idx)
 
-        def scatter(dense, rows):  # dense [B,N,C] (constant fill), rows [B*Ns,C] light-major -> dense with rows at idx
-            return dense.index_copy(1, idx, rows.reshape(dense.shape[0], ns, rows.shape[-1]))
+        # Dense outputs are described first and written at the end, ALL of them by one launch (ops.ScatterRows): a
+        # _Dense is "B x N x C filled with `fill`", optionally carrying surface rows [B*Ns, C] (light-major).
+        n_pix = points.shape[1]
+
+        def scatter(dense, rows):
+            return _Dense(dense.fill, dense.B, dense.C, rows)
+
+        def ones3(b=1):
+            return _Dense(1.0, b, 3)
 
         surf = gather(points).contiguous()
         out_n = {}
@@ -305,7 +319,7 @@ class PSNetwork(nn.Module):
                 else:
                     vis_pair = self._visibility_pair_launch(pe_x, ld0, lv0)
         if self.normal_mlp:  # renderer.py:127-143
-            normal_pred = torch.ones_like(points)
+            normal_pred = ones3()
             if ns > 0:
                 cols_n = self._cols(self.n_freqs_n, device)
                 normal_s = self._memo('normal', input, lambda: F.normalize(
@@ -317,16 +331,16 @@ class PSNetwork(nn.Module):
                         nz = torch.randn_like(surf) * self.normal_jitter_std  # = torch.normal(0, std) without its host-side std >= 0 check
                     nj = self._memo('normal_jitter', input, lambda: F.normalize(
                         self.normal_net(self._pe(surf + nz, self.n_freqs_n), cols_n), dim=-1))
-                    out_n['normal_jitter'] = scatter(torch.ones_like(points), nj)
+                    out_n['normal_jitter'] = scatter(ones3(), nj)
             out_n['normal_pred'] = normal_pred
 
         sg = self.render_model == 'sgbasis'
         lnum = input['light_direction'].shape[0]
-        rgb_values = torch.ones_like(points).repeat(lnum, 1, 1) if lnum > 1 else torch.ones_like(points)
-        albedo_values = torch.ones_like(points)
-        rough_values = torch.ones_like(rgb_values) if sg else torch.ones_like(points)
-        weight_values = torch.zeros(*points.shape[:-1], self.nbasis, device=device) if sg else None
-        vis_values = torch.ones_like(rgb_values)
+        rgb_values = ones3(lnum)
+        albedo_values = ones3()
+        rough_values = ones3(lnum) if sg else ones3()
+        weight_values = _Dense(0.0, 1, self.nbasis) if sg else None
+        vis_values = ones3(lnum)
         jitter = None
         vis_t_pre = None
         if ns > 0:
@@ -398,12 +412,12 @@ class PSNetwork(nn.Module):
             else:
                 rough_values = scatter(rough_values, rough.expand(-1, 3))
             if self.xyz_jitter_std > 0:  # renderer.py:211-231
-                aj = scatter(torch.ones_like(points), albedo_j)
+                aj = scatter(ones3(), albedo_j)
                 if sg:
-                    rj = scatter(torch.ones_like(weight_values), F.relu(rough_j))
+                    rj = scatter(_Dense(1.0, 1, self.nbasis), F.relu(rough_j))
                     r_ori = weight_values
                 else:
-                    rj = scatter(torch.ones_like(points), rough_j.expand(-1, 3))
+                    rj = scatter(ones3(), rough_j.expand(-1, 3))
                     r_ori = rough_values
                 jitter = {'albedo_values': albedo_values, 'albedo_jitter': aj,
                           'rough_values': r_ori, 'rough_jitter': rj}
@@ -422,7 +436,7 @@ class PSNetwork(nn.Module):
             if 'vis_train_gt' in input or 'light_vis_train' in input:  # renderer.py:251-262
                 lv = input['light_vis_train']
                 vnum = lv.shape[0]
-                vt = torch.ones_like(points).repeat(vnum, 1, 1) if vnum > 1 else torch.ones_like(points)
+                vt = ones3(vnum)
                 if ns > 0:
                     if vis_t_pre is not None:
                         vis_t = vis_t_pre
@@ -433,4 +447,24 @@ class PSNetwork(nn.Module):
                 out['vis_train'] = vt
         if sg:
             out['sg_weight'] = weight_values
+        # write every dense output: one launch for those that carry surface rows, constant fills for the others
+        lazy = {}  # id -> _Dense (one object may sit under two keys: 'rough_values' of the jitter dict is 'sg_weight')
+        for v in out.values():
+            if isinstance(v, _Dense):
+                lazy[id(v)] = v
+        with_rows = [v for v in lazy.values() if v.rows is not None]
+        done = {}
+        if with_rows:
+            inv = torch.full((n_pix,), -1, dtype=torch.int32, device=device)
+            inv[idx] = torch.arange(ns, dtype=torch.int32, device=device)
+            specs = tuple((v.B, v.C, v.fill) for v in with_rows)
+            dense = ops.ScatterRows.apply(idx, inv, specs, *[v.rows for v in with_rows])
+            for v, d in zip(with_rows, dense):
+                done[id(v)] = d
+        for v in lazy.values():
+            if v.rows is None:
+                done[id(v)] = torch.full((v.B, n_pix, v.C), v.fill, device=device)
+        for k in list(out.keys()):
+            if isinstance(out[k], _Dense):
+                out[k] = done[id(out[k])]
         return out
