@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: stage-2 BEAR train step (BASELINE.json configs[2]) in ray-samples/s.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (stand-alone: for N > 1 it starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one full optimisation step of the stage-2 joint BRDF + normal + visibility + light
@@ -9,17 +9,24 @@ optimisation (forward, losses, backward, Adam + SparseAdam, scheduler) on a synt
 that is already resident in HBM: 32768 pixels per GPU (90 % on the surface), L = 96 shading lights,
 V = 8 visibility-supervision lights, phase-2 of the train_fix schedule (all nets + lights trainable).
 A ray-sample is one (surface pixel, shading light) pair: Ns * L per step.  N > 1 shards
-pixels across ranks (weak scaling: 32768 px per GPU, the reference trains on all ~10^5 in-mask pixels
-per step) with one flat-bucket RCCL all-reduce of the gradients per step.
+pixels across ranks with one flat-bucket RCCL all-reduce of the gradients per step.  The headline line is
+WEAK scaling (32768 px per GPU; the reference trains on all ~10^5 in-mask pixels of a view per step); the
+``strong`` object on the same line times a FIXED global batch of 262144 pixels split N ways.
 
-Extra objects on the JSON line: ``roofline`` for the dominant kernel (the fused 256-wide visibility MLP,
-MFMA-bound, algorithmic FLOPs = 2 * 523,520 MAC per row) timed with HIP events on the launch stream, and
-``cpu_baseline`` = the CPU oracle (oracle/stage2.py, a verified restatement of the reference) timed on
-this host on a bounded sample of the same workload.
+Extra objects on the JSON line (all measured after the headline's timed region):
+  roofline      dominant kernel (fused 256-wide visibility MLP, MFMA-bound, 2 * 523,520 MAC per row), HIP events on the
+                launch stream
+  cpu_baseline  the CPU oracle (oracle/stage2.py, a verified restatement of the reference) on this host, N = 1 only
+  strong        strong-scaling measurement (fixed global batch)
+  allreduce_ms  average time of one gradient all-reduce of the step's bucket size (N > 1)
+  stage1        BASELINE configs[1] (stage-1 BEAR train step, 4096 rays x 128 samples, 256 march steps), N = 1 only:
+                ms/step, ray-samples/s, rooflines of the chain engine, the weight-gradient GEMM and the composite
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,8 +34,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_PIXELS, N_LIGHTS, N_VIS, N_LIGHTS_TOTAL = 32768, 96, 8, 1920
+STRONG_PIXELS = 8 * N_PIXELS  # fixed global batch of the strong-scaling line (= the weak batch of 8 GPUs)
 VIS_MACS = 523520  # visibility_net MACs per row
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
 
 
 def make_step(device, seed=0):
@@ -45,6 +54,7 @@ def make_step(device, seed=0):
     return step
 
 
+# ----------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_steps(n_pixels, steps):
     import torch
     from oracle import stage2 as o2
@@ -69,35 +79,136 @@ def _cpu_steps(n_pixels, steps):
     return ns, best
 
 
-def cpu_baseline(n_pixels=4096, steps=2):
-    """The oracle (port of the reference's stage-2 step) on the host: all cores on a bounded sample of the same
-    workload, and one thread (what the reference's own trainer pins, stage2/trainer.py:23) on a smaller one."""
+def cpu_baseline(n_pixels=4096, steps=3):
+    """The oracle (port of the reference's stage-2 step) on the host cores.  The thread count is swept on a 1024-pixel
+    sample (1 warm-up + 2 timed steps each) over {1, 8, 16, 32, 64, nproc}; the best count is then timed on a bounded
+    4096-pixel sample of the same workload (min of 3 after 1 warm-up).  One thread is what the reference's own trainer
+    pins (stage2/trainer.py:23) and is reported beside it."""
     import torch
-    threads = torch.get_num_threads()
-    ns, dt = _cpu_steps(n_pixels, steps)
-    res = {'value': ns * N_LIGHTS / dt, 'unit': 'ray-samples/s', 'cores': threads, 'kind': 'port',
-           'sample': 'oracle/stage2.py TrainStep, %d px (%d surface) x L=%d, V=%d, best of %d timed steps after 1 warm-up, '
-                     '%.2f s/step' % (n_pixels, ns, N_LIGHTS, N_VIS, steps, dt)}
-    torch.set_num_threads(1)
+    nproc = os.cpu_count() or 1
+    t_all = torch.get_num_threads()
+    sweep = {}
     try:
-        ns1, dt1 = _cpu_steps(1024, 2)
+        for th in sorted({t for t in (1, 8, 16, 32, 64, nproc) if t <= nproc}):
+            torch.set_num_threads(th)
+            ns1, dt1 = _cpu_steps(1024, 2)
+            sweep[th] = ns1 * N_LIGHTS / dt1
+        best_th = max(sweep, key=sweep.get)
+        torch.set_num_threads(best_th)
+        ns, dt = _cpu_steps(n_pixels, steps)
     finally:
-        torch.set_num_threads(threads)
-    res['single_thread'] = {'value': ns1 * N_LIGHTS / dt1, 'cores': 1,
-                            'sample': '1024 px (%d surface), best of 2 timed steps after 1 warm-up, %.2f s/step' % (ns1, dt1)}
-    return res
+        torch.set_num_threads(t_all)
+    return {'value': ns * N_LIGHTS / dt, 'unit': 'ray-samples/s', 'cores': best_th, 'kind': 'port',
+            'sample': 'oracle/stage2.py TrainStep, %d px (%d surface) x L=%d, V=%d, min of %d timed steps after 1 warm-up, '
+                      '%.2f s/step, %d threads = the best of the sweep' % (n_pixels, ns, N_LIGHTS, N_VIS, steps, dt, best_th),
+            'host_cores': nproc,
+            'thread_sweep_1024px': {str(k): round(v, 1) for k, v in sorted(sweep.items())},
+            'single_thread': {'value': sweep.get(1), 'cores': 1, 'sample': '1024 px, min of 2 timed steps after 1 warm-up'}}
+
+
+# ----------------------------------------------------------------------------------------------- stage 1 (configs[1])
+def stage1_measure(device, steps=6, warmup=2, rays=4096):
+    """BASELINE configs[1]: stage-1 BEAR train step, 4096 rays x 128 samples (96 inner + 32 outer, it > 5000), 256 march
+    steps + 8 secant, geometric-init weights.  Per-kernel numbers from HIP events on the launch stream."""
+    import torch
+    from psnerf_amd import hip
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.synthetic import stage1_batch, stage1_cfg
+    cfg = stage1_cfg('bear', **{'rendering.num_points_in': 96, 'rendering.num_points_out': 32,
+                                'training.n_training_points': rays})
+    it, S = 6000, 128
+    batch = {k: v.to(device) for k, v in stage1_batch(cfg, h=512, w=612, seed=0).items()}
+    torch.manual_seed(42)
+    net = NeuralNetwork(cfg)
+    tr = Trainer(Renderer(net, cfg, device=device), torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=device)
+    for _ in range(warmup):
+        tr.train_step(batch, it=it)
+    hip.PROFILE_EVENTS = ev = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        terms = tr.train_step(batch, it=it)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    hip.PROFILE_EVENTS = None
+
+    def agg(name):
+        sel = [(u, a.elapsed_time(b), f) for (k, u, a, b, f) in ev if k == name]
+        return sel
+
+    out = {'workload': 'stage1 BEAR train step (BASELINE configs[1]): %d rays x %d samples, 256 march steps + 8 secant, '
+                       'full step (march, render fwd, loss, double backward, Adam)' % (rays, S),
+           'value': round(rays * S / dt, 1), 'unit': 'ray-samples/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps,
+           'warmup': warmup, 'loss': round(float(terms['loss'].detach()), 6), 'dtype': 'f32', 'data': 'synthetic'}
+    ch = [(u, ms, f) for u, ms, f in agg('mlp_chain') if f]
+    if ch:
+        fl, ms = sum(f for _, _, f in ch), sum(m for _, m, _ in ch)
+        out['chain_engine'] = {'bound': 'mfma', 'kernel': 'mlp_infer_kernel<true,16>', 'achieved': round(fl / ms * 1e-9, 2),
+                               'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(fl / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS, 4),
+                               'ms_per_step': round(ms / steps, 3), 'launches_per_step': round(len(ch) / steps, 1)}
+    le = [(u, ms, f) for u, ms, f in agg('mlp_infer') if f]
+    if le:
+        fl, ms = sum(f for _, _, f in le), sum(m for _, m, _ in le)
+        out['occupancy_engine'] = {'bound': 'mfma', 'kernel': 'mlp_infer_kernel<false,16> (march / secant / root finder)',
+                                   'achieved': round(fl / ms * 1e-9, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': round(fl / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS, 4), 'ms_per_step': round(ms / steps, 3),
+                                   'launches_per_step': round(len(le) / steps, 1)}
+    gm = agg('gemm_tn_grouped')
+    if gm:
+        fl, ms = sum(u for u, _, _ in gm), sum(m for _, m, _ in gm)
+        out['weight_grad_gemm'] = {'bound': 'mfma', 'kernel': 'gemm_tn256_grouped_kernel (+128x128 tiles, + split-K reduction)',
+                                   'achieved': round(fl / ms * 1e-9, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': round(fl / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS, 4), 'ms_per_step': round(ms / steps, 3)}
+    for name in ('composite_fwd', 'composite_bwd'):
+        cp = agg(name)
+        if cp:
+            by, ms = sum(u for u, _, _ in cp), sum(m for _, m, _ in cp)
+            out[name] = {'bound': 'hbm', 'achieved': round(by / ms * 1e-6, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                         'frac': round(by / ms * 1e-6 / PEAK_HBM_GBS, 4), 'us_per_launch': round(ms / len(cp) * 1e3, 1),
+                         'note': '4096 rays = 10-19 MB per launch: launch/latency-bound at this size; the HBM roofline of '
+                                 'the kernel is measured at 2M rays by tools/bench_composite.py (profiles/)'}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- self-launch
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes through torch.distributed.run and
+    relay their output.  This parent never touches the GPU (no HIP call, no torch.cuda query), and the ranks are new
+    child processes -- nothing is exec'ed from a GPU-initialised process."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--pixels', type=int, default=N_PIXELS, help='pixels per GPU (default: the benchmark config)')
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--pixels', type=int, default=N_PIXELS, help='pixels per GPU of the weak-scaling headline')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help="what the headline value measures; 'strong' = the fixed %d-pixel global batch split N ways "
+                         '(the other mode is always reported as an extra object)' % STRONG_PIXELS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-stage1', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the strong-scaling / all-reduce extras')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo for 1-GPU dry runs)')
     ap.add_argument('--single-device', action='store_true', help='dry run: every rank uses cuda:0')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -108,59 +219,86 @@ def main():
     if args.single_device:
         local = 0
     if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)' % (args.gpus, world))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
     step = make_step(device)
-    inp, gt = stage2_inputs(args.pixels, N_LIGHTS, N_VIS, seed=100 + rank, device=device)
-    ns_local = int(inp['surface_mask'].sum())
     l_slt = torch.arange(N_LIGHTS, device=device) + 96 * 3  # the 96 lights of one view
 
-    def one_step():
-        return step.step(inp, gt, l_slt, train_order=False)
+    def timed(inp, gt, steps, warmup, profile=False):
+        """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+        for _ in range(warmup):
+            step.step(inp, gt, l_slt, train_order=False)
+        hip.PROFILE_EVENTS = [] if profile else None
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            terms, _ = step.step(inp, gt, l_slt, train_order=False)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        events, hip.PROFILE_EVENTS = hip.PROFILE_EVENTS, None
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        ns = torch.tensor([int(inp['surface_mask'].sum())], device=device, dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(ns, op=dist.ReduceOp.SUM)
+        return float(t.item()), int(ns.item()), terms, events
 
-    for _ in range(args.warmup):
-        one_step()
-    hip.PROFILE_EVENTS = [] if rank == 0 else None
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        terms, _ = one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    events = hip.PROFILE_EVENTS
-    hip.PROFILE_EVENTS = None
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
-    ns = torch.tensor([ns_local], device=device, dtype=torch.int64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ns, op=dist.ReduceOp.SUM)
-    dt = float(t.item())
-    ns_total = int(ns.item())
+    def weak_batch():
+        return stage2_inputs(args.pixels, N_LIGHTS, N_VIS, seed=100 + rank, device=device)
+
+    def strong_batch():
+        inp, gt = stage2_inputs(STRONG_PIXELS, N_LIGHTS, N_VIS, seed=100, device=device)  # same global batch on every rank
+        return step.dp.shard_stage2(inp, gt) if world > 1 else (inp, gt)
+
+    head_batch, other_batch = (weak_batch, strong_batch) if args.scaling == 'weak' else (strong_batch, weak_batch)
+    inp, gt = head_batch()
+    dt, ns_total, terms, events = timed(inp, gt, args.steps, args.warmup, profile=(rank == 0))
+    px_local = inp['uv'].shape[1]
+    del inp, gt
+    ms_per_step = dt / args.steps * 1e3
+    value = ns_total * N_LIGHTS / (dt / args.steps)
+
+    other = None
+    allreduce_ms = None
+    if not args.no_extra:
+        inp, gt = other_batch()
+        k2 = max(3, min(args.steps, 10 if args.scaling == 'weak' else 20))
+        dt2, ns2, _, _ = timed(inp, gt, k2, 2)
+        other = {'scaling': 'strong' if args.scaling == 'weak' else 'weak', 'value': round(ns2 * N_LIGHTS / (dt2 / k2), 1),
+                 'unit': 'ray-samples/s', 'ms_per_step': round(dt2 / k2 * 1e3, 3), 'steps': k2, 'warmup': 2,
+                 'pixels_per_gpu': inp['uv'].shape[1], 'surface_pixels_total': ns2,
+                 'global_pixels': STRONG_PIXELS if args.scaling == 'weak' else args.pixels * world}
+        del inp, gt
+        if world > 1:
+            allreduce_ms = round(step.dp.time_allreduce(step.dp.allreduce_bytes // 4), 4)
+    bucket_bytes = step.dp.allreduce_bytes
+
+    stage1 = None
+    if world == 1 and not args.no_stage1:
+        del step
+        torch.cuda.empty_cache()
+        stage1 = stage1_measure(device)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()  # every rank leaves the group cleanly before rank 0 prints
     if rank != 0:
         return
-    ms_per_step = dt / args.steps * 1e3
-    value = ns_total * N_LIGHTS / (dt / args.steps)
 
-    # dominant kernel: fused visibility MLP over L*Ns rows (one launch per step)
-    # (the largest launch of the step: (L + V) * Ns rows; the smaller launches are the backward chains of the V rows)
-    infer = [(r, a.elapsed_time(b)) for (name, r, a, b) in events if name == 'mlp_infer']
+    # dominant kernel: fused visibility MLP over (L + V) * Ns rows, one launch per step (the smaller launches of the
+    # same engine are the 128- / 64-wide BRDF / normal nets)
+    infer = [(r, a.elapsed_time(b)) for (name, r, a, b, _f) in events if name == 'mlp_infer']
     top = max([r for r, _ in infer]) if infer else 0
     durs = [t for r, t in infer if r == top]
-    rows = [r for r, t in infer if r == top]
     roofline = None
     if durs:
         avg_ms = sum(durs) / len(durs)
-        flops = 2.0 * VIS_MACS * (sum(rows) / len(rows))
-        achieved = flops / (avg_ms * 1e-3) / 1e12
+        achieved = 2.0 * VIS_MACS * top / (avg_ms * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
@@ -170,7 +308,8 @@ def main():
                 traffic = None
         roofline = {'bound': 'mfma', 'kernel': 'mlp_infer_kernel', 'achieved': round(achieved, 2),
                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    'traffic': traffic, 'avg_launch_ms': round(avg_ms, 3), 'launches': len(durs),
+                    'traffic': traffic if px_local == N_PIXELS else None, 'rows_per_launch': top,
+                    'avg_launch_ms': round(avg_ms, 3), 'launches': len(durs),
                     'share_of_step': round(avg_ms * len(durs) / args.steps / ms_per_step, 3)}
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # the CPU oracle is timed at N = 1 only (other ranks would idle behind it)
@@ -178,14 +317,17 @@ def main():
     line = {
         'metric': 'ray-samples/sec (train step) on BEAR stage2', 'value': round(value, 1), 'unit': 'ray-samples/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'stage2 BEAR BRDF+light joint opt (BASELINE configs[2]): %d px/GPU (%d surface total), '
                                'L=96 shading lights, V=8 visibility lights, sgbasis RGB 9 lobes, visibility + vis_loss on, '
-                               'train_fix phase 2, full step (fwd+loss+bwd+Adam+SparseAdam)' % (args.pixels, ns_total),
-                   'pixels_per_gpu': args.pixels, 'surface_pixels_total': ns_total, 'lights': N_LIGHTS,
+                               'train_fix phase 2, full step (fwd+loss+bwd+Adam+SparseAdam)' % (px_local, ns_total),
+                   'pixels_per_gpu': px_local, 'surface_pixels_total': ns_total, 'lights': N_LIGHTS,
                    'vis_lights': N_VIS, 'parallelism': 'pixel-dp%d' % world},
         'loss': round(float(terms['total'].detach()), 6),
         'roofline': roofline, 'cpu_baseline': cpu,
+        ('strong' if args.scaling == 'weak' else 'weak'): other,
+        'allreduce_ms': allreduce_ms, 'allreduce_bytes': bucket_bytes if world > 1 else None,
+        'stage1': stage1,
     }
     print(json.dumps(line), flush=True)
 

@@ -421,8 +421,14 @@ class TrainStep(object):
     are sparse embeddings optimised with SparseAdam (trainer.py:126-168)."""
 
     def __init__(self, model, conf, n_lights_total, light_init, lr=5e-4, light_lr=5e-4, light_inten_lr=1e-3,
-                 milestones=(), gamma=0.5, loss_kwargs=None, normal_loss_kwargs=None):
+                 milestones=(), gamma=0.5, loss_kwargs=None, normal_loss_kwargs=None, vis_plus=None):
         self.model, self.conf = model, conf
+        # trainer.py:149 -- light_vis_train = clones of the initial (SDPS-Net) light estimates, never optimised;
+        # torch.cat(self.light_vis_train) is indexed with l_slt at :377
+        self.light_vis_train_all = light_init.detach().clone()
+        # trainer.py:209-214 -- vis_plus tables: dict(light=[per view [P,3]], vis=[per view [P,hw]],
+        # view_light=[per view [L_v,3] initial estimates], view_vis=[per view [L_v,hw] dataset.visibility], vnum)
+        self.vis_plus = vis_plus
         lk = dict(sg_rgb_weight=1.0, loss_type='L1', albedo_smooth_weight=0.05, rough_smooth_weight=0.01,
                   vis_weight=1)
         lk.update(loss_kwargs or {})
@@ -463,12 +469,23 @@ class TrainStep(object):
             self.light_para.requires_grad_(True)
             self.light_inten_para.requires_grad_(True)
 
-    def step(self, model_input, ground_truth, l_slt, train_order=True, noise=None):
+    def step(self, model_input, ground_truth, l_slt, train_order=True, noise=None, vidx=None):
         if train_order:
             self.train_fix()
         model_input = dict(model_input)
         model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
         model_input['light_intensity'] = self.light_inten_para(l_slt)
+        if self.vis_plus is not None and vidx is not None:
+            # trainer.py:377 is overwritten by :384-392 when train.vis_plus is set
+            vp = self.vis_plus
+            light_plus = torch.cat([vp['light'][vidx], vp['view_light'][vidx]], dim=0)            # :386,388
+            vis_plus_v = torch.cat([vp['vis'][vidx].reshape(len(vp['light'][vidx]), -1), vp['view_vis'][vidx]], dim=0)  # :387
+            sidx = torch.tensor(np.random.choice(np.arange(len(light_plus)), vp['vnum'], replace=False)).long()  # :389
+            model_input['light_vis_train'] = light_plus[sidx]                                       # :390
+            assert light_plus.shape[0] == vis_plus_v.shape[0]                                       # :391
+            model_input['vis_train_gt'] = vis_plus_v[sidx][:, model_input['sampling_idx'][0]]       # :392
+        elif 'light_vis_train' not in model_input:
+            model_input['light_vis_train'] = F.normalize(self.light_vis_train_all[l_slt], p=2, dim=-1)  # :377
         out = self.model(model_input, noise=noise)
         terms = self.loss(out, ground_truth, model_input)
         loss = terms['loss']

@@ -30,6 +30,7 @@ class PackedMLP(object):
         self.desc, self.w, self.b = desc, w, b
         # stacked input-block weights of the layers evaluated through init tables
         self.init_wa, self.init_wb, self.init_bias = init_wa, init_wb, init_bias
+        self.macs_per_row = None  # algorithmic MACs per row inside the kernel (true, unpadded block shapes)
 
     def __call__(self, tab_a, n_rows, a_div=1, a_mod=None, tab_b=None, b_div=1, b_mod=1, out=None, save=None,
                  save_row0=0, mask=None, init_a_direct=None, aux2=None, save2=None, act_init=None):
@@ -48,7 +49,8 @@ class PackedMLP(object):
         uses_in = any(self.desc.layers[i].n_kt_in > 0 for i in range(self.desc.n_layers))
         return hip.mlp_infer(self.desc, self.w, self.b, tab_a if uses_in else None, a_div, a_mod,
                              tab_b if uses_in else None, b_div, b_mod, n_rows, out=out, init_a=init_a, init_b=init_b,
-                             save=save, save_row0=save_row0, mask=mask, aux2=aux2, save2=save2, act_init=act_init)
+                             save=save, save_row0=save_row0, mask=mask, aux2=aux2, save2=save2, act_init=act_init,
+                             macs_per_row=self.macs_per_row)
 
 
 def _pad_cols(w, n):
@@ -135,10 +137,13 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     hip.mlp_pack_layers(group)  # every block of the network in one launch
     desc.init_stride = width * len(init_wa)
     if init_wa:
-        return PackedMLP(desc, w_buf, b_buf, torch.cat(init_wa).contiguous().float(),
-                         torch.cat(init_wb).contiguous().float() if init_wb else None,
-                         torch.cat(init_bias).contiguous())
-    return PackedMLP(desc, w_buf, b_buf)
+        pk = PackedMLP(desc, w_buf, b_buf, torch.cat(init_wa).contiguous().float(),
+                       torch.cat(init_wb).contiguous().float() if init_wb else None,
+                       torch.cat(init_bias).contiguous())
+    else:
+        pk = PackedMLP(desc, w_buf, b_buf)
+    pk.macs_per_row = sum(_src(w)[2] * _src(w)[3] for w, _, _, _ in plan)
+    return pk
 
 
 def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, precompute=True, width=256):

@@ -164,3 +164,26 @@ class ViewSampler(object):
             sample['sampling_idx'] = s.clone()
         sample['pose'] = self.poses[idx]
         return idx, sample, ground_truth
+
+    def batch(self, idx, device=None):
+        """(vidx, model_input, ground_truth, l_slt) as TrainRunner.run sees them after DataLoader(batch_size=1) collation
+        and its multi_light un-batching (stage2/trainer.py:364-379): per-pixel tensors carry a leading batch dimension of
+        1, the per-light ones (rgb [L,n,3], light_direction [L,3], visibility [L,n]) do not, and ``l_slt`` = the rows of
+        the concatenated per-view light tables (sum of the preceding views' light counts + lidx)."""
+        _, sample, gt = self[idx]
+        mi = {}
+        for k, v in sample.items():
+            if k in ('light_direction', 'visibility', 'lidx'):
+                mi[k] = v
+            elif torch.is_tensor(v):
+                mi[k] = v[None]
+            else:
+                mi[k] = v
+        accu = [int(ld.shape[0]) for ld in self.light_direction]
+        l_slt = sum(accu[:idx]) + sample['lidx']
+        gt = dict(gt)
+        if device is not None:
+            mi = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in mi.items()}
+            gt = {k: v.to(device) for k, v in gt.items()}
+            l_slt = l_slt.to(device)
+        return idx, mi, gt, l_slt

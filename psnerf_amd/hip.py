@@ -111,8 +111,29 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 
 # When set to a list (bench.py), kernel wrappers that support it append
-# (name, n_rows, start_event, end_event) recorded on the launch stream.
+# (name, units, start_event, end_event, flops or None) recorded on the launch stream; units = rows for the MLP engines,
+# algorithmic FLOPs for the grouped weight-gradient GEMM, algorithmic bytes for the composite kernels.
 PROFILE_EVENTS = None
+
+
+class _Prof(object):
+    """``with _Prof(name, units):`` brackets one C-ABI launch with HIP events on the launch stream when PROFILE_EVENTS is
+    a list (bench.py); ``units`` = rows, or algorithmic FLOPs / bytes of the launch, as the name's consumer defines."""
+
+    def __init__(self, name, units, flops=None):
+        self.name, self.units, self.flops, self.prof = name, units, flops, PROFILE_EVENTS
+
+    def __enter__(self):
+        if self.prof is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.prof is not None and exc[0] is None:
+            self.e1.record()
+            self.prof.append((self.name, self.units, self.e0, self.e1, self.flops))
+        return False
 
 
 def _check(rc, what):
@@ -149,9 +170,12 @@ def composite_fwd(alpha, rgb, white_bg, need_weights=True):
     weights = torch.empty_like(alpha) if need_weights else None
     rgb_out = torch.empty(N, 3, device=alpha.device, dtype=torch.float32) if rgb is not None else None
     acc = torch.empty(N, device=alpha.device, dtype=torch.float32)
-    _check(_lib.psn_composite_fwd(_ptr(alpha, 'alpha'), _ptr(rgb, 'rgb', True), N, S, int(bool(white_bg)),
-                                  _ptr(weights, 'weights', True), _ptr(rgb_out, 'rgb_out', True), _ptr(acc, 'acc'),
-                                  _stream()), 'composite_fwd')
+    # algorithmic bytes: alpha 4 S (+ colour 12 S) in, weights 4 S (if kept) + rgb 12 + acc 4 out
+    nbytes = N * (4 * S + (12 * S + 12 if rgb is not None else 0) + (4 * S if need_weights else 0) + 4)
+    with _Prof('composite_fwd' if rgb is not None else 'composite_alpha', nbytes):
+        _check(_lib.psn_composite_fwd(_ptr(alpha, 'alpha'), _ptr(rgb, 'rgb', True), N, S, int(bool(white_bg)),
+                                      _ptr(weights, 'weights', True), _ptr(rgb_out, 'rgb_out', True), _ptr(acc, 'acc'),
+                                      _stream()), 'composite_fwd')
     return weights, rgb_out, acc
 
 
@@ -159,9 +183,10 @@ def composite_bwd(alpha, rgb, d_rgb_out, d_acc, white_bg):
     N, S = alpha.shape
     d_alpha = torch.empty_like(alpha)
     d_rgb = torch.empty_like(rgb) if rgb is not None else None
-    _check(_lib.psn_composite_bwd(_ptr(alpha, 'alpha'), _ptr(rgb, 'rgb', True), _ptr(d_rgb_out, 'd_rgb_out', True),
-                                  _ptr(d_acc, 'd_acc', True), N, S, int(bool(white_bg)), _ptr(d_alpha, 'd_alpha'),
-                                  _ptr(d_rgb, 'd_rgb', True), _stream()), 'composite_bwd')
+    with _Prof('composite_bwd', N * (36 * S + 16)):  # 36 S + 16 bytes per ray
+        _check(_lib.psn_composite_bwd(_ptr(alpha, 'alpha'), _ptr(rgb, 'rgb', True), _ptr(d_rgb_out, 'd_rgb_out', True),
+                                      _ptr(d_acc, 'd_acc', True), N, S, int(bool(white_bg)), _ptr(d_alpha, 'd_alpha'),
+                                      _ptr(d_rgb, 'd_rgb', True), _stream()), 'composite_bwd')
     return d_alpha, d_rgb
 
 
@@ -385,8 +410,10 @@ def gemm_tn_grouped(items, split_k=None):
             need += (2 if A2 is not None else 1) * sk * M * N + sk * M + 16
             keep.append((C, cs))
         ws = workspace(need, dev)
-        _check(_lib.psn_gemm_tn_grouped(len(chunk), ctypes.addressof(arr), K, split_k, ws.data_ptr(), ws.numel(), _stream()),
-               'gemm_tn_grouped')
+        flops = sum(2.0 * K * arr[i].M * arr[i].N * (2 if chunk[i].get('A2') is not None else 1) for i in range(len(chunk)))
+        with _Prof('gemm_tn_grouped', flops):
+            _check(_lib.psn_gemm_tn_grouped(len(chunk), ctypes.addressof(arr), K, split_k, ws.data_ptr(), ws.numel(), _stream()),
+                   'gemm_tn_grouped')
         res += keep
     return res
 
@@ -436,7 +463,7 @@ def mlp_pack_layers(plan):
 
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
-              init_b=None, save=None, save_row0=0, mask=None, aux2=None, save2=None, act_init=None):
+              init_b=None, save=None, save_row0=0, mask=None, aux2=None, save2=None, act_init=None, macs_per_row=None):
     """save: list (one entry per hidden layer, None allowed) of [n_rows - save_row0, 256] tensors that receive the
     post-activation outputs of the rows >= save_row0."""
     if out is None and desc.n_out > 0:
@@ -455,17 +482,14 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
     if save is not None:
         assert len(save) == n_hidden
         save_arr = (ctypes.c_void_p * len(save))(*[None if t is None else _ptr(t, 'save') for t in save])
-    prof = PROFILE_EVENTS
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
-                              _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,
-                              _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), save_arr, save_row0, mask_arr,
-                              aux2_arr, save2_arr, _ptr(act_init, 'act_init', True), n_rows, _ptr(out, 'out', True), _stream()), 'mlp_infer')
-    if prof is not None:
-        e1.record()
-        prof.append(('mlp_infer', n_rows, e0, e1))
+    # 'mlp_infer' = the lean engine, 'mlp_chain' = the chain engine (same dispatch rule as psn_mlp_infer)
+    chain = act_init is not None or mask is not None or aux2 is not None or save2 is not None or any(
+        desc.layers[l].act > ACT_SOFTPLUS100 for l in range(desc.n_layers))
+    with _Prof('mlp_chain' if chain else 'mlp_infer', n_rows, None if macs_per_row is None else 2.0 * macs_per_row * n_rows):
+        _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
+                                  _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,
+                                  _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), save_arr, save_row0, mask_arr,
+                                  aux2_arr, save2_arr, _ptr(act_init, 'act_init', True), n_rows, _ptr(out, 'out', True), _stream()), 'mlp_infer')
     return out
 
 
@@ -529,16 +553,10 @@ def mlp_infer_bf16(desc, packed_w, final_bias, tab_a, a_div, a_mod, tab_b, b_div
         out = torch.empty(n_rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
     assert packed_w.dtype == torch.bfloat16 and packed_w.is_cuda and packed_w.is_contiguous()
     assert final_bias.numel() == 32
-    prof = PROFILE_EVENTS
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _check(_lib.psn_mlp_infer_bf16(ctypes.byref(desc), packed_w.data_ptr(), _ptr(final_bias, 'final_bias'),
-                                   _bf16_table(tab_a, 'tab_a'), a_div, a_mod, _bf16_table(tab_b, 'tab_b'), b_div, b_mod,
-                                   n_rows, _ptr(out, 'out'), _stream()), 'mlp_infer_bf16')
-    if prof is not None:
-        e1.record()
-        prof.append(('mlp_infer_bf16', n_rows, e0, e1))
+    with _Prof('mlp_infer_bf16', n_rows):
+        _check(_lib.psn_mlp_infer_bf16(ctypes.byref(desc), packed_w.data_ptr(), _ptr(final_bias, 'final_bias'),
+                                       _bf16_table(tab_a, 'tab_a'), a_div, a_mod, _bf16_table(tab_b, 'tab_b'), b_div, b_mod,
+                                       n_rows, _ptr(out, 'out'), _stream()), 'mlp_infer_bf16')
     return out
 
 

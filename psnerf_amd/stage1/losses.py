@@ -42,13 +42,15 @@ class Loss(nn.Module):
             cnt = self._g(int(norm_mask.sum()) if norm_count is None else norm_count)
             if cnt > 0:
                 # masked sum instead of the reference's boolean gathers (each a nonzero + host synchronisation)
-                l_n = ((normal - normal_gt).abs() * norm_mask.unsqueeze(-1).to(normal.dtype)).sum() / float(cnt)
+                # (where, not a product: non-finite values outside the mask are ignored like in the reference)
+                d_n = (normal - normal_gt).abs()
+                l_n = torch.where(norm_mask.bool().unsqueeze(-1), d_n, d_n.new_zeros(())).sum() / float(cnt)
                 loss = loss + self.norm_weight * l_n
                 terms['normal_loss'] = l_n
         if mask is not None and mask_gt is not None:
             cnt = self._g(int(mask_valid.sum()) if valid_count is None else valid_count)
             bce = F.binary_cross_entropy(mask.clamp(0, 1), mask_gt, reduction='none')  # log terms are clamped at -100: finite
-            l_m = (bce * mask_valid.to(bce.dtype)).sum() / float(max(cnt, 1))
+            l_m = torch.where(mask_valid.bool(), bce, bce.new_zeros(())).sum() / float(max(cnt, 1))
             loss = loss + self.mask_weight * l_m
             terms['mask_loss'] = l_m
         terms['loss'] = loss

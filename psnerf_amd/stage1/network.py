@@ -77,12 +77,31 @@ class NeuralNetwork(nn.Module):
         for l in range(self.n_app):
             lin = nn.Linear(dims_app[l], dims_app[l + 1])
             setattr(self, 'lina%d' % l, WNLinear(lin.weight.detach(), lin.bias.detach()))
+        self._pack_epoch = 0
         self._packed = None
         self._packed_key = None
         self._chains = None
         self._chains_key = None
         self._app_packed = None
         self._app_key = None
+
+    # ---- weight-pack caches ---------------------------------------------------------------------
+    def _params_key(self):
+        """Version counter and storage address of EVERY parameter + the invalidation epoch (see invalidate_packs)."""
+        return (self._pack_epoch,) + tuple((int(q._version), q.data_ptr()) for q in self.parameters())
+
+    def invalidate_packs(self):
+        """Drop the cached occupancy / chain packs.  Needed only after editing parameters through ``.data`` (EMA swaps,
+        manual clipping): such edits bump neither the version counters nor the storage addresses the caches key on."""
+        self._pack_epoch += 1
+
+    def _apply(self, fn, *a, **k):
+        self._pack_epoch += 1
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pack_epoch += 1
+        return super()._load_from_state_dict(*a, **k)
 
     # ---- effective weights ----------------------------------------------------------------------
     def _effective(self, prefix, n, scales):
@@ -112,7 +131,7 @@ class NeuralNetwork(nn.Module):
     MAX_ROWS = 1 << 20  # rows per GeoField call: bounds the saved activations to ~50 GB of the 288 GB HBM
 
     def _geo_chains(self, params):
-        key = tuple(int(q._version) for q in self.parameters()) + (self.lin0.weight_v.data_ptr(),)
+        key = self._params_key()
         if self._chains is None or self._chains_key != key:
             with torch.no_grad():
                 self._chains = fused.pack_geo_chains(params[0::2], params[1::2], self.skips, self.d_pe)
@@ -163,7 +182,7 @@ class NeuralNetwork(nn.Module):
         return torch.cat([logit, feat], dim=1), grad
 
     def _occupancy_packed(self):
-        key = tuple(int(q._version) for q in self.parameters()) + (self.lin0.weight_v.data_ptr(),)
+        key = self._params_key()
         if self._packed is None or self._packed_key != key:
             with torch.no_grad():
                 # without the 1/sqrt(2) fold: pack_geo_occupancy applies it itself
@@ -194,7 +213,7 @@ class NeuralNetwork(nn.Module):
         return self._app(x)
 
     def _app_chains(self, Ws, bs, d_x):
-        key = tuple(int(q._version) for q in self.parameters()) + (self.lina0.weight_v.data_ptr(),)
+        key = self._params_key()
         if self._app_packed is None or self._app_key != key:
             with torch.no_grad():
                 self._app_packed = fused.pack_app_chains(Ws, bs, d_x)

@@ -36,10 +36,16 @@ class Trainer(object):
 
     def train_step(self, data, it=None, pix=None, noise=None):
         self.model.train()
-        self.optimizer.zero_grad()
+        if self.dp.enabled:
+            trainable = [p for p in self.model.parameters() if p.requires_grad]
+            self.dp.prepare_grads(trainable)  # one memset; every .grad becomes a view into the flat all-reduce bucket
+        else:
+            self.optimizer.zero_grad()
         terms = self.compute_loss(data, it=it, pix=pix, noise=noise)
-        terms['loss'].backward()
-        self.dp.allreduce_grads([p for p in self.model.parameters() if p.requires_grad])
+        if terms['loss'].requires_grad:
+            terms['loss'].backward()
+        if self.dp.enabled:
+            self.dp.allreduce_grads(trainable)
         self.optimizer.step()
         net = getattr(self.model, 'model', None)
         if hasattr(net, 'prepack'):

@@ -10,8 +10,9 @@ from torch.nn import functional as F
 
 def _masked_mean(diff, mask_b, count, channels):
     """mean over the masked elements of ``diff`` [B,N,C] (mask_b [B,N] bool, ``count`` masked pixels per batch row
-    summed over rows) without a boolean gather: sum(diff * mask) / (count * C)."""
-    return (diff * mask_b.unsqueeze(-1).to(diff.dtype)).sum() / float(count * channels)
+    summed over rows) without a boolean gather: sum(where(mask, diff, 0)) / (count * C).  ``where`` rather than a
+    multiplication: like the reference's boolean indexing it ignores non-finite values outside the mask (NaN * 0 = NaN)."""
+    return torch.where(mask_b.bool().unsqueeze(-1), diff, diff.new_zeros(())).sum() / float(count * channels)
 
 
 class MainLoss(nn.Module):

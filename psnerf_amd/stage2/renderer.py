@@ -25,6 +25,13 @@ from .. import fused, hip, ops
 PE_STRIDE = 64  # 3 + 6*10 = 63 real columns + 1 zero pad
 
 
+def params_key(params, epoch=0):
+    """Cache key of a weight pack: version counter AND storage address of EVERY parameter (an assign-style
+    load_state_dict replaces storages of individual layers), plus the module's invalidation epoch.  In-place edits
+    through ``.data`` bump neither: callers that do that (EMA swaps, manual clipping) call ``invalidate_packs()``."""
+    return (epoch,) + tuple((int(p._version), p.data_ptr()) for p in params)
+
+
 def camera_rays(uv, pose, intrinsics):
     """stage2/utils/rend_util.py:90-147 (4x4 pose case), device-agnostic."""
     fx, fy = intrinsics[:, 0, 0], intrinsics[:, 1, 1]
@@ -50,6 +57,18 @@ class MLP(nn.Module):
         self.final = final
         self.din, self.width = din, W
 
+    def invalidate_packs(self):
+        """Drop the cached weight packs (call after editing parameters through ``.data``)."""
+        self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_packs()
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self.invalidate_packs()
+        return super()._load_from_state_dict(*a, **k)
+
     def _skip_index(self):
         s = [i for i in self.skip_at if 0 <= i < len(self.linears) - 1]
         assert len(s) <= 1, 'at most one skip connection is supported'
@@ -72,7 +91,7 @@ class MLP(nn.Module):
         if not (self.FUSED and self.width in (64, 128, 256) and self.din <= 64 and self.linears[-1].weight.shape[0] <= 32
                 and all(l.weight.shape[0] == self.width for l in list(self.linears)[:-1]) and self.linears[0].weight.is_cuda):
             return None
-        key = tuple(int(p._version) for p in self.parameters()) + (self.linears[0].weight.data_ptr(),)
+        key = params_key(self.parameters(), getattr(self, '_pack_epoch', 0))
         if getattr(self, '_pack_key', None) != key:
             Ws, bs = self.weights()
             self._pack = ops.FusedReluNet.pack(Ws, bs, self.din, self._skip_index(), self.final == 'sigmoid', self.width)
@@ -166,6 +185,22 @@ class PSNetwork(nn.Module):
                                       skip_at=[conf.get_int('visibility.net.mlp_skip_at')])
 
     # -- helpers ---------------------------------------------------------------------------------
+    def invalidate_packs(self):
+        """Drop every cached weight pack of the model (call after editing parameters through ``.data``: such edits
+        change neither the version counters nor the storage addresses the caches are keyed on)."""
+        self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
+        for m in self.modules():
+            if isinstance(m, MLP):
+                m.invalidate_packs()
+
+    def _apply(self, fn, *a, **k):
+        self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
+        return super()._load_from_state_dict(*a, **k)
+
     def _pe(self, x, n_freqs):
         return ops.positional_encoding(x, n_freqs, PE_STRIDE)
 
@@ -209,7 +244,7 @@ class PSNetwork(nn.Module):
         net = self.visibility_net
         if net.width != 256 or not net.linears[0].weight.is_cuda:
             return None
-        key = tuple(int(p._version) for p in net.parameters()) + (net.linears[0].weight.data_ptr(),)
+        key = params_key(net.parameters(), getattr(self, '_pack_epoch', 0))
         if getattr(self, '_vis_pack_key', None) != key:
             Ws, bs = net.weights()
             half = 3 + 6 * self.n_freqs
@@ -233,7 +268,7 @@ class PSNetwork(nn.Module):
         if cache is None or torch.is_grad_enabled():
             return fn()
         key = (tag,) + tuple((input[k].data_ptr(), input[k]._version) for k in ('points', 'surface_mask', 'uv')) \
-            + tuple(int(p._version) for p in self.parameters())
+            + params_key(self.parameters(), getattr(self, '_pack_epoch', 0))
         if key not in cache:
             cache[key] = fn()
         return cache[key]
@@ -241,7 +276,7 @@ class PSNetwork(nn.Module):
     def _visibility_prepack_bf16(self):
         """visibility-net weights in the fragment order of the bf16 engine, rebuilt only when the parameters changed."""
         net = self.visibility_net
-        key = tuple(int(p._version) for p in net.parameters()) + (net.linears[0].weight.data_ptr(),)
+        key = params_key(net.parameters(), getattr(self, '_pack_epoch', 0))
         if getattr(self, '_vis_pack16_key', None) != key:
             Ws, bs = net.weights()
             half = 3 + 6 * self.n_freqs

@@ -2,6 +2,7 @@
 train_fix schedule (stage2/trainer.py:485-513), without datasets / checkpoints / plots (out of scope,
 SURVEY 2).  Adam on the MLPs, SparseAdam on the light direction [n,3] and intensity [n,1] embeddings
 (trainer.py:126-168), per-iteration MultiStepLR."""
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -11,9 +12,43 @@ from ..optim import RowSparseAdam
 from .loss import MainLoss, NormalLoss
 
 
+class VisPlus(object):
+    """The extra visibility supervision of ``train.vis_plus`` (stage2/trainer.py:209-214 tables, :384-392 per-step
+    selection): per view, the P extra directions written by stage 1 (``vis_plus/light_dir.json`` + ``vis_plus/view_XX.npy``)
+    followed by the view's L_v initial (SDPS-Net) light estimates with the stage-1 visibility maps of the calibrated
+    lights; every step draws ``train.vis_train_num`` of the P + L_v rows with ``np.random.choice(replace=False)``.
+
+    ``views[v]`` = handoff.load_view(...) dictionaries ('vis_plus' [P,hw], 'vis_plus_light' [P,3], 'visibility'
+    [L_v,hw]); ``light_vis_train[v]`` [L_v,3] = the FIXED initial light estimates of view v (trainer.py:149; they are
+    concatenated un-normalised, :388).  All tables stay resident in HBM (P = 256: 0.3 GB per 612x512 view), so the
+    per-step selection is one two-index gather on the device instead of the reference's host tensor construction +
+    H2D copy of the whole [P + L_v, hw] table every iteration."""
+
+    def __init__(self, views, light_vis_train, vnum, device, rng=None):
+        self.vnum, self.device = int(vnum), device
+        self.rng = rng if rng is not None else np.random
+        self.lights = [torch.cat([v['vis_plus_light'].to(device).float(), lv.to(device).float()], dim=0)
+                       for v, lv in zip(views, light_vis_train)]
+        self.vis = [torch.cat([v['vis_plus'].to(device).float().reshape(v['vis_plus'].shape[0], -1),
+                               v['visibility'].to(device).float()], dim=0) for v in views]
+        for l, m in zip(self.lights, self.vis):
+            assert l.shape[0] == m.shape[0]  # trainer.py:391
+
+    def select(self, vidx, sampling_idx=None):
+        """(light_vis_train [vnum,3], vis_train_gt [vnum,n]) of one step; consumes one np.random.choice draw."""
+        lights, vis = self.lights[int(vidx)], self.vis[int(vidx)]
+        sidx = torch.as_tensor(self.rng.choice(np.arange(lights.shape[0]), self.vnum, replace=False)).long().to(self.device)
+        if sampling_idx is None:
+            return lights[sidx], vis[sidx]
+        return lights[sidx], vis[sidx[:, None], sampling_idx.to(self.device).long()[None, :]]
+
+
 class TrainStep(object):
-    def __init__(self, model, conf, n_lights_total, light_init, device, milestones=(), dp=None):
+    def __init__(self, model, conf, n_lights_total, light_init, device, milestones=(), dp=None, vis_plus=None):
         self.model, self.conf, self.device = model, conf, device
+        # frozen copy of the initial light estimates = torch.cat(self.light_vis_train) of trainer.py:149,377
+        self.light_vis_table = light_init.detach().clone().to(device)
+        self.vis_plus = vis_plus
         lk = dict(sg_rgb_weight=1.0, loss_type='L1', albedo_smooth_weight=0.05, rough_smooth_weight=0.01, vis_weight=1)
         lc = conf.get_config('loss', default=None) if hasattr(conf, 'get_config') else None
         if lc:
@@ -64,15 +99,32 @@ class TrainStep(object):
             self.light_para.requires_grad_(True)
             self.light_inten_para.requires_grad_(True)
 
-    def step(self, model_input, ground_truth, l_slt, train_order=True, noise=None):
+    def step(self, model_input, ground_truth, l_slt, train_order=True, noise=None, vidx=None):
         """One optimisation step on (this rank's pixel slice of) a batch.  ``l_slt`` are the rows of the
-        light tables used by this batch (trainer.py:367-379)."""
+        light tables used by this batch (trainer.py:367-379).
+
+        Visibility supervision lights (trainer.py:377-392):
+          * ``vidx`` given and a VisPlus table attached -> the reference's vis_plus draw for that view (the pixel
+            subset is ``model_input['sampling_idx']`` when present);
+          * ``model_input`` already carries 'light_vis_train' (+ 'vis_train_gt') -> a ready-made selection (synthetic
+            batches, parity fixtures) is kept;
+          * otherwise -> the fixed initial estimates of the batch's lights, normalised (trainer.py:377), supervised
+            against ``model_input['visibility']`` (loss.py:84-85)."""
         if train_order:
             self.train_fix()
         self.dp.new_step()
         model_input = dict(model_input)
         model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
         model_input['light_intensity'] = self.light_inten_para(l_slt)
+        if self.vis_plus is not None and vidx is not None:
+            # under data parallelism 'sampling_idx' is this rank's pixel slice (dist.shard_stage2) and every rank draws
+            # the same rows from an identically seeded np.random stream
+            sidx = model_input.get('sampling_idx')
+            if sidx is not None and sidx.dim() == 2:
+                sidx = sidx[0]  # batch dimension of the collated sample (trainer.py:392)
+            model_input['light_vis_train'], model_input['vis_train_gt'] = self.vis_plus.select(vidx, sidx)
+        elif 'light_vis_train' not in model_input:
+            model_input['light_vis_train'] = F.normalize(self.light_vis_table[l_slt], p=2, dim=-1)
         # ONE mask count per step (a tiny all-reduce under data parallelism), shared by every loss term.  Both masks
         # are inputs (the model passes them through as 'network_object_mask' / 'object_mask'), so the count -- a host
         # synchronisation -- is taken BEFORE the forward pass: afterwards the host runs ahead of the GPU through
@@ -82,13 +134,21 @@ class TrainStep(object):
         terms = dict(self.loss(out, ground_truth, model_input, count=count))
         terms_n = self.loss_n(out, count=count)
         loss = terms['loss'] + terms_n['loss']
-        self.sg_optimizer.zero_grad()
         train_light = self.light_para.weight.requires_grad
-        if train_light:
-            self.light_optimizer.zero_grad()
-        loss.backward()
-        self.dp.allreduce_grads([p for p in self.model.parameters() if p.requires_grad]
-                                + ([self.light_para.weight, self.light_inten_para.weight] if train_light else []))
+        if self.dp.enabled:
+            trainable = [p for p in self.model.parameters() if p.requires_grad] \
+                + ([self.light_para.weight, self.light_inten_para.weight] if train_light else [])
+            self.dp.prepare_grads(trainable)  # one memset; every .grad becomes a view into the flat all-reduce bucket
+        else:
+            self.sg_optimizer.zero_grad()
+            if train_light:
+                self.light_optimizer.zero_grad()
+        if loss.requires_grad:
+            loss.backward()
+        # (a rank whose pixel slice has no surface pixel gets constants from the model: its loss has no graph, it skips
+        # backward and contributes the zero-filled bucket, so the other ranks never wait for a collective it left out)
+        if self.dp.enabled:
+            self.dp.allreduce_grads(trainable)
         self.sg_optimizer.step()
         if train_light:
             self.light_optimizer.step(rows=l_slt)

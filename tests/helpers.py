@@ -53,6 +53,78 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-def assert_close(a, b, rtol, name=''):
-    e = rel_err(a, b)
-    assert e <= rtol, '%s: max-abs err / max-abs ref = %.3e > %.1e' % (name, e, rtol)
+# Absolute floors of the ELEMENTWISE parity metric |a - b| <= rtol * |b| + atol (north star: 1e-4 relative fp32).
+# A relative bound alone is meaningless for elements that are (nearly) zero: an fp32 dot product of K terms of size
+# ~1 carries ~sqrt(K) * 6e-8 of summation-order noise whatever its result is, so every output class gets the floor
+# that corresponds to ITS arithmetic, not a looser one:
+ATOL_UNIT = 1e-6    # quantities in [0, 1] or of unit length: rgb, albedo, alpha / occupancy, acc, visibility, normals
+ATOL_LOGIT = 1e-5   # raw MLP outputs of magnitude O(1..10): logits, features, d occ / d p, SG lobe weights
+ATOL_DEPTH = 1e-4   # ray depths d in [28, 35] found by root-finding on an fp32 network (1 ulp of d = 2-4e-6; the secant
+                    # update divides by f_high - f_low, which amplifies 1e-6 differences of the occupancy)
+
+# PSN_PARITY_REPORT=1: do not assert in the elementwise mode, collect the worst |a-b| / bound per name and print a
+# table at exit (used to calibrate / audit the floors above on the GPU box).
+_REPORT = os.environ.get('PSN_PARITY_REPORT') == '1'
+_report_rows = {}
+
+
+def _print_report():
+    if _report_rows:
+        print('\n==== parity report: worst |a-b| / (rtol |b| + atol) per check ====')
+        for name, (ratio, d, ref, rtol, atol) in sorted(_report_rows.items(), key=lambda kv: -kv[1][0]):
+            print('%-60s ratio %8.3f  |a-b| %.3e  ref %+.4e  rtol %.0e atol %.0e' % (name[:60], ratio, d, ref, rtol, atol))
+
+
+if _REPORT:
+    import atexit
+    atexit.register(_print_report)
+
+
+def assert_close(a, b, rtol, name='', atol=None):
+    """atol given  -> ELEMENTWISE: every element satisfies |a - b| <= rtol * |b| + atol (forward outputs, losses).
+    atol = None -> max|a - b| <= rtol * max|b|: the max-normalised form, kept for GRADIENT tensors and their digests
+    only (a gradient element is a sum over thousands of rows whose rounding noise scales with the tensor, not with
+    the element) and for raw kernel checks against float64 references."""
+    if atol is None:
+        e = rel_err(a, b)
+        assert e <= rtol, '%s: max-abs err / max-abs ref = %.3e > %.1e' % (name, e, rtol)
+        return
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, dtype=np.float64)
+    assert a.shape == b.shape, '%s: shape %s vs %s' % (name, a.shape, b.shape)
+    if a.size == 0:
+        return
+    both_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    d = np.where(both_inf, 0.0, np.abs(a - b))
+    bound = rtol * np.where(both_inf, 0.0, np.abs(b)) + atol
+    ratio = d / bound
+    ratio = np.where(np.isnan(ratio), np.inf, ratio)
+    i = int(np.argmax(ratio))
+    worst = float(ratio.reshape(-1)[i])
+    if _REPORT:
+        if name not in _report_rows or worst > _report_rows[name][0]:
+            _report_rows[name] = (worst, float(d.reshape(-1)[i]), float(b.reshape(-1)[i]), rtol, atol)
+        return
+    assert worst <= 1.0, ('%s: element %d: |a-b| = %.3e > %.0e * |%.4e| + %.0e (x%.2f); %d of %d elements out of bound'
+                          % (name, i, float(d.reshape(-1)[i]), rtol, float(b.reshape(-1)[i]), atol, worst,
+                             int((ratio > 1).sum()), a.size))
+
+
+# Stage-2 output dictionary (stage2/model/renderer.py:235-264): absolute floor per key.
+#   sg_specular_rgb_values = sum_k w_k exp(lambda_k (h.n - 1)) with lambda up to e^10 = 22026 (sgbasis.py:12,25): one ulp of
+#   h.n (6e-8) moves the sharpest lobe by 22026 * 6e-8 = 1.3e-3 RELATIVE, in the reference's own arithmetic as much as in
+#   ours (SURVEY 7 hard part 4).  Its floor is therefore relative to the largest lobe sum of the tensor (1e-4 of max|ref|);
+#   the rendered colour sg_rgb_values, into which it enters, is held to the plain [0, 1] floor.
+STAGE2_ATOL = {
+    'sg_rgb_values': ATOL_UNIT, 'sg_diffuse_albedo_values': ATOL_UNIT, 'albedo_values': ATOL_UNIT, 'albedo_jitter': ATOL_UNIT,
+    'normal_pred': ATOL_UNIT, 'normal_jitter': ATOL_UNIT, 'normal_values': ATOL_UNIT, 'points': ATOL_UNIT,
+    'visibility': ATOL_LOGIT, 'vis_train': ATOL_LOGIT, 'rough_values': ATOL_LOGIT, 'rough_jitter': ATOL_LOGIT,
+    'sg_weight': ATOL_LOGIT, 'sg_specular_rgb_values': 'max',
+}
+
+
+def assert_outputs_close(key, a, b, rtol=1e-4, prefix=''):
+    atol = STAGE2_ATOL.get(key, ATOL_UNIT)
+    if atol == 'max':
+        atol = rtol * float(np.abs(np.asarray(b, dtype=np.float64)).max())
+    assert_close(a, b, rtol, prefix + key, atol=atol)

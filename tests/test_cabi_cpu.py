@@ -209,3 +209,68 @@ def test_row_sparse_adam_matches_sparse_adam():
         o_b.zero_grad()
         (b(torch.tensor([1])) * 1.0).sum().backward()
         o_b.step()  # dense gradient without rows
+
+
+def test_vis_plus_selection_matches_reference_draw_and_layout():
+    """stage2/trainer.py:384-392 (train.vis_plus): cat(P extra directions, the view's L_v initial light estimates) and
+    cat(vis_plus maps, the view's stage-1 visibility maps), ONE np.random.choice(P + L_v, vnum, replace=False) per step,
+    rows gathered at the step's sampling_idx -- and trainer.py:377 (light_vis_train = normalize(initial estimates[l_slt]))
+    when vis_plus is off.  Also ViewSampler.batch = the collated + un-batched sample of trainer.py:364-379."""
+    import numpy as np
+    import torch
+    from psnerf_amd.handoff import ViewSampler
+    from psnerf_amd.stage2.trainer import VisPlus
+    h, w, P = 5, 7, 6
+    g = torch.Generator().manual_seed(0)
+    Ls = [4, 3]
+    views, init, imgs, omasks, ldirs = [], [], [], [], []
+    for L in Ls:
+        views.append({'points': torch.randn(1, h * w, 3, generator=g), 'normal': torch.randn(1, h * w, 3, generator=g),
+                      'surface_mask': torch.rand(1, h * w, generator=g) > 0.3, 'visibility': torch.rand(L, h * w, generator=g),
+                      'vis_plus': torch.rand(P, h * w, generator=g), 'vis_plus_light': torch.randn(P, 3, generator=g),
+                      'img_res': [h, w]})
+        init.append(torch.randn(L, 3, generator=g) * 2.0)  # deliberately not unit length: :388 concatenates them as they are
+        imgs.append(torch.rand(L, h * w, 3, generator=g))
+        omasks.append(torch.rand(h * w, generator=g) > 0.2)
+        ldirs.append(torch.randn(L, 3, generator=g))
+    vp = VisPlus(views, init, vnum=5, device='cpu')
+    ds = ViewSampler(views, imgs, omasks, ldirs, [torch.eye(4)] * 2, torch.eye(4), light_bs=2, n_pixels=9)
+    np.random.seed(7)
+    vidx, mi, gt, l_slt = ds.batch(1)
+    lv, gtv = vp.select(vidx, mi['sampling_idx'][0])
+    # the reference's sequence on the same stream: dataset draws (lights, pixels), then the trainer's vis_plus draw
+    np.random.seed(7)
+    lidx = np.random.choice(np.arange(Ls[1]), 2, replace=False)
+    sidx_px = np.random.choice(np.arange(h * w)[omasks[1].numpy()], 9, replace=False)
+    light_plus = torch.cat([views[1]['vis_plus_light'], init[1]], dim=0)
+    vis_plus_v = torch.cat([views[1]['vis_plus'].reshape(P, -1), views[1]['visibility']], dim=0)
+    sidx = np.random.choice(np.arange(len(light_plus)), 5, replace=False)
+    assert vidx == 1 and mi['lidx'].tolist() == lidx.tolist() and mi['sampling_idx'][0].tolist() == sidx_px.tolist()
+    assert l_slt.tolist() == (Ls[0] + lidx).tolist()  # rows of the concatenated per-view light tables (trainer.py:370-373)
+    assert torch.equal(lv, light_plus[sidx]) and torch.equal(gtv, vis_plus_v[sidx][:, sidx_px])
+    assert mi['uv'].shape == (1, 9, 2) and mi['points'].shape == (1, 9, 3) and mi['surface_mask'].shape == (1, 9)
+    assert mi['light_direction'].shape == (2, 3) and mi['visibility'].shape == (2, 9) and gt['rgb'].shape == (2, 9, 3)
+    assert mi['intrinsics'].shape == (1, 4, 4) and mi['pose'].shape == (1, 4, 4)
+
+
+def test_masked_losses_ignore_nonfinite_values_outside_the_mask():
+    """The reference selects with boolean indexing (stage2/model/loss.py:27-38, stage1/model/losses.py:53-63): a NaN in
+    a masked-OUT element must not reach the loss (a product with a 0/1 mask would turn it into NaN)."""
+    import torch
+    from psnerf_amd.stage2.loss import _masked_mean
+    from psnerf_amd.stage1.losses import Loss
+    d = torch.tensor([[[1.0, 2.0], [float('nan'), float('inf')], [3.0, 5.0]]])
+    m = torch.tensor([[True, False, True]])
+    assert float(_masked_mean(d, m, 2, 2)) == (1 + 2 + 3 + 5) / 4.0
+    n = 6
+    out = {'rgb': torch.rand(1, n, 3), 'diff_norm': torch.rand(3), 'normal_pred': torch.rand(1, n, 3)}
+    ngt = torch.rand(1, n, 3)
+    ngt[0, 1] = float('nan')
+    nmask = torch.ones(1, n, dtype=torch.bool)
+    nmask[0, 1] = False
+    acc = torch.rand(1, n)
+    mgt = (torch.rand(1, n) > 0.5).float()
+    valid = torch.ones(1, n, dtype=torch.bool)
+    valid[0, 2] = False
+    t = Loss(1.0, 0.1, 0.5, 0.7)(out, torch.rand(1, n, 3), ngt, nmask, acc, mgt, valid)
+    assert all(bool(torch.isfinite(v)) for v in t.values())

@@ -170,3 +170,48 @@ def test_stage1_two_rank_loss_gradients(tmp_path):
     terms = Loss(1.0, 0.1, 0.5, 0.7)(out, rgb_gt, normal_gt, norm_mask, out['acc_map'], mask_gt, mask_valid)
     terms['loss'].backward()
     assert_close(got['grad'], theta.grad, 2e-5, 'stage-1 dp grad')
+
+
+# ---- flat gradient bucket: views, one memset, a rank without a graph ------------------------------------------
+def _worker_bucket(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from psnerf_amd import dist as pdist
+    pdist.init_from_env(backend='gloo')
+    dp = pdist.DataParallel(torch.device('cpu'))
+    g = torch.Generator().manual_seed(0)
+    ps = [torch.randn(5, 3, generator=g).requires_grad_(), torch.randn(7, generator=g).requires_grad_(),
+          torch.randn(2, 2, generator=g)]  # the last one is frozen (requires_grad False): never in the bucket
+    log = []
+    for step in range(3):
+        train = [p for p in ps if p.requires_grad]
+        dp.prepare_grads(train)
+        flat, views = dp._bucket(train)
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(train, views)) and float(flat.abs().sum()) == 0.0
+        # rank 1 has "no surface pixel" on step 1: its loss has no graph and it skips backward (trainer behaviour)
+        if not (rank == 1 and step == 1):
+            loss = ((ps[0] * (rank + 1 + step)).sum() + (ps[1] ** 2).sum() * (rank + 1))
+            loss.backward()
+            assert ps[0].grad.data_ptr() == views[0].data_ptr(), 'autograd must accumulate into the bucket view'
+        dp.allreduce_grads(train)
+        log.append([p.grad.clone() for p in train])
+    assert dp.n_allreduce == 3 and ps[2].grad is None
+    if rank == 0:
+        torch.save({'log': log, 'ps': [p.detach() for p in ps]}, tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_views_and_rank_without_graph(tmp_path):
+    tmp = str(tmp_path / 'bucket.pt')
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_bucket, args=(2, port, tmp), nprocs=2, join=True)
+    got = torch.load(tmp)
+    ps = got['ps']
+    for step, (g0, g1) in enumerate(got['log']):
+        ranks = [0] if step == 1 else [0, 1]
+        want0 = sum(float(r + 1 + step) for r in ranks) * torch.ones_like(ps[0])
+        want1 = sum(2.0 * (r + 1) for r in ranks) * ps[1]
+        assert torch.allclose(g0, want0) and torch.allclose(g1, want1, rtol=1e-6), step

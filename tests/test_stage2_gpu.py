@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import GOLDEN, assert_close, grad_digest, stage2_state_dict, state_dict_digest
+from tests.helpers import GOLDEN, assert_close, assert_outputs_close, grad_digest, stage2_state_dict, state_dict_digest
 from psnerf_amd.synthetic import stage2_inputs
 
 pytestmark = pytest.mark.gpu
@@ -54,9 +54,9 @@ def test_psnetwork_golden(cuda, L, phase):
     out, t, gr = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, phase, torch.from_numpy(g['nz_xyz']), cuda)
     for k in g.files:
         if k.startswith('out_'):
-            assert_close(out[k[4:]].detach().cpu(), g[k], 1e-4, k)
+            assert_outputs_close(k[4:], out[k[4:]].detach().cpu(), g[k])
     for k, v in zip(g['loss_names'], g['loss_vals']):
-        assert_close(float(t[str(k)].detach()), v, 1e-4, str(k))
+        assert_close(float(t[str(k)].detach()), v, 1e-4, str(k), atol=0.0)
     names, norms, projs = grad_digest(gr)
     assert names == list(g['grad_names'])
     assert_close(norms, g['grad_norms'], 1e-3, 'grad norms')
@@ -84,10 +84,10 @@ def test_psnetwork_vs_oracle(cuda, N, L, V):
     out, t, gr = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, 2, nz, cuda)
     for k in o_out:
         if torch.is_tensor(o_out[k]) and o_out[k].dtype.is_floating_point:
-            assert_close(out[k].detach().cpu(), o_out[k].detach(), 1e-4, k)
+            assert_outputs_close(k, out[k].detach().cpu(), o_out[k].detach())
     for k in o_t:
         if o_t[k] is not None:
-            assert_close(float(t[k]), float(o_t[k]), 1e-4, k)
+            assert_close(float(t[k]), float(o_t[k]), 1e-4, k, atol=0.0)
     assert sorted(gr.keys()) == sorted(o_g.keys())
     for k in o_g:
         assert_close(gr[k].cpu(), o_g[k], 1e-3, 'grad ' + k)
@@ -141,7 +141,7 @@ def test_train_steps_match_oracle(cuda):
         inp_d = {k: v.to(cuda) for k, v in inp.items()}
         gt_d = {k: v.to(cuda) for k, v in gt.items()}
         pt, _ = step.step(inp_d, gt_d, l_slt.to(cuda), noise={'xyz': nz.to(cuda)})
-        assert_close(float(pt['total']), float(ot['total']), 2e-4, 'loss it%d' % it)
+        assert_close(float(pt['total']), float(ot['total']), 2e-4, 'loss it%d' % it, atol=0.0)
     # Adam's first steps move every weight by ~lr*sign(g): elements whose gradient is at the fp32 noise
     # floor may legitimately step the other way (|delta| <= 2*lr per step), so bound the max by that and
     # require the bulk (mean abs difference) to agree tightly.
@@ -168,12 +168,109 @@ def test_psnetwork_microfacet_golden(cuda):
     out, t, gr = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, 2, torch.from_numpy(g['nz_xyz']), cuda)
     for k in g.files:
         if k.startswith('out_'):
-            assert_close(out[k[4:]].detach().cpu(), g[k], 1e-4, k)
+            assert_outputs_close(k[4:], out[k[4:]].detach().cpu(), g[k])
     for k, v in zip(g['loss_names'], g['loss_vals']):
-        assert_close(float(t[str(k)].detach()), v, 1e-4, str(k))
+        assert_close(float(t[str(k)].detach()), v, 1e-4, str(k), atol=0.0)
     names, norms, projs = grad_digest(gr)
     assert names == list(g['grad_names'])
     assert_close(norms, g['grad_norms'], 1e-3, 'grad norms')
     assert_close(projs, g['grad_projs'], 2e-3, 'grad projs')
     assert_close(gr['__light_dir'].cpu(), g['g_light_dir'], 1e-3, 'light dir grad')
     assert_close(gr['__light_int'].cpu(), g['g_light_int'], 1e-3, 'light int grad')
+
+
+def _vis_plus_scene(h=12, w=16, P=6, Ls=(5, 4), seed=0):
+    """Two in-memory views in the hand-off layout (handoff.load_view) with vis_plus tables + images / masks / lights."""
+    g = torch.Generator().manual_seed(seed)
+    from psnerf_amd.synthetic import look_at_pose
+    views, init, imgs, omasks, ldirs = [], [], [], [], []
+    for L in Ls:
+        views.append({'points': torch.rand(1, h * w, 3, generator=g) * 1.2 - 0.6,
+                      'normal': torch.nn.functional.normalize(torch.randn(1, h * w, 3, generator=g), dim=-1),
+                      'surface_mask': torch.rand(1, h * w, generator=g) > 0.2,
+                      'visibility': (torch.rand(L, h * w, generator=g) > 0.3).float(),
+                      'vis_plus': (torch.rand(P, h * w, generator=g) > 0.3).float(),
+                      'vis_plus_light': torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1),
+                      'img_res': [h, w]})
+        init.append(torch.nn.functional.normalize(torch.randn(L, 3, generator=g), dim=-1))
+        imgs.append(torch.rand(L, h * w, 3, generator=g))
+        omasks.append(torch.rand(h * w, generator=g) > 0.1)
+        ldirs.append(torch.nn.functional.normalize(torch.randn(L, 3, generator=g), dim=-1))
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 60.0
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    poses = [look_at_pose(3.0, az_deg=10.0 * i) for i in range(len(Ls))]
+    return views, init, imgs, omasks, ldirs, poses, K
+
+
+def test_train_step_vis_plus_vs_oracle(cuda):
+    """a24: TrainRunner.run's step body incl. light_vis_train (trainer.py:377) and the vis_plus supervision draw
+    (:384-392), fed by ViewSampler.batch: HIP TrainStep vs the oracle's restatement on the same np.random stream."""
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.handoff import ViewSampler
+    from psnerf_amd.stage2.trainer import VisPlus
+    from oracle import stage2 as o2
+    views, init, imgs, omasks, ldirs, poses, K = _vis_plus_scene()
+    sd = stage2_state_dict(o2.bear_conf(), seed=13)
+    light_init = torch.cat(init, dim=0)
+    NL = light_init.shape[0]
+    vnum = 3
+    onet = o2.PSNetwork(o2.bear_conf())
+    onet.load_state_dict(sd)
+    o_vp = dict(light=[v['vis_plus_light'] for v in views], vis=[v['vis_plus'] for v in views], view_light=init,
+                view_vis=[v['visibility'] for v in views], vnum=vnum)
+    ostep = o2.TrainStep(onet, o2.bear_conf(), NL, light_init, vis_plus=o_vp)
+    net = s2.PSNetwork(s2.bear_conf())
+    net.load_state_dict(sd)
+    net.to(cuda)
+    step = s2.TrainStep(net, s2.bear_conf(), NL, light_init.to(cuda), cuda, vis_plus=VisPlus(views, init, vnum, cuda))
+    ostep.cur_iter = step.cur_iter = 5001
+    for it, vidx in enumerate((1, 0)):
+        results = []
+        for which in ('oracle', 'hip'):
+            np.random.seed(100 + it)
+            ds = ViewSampler(views, imgs, omasks, ldirs, poses, K, light_bs=3, n_pixels=150)
+            dev = 'cpu' if which == 'oracle' else cuda
+            v, mi, gt, l_slt = ds.batch(vidx, device=dev)
+            ns = int(mi['surface_mask'].sum())
+            nz = torch.randn(ns, 3, generator=torch.Generator().manual_seed(5 + it)) * 0.01
+            tr = ostep if which == 'oracle' else step
+            terms, out = tr.step(mi, gt, l_slt, train_order=False, noise={'xyz': nz.to(dev)}, vidx=v)
+            results.append((terms, out))
+        (ot, oo), (pt, po) = results
+        assert po['vis_train'].shape == (vnum, 150, 3)
+        for k in ('sg_rgb_values', 'vis_train', 'visibility'):
+            assert_outputs_close(k, po[k].detach().cpu(), oo[k].detach(), prefix='it%d ' % it)
+        for k in ('total', 'vis_loss', 'sg_rgb_loss'):
+            assert_close(float(pt[k]), float(ot[k]), 1e-4, '%s it%d' % (k, it), atol=0.0)
+    # without a VisPlus table and without ready-made supervision lights: trainer.py:377 (V = L, supervised against
+    # model_input['visibility'], loss.py:84-85)
+    np.random.seed(3)
+    ds = ViewSampler(views, imgs, omasks, ldirs, poses, K, light_bs=3, n_pixels=150)
+    _, mi, gt, l_slt = ds.batch(0)
+    nz = torch.randn(int(mi['surface_mask'].sum()), 3, generator=torch.Generator().manual_seed(9)) * 0.01
+    ot, oo = ostep.step(mi, gt, l_slt, train_order=False, noise={'xyz': nz})
+    pt, po = step.step({k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in mi.items()},
+                       {k: v.to(cuda) for k, v in gt.items()}, l_slt.to(cuda), train_order=False, noise={'xyz': nz.to(cuda)})
+    assert po['vis_train'].shape == (3, 150, 3)
+    assert_outputs_close('vis_train', po['vis_train'].detach().cpu(), oo['vis_train'].detach())
+    assert_close(float(pt['vis_loss']), float(ot['vis_loss']), 1e-4, 'vis_loss (trainer.py:377 branch)', atol=0.0)
+
+
+def test_invalidate_packs_after_data_edit(cuda):
+    """Weight packs are cached by parameter version + storage address; an edit through ``.data`` changes neither, so
+    callers announce it with invalidate_packs().  load_state_dict and .to() invalidate by themselves."""
+    import psnerf_amd.stage2 as s2
+    net = s2.PSNetwork(s2.bear_conf()).to(cuda).eval()
+    inp, _ = stage2_inputs(300, 3, 2, seed=2, device=cuda)
+    with torch.no_grad():
+        a = net(inp)['sg_rgb_values'].clone()
+        for m in (net.albedo_net, net.visibility_net):
+            m.linears[1].weight.data.mul_(1.5)  # not the first layer, no version bump
+        net.invalidate_packs()
+        b = net(inp)['sg_rgb_values'].clone()
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        sd['albedo_net.linears.2.weight'] = sd['albedo_net.linears.2.weight'] * 0.5
+        net.load_state_dict(sd)
+        c = net(inp)['sg_rgb_values'].clone()
+    assert float((a - b).abs().max()) > 1e-4 and float((b - c).abs().max()) > 1e-4
