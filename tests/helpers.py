@@ -80,8 +80,10 @@ if _REPORT:
     atexit.register(_print_report)
 
 
-def assert_close(a, b, rtol, name='', atol=None):
+def assert_close(a, b, rtol, name='', atol=None, outliers=None):
     """atol given  -> ELEMENTWISE: every element satisfies |a - b| <= rtol * |b| + atol (forward outputs, losses).
+    outliers = (fraction, factor): at most ``fraction`` of the elements may exceed the bound, and none by more than
+    ``factor`` x (only for the two specular-highlight outputs, see STAGE2_OUTLIERS).
     atol = None -> max|a - b| <= rtol * max|b|: the max-normalised form, kept for GRADIENT tensors and their digests
     only (a gradient element is a sum over thousands of rows whose rounding noise scales with the tensor, not with
     the element) and for raw kernel checks against float64 references."""
@@ -103,7 +105,15 @@ def assert_close(a, b, rtol, name='', atol=None):
     worst = float(ratio.reshape(-1)[i])
     if _REPORT:
         if name not in _report_rows or worst > _report_rows[name][0]:
-            _report_rows[name] = (worst, float(d.reshape(-1)[i]), float(b.reshape(-1)[i]), rtol, atol)
+            _report_rows[name + (' [%d of %d out]' % (int((ratio > 1).sum()), a.size) if worst > 1 else '')] = (
+                worst, float(d.reshape(-1)[i]), float(b.reshape(-1)[i]), rtol, atol)
+        return
+    if outliers is not None and worst > 1.0:
+        frac, factor = outliers
+        n_out = int((ratio > 1).sum())
+        assert n_out <= frac * a.size and worst <= factor, (
+            '%s: %d of %d elements beyond %.0e * |b| + %.0e (allowed: %.0e of them), worst x%.2f (allowed x%.1f)'
+            % (name, n_out, a.size, rtol, atol, frac, worst, factor))
         return
     assert worst <= 1.0, ('%s: element %d: |a-b| = %.3e > %.0e * |%.4e| + %.0e (x%.2f); %d of %d elements out of bound'
                           % (name, i, float(d.reshape(-1)[i]), rtol, float(b.reshape(-1)[i]), atol, worst,
@@ -123,8 +133,17 @@ STAGE2_ATOL = {
 }
 
 
+# The two outputs that contain the specular lobes may have a FEW highlight-peak elements beyond the bound: the lobe
+# argument lambda_k (h.n - 1) multiplies the fp32 noise of the predicted normal n (observed 4e-6 absolute, the GEMM
+# summation order of normal_net) by lambda_k <= 22026, i.e. a highlight element carries up to w_k lambda_k dn ~ 0.02 *
+# 22026 * 4e-6 = 2e-3 of conditioning error in ANY fp32 evaluation whose normal differs in the last bits.  Measured on
+# the full-size batch (110592 elements, round 2): 1 element of sg_rgb_values at 3.4 x the bound, specular at 3.0 x.
+# Allowed: <= 1e-3 of the elements, none beyond 5 x the bound (everything else is held to the plain bound).
+STAGE2_OUTLIERS = {'sg_rgb_values': (1e-3, 5.0), 'sg_specular_rgb_values': (1e-3, 5.0)}
+
+
 def assert_outputs_close(key, a, b, rtol=1e-4, prefix=''):
     atol = STAGE2_ATOL.get(key, ATOL_UNIT)
     if atol == 'max':
         atol = rtol * float(np.abs(np.asarray(b, dtype=np.float64)).max())
-    assert_close(a, b, rtol, prefix + key, atol=atol)
+    assert_close(a, b, rtol, prefix + key, atol=atol, outliers=STAGE2_OUTLIERS.get(key))

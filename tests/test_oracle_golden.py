@@ -203,3 +203,49 @@ def test_stage2_psnetwork_microfacet():
         assert_close(float(t[str(k)]), v, 2e-6, str(k))
     t['total'].backward()
     assert_close(ldir.grad, g['g_light_dir'], 1e-5, 'light dir grad')
+
+
+def test_stage2_camera_rays_vs_reference_rend_util():
+    """The fixture holds the outputs of the reference's OWN utils/rend_util.get_camera_params (tools/gen_golden.py
+    imports the real module; fx != fy so both focal lengths are exercised)."""
+    g = load('stage2_camera.npz')
+    rd, loc = o2.camera_rays(T(g['uv']), T(g['pose']), T(g['K']))
+    assert_close(rd, g['ray_dirs'], 1e-7, 'ray dirs')
+    assert np.array_equal(loc.numpy(), g['cam_loc'])
+
+
+def _normal_jitter_case(mod, dev='cpu'):
+    g = load('stage2_psnet_normal_jitter.npz')
+    conf = mod.bear_conf(**{'normal.net.xyz_jitter_std': 0.02})
+    sd = stage2_state_dict(o2.bear_conf(**{'normal.net.xyz_jitter_std': 0.02}), seed=35)
+    assert state_dict_digest(sd) == str(g['sd_digest'])
+    net = mod.PSNetwork(conf)
+    net.load_state_dict(sd)
+    net.to(dev)
+    inp, gt = stage2_inputs(int(g['N']), int(g['L']), int(g['V']), seed=int(g['input_seed']))
+    inp = {k: v.to(dev) for k, v in inp.items()}
+    gt = {k: v.to(dev) for k, v in gt.items()}
+    ldir = inp['light_direction'].clone().requires_grad_(True)
+    inp['light_direction'] = torch.nn.functional.normalize(ldir, p=2, dim=-1)
+    out = net(inp, noise={'normal': T(g['nz_normal']).to(dev), 'xyz': T(g['nz_xyz']).to(dev)})
+    t = dict(mod.MainLoss(loss_type='L1', sg_rgb_weight=1.0, albedo_smooth_weight=0.05, rough_smooth_weight=0.01,
+                          vis_weight=1)(out, gt, inp))
+    tn = mod.NormalLoss(1, 0.05)(out)
+    t.update(normal_loss=tn['normal_loss'], normal_smooth_loss=tn['normal_smooth_loss'], total=t['loss'] + tn['loss'])
+    t['total'].backward()
+    gr = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    return g, out, t, gr
+
+
+def test_stage2_psnetwork_normal_jitter():
+    """normal.net.xyz_jitter_std > 0 (renderer.py:133-140): second normal-net evaluation + NormalLoss smooth term."""
+    g, out, t, gr = _normal_jitter_case(o2)
+    for k in g.files:
+        if k.startswith('out_'):
+            assert_close(out[k[4:]].detach(), g[k], 2e-6, k)
+    for k, v in zip(g['loss_names'], g['loss_vals']):
+        assert_close(float(t[str(k)]), v, 2e-6, str(k))
+    names, norms, projs = grad_digest(gr)
+    assert names == list(g['grad_names'])
+    assert_close(norms, g['grad_norms'], 2e-5, 'grad norms')
+    assert_close(projs, g['grad_projs'], 1e-4, 'grad projs')

@@ -274,3 +274,30 @@ def test_invalidate_packs_after_data_edit(cuda):
         net.load_state_dict(sd)
         c = net(inp)['sg_rgb_values'].clone()
     assert float((a - b).abs().max()) > 1e-4 and float((b - c).abs().max()) > 1e-4
+
+
+def test_camera_rays_vs_reference_rend_util(cuda):
+    """psnerf_amd.stage2.renderer.camera_rays against the outputs of the reference's own rend_util.get_camera_params."""
+    from psnerf_amd.stage2.renderer import camera_rays
+    g = np.load(os.path.join(GOLDEN, 'stage2_camera.npz'))
+    T = lambda a: torch.from_numpy(a).to(cuda)
+    rd, loc = camera_rays(T(g['uv']), T(g['pose']), T(g['K']))
+    assert_close(rd.cpu(), g['ray_dirs'], 1e-6, 'ray dirs', atol=1e-7)
+    assert np.array_equal(loc.cpu().numpy(), g['cam_loc'])
+
+
+def test_psnetwork_normal_jitter_golden(cuda):
+    """normal.net.xyz_jitter_std > 0 (renderer.py:133-140): the branch bear.conf leaves off, pinned by its own golden."""
+    import psnerf_amd.stage2 as s2
+    from tests.test_oracle_golden import _normal_jitter_case
+    g, out, t, gr = _normal_jitter_case(s2, cuda)
+    assert 'normal_jitter' in out
+    for k in g.files:
+        if k.startswith('out_'):
+            assert_outputs_close(k[4:], out[k[4:]].detach().cpu(), g[k])
+    for k, v in zip(g['loss_names'], g['loss_vals']):
+        assert_close(float(t[str(k)].detach()), v, 1e-4, str(k), atol=0.0)
+    names, norms, projs = grad_digest(gr)
+    assert names == list(g['grad_names'])
+    assert_close(norms, g['grad_norms'], 1e-3, 'grad norms')
+    assert_close(projs, g['grad_projs'], 2e-3, 'grad projs')

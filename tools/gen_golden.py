@@ -229,22 +229,81 @@ def gen_stage1():
 def gen_stage2():
     import types
     from oracle import stage2 as o2
-    # harness-side shims (no reference edits): utils.rend_util needs imageio/cv2 and downloads at import
-    utils = types.ModuleType('utils')
-    rend = types.ModuleType('utils.rend_util')
-    rend.get_camera_params = lambda uv, pose, intr: o2.camera_rays(uv, pose, intr)
-    utils.rend_util = rend
-    sys.modules['utils'] = utils
-    sys.modules['utils.rend_util'] = rend
-    torch.Tensor.cuda = lambda self, *a, **k: self  # reference losses hard-code .cuda()
+    # harness-side shims (no reference edits): the REAL utils/rend_util.py is imported; only the third-party modules it
+    # needs at import time and that this image lacks (imageio incl. its download-at-import, skimage, cv2) are empty
+    # placeholders in sys.modules -- get_camera_params / lift (rend_util.py:90-147) use none of them.
+    for name in ('imageio', 'imageio.plugins', 'imageio.plugins.freeimage', 'skimage', 'cv2'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['imageio'].plugins = sys.modules['imageio.plugins']
+    sys.modules['imageio.plugins'].freeimage = sys.modules['imageio.plugins.freeimage']
+    sys.modules['imageio.plugins.freeimage'].download = lambda *a, **k: None
+    torch.Tensor.cuda = lambda self, *a, **k: self  # reference code hard-codes .cuda()
     sys.path.insert(0, os.path.join(REF, 'stage2'))
+    from utils import rend_util as RREND  # the reference's own module
+    assert os.path.realpath(RREND.__file__).startswith(os.path.realpath(REF)), RREND.__file__
     from model.renderer import PSNetwork as RPS
     from model.loss import MainLoss as RMain, NormalLoss as RNormal
     from model.sgbasis import SGBasis as RSG
     from model.microfacet import Microfacet as RMF
 
-    # camera helper parity against the real rend_util source is by inspection (cannot import); the
-    # stub IS the oracle's camera_rays, restated from utils/rend_util.py:90-147.
+    # ---- camera rays: the reference's get_camera_params vs the oracle's restatement, + a fixture for the HIP side
+    from psnerf_amd.synthetic import look_at_pose
+    gc = torch.Generator().manual_seed(8)
+    uv_c = torch.stack([torch.randint(0, 612, (300,), generator=gc).float(), torch.randint(0, 512, (300,), generator=gc).float()], -1)[None]
+    K_c = torch.eye(4)[None].clone()
+    K_c[0, 0, 0], K_c[0, 1, 1], K_c[0, 0, 2], K_c[0, 1, 2] = 3759.0, 3741.5, 306.0, 256.0  # fx != fy: both are used (rend_util.py:131-139)
+    pose_c = look_at_pose(31.5, az_deg=40.0, el_deg=-15.0)[None]
+    rd_r, loc_r = RREND.get_camera_params(uv_c, pose_c, K_c)
+    rd_o, loc_o = o2.camera_rays(uv_c, pose_c, K_c)
+    check('camera rays', rd_o, rd_r, 1e-7)
+    check('camera loc', loc_o, loc_r, 0.0)
+    np.savez_compressed(os.path.join(GOLDEN, 'stage2_camera.npz'), uv=np_(uv_c), K=np_(K_c), pose=np_(pose_c),
+                        ray_dirs=np_(rd_r), cam_loc=np_(loc_r))
+
+    # ---- normal jitter > 0 (renderer.py:133-140; bear.conf has 0): TWO torch.normal draws, normal jitter first
+    conf_j = o2.bear_conf(**{'normal.net.xyz_jitter_std': 0.02})
+    sd_j = stage2_state_dict(conf_j, seed=35)
+    rnet, onet = RPS(conf_j), o2.PSNetwork(conf_j)
+    rnet.load_state_dict(sd_j)
+    onet.load_state_dict(sd_j)
+    N, L, V = 300, 4, 3
+    inp, gt = stage2_inputs(N, L, V, seed=61)
+    ns = int(inp['surface_mask'].sum())
+    torch.manual_seed(79)
+    nz_n = torch.normal(0, torch.ones(ns, 3) * 0.02)
+    nz_x = torch.normal(0, torch.ones(ns, 3) * 0.01)
+    res = []
+    for net, Main, Norm, kw in ((rnet, RMain, RNormal, {}), (onet, o2.MainLoss, o2.NormalLoss, {'noise': {'normal': nz_n, 'xyz': nz_x}})):
+        i2 = {k: v.clone() for k, v in inp.items()}
+        ldir = i2['light_direction'].clone().requires_grad_(True)
+        i2['light_direction'] = torch.nn.functional.normalize(ldir, p=2, dim=-1)
+        torch.manual_seed(79)
+        out = net(i2, **kw)
+        t = Main(loss_type='L1', sg_rgb_weight=1.0, albedo_smooth_weight=0.05, rough_smooth_weight=0.01, vis_weight=1)(out, gt, i2)
+        tn = Norm(1, 0.05)(out)
+        total = t['loss'] + tn['loss']
+        total.backward()
+        gr = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+        res.append((out, dict(t, total=total, normal_loss=tn['normal_loss'], normal_smooth_loss=tn['normal_smooth_loss']), gr))
+    assert 'normal_jitter' in res[0][0] and res[0][1]['normal_smooth_loss'] is not None
+    keys = [k for k in res[0][0] if torch.is_tensor(res[0][0][k]) and res[0][0][k].dtype.is_floating_point]
+    for k in keys:
+        check('normal-jitter %s' % k, res[1][0][k], res[0][0][k], 2e-6)
+    for k in res[0][1]:
+        if res[0][1][k] is not None:
+            check('normal-jitter loss %s' % k, res[1][1][k], res[0][1][k], 2e-6)
+    names, norms, projs = grad_digest(res[0][2])
+    _, onorms, oprojs = grad_digest(res[1][2])
+    check('normal-jitter grad norms', onorms, norms, 2e-5)
+    check('normal-jitter grad projs', oprojs, projs, 1e-4)
+    lk = sorted(k for k in res[0][1] if res[0][1][k] is not None)
+    np.savez_compressed(
+        os.path.join(GOLDEN, 'stage2_psnet_normal_jitter.npz'), sd_digest=state_dict_digest(sd_j), N=N, L=L, V=V,
+        input_seed=61, nz_normal=np_(nz_n), nz_xyz=np_(nz_x), loss_names=np.array(lk),
+        loss_vals=np.array([float(res[0][1][k]) for k in lk]), grad_names=np.array(names), grad_norms=norms,
+        grad_projs=projs, **{('out_' + k): np_(res[0][0][k]) for k in keys})
+
     g = torch.Generator().manual_seed(21)
     n = 200
     v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
