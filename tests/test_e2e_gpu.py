@@ -1,0 +1,29 @@
+"""BASELINE configs[4] as one chain at small size: stage-1 training -> shape_extract (+ shadow-ray visibility, vis_plus)
+-> npy hand-off -> stage-2 training across the train_fix switch with the vis_plus draw -> envmap relight on the fp32
+path and the bf16 engine (tools/run_e2e.py holds the asserts: finite + decreasing losses, PSNR parity <= 0.05 dB)."""
+import importlib.util
+import json
+import os
+import sys
+
+import pytest
+
+from tests.helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_end_to_end_small(cuda, tmp_path, capsys, monkeypatch):
+    spec = importlib.util.spec_from_file_location('run_e2e', os.path.join(ROOT, 'tools', 'run_e2e.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, 'argv', ['run_e2e.py', '--h', '40', '--w', '40', '--views', '2', '--lights', '5', '--light-bs', '3',
+                                      '--vis-plus', '6', '--vis-train-num', '3', '--rays', '192', '--s1-steps', '24',
+                                      '--s2-steps', '32', '--pixels', '600', '--envmap-h', '4', '--out', str(tmp_path / 'shape')])
+    mod.main()
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['e2e'] == 'ok' and min(res['surface_pixels']) > 0
+    assert abs(res['relight']['psnr_fp32'] - res['relight']['psnr_bf16']) <= 0.05
+    for sub in ('points', 'normal', 'mask', 'visibility', 'vis_plus'):
+        assert os.path.exists(os.path.join(str(tmp_path / 'shape'), sub, 'view_01.npy'))

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] as ONE run: stage-1 training -> shape_extract (with shadow-ray visibility + vis_plus) ->
+on-disk hand-off -> stage-2 joint optimisation (train_fix schedule, vis_plus supervision draw, light tables) ->
+environment-map relighting on the fp32 path and on the bf16 MFMA engine.
+
+ARMADILLO-shaped synthetic scene (the datasets are not shipped): stage1/configs/armadillo.yaml == bunny.yaml up to paths
+(near 2, far 6, radius 2); stage2/confs/armadillo.conf == bear.conf up to paths, brdf.light_intensity = 4.0 and the
+light intensities not being trained.  Ground truth: a Lambertian sphere of radius 0.6 (what geometric_init starts
+from) under L directional lights per view.
+
+    python tools/run_e2e.py [--h 48 --w 64 --views 2 --lights 6 --s1-steps 30 --s2-steps 40 ...]
+    python -m torch.distributed.run --nproc-per-node N ... tools/run_e2e.py     (pixel / ray data parallel, dist.py)
+
+Checks (assert): every loss finite; stage-1 and stage-2 losses decrease; |PSNR(bf16 relight) - PSNR(fp32 relight)| <=
+0.05 dB against a common ground truth.  Prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def sphere_scene(K, c2w, h, w, lights, radius=0.6, albedo=(0.7, 0.5, 0.3), intensity=4.0):
+    """Analytic ground truth of one view: images [L, h*w, 3] (row-major h*w), object mask [h*w], normals [h*w,3]."""
+    import torch
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing='ij')
+    d = torch.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[0, 0], torch.ones_like(xs)], -1).reshape(-1, 3)  # fx for both axes (common.py:220)
+    d = torch.nn.functional.normalize(d @ c2w[:3, :3].T, dim=-1)
+    o = c2w[:3, 3]
+    b = (d * o).sum(-1)
+    disc = b * b - (o.dot(o) - radius * radius)
+    hit = disc > 0
+    t = -b - torch.sqrt(disc.clamp(min=0))
+    n = torch.nn.functional.normalize(o + t[:, None] * d, dim=-1)
+    cos = (n[None] * lights[:, None, :]).sum(-1).clamp(min=0)  # [L, hw]
+    img = intensity * torch.tensor(albedo)[None, None, :] * cos[..., None] / 3.14159
+    img = torch.where(hit[None, :, None], img.clamp(0, 1), torch.zeros_like(img))
+    return img, hit, torch.where(hit[:, None], n, torch.zeros_like(n))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--h', type=int, default=48)
+    ap.add_argument("--w", type=int, default=48)
+    ap.add_argument('--views', type=int, default=2)
+    ap.add_argument('--lights', type=int, default=6)
+    ap.add_argument('--light-bs', type=int, default=4)
+    ap.add_argument('--vis-plus', type=int, default=8, help='extra visibility supervision directions per view')
+    ap.add_argument('--vis-train-num', type=int, default=4)
+    ap.add_argument('--rays', type=int, default=256)
+    ap.add_argument('--s1-steps', type=int, default=30)
+    ap.add_argument('--s2-steps', type=int, default=40)
+    ap.add_argument('--pixels', type=int, default=1024, help='stage-2 pixels per step (in-mask sampling)')
+    ap.add_argument('--envmap-h', type=int, default=8)
+    ap.add_argument('--out', default=None, help='hand-off directory (default: a temporary one)')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from psnerf_amd import dist as pdist, handoff, metrics
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.synthetic import stage1_camera, stage1_cfg, look_at_pose
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.stage2 import relight
+    from psnerf_amd.stage2.trainer import VisPlus
+
+    rank, local, world = pdist.init_from_env()
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(42)
+    np.random.seed(42)  # stage1/train.py:14-15; every rank draws the same pixels / lights
+    h, w = args.h, args.w
+    t_all = time.time()
+
+    # ------------------------------------------------------------------ scene
+    cfg = stage1_cfg('bunny', **{'training.n_training_points': args.rays, 'training.normal_loss': False})
+    K, _, S = stage1_camera(cfg, h=h, w=w)
+    g = torch.Generator().manual_seed(1)
+    poses = [look_at_pose(4.0, az_deg=25.0 * v, el_deg=15.0) for v in range(args.views)]
+    lights, images, omasks = [], [], []
+    for v in range(args.views):
+        toward = torch.nn.functional.normalize(poses[v][:3, 3], dim=0)
+        l = torch.nn.functional.normalize(toward[None] + 0.6 * torch.randn(args.lights, 3, generator=g), dim=-1)
+        img, hit, _n = sphere_scene(K[0], poses[v], h, w, l)
+        lights.append(l)
+        images.append(img)
+        omasks.append(hit)
+
+    # ------------------------------------------------------------------ stage 1 (a16): train on the mean-light image
+    net1 = NeuralNetwork(cfg)
+    ren = Renderer(net1, cfg, device=dev)
+    tr1 = Trainer(ren, torch.optim.Adam(net1.parameters(), lr=1e-4), cfg, device=dev)
+    batches = []
+    for v in range(args.views):
+        mean_img = images[v].mean(0).reshape(h, w, 3).permute(2, 0, 1)[None]
+        mean_img = torch.where(omasks[v].reshape(1, 1, h, w), mean_img, torch.ones_like(mean_img))  # white background
+        batches.append({'img': mean_img.to(dev), 'img.mask': omasks[v].reshape(1, h, w).float().to(dev),
+                        'img.world_mat': poses[v][None].to(dev), 'img.camera_mat': K.to(dev), 'img.scale_mat': S.to(dev)})
+    s1_losses = []
+    t0 = time.time()
+    for it in range(args.s1_steps):
+        terms = tr1.train_step(batches[it % args.views], it=it)
+        s1_losses.append(float(terms['loss'].detach()))
+    torch.cuda.synchronize()
+    t_s1 = time.time() - t0
+    assert all(np.isfinite(s1_losses)), s1_losses
+    k = max(2, args.s1_steps // 5)
+    assert np.mean(s1_losses[-k:]) < np.mean(s1_losses[:k]), ('stage-1 loss did not decrease', s1_losses[:k], s1_losses[-k:])
+
+    # ------------------------------------------------------------------ shape_extract + hand-off (a14, f2)
+    out_dir = args.out or tempfile.mkdtemp(prefix='psnerf_e2e_')
+    t0 = time.time()
+    plus_dirs = []
+    for v in range(args.views):
+        # shape_extract.py:118-131: extra directions on the camera-facing hemisphere (farthest-point sampling there;
+        # seeded random directions here -- the choice of directions is not on the accelerated path)
+        toward = torch.nn.functional.normalize(poses[v][:3, 3], dim=0)
+        pd = torch.nn.functional.normalize(torch.randn(args.vis_plus, 3, generator=g), dim=-1)
+        pd = torch.where(((pd * toward).sum(-1) < 0)[:, None], -pd, pd)
+        plus_dirs.append(pd)
+        if rank == 0:
+            handoff.export_view(ren, K.to(dev), poses[v][None].to(dev), S.to(dev), h, w, out_dir, v + 1,
+                                light_dir=lights[v].to(dev), vis_plus_dir=pd.to(dev))
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t_extract = time.time() - t0
+    views = [handoff.load_view(out_dir, v + 1) for v in range(args.views)]
+    n_surf = [int(vw['surface_mask'].sum()) for vw in views]
+    assert min(n_surf) > 0, 'stage-1 surface is empty in some view'
+
+    # ------------------------------------------------------------------ stage 2 (a19-a24)
+    conf = s2.bear_conf(**{'brdf.light_intensity': 4.0, 'train.light_bs': args.light_bs,
+                           'train.vis_train_num': args.vis_train_num})
+    torch.manual_seed(43)
+    net2 = s2.PSNetwork(conf).to(dev)
+    # "predicted" initial lights = ground truth + noise (SDPS-Net estimates are not on the path)
+    light_pred = [torch.nn.functional.normalize(l + 0.05 * torch.randn(l.shape, generator=g), dim=-1) for l in lights]
+    n_total = sum(l.shape[0] for l in lights)
+    vp = VisPlus(views, light_pred, args.vis_train_num, dev)
+    step = s2.TrainStep(net2, conf, n_total, torch.cat(light_pred).to(dev), dev, vis_plus=vp)
+    ds = handoff.ViewSampler(views, images, omasks, lights, poses, K[0], light_bs=args.light_bs, n_pixels=args.pixels)
+    switch = args.s2_steps // 2
+    step.cur_iter = 0
+    s2_losses, phases = [], []
+    t0 = time.time()
+    for it in range(args.s2_steps):
+        if it == switch:
+            step.cur_iter = 5000  # jump to the train_fix switch (trainer.py:485-513) instead of running 5000 iterations
+        vidx, mi, gt, l_slt = ds.batch(it % args.views, device=dev)
+        if step.dp.enabled:
+            mi, gt = step.dp.shard_stage2(mi, gt)
+        terms, _ = step.step(mi, gt, l_slt, train_order=True, vidx=vidx)
+        s2_losses.append(float(terms['total'].detach()))
+        phases.append(1 if step.cur_iter <= 5000 else 2)
+    torch.cuda.synchronize()
+    t_s2 = time.time() - t0
+    assert all(np.isfinite(s2_losses)), s2_losses
+    k = max(2, switch // 4)
+    ph1, ph2 = s2_losses[:switch], s2_losses[switch:]
+    assert np.mean(ph1[-k:]) < np.mean(ph1[:k]), ('stage-2 phase-1 loss did not decrease', ph1[:k], ph1[-k:])
+    assert np.mean(ph2[-k:]) < np.mean(ph2[:k]), ('stage-2 phase-2 loss did not decrease', ph2[:k], ph2[-k:])
+
+    # ------------------------------------------------------------------ envmap relight, fp32 vs bf16 engine (f1, g1)
+    net2.eval()
+    lh = args.envmap_h
+    env = np.random.RandomState(0).rand(lh, 2 * lh, 3).astype(np.float32) * (4.0 / (lh * 2 * lh))
+    _, mi, _, _ = handoff.ViewSampler(views, images, omasks, lights, poses, K[0], light_bs=args.light_bs, split='test').batch(0, device=dev)
+    base = {k2: mi[k2] for k2 in ('uv', 'intrinsics', 'pose', 'object_mask', 'normal', 'points', 'surface_mask')}
+    t0 = time.time()
+    rgb32 = relight.render_envmap(net2, base, env, light_h=lh, light_batch=64)
+    rgb16 = relight.render_envmap(net2, base, env, light_h=lh, light_batch=64, precision='bf16')
+    torch.cuda.synchronize()
+    t_relight = time.time() - t0
+    noise = 0.03 * torch.randn(rgb32.shape, generator=torch.Generator().manual_seed(0)).to(dev)
+    gt_img = (rgb32 + noise).clamp(0, 1).cpu().numpy()
+    p32, p16 = metrics.PSNR(rgb32.cpu().numpy(), gt_img), metrics.PSNR(rgb16.cpu().numpy(), gt_img)
+    assert abs(p32 - p16) <= 0.05, (p32, p16)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            'e2e': 'ok', 'n_gpus': world, 'image': [h, w], 'views': args.views, 'lights_per_view': args.lights,
+            'surface_pixels': n_surf, 'stage1': {'steps': args.s1_steps, 'loss_first': s1_losses[0], 'loss_last': s1_losses[-1],
+                                                 'seconds': round(t_s1, 2)},
+            'shape_extract_seconds': round(t_extract, 2), 'handoff_dir': out_dir,
+            'stage2': {'steps': args.s2_steps, 'switch_at': switch, 'loss_phase1': [ph1[0], ph1[-1]],
+                       'loss_phase2': [ph2[0], ph2[-1]], 'seconds': round(t_s2, 2)},
+            'relight': {'envmap': [lh, 2 * lh], 'psnr_fp32': round(p32, 4), 'psnr_bf16': round(p16, 4),
+                        'psnr_between': round(metrics.PSNR(rgb16.cpu().numpy(), rgb32.cpu().numpy()), 2),
+                        'seconds': round(t_relight, 2)},
+            'total_seconds': round(time.time() - t_all, 2)}))
+
+
+if __name__ == '__main__':
+    main()
