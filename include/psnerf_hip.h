@@ -167,7 +167,7 @@ enum {
     PSN_ACT_RELU_MASK = 3,     /* act = z * (a1 > 0)               (ReLU backward with the saved activation) */
     PSN_ACT_MUL_AUX = 4,       /* act = z * a1;                    second = z                               */
     PSN_ACT_MUL2 = 5,          /* act = z * a1;                    second = z * a2                          */
-    PSN_ACT_SOFTPLUS_BWD = 6,  /* act = a1 * (z + 100 a2 (1 - a1))  (softplus double-backward combine)       */
+    PSN_ACT_SOFTPLUS_BWD = 6,  /* act = a1 z + 100 (1 - a1) a2     (softplus double-backward combine)        */
     PSN_ACT_HEAD = 7           /* side output: z is dumped, the activations are left untouched              */
 };
 enum { PSN_OUT_NONE = 0, PSN_OUT_SIGMOID = 1, PSN_OUT_OCC = 2 /* sigmoid(-10 x), network.py:125 */ };

@@ -203,7 +203,7 @@ __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&
             else if constexpr (CODE == PSN_ACT_RELU_MASK) o[r] = t1[mt][r] > 0.0f ? z : 0.0f;
             else if constexpr (CODE == PSN_ACT_MUL_AUX) o[r] = z * t1[mt][r];
             else if constexpr (CODE == PSN_ACT_MUL2) { o[r] = z * t1[mt][r]; o2[r] = z * t2[mt][r]; }
-            else if constexpr (CODE == PSN_ACT_SOFTPLUS_BWD) o[r] = t1[mt][r] * (z + 100.0f * t2[mt][r] * (1.0f - t1[mt][r]));
+            else if constexpr (CODE == PSN_ACT_SOFTPLUS_BWD) o[r] = fmaf(t1[mt][r], z, 100.0f * (1.0f - t1[mt][r]) * t2[mt][r]);
             else o[r] = z;
         }
         act[mt] = o;
@@ -311,7 +311,13 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         /* this wave's LDS-DMA pieces have landed; activation dumps issued after them may stay in flight */ \
         wait_for_weights<NMT>(pending_stages > 0 ? pending_dump : 0);                                       \
         if (pending_stages > 0) --pending_stages;                                                           \
-        __syncthreads(); /* every wave's pieces landed; the other buffer is no longer being read */         \
+        /* every wave's pieces landed; the other buffer is no longer being read (its fragments fed MFMAs that have  \
+           issued).  CHAIN: a bare s_barrier -- __syncthreads() is fence + barrier, and its workgroup-scope release \
+           is lowered to s_waitcnt vmcnt(0): every stage barrier then waited for ALL of the wave's outstanding     \
+           dump stores, i.e. the counted wait above was void and each layer's dumps were serialised with the next  \
+           layer's first stage */                                                                                  \
+        if constexpr (CHAIN) asm volatile("s_barrier" ::: "memory");                                         \
+        else __syncthreads();                                                                               \
         const int s_ = (S_IDX);                                                                             \
         float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);             \

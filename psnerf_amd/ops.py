@@ -660,21 +660,23 @@ class GeoFieldFused(torch.autograd.Function):
         U = R = None
         if with_grad:
             U = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]   # U[l] = R[l+1] * S[l]
-            R = [None] + [torch.empty(Q, 256, device=dev) for _ in range(n - 2)]  # R[l], l = 1..n-2 (raw sweep values)
+            # Raw sweep values R[l] are NOT dumped (the adjoint chain works from U, see backward) -- except at the skip
+            # layer, whose last d_pe columns are the sweep's contribution to d logit / d pe through the skip input.
+            r_sk = torch.empty(Q, 256, device=dev)
             r0 = torch.empty(Q, 256, device=dev)
             w_row = Ws[n - 1][0:1, :].contiguous()
             chains['sweep'](None, Q, a_div=1, a_mod=1, init_a_direct=w_row,
                             mask=[S[n - 2 - j] for j in range(n - 1)] + [None],
                             save=[U[n - 2 - j] for j in range(n - 1)] + [r0],
-                            save2=[None] + [R[n - 1 - j] for j in range(1, n - 1)] + [None])
+                            save2=[None] + [r_sk if n - 1 - j == sk else None for j in range(1, n - 1)] + [None])
             d_pe_t = r0[:, :64].contiguous()
-            d_pe_t[:, :d_pe] += R[sk][:, d_a:d_a + d_pe]
+            d_pe_t[:, :d_pe] += r_sk[:, d_a:d_a + d_pe]
             grad = hip.pe_encode_bwd(p, d_pe_t, n_octaves, scale)
         if any(ctx.needs_input_grad):
             ctx.meta = (n, sk, d_pe, d_a, n_octaves, scale, with_grad, chains)
             keep = [p, pe] + Ws + A + S
             if with_grad:
-                keep += U + R[1:]
+                keep += U
             ctx.save_for_backward(*keep)
         if grad is None:
             grad = torch.zeros(Q, 3, device=dev)
@@ -697,26 +699,27 @@ class GeoFieldFused(torch.autograd.Function):
         dW = [None] * n
         db = [None] * n
 
-        dS = None
+        E = None
         if sweep:
             base = 2 + 3 * n - 2
             U = sv[base:base + n - 1]
-            R = [None] + sv[base + n - 1:base + n - 1 + (n - 2)]
             dd_pe = hip.pe_encode_jvp(p, d_grad.contiguous(), n_octaves, 64, scale)  # adjoint of d_pe, [Q,64]
             dR = [dd_pe] + [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]   # dR[l], l = 0..n-1
-            dS = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]
-            r_last = w_row.expand(Q, 256).contiguous()
-            chains['sweep_bwd'](dd_pe, Q, mask=list(S), aux2=[R[l + 1] for l in range(n - 2)] + [r_last],
-                                save=dR[1:], save2=dS)
+            # Adjoint of the sweep u_l = r_{l+1} * s_l, r_l = W_l^T u_l:  du_l = W_l dr_l,  dr_{l+1} = du_l * s_l  and
+            # ds_l = du_l * r_{l+1}.  ds_l only ever enters the value adjoint as s_l' ds_l = 100 s_l (1 - s_l) du_l r_{l+1}
+            # = 100 (1 - s_l) (du_l * u_l): the chain therefore multiplies with the dumped U_l instead of a dumped R_{l+1}
+            # (one tensor less written by the sweep and none read back), and dumps E_l = du_l * u_l.
+            E = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]
+            chains['sweep_bwd'](dd_pe, Q, mask=list(S), aux2=list(U), save=dR[1:], save2=E)
             dR[sk][:, d_a:] = dd_pe[:, :d_pe]  # adjoint of the skip layer's [a | pe] sweep value
 
-        # adjoint of the value pass
+        # adjoint of the value pass: dz_l = s_l da_l + 100 (1 - s_l) E_l
         dZ = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]  # dZ[l] = d loss / d z_l
         init = (d_logit * w_row).contiguous()  # [Q,256] rank-1 term of W_last^T d_out
         key = 'value_bwd' if sweep else 'value_bwd_nosweep'
         chains[key](None, Q, a_div=1, a_mod=Q, init_a_direct=init, act_init=d_feat,
                     mask=[S[n - 2 - j] for j in range(n - 1)],
-                    aux2=[dS[n - 2 - j] for j in range(n - 1)] if sweep else None,
+                    aux2=[E[n - 2 - j] for j in range(n - 1)] if sweep else None,
                     save=[dZ[n - 2 - j] for j in range(n - 1)])
         # Every weight gradient of the call in ONE grouped launch: dW_l = dZ_l^T A_{l-1} (+ U_l^T dR_l from the sweep),
         # the bias gradients are the column sums of dZ_l, a by-product of staging the A tiles.

@@ -382,7 +382,7 @@ def test_mlp_chain_activation_programs(cuda):
     a2 = z2 * D(m2)
     z3 = a2 @ D(W[3]).t() + D(b[3])
     z4 = a2 @ D(W[4]).t() + D(b[4])            # HEAD leaves the activations of layer 2 in place
-    a4 = D(s4) * (z4 + 100.0 * D(t4) * (1.0 - D(s4)))
+    a4 = D(s4) * z4 + 100.0 * (1.0 - D(s4)) * D(t4)
     z5 = a4 @ D(W[5]).t() + D(b[5])
     a5 = torch.where(D(h5) > 0, z5, torch.zeros_like(z5))
     a6 = torch.relu(a5 @ D(W[6]).t() + D(b[6]))

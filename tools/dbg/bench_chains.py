@@ -29,7 +29,7 @@ for it in range(3):
     ev = hip.PROFILE_EVENTS
     hip.PROFILE_EVENTS = None
     if it == 2:
-        for n, m, (nm, rows, a, b) in zip(names, macs, ev):
+        for n, m, (nm, rows, a, b, _f) in zip(names, macs, ev):
             ms = a.elapsed_time(b)
             print('%-14s %7.3f ms  %6.1f TF/s (padded-256 MACs)' % (n, ms, 2.0 * m * rows / ms / 1e9))
         print('forward %.3f ms  backward %.3f ms' % (e0.elapsed_time(e1), e1.elapsed_time(e2)))

@@ -1,21 +1,51 @@
 #!/bin/bash
+# Per-chain hardware counters of ops.GeoFieldFused (F1 value pass, F2 sweep, B1 sweep adjoint, B2 value adjoint) at
+# 262144 query points: HBM-side traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and matrix-pipe occupancy.
+# Writes gpurun_out/$1/pmc_chains.json (copied to profiles/ by hand).  rocprofv3 runs python3 directly (no wrapper).
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 i=0
-for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_WR" \
-         "SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM"; do
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"; do
     i=$((i+1))
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pc$i -o c -- python3 $R/tools/dbg/bench_chains.py > /dev/null 2>&1
+    rm -rf /tmp/pc$i
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pc$i -o c -- python3 $R/tools/dbg/bench_chains.py > $OUT/pmc_chains_run$i.log 2>&1
     F=$(find /tmp/pc$i -name '*counter_collection*' | head -1)
-    python3 - "$F" <<'PY'
-import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'mlp_infer_kernel<true>' in r['Kernel_Name']]
-ids = sorted(set(int(r['Dispatch_Id']) for r in rows))
-# dispatches 8..11 = the third (timed) iteration of the four chains F1, F2, B1, B2
-sel = ids[8:12]
-for d, name in zip(sel, ['F1', 'F2', 'B1', 'B2']):
-    vals = {r['Counter_Name']: float(r['Counter_Value']) for r in rows if int(r['Dispatch_Id']) == d}
-    print(name, ' '.join('%s=%.3e' % (k.replace('SQ_', ''), v) for k, v in sorted(vals.items())))
-PY
+    cp "$F" $OUT/pmc_chains_pass$i.csv 2>/dev/null
 done
+python3 - $OUT <<'PY'
+import csv, json, sys, os
+out = sys.argv[1]
+res = {}
+names = ['F1 value pass', 'F2 sweep', 'B1 sweep adjoint', 'B2 value adjoint']
+for i in (1, 2, 3):
+    p = os.path.join(out, 'pmc_chains_pass%d.csv' % i)
+    if not os.path.exists(p):
+        continue
+    rows = [r for r in csv.DictReader(open(p)) if 'mlp_infer_kernel<true' in r['Kernel_Name']]
+    ids = sorted(set(int(r['Dispatch_Id']) for r in rows))
+    sel = ids[8:12]  # third iteration of the four chains
+    for d, name in zip(sel, names):
+        for r in rows:
+            if int(r['Dispatch_Id']) == d:
+                res.setdefault(name, {})[r['Counter_Name']] = float(r['Counter_Value'])
+Q = 262144
+alg = {'F1 value pass': (0, 2), 'F2 sweep': (1, 2), 'B1 sweep adjoint': (2, 2), 'B2 value adjoint': (2, 1)}
+for name, v in res.items():
+    rd, wr = alg[name]
+    v['algorithmic_read_bytes'] = rd * 8 * 1024 * Q
+    v['algorithmic_write_bytes'] = wr * 8 * 1024 * Q
+    if 'FETCH_SIZE' in v:
+        v['fetch_bytes_corrected'] = 2 * v['FETCH_SIZE'] * 1024  # gfx950: 128-B requests tallied as 64 B (MI355X_MICROARCH.md, HBM)
+    if 'WRITE_SIZE' in v:
+        v['write_bytes'] = v['WRITE_SIZE'] * 1024
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in v and 'GRBM_GUI_ACTIVE' in v:
+        v['mfma_busy_frac'] = round(v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (v['GRBM_GUI_ACTIVE'] / 8.0), 4)
+json.dump({'_comment': 'rocprofv3 --pmc (3 separate passes, --kernel-trace only) on tools/dbg/bench_chains.py, 262144 query points, '
+           'third iteration; FETCH_SIZE / WRITE_SIZE in KB; read side doubled per MI355X_MICROARCH.md', 'rows': Q, 'chains': res},
+          open(os.path.join(out, 'pmc_chains.json'), 'w'), indent=1)
+print(json.dumps(res, indent=1))
+PY
