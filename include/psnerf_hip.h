@@ -256,6 +256,23 @@ int psn_gather_rows(int n_items, const PsnScatterItem* items, const int64_t* idx
 int psn_secant_step(const float* occ, float tau, float* d_pred, float* d_low, float* d_high, float* f_low, float* f_high,
                     const float* origin, const float* dir, float* p_mid, int64_t n, void* stream);
 
+/* First free -> occupied crossing of the ray-march sweep, stage1/model/rendering.py:457-504: occ [n_rays, n_steps]
+ * (occupancy of the sweep points), far [n_rays] (sphere exit depth), u / omu [n_steps] = linspace(0, 1) and 1 - it (the
+ * sweep depths are near * omu + far * u).  bracket [4, n_rays] = d_low, d_high, f_low, f_high of the crossing (values are
+ * occupancy - tau); flags [n_rays] int32: bit 0 = a free -> occupied crossing exists on a ray that starts in free space
+ * (the reference's `mask`), bit 1 = the ray starts in free space (`mask_0_not_occupied`). */
+int psn_first_crossing(const float* occ, const float* far, const float* u, const float* omu, float near, float tau,
+                       int64_t n_rays, int n_steps, float* bracket, int* flags, void* stream);
+
+/* Fused secant refinement, stage1/model/rendering.py:525-555: n_iter regula-falsi iterations for every ray inside ONE
+ * launch -- query point origin + d_pred * dir, its positional encoding (pe_octaves bands, input scaled by pe_scale), the
+ * occupancy network (desc / packed_w / packed_b as for psn_mlp_infer: 256-wide, one output, PSN_OUT_OCC, input block =
+ * one 64-column encoding) and the bracket update -- instead of one encoding + network + update launch per iteration.
+ * bracket [4, n_rays] as written by psn_first_crossing (not modified); d_out [n_rays] = the final d_pred. */
+int psn_root_find(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* origin, const float* dir,
+                  const float* bracket, int64_t n_rays, float tau, int n_iter, int pe_octaves, float pe_scale, float* d_out,
+                  void* stream);
+
 /* ------------------------------------------------------------------------
  * Weight normalisation of up to PSN_WN_MAX_ITEMS layers in one launch: nn.utils.weight_norm(nn.Linear) as used by every
  * layer of stage1/model/network.py:37-66 (state_dict keys weight_g [rows,1], weight_v [rows,cols]).

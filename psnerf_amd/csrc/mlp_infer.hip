@@ -50,6 +50,12 @@ struct InferArgs {
     const float* aux2[PSN_MLP_MAX_LAYERS];  // aux2: second row-major operand (PSN_ACT_MUL2 / PSN_ACT_SOFTPLUS_BWD)
     float* save2[PSN_MLP_MAX_LAYERS];       // second dump (sigmoid of PSN_ACT_SOFTPLUS100, raw acc of MUL_AUX, acc*aux2 of MUL2)
     const float* act_init;                  // optional row-major [n_rows, 256] initial activations (chains that start from a tensor)
+    // SRC == 1 (fused secant root finder, psn_root_find): the rows are rays, the network input is computed in the kernel
+    const float* ray_o;      // [n_rows, 3]
+    const float* ray_d;      // [n_rows, 3]
+    const float* bracket;    // [4, n_rows]: d_low, d_high, f_low, f_high
+    float tau, pe_scale;
+    int n_iter, pe_octaves;
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -233,7 +239,14 @@ __device__ __forceinline__ void wait_for_weights(int stores) {
 
 // CHAIN = false: lean inference / forward-with-dump path (NONE / RELU / SOFTPLUS100 activations, one dump per layer).
 // CHAIN = true : general per-layer activation programs with row-major operands and two dumps (training chains).
-template <bool CHAIN, int NMT>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
+// SRC = 0: input features from tables (everything above).  SRC = 1: the fused secant root finder of the stage-1 ray march
+// (stage1/model/rendering.py:525-555): every row is a ray with a bracket [d_low, d_high] around the first free -> occupied
+// crossing; the kernel iterates  p = o + d_pred dir -> positional encoding -> occupancy network -> regula-falsi update
+// n_iter times WITHOUT leaving the launch (the reference, and round 1, paid one network launch + one encoding launch +
+// one update launch per iteration, and a host synchronisation to compact the hit rays first).  A ray's iterations
+// depend on nothing but the ray, so no inter-workgroup exchange is needed; the launch is latency-bound (one
+// workgroup per 64 rays) and costs about one serial pass through the network per iteration.
+template <bool CHAIN, int NMT, int SRC = 0>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
 __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     constexpr int W = 16 * NMT;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages + all biases
@@ -273,6 +286,33 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             xin[t][1] = v.y;
             xin[t][2] = v.z;
             xin[t][3] = v.w;
+        }
+    };
+
+    // SRC == 1: the positional encoding of the current query point, straight into the B-operand registers; the same
+    // expressions as pe_encode_kernel (csrc/pe.hip), so the values are bit-identical to the table path
+    float qx = 0.f, qy = 0.f, qz = 0.f;  // current query point of this lane's ray
+    auto compute_xin = [&](floatx4 (&xin)[8]) {
+        const int width = 3 + 6 * g.pe_octaves;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = 0.0f;
+                if (t < 4) {
+                    const int col = 16 * t + 4 * lg + r;
+                    if (col < 3) {
+                        v = (col == 0 ? qx : (col == 1 ? qy : qz)) * g.pe_scale;
+                    } else if (col < width) {
+                        const int q = col - 3;
+                        const int f = q / 6, w = q - 6 * f;
+                        const int c = w % 3;
+                        const float arg = ldexpf((c == 0 ? qx : (c == 1 ? qy : qz)) * g.pe_scale, f);
+                        v = (w >= 3) ? cosf(arg) : sinf(arg);
+                    }
+                }
+                xin[t][r] = v;
+            }
         }
     };
 
@@ -329,6 +369,19 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     }
 
     const int n_hidden = g.d.n_out > 0 ? n_layers - 1 : n_layers;  // n_out == 0: no final layer (backward chains)
+    // SRC == 1: bracket and ray of this lane's row (replicated over the four lane groups of a row)
+    float ox = 0.f, oy = 0.f, oz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, dl = 0.f, dh = 0.f, fl = 0.f, fh = 0.f, dp = 0.f;
+    if constexpr (SRC == 1) {
+        ox = g.ray_o[rowc * 3 + 0]; oy = g.ray_o[rowc * 3 + 1]; oz = g.ray_o[rowc * 3 + 2];
+        vx = g.ray_d[rowc * 3 + 0]; vy = g.ray_d[rowc * 3 + 1]; vz = g.ray_d[rowc * 3 + 2];
+        dl = g.bracket[rowc]; dh = g.bracket[g.n_rows + rowc]; fl = g.bracket[2 * g.n_rows + rowc]; fh = g.bracket[3 * g.n_rows + rowc];
+        dp = (-fl) * (dh - dl) / (fh - fl) + dl;  // rendering.py:526 (same expression as secant_step_kernel)
+    }
+    const int n_iter = SRC == 1 ? g.n_iter : 1;
+    for (int iter = 0; iter < n_iter; ++iter) {
+    if constexpr (SRC == 1) {  // rendering.py:531: p_mid = ray0 + d_pred * direction
+        qx = ox + dp * vx; qy = oy + dp * vy; qz = oz + dp * vz;
+    }
     int li = 0;
     for (; li < n_hidden; ++li) {
         const PsnMlpLayer L = g.d.layers[li];
@@ -379,7 +432,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         }
         if (L.n_kt_in > 0) {
             floatx4 xin[8];
-            load_xin(xin);
+            if constexpr (SRC == 1) compute_xin(xin);
+            else load_xin(xin);
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 if (kt < L.n_kt_in) PSN_STAGE(NMT, xin[2 * kt], xin[2 * kt + 1], L.n_kt_act + kt)
@@ -454,10 +508,28 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         wait_for_weights<NMT>(pending_stages > 0 ? pending_dump : 0);
         __syncthreads();
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
+        if constexpr (SRC == 1) {
+            // the next iteration starts over with layer 0: request its first weight stage into the buffer that the
+            // last hidden stage has just released (every wave is past the barrier above)
+            if (iter + 1 < n_iter) stage_load<2 * NMT>(g.w + g.d.layers[0].w_off, smem + ((gstage + 1) & 1) * kStageFloats, wave, lane);
+        }
 #pragma unroll
         for (int kt = 0; kt < NMT / 2; ++kt) stage_compute<2, NMT>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane, [](int) {});
+        if constexpr (SRC == 1) ++gstage;
     }
+    if constexpr (SRC == 1) {
+        // occupancy of row lj sits in the lane group lg == 0 (output feature 0): rendering.py:537-548
+        float fm = sigmoidf_(acc[0][0] * -10.0f) - g.tau;
+        fm = __shfl(fm, lj);
+        if (fm < 0.0f) { dl = dp; fl = fm; } else { dh = dp; fh = fm; }
+        dp = (-fl) * (dh - dl) / (fh - fl) + dl;
+    }
+    }  // iterations (SRC == 1; a single pass otherwise)
 #undef PSN_STAGE
+    if constexpr (SRC == 1) {
+        if (row < g.n_rows && lg == 0) g.out[row] = dp;
+        return;
+    }
 
     // ---- output: feature f = 16*mt + 4*g + r of the final layer ---------------------------------
     if (row < g.n_rows && g.d.n_out > 0) {
@@ -654,5 +726,39 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         else hipLaunchKernelGGL((mlp_infer_kernel<false, 4>), grid, block, lds_bytes, st, a);
     }
     PSN_CHECK_LAUNCH("mlp_infer");
+    return PSN_OK;
+}
+
+// Fused secant refinement of the ray march (stage1/model/rendering.py:525-555) on the occupancy network packed by
+// fused.pack_geo_occupancy (256-wide softplus network whose input block is the positional encoding of the point).
+extern "C" int psn_root_find(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* origin,
+                             const float* dir, const float* bracket, int64_t n_rays, float tau, int n_iter, int pe_octaves,
+                             float pe_scale, float* d_out, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(desc && packed_w && packed_b && origin && dir && bracket && d_out, "root_find: null pointer");
+    const PsnMlpDesc& d = *desc;
+    PSN_CHECK_ARG(d.n_layers >= 2 && d.n_layers <= PSN_MLP_MAX_LAYERS && d.n_out == 1 && d.out_act == PSN_OUT_OCC,
+                  "root_find: expects an occupancy network (one output, PSN_OUT_OCC)");
+    PSN_CHECK_ARG(d.in_kt_a == 2 && d.in_kt_b == 0 && 3 + 6 * pe_octaves <= 64 && pe_octaves >= 0,
+                  "root_find: the input block is one 64-column positional encoding (in_kt_a = 2), got in_kt_a=%d octaves=%d", d.in_kt_a, pe_octaves);
+    PSN_CHECK_ARG(d.layers[0].n_kt_in == 2 && d.layers[0].n_kt_act == 0 && d.layers[0].init_off < 0, "root_find: layer 0 reads the encoding as k-tiles");
+    for (int l = 0; l < d.n_layers; ++l) {
+        const PsnMlpLayer& L = d.layers[l];
+        const bool last = l == d.n_layers - 1;
+        PSN_CHECK_ARG(L.n_mt == (last ? 1 : 8) && L.init_off < 0, "root_find: layer %d: 256-wide hidden layers without init tables only", l);
+        PSN_CHECK_ARG(L.act == (last ? PSN_ACT_NONE : PSN_ACT_SOFTPLUS100) || L.act == PSN_ACT_RELU || L.act == PSN_ACT_NONE, "root_find: layer %d activation", l);
+        PSN_CHECK_ARG(L.b_off == (int64_t)l * 256, "root_find: biases must be packed back to back");
+    }
+    PSN_CHECK_ARG(n_iter >= 0 && n_iter <= 64, "root_find: n_iter=%d", n_iter);
+    if (n_rays <= 0) return PSN_OK;
+    InferArgs a = {};
+    a.d = d; a.w = packed_w; a.b = packed_b; a.a_div = 1; a.a_mod = 1; a.b_div = 1; a.b_mod = 1; a.n_rows = n_rays; a.out = d_out;
+    a.n_bias = (d.n_layers - 1) * 256 + 32;
+    a.ray_o = origin; a.ray_d = dir; a.bracket = bracket; a.tau = tau; a.pe_scale = pe_scale; a.n_iter = n_iter; a.pe_octaves = pe_octaves;
+    const int64_t blocks = (n_rays + kWaves * 16 - 1) / (kWaves * 16);
+    PSN_CHECK_ARG(blocks < (1ll << 31), "root_find: too many rays");
+    const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
+    hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 1>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("root_find");
     return PSN_OK;
 }

@@ -158,3 +158,64 @@ extern "C" int psn_secant_step(const float* occ, float tau, float* d_pred, float
     PSN_CHECK_LAUNCH("secant_step");
     return PSN_OK;
 }
+
+// ---- first free -> occupied crossing of the ray-march sweep (stage1/model/rendering.py:457-504) ----------------------
+// One wave per ray over its M sweep values val[m] = occupancy - tau:
+//   first_free = val[0] < 0;  i* = the first m with val[m] val[m+1] < 0 (the reference takes argmin of
+//   sign(val[m] val[m+1]) (M - m), whose unique minimum is that m whenever one exists);  the crossing counts if it goes
+//   from free to occupied (val[i*] < 0) and the ray starts in free space;  bracket = sweep depths / values i*, i* + 1.
+// Outputs: bracket [4, N] (d_low, d_high, f_low, f_high; a benign (0, 1, -1, 1) for rays without a crossing),
+// flags [N] int32: bit 0 = crossing found (mask), bit 1 = first_free.
+namespace psn {
+__global__ __launch_bounds__(256) void first_crossing_kernel(const float* __restrict__ occ, const float* __restrict__ far,
+                                                             const float* __restrict__ u, const float* __restrict__ omu,
+                                                             float near, float tau, int64_t n, int M,
+                                                             float* __restrict__ bracket, int* __restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    const float* v = occ + ray * M;
+    int best = M;  // first index with a sign change
+    for (int m = lane; m + 1 < M; m += 64) {
+        const float p = (v[m] - tau) * (v[m + 1] - tau);
+        if (p < 0.0f && m < best) best = m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(best, o);
+        best = other < best ? other : best;
+    }
+    if (lane == 0) {
+        const float v0 = v[0] - tau;
+        const bool first_free = v0 < 0.0f;
+        bool mask = false;
+        float dl = 0.0f, dh = 1.0f, fl = -1.0f, fh = 1.0f;
+        if (best < M) {
+            const int i2 = best + 1 < M - 1 ? best + 1 : M - 1;
+            const float f_lo = v[best] - tau;
+            mask = f_lo < 0.0f && first_free;
+            if (mask) {
+                const float fr = far[ray];
+                dl = near * omu[best] + fr * u[best];  // the sweep depth number i (rendering.py:447-453)
+                dh = near * omu[i2] + fr * u[i2];
+                fl = f_lo;
+                fh = v[i2] - tau;
+            }
+        }
+        bracket[ray] = dl; bracket[n + ray] = dh; bracket[2 * n + ray] = fl; bracket[3 * n + ray] = fh;
+        flags[ray] = (mask ? 1 : 0) | (first_free ? 2 : 0);
+    }
+}
+}  // namespace psn
+
+extern "C" int psn_first_crossing(const float* occ, const float* far, const float* u, const float* omu, float near, float tau,
+                                  int64_t n_rays, int n_steps, float* bracket, int* flags, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(occ && far && u && omu && bracket && flags, "first_crossing: null pointer");
+    PSN_CHECK_ARG(n_steps >= 2, "first_crossing: n_steps=%d", n_steps);
+    if (n_rays <= 0) return PSN_OK;
+    hipLaunchKernelGGL(first_crossing_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, occ, far, u, omu,
+                       near, tau, n_rays, n_steps, bracket, flags);
+    PSN_CHECK_LAUNCH("first_crossing");
+    return PSN_OK;
+}

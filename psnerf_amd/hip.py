@@ -99,6 +99,8 @@ SIGNATURES = {
     'psn_scatter_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_gather_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_secant_step': (i32, [c_f, f32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, c_f]),
+    'psn_first_crossing': (i32, [c_f, c_f, c_f, c_f, f32, f32, i64, i32, c_f, c_f, c_f]),
+    'psn_root_find': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, i64, f32, i32, i32, f32, c_f, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_mlp_pack_bf16': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
@@ -282,6 +284,28 @@ def secant_step(occ, tau, d_pred, d_low, d_high, f_low, f_high, origin, directio
                                 _ptr(d_high, 'd_high'), _ptr(f_low, 'f_low'), _ptr(f_high, 'f_high'),
                                 _ptr(origin, 'origin', True), _ptr(direction, 'direction', True), _ptr(p_mid, 'p_mid', True),
                                 d_pred.numel(), _stream()), 'secant_step')
+
+
+def first_crossing(occ, far, u, omu, near, tau):
+    """occ [N, M] sweep occupancies -> (bracket [4, N] float32, flags [N] int32) -- see psn_first_crossing."""
+    N, M = occ.shape
+    bracket = torch.empty(4, N, device=occ.device, dtype=torch.float32)
+    flags = torch.empty(N, device=occ.device, dtype=torch.int32)
+    _check(_lib.psn_first_crossing(_ptr(occ, 'occ'), _ptr(far, 'far'), _ptr(u, 'u'), _ptr(omu, 'omu'), float(near), float(tau),
+                                   N, M, bracket.data_ptr(), flags.data_ptr(), _stream()), 'first_crossing')
+    return bracket, flags
+
+
+def root_find(desc, packed_w, packed_b, origin, direction, bracket, tau, n_iter, pe_octaves, pe_scale):
+    """n_iter secant iterations on every ray in one launch (psn_root_find) -> d_pred [N]."""
+    N = origin.shape[0]
+    assert bracket.shape == (4, N)
+    out = torch.empty(N, device=origin.device, dtype=torch.float32)
+    with _Prof('root_find', N, None):
+        _check(_lib.psn_root_find(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'), _ptr(origin, 'origin'),
+                                  _ptr(direction, 'direction'), _ptr(bracket, 'bracket'), N, float(tau), int(n_iter), int(pe_octaves),
+                                  float(pe_scale), out.data_ptr(), _stream()), 'root_find')
+    return out
 
 
 def workspace(n_floats, device):

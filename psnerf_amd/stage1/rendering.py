@@ -108,54 +108,46 @@ class Renderer(nn.Module):
         p_prop = torch.empty(B * N, n_steps, 3, device=dev)
         hip.sample_points(ray0.reshape(-1, 3).contiguous(), ray_direction.reshape(-1, 3).contiguous(),
                           far.reshape(-1), p_prop, False, float(depth_range[0]), u)
-        val = (self._occ(p_prop.reshape(-1, 3)) - tau).view(B, N, n_steps)
+        occ = self._occ(p_prop.reshape(-1, 3)).view(B * N, n_steps)
         if clip:
-            pp4 = p_prop.view(B, N, n_steps, 3)
-            val[(pp4 > 1).any(-1)] = -1
-            val[(pp4 < -1).any(-1)] = -1
-        first_free = val[:, :, 0] < 0
-        sgn = torch.cat([torch.sign(val[:, :, :-1] * val[:, :, 1:]), torch.ones(B, N, 1, device=dev)], dim=-1)
-        cost = sgn * torch.arange(n_steps, 0, -1, device=dev).float()
-        values, idx = torch.min(cost, -1)
-        has_change = values < 0
-        from_free = torch.gather(val, 2, idx.unsqueeze(-1)).squeeze(-1) < 0
-        mask = has_change & from_free & first_free
-        idx2 = torch.clamp(idx + 1, max=n_steps - 1)
-        gat = lambda src, i: torch.gather(src, 2, i.unsqueeze(-1)).reshape(-1)
-        depth = lambda i: (float(depth_range[0]) * u[1][i] + far * u[0][i]).reshape(-1)  # the sweep depth number i
-        return dict(ray0=ray0, ray_direction=ray_direction, tau=tau, mask=mask, first_free=first_free, far=far,
-                    d_low=depth(idx), f_low=gat(val, idx), d_high=depth(idx2), f_high=gat(val, idx2))
+            pp4 = p_prop.view(B * N, n_steps, 3)
+            occ = occ.clone()
+            occ[(pp4 > 1).any(-1)] = tau - 1
+            occ[(pp4 < -1).any(-1)] = tau - 1
+        # first free -> occupied crossing and its bracket (rendering.py:457-504): one launch, one wave per ray
+        bracket, flags = hip.first_crossing(occ.contiguous(), far.reshape(-1).contiguous(), u[0], u[1],
+                                            float(depth_range[0]), tau)
+        return dict(ray0=ray0, ray_direction=ray_direction, tau=tau, far=far, bracket=bracket, flags=flags)
 
     @torch.no_grad()
     def _march_finish(self, st, n_secant_steps):
-        """Second half: ONE nonzero() (the data-dependent host synchronisation of the march) gives the list of rays
-        with a free -> occupied crossing; every gather / scatter below is an index op with it (rendering.py:480-520)."""
-        ray0, ray_direction, mask = st['ray0'], st['ray_direction'], st['mask']
+        """Second half (rendering.py:480-523): the secant refinement of EVERY ray in one launch (rays without a crossing
+        carry a benign bracket and are overwritten below), no compaction and therefore no host synchronisation: the
+        refinement is latency-bound -- one serial pass through the network per iteration, whatever the number of rays
+        up to 64 per CU -- so masked rays cost nothing, while nonzero() cost a round trip to the host."""
+        ray0, ray_direction = st['ray0'], st['ray_direction']
         B, N, _ = ray0.shape
-        dev = ray0.device
-        mi = mask.reshape(-1).nonzero(as_tuple=True)[0]
-        d_pred = self.secant(st['f_low'][mi], st['f_high'][mi], st['d_low'][mi], st['d_high'][mi], n_secant_steps,
-                             ray0.reshape(-1, 3)[mi], ray_direction.reshape(-1, 3)[mi], st['tau'])
-        out = torch.full((B * N,), float('inf'), device=dev)
-        out[mi] = d_pred
-        out = out.view(B, N)
-        return torch.where(st['first_free'], out, torch.zeros_like(out))
+        mask = (st['flags'] & 1).bool()
+        first_free = (st['flags'] & 2).bool()
+        d_pred = self._root_find(st['bracket'], ray0.reshape(-1, 3).contiguous(), ray_direction.reshape(-1, 3).contiguous(),
+                                 st['tau'], n_secant_steps)
+        out = torch.where(mask, d_pred, torch.full_like(d_pred, float('inf')))
+        out = torch.where(first_free, out, torch.zeros_like(out))
+        return out.view(B, N)
+
+    def _root_find(self, bracket, origin, direction, tau, n_iter):
+        m = self.model
+        packed = m._occupancy_packed()
+        return hip.root_find(packed.desc, packed.w, packed.b, origin, direction, bracket, tau, n_iter, m.octaves_pe,
+                             1.0 / m.rescale)
 
     # ---- stage1/model/rendering.py:525-555 -------------------------------------------------------
     @torch.no_grad()
     def secant(self, f_low, f_high, d_low, d_high, n_secant_steps, ray0_masked, ray_direction_masked, tau, it=0):
-        if f_low.is_cuda and f_low.numel() > 0:
-            # one launch per iteration for the bracket update, the next estimate and the next query point
-            d_low, d_high, f_low, f_high = (t.contiguous().clone() for t in (d_low, d_high, f_low, f_high))
-            origin, direction = ray0_masked.contiguous(), ray_direction_masked.contiguous()
-            d_pred = torch.empty_like(d_low)
-            p_mid = torch.empty(d_low.shape[0], 3, device=d_low.device)
-            hip.secant_step(None, tau, d_pred, d_low, d_high, f_low, f_high, origin, direction, p_mid)
-            for i in range(n_secant_steps):
-                occ = self._occ(p_mid)[..., 0].contiguous()
-                hip.secant_step(occ, tau, d_pred, d_low, d_high, f_low, f_high, origin, direction,
-                                p_mid if i + 1 < n_secant_steps else None)
-            return d_pred
+        if f_low.is_cuda and f_low.numel() > 0 and hasattr(self.model, '_occupancy_packed') and self.model._hidden_is_256():
+            # all iterations in one launch (psn_root_find)
+            bracket = torch.stack([d_low, d_high, f_low, f_high]).float().contiguous()
+            return self._root_find(bracket, ray0_masked.contiguous(), ray_direction_masked.contiguous(), tau, n_secant_steps)
         d_pred = -f_low * (d_high - d_low) / (f_high - f_low) + d_low
         if d_pred.numel() == 0:
             return d_pred

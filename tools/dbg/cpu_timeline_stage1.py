@@ -29,6 +29,13 @@ wrap(_hip, 'mlp_infer', 'mlp_infer')
 wrap(_hip, 'gemm_tn_grouped', 'gemm_tn_grouped')
 wrap(_hip, 'composite_fwd', 'composite_fwd')
 wrap(_hip, 'composite_bwd', 'composite_bwd')
+wrap(_hip, 'root_find', 'root_find')
+wrap(_hip, 'first_crossing', 'first_crossing')
+wrap(_hip, 'sample_points', 'sample_points')
+wrap(torch.Tensor, 'nonzero', 'SYNC nonzero')
+wrap(torch.Tensor, '__int__', 'SYNC int()')
+wrap(torch.Tensor, 'item', 'SYNC item')
+wrap(tr.optimizer, 'step', 'adam.step')
 t0 = time.perf_counter()
 tr.train_step(bd, it=6000)
 t1 = time.perf_counter()

@@ -1,0 +1,10 @@
+#!/bin/bash
+O=$GRAFT_REPO_ROOT/gpurun_out/r02f
+mkdir -p $O
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o s1 -- python3 $GRAFT_REPO_ROOT/tools/bench_stage1.py --steps 4 --warmup 2 > $O/s1.json 2> $O/s1.err
+F=$(find /tmp/p1 -name '*kernel_stats.csv' | head -1)
+cp $F $O/s1_kernel_stats.csv
+head -12 $F | cut -c1-160
+cat $O/s1.json
