@@ -264,6 +264,15 @@ int psn_secant_step(const float* occ, float tau, float* d_pred, float* d_low, fl
 int psn_first_crossing(const float* occ, const float* far, const float* u, const float* omu, float near, float tau,
                        int64_t n_rays, int n_steps, float* bracket, int* flags, void* stream);
 
+/* Shadow-ray sample points that lie inside the object box, stage1/model/rendering.py:378-408: for the dense rows
+ * q = (l n_surf + s) n_steps + m the point p = surf[s] + ldir[l] (lnear omu[m] + lfar u[m]) is generated and, if
+ * |p|_inf <= box, appended (atomic counter, caller zeroes it) as pts[k] = p, rows[k] = q.  pts [>= in-box count, 3],
+ * rows [>= in-box count] int64, counter [1] uint64.  The caller evaluates the occupancy on pts only; every other row has
+ * occupancy 0 by the reference's own rule (alpha[~amask] = 0). */
+int psn_shadow_points(const float* surf, const float* ldir, int64_t n_surf, int n_lights, int n_steps, float lnear, float lfar,
+                      const float* u, const float* omu, float box, float* pts, int64_t* rows, unsigned long long* counter,
+                      void* stream);
+
 /* Fused secant refinement, stage1/model/rendering.py:525-555: n_iter regula-falsi iterations for every ray inside ONE
  * launch -- query point origin + d_pred * dir, its positional encoding (pe_octaves bands, input scaled by pe_scale), the
  * occupancy network (desc / packed_w / packed_b as for psn_mlp_infer: 256-wide, one output, PSN_OUT_OCC, input block =

@@ -219,3 +219,63 @@ extern "C" int psn_first_crossing(const float* occ, const float* far, const floa
     PSN_CHECK_LAUNCH("first_crossing");
     return PSN_OK;
 }
+
+// ---- shadow-ray sample points inside the object box (stage1/model/rendering.py:378-408) ------------------------------
+// light_visibility evaluates the occupancy network on n_steps points of every (light, surface point) ray and then sets
+// the occupancy of the points outside the [-box, box]^3 cube to zero.  Those points need no network evaluation at all:
+// this kernel generates p = surf[s] + ldir[l] * d[m] (the reference's op order), tests the cube, and COMPACTS the rows
+// that are inside (wave ballot + one atomic per wave) into pts [k, 3] with their dense row number rows[k] = (l ns + s)
+// n_steps + m.  For an object of radius ~0.6 in the 1.1 cube about a quarter of the 128 samples of a ray survive, so
+// the shadow-ray pass of shape_extract does ~4x fewer network rows with bit-identical visibility (the rows left out
+// contribute alpha = 0 to the composite exactly as in the reference).  Order of the compacted rows is not deterministic;
+// the value of every row is.
+namespace psn {
+__global__ __launch_bounds__(256) void shadow_points_kernel(const float* __restrict__ surf, const float* __restrict__ ldir,
+                                                            int64_t ns, int nl, int S, float lnear, float lfar,
+                                                            const float* __restrict__ u, const float* __restrict__ omu, float box,
+                                                            float* __restrict__ pts, int64_t* __restrict__ rows,
+                                                            unsigned long long* __restrict__ counter) {
+    const int64_t total = (int64_t)nl * ns * S;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool inside = false;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (e < total) {
+        const int m = (int)(e % S);
+        const int64_t ray = e / S;
+        const int64_t sidx = ray % ns;
+        const int l = (int)(ray / ns);
+        const float d = lnear * omu[m] + lfar * u[m];
+        px = surf[sidx * 3 + 0] + ldir[l * 3 + 0] * d;
+        py = surf[sidx * 3 + 1] + ldir[l * 3 + 1] * d;
+        pz = surf[sidx * 3 + 2] + ldir[l * 3 + 2] * d;
+        inside = px <= box && py <= box && pz <= box && px >= -box && py >= -box && pz >= -box;
+    }
+    const unsigned long long bal = __ballot(inside);
+    const int lane = threadIdx.x & 63;
+    const int cnt = __popcll(bal);
+    unsigned long long base = 0;
+    if (lane == 0 && cnt > 0) base = atomicAdd(counter, (unsigned long long)cnt);
+    base = __shfl(base, 0);
+    if (inside) {
+        const unsigned long long k = base + __popcll(bal & ((1ull << lane) - 1ull));
+        pts[k * 3 + 0] = px; pts[k * 3 + 1] = py; pts[k * 3 + 2] = pz;
+        rows[k] = e;
+    }
+}
+}  // namespace psn
+
+extern "C" int psn_shadow_points(const float* surf, const float* ldir, int64_t n_surf, int n_lights, int n_steps, float lnear,
+                                 float lfar, const float* u, const float* omu, float box, float* pts, int64_t* rows,
+                                 unsigned long long* counter, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(surf && ldir && u && omu && pts && rows && counter, "shadow_points: null pointer");
+    PSN_CHECK_ARG(n_steps >= 1 && n_lights >= 0 && n_surf >= 0, "shadow_points: bad sizes");
+    const int64_t total = (int64_t)n_lights * n_surf * n_steps;
+    if (total <= 0) return PSN_OK;
+    const int64_t blocks = (total + 255) / 256;
+    PSN_CHECK_ARG(blocks < (1ll << 31), "shadow_points: too many samples per call");
+    hipLaunchKernelGGL(shadow_points_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, surf, ldir, n_surf, n_lights,
+                       n_steps, lnear, lfar, u, omu, box, pts, rows, counter);
+    PSN_CHECK_LAUNCH("shadow_points");
+    return PSN_OK;
+}

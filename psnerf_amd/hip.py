@@ -100,6 +100,7 @@ SIGNATURES = {
     'psn_gather_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_secant_step': (i32, [c_f, f32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, c_f]),
     'psn_first_crossing': (i32, [c_f, c_f, c_f, c_f, f32, f32, i64, i32, c_f, c_f, c_f]),
+    'psn_shadow_points': (i32, [c_f, c_f, i64, i32, i32, f32, f32, c_f, c_f, f32, c_f, c_f, c_f, c_f]),
     'psn_root_find': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, i64, f32, i32, i32, f32, c_f, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
@@ -294,6 +295,20 @@ def first_crossing(occ, far, u, omu, near, tau):
     _check(_lib.psn_first_crossing(_ptr(occ, 'occ'), _ptr(far, 'far'), _ptr(u, 'u'), _ptr(omu, 'omu'), float(near), float(tau),
                                    N, M, bracket.data_ptr(), flags.data_ptr(), _stream()), 'first_crossing')
     return bracket, flags
+
+
+def shadow_points(surf, ldir, n_steps, lnear, lfar, u, omu, box):
+    """In-box shadow-ray sample points (psn_shadow_points) -> (pts [cap,3], rows [cap] int64, counter [1] int64 on the
+    device: the number of valid leading entries).  cap = all L*Ns*n_steps rows (worst case)."""
+    L, Ns = ldir.shape[0], surf.shape[0]
+    cap = L * Ns * n_steps
+    pts = torch.empty(max(cap, 1), 3, device=surf.device, dtype=torch.float32)
+    rows = torch.empty(max(cap, 1), device=surf.device, dtype=torch.int64)
+    counter = torch.zeros(1, device=surf.device, dtype=torch.int64)
+    _check(_lib.psn_shadow_points(_ptr(surf, 'surf'), _ptr(ldir, 'ldir'), Ns, L, int(n_steps), float(lnear), float(lfar),
+                                  _ptr(u, 'u'), _ptr(omu, 'omu'), float(box), pts.data_ptr(), rows.data_ptr(), counter.data_ptr(),
+                                  _stream()), 'shadow_points')
+    return pts, rows, counter
 
 
 def root_find(desc, packed_w, packed_b, origin, direction, bracket, tau, n_iter, pe_octaves, pe_scale):

@@ -310,17 +310,24 @@ class Renderer(nn.Module):
         """Shadow-ray transmittance from every surface point toward every light: 1 - acc, [L*Ns]."""
         dev = surf.device
         L, Ns = light_dir.shape[0], surf.shape[0]
-        t = torch.linspace(0, 1, steps=n_steps, device=dev).view(1, n_steps, 1)
-        d = lnear * (1.0 - t) + lfar * t
+        surf = surf.contiguous()
+        u = self._u(n_steps, dev)
         per_light = Ns * n_steps
-        lights_per_chunk = max(1, MAX_QUERY_ROWS // max(per_light, 1))
+        # Dense rows per launch group: the 12-byte points and 8-byte row numbers of the worst case (every sample inside
+        # the box); the 256-byte encodings are only built for the rows that survive the box test.
+        lights_per_chunk = max(1, (4 * MAX_QUERY_ROWS) // max(per_light, 1))
         outs = []
         for l0 in range(0, L, lights_per_chunk):
-            ld = light_dir[l0:l0 + lights_per_chunk]
-            p = surf[None, :, None, :] + ld[:, None, None, :] * d[None]  # [l, Ns, S, 3]
-            alpha = self._occ(p.reshape(-1, 3)).view(-1, n_steps)
-            inside = torch.logical_and((p <= 1.1).all(dim=-1), (p >= -1.1).all(dim=-1)).view(-1, n_steps)
-            alpha = torch.where(inside, alpha, torch.zeros_like(alpha)).contiguous()
-            _, _, acc = hip.composite_fwd(alpha, None, False, need_weights=False)
+            ld = light_dir[l0:l0 + lights_per_chunk].contiguous()
+            n_rays = ld.shape[0] * Ns
+            # points of the samples that lie inside the +-1.1 box, compacted (csrc/sample.hip): the others have
+            # occupancy 0 by rendering.py:400-401 and never reach the network
+            pts, rows, counter = hip.shadow_points(surf, ld, n_steps, lnear, lfar, u[0], u[1], 1.1)
+            n_in = int(counter.item())  # one synchronisation per launch group (this is the extraction path, not training)
+            alpha = torch.zeros(n_rays * n_steps, device=dev)
+            if n_in > 0:
+                alpha.index_copy_(0, rows[:n_in], self._occ(pts[:n_in]).reshape(-1))
+            _, _, acc = hip.composite_fwd(alpha.view(n_rays, n_steps), None, False, need_weights=False)
             outs.append(1 - acc)
+            self.last_shadow_stats = (n_in, n_rays * n_steps)
         return torch.cat(outs, 0)
