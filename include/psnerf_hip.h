@@ -283,6 +283,41 @@ int psn_root_find(const PsnMlpDesc* desc, const float* packed_w, const float* pa
                   void* stream);
 
 /* ------------------------------------------------------------------------
+ * Stage-2 losses, stage2/model/loss.py:27-58,76-92 (MainLoss) and :123-141 (NormalLoss), over the dense outputs of the
+ * model with mask = mask_a & mask_b (network_object_mask & object_mask, bool [N]):
+ *   term 0  rgb        sum |rgb - rgb_gt| (l2 = 0) or squared (l2 = 1) over [L, N, 3]
+ *   term 1  albedo     sum |alb - alb_j| over [N, 3]              term 2  SG weights  sum |wgt - wgt_j| over [N, nb]
+ *   term 3  visibility sum |vis[v, n, 0] - vis_gt[v, n]| (or squared) over [V, N]   (vis is [V, N, 3])
+ *   term 4  normal     sum (nrm - normalize(nrm_gt))^2 over [N, 3]   term 5  normal smoothness  sum |nrm - nrm_j|
+ * A term whose first pointer is NULL is skipped (0).  out[i] = sum_i * inv_denom[i] (i < 6), out[6] = sum_i weight[i] out[i];
+ * inv_denom, weight: HOST arrays [6] (passed by value).  partial: device workspace of >= 2048 * 6 floats.  Deterministic
+ * summation order.
+ * psn_stage2_loss_bwd writes d(out[6]) / d(input) * g_total[0] for every non-NULL d_* (k_i = weight_i * inv_denom_i on the
+ * host); masked-out pixels get zeros; d_vis channels 1, 2 are zero. */
+int psn_stage2_loss_fwd(const float* rgb, const float* rgb_gt, int L, const float* alb, const float* alb_j, const float* wgt,
+                        const float* wgt_j, int nb, const float* vis, const float* vis_gt, int V, const float* nrm,
+                        const float* nrm_gt, const float* nrm_j, const unsigned char* mask_a, const unsigned char* mask_b,
+                        int64_t N, int l2, const float* inv_denom, const float* weight, float* partial, float* out, void* stream);
+int psn_stage2_loss_bwd(const float* g_total, const float* rgb, const float* rgb_gt, int L, float k_rgb, float* d_rgb,
+                        const float* alb, const float* alb_j, float k_alb, float* d_alb, float* d_alb_j, const float* wgt,
+                        const float* wgt_j, int nb, float k_wgt, float* d_wgt, float* d_wgt_j, const float* vis, const float* vis_gt,
+                        int V, float k_vis, float* d_vis, const float* nrm, const float* nrm_gt, const float* nrm_j, float k_nrm,
+                        float k_nrmj, float* d_nrm, float* d_nrm_j, const unsigned char* mask_a, const unsigned char* mask_b,
+                        int64_t N, int l2, void* stream);
+
+/* torch.optim.SparseAdam on the touched rows of up to PSN_ROW_ADAM_MAX tables in one launch (the per-light direction
+ * [n, 3] and intensity [n, 1] embeddings, stage2/trainer.py:126-168): rows listed in idx [n_idx] int64 (duplicates
+ * allowed) advance their moments and move by -step_size m / (sqrt(v) + eps), step_size = lr sqrt(1 - b2^t) / (1 - b1^t)
+ * computed by the caller; all other rows and their moments stay untouched.  grad is the DENSE gradient [rows, cols]. */
+#define PSN_ROW_ADAM_MAX 4
+typedef struct {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t rows; int cols;
+    float one_minus_beta1, one_minus_beta2, eps, step_size;  /* 1 - beta computed in double by the caller, like torch */
+} PsnRowAdamItem;
+int psn_row_adam(int n_items, const PsnRowAdamItem* items, const int64_t* idx, int n_idx, void* stream);
+
+/* ------------------------------------------------------------------------
  * Weight normalisation of up to PSN_WN_MAX_ITEMS layers in one launch: nn.utils.weight_norm(nn.Linear) as used by every
  * layer of stage1/model/network.py:37-66 (state_dict keys weight_g [rows,1], weight_v [rows,cols]).
  *   fwd: w = v * (g / |v|_row) [* scale]       (scale = 1/sqrt(2) folds the cat[x, pe]/sqrt(2) of network.py:90-91)

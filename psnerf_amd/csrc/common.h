@@ -26,6 +26,13 @@ void set_error(const char* fmt, ...);
         }                                                                        \
     } while (0)
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + barrier and its workgroup-scope release is
+// lowered to `s_waitcnt vmcnt(0) lgkmcnt(0)`: every barrier then also waits for all of the wave's outstanding GLOBAL
+// loads and stores -- which defeats any prefetch that is meant to stay in flight across a k-tile (gemm_tn256: the rows
+// of tile t + 3) or dump stores that should drain under the next layer (chain engine).  Use this when the barrier only
+// publishes LDS writes / retires LDS reads; data hand-offs through global memory still need __syncthreads().
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
         __builtin_amdgcn_sched_barrier(0);                                                       \
         T_PAIR(T, S, 0) T_PAIR(T, S, 1) T_PAIR(T, S, 2) T_PAIR(T, S, 3)                          \
         T_PAIR(T, S, 4) T_PAIR(T, S, 5) T_PAIR(T, S, 6) T_PAIR(T, S, 7)                          \
-        __syncthreads();                                                                         \
+        lds_barrier(); /* NOT __syncthreads(): the operand rows of tile T + 3 stay in flight across the barrier */ \
     }
 #define T_PAIR(T, S, J)                                                                          \
     {                                                                                            \

@@ -1,0 +1,273 @@
+// Stage-2 losses in two launches forward and one backward (stage2/model/loss.py:27-58,76-92,123-141):
+//   rgb:      mean over masked pixels, lights, channels of |rgb - gt| (L1) or (rgb - gt)^2 (L2)
+//   albedo / SG-weight smoothness: mean |x - x_jitter|          visibility: mean |vis_train[..., 0] - vis_gt| (or ^2)
+//   normal:   mean (n_pred - normalize(n_stage1))^2             normal smoothness: mean |n_pred - n_jitter|
+// with mask = network_object_mask & object_mask and count = number of masked pixels (summed over ranks by the caller).
+// The torch formulation is ~35 elementwise / reduction launches forward and ~40 backward on [L, N, 3] tensors that are
+// each a few MB -- all latency-bound; here every dense tensor is read once and every gradient written once.
+// HBM-bound: forward reads 24 L + ~300 B per pixel, backward writes 12 L + ~150 B per pixel.
+#include "common.h"
+
+namespace psn {
+
+struct LossArgs {
+    const float* rgb; const float* rgb_gt; int L;          // [L, N, 3]
+    const float* alb; const float* alb_j;                  // [N, 3] or null
+    const float* wgt; const float* wgt_j; int nb;          // [N, nb] or null
+    const float* vis; const float* vis_gt; int V;          // vis [V, N, 3] (channel 0), gt [V, N]; or null
+    const float* nrm; const float* nrm_gt; const float* nrm_j;  // [N, 3]; nrm_gt is normalised here; nrm / nrm_j may be null
+    const unsigned char* mask_a; const unsigned char* mask_b;   // [N] bool each
+    int64_t N;
+    int l2;                                                // image / visibility loss: 0 = L1, 1 = L2
+    float* partial;                                        // [blocks, 6]
+    // backward
+    const float* g_total;                                  // [1] upstream gradient of the weighted total
+    float k_rgb, k_alb, k_wgt, k_vis, k_nrm, k_nrmj;       // weight_i / denominator_i
+    float* d_rgb; float* d_alb; float* d_alb_j; float* d_wgt; float* d_wgt_j; float* d_vis; float* d_nrm; float* d_nrm_j;
+};
+
+__device__ __forceinline__ float img_term(float a, float b, int l2) { const float d = a - b; return l2 ? d * d : fabsf(d); }
+__device__ __forceinline__ float img_grad(float a, float b, int l2) {
+    const float d = a - b;
+    return l2 ? 2.0f * d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f));
+}
+
+__global__ __launch_bounds__(256) void stage2_loss_fwd_kernel(LossArgs a) {
+    // blockIdx.y selects a chunk of lights for the [L, N, 3] term (enough independent loads in flight to stream it);
+    // the per-pixel terms are computed by chunk 0 only
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int lc = (a.L + gridDim.y - 1) / gridDim.y;
+    const int l0 = blockIdx.y * lc, l1 = min(a.L, l0 + lc);
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < a.N; n += (int64_t)gridDim.x * 256) {
+        if (!(a.mask_a[n] && a.mask_b[n])) continue;
+        if (a.rgb != nullptr) {
+#pragma unroll 4
+            for (int l = l0; l < l1; ++l) {
+                const float* p = a.rgb + ((int64_t)l * a.N + n) * 3;
+                const float* q = a.rgb_gt + ((int64_t)l * a.N + n) * 3;
+                s[0] += img_term(p[0], q[0], a.l2) + img_term(p[1], q[1], a.l2) + img_term(p[2], q[2], a.l2);
+            }
+        }
+        if (blockIdx.y != 0) continue;
+        if (a.alb != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s[1] += fabsf(a.alb[n * 3 + c] - a.alb_j[n * 3 + c]);
+        }
+        if (a.wgt != nullptr) {
+            for (int k = 0; k < a.nb; ++k) s[2] += fabsf(a.wgt[n * a.nb + k] - a.wgt_j[n * a.nb + k]);
+        }
+        if (a.vis != nullptr) {
+            for (int v = 0; v < a.V; ++v) s[3] += img_term(a.vis[((int64_t)v * a.N + n) * 3], a.vis_gt[(int64_t)v * a.N + n], a.l2);
+        }
+        if (a.nrm != nullptr) {
+            const float gx = a.nrm_gt[n * 3], gy = a.nrm_gt[n * 3 + 1], gz = a.nrm_gt[n * 3 + 2];
+            const float inv = 1.0f / fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize(dim=-1)
+            const float dx = a.nrm[n * 3] - gx * inv, dy = a.nrm[n * 3 + 1] - gy * inv, dz = a.nrm[n * 3 + 2] - gz * inv;
+            s[4] += dx * dx + dy * dy + dz * dz;
+            if (a.nrm_j != nullptr) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) s[5] += fabsf(a.nrm[n * 3 + c] - a.nrm_j[n * 3 + c]);
+            }
+        }
+    }
+    __shared__ float red[4][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float v = s[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+        a.partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// out[0..5] = term_i = sum_i / denom_i, out[6] = sum_i weight_i term_i   (fixed summation order: deterministic)
+struct LossScale { float inv_denom[6]; float weight[6]; };
+__global__ __launch_bounds__(64) void stage2_loss_final_kernel(const float* __restrict__ partial, int blocks, LossScale sc,
+                                                               float* __restrict__ out) {
+    const int i = threadIdx.x;
+    float term = 0.f;
+    if (i < 6) {
+        float s = 0.f;
+        for (int b = 0; b < blocks; ++b) s += partial[(int64_t)b * 6 + i];
+        term = s * sc.inv_denom[i];
+        out[i] = term;
+    }
+    float w = i < 6 ? sc.weight[i] * term : 0.f;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+    if (i == 0) out[6] = w;
+}
+
+__global__ __launch_bounds__(256) void stage2_loss_bwd_kernel(LossArgs a) {
+    const float g = a.g_total[0];
+    const int lc = (a.L + gridDim.y - 1) / gridDim.y;
+    const int l0 = blockIdx.y * lc, l1 = min(a.L, l0 + lc);
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < a.N; n += (int64_t)gridDim.x * 256) {
+        const bool m = a.mask_a[n] && a.mask_b[n];
+        if (a.d_rgb != nullptr) {
+            const float k = g * a.k_rgb;
+#pragma unroll 4
+            for (int l = l0; l < l1; ++l) {
+                const int64_t o = ((int64_t)l * a.N + n) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.d_rgb[o + c] = m ? k * img_grad(a.rgb[o + c], a.rgb_gt[o + c], a.l2) : 0.f;
+            }
+        }
+        if (blockIdx.y != 0) continue;
+        if (a.d_alb != nullptr) {
+            const float k = g * a.k_alb;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = m ? k * img_grad(a.alb[n * 3 + c], a.alb_j[n * 3 + c], 0) : 0.f;
+                a.d_alb[n * 3 + c] = v;
+                a.d_alb_j[n * 3 + c] = -v;
+            }
+        }
+        if (a.d_wgt != nullptr) {
+            const float k = g * a.k_wgt;
+            for (int q = 0; q < a.nb; ++q) {
+                const float v = m ? k * img_grad(a.wgt[n * a.nb + q], a.wgt_j[n * a.nb + q], 0) : 0.f;
+                a.d_wgt[n * a.nb + q] = v;
+                a.d_wgt_j[n * a.nb + q] = -v;
+            }
+        }
+        if (a.d_vis != nullptr) {
+            const float k = g * a.k_vis;
+            for (int v = 0; v < a.V; ++v) {
+                const int64_t o = ((int64_t)v * a.N + n) * 3;
+                a.d_vis[o] = m ? k * img_grad(a.vis[o], a.vis_gt[(int64_t)v * a.N + n], a.l2) : 0.f;
+                a.d_vis[o + 1] = 0.f;
+                a.d_vis[o + 2] = 0.f;
+            }
+        }
+        if (a.d_nrm != nullptr) {
+            float gn[3] = {0.f, 0.f, 0.f}, gj[3] = {0.f, 0.f, 0.f};
+            if (m) {
+                const float gx = a.nrm_gt[n * 3], gy = a.nrm_gt[n * 3 + 1], gz = a.nrm_gt[n * 3 + 2];
+                const float inv = 1.0f / fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
+                const float t[3] = {gx * inv, gy * inv, gz * inv};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gn[c] = g * a.k_nrm * 2.0f * (a.nrm[n * 3 + c] - t[c]);
+                if (a.nrm_j != nullptr) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = g * a.k_nrmj * img_grad(a.nrm[n * 3 + c], a.nrm_j[n * 3 + c], 0);
+                        gn[c] += v;
+                        gj[c] = -v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a.d_nrm[n * 3 + c] = gn[c];
+                if (a.d_nrm_j != nullptr) a.d_nrm_j[n * 3 + c] = gj[c];
+            }
+        }
+    }
+}
+
+constexpr int kLossBlocksX = 256, kLossChunksY = 8;  // partial: [kLossBlocksX * kLossChunksY, 6] floats at most
+
+}  // namespace psn
+
+extern "C" int psn_stage2_loss_fwd(const float* rgb, const float* rgb_gt, int L, const float* alb, const float* alb_j,
+                                   const float* wgt, const float* wgt_j, int nb, const float* vis, const float* vis_gt, int V,
+                                   const float* nrm, const float* nrm_gt, const float* nrm_j, const unsigned char* mask_a,
+                                   const unsigned char* mask_b, int64_t N, int l2, const float* inv_denom, const float* weight,
+                                   float* partial, float* out, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(mask_a && mask_b && partial && out && inv_denom && weight, "stage2_loss_fwd: null pointer");
+    PSN_CHECK_ARG((rgb == nullptr || rgb_gt) && (alb == nullptr || alb_j) && (wgt == nullptr || (wgt_j && nb > 0)) &&
+                  (vis == nullptr || vis_gt) && (nrm == nullptr || nrm_gt), "stage2_loss_fwd: incomplete term");
+    LossArgs a = {};
+    a.rgb = rgb; a.rgb_gt = rgb_gt; a.L = L; a.alb = alb; a.alb_j = alb_j; a.wgt = wgt; a.wgt_j = wgt_j; a.nb = nb;
+    a.vis = vis; a.vis_gt = vis_gt; a.V = V; a.nrm = nrm; a.nrm_gt = nrm_gt; a.nrm_j = nrm_j; a.mask_a = mask_a; a.mask_b = mask_b;
+    a.N = N; a.l2 = l2; a.partial = partial;
+    int bx = (int)((N + 255) / 256);
+    if (bx > kLossBlocksX) bx = kLossBlocksX;
+    if (bx < 1) bx = 1;
+    const int by = (rgb != nullptr && L >= 2 * kLossChunksY) ? kLossChunksY : 1;
+    hipLaunchKernelGGL(stage2_loss_fwd_kernel, dim3(bx, by), dim3(256), 0, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("stage2_loss_fwd");
+    LossScale sc;
+    for (int i = 0; i < 6; ++i) { sc.inv_denom[i] = inv_denom[i]; sc.weight[i] = weight[i]; }
+    hipLaunchKernelGGL(stage2_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, bx * by, sc, out);
+    PSN_CHECK_LAUNCH("stage2_loss_fwd (final)");
+    return PSN_OK;
+}
+
+extern "C" int psn_stage2_loss_bwd(const float* g_total, const float* rgb, const float* rgb_gt, int L, float k_rgb, float* d_rgb,
+                                   const float* alb, const float* alb_j, float k_alb, float* d_alb, float* d_alb_j,
+                                   const float* wgt, const float* wgt_j, int nb, float k_wgt, float* d_wgt, float* d_wgt_j,
+                                   const float* vis, const float* vis_gt, int V, float k_vis, float* d_vis,
+                                   const float* nrm, const float* nrm_gt, const float* nrm_j, float k_nrm, float k_nrmj, float* d_nrm,
+                                   float* d_nrm_j, const unsigned char* mask_a, const unsigned char* mask_b, int64_t N, int l2,
+                                   void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(g_total && mask_a && mask_b, "stage2_loss_bwd: null pointer");
+    LossArgs a = {};
+    a.g_total = g_total; a.rgb = rgb; a.rgb_gt = rgb_gt; a.L = L; a.k_rgb = k_rgb; a.d_rgb = d_rgb;
+    a.alb = alb; a.alb_j = alb_j; a.k_alb = k_alb; a.d_alb = d_alb; a.d_alb_j = d_alb_j;
+    a.wgt = wgt; a.wgt_j = wgt_j; a.nb = nb; a.k_wgt = k_wgt; a.d_wgt = d_wgt; a.d_wgt_j = d_wgt_j;
+    a.vis = vis; a.vis_gt = vis_gt; a.V = V; a.k_vis = k_vis; a.d_vis = d_vis;
+    a.nrm = nrm; a.nrm_gt = nrm_gt; a.nrm_j = nrm_j; a.k_nrm = k_nrm; a.k_nrmj = k_nrmj; a.d_nrm = d_nrm; a.d_nrm_j = d_nrm_j;
+    a.mask_a = mask_a; a.mask_b = mask_b; a.N = N; a.l2 = l2;
+    PSN_CHECK_ARG((d_rgb == nullptr || (rgb && rgb_gt)) && (d_alb == nullptr || (alb && alb_j && d_alb_j)) &&
+                  (d_wgt == nullptr || (wgt && wgt_j && d_wgt_j)) && (d_vis == nullptr || (vis && vis_gt)) &&
+                  (d_nrm == nullptr || (nrm && nrm_gt)), "stage2_loss_bwd: incomplete term");
+    if (N <= 0) return PSN_OK;
+    int64_t blocks = (N + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    const int by = (d_rgb != nullptr && L >= 2 * kLossChunksY) ? kLossChunksY : 1;
+    hipLaunchKernelGGL(stage2_loss_bwd_kernel, dim3((unsigned)blocks, by), dim3(256), 0, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("stage2_loss_bwd");
+    return PSN_OK;
+}
+
+// ---- SparseAdam on the rows of the per-light tables (stage2/trainer.py:126-168, torch.optim.SparseAdam) ------------
+// One thread per table row: the row moves iff it is among idx[0..n_idx) (the lights of this step; duplicates allowed),
+// with torch's sparse_adam arithmetic: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); p += -step_size m / (sqrt(v) + eps).
+namespace psn {
+struct RowAdamArgs { PsnRowAdamItem it[PSN_ROW_ADAM_MAX]; const int64_t* idx; int n_idx; int n; };
+__global__ __launch_bounds__(256) void row_adam_kernel(RowAdamArgs a) {
+    const int item = blockIdx.y;
+    if (item >= a.n) return;
+    const PsnRowAdamItem it = a.it[item];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= it.rows) return;
+    bool touched = false;
+    for (int i = 0; i < a.n_idx; ++i) touched = touched || a.idx[i] == r;
+    if (!touched) return;
+    for (int c = 0; c < it.cols; ++c) {
+        const int64_t e = r * it.cols + c;
+        const float g = it.grad[e];
+        float m = it.exp_avg[e], v = it.exp_avg_sq[e];
+        m += (g - m) * it.one_minus_beta1;
+        v += (g * g - v) * it.one_minus_beta2;
+        it.exp_avg[e] = m;
+        it.exp_avg_sq[e] = v;
+        it.param[e] += (m / (sqrtf(v) + it.eps)) * (-it.step_size);
+    }
+}
+}  // namespace psn
+
+extern "C" int psn_row_adam(int n_items, const PsnRowAdamItem* items, const int64_t* idx, int n_idx, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(items && idx && n_items >= 1 && n_items <= PSN_ROW_ADAM_MAX && n_idx >= 0, "row_adam: bad arguments");
+    RowAdamArgs a = {};
+    int64_t max_rows = 0;
+    for (int i = 0; i < n_items; ++i) {
+        PSN_CHECK_ARG(items[i].param && items[i].grad && items[i].exp_avg && items[i].exp_avg_sq && items[i].rows >= 0 && items[i].cols >= 1,
+                      "row_adam: item %d", i);
+        a.it[i] = items[i];
+        if (items[i].rows > max_rows) max_rows = items[i].rows;
+    }
+    a.idx = idx; a.n_idx = n_idx; a.n = n_items;
+    if (max_rows <= 0 || n_idx == 0) return PSN_OK;
+    hipLaunchKernelGGL(row_adam_kernel, dim3((unsigned)((max_rows + 255) / 256), n_items), dim3(256), 0, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("row_adam");
+    return PSN_OK;
+}

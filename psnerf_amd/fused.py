@@ -65,6 +65,22 @@ def _pad_vec(b, n):
     return torch.nn.functional.pad(b, (0, n - b.shape[0])) if b.shape[0] < n else b
 
 
+_ZEROS = {}
+
+
+def _zeros(shape, device):
+    """Cached constant zeros (never written): the backward chains are re-packed every step and would otherwise pay a
+    fill launch per dummy bias / init block."""
+    key = (tuple(shape) if not isinstance(shape, int) else (shape,), str(device))
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(*key[0], device=device)
+    return z
+
+
+DIRECT_INIT = 'direct'  # layer spec init_a=DIRECT_INIT: the init table is supplied by the caller at call time (no weights)
+
+
 class Transposed(object):
     """Marker for pack_layers: use the transpose of ``w`` (backward chains) without materialising it."""
 
@@ -97,6 +113,7 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     assert len(layers) <= hip.MAX_LAYERS
     plan, biases = [], []
     init_wa, init_wb, init_bias = [], [], []
+    direct_init_off = None
     off = b_off = 0
     for li, L in enumerate(layers):
         last = has_final and li == len(layers) - 1
@@ -105,7 +122,11 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
         lay = desc.layers[li]
         lay.init_off = -1
         bias = _pad_vec(L['bias'].detach().float(), rows)
-        if L.get('init_a') is not None:
+        if isinstance(L.get('init_a'), str) and L['init_a'] == DIRECT_INIT:
+            assert not last and not init_wa and direct_init_off is None
+            lay.init_off = 0
+            direct_init_off = 0
+        elif L.get('init_a') is not None:
             assert not last
             lay.init_off = width * len(init_wa)
             init_wa.append(_pad_rows(_pad_cols(L['init_a'], in_kt_a * 32), width))
@@ -128,14 +149,17 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
         lay.n_kt_in, lay.n_kt_act, lay.n_mt, lay.act = n_kt_in, n_kt_act, n_mt, L['act']
         b_off += rows
     w_buf = torch.empty(max(off, 4), device=device, dtype=torch.float32)
-    b_buf = torch.cat(biases).contiguous()
+    if all(bv.data_ptr() == _zeros(bv.shape[0], device).data_ptr() for bv in biases):
+        b_buf = _zeros(sum(bv.shape[0] for bv in biases), device)  # all-zero biases of a backward chain
+    else:
+        b_buf = torch.cat(biases).contiguous()
     group = []
     for w, n_mt, k_tiles, o in plan:
         m, tr, r, c = _src(w)
         assert r <= n_mt * 32 and c <= k_tiles * 32, 'pack_layers: block %dx%d does not fit %dx%d' % (r, c, n_mt * 32, k_tiles * 32)
         group.append((m if m.dtype == torch.float32 else m.float(), tr, n_mt, k_tiles, w_buf[o:o + n_mt * k_tiles * 1024]))
     hip.mlp_pack_layers(group)  # every block of the network in one launch
-    desc.init_stride = width * len(init_wa)
+    desc.init_stride = width * len(init_wa) if direct_init_off is None else width
     if init_wa:
         pk = PackedMLP(desc, w_buf, b_buf, torch.cat(init_wa).contiguous().float(),
                        torch.cat(init_wb).contiguous().float() if init_wb else None,
@@ -280,14 +304,11 @@ def pack_relu_bwd(weights, skip_at, width=256):
     Returns a PackedMLP whose call needs init_a_direct, mask=[h_{n-2}, ..., h_0], save=[dz_{n-2}, ..., dz_0]."""
     n = len(weights)
     dev = weights[0].device
-    zeros = torch.zeros(width, device=dev)
-    layers = [dict(init_a=torch.zeros(width, 32, device=dev), init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
+    zeros = _zeros(width, dev)
+    layers = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
     for l in range(n - 2, 0, -1):  # forward layers n-2 .. 1 -> their transposed [in(256), out(256)] blocks
         layers.append(dict(w_act=Transposed(weights[l][:, :width]), bias=zeros, act=hip.ACT_RELU_MASK))
-    packed = pack_layers(layers, 1, 0, 0, hip.OUT_NONE, dev, has_final=False, width=width)
-    packed.init_wa = packed.init_wb = packed.init_bias = None  # the init table is always supplied by the caller
-    packed.desc.init_stride = width
-    return packed
+    return pack_layers(layers, 1, 0, 0, hip.OUT_NONE, dev, has_final=False, width=width)
 
 
 # --------------------------------------------------------------------------- stage-1 geometry-field chains
@@ -305,7 +326,7 @@ def pack_geo_chains(weights, biases, skips, d_pe):
     dev = weights[0].device
     W = [w.detach() for w in weights]
     b = [x.detach() for x in biases]
-    zeros = torch.zeros(256, device=dev)
+    zeros = _zeros(256, dev)
     ka = (d_pe + 31) // 32
     d_a = W[sk].shape[1] - d_pe  # width of the activation part of the skip layer's input (217)
 
@@ -323,13 +344,11 @@ def pack_geo_chains(weights, biases, skips, d_pe):
     fwd = pack_layers(layers, ka, 0, 1, hip.OUT_NONE, dev)
 
     # F2: reverse sweep r_l = (r_{l+1} * s_l) W_l, starting from row 0 of the last layer (init table with one row)
-    layers = [dict(init_a=torch.zeros(256, ka * 32, device=dev), init_b=None, w_act=None, bias=zeros, act=hip.ACT_MUL_AUX)]
+    layers = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=hip.ACT_MUL_AUX)]
     for l in range(n - 2, 0, -1):
         layers.append(dict(w_act=_t(W[l]), bias=zeros, act=hip.ACT_MUL_AUX))
     layers.append(dict(w_act=_t(W[0]), bias=zeros, act=hip.ACT_HEAD))
     sweep = pack_layers(layers, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
-    sweep.init_wa = sweep.init_wb = sweep.init_bias = None
-    sweep.desc.init_stride = 256
 
     # B1: adjoint of the sweep: du_l = dR_l W_l^T ; dR_{l+1} = du_l * s_l ; dS_l = du_l * R_{l+1}
     layers = [dict(bias=zeros, act=hip.ACT_MUL2, **fwd_in(l)) for l in range(n - 1)]
@@ -337,13 +356,10 @@ def pack_geo_chains(weights, biases, skips, d_pe):
 
     # B2: adjoint of the value pass: da_l = W_l^T dz_l ; dz_{l-1} = s (da + 100 dS (1 - s))   [or s * da without sweep]
     def value_bwd(act):
-        ls = [dict(init_a=torch.zeros(256, ka * 32, device=dev), init_b=None, w_act=_t(W[n - 1][1:]), bias=zeros, act=act)]
+        ls = [dict(init_a=DIRECT_INIT, init_b=None, w_act=_t(W[n - 1][1:]), bias=zeros, act=act)]
         for l in range(n - 2, 0, -1):
             ls.append(dict(w_act=_t(W[l]), bias=zeros, act=act))
-        pk = pack_layers(ls, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
-        pk.init_wa = pk.init_wb = pk.init_bias = None
-        pk.desc.init_stride = 256
-        return pk
+        return pack_layers(ls, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
 
     return dict(fwd=fwd, sweep=sweep, sweep_bwd=sweep_bwd, value_bwd=value_bwd(hip.ACT_SOFTPLUS_BWD),
                 value_bwd_nosweep=value_bwd(hip.ACT_MUL_AUX), d_a=d_a)
@@ -361,17 +377,15 @@ def pack_app_chains(weights, biases, d_x):
     b = [x.detach() for x in biases]
     assert W[0].shape[1] == d_x + 256 and all(w.shape == (256, 256) for w in W[1:n - 1]) and d_x <= 64
     ka = (d_x + 31) // 32
-    zeros = torch.zeros(256, device=dev)
+    zeros = _zeros(256, dev)
     layers = [dict(w_in=W[0][:, :d_x], w_act=W[0][:, d_x:], bias=b[0], act=hip.ACT_RELU)]
     for l in range(1, n - 1):
         layers.append(dict(w_in=None, w_act=W[l], bias=b[l], act=hip.ACT_RELU))
     layers.append(dict(w_in=None, w_act=W[n - 1], bias=b[n - 1], act=hip.ACT_NONE))
     fwd = pack_layers(layers, ka, 0, W[n - 1].shape[0], hip.OUT_NONE, dev)
-    ls = [dict(init_a=torch.zeros(256, ka * 32, device=dev), init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
+    ls = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
     for l in range(n - 2, 0, -1):
         ls.append(dict(w_act=_t(W[l]), bias=zeros, act=hip.ACT_RELU_MASK))
     ls.append(dict(w_act=_t(W[0][:, d_x:]), bias=zeros, act=hip.ACT_HEAD))
     bwd = pack_layers(ls, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
-    bwd.init_wa = bwd.init_wb = bwd.init_bias = None
-    bwd.desc.init_stride = 256
     return dict(fwd=fwd, bwd=bwd)

@@ -69,6 +69,11 @@ class PsnGemmTnItem(ctypes.Structure):
                 ('B_tab2', ctypes.c_void_p), ('ldb_tab2', i64), ('b2_div', i64), ('b2_mod', i64), ('b_split', i32)]
 
 
+class PsnRowAdamItem(ctypes.Structure):
+    _fields_ = [('param', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p), ('exp_avg_sq', ctypes.c_void_p),
+                ('rows', i64), ('cols', i32), ('one_minus_beta1', f32), ('one_minus_beta2', f32), ('eps', f32), ('step_size', f32)]
+
+
 MAX_GROUP = 12
 
 # every exported symbol of include/psnerf_hip.h with its signature
@@ -100,6 +105,11 @@ SIGNATURES = {
     'psn_gather_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_secant_step': (i32, [c_f, f32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, c_f]),
     'psn_first_crossing': (i32, [c_f, c_f, c_f, c_f, f32, f32, i64, i32, c_f, c_f, c_f]),
+    'psn_stage2_loss_fwd': (i32, [c_f, c_f, i32, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, i64, i32, c_f, c_f, c_f,
+                                  c_f, c_f]),
+    'psn_stage2_loss_bwd': (i32, [c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, f32, c_f, c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, c_f, i32, f32,
+                                  c_f, c_f, c_f, c_f, f32, f32, c_f, c_f, c_f, c_f, i64, i32, c_f]),
+    'psn_row_adam': (i32, [i32, ctypes.c_void_p, c_f, i32, c_f]),
     'psn_shadow_points': (i32, [c_f, c_f, i64, i32, i32, f32, f32, c_f, c_f, f32, c_f, c_f, c_f, c_f]),
     'psn_root_find': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, i64, f32, i32, i32, f32, c_f, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
@@ -295,6 +305,66 @@ def first_crossing(occ, far, u, omu, near, tau):
     _check(_lib.psn_first_crossing(_ptr(occ, 'occ'), _ptr(far, 'far'), _ptr(u, 'u'), _ptr(omu, 'omu'), float(near), float(tau),
                                    N, M, bracket.data_ptr(), flags.data_ptr(), _stream()), 'first_crossing')
     return bracket, flags
+
+
+def _fp(t):
+    return None if t is None else _ptr(t, 'loss tensor')
+
+
+def _bp(t):
+    assert t.is_cuda and t.dtype == torch.bool and t.is_contiguous()
+    return t.data_ptr()
+
+
+def stage2_loss_fwd(rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, l2, inv_denom, weight):
+    """Seven floats on the device: the six loss terms and their weighted total (psn_stage2_loss_fwd)."""
+    N = mask_a.numel()
+    out = torch.empty(7, device=mask_a.device, dtype=torch.float32)
+    partial = workspace(2048 * 6, mask_a.device)
+    _check(_lib.psn_stage2_loss_fwd(_fp(rgb), _fp(rgb_gt), 0 if rgb is None else rgb.shape[0], _fp(alb), _fp(alb_j), _fp(wgt), _fp(wgt_j),
+                                    0 if wgt is None else wgt.shape[-1], _fp(vis), _fp(vis_gt), 0 if vis is None else vis.shape[0],
+                                    _fp(nrm), _fp(nrm_gt), _fp(nrm_j), _bp(mask_a), _bp(mask_b), N, int(l2),
+                                    ctypes.cast((ctypes.c_float * 6)(*[float(x) for x in inv_denom]), ctypes.c_void_p),
+                                    ctypes.cast((ctypes.c_float * 6)(*[float(x) for x in weight]), ctypes.c_void_p),
+                                    partial.data_ptr(), out.data_ptr(), _stream()), 'stage2_loss_fwd')
+    return out
+
+
+def stage2_loss_bwd(g_total, rgb, rgb_gt, k_rgb, alb, alb_j, k_alb, wgt, wgt_j, k_wgt, vis, vis_gt, k_vis, nrm, nrm_gt, nrm_j, k_nrm,
+                    k_nrmj, mask_a, mask_b, l2, need):
+    """Gradients of the weighted total with respect to the tensors named in ``need`` (a set of 'rgb', 'alb', 'wgt', 'vis',
+    'nrm'); returns dict name -> gradient (alb / wgt / nrm also give the jitter gradients as name + '_j')."""
+    N = mask_a.numel()
+    new = lambda t: torch.empty_like(t)
+    d = {}
+    if 'rgb' in need: d['rgb'] = new(rgb)
+    if 'alb' in need: d['alb'], d['alb_j'] = new(alb), new(alb_j)
+    if 'wgt' in need: d['wgt'], d['wgt_j'] = new(wgt), new(wgt_j)
+    if 'vis' in need: d['vis'] = new(vis)
+    if 'nrm' in need:
+        d['nrm'] = new(nrm)
+        if nrm_j is not None:
+            d['nrm_j'] = new(nrm_j)
+    g = lambda k: None if k not in d else d[k].data_ptr()
+    _check(_lib.psn_stage2_loss_bwd(_ptr(g_total, 'g_total'), _fp(rgb), _fp(rgb_gt), 0 if rgb is None else rgb.shape[0], float(k_rgb), g('rgb'),
+                                    _fp(alb), _fp(alb_j), float(k_alb), g('alb'), g('alb_j'), _fp(wgt), _fp(wgt_j),
+                                    0 if wgt is None else wgt.shape[-1], float(k_wgt), g('wgt'), g('wgt_j'), _fp(vis), _fp(vis_gt),
+                                    0 if vis is None else vis.shape[0], float(k_vis), g('vis'), _fp(nrm), _fp(nrm_gt), _fp(nrm_j),
+                                    float(k_nrm), float(k_nrmj), g('nrm'), g('nrm_j'), _bp(mask_a), _bp(mask_b), N, int(l2), _stream()),
+           'stage2_loss_bwd')
+    return d
+
+
+def row_adam(items, idx):
+    """items: list of (param, grad, exp_avg, exp_avg_sq, beta1, beta2, eps, step_size) with dense [rows, cols] fp32 device
+    tensors; idx: int64 device tensor of the rows that move (psn_row_adam)."""
+    arr = (PsnRowAdamItem * len(items))()
+    for e, (p, g, m, v, b1, b2, eps, ss) in zip(arr, items):
+        p2 = p.view(p.shape[0], -1)
+        e.param, e.grad, e.exp_avg, e.exp_avg_sq = _ptr(p, 'param'), _ptr(g, 'grad'), _ptr(m, 'exp_avg'), _ptr(v, 'exp_avg_sq')
+        e.rows, e.cols, e.one_minus_beta1, e.one_minus_beta2, e.eps, e.step_size = p2.shape[0], p2.shape[1], 1 - b1, 1 - b2, eps, ss
+    assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()
+    _check(_lib.psn_row_adam(len(items), ctypes.addressof(arr), idx.data_ptr(), idx.numel(), _stream()), 'row_adam')
 
 
 def shadow_points(surf, ldir, n_steps, lnear, lfar, u, omu, box):

@@ -865,3 +865,42 @@ class FusedReluNet(torch.autograd.Function):
         for l in range(n):
             grads += [dW[l] if dWx[l] is None else torch.cat([dW[l], dWx[l]], dim=1), db[l]]
         return (None, None, None, None, None, None) + tuple(grads)
+
+
+# --------------------------------------------------------------------------- stage-2 losses, fused
+class Stage2Losses(torch.autograd.Function):
+    """MainLoss + NormalLoss of stage 2 (stage2/model/loss.py:27-92,123-141) over the dense model outputs in two launches
+    forward and one backward (csrc/loss.hip) instead of ~75 elementwise / reduction launches.
+    apply(rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, l2, inv_denom, weight)
+    -> (total (0-dim), terms [6] (no gradient)).  Tensors of inactive terms are None; inv_denom / weight: 6 floats."""
+
+    @staticmethod
+    def forward(ctx, rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, l2, inv_denom, weight):
+        c = lambda t: None if t is None else t.detach().contiguous()
+        ts = [c(t) for t in (rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j)]
+        ma, mb = mask_a.contiguous(), mask_b.contiguous()
+        out = hip.stage2_loss_fwd(*ts, ma, mb, l2, inv_denom, weight)
+        ctx.ts, ctx.masks, ctx.l2 = ts, (ma, mb), l2
+        ctx.k = [w * d for w, d in zip(weight, inv_denom)]
+        ctx.need = ctx.needs_input_grad
+        terms = out[:6]
+        ctx.mark_non_differentiable(terms)
+        return out[6], terms
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j = ctx.ts
+        k, ng = ctx.k, ctx.need
+        need = set()
+        if rgb is not None and ng[0] and k[0] != 0.0: need.add('rgb')
+        if alb is not None and (ng[2] or ng[3]) and k[1] != 0.0: need.add('alb')
+        if wgt is not None and (ng[4] or ng[5]) and k[2] != 0.0: need.add('wgt')
+        if vis is not None and ng[6] and k[3] != 0.0: need.add('vis')
+        if nrm is not None and (ng[8] or ng[10]) and (k[4] != 0.0 or k[5] != 0.0): need.add('nrm')
+        d = {}
+        if need:
+            d = hip.stage2_loss_bwd(g_total.reshape(1).contiguous(), rgb, rgb_gt, k[0], alb, alb_j, k[1], wgt, wgt_j, k[2], vis, vis_gt,
+                                    k[3], nrm, nrm_gt, nrm_j, k[4], k[5], ctx.masks[0], ctx.masks[1], ctx.l2, need)
+        g = d.get
+        return (g('rgb'), None, g('alb'), g('alb_j'), g('wgt'), g('wgt_j'), g('vis'), None, g('nrm'), None, g('nrm_j'),
+                None, None, None, None, None)

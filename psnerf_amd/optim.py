@@ -15,6 +15,33 @@ import torch
 
 
 class RowSparseAdam(torch.optim.Optimizer):
+    def _fused_step(self, rows):
+        """All tables in ONE launch (psn_row_adam, csrc/loss.hip) when every gradient is a dense fp32 device tensor;
+        the torch formulation below is ~14 elementwise launches per table."""
+        from . import hip
+        items = []
+        for group in self.param_groups:
+            b1, b2 = group['betas']
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    return False
+                state = self.state[p]
+                if len(state) == 0:
+                    state['step'] = 0
+                    state['exp_avg'] = torch.zeros_like(p)
+                    state['exp_avg_sq'] = torch.zeros_like(p)
+                t = int(state['step']) + 1
+                items.append((p, state, b1, b2, group['eps'], group['lr'] * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)))
+        if not items or len(items) > 4:
+            return False
+        for p, state, *_ in items:
+            state['step'] = int(state['step']) + 1
+        hip.row_adam([(p, p.grad, st['exp_avg'], st['exp_avg_sq'], b1, b2, eps, ss) for p, st, b1, b2, eps, ss in items],
+                     rows.contiguous())
+        return True
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, maximize=False):
         if not 0.0 < lr:
             raise ValueError('Invalid learning rate: %r' % (lr,))
@@ -26,6 +53,8 @@ class RowSparseAdam(torch.optim.Optimizer):
     def step(self, rows=None):
         """rows: 1-D index tensor of the table rows used by this step (duplicates allowed).  Required when the
         gradients are dense (nn.Embedding(sparse=False)); with sparse gradients the rows are their indices."""
+        if rows is not None and rows.is_cuda and self._fused_step(rows):
+            return
         for group in self.param_groups:
             beta1, beta2 = group['betas']
             for p in group['params']:

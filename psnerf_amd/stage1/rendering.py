@@ -93,7 +93,12 @@ class Renderer(nn.Module):
     def ray_marching(self, ray0, ray_direction, model=None, c=None, tau=0.5, n_steps=(128, 129), n_secant_steps=8,
                      depth_range=(25, 40), max_points=3500000, rad=1.0, clip=False):
         state = self._march_launch(ray0, ray_direction, tau, n_steps, depth_range, rad, clip)
-        return self._march_finish(state, n_secant_steps)
+        return self._finish(state, n_secant_steps)
+
+    COMPACT_SECANT = False  # True: the round-1 secant (host-synchronised compaction + per-iteration launches)
+
+    def _finish(self, state, n_secant_steps):
+        return self._march_finish_compact(state, n_secant_steps) if self.COMPACT_SECANT else self._march_finish(state, n_secant_steps)
 
     @torch.no_grad()
     def _march_launch(self, ray0, ray_direction, tau, n_steps, depth_range, rad, clip):
@@ -134,6 +139,32 @@ class Renderer(nn.Module):
         out = torch.where(mask, d_pred, torch.full_like(d_pred, float('inf')))
         out = torch.where(first_free, out, torch.zeros_like(out))
         return out.view(B, N)
+
+    @torch.no_grad()
+    def _march_finish_compact(self, st, n_secant_steps):
+        """The round-1 formulation of the second half, kept as a cross-check of the fused root finder (tests) and for
+        A/B timing: nonzero() compacts the rays with a crossing (a host synchronisation), then one encoding + network +
+        update launch per secant iteration on the compacted rays."""
+        ray0, ray_direction = st['ray0'], st['ray_direction']
+        B, N, _ = ray0.shape
+        dev = ray0.device
+        mask = (st['flags'] & 1).bool()
+        first_free = (st['flags'] & 2).bool()
+        mi = mask.nonzero(as_tuple=True)[0]
+        b = st['bracket'][:, mi]
+        d_low, d_high, f_low, f_high = (b[i].contiguous().clone() for i in range(4))
+        origin, direction = ray0.reshape(-1, 3)[mi].contiguous(), ray_direction.reshape(-1, 3)[mi].contiguous()
+        d_pred = torch.empty_like(d_low)
+        if mi.numel() > 0:
+            p_mid = torch.empty(d_low.shape[0], 3, device=dev)
+            hip.secant_step(None, st['tau'], d_pred, d_low, d_high, f_low, f_high, origin, direction, p_mid)
+            for i in range(n_secant_steps):
+                occ = self._occ(p_mid)[..., 0].contiguous()
+                hip.secant_step(occ, st['tau'], d_pred, d_low, d_high, f_low, f_high, origin, direction,
+                                p_mid if i + 1 < n_secant_steps else None)
+        out = torch.full((B * N,), float('inf'), device=dev)
+        out[mi] = d_pred
+        return torch.where(first_free, out, torch.zeros_like(out)).view(B, N)
 
     def _root_find(self, bracket, origin, direction, tau, n_iter):
         m = self.model
@@ -189,7 +220,7 @@ class Renderer(nn.Module):
             cam, rays, state = pref[2]  # requested earlier by prefetch_surface: the sweep is already running
         else:
             cam, rays, state = self._surface_launch(pixels, camera_mat, world_mat, ray_steps)
-        d_i = self._march_finish(state, 8)
+        d_i = self._finish(state, 8)
         zero_occ = d_i == 0
         ok = finite_mask(d_i)
         dists = torch.where(ok, d_i, torch.ones_like(d_i))

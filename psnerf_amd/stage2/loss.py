@@ -105,3 +105,53 @@ class NormalLoss(nn.Module):
                 (model_outputs['normal_pred'] - model_outputs['normal_jitter']).abs(), mask, count, 3)
             loss = loss + self.normal_smooth_weight * s_loss
         return {'loss': loss, 'normal_loss': n_loss, 'normal_smooth_loss': s_loss}
+
+
+def fused_losses(main, normal, model_outputs, ground_truth, model_input, count):
+    """MainLoss.forward + NormalLoss.forward (same branches, same dictionary keys) through ops.Stage2Losses: two launches
+    forward, one backward.  Returns (total loss, MainLoss-style dict, NormalLoss-style dict) or None when the fused path
+    does not apply (tensors not on the GPU, an output the kernels expect is missing): callers then use the modules."""
+    from .. import ops
+    o = model_outputs
+    need = ('sg_rgb_values', 'normal_pred', 'normal_values', 'network_object_mask', 'object_mask')
+    if any(k not in o for k in need) or not o['sg_rgb_values'].is_cuda or main.loss_type not in ('L1', 'L2'):
+        return None
+    ma, mb = o['network_object_mask'][0], o['object_mask'][0]
+    if ma.dtype != torch.bool or mb.dtype != torch.bool:
+        return None
+    rgb, rgb_gt = o['sg_rgb_values'], ground_truth['rgb'].to(o['sg_rgb_values'].device)
+    L, N = rgb.shape[0], rgb.shape[1]
+    alb = alb_j = wgt = wgt_j = vis = vis_gt = nrm_j = None
+    if 'albedo_jitter' in o and main.albedo_smooth_weight > 0:
+        alb, alb_j = o['albedo_values'], o['albedo_jitter']  # [1, N, 3]: the kernels read them as [N, 3]
+    if 'rough_jitter' in o and main.rough_smooth_weight > 0:
+        wgt, wgt_j = o['rough_values'], o['rough_jitter']
+    has_vis = 'visibility' in model_input and 'visibility' in o
+    if has_vis:  # loss.py:81-87
+        if 'vis_train_gt' in model_input and 'light_vis_train' in model_input and 'vis_train' in o:
+            vis, vis_gt = o['vis_train'], model_input['vis_train_gt']
+        elif 'light_vis_train' in model_input and 'vis_train' in o:
+            vis, vis_gt = o['vis_train'], model_input['visibility']
+        else:
+            vis, vis_gt = o['visibility'], model_input['visibility']
+        vis_gt = vis_gt.float()
+    nrm, nrm_gt = o['normal_pred'], o['normal_values']
+    if 'normal_jitter' in o and normal.normal_smooth_weight > 0:
+        nrm_j = o['normal_jitter']
+    c = float(max(count, 1))
+    nb = 1 if wgt is None else wgt.shape[-1]
+    V = 1 if vis is None else vis.shape[0]
+    inv = [1.0 / (c * L * 3), 1.0 / (c * 3), 1.0 / (c * nb), 1.0 / (c * V), 1.0 / (c * 3), 1.0 / (c * 3)]
+    if count == 0:
+        inv = [0.0] * 6  # the reference returns 0 for every term of an empty mask
+    w = [float(main.sg_rgb_weight), float(main.albedo_smooth_weight) if alb is not None else 0.0,
+         float(main.rough_smooth_weight) if wgt is not None else 0.0, float(main.vis_weight) if vis is not None else 0.0,
+         float(normal.normal_weight), float(normal.normal_smooth_weight) if nrm_j is not None else 0.0]
+    total, t = ops.Stage2Losses.apply(rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, ma, mb,
+                                      1 if main.loss_type == 'L2' else 0, inv, w)
+    terms = {'sg_rgb_loss': t[0], 'albedo_smooth_loss': t[1] if alb is not None else None,
+             'rough_smooth_loss': t[2] if wgt is not None else None, 'loss': total}
+    if has_vis:
+        terms['vis_loss'] = t[3]
+    terms_n = {'loss': total, 'normal_loss': t[4], 'normal_smooth_loss': t[5] if nrm_j is not None else None}
+    return total, terms, terms_n

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from ..dist import DataParallel
 from ..optim import RowSparseAdam
-from .loss import MainLoss, NormalLoss
+from .loss import MainLoss, NormalLoss, fused_losses
 
 
 class VisPlus(object):
@@ -44,6 +44,8 @@ class VisPlus(object):
 
 
 class TrainStep(object):
+    FUSED_LOSSES = True  # False: evaluate MainLoss / NormalLoss with the torch formulation (cross-check, other loss types)
+
     def __init__(self, model, conf, n_lights_total, light_init, device, milestones=(), dp=None, vis_plus=None):
         self.model, self.conf, self.device = model, conf, device
         # frozen copy of the initial light estimates = torch.cat(self.light_vis_train) of trainer.py:149,377
@@ -131,9 +133,14 @@ class TrainStep(object):
         # forward, losses and backward instead of stalling behind the 22 ms visibility launch.
         count = self.dp.global_count(model_input['surface_mask'] & model_input['object_mask'])
         out = self.model(model_input, noise=noise)
-        terms = dict(self.loss(out, ground_truth, model_input, count=count))
-        terms_n = self.loss_n(out, count=count)
-        loss = terms['loss'] + terms_n['loss']
+        fl = fused_losses(self.loss, self.loss_n, out, ground_truth, model_input, count) if self.FUSED_LOSSES else None
+        if fl is not None:  # both loss modules in two launches forward / one backward (csrc/loss.hip)
+            loss, terms, terms_n = fl
+            terms = dict(terms)
+        else:
+            terms = dict(self.loss(out, ground_truth, model_input, count=count))
+            terms_n = self.loss_n(out, count=count)
+            loss = terms['loss'] + terms_n['loss']
         train_light = self.light_para.weight.requires_grad
         if self.dp.enabled:
             trainable = [p for p in self.model.parameters() if p.requires_grad] \

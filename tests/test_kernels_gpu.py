@@ -545,3 +545,29 @@ def test_secant_step_matches_torch_formulation(cuda):
         assert torch.equal(d_pred, r_pred), it
         for k, t in (('d_low', d_low), ('d_high', d_high), ('f_low', f_low), ('f_high', f_high)):
             assert torch.equal(t, ref[k]), (it, k)
+
+
+def test_row_adam_kernel_matches_sparse_adam(cuda):
+    """psn_row_adam (one launch for both light tables) = torch.optim.SparseAdam on the touched rows, several steps with
+    changing row sets and duplicate rows; untouched rows and their moments do not move."""
+    from psnerf_amd.optim import RowSparseAdam
+    g = torch.Generator().manual_seed(0)
+    n = 50
+    w3, w1 = torch.randn(n, 3, generator=g), torch.randn(n, 1, generator=g)
+    ref3, ref1 = torch.nn.Embedding(n, 3, sparse=True), torch.nn.Embedding(n, 1, sparse=True)
+    a3, a1 = torch.nn.Embedding(n, 3).to(cuda), torch.nn.Embedding(n, 1).to(cuda)
+    ref3.weight.data.copy_(w3); ref1.weight.data.copy_(w1); a3.weight.data.copy_(w3); a1.weight.data.copy_(w1)
+    o_ref = torch.optim.SparseAdam([{'params': list(ref3.parameters())}, {'params': list(ref1.parameters()), 'lr': 1e-2}], lr=5e-3)
+    o_a = RowSparseAdam([{'params': list(a3.parameters())}, {'params': list(a1.parameters()), 'lr': 1e-2}], lr=5e-3)
+    for it in range(5):
+        rows = torch.randint(0, n, (9,), generator=g)
+        c3, c1 = torch.randn(9, 3, generator=g), torch.randn(9, 1, generator=g)
+        o_ref.zero_grad(); o_a.zero_grad()
+        ((ref3(rows) * c3).sum() + (ref1(rows) * c1).sum()).backward()
+        ((a3(rows.to(cuda)) * c3.to(cuda)).sum() + (a1(rows.to(cuda)) * c1.to(cuda)).sum()).backward()
+        o_ref.step()
+        o_a.step(rows=rows.to(cuda))
+        assert_close(a3.weight.detach().cpu(), ref3.weight.detach(), 1e-6, 'dir table it%d' % it, atol=1e-7)
+        assert_close(a1.weight.detach().cpu(), ref1.weight.detach(), 1e-6, 'intensity table it%d' % it, atol=1e-7)
+    st = o_a.state[a3.weight]
+    assert int(st['step']) == 5 and set(st.keys()) == {'step', 'exp_avg', 'exp_avg_sq'}

@@ -301,3 +301,54 @@ def test_psnetwork_normal_jitter_golden(cuda):
     assert names == list(g['grad_names'])
     assert_close(norms, g['grad_norms'], 1e-3, 'grad norms')
     assert_close(projs, g['grad_projs'], 2e-3, 'grad projs')
+
+
+@pytest.mark.parametrize('loss_type,phase', [('L1', 2), ('L2', 2), ('L1', 1)])
+def test_fused_losses_match_modules(cuda, loss_type, phase):
+    """ops.Stage2Losses (csrc/loss.hip) against MainLoss + NormalLoss of the torch formulation: every term, the total and
+    the gradients of every dense output; also with normal jitter and with an empty mask."""
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.stage2.loss import fused_losses
+    conf = s2.bear_conf(**{'normal.net.xyz_jitter_std': 0.02})
+    net = s2.PSNetwork(conf)
+    net.load_state_dict(stage2_state_dict(__import__('oracle.stage2', fromlist=['x']).bear_conf(**{'normal.net.xyz_jitter_std': 0.02}), seed=35))
+    net.to(cuda)
+    inp, gt = stage2_inputs(700, 7, 3, seed=4, device=cuda)
+    lw = dict(sg_rgb_weight=1.0, albedo_smooth_weight=0.05, rough_smooth_weight=0.01, vis_weight=1) if phase == 2 else \
+        dict(sg_rgb_weight=0, albedo_smooth_weight=0, rough_smooth_weight=0, vis_weight=10)
+    main, normal = s2.MainLoss(loss_type=loss_type, **lw), s2.NormalLoss(1, 0.05)
+    keys = ('sg_rgb_values', 'albedo_values', 'albedo_jitter', 'rough_values', 'rough_jitter', 'vis_train', 'normal_pred', 'normal_jitter')
+    res = []
+    for fused_path in (False, True):
+        torch.manual_seed(0)
+        out = net(inp)
+        leaves = {k: out[k].detach().clone().requires_grad_(True) for k in keys}
+        o2 = dict(out)
+        o2.update(leaves)
+        count = int((o2['network_object_mask'] & o2['object_mask']).sum())
+        if fused_path:
+            total, t, tn = fused_losses(main, normal, o2, gt, inp, count)
+        else:
+            t, tn = main(o2, gt, inp, count=count), normal(o2, count=count)
+            total = t['loss'] + tn['loss']
+        total.backward()
+        res.append((total.detach(), {k: v for k, v in list(t.items()) + [('n_' + k, v) for k, v in tn.items()] if v is not None and k != 'loss'},
+                    {k: v.grad for k, v in leaves.items()}))
+    (t0, d0, g0), (t1, d1, g1) = res
+    assert_close(float(t1), float(t0), 2e-6, 'total', atol=0.0)
+    for k in d0:
+        if k in ('n_loss',):
+            continue
+        assert_close(float(d1[k]), float(d0[k]), 2e-6, k, atol=1e-12)
+    for k in g0:
+        if g0[k] is None or g1[k] is None:  # a term with weight 0: zeros in the torch formulation, no gradient at all here
+            for gg in (g0[k], g1[k]):
+                assert gg is None or float(gg.abs().max()) == 0.0, k
+        else:
+            assert_close(g1[k].cpu(), g0[k].cpu(), 2e-6, 'grad ' + k)  # max-normalised: two roundings of the same sum
+    # empty mask: every term 0, no NaN
+    inp2 = dict(inp)
+    inp2['object_mask'] = torch.zeros_like(inp['object_mask'])
+    out = net(inp2)
+    total, t, tn = fused_losses(main, normal, out, gt, inp2, 0)
+    assert float(total) == 0.0 and float(t['sg_rgb_loss']) == 0.0

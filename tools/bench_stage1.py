@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--cpu', action='store_true')
+    ap.add_argument('--compact-secant', action='store_true', help='round-1 secant (A/B)')
     args = ap.parse_args()
     import torch
     from psnerf_amd.synthetic import stage1_cfg, stage1_batch
@@ -34,6 +35,7 @@ def main():
         torch.manual_seed(42)
         net = NeuralNetwork(cfg)
         ren = Renderer(net, cfg, device=dev)
+        ren.COMPACT_SECANT = args.compact_secant
         tr = Trainer(ren, torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=dev)
         batch_d = {k: v.to(dev) for k, v in batch.items()}
         for _ in range(args.warmup):
