@@ -305,6 +305,13 @@ int psn_stage2_loss_bwd(const float* g_total, const float* rgb, const float* rgb
                         float k_nrmj, float* d_nrm, float* d_nrm_j, const unsigned char* mask_a, const unsigned char* mask_b,
                         int64_t N, int l2, void* stream);
 
+/* Sums of x [V, Ns, C] (C <= 256, V <= PSN_PAIR_SUMS_MAX_V) over V and over Ns in one pass: sx [Ns, C] = sum_v x and
+ * sl_part [*n_chunks, V, C] = per-chunk partial sums over Ns (the caller adds the chunks; at most PSN_PAIR_SUMS_MAX_CHUNKS).
+ * Used for the separable weight gradient of a layer whose input block is [table(x_n) | table(l_v)]. */
+#define PSN_PAIR_SUMS_MAX_V 16
+#define PSN_PAIR_SUMS_MAX_CHUNKS 2048
+int psn_pair_sums(const float* x, int V, int64_t Ns, int C, float* sx, float* sl_part, int* n_chunks, void* stream);
+
 /* torch.optim.SparseAdam on the touched rows of up to PSN_ROW_ADAM_MAX tables in one launch (the per-light direction
  * [n, 3] and intensity [n, 1] embeddings, stage2/trainer.py:126-168): rows listed in idx [n_idx] int64 (duplicates
  * allowed) advance their moments and move by -step_size m / (sqrt(v) + eps), step_size = lr sqrt(1 - b2^t) / (1 - b1^t)

@@ -85,20 +85,58 @@ __global__ __launch_bounds__(256) void stage2_loss_fwd_kernel(LossArgs a) {
 
 // out[0..5] = term_i = sum_i / denom_i, out[6] = sum_i weight_i term_i   (fixed summation order: deterministic)
 struct LossScale { float inv_denom[6]; float weight[6]; };
-__global__ __launch_bounds__(64) void stage2_loss_final_kernel(const float* __restrict__ partial, int blocks, LossScale sc,
+// 256 threads: thread t sums slice t >> 3 (of 32) of term t & 7; fixed tree afterwards: deterministic
+__global__ __launch_bounds__(256) void stage2_loss_final_kernel(const float* __restrict__ partial, int blocks, LossScale sc,
                                                                float* __restrict__ out) {
-    const int i = threadIdx.x;
-    float term = 0.f;
-    if (i < 6) {
-        float s = 0.f;
-        for (int b = 0; b < blocks; ++b) s += partial[(int64_t)b * 6 + i];
-        term = s * sc.inv_denom[i];
-        out[i] = term;
-    }
-    float w = i < 6 ? sc.weight[i] * term : 0.f;
+    __shared__ float red[32][8];
+    const int i = threadIdx.x & 7, j = threadIdx.x >> 3;
+    float s = 0.f;
+    if (i < 6)
+        for (int b = j; b < blocks; b += 32) s += partial[(int64_t)b * 6 + i];
+    red[j][i] = s;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float tot = 0.f;
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
-    if (i == 0) out[6] = w;
+        for (int k = 0; k < 32; ++k) tot += red[k][threadIdx.x];
+        const float term = threadIdx.x < 6 ? tot * sc.inv_denom[threadIdx.x] : 0.f;
+        if (threadIdx.x < 6) out[threadIdx.x] = term;
+        float w = threadIdx.x < 6 ? sc.weight[threadIdx.x] * term : 0.f;
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+        if (threadIdx.x == 0) out[6] = w;
+    }
+}
+
+// Sums of a [V, Ns, C] tensor over its first and over its second dimension in ONE pass (C <= 256 columns = threads):
+//   sx[n, c] = sum_v x[v, n, c]        sl_part[chunk, v, c] = sum over the chunk's n of x[v, n, c]
+// (separable input-block weight gradient of the visibility network, ops.VisibilityPair.backward)
+__global__ __launch_bounds__(256) void pair_sums_kernel(const float* __restrict__ x, int V, int64_t Ns, int C, int rows_per_block,
+                                                        float* __restrict__ sx, float* __restrict__ sl_part) {
+    // thread = (column quad cg, row lane rl): 16-byte loads, four rows of the block's slab in flight per light
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * rows_per_block, n1 = min(Ns, n0 + rows_per_block);
+    const bool live = 4 * cg < C;  // C is a multiple of 4
+    float4 sl[PSN_PAIR_SUMS_MAX_V];
+#pragma unroll
+    for (int v = 0; v < PSN_PAIR_SUMS_MAX_V; ++v) sl[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        for (int64_t n = n0 + rl; n < n1; n += 4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int v = 0; v < PSN_PAIR_SUMS_MAX_V; ++v) {
+                if (v < V) {
+                    const float4 t = *reinterpret_cast<const float4*>(x + ((int64_t)v * Ns + n) * C + 4 * cg);
+                    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                    sl[v].x += t.x; sl[v].y += t.y; sl[v].z += t.z; sl[v].w += t.w;
+                }
+            }
+            *reinterpret_cast<float4*>(sx + n * C + 4 * cg) = acc;
+        }
+#pragma unroll
+        for (int v = 0; v < PSN_PAIR_SUMS_MAX_V; ++v)
+            if (v < V) *reinterpret_cast<float4*>(sl_part + (((int64_t)blockIdx.x * 4 + rl) * V + v) * C + 4 * cg) = sl[v];
+    }
 }
 
 __global__ __launch_bounds__(256) void stage2_loss_bwd_kernel(LossArgs a) {
@@ -194,7 +232,7 @@ extern "C" int psn_stage2_loss_fwd(const float* rgb, const float* rgb_gt, int L,
     PSN_CHECK_LAUNCH("stage2_loss_fwd");
     LossScale sc;
     for (int i = 0; i < 6; ++i) { sc.inv_denom[i] = inv_denom[i]; sc.weight[i] = weight[i]; }
-    hipLaunchKernelGGL(stage2_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, bx * by, sc, out);
+    hipLaunchKernelGGL(stage2_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, bx * by, sc, out);
     PSN_CHECK_LAUNCH("stage2_loss_fwd (final)");
     return PSN_OK;
 }
@@ -269,5 +307,20 @@ extern "C" int psn_row_adam(int n_items, const PsnRowAdamItem* items, const int6
     if (max_rows <= 0 || n_idx == 0) return PSN_OK;
     hipLaunchKernelGGL(row_adam_kernel, dim3((unsigned)((max_rows + 255) / 256), n_items), dim3(256), 0, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("row_adam");
+    return PSN_OK;
+}
+
+extern "C" int psn_pair_sums(const float* x, int V, int64_t Ns, int C, float* sx, float* sl_part, int* n_chunks, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(x && sx && sl_part && n_chunks, "pair_sums: null pointer");
+    PSN_CHECK_ARG(V >= 1 && V <= PSN_PAIR_SUMS_MAX_V && C >= 1 && C <= 256 && Ns >= 0, "pair_sums: V=%d C=%d (V <= %d, C <= 256)", V, C, PSN_PAIR_SUMS_MAX_V);
+    PSN_CHECK_ARG(C % 4 == 0 && (((uintptr_t)x | (uintptr_t)sx | (uintptr_t)sl_part) & 15) == 0, "pair_sums: C must be a multiple of 4, buffers 16-byte aligned");
+    int rows = 32;
+    int64_t chunks = (Ns + rows - 1) / rows;
+    while (chunks * 4 > PSN_PAIR_SUMS_MAX_CHUNKS) { rows *= 2; chunks = (Ns + rows - 1) / rows; }
+    *n_chunks = (int)chunks * 4;  // one partial per (block, row lane)
+    if (Ns <= 0) return PSN_OK;
+    hipLaunchKernelGGL(pair_sums_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x, V, Ns, C, rows, sx, sl_part);
+    PSN_CHECK_LAUNCH("pair_sums");
     return PSN_OK;
 }

@@ -109,6 +109,7 @@ SIGNATURES = {
                                   c_f, c_f]),
     'psn_stage2_loss_bwd': (i32, [c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, f32, c_f, c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, c_f, i32, f32,
                                   c_f, c_f, c_f, c_f, f32, f32, c_f, c_f, c_f, c_f, i64, i32, c_f]),
+    'psn_pair_sums': (i32, [c_f, i32, i64, i32, c_f, c_f, ctypes.POINTER(ctypes.c_int), c_f]),
     'psn_row_adam': (i32, [i32, ctypes.c_void_p, c_f, i32, c_f]),
     'psn_shadow_points': (i32, [c_f, c_f, i64, i32, i32, f32, f32, c_f, c_f, f32, c_f, c_f, c_f, c_f]),
     'psn_root_find': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, i64, f32, i32, i32, f32, c_f, c_f]),
@@ -353,6 +354,16 @@ def stage2_loss_bwd(g_total, rgb, rgb_gt, k_rgb, alb, alb_j, k_alb, wgt, wgt_j, 
                                     float(k_nrm), float(k_nrmj), g('nrm'), g('nrm_j'), _bp(mask_a), _bp(mask_b), N, int(l2), _stream()),
            'stage2_loss_bwd')
     return d
+
+
+def pair_sums(x, V, Ns):
+    """x [V * Ns, C] (light-major rows) -> (sum over V [Ns, C], sum over Ns [V, C]) in one pass over x (psn_pair_sums)."""
+    C = x.shape[1]
+    sx = torch.empty(Ns, C, device=x.device, dtype=torch.float32)
+    part = torch.empty(2048, V, C, device=x.device, dtype=torch.float32)
+    n_chunks = ctypes.c_int(0)
+    _check(_lib.psn_pair_sums(_ptr(x, 'x'), V, Ns, C, sx.data_ptr(), part.data_ptr(), ctypes.byref(n_chunks), _stream()), 'pair_sums')
+    return sx, part[:n_chunks.value].sum(0)
 
 
 def row_adam(items, idx):

@@ -609,23 +609,40 @@ class VisibilityPair(torch.autograd.Function):
         grads[2 * (n - 1) + 1] = g.sum(0)
         items = []
         where = []
+        xl = {}  # layer -> (d W_x [256, 64], d W_l [256, 64], bias gradient or None)
         for li in range(n - 2, -1, -1):
             dz = DZ[n - 2 - li]
             if li > 0:
                 items.append(dict(A=dz, B=H[li - 1], colsum=True))
                 where.append((li, 'w'))
             if li == 0 or li - 1 == ctx.skip_at:
-                items.append(dict(A=dz, B=pe_x, b_div=1, b_mod=Ns, B_tab2=pe_lv, b2_div=Ns, b2_mod=V, colsum=(li == 0)))
-                where.append((li, 'xl'))
+                # The input block [PE(x_n) | PE(l_v)] of row k = v Ns + n is separable: sum the V light slices of dz first,
+                #   d W_x = sum_n (sum_v dz[v, n])^T PE(x_n)   (K = Ns instead of V Ns),
+                #   d W_l = sum_v (sum_n dz[v, n])^T PE(l_v)   (K = V),
+                # two reductions that read dz once each instead of a K = V Ns product on 128-column tiles (which ran at
+                # ~40 TF: the narrow-tile kernel is the slow one of the weight-gradient set).
+                if V <= 16:
+                    dz_x, dz_l = hip.pair_sums(dz, V, Ns)            # [Ns, 256], [V, 256]: one pass over dz
+                else:
+                    dz3 = dz.view(V, Ns, dz.shape[1])
+                    dz_x, dz_l = dz3.sum(0), dz3.sum(1)
+                sk_x = _split_k_for(Ns, 256, pe_x.shape[1])
+                dWx = hip.gemm(dz_x, pe_x, trans_a=True, split_k=sk_x)          # [256, 64]
+                dWl = hip.gemm(dz_l, pe_lv.contiguous(), trans_a=True)          # [256, 64]
+                xl[li] = (dWx, dWl, dz_l.sum(0) if li == 0 else None)
         parts = {}
-        for (li, kind), (C, cs) in zip(where, hip.gemm_tn_grouped(items)):
-            parts[(li, kind)] = C
-            if cs is not None:
-                grads[2 * li + 1] = cs
+        if items:
+            for (li, kind), (C, cs) in zip(where, hip.gemm_tn_grouped(items)):
+                parts[(li, kind)] = C
+                if cs is not None:
+                    grads[2 * li + 1] = cs
         for li in range(n - 1):
             blocks = [parts[(li, 'w')]] if (li, 'w') in parts else []
-            if (li, 'xl') in parts:  # columns [0, 64) = d W_x (table pe_x), [64, 128) = d W_l (table pe_lv)
-                blocks += [parts[(li, 'xl')][:, cols_a], parts[(li, 'xl')][:, pe_x.shape[1] + cols_b]]
+            if li in xl:  # columns: d W_x (table pe_x), d W_l (table pe_lv)
+                dWx, dWl, cs0 = xl[li]
+                blocks += [dWx[:, cols_a], dWl[:, cols_b]]
+                if cs0 is not None:
+                    grads[2 * li + 1] = cs0
             grads[2 * li] = blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=1)
         return (None, None, None, None, None, None) + tuple(grads)
 
