@@ -24,12 +24,40 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float o = __shfl_up(v, d, 64);
-        if (lane >= d) v *= o;
-    }
+// Cross-lane data through DPP (data-parallel primitives: the operand of a VALU instruction is taken from another lane
+// of the same row of 16, or broadcast from the row below) instead of __shfl_up (ds_bpermute_b32: an LDS-crossbar round
+// trip + a select per step).  Lanes without a source keep `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_from(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
+constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118;
+constexpr int kRowBcast15 = 0x142, kRowBcast31 = 0x143, kWaveShr1 = 0x138;
+
+// inclusive product scan inside every row of 16 lanes (Kogge-Stone, 4 DPP multiplies)
+__device__ __forceinline__ float row_incl_prod(float v) {
+    v *= dpp_from<kRowShr1, 0xf>(1.0f, v);
+    v *= dpp_from<kRowShr2, 0xf>(1.0f, v);
+    v *= dpp_from<kRowShr4, 0xf>(1.0f, v);
+    v *= dpp_from<kRowShr8, 0xf>(1.0f, v);
+    return v;
+}
+// ... over the whole wave: rows 1 and 3 take lane 15 of the row below, then rows 2 and 3 take lane 31
+__device__ __forceinline__ float wave_incl_prod(float v, int /*lane*/) {
+    v = row_incl_prod(v);
+    v *= dpp_from<kRowBcast15, 0xa>(1.0f, v);
+    v *= dpp_from<kRowBcast31, 0xc>(1.0f, v);
+    return v;
+}
+// value of the previous lane of the wave (lane 0: `first`)
+__device__ __forceinline__ float wave_prev(float v, float first) { return dpp_from<kWaveShr1, 0xf>(first, v); }
+// inclusive sum scan inside a row of 16 lanes: lane 15 of the row ends up with the row total
+__device__ __forceinline__ float row_incl_sum(float v) {
+    v += dpp_from<kRowShr1, 0xf>(0.0f, v);
+    v += dpp_from<kRowShr2, 0xf>(0.0f, v);
+    v += dpp_from<kRowShr4, 0xf>(0.0f, v);
+    v += dpp_from<kRowShr8, 0xf>(0.0f, v);
     return v;
 }
 __device__ __forceinline__ float wave_incl_sum_rev(float v, int lane) {  // suffix (inclusive) sum
@@ -148,8 +176,7 @@ __device__ __forceinline__ void fwd_ray(const RayRegs<E>& r, bool has_rgb, int64
 #pragma unroll
     for (int i = 0; i < E; ++i) p[i + 1] = p[i] * (s0 + i < S ? (1.0f - r.a[i] + kEps) : 1.0f);
     const float incl = wave_incl_prod(p[E], lane);
-    float pre = __shfl_up(incl, 1, 64);
-    if (lane == 0) pre = 1.0f;
+    const float pre = wave_prev(incl, 1.0f);
     float w[E];
     float acc = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
 #pragma unroll
@@ -215,6 +242,44 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     }
 }
 
+// Accumulated opacity only (shadow rays, stage1/model/rendering.py:405-406: no colours, no weights kept), S <= 128 and a
+// multiple of 16: FOUR rays per wave -- a ray occupies one DPP row of 16 lanes, a lane owns E = S / 16 consecutive samples
+// (16-byte loads), the transmittance scan is the 4-step row scan and the ray sum a 4-step row reduction.  With one ray
+// per wave (E = 2 at S = 128) the cross-lane steps outnumbered the loads: 2.6 TB/s.
+template <int E>
+__global__ __launch_bounds__(256) void composite_acc4_kernel(const float* __restrict__ alpha, int64_t n_rays, int S,
+                                                             float* __restrict__ acc_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 15, rq = lane >> 4;
+    const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * 4;
+    for (int64_t ray = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 4 + rq; ray < n_rays + 3; ray += stride) {
+        const bool live = ray < n_rays;  // (the loop bound keeps whole waves together for the DPP steps)
+        float a[E];
+        const int s0 = sub * E;
+        if (live && s0 < S) {
+#pragma unroll
+            for (int i = 0; i < E; i += 4) {
+                const float4 t = nt_load4(alpha + ray * S + s0 + i);
+                a[i] = t.x; a[i + 1] = t.y; a[i + 2] = t.z; a[i + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) a[i] = 0.0f;
+        }
+        float p[E + 1];
+        p[0] = 1.0f;
+#pragma unroll
+        for (int i = 0; i < E; ++i) p[i + 1] = p[i] * (s0 + i < S ? (1.0f - a[i] + kEps) : 1.0f);
+        const float incl = row_incl_prod(p[E]);
+        const float pre = dpp_from<kRowShr1, 0xf>(1.0f, incl);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < E; ++i) acc += a[i] * (pre * p[i]);
+        acc = row_incl_sum(acc);
+        if (live && sub == 15) acc_out[ray] = acc;
+    }
+}
+
 template <int E>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ alpha,
                                                             const float* __restrict__ rgb,
@@ -247,8 +312,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
             a[e] = s < S ? __builtin_nontemporal_load(a_row + s) : 0.0f;
             float t = s < S ? (1.0f - a[e] + kEps) : 1.0f;
             float incl = wave_incl_prod(t, lane);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0f;
+            float excl = wave_prev(incl, 1.0f);
             T[e] = excl * carry;
             carry *= __shfl(incl, 63, 64);
             w[e] = a[e] * T[e];
@@ -326,6 +390,15 @@ extern "C" int psn_composite_fwd(const float* alpha, const float* rgb, int64_t n
     PSN_CHECK_ARG(n_samples >= 1 && n_samples <= 1024, "composite_fwd: n_samples=%d out of [1,1024]", n_samples);
     if (n_rays <= 0) return PSN_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (rgb == nullptr && weights == nullptr && n_samples % 16 == 0 && n_samples / 16 >= 4 && n_samples <= 128 &&
+        (n_samples / 16) % 4 == 0 && ((uintptr_t)alpha & 15) == 0) {  // opacity only: four rays per wave
+        int64_t blocks = (n_rays + kWavesPerBlock * 4 - 1) / (kWavesPerBlock * 4);
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        if (n_samples == 64) hipLaunchKernelGGL(composite_acc4_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, alpha, n_rays, n_samples, acc_out);
+        else hipLaunchKernelGGL(composite_acc4_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, alpha, n_rays, n_samples, acc_out);
+        PSN_CHECK_LAUNCH("composite_fwd (opacity only)");
+        return PSN_OK;
+    }
     int E = (n_samples + 63) / 64;
     if (E <= 1) return launch_fwd<1>(alpha, rgb, n_rays, n_samples, white_bg, weights, rgb_out, acc_out, st);
     if (E <= 2) return launch_fwd<2>(alpha, rgb, n_rays, n_samples, white_bg, weights, rgb_out, acc_out, st);

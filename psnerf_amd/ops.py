@@ -42,19 +42,20 @@ def positional_encoding(x, n_freqs, out_stride=None, scale=1.0):
 
 # --------------------------------------------------------------------------- alpha composite
 class AlphaComposite(torch.autograd.Function):
-    """stage1/model/rendering.py:196-197,214-216: returns (rgb [N,3] incl. white background, acc [N], weights)."""
+    """stage1/model/rendering.py:196-197,214-216: returns (rgb [N,3] incl. white background, acc [N]).  The per-sample
+    weights are an intermediate of the reference (not part of its output dictionary) and the backward kernel rebuilds
+    them from alpha, so they are not written: 16 S + 16 B per ray instead of 20 S + 16."""
 
     @staticmethod
     def forward(ctx, alpha, rgb, white_bg):
         alpha, rgb = alpha.contiguous(), rgb.contiguous()
-        w, out, acc = hip.composite_fwd(alpha, rgb, white_bg)
+        _w, out, acc = hip.composite_fwd(alpha, rgb, white_bg, need_weights=False)
         ctx.save_for_backward(alpha, rgb)
         ctx.white_bg = white_bg
-        ctx.mark_non_differentiable(w)
-        return out, acc, w
+        return out, acc
 
     @staticmethod
-    def backward(ctx, d_out, d_acc, _dw):
+    def backward(ctx, d_out, d_acc):
         alpha, rgb = ctx.saved_tensors
         d_out = torch.zeros(alpha.shape[0], 3, device=alpha.device) if d_out is None else d_out.contiguous()
         d_acc = None if d_acc is None else d_acc.contiguous()

@@ -293,7 +293,7 @@ class Renderer(nn.Module):
         rgb, alpha = self.model(p_fg, view, return_addocc=True)  # one launch chain; no 64000-point chunking needed
         rgb = rgb.reshape(B * N, full_steps, 3)
         alpha = alpha.reshape(B * N, full_steps)
-        rgb_values, acc, _w = ops.alpha_composite(alpha, rgb, bool(self.white_background))
+        rgb_values, acc = ops.alpha_composite(alpha, rgb, bool(self.white_background))
         norm_pred = torch.zeros(B * N, 3, device=dev)
         diff_norm = None
         if n_surf > 0:

@@ -43,6 +43,7 @@ def main():
     res = {}
     cases = [
         ('fwd', lambda: hip.composite_fwd(alpha, rgb, True), (20 * S + 16) * N),
+        ('fwd_no_weights', lambda: hip.composite_fwd(alpha, rgb, True, need_weights=False), (16 * S + 16) * N),
         ('bwd', lambda: hip.composite_bwd(alpha, rgb, d_rgb, d_acc, True), (36 * S + 16) * N),
         ('fwd_acc_only', lambda: hip.composite_fwd(alpha, None, False, need_weights=False), (4 * S + 4) * N),
     ]
