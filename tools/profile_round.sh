@@ -12,14 +12,14 @@ mkdir -p "$O"
 export TMPDIR=/tmp
 cd /tmp
 python3 $R/bench.py > $O/bench_stage2.json 2> $O/bench_stage2.err
-python3 $R/tools/bench_stage1.py > $O/bench_stage1.json 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps2 -o s2 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+python3 $R/tools/bench_stage1.py --steps 10 --warmup 3 > $O/bench_stage1.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps2 -o s2 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-stage1 --no-extra > /dev/null 2>&1
 cp $(find /tmp/ps2 -name '*kernel_stats*' | head -1) $O/bench_stage2_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps1 -o s1 -- python3 $R/tools/bench_stage1.py --steps 3 --warmup 1 > /dev/null 2>&1
 cp $(find /tmp/ps1 -name '*kernel_stats*' | head -1) $O/bench_stage1_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     N=$(echo $C | cut -d' ' -f1)
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$N -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$N -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stage1 --no-extra > /dev/null 2>&1
     F=$(find /tmp/pmc_$N -name '*counter_collection*' | head -1)
     # keep the header and the fused-MLP dispatches only (the full table is large)
     (head -1 $F; grep mlp_infer_kernel $F) > $O/pmc_$N.csv
