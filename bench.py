@@ -8,6 +8,9 @@ One "step" = one full optimisation step of the stage-2 joint BRDF + normal + vis
 optimisation (forward, losses, backward, Adam + SparseAdam, scheduler) on a synthetic BEAR-shaped batch
 that is already resident in HBM: 32768 pixels per GPU (90 % on the surface), L = 96 shading lights,
 V = 8 visibility-supervision lights, phase-2 of the train_fix schedule (all nets + lights trainable).
+The batch is what handoff.ViewSampler.batch hands to the trainer: the reference's dictionary plus 'surface_idx', the
+index list of the surface pixels that the sampler builds on the host from the stage-1 mask (an input re-encoded, not
+a result: the step then contains no host synchronisation, everything else of the step runs inside the timed region).
 A ray-sample is one (surface pixel, shading light) pair: Ns * L per step.  N > 1 shards
 pixels across ranks with one flat-bucket RCCL all-reduce of the gradients per step.  The headline line is
 WEAK scaling (32768 px per GPU; the reference trains on all ~10^5 in-mask pixels of a view per step); the
@@ -255,10 +258,10 @@ def main():
         return float(t.item()), int(ns.item()), terms, events
 
     def weak_batch():
-        return stage2_inputs(args.pixels, N_LIGHTS, N_VIS, seed=100 + rank, device=device)
+        return stage2_inputs(args.pixels, N_LIGHTS, N_VIS, seed=100 + rank, device=device, with_surface_idx=True)
 
     def strong_batch():
-        inp, gt = stage2_inputs(STRONG_PIXELS, N_LIGHTS, N_VIS, seed=100, device=device)  # same global batch on every rank
+        inp, gt = stage2_inputs(STRONG_PIXELS, N_LIGHTS, N_VIS, seed=100, device=device, with_surface_idx=True)  # same global batch on every rank
         return step.dp.shard_stage2(inp, gt) if world > 1 else (inp, gt)
 
     head_batch, other_batch = (weak_batch, strong_batch) if args.scaling == 'weak' else (strong_batch, weak_batch)
@@ -327,7 +330,8 @@ def main():
                                'L=96 shading lights, V=8 visibility lights, sgbasis RGB 9 lobes, visibility + vis_loss on, '
                                'train_fix phase 2, full step (fwd+loss+bwd+Adam+SparseAdam)' % (px_local, ns_total),
                    'pixels_per_gpu': px_local, 'surface_pixels_total': ns_total, 'lights': N_LIGHTS,
-                   'vis_lights': N_VIS, 'parallelism': 'pixel-dp%d' % world},
+                   'vis_lights': N_VIS, 'parallelism': 'pixel-dp%d' % world,
+                   'batch': "ViewSampler.batch layout: reference dictionary + 'surface_idx' (host-built index list of the surface mask)"},
         'loss': round(float(terms['total'].detach()), 6),
         'roofline': roofline, 'cpu_baseline': cpu,
         ('strong' if args.scaling == 'weak' else 'weak'): other,

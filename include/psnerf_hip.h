@@ -290,20 +290,24 @@ int psn_root_find(const PsnMlpDesc* desc, const float* packed_w, const float* pa
  *   term 3  visibility sum |vis[v, n, 0] - vis_gt[v, n]| (or squared) over [V, N]   (vis is [V, N, 3])
  *   term 4  normal     sum (nrm - normalize(nrm_gt))^2 over [N, 3]   term 5  normal smoothness  sum |nrm - nrm_j|
  * A term whose first pointer is NULL is skipped (0).  out[i] = sum_i * inv_denom[i] (i < 6), out[6] = sum_i weight[i] out[i];
- * inv_denom, weight: HOST arrays [6] (passed by value).  partial: device workspace of >= 2048 * 6 floats.  Deterministic
- * summation order.
+ * inv_denom, weight: HOST arrays [6] (passed by value).  count_dev (optional, device [1] float): the masked-pixel count;
+ * when given, inv_denom holds only the per-pixel multiplicities (1 / (L 3), 1 / 3, 1 / nb, 1 / V, 1 / 3, 1 / 3) and
+ * every term (and every gradient in _bwd) is divided by count_dev[0] on the device (0 for an empty mask), so the count --
+ * possibly all-reduced over ranks -- never has to reach the host.  partial: device workspace of >= 2048 * 6 floats.
+ * Deterministic summation order.
  * psn_stage2_loss_bwd writes d(out[6]) / d(input) * g_total[0] for every non-NULL d_* (k_i = weight_i * inv_denom_i on the
  * host); masked-out pixels get zeros; d_vis channels 1, 2 are zero. */
 int psn_stage2_loss_fwd(const float* rgb, const float* rgb_gt, int L, const float* alb, const float* alb_j, const float* wgt,
                         const float* wgt_j, int nb, const float* vis, const float* vis_gt, int V, const float* nrm,
                         const float* nrm_gt, const float* nrm_j, const unsigned char* mask_a, const unsigned char* mask_b,
-                        int64_t N, int l2, const float* inv_denom, const float* weight, float* partial, float* out, void* stream);
+                        int64_t N, int l2, const float* inv_denom, const float* weight, const float* count_dev, float* partial,
+                        float* out, void* stream);
 int psn_stage2_loss_bwd(const float* g_total, const float* rgb, const float* rgb_gt, int L, float k_rgb, float* d_rgb,
                         const float* alb, const float* alb_j, float k_alb, float* d_alb, float* d_alb_j, const float* wgt,
                         const float* wgt_j, int nb, float k_wgt, float* d_wgt, float* d_wgt_j, const float* vis, const float* vis_gt,
                         int V, float k_vis, float* d_vis, const float* nrm, const float* nrm_gt, const float* nrm_j, float k_nrm,
                         float k_nrmj, float* d_nrm, float* d_nrm_j, const unsigned char* mask_a, const unsigned char* mask_b,
-                        int64_t N, int l2, void* stream);
+                        int64_t N, int l2, const float* count_dev, void* stream);
 
 /* Sums of x [V, Ns, C] (C <= 256, V <= PSN_PAIR_SUMS_MAX_V) over V and over Ns in one pass: sx [Ns, C] = sum_v x and
  * sl_part [*n_chunks, V, C] = per-chunk partial sums over Ns (the caller adds the chunks; at most PSN_PAIR_SUMS_MAX_CHUNKS).

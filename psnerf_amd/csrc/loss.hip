@@ -22,6 +22,7 @@ struct LossArgs {
     float* partial;                                        // [blocks, 6]
     // backward
     const float* g_total;                                  // [1] upstream gradient of the weighted total
+    const float* count_dev;                                // optional [1]: every k_* is divided by it (see LossScale)
     float k_rgb, k_alb, k_wgt, k_vis, k_nrm, k_nrmj;       // weight_i / denominator_i
     float* d_rgb; float* d_alb; float* d_alb_j; float* d_wgt; float* d_wgt_j; float* d_vis; float* d_nrm; float* d_nrm_j;
 };
@@ -84,7 +85,10 @@ __global__ __launch_bounds__(256) void stage2_loss_fwd_kernel(LossArgs a) {
 }
 
 // out[0..5] = term_i = sum_i / denom_i, out[6] = sum_i weight_i term_i   (fixed summation order: deterministic)
-struct LossScale { float inv_denom[6]; float weight[6]; };
+// inv_denom[i] is the reciprocal of term i's element count; with count_dev != null it is only the per-pixel multiplicity
+// (1 / (L 3), 1 / 3, ...) and the masked-pixel count is read from the device (a count that was all-reduced over ranks, or
+// simply never brought to the host: no synchronisation between data loading and the first launch of the step).
+struct LossScale { float inv_denom[6]; float weight[6]; const float* count_dev; };
 // 256 threads: thread t sums slice t >> 3 (of 32) of term t & 7; fixed tree afterwards: deterministic
 __global__ __launch_bounds__(256) void stage2_loss_final_kernel(const float* __restrict__ partial, int blocks, LossScale sc,
                                                                float* __restrict__ out) {
@@ -99,7 +103,8 @@ __global__ __launch_bounds__(256) void stage2_loss_final_kernel(const float* __r
         float tot = 0.f;
 #pragma unroll
         for (int k = 0; k < 32; ++k) tot += red[k][threadIdx.x];
-        const float term = threadIdx.x < 6 ? tot * sc.inv_denom[threadIdx.x] : 0.f;
+        const float cnt = sc.count_dev != nullptr ? sc.count_dev[0] : 1.0f;
+        const float term = (threadIdx.x < 6 && cnt > 0.0f) ? tot * sc.inv_denom[threadIdx.x] / cnt : 0.f;
         if (threadIdx.x < 6) out[threadIdx.x] = term;
         float w = threadIdx.x < 6 ? sc.weight[threadIdx.x] * term : 0.f;
 #pragma unroll
@@ -140,7 +145,11 @@ __global__ __launch_bounds__(256) void pair_sums_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void stage2_loss_bwd_kernel(LossArgs a) {
-    const float g = a.g_total[0];
+    float g = a.g_total[0];
+    if (a.count_dev != nullptr) {
+        const float cnt = a.count_dev[0];
+        g = cnt > 0.0f ? g / cnt : 0.0f;
+    }
     const int lc = (a.L + gridDim.y - 1) / gridDim.y;
     const int l0 = blockIdx.y * lc, l1 = min(a.L, l0 + lc);
     for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < a.N; n += (int64_t)gridDim.x * 256) {
@@ -215,7 +224,7 @@ extern "C" int psn_stage2_loss_fwd(const float* rgb, const float* rgb_gt, int L,
                                    const float* wgt, const float* wgt_j, int nb, const float* vis, const float* vis_gt, int V,
                                    const float* nrm, const float* nrm_gt, const float* nrm_j, const unsigned char* mask_a,
                                    const unsigned char* mask_b, int64_t N, int l2, const float* inv_denom, const float* weight,
-                                   float* partial, float* out, void* stream) {
+                                   const float* count_dev, float* partial, float* out, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(mask_a && mask_b && partial && out && inv_denom && weight, "stage2_loss_fwd: null pointer");
     PSN_CHECK_ARG((rgb == nullptr || rgb_gt) && (alb == nullptr || alb_j) && (wgt == nullptr || (wgt_j && nb > 0)) &&
@@ -232,6 +241,7 @@ extern "C" int psn_stage2_loss_fwd(const float* rgb, const float* rgb_gt, int L,
     PSN_CHECK_LAUNCH("stage2_loss_fwd");
     LossScale sc;
     for (int i = 0; i < 6; ++i) { sc.inv_denom[i] = inv_denom[i]; sc.weight[i] = weight[i]; }
+    sc.count_dev = count_dev;
     hipLaunchKernelGGL(stage2_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, bx * by, sc, out);
     PSN_CHECK_LAUNCH("stage2_loss_fwd (final)");
     return PSN_OK;
@@ -243,11 +253,11 @@ extern "C" int psn_stage2_loss_bwd(const float* g_total, const float* rgb, const
                                    const float* vis, const float* vis_gt, int V, float k_vis, float* d_vis,
                                    const float* nrm, const float* nrm_gt, const float* nrm_j, float k_nrm, float k_nrmj, float* d_nrm,
                                    float* d_nrm_j, const unsigned char* mask_a, const unsigned char* mask_b, int64_t N, int l2,
-                                   void* stream) {
+                                   const float* count_dev, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(g_total && mask_a && mask_b, "stage2_loss_bwd: null pointer");
     LossArgs a = {};
-    a.g_total = g_total; a.rgb = rgb; a.rgb_gt = rgb_gt; a.L = L; a.k_rgb = k_rgb; a.d_rgb = d_rgb;
+    a.g_total = g_total; a.count_dev = count_dev; a.rgb = rgb; a.rgb_gt = rgb_gt; a.L = L; a.k_rgb = k_rgb; a.d_rgb = d_rgb;
     a.alb = alb; a.alb_j = alb_j; a.k_alb = k_alb; a.d_alb = d_alb; a.d_alb_j = d_alb_j;
     a.wgt = wgt; a.wgt_j = wgt_j; a.nb = nb; a.k_wgt = k_wgt; a.d_wgt = d_wgt; a.d_wgt_j = d_wgt_j;
     a.vis = vis; a.vis_gt = vis_gt; a.V = V; a.k_vis = k_vis; a.d_vis = d_vis;

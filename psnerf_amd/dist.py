@@ -17,6 +17,7 @@ import torch.distributed as dist
 
 PIXEL_KEYS_DIM1 = ('uv', 'object_mask', 'surface_mask', 'points', 'normal', 'vis_train_gt', 'visibility',
                    'sampling_idx')
+# (a batch's 'surface_idx' -- the index list of its surface pixels, see PSNetwork.forward -- is rebuilt for the shard)
 
 
 class DataParallel(object):
@@ -43,6 +44,8 @@ class DataParallel(object):
         for k in PIXEL_KEYS_DIM1:
             if k in mi and torch.is_tensor(mi[k]) and mi[k].dim() >= 2 and mi[k].shape[1] == n:
                 mi[k] = mi[k][:, lo:hi].contiguous()
+        if 'surface_idx' in mi:  # index list of the shard's own surface pixels (one nonzero at sharding time)
+            mi['surface_idx'] = mi['surface_mask'][0].nonzero(as_tuple=True)[0]
         gt = dict(ground_truth)
         if 'rgb' in gt:
             gt['rgb'] = gt['rgb'][:, lo:hi].contiguous()
@@ -64,6 +67,15 @@ class DataParallel(object):
         if self.enabled:
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         return int(c.item())
+
+    def global_count_tensor(self, mask):
+        """Number of True elements of ``mask`` summed over ranks, as a device float tensor [1]: one tiny reduction launch
+        (+ one all-reduce under data parallelism) and NO host synchronisation -- the fused loss kernels divide by it on
+        the device.  Every rank must call this the same number of times per step."""
+        c = mask.sum().to(torch.float32).reshape(1)
+        if self.enabled:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        return c
 
     def global_sum_int(self, value):
         t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)

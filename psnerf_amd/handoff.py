@@ -179,6 +179,8 @@ class ViewSampler(object):
                 mi[k] = v[None]
             else:
                 mi[k] = v
+        # index list of the batch's surface pixels, built here on the host (PSNetwork.forward then needs no nonzero())
+        mi['surface_idx'] = sample['surface_mask'].nonzero(as_tuple=True)[0]
         accu = [int(ld.shape[0]) for ld in self.light_direction]
         l_slt = sum(accu[:idx]) + sample['lidx']
         gt = dict(gt)

@@ -106,9 +106,9 @@ SIGNATURES = {
     'psn_secant_step': (i32, [c_f, f32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, c_f]),
     'psn_first_crossing': (i32, [c_f, c_f, c_f, c_f, f32, f32, i64, i32, c_f, c_f, c_f]),
     'psn_stage2_loss_fwd': (i32, [c_f, c_f, i32, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, i64, i32, c_f, c_f, c_f,
-                                  c_f, c_f]),
+                                  c_f, c_f, c_f]),
     'psn_stage2_loss_bwd': (i32, [c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, f32, c_f, c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, c_f, i32, f32,
-                                  c_f, c_f, c_f, c_f, f32, f32, c_f, c_f, c_f, c_f, i64, i32, c_f]),
+                                  c_f, c_f, c_f, c_f, f32, f32, c_f, c_f, c_f, c_f, i64, i32, c_f, c_f]),
     'psn_pair_sums': (i32, [c_f, i32, i64, i32, c_f, c_f, ctypes.POINTER(ctypes.c_int), c_f]),
     'psn_row_adam': (i32, [i32, ctypes.c_void_p, c_f, i32, c_f]),
     'psn_shadow_points': (i32, [c_f, c_f, i64, i32, i32, f32, f32, c_f, c_f, f32, c_f, c_f, c_f, c_f]),
@@ -317,7 +317,8 @@ def _bp(t):
     return t.data_ptr()
 
 
-def stage2_loss_fwd(rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, l2, inv_denom, weight):
+def stage2_loss_fwd(rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, l2, inv_denom, weight,
+                    count_dev=None):
     """Seven floats on the device: the six loss terms and their weighted total (psn_stage2_loss_fwd)."""
     N = mask_a.numel()
     out = torch.empty(7, device=mask_a.device, dtype=torch.float32)
@@ -327,12 +328,12 @@ def stage2_loss_fwd(rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_g
                                     _fp(nrm), _fp(nrm_gt), _fp(nrm_j), _bp(mask_a), _bp(mask_b), N, int(l2),
                                     ctypes.cast((ctypes.c_float * 6)(*[float(x) for x in inv_denom]), ctypes.c_void_p),
                                     ctypes.cast((ctypes.c_float * 6)(*[float(x) for x in weight]), ctypes.c_void_p),
-                                    partial.data_ptr(), out.data_ptr(), _stream()), 'stage2_loss_fwd')
+                                    _ptr(count_dev, 'count_dev', True), partial.data_ptr(), out.data_ptr(), _stream()), 'stage2_loss_fwd')
     return out
 
 
 def stage2_loss_bwd(g_total, rgb, rgb_gt, k_rgb, alb, alb_j, k_alb, wgt, wgt_j, k_wgt, vis, vis_gt, k_vis, nrm, nrm_gt, nrm_j, k_nrm,
-                    k_nrmj, mask_a, mask_b, l2, need):
+                    k_nrmj, mask_a, mask_b, l2, need, count_dev=None):
     """Gradients of the weighted total with respect to the tensors named in ``need`` (a set of 'rgb', 'alb', 'wgt', 'vis',
     'nrm'); returns dict name -> gradient (alb / wgt / nrm also give the jitter gradients as name + '_j')."""
     N = mask_a.numel()
@@ -351,8 +352,8 @@ def stage2_loss_bwd(g_total, rgb, rgb_gt, k_rgb, alb, alb_j, k_alb, wgt, wgt_j, 
                                     _fp(alb), _fp(alb_j), float(k_alb), g('alb'), g('alb_j'), _fp(wgt), _fp(wgt_j),
                                     0 if wgt is None else wgt.shape[-1], float(k_wgt), g('wgt'), g('wgt_j'), _fp(vis), _fp(vis_gt),
                                     0 if vis is None else vis.shape[0], float(k_vis), g('vis'), _fp(nrm), _fp(nrm_gt), _fp(nrm_j),
-                                    float(k_nrm), float(k_nrmj), g('nrm'), g('nrm_j'), _bp(mask_a), _bp(mask_b), N, int(l2), _stream()),
-           'stage2_loss_bwd')
+                                    float(k_nrm), float(k_nrmj), g('nrm'), g('nrm_j'), _bp(mask_a), _bp(mask_b), N, int(l2),
+                                    _ptr(count_dev, 'count_dev', True), _stream()), 'stage2_loss_bwd')
     return d
 
 

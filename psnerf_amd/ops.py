@@ -889,16 +889,18 @@ class FusedReluNet(torch.autograd.Function):
 class Stage2Losses(torch.autograd.Function):
     """MainLoss + NormalLoss of stage 2 (stage2/model/loss.py:27-92,123-141) over the dense model outputs in two launches
     forward and one backward (csrc/loss.hip) instead of ~75 elementwise / reduction launches.
-    apply(rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, l2, inv_denom, weight)
-    -> (total (0-dim), terms [6] (no gradient)).  Tensors of inactive terms are None; inv_denom / weight: 6 floats."""
+    apply(rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, l2, inv_denom, weight[, count_dev])
+    -> (total (0-dim), terms [6] (no gradient)).  Tensors of inactive terms are None; inv_denom / weight: 6 floats;
+    count_dev: optional device float [1] = masked-pixel count (then inv_denom excludes it, see psn_stage2_loss_fwd)."""
 
     @staticmethod
-    def forward(ctx, rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, l2, inv_denom, weight):
+    def forward(ctx, rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, l2, inv_denom, weight,
+                count_dev=None):
         c = lambda t: None if t is None else t.detach().contiguous()
         ts = [c(t) for t in (rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j)]
         ma, mb = mask_a.contiguous(), mask_b.contiguous()
-        out = hip.stage2_loss_fwd(*ts, ma, mb, l2, inv_denom, weight)
-        ctx.ts, ctx.masks, ctx.l2 = ts, (ma, mb), l2
+        out = hip.stage2_loss_fwd(*ts, ma, mb, l2, inv_denom, weight, count_dev)
+        ctx.ts, ctx.masks, ctx.l2, ctx.count_dev = ts, (ma, mb), l2, count_dev
         ctx.k = [w * d for w, d in zip(weight, inv_denom)]
         ctx.need = ctx.needs_input_grad
         terms = out[:6]
@@ -918,7 +920,7 @@ class Stage2Losses(torch.autograd.Function):
         d = {}
         if need:
             d = hip.stage2_loss_bwd(g_total.reshape(1).contiguous(), rgb, rgb_gt, k[0], alb, alb_j, k[1], wgt, wgt_j, k[2], vis, vis_gt,
-                                    k[3], nrm, nrm_gt, nrm_j, k[4], k[5], ctx.masks[0], ctx.masks[1], ctx.l2, need)
+                                    k[3], nrm, nrm_gt, nrm_j, k[4], k[5], ctx.masks[0], ctx.masks[1], ctx.l2, need, ctx.count_dev)
         g = d.get
         return (g('rgb'), None, g('alb'), g('alb_j'), g('wgt'), g('wgt_j'), g('vis'), None, g('nrm'), None, g('nrm_j'),
-                None, None, None, None, None)
+                None, None, None, None, None, None)

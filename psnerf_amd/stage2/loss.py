@@ -138,17 +138,20 @@ def fused_losses(main, normal, model_outputs, ground_truth, model_input, count):
     nrm, nrm_gt = o['normal_pred'], o['normal_values']
     if 'normal_jitter' in o and normal.normal_smooth_weight > 0:
         nrm_j = o['normal_jitter']
-    c = float(max(count, 1))
+    # ``count`` may be a python int (host-known) or a device float tensor [1] (never synchronised; under data
+    # parallelism the all-reduced count): the kernels then divide by it on the device
+    count_dev = count.reshape(1).float() if torch.is_tensor(count) else None
+    c = 1.0 if count_dev is not None else float(max(count, 1))
     nb = 1 if wgt is None else wgt.shape[-1]
     V = 1 if vis is None else vis.shape[0]
     inv = [1.0 / (c * L * 3), 1.0 / (c * 3), 1.0 / (c * nb), 1.0 / (c * V), 1.0 / (c * 3), 1.0 / (c * 3)]
-    if count == 0:
+    if count_dev is None and count == 0:
         inv = [0.0] * 6  # the reference returns 0 for every term of an empty mask
     w = [float(main.sg_rgb_weight), float(main.albedo_smooth_weight) if alb is not None else 0.0,
          float(main.rough_smooth_weight) if wgt is not None else 0.0, float(main.vis_weight) if vis is not None else 0.0,
          float(normal.normal_weight), float(normal.normal_smooth_weight) if nrm_j is not None else 0.0]
     total, t = ops.Stage2Losses.apply(rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, ma, mb,
-                                      1 if main.loss_type == 'L2' else 0, inv, w)
+                                      1 if main.loss_type == 'L2' else 0, inv, w, count_dev)
     terms = {'sg_rgb_loss': t[0], 'albedo_smooth_loss': t[1] if alb is not None else None,
              'rough_smooth_loss': t[2] if wgt is not None else None, 'loss': total}
     if has_vis:

@@ -313,7 +313,14 @@ class PSNetwork(nn.Module):
         device = uv.device
         ray_dirs, _ = camera_rays(uv, pose, intr)
         surface_mask, points, normals = input['surface_mask'], input['points'], input['normal']
-        idx = surface_mask[0].nonzero(as_tuple=True)[0]  # the one data-dependent sync of the forward
+        # The index list of the surface pixels: nonzero() is the one data-dependent host synchronisation of the forward.
+        # A batch may bring the list along ('surface_idx', int64, ascending = surface_mask[0].nonzero()): the mask is an
+        # INPUT (stage-1 hand-off data), so the data pipeline -- handoff.ViewSampler on the host, where the mask lives
+        # anyway -- can build it while the previous step is still running, and the host then queues a whole step
+        # without ever waiting for the GPU.
+        idx = input.get('surface_idx')
+        if idx is None:
+            idx = surface_mask[0].nonzero(as_tuple=True)[0]
         ns = idx.shape[0]
 
         def gather(t):  # [1,N,C] -> [Ns,C]

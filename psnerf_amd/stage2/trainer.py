@@ -131,9 +131,18 @@ class TrainStep(object):
         # are inputs (the model passes them through as 'network_object_mask' / 'object_mask'), so the count -- a host
         # synchronisation -- is taken BEFORE the forward pass: afterwards the host runs ahead of the GPU through
         # forward, losses and backward instead of stalling behind the 22 ms visibility launch.
-        count = self.dp.global_count(model_input['surface_mask'] & model_input['object_mask'])
+        both = model_input['surface_mask'] & model_input['object_mask']
+        if self.FUSED_LOSSES and both.is_cuda:
+            # the count stays on the device (all-reduced there under data parallelism): the fused loss kernels divide by
+            # it, so the step has no host synchronisation of its own (the model's only one is the surface-pixel list,
+            # and a batch may bring that along as 'surface_idx')
+            count = self.dp.global_count_tensor(both)
+        else:
+            count = self.dp.global_count(both)
         out = self.model(model_input, noise=noise)
         fl = fused_losses(self.loss, self.loss_n, out, ground_truth, model_input, count) if self.FUSED_LOSSES else None
+        if fl is None and torch.is_tensor(count):
+            count = int(count.item())
         if fl is not None:  # both loss modules in two launches forward / one backward (csrc/loss.hip)
             loss, terms, terms_n = fl
             terms = dict(terms)

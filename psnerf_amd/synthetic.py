@@ -100,7 +100,7 @@ def stage1_batch(cfg, h=64, w=80, seed=0):
             'img.normal': normal, 'img.norm_mask': (torch.rand(1, h, w, generator=g) > 0.2).float()}
 
 
-def stage2_inputs(n_pixels, n_lights, n_vis, seed=0, surface_frac=0.9, h=512, w=612, device='cpu'):
+def stage2_inputs(n_pixels, n_lights, n_vis, seed=0, surface_frac=0.9, h=512, w=612, device='cpu', with_surface_idx=False):
     """Synthetic stage-2 model_input / ground_truth (keys of stage2/model/renderer.py:110-125 and
     stage2/trainer.py:364-392): points U(-0.6,0.6)^3, unit normals, lights in the camera hemisphere."""
     g = torch.Generator().manual_seed(seed)
@@ -132,6 +132,8 @@ def stage2_inputs(n_pixels, n_lights, n_vis, seed=0, surface_frac=0.9, h=512, w=
         'visibility': (torch.rand(n_lights, n_pixels, generator=g) < 0.7).float(),
     }
     gt = {'rgb': torch.rand(n_lights, n_pixels, 3, generator=g)}
+    if with_surface_idx:  # what handoff.ViewSampler.batch adds on the host: the index list of the surface pixels
+        inp['surface_idx'] = surface_mask[0].nonzero(as_tuple=True)[0]
     if device != 'cpu':
         inp = {k: v.to(device) for k, v in inp.items()}
         gt = {k: v.to(device) for k, v in gt.items()}

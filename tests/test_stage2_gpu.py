@@ -352,3 +352,22 @@ def test_fused_losses_match_modules(cuda, loss_type, phase):
     out = net(inp2)
     total, t, tn = fused_losses(main, normal, out, gt, inp2, 0)
     assert float(total) == 0.0 and float(t['sg_rgb_loss']) == 0.0
+
+
+def test_surface_idx_from_the_data_pipeline(cuda):
+    """A batch that carries 'surface_idx' (the index list handoff.ViewSampler.batch builds on the host) gives bit-identical
+    outputs to one whose list PSNetwork.forward derives itself with nonzero(); a TrainStep on it needs no host round trip."""
+    import psnerf_amd.stage2 as s2
+    net = s2.PSNetwork(s2.bear_conf()).to(cuda)
+    inp, gt = stage2_inputs(900, 4, 2, seed=8, device=cuda)
+    inp2, _ = stage2_inputs(900, 4, 2, seed=8, device=cuda, with_surface_idx=True)
+    assert torch.equal(inp2['surface_idx'], inp['surface_mask'][0].nonzero(as_tuple=True)[0])
+    nz = torch.randn(int(inp['surface_mask'].sum()), 3, device=cuda) * 0.01
+    a, b = net(inp, noise={'xyz': nz}), net(inp2, noise={'xyz': nz})
+    for k in a:
+        if torch.is_tensor(a[k]):
+            assert torch.equal(a[k], b[k]), k
+    step = s2.TrainStep(net, s2.bear_conf(), 8, torch.nn.functional.normalize(torch.randn(8, 3), dim=-1).to(cuda), cuda)
+    step.cur_iter = 5001
+    t1, _ = step.step(inp2, gt, torch.arange(4, device=cuda), train_order=False, noise={'xyz': nz})
+    assert bool(torch.isfinite(t1['total']))
