@@ -28,14 +28,14 @@ def camera_origin(n_points, world_mat):
 def pixel_rays(pixels, camera_mat, world_mat):
     """stage1/model/common.py:210-226 -- both pixel axes are divided by fx = K[0,0,0] (reference quirk)."""
     q = (pixels - camera_mat[0, :2, 2]) / camera_mat[0, 0, 0]
-    q = torch.cat([q, torch.ones_like(q[..., :1])], dim=2)
-    return torch.einsum('bij,bnj->bni', world_mat[:, :3, :3], q)
+    R = world_mat[:, :3, :3]  # d_i = R_i0 qx + R_i1 qy + R_i2 (broadcast products; no library GEMM on the path)
+    return q[..., 0:1] * R[:, None, :, 0] + q[..., 1:2] * R[:, None, :, 1] + R[:, None, :, 2]
 
 
 def sphere_intersection(cam_loc, ray_dirs, r=1.0):
     """stage1/model/rendering.py:576-596."""
     n_img, n_pix, _ = ray_dirs.shape
-    b = torch.bmm(ray_dirs, cam_loc.unsqueeze(-1)).squeeze(-1).reshape(-1)
+    b = (ray_dirs * cam_loc.unsqueeze(1)).sum(-1).reshape(-1)
     under = b ** 2 - (cam_loc.norm(2, 1).reshape(-1, 1).expand(n_img, n_pix).reshape(-1) ** 2 - r ** 2)
     hit = under > 0
     root = torch.sqrt(under.clamp(min=0))

@@ -84,7 +84,9 @@ class Trainer(object):
                 norm_mask_gt[normal_gt[..., -1] < np.cos(np.deg2rad(self.angle))] = False
             flip = torch.ones(1, 1, 3, device=dev)
             flip[..., 1:] = -1.0  # (1, -1, -1) without a host-to-device copy
-            normal_gt = torch.einsum('bij,bnj->bni', world_mat[:, :3, :3] * flip, normal_gt)
+            Rf = world_mat[:, :3, :3] * flip  # rotation as broadcast products (no library GEMM on the path)
+            normal_gt = (normal_gt[..., 0:1] * Rf[:, None, :, 0] + normal_gt[..., 1:2] * Rf[:, None, :, 1]
+                         + normal_gt[..., 2:3] * Rf[:, None, :, 2])
         norm_count = int(norm_mask_gt.sum()) if normal_gt is not None else None
         valid_count = int(mask_valid.sum()) if self.mask_loss else None
         out = self.model(pix, camera_mat, world_mat, scale_mat, self.rendering_technique, it=it, eval_=eval_mode,

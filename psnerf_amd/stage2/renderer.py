@@ -39,7 +39,10 @@ def camera_rays(uv, pose, intrinsics):
     z = torch.ones_like(uv[:, :, 0])
     x = (uv[:, :, 0] - cx.unsqueeze(-1)) / fx.unsqueeze(-1) * z
     y = (uv[:, :, 1] - cy.unsqueeze(-1)) / fy.unsqueeze(-1) * z
-    d = torch.einsum('bij,bnj->bni', pose[:, :3, :3], torch.stack((x, y, z), dim=-1))
+    # d_i = R_i0 x + R_i1 y + R_i2 z as broadcast products (an einsum / bmm here would be the only library GEMM call of the
+    # whole path: three multiply-adds per ray need no matrix kernel)
+    R = pose[:, :3, :3]
+    d = x.unsqueeze(-1) * R[:, None, :, 0] + y.unsqueeze(-1) * R[:, None, :, 1] + z.unsqueeze(-1) * R[:, None, :, 2]
     return F.normalize(d, dim=2), pose[:, :3, 3]
 
 
