@@ -1,7 +1,7 @@
 #!/bin/bash
 # end-of-round measurement set (round 2): everything quoted in DESIGN.md / profiles/README.md
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=r02z
+TAG=${1:-r02z}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 bash $R/tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
