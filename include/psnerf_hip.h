@@ -144,6 +144,14 @@ int psn_sample_points(const float* origin, const float* dir, const float* dist, 
                       int64_t n, int hit, float near, float delta, const float* u0, const float* omu0, int c0,
                       const float* u1, const float* omu1, int c1, const float* noise, float* out, void* stream);
 
+/* Both ray groups of a stage-1 step in one launch: ray r uses the hit profile (as hit = 1 above, with dist / delta /
+ * u0 / u1) if flags[r] != 0 and the free-space profile d = near * omum + far * um over all c0 + c1 samples otherwise
+ * (flags [n] bytes: the renderer's hit mask).  No index lists, hence no nonzero() / host synchronisation. */
+int psn_sample_points_flagged(const float* origin, const float* dir, const float* dist, const float* far,
+                              const unsigned char* flags, int64_t n, float near, float delta, const float* u0, const float* omu0,
+                              int c0, const float* u1, const float* omu1, int c1, const float* um, const float* omum,
+                              const float* noise, float* out, void* stream);
+
 /* ------------------------------------------------------------------------
  * Fully fused MLP inference (activations never leave registers).  Replaces the
  * no-grad network evaluations: stage2 visibility_net over L*Ns rows

@@ -24,6 +24,8 @@ struct SampleArgs {
     const float* u0; const float* omu0;  // [c0] linspace(0,1,c0) and 1 - it
     const float* u1; const float* omu1;  // [c1] or nullptr
     const float* noise;    // [n, c0 + c1] or nullptr
+    const unsigned char* flags;          // [N] per-ray group (1 = hit profile, 0 = miss profile) or nullptr = `hit` for all
+    const float* um; const float* omum;  // [c0 + c1] linspace(0,1) / 1 - it: the miss profile when flags != nullptr
     float* out;            // [N, c0 + c1, 3]
     int64_t n;
     int c0, c1, hit;
@@ -44,7 +46,11 @@ __global__ __launch_bounds__(256) void sample_points_kernel(SampleArgs a) {
     const int s = (int)(e % S);
     const int64_t ray = a.idx != nullptr ? a.idx[r] : r;
     float lo0, hi0, lo1 = 0.f, hi1 = 0.f;
-    if (a.hit) {
+    // per-ray group flags: both ray groups of a step in ONE launch without index lists (which would have to come from a
+    // nonzero() = a host synchronisation); a miss ray then reads the single-segment table um / omum
+    const bool is_hit = a.flags != nullptr ? a.flags[ray] != 0 : a.hit != 0;
+    const bool miss_tab = a.flags != nullptr && !is_hit;
+    if (is_hit) {
         const float d = a.dist[ray];
         float dnp = d - a.delta, dfp = d + a.delta;
         dnp = dnp < a.near ? a.near : dnp;
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256) void sample_points_kernel(SampleArgs a) {
     // near (1 - u) + near u wobbles by an ulp) -- so the sequence is scanned once and only a non-monotonic ray pays for
     // a rank-based selection of its sorted depths.
     bool mono = true;
-    if (a.c1 > 0) {
+    if (a.c1 > 0 && !miss_tab) {
         float prev = profile_depth(a, 0, lo0, hi0, lo1, hi1);
         for (int i = 1; i < S; ++i) {
             const float cur = profile_depth(a, i, lo0, hi0, lo1, hi1);
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(256) void sample_points_kernel(SampleArgs a) {
         }
     }
     auto depth_at = [&](int pos) -> float {
+        if (miss_tab) return lo0 * a.omum[pos] + hi0 * a.um[pos];
         if (mono) return profile_depth(a, pos, lo0, hi0, lo1, hi1);
         for (int j = 0; j < S; ++j) {  // the element whose (stable) rank is pos
             const float vj = profile_depth(a, j, lo0, hi0, lo1, hi1);
@@ -99,9 +106,10 @@ __global__ __launch_bounds__(256) void sample_points_kernel(SampleArgs a) {
 
 }  // namespace psn
 
-extern "C" int psn_sample_points(const float* origin, const float* dir, const float* dist, const float* far, const int64_t* idx,
-                                 int64_t n, int hit, float near, float delta, const float* u0, const float* omu0, int c0,
-                                 const float* u1, const float* omu1, int c1, const float* noise, float* out, void* stream) {
+static int sample_points_impl(const float* origin, const float* dir, const float* dist, const float* far, const int64_t* idx,
+                              int64_t n, int hit, float near, float delta, const float* u0, const float* omu0, int c0,
+                              const float* u1, const float* omu1, int c1, const float* noise, const unsigned char* flags,
+                              const float* um, const float* omum, float* out, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(origin && dir && far && out && u0 && omu0 && c0 >= 1, "sample_points: null pointer or empty profile");
     PSN_CHECK_ARG(!hit || dist, "sample_points: hit rays need their surface depth");
@@ -110,12 +118,30 @@ extern "C" int psn_sample_points(const float* origin, const float* dir, const fl
     SampleArgs a;
     a.origin = origin; a.dir = dir; a.dist = dist; a.far = far; a.idx = idx; a.u0 = u0; a.omu0 = omu0; a.u1 = u1; a.omu1 = omu1;
     a.noise = noise; a.out = out; a.n = n; a.c0 = c0; a.c1 = c1; a.hit = hit; a.near = near; a.delta = delta;
+    a.flags = flags; a.um = um; a.omum = omum;
+    PSN_CHECK_ARG(flags == nullptr || (um && omum && dist && idx == nullptr), "sample_points: per-ray flags need the miss table, dist and no index list");
     const int64_t total = n * (int64_t)(c0 + c1);
     const int64_t blocks = (total + 255) / 256;
     PSN_CHECK_ARG(blocks < (1ll << 31), "sample_points: too many samples");
     hipLaunchKernelGGL(sample_points_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("sample_points");
     return PSN_OK;
+}
+
+extern "C" int psn_sample_points(const float* origin, const float* dir, const float* dist, const float* far, const int64_t* idx,
+                                 int64_t n, int hit, float near, float delta, const float* u0, const float* omu0, int c0,
+                                 const float* u1, const float* omu1, int c1, const float* noise, float* out, void* stream) {
+    return sample_points_impl(origin, dir, dist, far, idx, n, hit, near, delta, u0, omu0, c0, u1, omu1, c1, noise, nullptr, nullptr,
+                              nullptr, out, stream);
+}
+
+extern "C" int psn_sample_points_flagged(const float* origin, const float* dir, const float* dist, const float* far,
+                                         const unsigned char* flags, int64_t n, float near, float delta, const float* u0,
+                                         const float* omu0, int c0, const float* u1, const float* omu1, int c1, const float* um,
+                                         const float* omum, const float* noise, float* out, void* stream) {
+    PSN_CHECK_ARG(flags != nullptr, "sample_points_flagged: null flags");
+    return sample_points_impl(origin, dir, dist, far, nullptr, n, 1, near, delta, u0, omu0, c0, u1, omu1, c1, noise, flags, um, omum,
+                              out, stream);
 }
 
 // ---- secant refinement step (stage1/model/rendering.py:525-555) ------------------------------------------------------

@@ -90,6 +90,7 @@ SIGNATURES = {
     'psn_gemm_tn_grouped': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
     'psn_colsum': (i32, [c_f, c_f, i32, i64, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_sample_points': (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f]),
+    'psn_sample_points_flagged': (i32, [c_f, c_f, c_f, c_f, c_f, i64, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f]),
     'psn_mlp_pack_layer': (i32, [c_f, i64, i32, i32, i32, i32, i32, c_f, c_f]),
     'psn_mlp_pack_layers': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_sg_shade_fwd': (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, i32, i64, i32, i32, c_f, c_f, c_f]),
@@ -247,6 +248,24 @@ def sample_points(origin, direction, far, out, hit, near, u0, idx=None, dist=Non
                                   _ptr(u0[0], 'u0'), _ptr(u0[1], 'omu0'), c0,
                                   None if u1 is None else _ptr(u1[0], 'u1'), None if u1 is None else _ptr(u1[1], 'omu1'), c1,
                                   _ptr(noise, 'noise', True), _ptr(out, 'out'), _stream()), 'sample_points')
+    return out
+
+
+def sample_points_flagged(origin, direction, dist, far, flags, out, near, delta, u0, u1, u_miss, noise=None):
+    """Every ray of out [N,S,3] in one launch: hit profile where flags (bool [N]) is set, free-space profile elsewhere
+    (psn_sample_points_flagged).  u0 / u1 / u_miss: (linspace, 1 - linspace) pairs; u1 may be None (S = c0)."""
+    n = origin.shape[0]
+    c0 = u0[0].numel()
+    c1 = 0 if u1 is None else u1[0].numel()
+    assert out.shape[1] == c0 + c1 == u_miss[0].numel() and out.is_contiguous()
+    assert flags.dtype == torch.bool and flags.is_cuda and flags.is_contiguous() and flags.numel() == n
+    if noise is not None:
+        assert noise.numel() == n * (c0 + c1)
+    _check(_lib.psn_sample_points_flagged(_ptr(origin, 'origin'), _ptr(direction, 'direction'), _ptr(dist, 'dist'), _ptr(far, 'far'),
+                                          flags.data_ptr(), n, float(near), float(delta), _ptr(u0[0], 'u0'), _ptr(u0[1], 'omu0'), c0,
+                                          None if u1 is None else _ptr(u1[0], 'u1'), None if u1 is None else _ptr(u1[1], 'omu1'), c1,
+                                          _ptr(u_miss[0], 'um'), _ptr(u_miss[1], 'omum'), _ptr(noise, 'noise', True), _ptr(out, 'out'),
+                                          _stream()), 'sample_points_flagged')
     return out
 
 

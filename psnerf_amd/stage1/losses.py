@@ -14,9 +14,17 @@ class Loss(nn.Module):
         self.norm_weight, self.mask_weight = norm_weight, mask_weight
         self.device = device
         self.global_sum = None  # callable(int) -> int summed over ranks (set by the DP trainer)
+        self.global_count = None  # callable(bool mask) -> device float [1], summed over ranks (sync-free path)
+        self._rays_global = {}    # local ray count -> ray count summed over ranks
 
     def _g(self, n):
         return n if self.global_sum is None else self.global_sum(n)
+
+    def _count(self, mask):
+        """Masked-element count as a device tensor (no host synchronisation), summed over ranks under DP."""
+        if self.global_count is not None:
+            return self.global_count(mask)
+        return mask.sum().to(torch.float32).reshape(1)
 
     def forward(self, out_dict, rgb_gt, normal_gt=None, norm_mask=None, mask=None, mask_gt=None, mask_valid=None,
                 norm_count=None, valid_count=None):
@@ -28,17 +36,32 @@ class Loss(nn.Module):
         zero = torch.zeros((), device=dev)  # a fill kernel: torch.tensor(0.0, device=...) is a pageable H2D copy = a stream sync
         rgb_gt = rgb_gt.to(dev)
         if self.full_weight != 0.0:
-            l_rgb = (rgb - rgb_gt).abs().sum() / float(self._g(rgb.shape[1]))
+            # (the ray count of a shard is fixed by n_training_points and the world size: its global sum is exchanged once)
+            n_local = rgb.shape[1]
+            if n_local not in self._rays_global:
+                self._rays_global[n_local] = self._g(n_local)
+            l_rgb = (rgb - rgb_gt).abs().sum() / float(self._rays_global[n_local])
         else:
             l_rgb = zero
-        if diff_norm is not None and self.grad_weight != 0.0:
+        dev_counts = out_dict.get('diff_norm_full') is not None  # the renderer's sync-free training forward
+        if dev_counts and self.grad_weight != 0.0:
+            # mean over the hit rays of a full-size [N] tensor: masked sum / device-resident hit count (0 for no hits)
+            hit = out_dict['mask_pred'].reshape(-1)
+            dn = out_dict['diff_norm_full']
+            l_grad = torch.where(hit, dn, dn.new_zeros(())).sum() / self._count(hit).clamp(min=1.0)[0]
+        elif diff_norm is not None and self.grad_weight != 0.0:
             n_hit = self._g(diff_norm.shape[0])
             l_grad = zero if n_hit == 0 else diff_norm.sum() / float(n_hit)
         else:
             l_grad = zero
         loss = self.full_weight * l_rgb + self.grad_weight * l_grad
         terms = {'fullrgb_loss': l_rgb, 'grad_loss': l_grad}
-        if normal is not None and normal_gt is not None:
+        if normal is not None and normal_gt is not None and dev_counts and norm_count is None:
+            d_n = (normal - normal_gt).abs()
+            l_n = torch.where(norm_mask.bool().unsqueeze(-1), d_n, d_n.new_zeros(())).sum() / self._count(norm_mask.bool()).clamp(min=1.0)[0]
+            loss = loss + self.norm_weight * l_n
+            terms['normal_loss'] = l_n
+        elif normal is not None and normal_gt is not None:
             cnt = self._g(int(norm_mask.sum()) if norm_count is None else norm_count)
             if cnt > 0:
                 # masked sum instead of the reference's boolean gathers (each a nonzero + host synchronisation)
@@ -47,7 +70,12 @@ class Loss(nn.Module):
                 l_n = torch.where(norm_mask.bool().unsqueeze(-1), d_n, d_n.new_zeros(())).sum() / float(cnt)
                 loss = loss + self.norm_weight * l_n
                 terms['normal_loss'] = l_n
-        if mask is not None and mask_gt is not None:
+        if mask is not None and mask_gt is not None and dev_counts and valid_count is None:
+            bce = F.binary_cross_entropy(mask.clamp(0, 1), mask_gt, reduction='none')
+            l_m = torch.where(mask_valid.bool(), bce, bce.new_zeros(())).sum() / self._count(mask_valid.bool()).clamp(min=1.0)[0]
+            loss = loss + self.mask_weight * l_m
+            terms['mask_loss'] = l_m
+        elif mask is not None and mask_gt is not None:
             cnt = self._g(int(mask_valid.sum()) if valid_count is None else valid_count)
             bce = F.binary_cross_entropy(mask.clamp(0, 1), mask_gt, reduction='none')  # log terms are clamped at -100: finite
             l_m = torch.where(mask_valid.bool(), bce, bce.new_zeros(())).sum() / float(max(cnt, 1))

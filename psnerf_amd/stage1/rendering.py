@@ -244,6 +244,8 @@ class Renderer(nn.Module):
 
         cam, rays, dists, obj_mask, points = self._surface(pixels, camera_mat, world_mat, cfg['ray_marching_steps'])
         far = self._last_far  # = sphere_intersection(cam, rays, r)[..., 1], already computed for the sweep
+        if self.sync_free and not eval_ and not noise and near > 0 and pixels.is_cuda:
+            return self._unisurf_sync_free(cam, rays, dists, obj_mask, points, far, it, add_noise)
 
         # hit / miss ray lists ONCE (two nonzero() = the data-dependent host synchronisations of this function); every
         # gather / scatter below is an index op with them instead of a boolean mask (each of which would sync again)
@@ -311,6 +313,48 @@ class Renderer(nn.Module):
             'normal_pred': norm_pred.reshape(B, -1, 3),
             'acc_map': acc.reshape(B, -1),
         }
+
+    sync_free = False  # set by the Trainer: training forward without host synchronisation (see _unisurf_sync_free)
+
+    def _unisurf_sync_free(self, cam, rays, dists, obj_mask, points, far, it, add_noise):
+        """The training forward of unisurf() (rendering.py:110-224) without a single host synchronisation.  The
+        reference-shaped path above needs the hit / miss ray LISTS (two nonzero() calls) because it samples the two
+        groups separately, evaluates the surface normals on the compacted hit points and returns a compact
+        ``diff_norm [N_hit]``.  Here both groups are sampled by one launch that reads the per-ray hit flag
+        (psn_sample_points_flagged), the normals are evaluated for ALL rays (2 N instead of 2 N_hit points next to N S
+        render samples: +1 %) and masked, and the smoothness term is returned as ``diff_norm_full [N]`` + ``mask_pred``
+        for a masked sum over a device-resident count (Loss).  Same arithmetic per ray; the random draws have the
+        reference's distribution but not its stream order (group-sized draws need the group sizes on the host) --
+        parity tests inject their noise and therefore take the reference-shaped path."""
+        cfg = self.cfg
+        dev = cam.device
+        N = cam.shape[0]
+        steps, steps_out = cfg['num_points_in'], cfg['num_points_out']
+        near = float(self.depth_range[0])
+        delta = float(torch.max(cfg['interval_start'] * torch.exp(-1 * cfg['interval_decay'] * it * torch.ones(1)),
+                                cfg['interval_end'] * torch.ones(1)))
+        full_steps = steps + steps_out if it > 5000 else steps  # near > 0: (dnp != 0).all() holds (rendering.py:124)
+        nz = torch.rand(N * full_steps, device=dev) if add_noise else None
+        p_fg = torch.empty(N, full_steps, 3, device=dev)
+        flags = obj_mask.contiguous()
+        if full_steps != steps:
+            hip.sample_points_flagged(cam, rays, dists.contiguous(), far, flags, p_fg, near, delta, self._u(steps_out, dev),
+                                      self._u(steps, dev), self._u(full_steps, dev), noise=nz)
+        else:
+            hip.sample_points_flagged(cam, rays, dists.contiguous(), far, flags, p_fg, near, delta, self._u(steps, dev), None,
+                                      self._u(full_steps, dev), noise=nz)
+        p_fg = p_fg.reshape(-1, 3)
+        view = (-1 * rays).unsqueeze(-2).expand(-1, full_steps, -1).reshape(-1, 3)
+        pp = torch.cat([points, points + (torch.rand_like(points) - 0.5) * 0.01], dim=0)  # every ray; masked below
+        rgb, alpha = self.model(p_fg, view, return_addocc=True)
+        rgb_values, acc = ops.alpha_composite(alpha.reshape(N, full_steps), rgb.reshape(N, full_steps, 3),
+                                              bool(self.white_background))
+        g = self.model.gradient(pp)[:, 0, :]
+        nrm = g / (g.norm(2, dim=1).unsqueeze(-1) + 10 ** (-5))
+        norm_pred = torch.where(flags.unsqueeze(-1), nrm[:N], torch.zeros_like(nrm[:N]))
+        diff_full = torch.norm(nrm[:N] - nrm[N:], dim=-1)
+        return {'rgb': rgb_values.reshape(1, -1, 3), 'mask_pred': obj_mask, 'diff_norm': None, 'diff_norm_full': diff_full,
+                'normal_pred': norm_pred.reshape(1, -1, 3), 'acc_map': acc.reshape(1, -1)}
 
     # ---- stage1/model/rendering.py:297-376 -------------------------------------------------------
     @torch.no_grad()

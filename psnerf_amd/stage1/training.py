@@ -33,6 +33,10 @@ class Trainer(object):
         self.dp = dp if dp is not None else DataParallel(device)
         if self.dp.enabled:
             self.loss.global_sum = self.dp.global_sum_int
+            self.loss.global_count = self.dp.global_count_tensor
+        # training forward without host synchronisation (Renderer._unisurf_sync_free); a caller that injects noise or
+        # needs the reference-shaped out_dict (compact diff_norm) gets the reference-shaped path
+        self.sync_free = bool(kwargs.get('sync_free', True))
 
     def train_step(self, data, it=None, pix=None, noise=None):
         self.model.train()
@@ -87,8 +91,14 @@ class Trainer(object):
             Rf = world_mat[:, :3, :3] * flip  # rotation as broadcast products (no library GEMM on the path)
             normal_gt = (normal_gt[..., 0:1] * Rf[:, None, :, 0] + normal_gt[..., 1:2] * Rf[:, None, :, 1]
                          + normal_gt[..., 2:3] * Rf[:, None, :, 2])
-        norm_count = int(norm_mask_gt.sum()) if normal_gt is not None else None
-        valid_count = int(mask_valid.sum()) if self.mask_loss else None
+        sync_free = (self.sync_free and not noise and not eval_mode and self.rendering_technique == 'unisurf'
+                     and hasattr(self.model, '_unisurf_sync_free') and pix.is_cuda)
+        if hasattr(self.model, 'sync_free'):
+            self.model.sync_free = sync_free
+        # mask counts: on the device in the sync-free path (Loss divides by them there), else on the host BEFORE the
+        # network call (so that no synchronisation sits between forward and backward)
+        norm_count = int(norm_mask_gt.sum()) if (normal_gt is not None and not sync_free) else None
+        valid_count = int(mask_valid.sum()) if (self.mask_loss and not sync_free) else None
         out = self.model(pix, camera_mat, world_mat, scale_mat, self.rendering_technique, it=it, eval_=eval_mode,
                          noise=noise)
         mask_pred = out.get('acc_map')

@@ -199,3 +199,45 @@ def test_train_step_vs_oracle(cuda):
         d = (v.cpu() - osd[k]).abs()
         assert float(d.max()) <= 2 * 2 * 1e-4 + 1e-6, 'param %s max diff %.3e' % (k, float(d.max()))
         assert float(d.mean()) <= 1e-5, 'param %s mean diff %.3e' % (k, float(d.mean()))
+
+
+def test_sync_free_training_forward_matches_reference_shaped_path(cuda, monkeypatch):
+    """Renderer._unisurf_sync_free (both ray groups in one flagged sampling launch, normals of every ray masked, loss
+    denominators on the device) against the reference-shaped path (index lists, compact diff_norm, host counts): same
+    outputs, same loss terms, same parameter gradients -- with the random offsets pinned to a constant in both."""
+    from psnerf_amd.stage1 import Loss, NeuralNetwork, Renderer
+    from psnerf_amd.synthetic import stage1_camera
+    monkeypatch.setattr(torch, 'rand_like', lambda t, **k: torch.full_like(t, 0.75))
+    cfg = stage1_cfg('bunny')
+    sd = stage1_state_dict(cfg, seed=11)
+    h, w = 48, 64
+    K, c2w, S = stage1_camera(cfg, h=h, w=w)
+    gen = torch.Generator().manual_seed(5)
+    n = 200
+    pix = torch.stack([torch.randint(0, w, (n,), generator=gen).float(), torch.randint(0, h, (n,), generator=gen).float()], -1)[None].to(cuda)
+    rgb_gt = torch.rand(1, n, 3, generator=gen).to(cuda)
+    ngt = torch.nn.functional.normalize(torch.randn(1, n, 3, generator=gen), dim=-1).to(cuda)
+    nmask = (torch.rand(1, n, generator=gen) > 0.3).to(cuda)
+    res = []
+    for it in (100, 6000):
+        pair = []
+        for sync_free in (False, True):
+            net = NeuralNetwork(cfg)
+            net.load_state_dict(sd)
+            ren = Renderer(net, cfg, device=cuda)
+            ren.sync_free = sync_free
+            out = ren(pix, K.to(cuda), c2w.to(cuda), S.to(cuda), 'unisurf', add_noise=False, eval_=False, it=it)
+            assert (out.get('diff_norm_full') is not None) == sync_free
+            terms = Loss(1.0, 0.005, 0.05, 1.0, device=cuda)(out, rgb_gt, ngt, nmask)
+            terms['loss'].backward()
+            pair.append((out, terms, {k: v.grad.clone() for k, v in net.named_parameters()}))
+        (o0, t0, g0), (o1, t1, g1) = pair
+        assert torch.equal(o0['mask_pred'], o1['mask_pred']) and int(o0['mask_pred'].sum()) > 0
+        for k in ('rgb', 'acc_map', 'normal_pred'):
+            assert_close(o1[k].detach().cpu(), o0[k].detach().cpu(), 1e-6, '%s it%d' % (k, it), atol=ATOL_UNIT)
+        hit = o0['mask_pred']
+        assert_close(o1['diff_norm_full'][hit].detach().cpu(), o0['diff_norm'].detach().cpu(), 1e-5, 'diff_norm it%d' % it, atol=1e-7)
+        for k in t0:
+            assert_close(float(t1[k].detach()), float(t0[k].detach()), 1e-5, '%s it%d' % (k, it), atol=0.0)
+        for k in g0:
+            assert_close(g1[k].cpu(), g0[k].cpu(), 1e-4, 'grad %s it%d' % (k, it))
