@@ -274,3 +274,16 @@ def test_masked_losses_ignore_nonfinite_values_outside_the_mask():
     valid[0, 2] = False
     t = Loss(1.0, 0.1, 0.5, 0.7)(out, torch.rand(1, n, 3), ngt, nmask, acc, mgt, valid)
     assert all(bool(torch.isfinite(v)) for v in t.values())
+
+
+def test_gen_light_xyz_vs_reference_eval_utils():
+    """psnerf_amd.stage2.relight.gen_light_xyz against the outputs of the reference's own utils/eval_utils.gen_light_xyz
+    (16 x 32 lat-long grid of stage2/eval.py:203; fixture written by tools/gen_golden.py, which also checks split_input /
+    merge_output against utils/general.py)."""
+    import numpy as np
+    from psnerf_amd.stage2 import relight
+    from tests.helpers import GOLDEN
+    import os
+    g = np.load(os.path.join(GOLDEN, 'stage2_light_xyz.npz'))
+    xyz, areas = relight.gen_light_xyz(16, 32, envmap_radius=1)
+    assert np.array_equal(xyz, g['xyz']) and np.array_equal(areas, g['areas'])

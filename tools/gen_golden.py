@@ -232,7 +232,7 @@ def gen_stage2():
     # harness-side shims (no reference edits): the REAL utils/rend_util.py is imported; only the third-party modules it
     # needs at import time and that this image lacks (imageio incl. its download-at-import, skimage, cv2) are empty
     # placeholders in sys.modules -- get_camera_params / lift (rend_util.py:90-147) use none of them.
-    for name in ('imageio', 'imageio.plugins', 'imageio.plugins.freeimage', 'skimage', 'cv2'):
+    for name in ('imageio', 'imageio.plugins', 'imageio.plugins.freeimage', 'skimage', 'cv2'):  # (eval_utils needs imageio + cv2 too)
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
     sys.modules['imageio'].plugins = sys.modules['imageio.plugins']
@@ -260,6 +260,32 @@ def gen_stage2():
     check('camera loc', loc_o, loc_r, 0.0)
     np.savez_compressed(os.path.join(GOLDEN, 'stage2_camera.npz'), uv=np_(uv_c), K=np_(K_c), pose=np_(pose_c),
                         ray_dirs=np_(rd_r), cam_loc=np_(loc_r))
+
+    # ---- environment-map light grid + pixel split / merge: the reference's own eval_utils / general modules
+    from utils import eval_utils as REVAL
+    from utils import general as RGEN
+    from psnerf_amd.stage2 import relight as prl
+    assert os.path.realpath(REVAL.__file__).startswith(os.path.realpath(REF))
+    xyz_r, areas_r = REVAL.gen_light_xyz(16, 32, envmap_radius=1)   # eval.py:203 uses the default radius; direction is normalised after
+    xyz_p, areas_p = prl.gen_light_xyz(16, 32, envmap_radius=1)
+    check('gen_light_xyz', xyz_p, xyz_r, 1e-15)
+    check('gen_light_xyz areas', areas_p, areas_r, 1e-15)
+    npx = 2500  # the reference splits into chunks of 1024 pixels (general.py:28)
+    mi = {'uv': torch.rand(1, npx, 2), 'points': torch.rand(1, npx, 3), 'intrinsics': torch.eye(4)[None],
+          'object_mask': torch.rand(1, npx) > 0.5}
+    sp_r = RGEN.split_input(dict(mi), npx)
+    sp_p = prl.split_input(dict(mi), npx, n_pixels=1024)
+    assert len(sp_r) == len(sp_p) == 3
+    for a, b in zip(sp_r, sp_p):
+        for k in ('uv', 'points', 'object_mask'):
+            assert torch.equal(a[k], b[k]), k
+    res = [{'sg_rgb_values': torch.rand(2, 1024, 3), 'mask': torch.rand(1, 1024) > 0.5} for _ in range(2)] + \
+          [{'sg_rgb_values': torch.rand(2, 452, 3), 'mask': torch.rand(1, 452) > 0.5}]
+    mr, mp = RGEN.merge_output(res, npx, 1), prl.merge_output(res, npx, 1)
+    for k in mr:
+        assert torch.equal(mr[k], mp[k]), k
+    np.savez_compressed(os.path.join(GOLDEN, 'stage2_light_xyz.npz'), xyz=xyz_r, areas=areas_r)
+    print('  [ok ] relight helpers == reference eval_utils.gen_light_xyz / general.split_input / merge_output')
 
     # ---- normal jitter > 0 (renderer.py:133-140; bear.conf has 0): TWO torch.normal draws, normal jitter first
     conf_j = o2.bear_conf(**{'normal.net.xyz_jitter_std': 0.02})
