@@ -3,12 +3,15 @@
 
 state_dict keys are the reference's (``lin{l}.{bias,weight_g,weight_v}``, ``lina{l}.*``), so released
 checkpoints load unchanged.  Mapping to kernels:
-  * training / with-graph evaluation  -> ops.GeoField (value pass + reverse-mode spatial-gradient sweep
-    + hand-written double backward, all fp32-MFMA GEMMs) and ops.ReluMLP (appearance net);
-  * no-grad occupancy queries (ray marching, secant, shadow rays) -> the register-resident fused
-    inference kernel (fused.pack_geo_occupancy), re-packed once per optimiser step.
-Weight normalisation (w = g * v / |v|) is evaluated with torch ops on the (tiny) weight tensors so that
-autograd carries dW back to weight_g / weight_v.
+  * training / with-graph evaluation  -> ops.GeoFieldFused (value pass, reverse-mode spatial-gradient sweep and the
+    hand-written adjoints of both as four launches of the register-resident chain engine + one grouped weight-gradient
+    launch) and ops.AppNetFused (appearance net); networks the engine does not hold (hidden width != 256) fall back to
+    ops.GeoField / ops.ReluMLP (fp32-MFMA GEMM sequences);
+  * no-grad occupancy queries (ray-march sweep, shadow rays) -> the lean register-resident engine
+    (fused.pack_geo_occupancy), re-packed once per optimiser step; the secant refinement -> psn_root_find, the same
+    engine iterating inside one launch.
+Weight normalisation (w = g * v / |v|) of all layers of a network is one launch forward / one backward
+(ops.WeightNormAll), so autograd carries dW back to weight_g / weight_v.
 """
 import numpy as np
 import torch

@@ -1,11 +1,14 @@
 """Stage-1 renderer with the reference's ``Renderer`` interface (stage1/model/rendering.py:9-555,
 minus the phong preview, which is out of scope -- SURVEY 2).
 
-Kernel mapping: every occupancy query without a graph (ray marching, secant refinement, shadow-ray
-light visibility) goes through the fused register-resident MLP kernel; the render samples go through
-ops.GeoField + the appearance MLP; the transmittance composite is the wave-scan kernel
-(ops.alpha_composite / hip.composite_fwd).  Ray set-up, interval sampling and the sign-change search
-are small elementwise torch ops on [N, S] tensors (host-side plumbing).
+Kernel mapping: every occupancy query without a graph (ray-march sweep, secant refinement, shadow-ray light
+visibility) goes through the register-resident occupancy engine -- the sweep as one launch over all N x M points, the
+first free -> occupied crossing as psn_first_crossing, ALL secant iterations inside one psn_root_find launch, the shadow
+rays only for the samples inside the +-1.1 box (psn_shadow_points); the render samples go through ops.GeoFieldFused + the
+appearance chains; the transmittance composite is the wave-scan kernel (ops.alpha_composite / hip.composite_fwd); depth
+profiles, stratified jitter and sample points are psn_sample_points launches.  Camera rays and the sphere intersection are
+a handful of elementwise torch ops on [N, 3] tensors.  The ray march never synchronises with the host; the training
+forward does not either when the Trainer selects Renderer._unisurf_sync_free.
 
 All random draws can be injected (``noise={'miss','hit','nbr'}``) for parity tests; by default they are
 drawn on the device.

@@ -8,12 +8,15 @@ state_dict keys ({albedo,rough,normal,visibility}_net.linears.{i}.{weight,bias},
 MI355X mapping:
   * positional encodings -> psn_pe_encode tables (one row per surface point / per light), padded to 64
     floats so every row is one aligned MFMA k-tile pair;
-  * albedo / rough / normal nets and the V supervision-light visibility rows -> ops.ReluMLP (fp32-MFMA
-    GEMMs with fused bias+ReLU / ReLU-mask epilogues, split-K weight gradients);
-  * the L shading-light visibility rows (97 % of the FLOPs, no gradient reaches them: renderer.py:197
-    detach + loss.py:82-83) -> ops.FusedPairMLP, the register-resident fused kernel, which never
-    materialises the [L*Ns, 126] input or any activation;
-  * SG shading -> ops.sg_shade (fused forward/backward kernel).
+  * visibility net: the L shading-light rows (97 % of the FLOPs; no gradient reaches them: renderer.py:197
+    detach + loss.py:82-83) and the V supervision-light rows in ONE launch of the register-resident engine
+    (ops.VisibilityPair: input block through per-point / per-light init tables, the supervised rows leave their
+    activations behind for a chain backward + grouped weight gradients); ops.FusedPairMLP when only the
+    shading rows exist (evaluation), the bf16 engine when the caller opts in;
+  * albedo / SG-weight / normal nets (128- and 64-wide) -> ops.FusedReluNet (one forward launch with dumps,
+    one backward chain, one grouped weight-gradient launch); other widths -> ops.ReluMLP (layer-wise GEMMs);
+  * SG / GGX shading -> ops.sg_shade / ops.mf_shade (fused forward / backward kernels);
+  * the dense [B, N, C] output dictionary -> one psn_scatter_rows launch (ops.ScatterRows).
 """
 import numpy as np
 import torch
