@@ -241,3 +241,72 @@ def test_sync_free_training_forward_matches_reference_shaped_path(cuda, monkeypa
             assert_close(float(t1[k].detach()), float(t0[k].detach()), 1e-5, '%s it%d' % (k, it), atol=0.0)
         for k in g0:
             assert_close(g1[k].cpu(), g0[k].cpu(), 1e-4, 'grad %s it%d' % (k, it))
+
+
+def test_root_finder_and_crossing_vs_stepwise_formulation(cuda):
+    """psn_first_crossing against the torch formulation of rendering.py:457-504, and psn_root_find (all secant iterations
+    in one launch, in-kernel positional encoding) against the step-by-step secant (one encoding + network + update launch
+    per iteration on the compacted rays, the round-1 path): identical masks, depths equal to fp32 round-off."""
+    from psnerf_amd import hip
+    from psnerf_amd.stage1.rendering import camera_origin, pixel_rays, sphere_intersection
+    from psnerf_amd.synthetic import stage1_camera
+    cfg, net, ren = _renderer(cuda)
+    h, w = 48, 64
+    K, c2w, S = stage1_camera(cfg, h=h, w=w)
+    gen = torch.Generator().manual_seed(9)
+    n = 333
+    pix = torch.stack([torch.randint(0, w, (n,), generator=gen).float(), torch.randint(0, h, (n,), generator=gen).float()], -1)[None].to(cuda)
+    cam = camera_origin(n, c2w.to(cuda))
+    rays = pixel_rays(pix, K.to(cuda), c2w.to(cuda))
+    rays = rays / rays.norm(2, 2).unsqueeze(-1)
+    with torch.no_grad():
+        st = ren._march_launch(cam, rays, 0.5, [256, 257], ren.depth_range, cfg['rendering']['radius'], False)
+        # -- first crossing vs the reference's tensor formulation
+        M = 256
+        u = ren._u(M, cuda)
+        p_prop = torch.empty(n, M, 3, device=cuda)
+        far = sphere_intersection(cam[:, 0], rays, r=cfg['rendering']['radius'])[0][..., 1].contiguous()
+        hip.sample_points(cam.reshape(-1, 3).contiguous(), rays.reshape(-1, 3).contiguous(), far.reshape(-1), p_prop, False,
+                          float(ren.depth_range[0]), u)
+        val = (ren._occ(p_prop.reshape(-1, 3)) - 0.5).view(1, n, M)
+        sgn = torch.cat([torch.sign(val[:, :, :-1] * val[:, :, 1:]), torch.ones(1, n, 1, device=cuda)], dim=-1)
+        cost = sgn * torch.arange(M, 0, -1, device=cuda).float()
+        values, idx = torch.min(cost, -1)
+        mask_ref = (values < 0) & (torch.gather(val, 2, idx.unsqueeze(-1)).squeeze(-1) < 0) & (val[:, :, 0] < 0)
+        flags = st['flags']
+        assert torch.equal((flags & 1).bool(), mask_ref.reshape(-1)) and torch.equal((flags & 2).bool(), (val[0, :, 0] < 0))
+        m = mask_ref.reshape(-1)
+        idx2 = torch.clamp(idx + 1, max=M - 1)
+        dep = lambda i: (float(ren.depth_range[0]) * u[1][i] + far * u[0][i]).reshape(-1)
+        gat = lambda i: torch.gather(val, 2, i.unsqueeze(-1)).reshape(-1)
+        for row, ref in enumerate((dep(idx), dep(idx2), gat(idx), gat(idx2))):
+            assert torch.equal(st['bracket'][row][m], ref[m]), 'bracket row %d' % row
+        # -- fused vs step-by-step secant
+        d_fused = ren._march_finish(st, 8)
+        d_step = ren._march_finish_compact(st, 8)
+    fin = torch.isfinite(d_step)
+    assert torch.equal(fin, torch.isfinite(d_fused)) and int(m.sum()) > 20
+    assert torch.equal(d_step == 0, d_fused == 0)
+    assert_close(d_fused[fin].cpu(), d_step[fin].cpu(), 1e-6, 'fused vs step-by-step secant', atol=1e-6)
+
+
+def test_shadow_ray_compaction_is_bit_identical(cuda):
+    """light_visibility with in-box compaction (psn_shadow_points) == the dense formulation of rendering.py:378-408
+    (every sample evaluated, out-of-box occupancies zeroed afterwards), bit for bit, incl. points outside the box."""
+    from psnerf_amd import hip
+    cfg, net, ren = _renderer(cuda)
+    g = torch.Generator().manual_seed(2)
+    surf = (torch.rand(300, 3, generator=g) * 2.4 - 1.2).to(cuda)  # some points outside the +-1.1 box
+    ld = torch.nn.functional.normalize(torch.randn(7, 3, generator=g), dim=-1).to(cuda)
+    with torch.no_grad():
+        v = ren.light_visibility(surf=surf, light_dir=ld)
+        n_in, n_all = ren.last_shadow_stats
+        t = torch.linspace(0, 1, steps=128, device=cuda).view(1, 128, 1)
+        d = 0.1 * (1.0 - t) + 3.5 * t
+        p = surf[None, :, None, :] + ld[:, None, None, :] * d[None]
+        alpha = ren._occ(p.reshape(-1, 3)).view(-1, 128)
+        inside = torch.logical_and((p <= 1.1).all(dim=-1), (p >= -1.1).all(dim=-1)).view(-1, 128)
+        assert n_in == int(inside.sum()) and 0 < n_in < n_all
+        alpha = torch.where(inside, alpha, torch.zeros_like(alpha)).contiguous()
+        ref = 1 - hip.composite_fwd(alpha, None, False, need_weights=False)[2]
+    assert torch.equal(v, ref)
