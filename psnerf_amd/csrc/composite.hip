@@ -242,6 +242,91 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     }
 }
 
+// Forward with every global access a contiguous one over the wave (the backward kernel's layout): lane l owns samples
+// l, l + 64, ..., the colours are read as the flat [3 S] row (element k = l + 64 j) and meet their weights through LDS.
+// fwd_ray's blocked layout (lane owns E consecutive samples) reads the colours with a 12 E-byte lane stride, which costs
+// ~10 % of the achieved HBM rate at S = 128 (4.8-5.1 TB/s there against 5.5 TB/s for the backward kernel).
+template <int E>
+struct FlatRegs {
+    float a[E];
+    float c[3 * E];
+};
+template <int E>
+__device__ __forceinline__ void flat_load(FlatRegs<E>& r, const float* __restrict__ alpha, const float* __restrict__ rgb,
+                                          int64_t ray, int S, int lane) {
+    const float* a_row = alpha + ray * S;
+    const float* c_row = rgb + ray * S * 3;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int s = e * 64 + lane;
+        r.a[e] = s < S ? __builtin_nontemporal_load(a_row + s) : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 3 * E; ++j) {
+        const int k = j * 64 + lane;
+        r.c[j] = k < 3 * S ? __builtin_nontemporal_load(c_row + k) : 0.0f;
+    }
+}
+template <int E>
+__device__ __forceinline__ void flat_ray(const FlatRegs<E>& r, float* __restrict__ wl, int64_t ray, int S, int white_bg,
+                                         int lane, float* __restrict__ weights, float* __restrict__ rgb_out,
+                                         float* __restrict__ acc_out) {
+    float carry = 1.0f, acc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int s = e * 64 + lane;
+        const float t = s < S ? (1.0f - r.a[e] + kEps) : 1.0f;
+        const float incl = wave_incl_prod(t, lane);
+        const float w = r.a[e] * (wave_prev(incl, 1.0f) * carry);
+        if (E > 1) carry *= __shfl(incl, 63, 64);
+        acc += w;
+        wl[s] = w;
+        if (weights != nullptr && s < S) __builtin_nontemporal_store(w, weights + ray * S + s);
+    }
+    wave_lds_sync();
+    // flat element k = lane + 64 j is channel (lane + j) % 3 of sample k / 3: three rotating accumulators
+    float q[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3 * E; ++j) {
+        const int k = j * 64 + lane;
+        q[j % 3] += wl[k < 3 * S ? k / 3 : 0] * r.c[j];
+    }
+    wave_lds_sync();  // wl is rewritten by the next ray
+    const int l3 = lane % 3;
+    const float q0 = l3 == 0 ? q[0] : (l3 == 1 ? q[2] : q[1]);
+    const float q1 = l3 == 0 ? q[1] : (l3 == 1 ? q[0] : q[2]);
+    const float q2 = l3 == 0 ? q[2] : (l3 == 1 ? q[1] : q[0]);
+    const float v = wave_sum4(acc, q0, q1, q2, lane);
+    const float acc_all = __shfl(v, 0, 64);
+    if (lane == 0) acc_out[ray] = v;
+    if ((lane & 15) == 0 && lane != 0) rgb_out[ray * 3 + (lane >> 4) - 1] = v + (white_bg ? (1.0f - acc_all) : 0.0f);
+}
+template <int E>
+__global__ __launch_bounds__(256) void composite_fwd_flat_kernel(const float* __restrict__ alpha, const float* __restrict__ rgb,
+                                                                 int64_t n_rays, int S, int white_bg, float* __restrict__ weights,
+                                                                 float* __restrict__ rgb_out, float* __restrict__ acc_out) {
+    __shared__ float lds[kWavesPerBlock][E * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* wl = lds[wave];
+    const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+    int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (ray >= n_rays) return;
+    FlatRegs<E> r0, r1;
+    flat_load<E>(r0, alpha, rgb, ray, S, lane);
+    while (true) {
+        int64_t nxt = ray + stride;
+        if (nxt < n_rays) flat_load<E>(r1, alpha, rgb, nxt, S, lane);
+        flat_ray<E>(r0, wl, ray, S, white_bg, lane, weights, rgb_out, acc_out);
+        if (nxt >= n_rays) break;
+        ray = nxt;
+        nxt = ray + stride;
+        if (nxt < n_rays) flat_load<E>(r0, alpha, rgb, nxt, S, lane);
+        flat_ray<E>(r1, wl, ray, S, white_bg, lane, weights, rgb_out, acc_out);
+        if (nxt >= n_rays) break;
+        ray = nxt;
+    }
+}
+
 // Accumulated opacity only (shadow rays, stage1/model/rendering.py:405-406: no colours, no weights kept), S <= 128 and a
 // multiple of 16: FOUR rays per wave -- a ray occupies one DPP row of 16 lanes, a lane owns E = S / 16 consecutive samples
 // (16-byte loads), the transmittance scan is the 4-step row scan and the ray sum a 4-step row reduction.  With one ray
@@ -397,6 +482,16 @@ extern "C" int psn_composite_fwd(const float* alpha, const float* rgb, int64_t n
         if (n_samples == 64) hipLaunchKernelGGL(composite_acc4_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, alpha, n_rays, n_samples, acc_out);
         else hipLaunchKernelGGL(composite_acc4_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, alpha, n_rays, n_samples, acc_out);
         PSN_CHECK_LAUNCH("composite_fwd (opacity only)");
+        return PSN_OK;
+    }
+    // measured at S = 128, 2 M rays (tools/bench_composite.py, same box, 3 runs): without the weights output the flat layout
+    // reaches 5.32-5.34 TB/s against 4.69-4.72 for the blocked one; with it the blocked one keeps a 2 % lead (4.93 vs 4.84)
+    if (weights == nullptr && rgb != nullptr && n_samples > 64 && n_samples <= 128) {
+        int64_t blocks = (n_rays + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(composite_fwd_flat_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, alpha, rgb, n_rays, n_samples,
+                           white_bg, weights, rgb_out, acc_out);
+        PSN_CHECK_LAUNCH("composite_fwd (flat layout)");
         return PSN_OK;
     }
     int E = (n_samples + 63) / 64;

@@ -23,13 +23,17 @@ def test_composite_golden(cuda, S):
     assert_close(w.cpu(), g['w%d' % S], 2e-6, 'w')
     assert_close(out.cpu(), g['out%d' % S], 2e-6, 'rgb')
     assert_close(acc.cpu(), g['acc%d' % S], 2e-6, 'acc')
+    w0, out0, acc0 = hip.composite_fwd(alpha, rgb, True, need_weights=False)  # the training path (flat-layout kernel for 64 < S <= 128)
+    assert w0 is None
+    assert_close(out0.cpu(), g['out%d' % S], 2e-6, 'rgb (no weights)')
+    assert_close(acc0.cpu(), g['acc%d' % S], 2e-6, 'acc (no weights)')
     da, dc = hip.composite_bwd(alpha, rgb, T(g['c1_%d' % S], cuda), T(g['c2_%d' % S], cuda), True)
     assert_close(dc.cpu(), g['drgb%d' % S], 2e-6, 'd_rgb')
     assert_close(da.cpu(), g['dalpha%d' % S], 1e-4, 'd_alpha')  # /t with t ~ 1e-6 on the alpha==1 rows
 
 
 @pytest.mark.parametrize('N,S', [(1, 1), (5, 7), (1000, 63), (333, 65), (4096, 128), (17, 300), (3, 1024),
-                                 (21, 100), (50, 256), (9, 512), (4, 1000), (70001, 2)])  # vector / scalar row paths, idle lanes
+                                 (21, 100), (257, 96), (6, 127), (50, 256), (9, 512), (4, 1000), (70001, 2)])  # vector / scalar row paths, idle lanes
 def test_composite_shapes(cuda, N, S):
     from psnerf_amd import hip
     from oracle import stage1 as o1
@@ -45,6 +49,11 @@ def test_composite_shapes(cuda, N, S):
     w, out, acc = hip.composite_fwd(a32, c32, False)
     assert_close(w.cpu(), w_ref.detach(), 5e-6, 'w')
     assert_close(out.cpu(), rgb_ref.detach(), 5e-6, 'rgb')
+    for white in (False, True):  # colours without the weights output
+        w0, out0, acc0 = hip.composite_fwd(a32, c32, white, need_weights=False)
+        assert w0 is None
+        assert_close(out0.cpu(), rgb_ref.detach() + ((1 - acc_ref.detach())[:, None] if white else 0), 5e-6, 'rgb (no weights)')
+        assert_close(acc0.cpu(), acc_ref.detach(), 5e-6, 'acc (no weights)')
     da, dc = hip.composite_bwd(a32, c32, c1.float().to(cuda), c2.float().to(cuda), False)
     assert_close(dc.cpu(), c64.grad, 5e-6, 'd_rgb')
     assert_close(da.cpu(), a64.grad, 2e-5, 'd_alpha')
