@@ -33,6 +33,23 @@ void set_error(const char* fmt, ...);
 // publishes LDS writes / retires LDS reads; data hand-offs through global memory still need __syncthreads().
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+
+// LDS-DMA of one 1 KB piece (64 lanes x 16 B): global (gbase + voff + OFF) -> LDS (lds + OFF + 16 * lane); gbase and lds
+// wave-uniform (SGPRs), voff = 16 * lane.  Inline assembly on purpose: hipcc models the builtin
+// (__builtin_amdgcn_global_load_lds, a FLAT-encoded instruction with a global AND an LDS memory operand) as a "flat access
+// that may touch both address spaces", and while one is pending its waitcnt pass turns EVERY lgkmcnt wait of the wave into
+// lgkmcnt(0) -- the fragment prefetches of the fused MLP engines, meant to stay in flight for hundreds of cycles, were
+// drained at each use (one exposed LDS latency per 4-12 MFMAs).  An asm statement is invisible to that pass: the DS
+// waits become exact, and the landing of the pieces is waited for explicitly (s_waitcnt vmcnt) before the stage barrier
+// as before.  The scalar-base form also reads one address VGPR instead of two.
+template <int OFF>
+__device__ __forceinline__ void lds_dma_16(const void* gbase, unsigned lds, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(gbase), "s"(lds), "n"(OFF));
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const void*)p;
+}
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 

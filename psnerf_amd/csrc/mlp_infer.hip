@@ -70,7 +70,7 @@ constexpr int kWaves = 4;  // per workgroup; two workgroups share a CU (2 waves 
 // fragment reads and spread over its first MFMAs (sched_group_barrier): issued as a block ahead of the first MFMA their
 // ~50 issue slots were the largest single loss of the kernel (8 % when measured by removing the stream); a piece's
 // issue fits into the 32-cycle gap of an MFMA.
-template <int NMT, int NACC, typename RequestNext>
+template <int NMT, int NACC, bool ASMDMA, typename RequestNext>
 __device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx4& b0, const floatx4& b1,
                                               const float4* __restrict__ wl, int lane, RequestNext request_next) {
     if constexpr (NMT >= 8) {
@@ -81,37 +81,74 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx
         for (int m = 0; m < 8; ++m) a[0][m] = wl[m * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);  // the first group's reads are in flight (exposed once per stage)
         constexpr int NPW = NMT / 2;        // LDS-DMA pieces of the next stage per wave: spread over the first MFMAs below
+        if constexpr (ASMDMA) {
 #pragma unroll
-        for (int j = 0; j < NPW; ++j) request_next(j);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int e = g / GE, m0 = (g % GE) * 8;
-            const floatx4& bs = e ? b1 : b0;
-            if (g < NG - 1) {
-                const int e1 = (g + 1) / GE, m1 = ((g + 1) % GE) * 8;
-#pragma unroll
-                for (int m = 0; m < 8; ++m) a[(g + 1) & 1][m] = wl[(e1 * NMT + m1 + m) * 64 + lane];
-            }
-            const float4(&ag)[8] = a[g & 1];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].x, bs[0], acc[m0 + m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].y, bs[1], acc[m0 + m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].z, bs[2], acc[m0 + m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].w, bs[3], acc[m0 + m], 0, 0, 0);
-            // pin the order: this group's 8 prefetch reads spread over its first 8 MFMAs, then the other 24 MFMAs
-            if (g < NG - 1) {
+            for (int g = 0; g < NG; ++g) {
+                const int e = g / GE, m0 = (g % GE) * 8;
+                const floatx4& bs = e ? b1 : b0;
+                const float4(&ag)[8] = a[g & 1];
+                // The order is pinned by scheduling regions (the LDS-DMA pieces are asm statements, which no scheduling
+                // group matches): four chunks of [2 prefetch reads of group g+1 | 2 MFMAs | NPW/4 pieces (g == 0)], then the
+                // other 24 MFMAs of the group.
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    if (g == 0) __builtin_amdgcn_sched_group_barrier(0x020, NPW / 4, 0);
+                    if (g < NG - 1) {
+                        const int e1 = (g + 1) / GE, m1 = ((g + 1) % GE) * 8;
+                        a[(g + 1) & 1][2 * k] = wl[(e1 * NMT + m1 + 2 * k) * 64 + lane];
+                        a[(g + 1) & 1][2 * k + 1] = wl[(e1 * NMT + m1 + 2 * k + 1) * 64 + lane];
+                    }
+                    acc[m0 + 2 * k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[2 * k].x, bs[0], acc[m0 + 2 * k], 0, 0, 0);
+                    acc[m0 + 2 * k + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[2 * k + 1].x, bs[0], acc[m0 + 2 * k + 1], 0, 0, 0);
+                    if (g == 0) {
+#pragma unroll
+                        for (int j = 0; j < NPW / 4; ++j) request_next(k * (NPW / 4) + j);
+                    }
+                    if (g == 0 || g < NG - 1) __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].y, bs[1], acc[m0 + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].z, bs[2], acc[m0 + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].w, bs[3], acc[m0 + m], 0, 0, 0);
+                // the last group stays open: what follows the stage (the operand loads of a chain layer's activation program,
+                // the next stage's waits) may be hoisted under its MFMAs
+                if (g < NG - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) request_next(j);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int e = g / GE, m0 = (g % GE) * 8;
+                const floatx4& bs = e ? b1 : b0;
+                if (g < NG - 1) {
+                    const int e1 = (g + 1) / GE, m1 = ((g + 1) % GE) * 8;
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) a[(g + 1) & 1][m] = wl[(e1 * NMT + m1 + m) * 64 + lane];
+                }
+                const float4(&ag)[8] = a[g & 1];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].x, bs[0], acc[m0 + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].y, bs[1], acc[m0 + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].z, bs[2], acc[m0 + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[m].w, bs[3], acc[m0 + m], 0, 0, 0);
+                // pin the order: this group's 8 prefetch reads spread over its first 8 MFMAs (with the builtin LDS-DMA pieces,
+                // which the VMEM scheduling group matches, in group 0), then the other 24 MFMAs
+                if (g < NG - 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        if (g == 0) __builtin_amdgcn_sched_group_barrier(0x020, NPW / 4, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+                }
             }
         }
     } else {
@@ -139,13 +176,15 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx
 // consecutive 1 KB pieces share one base (global address and M0) and differ in the instruction offset only
 // (compile-time trip count, no kernarg reloads inside the stage: an s_load there forces s_waitcnt lgkmcnt(0), which
 // also drains the LDS reads).
-template <int NBLK>
+template <int NBLK, bool ASMDMA>
 __device__ __forceinline__ void stage_piece(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane, int j) {
     constexpr int NPW = NBLK / kWaves;
     static_assert(NBLK % kWaves == 0, "stage size");
     const int grp = j >> 2;
-    const char* base = reinterpret_cast<const char*>(gsrc + (wave * NPW + grp * 4) * 256);  // uniform (SGPR pair) + 32-bit lane offset
-    auto gp = (const __attribute__((address_space(1))) void*)(base + (unsigned)(lane * 16));
+    const float* base = gsrc + (wave * NPW + grp * 4) * 256;             // wave-uniform: SGPR pair
+    const unsigned lds = lds_addr(lds_dst + (wave * NPW + grp * 4) * 256);  // wave-uniform: M0
+    if constexpr (!ASMDMA) {
+    auto gp = (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + (unsigned)(lane * 16));
     auto lp = (__attribute__((address_space(3))) void*)(lds_dst + (wave * NPW + grp * 4) * 256);
     switch (j & 3) {
         case 0: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0); break;
@@ -153,11 +192,20 @@ __device__ __forceinline__ void stage_piece(const float* __restrict__ gsrc, floa
         case 2: __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0); break;
         default: __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0); break;
     }
+    } else {
+    const unsigned voff = lane * 16;
+    switch (j & 3) {
+        case 0: lds_dma_16<0>(base, lds, voff); break;
+        case 1: lds_dma_16<1024>(base, lds, voff); break;
+        case 2: lds_dma_16<2048>(base, lds, voff); break;
+        default: lds_dma_16<3072>(base, lds, voff); break;
+    }
+    }
 }
-template <int NBLK>
+template <int NBLK, bool ASMDMA>
 __device__ __forceinline__ void stage_load(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
 #pragma unroll
-    for (int j = 0; j < NBLK / kWaves; ++j) stage_piece<NBLK>(gsrc, lds_dst, wave, lane, j);
+    for (int j = 0; j < NBLK / kWaves; ++j) stage_piece<NBLK, ASMDMA>(gsrc, lds_dst, wave, lane, j);
 }
 
 __device__ __forceinline__ floatx4 ld4(const float* p) {
@@ -249,6 +297,10 @@ __device__ __forceinline__ void wait_for_weights(int stores) {
 template <bool CHAIN, int NMT, int SRC = 0>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
 __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     constexpr int W = 16 * NMT;
+    // LDS-DMA flavour (common.h lds_dma_16): asm pieces + explicit scheduling regions for the lean variant (exact lgkmcnt
+    // waits: visibility launch +1.9 %, march sweep +4 %), the builtin + scheduling groups for the chain variant (its
+    // F2 / B1 / B2 chains measured 1-2 % SLOWER with the regions, with either piece flavour)
+    constexpr bool kAsmDma = !CHAIN && SRC == 0;  // (the root finder is latency-bound and at the register limit: builtin)
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages + all biases
     float* bias_lds = smem + 2 * kStageFloats;
     const int tid = threadIdx.x;
@@ -262,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     {  // prefetch the first weight stage (layer 0 may be evaluated entirely through the init tables)
         const int l0 = (g.d.layers[0].n_kt_in + g.d.layers[0].n_kt_act > 0) ? 0 : 1;
         const PsnMlpLayer& L0 = g.d.layers[l0];
-        stage_load<2 * NMT>(g.w + L0.w_off, smem, wave, lane);
+        stage_load<2 * NMT, kAsmDma>(g.w + L0.w_off, smem, wave, lane);
     }
 
     // ---- input features -> registers (MFMA B-operand layout): 16-feature tile t, register r = feature 16t+4g+r
@@ -332,6 +384,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                 float4 t = *reinterpret_cast<const float4*>(ap + mt * 16);
                 act[mt][0] = t.x; act[mt][1] = t.y; act[mt][2] = t.z; act[mt][3] = t.w;
             }
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) asm volatile("" : "+v"(act[mt]));  // arrived before the first stage's LDS-DMA pieces (see load_xin)
         }
     }
 
@@ -364,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         /* branch-free request (a branch would end the scheduling region the pieces are spread over): after the very \
            last stage the idle buffer receives a copy of the first one */                                   \
         const float* src_ = s_ + 1 < n_st ? wl_g + (int64_t)(s_ + 1) * stage_floats : (next_w != nullptr ? next_w : g.w); \
-        stage_compute<NMT, NMT>(acc, B0, B1, wl, lane, [&](int j_) { stage_piece<2 * (NMT)>(src_, nxt, wave, lane, j_); }); \
+        stage_compute<NMT, NMT, kAsmDma>(acc, B0, B1, wl, lane, [&](int j_) { stage_piece<2 * (NMT), kAsmDma>(src_, nxt, wave, lane, j_); }); \
         ++gstage;                                                                                           \
     }
 
@@ -433,7 +487,13 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         if (L.n_kt_in > 0) {
             floatx4 xin[8];
             if constexpr (SRC == 1) compute_xin(xin);
-            else load_xin(xin);
+            else {
+                load_xin(xin);
+                // the features must have arrived BEFORE the stage issues its LDS-DMA pieces: those are asm statements the
+                // compiler's vmcnt bookkeeping does not see, so a wait placed behind them would be a full vmcnt(0)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(xin[t]));
+            }
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 if (kt < L.n_kt_in) PSN_STAGE(NMT, xin[2 * kt], xin[2 * kt + 1], L.n_kt_act + kt)
@@ -511,10 +571,10 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         if constexpr (SRC == 1) {
             // the next iteration starts over with layer 0: request its first weight stage into the buffer that the
             // last hidden stage has just released (every wave is past the barrier above)
-            if (iter + 1 < n_iter) stage_load<2 * NMT>(g.w + g.d.layers[0].w_off, smem + ((gstage + 1) & 1) * kStageFloats, wave, lane);
+            if (iter + 1 < n_iter) stage_load<2 * NMT, kAsmDma>(g.w + g.d.layers[0].w_off, smem + ((gstage + 1) & 1) * kStageFloats, wave, lane);
         }
 #pragma unroll
-        for (int kt = 0; kt < NMT / 2; ++kt) stage_compute<2, NMT>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane, [](int) {});
+        for (int kt = 0; kt < NMT / 2; ++kt) stage_compute<2, NMT, kAsmDma>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane, [](int) {});
         if constexpr (SRC == 1) ++gstage;
     }
     if constexpr (SRC == 1) {

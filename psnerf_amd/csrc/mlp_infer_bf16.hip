@@ -55,17 +55,15 @@ constexpr int kBfWaves = 4;
 // NPW global_load_lds plus ~NPW/4 address / M0 updates, no branches: the scheduler can spread them between MFMAs.
 template <int NPW>
 __device__ __forceinline__ void bf_dma_piece(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, int wave, int lane, int j) {
-    const unsigned char* g = gsrc + wave * (NPW * 1024);
-    unsigned char* l = lds_dst + wave * (NPW * 1024);
     const int grp = j >> 2;
-    const unsigned char* base = g + grp * 4096;
-    auto gp = (const __attribute__((address_space(1))) void*)(base + (unsigned)(lane * 16));
-    auto lp = (__attribute__((address_space(3))) void*)(l + grp * 4096);
+    const unsigned char* base = gsrc + wave * (NPW * 1024) + grp * 4096;      // wave-uniform: SGPR pair
+    const unsigned lds = lds_addr(lds_dst + wave * (NPW * 1024) + grp * 4096);  // wave-uniform: M0
+    const unsigned voff = lane * 16;
     switch (j & 3) {
-        case 0: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0); break;
-        case 1: __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0); break;
-        case 2: __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0); break;
-        default: __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0); break;
+        case 0: lds_dma_16<0>(base, lds, voff); break;
+        case 1: lds_dma_16<1024>(base, lds, voff); break;
+        case 2: lds_dma_16<2048>(base, lds, voff); break;
+        default: lds_dma_16<3072>(base, lds, voff); break;
     }
 }
 template <int NPW>
@@ -74,27 +72,28 @@ __device__ __forceinline__ void bf_stage_dma(const unsigned char* __restrict__ g
     for (int j = 0; j < NPW; ++j) bf_dma_piece<NPW>(gsrc, lds_dst, wave, lane, j);
 }
 
-// ReLU + round-to-nearest-even bf16 of accumulator registers [8 qp, 8 qp + 8): the next layer's B operand.
-__device__ __forceinline__ bf16x8 bf_pack_relu(const floatx16& c, int qp) {
-    intx4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        floatx2 f;
-        f[0] = c[8 * qp + 2 * i];
-        f[1] = c[8 * qp + 2 * i + 1];
-        shortx2 s = __builtin_bit_cast(shortx2, __builtin_convertvector(f, bf16x2));
-        const shortx2 z = {0, 0};
-        s = __builtin_elementwise_max(s, z);  // negative floats are negative int16: max with 0 is ReLU (and -0 -> +0)
-        o[i] = __builtin_bit_cast(int, s);
-    }
-    return __builtin_bit_cast(bf16x8, o);
+// ReLU + round-to-nearest-even bf16 of accumulator registers [8 qp + 2 i, 8 qp + 2 i + 2): dword i of the next layer's B operand.
+__device__ __forceinline__ int bf_pack_relu2(const floatx16& c, int qp, int i) {
+    floatx2 f;
+    f[0] = c[8 * qp + 2 * i];
+    f[1] = c[8 * qp + 2 * i + 1];
+    shortx2 s = __builtin_bit_cast(shortx2, __builtin_convertvector(f, bf16x2));
+    const shortx2 z = {0, 0};
+    s = __builtin_elementwise_max(s, z);  // negative floats are negative int16: max with 0 is ReLU (and -0 -> +0)
+    return __builtin_bit_cast(int, s);
 }
 
 // Epilogue of output-tile pair q (tiles 2q, 2q+1, both row tiles) = 8 jobs of 16 VALU instructions (8 accumulator
-// reads, 4 cvt, 4 max); job j writes B operand k-step 2 ot + qp of row tile t in place.
-__device__ __forceinline__ void bf_epilogue_job(const floatx16 (&acc)[2][8], bf16x8 (&bact)[2][16], int q, int j) {
+// reads, 4 cvt, 4 max); job j writes B operand k-step 2 ot + qp of row tile t in place, one dword per part i.
+__device__ __forceinline__ void bf_epilogue_part(const floatx16 (&acc)[2][8], bf16x8 (&bact)[2][16], int q, int j, int i) {
     const int ot = 2 * q + (j >> 2), t = (j >> 1) & 1, qp = j & 1;
-    bact[t][2 * ot + qp] = bf_pack_relu(acc[t][ot], qp);
+    intx4 o = __builtin_bit_cast(intx4, bact[t][2 * ot + qp]);
+    o[i] = bf_pack_relu2(acc[t][ot], qp, i);
+    bact[t][2 * ot + qp] = __builtin_bit_cast(bf16x8, o);
+}
+__device__ __forceinline__ void bf_epilogue_job(const floatx16 (&acc)[2][8], bf16x8 (&bact)[2][16], int q, int j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bf_epilogue_part(acc, bact, q, j, i);
 }
 
 enum { BF_SRC_ACT_LO = 0, BF_SRC_ACT_HI = 1, BF_SRC_IN = 2, BF_SRC_INB = 3 };  // B operands of a stage (+ bias k-step: ACT_LO, INB)
@@ -126,9 +125,10 @@ __device__ __forceinline__ void bf_stage_mma(floatx16 (&acc)[2][8], bf16x8 (&bac
         else return ks < 8 ? bin[t][ks] : bias_b;
     };
     auto frag = [&](int step, int o) -> bf16x8 { return wl[((step % NKS) * 8 + 2 * (step / NKS) + o) * 64 + lane]; };
-    bf16x8 a[3][2];
-    a[0][0] = frag(0, 0); a[0][1] = frag(0, 1);
-    a[1][0] = frag(1, 0); a[1][1] = frag(1, 1);
+    constexpr int R = 3;  // fragment ring: requested R - 1 k-steps = (R - 1) x 128 MFMA cycles ahead (deeper rings measured +-0)
+    bf16x8 a[R][2];
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) { a[i][0] = frag(i, 0); a[i][1] = frag(i, 1); }
     __builtin_amdgcn_sched_barrier(0);
     floatx16 zero;
 #pragma unroll
@@ -137,37 +137,26 @@ __device__ __forceinline__ void bf_stage_mma(floatx16 (&acc)[2][8], bf16x8 (&bac
     for (int step = 0; step < NSTEP; ++step) {
         const int p = step / NKS, ks = step % NKS;
         const int dma_left = p == DMA_PAIR ? NPW - 4 * ks : 0;  // one request per MFMA of the DMA pair until all NPW are out
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if (m < dma_left) request_piece(4 * ks + m);
-        if (step + 2 < NSTEP) {
-            a[(step + 2) % 3][0] = frag(step + 2, 0);
-            a[(step + 2) % 3][1] = frag(step + 2, 1);
+        if (step + R - 1 < NSTEP) {
+            a[(step + R - 1) % R][0] = frag(step + R - 1, 0);
+            a[(step + R - 1) % R][1] = frag(step + R - 1, 1);
         }
         const bf16x8 b0 = bop(0, ks), b1 = bop(1, ks);
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int ot = 2 * p + o;
-            acc[0][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step % 3][o], b0, (ZERO_C && ks == 0) ? zero : acc[0][ot], 0, 0, 0);
-            acc[1][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step % 3][o], b1, (ZERO_C && ks == 0) ? zero : acc[1][ot], 0, 0, 0);
-        }
         int q = -1;
         if (EPI == BF_EPI_FIRST && p < 2) q = 2 + p;
         if (EPI == BF_EPI_LAST && (p == 1 || p == 2)) q = p - 1;
         const bool job = q >= 0 && ks < 8;
-        if (job) bf_epilogue_job(acc, bact, q, ks);
-        // pin the order of this k-step: 2 fragment reads, then per MFMA 4 epilogue VALU (if any) and, in the DMA pair,
-        // one LDS-DMA request per MFMA until all NPW are out
-        if (step + 2 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        // The order of a k-step is pinned by one scheduling region per MFMA (the LDS-DMA pieces are asm statements, and the
+        // accumulator reads of a job are COPYs until register allocation: no scheduling group matches either):
+        //   [2 fragment reads (two k-steps ahead) | MFMA | piece | job part] [MFMA | piece | part] x 3
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (m < dma_left) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            if (job) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            const int o = m >> 1, t = m & 1, ot = 2 * p + o;
+            acc[t][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step % R][o], t ? b1 : b0, (ZERO_C && ks == 0) ? zero : acc[t][ot], 0, 0, 0);
+            if (m < dma_left) request_piece(4 * ks + m);
+            if (job) bf_epilogue_part(acc, bact, q, ks, m);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // region boundary per k-step: the accumulator reads of a job are COPYs until register allocation (no scheduling
-        // group matches them) and would otherwise all float to the top of the stage, ahead of the first MFMA
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -206,7 +195,13 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_bf16_kernel(Bf16Args g) {
             }
         }
     };
+    // (mask_in also makes the compiler wait for the loads HERE, before the stage issues LDS-DMA pieces: those are asm
+    // statements its vmcnt bookkeeping does not see, so a counted wait placed behind them would wait for them as well)
     auto mask_in = [&](bf16x8 (&bin)[2][8]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(bin[t][s]));
         if (!has_b) {
             const intx4 z = {0, 0, 0, 0};
 #pragma unroll

@@ -17,23 +17,32 @@ tb = hip.pe_encode(torch.nn.functional.normalize(torch.randn(L, 3, device=dev), 
 Q = Ns * L
 ref = packed(ta, Q, 1, Ns, tb, Ns, L)
 flops = 2.0 * (126 * 256 + 5 * 65536 + 382 * 256 + 256) * Q
+fns = []
 for path in sys.argv[1:]:
     lib = ctypes.CDLL(os.path.abspath(path))
     fn = lib.psn_mlp_infer_bf16
     fn.restype = ctypes.c_int
     c = ctypes.c_void_p
     fn.argtypes = [ctypes.POINTER(hip.PsnBf16Desc), c, c, c, ctypes.c_int64, ctypes.c_int64, c, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c, c]
-    out = torch.empty(Q, 1, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    def run():
-        rc = fn(ctypes.byref(packed.desc), packed.w.data_ptr(), packed.final_bias.data_ptr(), ta.data_ptr(), 1, Ns, tb.data_ptr(), Ns, L, Q, out.data_ptr(), st)
-        assert rc == 0, rc
-    for _ in range(3):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        run()
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    print('%-40s %.3f ms  %.1f TFLOP/s  max|d| vs product build %.2e' % (os.path.basename(path), ms, flops / ms * 1e-9, (out - ref).abs().max().item()))
+    fns.append((os.path.basename(path), fn))
+out = torch.empty(Q, 1, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+best = {}
+for rep in range(4):  # variants interleaved, minimum over the rounds: clocks drift by several % within a process
+    for name, fn in fns:
+        def run():
+            rc = fn(ctypes.byref(packed.desc), packed.w.data_ptr(), packed.final_bias.data_ptr(), ta.data_ptr(), 1, Ns, tb.data_ptr(), Ns, L, Q, out.data_ptr(), st)
+            assert rc == 0, rc
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        d = (out - ref).abs().max().item()
+        best[name] = min(best.get(name, (1e9, 0))[0], ms), d
+for name, _ in fns:
+    ms, d = best[name]
+    print('%-44s %.3f ms  %.1f TFLOP/s  max|d| vs product build %.2e' % (name, ms, flops / ms * 1e-9, d))
