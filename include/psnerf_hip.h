@@ -397,6 +397,23 @@ int psn_mlp_infer_bf16(const PsnBf16Desc* desc, const uint16_t* packed_w, const 
                        int64_t a_div, int64_t a_mod, const uint16_t* tab_b, int64_t b_div, int64_t b_mod, int64_t n_rows,
                        float* out, void* stream);
 
+/* Grouped form for the light-major rows (g, n) -> g * rows_per_group + n of stage2/model/renderer.py:163,193 (g = light,
+ * n = surface point; the 512-light evaluation of stage2/eval.py:199-218): the input block of a row is table A row n
+ * ([rows_per_group, 64] bf16) and the group's part of every input layer, W_b * B[g] + b, arrives as that group's bias:
+ * group_bias [n_groups][n_in][8 KB] = one bias k-step per (group, input layer in network order), written by
+ * psn_bf16_pack_group_bias from fp32 rows.  The light's encoding and its weight columns therefore stay in fp32 (one small
+ * product per light and input layer on the host side) and cost no k-steps per row.
+ * Weight stream: as above with 4 input k-steps (table A columns only) instead of 8 and WITHOUT the bias k-step of the
+ * layers that read the input block:
+ *   layer 0: input k-steps 0..3 (32 KB);  layer l >= 1: activation k-steps 0..7, bias k-step unless has_in[l];
+ *   if has_in[l]: input k-steps 0..3 (32 KB); activation k-steps 8..15;  final: 16 KB, then >= 56 KB of padding.
+ * out [n_groups * rows_per_group, n_out] fp32. */
+int psn_mlp_infer_bf16_grouped(const PsnBf16Desc* desc, const uint16_t* packed_w, const float* final_bias,
+                               const uint16_t* tab_a, int64_t rows_per_group, const uint16_t* group_bias, int64_t n_groups,
+                               float* out, void* stream);
+/* V [n, 256] fp32 -> dst [n][4096] bf16: bias k-steps (K slot 0 = bf16(v), slot 1 = bf16(v - slot 0), the rest 0). */
+int psn_bf16_pack_group_bias(const float* V, int64_t n, uint16_t* dst, void* stream);
+
 /* ------------------------------------------------------------------------
  * Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n:
  * stage2/model/sgbasis.py:16-32 + stage2/model/renderer.py:174-204

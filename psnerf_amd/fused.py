@@ -271,6 +271,79 @@ def pack_relu_mlp_bf16(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_N
     return PackedBf16(desc, buf, fb)
 
 
+class PackedBf16Grouped(object):
+    """A 256-wide ReLU network packed for the GROUPED form of the bf16 engine (psn_mlp_infer_bf16_grouped): rows
+    (g, n) -> g * Ns + n, the input block of a row is [table A row n | group features of g].  The group's part of every
+    input layer is folded into a per-group bias in fp32: V[g, i] = W_b,i @ x_g + b_i (one small product per call)."""
+
+    def __init__(self, desc, w, final_bias, wb_t, b_in):
+        self.desc, self.w, self.final_bias = desc, w, final_bias
+        self.wb_t = wb_t    # [64, n_in * 256] fp32: the table-B columns of the input layers, transposed, zero rows beyond din_b
+        self.b_in = b_in    # [n_in * 256] fp32: the biases of the input layers
+        self.n_in = b_in.numel() // 256
+
+    def group_bias(self, tab_b):
+        """tab_b [n_groups, 64] fp32 group features -> bias k-steps [n_groups * n_in, 4096] bfloat16."""
+        V = hip.gemm(tab_b, self.wb_t, bias=self.b_in, epi=hip.EPI_BIAS)  # [n_groups, n_in * 256]
+        return hip.bf16_pack_group_bias(V.view(-1, 256))
+
+    def __call__(self, tab_a, tab_b, out=None):
+        """tab_a [Ns, 64] bfloat16, tab_b [n_groups, 64] float32 -> [n_groups * Ns, n_out] (group-major rows)."""
+        return hip.mlp_infer_bf16_grouped(self.desc, self.w, self.final_bias, tab_a, self.group_bias(tab_b), tab_b.shape[0], out=out)
+
+
+def pack_relu_mlp_bf16_grouped(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE):
+    """As pack_relu_mlp_bf16 for the grouped form: the weight stream holds the table-A columns of the input layers only
+    (4 k-steps) and no bias k-step for them (include/psnerf_hip.h, psn_mlp_infer_bf16_grouped)."""
+    n = len(weights)
+    dev = weights[0].device
+    assert n - 1 <= hip.MAX_LAYERS and din_a <= 64 and 0 < din_b <= 64
+    assert all(w.shape[0] == 256 for w in weights[:-1]) and weights[-1].shape[0] <= 32
+    desc = hip.PsnBf16Desc()
+    desc.n_hidden, desc.n_out, desc.out_act = n - 1, weights[-1].shape[0], out_act
+    KS = 8 * 512
+    sizes = []
+    for li in range(n - 1):
+        has_in = li == 0 or li - 1 == skip_at
+        desc.has_in[li] = int(has_in)
+        sizes.append(4 * KS if li == 0 else (16 + (4 if has_in else 1)) * KS)
+    buf = torch.zeros(sum(sizes) + 72 * 512, device=dev, dtype=torch.bfloat16)
+
+    def bias_cols(b):
+        b = b.detach().float()
+        hi = b.to(torch.bfloat16).float()
+        return torch.stack([hi, b - hi], dim=1).contiguous()
+
+    wb, b_in = [], []
+    off = 0
+    for li in range(n - 1):
+        W = weights[li].detach().float()
+        dst = buf[off:off + sizes[li]]
+        if li == 0:
+            hip.mlp_pack_bf16(W[:, :din_a], False, 8, 0, 4, dst[:4 * KS])
+            wb.append(W[:, din_a:din_a + din_b]); b_in.append(biases[li].detach().float())
+        else:
+            W_act = W[:, :256]
+            hip.mlp_pack_bf16(W_act, True, 8, 0, 8, dst[:8 * KS])
+            hi = 8 * KS
+            if desc.has_in[li]:
+                hip.mlp_pack_bf16(W[:, 256:256 + din_a], False, 8, 0, 4, dst[hi:hi + 4 * KS])
+                wb.append(W[:, 256 + din_a:256 + din_a + din_b]); b_in.append(biases[li].detach().float())
+                hi += 4 * KS
+            else:
+                hip.mlp_pack_bf16(bias_cols(biases[li]), False, 8, 0, 1, dst[hi:hi + KS])
+                hi += KS
+            hip.mlp_pack_bf16(W_act, True, 8, 8, 8, dst[hi:hi + 8 * KS])
+        off += sizes[li]
+    hip.mlp_pack_bf16(weights[-1].detach().float(), True, 1, 0, 16, buf[off:off + 16 * 512])
+    fb = torch.zeros(32, device=dev)
+    fb[:weights[-1].shape[0]] = biases[-1].detach().float()
+    wb_t = torch.zeros(64, len(wb) * 256, device=dev)
+    for i, w in enumerate(wb):
+        wb_t[:din_b, i * 256:(i + 1) * 256] = w.t()
+    return PackedBf16Grouped(desc, buf, fb, wb_t.contiguous(), torch.cat(b_in).contiguous())
+
+
 def pack_geo_occupancy(weights, biases, skips, d_pe):
     """stage1 occupancy-only network (stage1/model/network.py:85-95,124-125): softplus(beta=100)
     stack, before layer l in ``skips`` the input becomes cat[x, pe]/sqrt(2); only output row 0 of the

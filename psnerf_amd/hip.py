@@ -118,6 +118,8 @@ SIGNATURES = {
     'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_mlp_pack_bf16': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
     'psn_mlp_infer_bf16': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, i64, c_f, c_f]),
+    'psn_mlp_infer_bf16_grouped': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, i64, c_f, i64, c_f, c_f]),
+    'psn_bf16_pack_group_bias': (i32, [c_f, i64, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library out of date: fail loudly
@@ -697,6 +699,35 @@ def mlp_infer_bf16(desc, packed_w, final_bias, tab_a, a_div, a_mod, tab_b, b_div
         _check(_lib.psn_mlp_infer_bf16(ctypes.byref(desc), packed_w.data_ptr(), _ptr(final_bias, 'final_bias'),
                                        _bf16_table(tab_a, 'tab_a'), a_div, a_mod, _bf16_table(tab_b, 'tab_b'), b_div, b_mod,
                                        n_rows, _ptr(out, 'out'), _stream()), 'mlp_infer_bf16')
+    return out
+
+
+def bf16_pack_group_bias(V, dst=None):
+    """V [n, 256] fp32 (one row per (group, input layer)) -> [n, 4096] bfloat16 bias k-steps of the bf16 engine."""
+    assert V.is_cuda and V.dtype == torch.float32 and V.is_contiguous() and V.dim() == 2 and V.shape[1] == 256
+    if dst is None:
+        dst = torch.empty(V.shape[0], 4096, device=V.device, dtype=torch.bfloat16)
+    assert dst.dtype == torch.bfloat16 and dst.is_contiguous() and dst.numel() == V.shape[0] * 4096
+    _check(_lib.psn_bf16_pack_group_bias(V.data_ptr(), V.shape[0], dst.data_ptr(), _stream()), 'bf16_pack_group_bias')
+    return dst
+
+
+def mlp_infer_bf16_grouped(desc, packed_w, final_bias, tab_a, group_bias, n_groups, out=None):
+    """Rows (g, n) -> g * tab_a.shape[0] + n; group_bias [n_groups * n_in_layers, 4096] bfloat16 (bf16_pack_group_bias)."""
+    rows = tab_a.shape[0]
+    if out is None:
+        out = torch.empty(n_groups * rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
+    assert packed_w.dtype == torch.bfloat16 and packed_w.is_cuda and packed_w.is_contiguous()
+    assert final_bias.numel() == 32
+    n_in = sum(1 for l in range(desc.n_hidden) if desc.has_in[l])
+    if not (group_bias.is_cuda and group_bias.dtype == torch.bfloat16 and group_bias.is_contiguous()
+            and group_bias.numel() == n_groups * n_in * 4096):
+        raise RuntimeError('group_bias: must be a contiguous [n_groups * %d, 4096] bfloat16 HIP tensor' % n_in)
+    assert out.numel() == n_groups * rows * desc.n_out
+    with _Prof('mlp_infer_bf16', n_groups * rows):
+        _check(_lib.psn_mlp_infer_bf16_grouped(ctypes.byref(desc), packed_w.data_ptr(), _ptr(final_bias, 'final_bias'),
+                                               _bf16_table(tab_a, 'tab_a'), rows, group_bias.data_ptr(), n_groups,
+                                               _ptr(out, 'out'), _stream()), 'mlp_infer_bf16_grouped')
     return out
 
 

@@ -262,9 +262,8 @@ class PSNetwork(nn.Module):
     @torch.no_grad()
     def _visibility_rows_bf16(self, pe_x, pe_l):
         """Gradient-free visibility_net rows (light-major) on the bf16 MFMA engine."""
-        ns, nl = pe_x.shape[0], pe_l.shape[0]
-        return self._visibility_prepack_bf16()(pe_x.to(torch.bfloat16), ns * nl, a_div=1, a_mod=ns,
-                                               tab_b=pe_l.to(torch.bfloat16), b_div=ns, b_mod=nl)
+        # grouped form: the light's half of the input block enters as a per-light bias (fp32 product, once per light)
+        return self._visibility_prepack_bf16()(pe_x.to(torch.bfloat16), pe_l.contiguous())
 
     def _memo(self, tag, input, fn):
         """Light-independent intermediate of a gradient-free evaluation, computed once per (pixel set, weights) while a
@@ -287,8 +286,8 @@ class PSNetwork(nn.Module):
             Ws, bs = net.weights()
             half = 3 + 6 * self.n_freqs
             with torch.no_grad():
-                self._vis_pack16 = fused.pack_relu_mlp_bf16(list(Ws), list(bs), half, half, net._skip_index(),
-                                                            hip.OUT_SIGMOID if net.final == 'sigmoid' else hip.OUT_NONE)
+                self._vis_pack16 = fused.pack_relu_mlp_bf16_grouped(list(Ws), list(bs), half, half, net._skip_index(),
+                                                                    hip.OUT_SIGMOID if net.final == 'sigmoid' else hip.OUT_NONE)
             self._vis_pack16_key = key
         return self._vis_pack16
 

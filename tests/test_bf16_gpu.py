@@ -78,6 +78,59 @@ def test_bf16_engine_vs_emulation(cuda, nA, nB, depth, skip_at, n_out, out_act):
     assert (out - o32).abs().max().item() < 2e-2
 
 
+def _emulate_grouped(Ws, bs, xa, xb, skip_at, out_act, din_a):
+    """The grouped form: table-A columns and activations rounded to bf16 as before; the group's part of an input layer,
+    W_b x_g + b, is an fp32 product entering as bias (bf16 hi + lo)."""
+    r = lambda t: t.to(torch.bfloat16).double()
+    h = None
+    for li in range(len(Ws) - 1):
+        W = Ws[li]
+        if li == 0 or li - 1 == skip_at:
+            o = 0 if li == 0 else 256
+            Wa, Wb = W[:, o:o + din_a], W[:, o + din_a:]
+            bias = (xb @ Wb.t() + bs[li]).float()
+            bh = bias.to(torch.bfloat16).float()
+            z = r(xa) @ r(Wa).t() + bh.double() + r(bias - bh)
+            if li > 0:
+                z = z + h @ r(W[:, :256]).t()
+        else:
+            bh = bs[li].to(torch.bfloat16).float()
+            z = h @ r(W).t() + bh.double() + r(bs[li] - bh)
+        h = r(torch.relu(z).float())
+    out = h @ r(Ws[-1]).t() + bs[-1].double()
+    if out_act == 1:
+        out = torch.sigmoid(out)
+    elif out_act == 2:
+        out = torch.sigmoid(-10.0 * out)
+    return out.float()
+
+
+@pytest.mark.parametrize('nA,nB,depth,skip_at,n_out,out_act', [
+    (1000, 7, 8, 3, 1, 1),     # visibility_net shape of bear.conf: 4 workgroups per group, the last one ragged (232 rows)
+    (37, 3, 8, 3, 1, 0),       # less than one workgroup per group
+    (256, 2, 2, -100, 1, 0),   # one hidden layer, groups of exactly one workgroup
+    (513, 5, 5, 1, 3, 0),      # other depth / skip position, several outputs
+    (300, 4, 12, 5, 32, 2),    # deepest network, full final tile
+])
+def test_bf16_engine_grouped_vs_emulation(cuda, nA, nB, depth, skip_at, n_out, out_act):
+    """psn_mlp_infer_bf16_grouped: group-major rows, the group's half of the input block folded into a per-group bias."""
+    from psnerf_amd import fused
+    Ws, bs = _net(63, 63, depth, skip_at, n_out, seed=depth + n_out, dev=cuda)
+    ta, tb = _table(nA, 63, 1, cuda), _table(nB, 63, 2, cuda)
+    pk = fused.pack_relu_mlp_bf16_grouped(Ws, bs, 63, 63, skip_at, out_act)
+    out = pk(ta.to(torch.bfloat16), tb)
+    ref = _emulate_grouped(Ws, bs, ta[:, :63].tile(nB, 1), tb[:, :63].repeat_interleave(nA, dim=0), skip_at, out_act, 63)
+    assert out.shape == (nA * nB, n_out)
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < 3e-3
+    # closer to the fp32 network than the two-table form (the group's features and weights are not rounded)
+    p32 = fused.pack_relu_mlp(Ws, bs, 63, 63, skip_at, out_act)
+    o32 = p32(ta, nA * nB, a_div=1, a_mod=nA, tab_b=tb, b_div=nA, b_mod=nB)
+    assert (out - o32).abs().max().item() < 2e-2
+    with pytest.raises(RuntimeError):
+        pk(ta, tb)  # fp32 table A
+
+
 def test_bf16_engine_single_table_and_index_maps(cuda):
     from psnerf_amd import fused
     Ws, bs = _net(40, 0, 6, 2, 2, seed=5, dev=cuda)

@@ -78,6 +78,10 @@ for rep in range(REPS):  # libraries interleaved, minimum over the rounds: clock
     out16 = torch.empty(Q, 1, device=dev)
     rec('vis bf16', timeit(lambda: p16(ta16, Q, 1, Ns, tb16, Ns, L, out=out16), n=10))
     res['vis16'] = out16.clone()
+    p16g = fused.pack_relu_mlp_bf16_grouped(ws, bs, 63, 63, 3, hip.OUT_SIGMOID)
+    out16g = torch.empty(Q, 1, device=dev)
+    rec('vis bf16 grp', timeit(lambda: p16g(ta16, tb, out=out16g), n=10))
+    res['vis16g'] = out16g.clone()
     occ = fused.pack_geo_occupancy(Wo, bo, [4], 39)
     oo = torch.empty(Qo, 1, device=dev)
     rec('occ march', timeit(lambda: occ(tabo, Qo, out=oo)))
@@ -94,8 +98,8 @@ for rep in range(REPS):  # libraries interleaved, minimum over the rounds: clock
         if it > 0:
             for n, (nm, rows, a, b, _f) in zip(names, ev):
                 rec(n, a.elapsed_time(b))
-            for (nm, rows, a, b, _f) in ev[4:]:
-                rec('wgrad ' + nm, a.elapsed_time(b))
+            for i_, (nm, rows, a, b, _f) in enumerate(ev[4:]):
+                rec('wgrad%d %s' % (i_, nm), a.elapsed_time(b))
     res['logit'], res['feat'], res['grad'] = logit.detach().clone(), feat.detach().clone(), grad.detach().clone()
     res['gW0'], res['gW4'] = params[0].grad.clone(), params[8].grad.clone()
     if not ref:
@@ -105,7 +109,7 @@ for rep in range(REPS):  # libraries interleaved, minimum over the rounds: clock
             d = (res[k] - ref[k]).abs().max().item()
             print('   %-22s %-6s max|d| vs first library %.3e (max |ref| %.3e)' % (tag, k, d, ref[k].abs().max().item()))
     hip._lib = orig
-flop = {'vis lean': 2.0 * 523520 * Q, 'vis bf16': 2.0 * 523520 * Q, 'occ march': 2.0 * (39 * 256 + 6 * 65536 + 256 * 217 + 256 * 256 + 256) * Qo}
+flop = {'vis lean': 2.0 * 523520 * Q, 'vis bf16': 2.0 * 523520 * Q, 'vis bf16 grp': 2.0 * 523520 * Q, 'occ march': 2.0 * (39 * 256 + 6 * 65536 + 256 * 217 + 256 * 256 + 256) * Qo}
 for n, m in zip(names, macs):
     flop[n] = 2.0 * m * Qc
 keys = list(next(iter(best.values())).keys())
