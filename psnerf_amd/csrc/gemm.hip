@@ -580,6 +580,127 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
         }
 }
 
+// ---- weight gradients of an input block: 256 x (<= 64) outputs, ONE tile per workgroup ------------------------------
+// dW_in = dZ^T X_in with a narrow X_in (the 39 / 33 encoding columns that enter layer 0 of the stage-1 networks,
+// stage1/model/network.py:85-106): HBM-bound -- per k-row 1 KB of dZ against 2 x 256 x 64 MACs -- so the job is to read
+// dZ exactly once and to keep enough rows in flight, not to keep the matrix pipe busy.  The 128 x 128 tiles of
+// gemm_tn_grouped_kernel pad N to 128 (3x the MFMA work) and split M over two workgroups that both read X_in:
+// ~40 TFLOP/s.  Here: 4 waves x (64 x 64) = 2 x 2 MFMA tiles, 21 KB of LDS per buffer, three workgroups per CU, two
+// k-tiles of operand rows in flight per workgroup (same staging scheme as the 256 x 256 kernel).
+constexpr int T64 = 64, T64_LD = T64 + 4, TALL_BUF = BK * (T256_LD + T64_LD);
+__device__ __forceinline__ void fetch_tile64(const float* __restrict__ src, int64_t ld, int n_cols, int k0, int k_end, int tid, float4& v) {
+    const int cq = min((tid & 15) * 4, ((n_cols - 1) >> 2) << 2);
+    const int kc = min(k0 + (tid >> 4), k_end - 1);
+    v = *reinterpret_cast<const float4*>(src + (int64_t)kc * ld + cq);
+}
+__device__ __forceinline__ void mask_tile64(int n_cols, int k0, int k_end, int tid, float4& v) {
+    const int cq = (tid & 15) * 4;
+    const bool kin = k0 + (tid >> 4) < k_end;
+    v.x = (kin && cq + 0 < n_cols) ? v.x : 0.f;
+    v.y = (kin && cq + 1 < n_cols) ? v.y : 0.f;
+    v.z = (kin && cq + 2 < n_cols) ? v.z : 0.f;
+    v.w = (kin && cq + 3 < n_cols) ? v.w : 0.f;
+}
+__global__ __launch_bounds__(256, 3) void gemm_tn_tall_grouped_kernel(GroupedArgs gg) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * TALL_BUF];  // 2 x {A[16][260], B[16][68]}
+    int gi = 0;
+    while (gi + 1 < gg.n && (int64_t)blockIdx.x >= gg.block_start[gi + 1]) ++gi;
+    const GemmArgs g = gg.g[gi];
+    const int split = (int)((int64_t)blockIdx.x - gg.block_start[gi]);
+    if (split >= g.split_k) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const bool seg2 = split >= g.seg_splits;
+    const float* Ap = seg2 ? g.A2 : g.A;
+    const float* Bp = seg2 ? g.B2 : g.B;
+    const int64_t lda = seg2 ? g.lda2 : g.lda, ldb = seg2 ? g.ldb2 : g.ldb;
+    const int k_begin = (seg2 ? split - g.seg_splits : split) * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int nt = (k_end - k_begin + BK - 1) / BK;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+    float4 ra[2][4], rb[2];
+    const bool do_cs = g.colsum != nullptr && !seg2;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#define TL_FETCH(T, S)                                                                          \
+    fetch_tile256(Ap, lda, (int)g.M, k_begin + (T) * BK, k_end, tid, ra[S]);                    \
+    fetch_tile64(Bp, ldb, g.N, k_begin + (T) * BK, k_end, tid, rb[S]);
+#define TL_STORE(BUF, S, T)                                                                     \
+    mask_tile256((int)g.M, k_begin + (T) * BK, k_end, tid, ra[S]);                              \
+    mask_tile64(g.N, k_begin + (T) * BK, k_end, tid, rb[S]);                                    \
+    if (do_cs) {                                                                                \
+        cs.x += (ra[S][0].x + ra[S][1].x) + (ra[S][2].x + ra[S][3].x); cs.y += (ra[S][0].y + ra[S][1].y) + (ra[S][2].y + ra[S][3].y); \
+        cs.z += (ra[S][0].z + ra[S][1].z) + (ra[S][2].z + ra[S][3].z); cs.w += (ra[S][0].w + ra[S][1].w) + (ra[S][2].w + ra[S][3].w); \
+    }                                                                                           \
+    store_tile<false, T256>(lds + (BUF) * TALL_BUF, tid, ra[S]);                                \
+    *reinterpret_cast<float4*>(lds + (BUF) * TALL_BUF + BK * T256_LD + (tid >> 4) * T64_LD + (tid & 15) * 4) = rb[S];
+    // step T: multiply tile T out of buffer T & 1; register set S = T & 1 holds tile T + 1 (requested two steps ago): write
+    // it to the other buffer and re-use the set for tile T + 3
+#define TL_STEP(T, S)                                                                           \
+    {                                                                                           \
+        const float* As = lds + ((T) & 1) * TALL_BUF + wave * 64 + li;                          \
+        const float* Bs = lds + ((T) & 1) * TALL_BUF + BK * T256_LD + li;                       \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                         \
+            float pa[2], pb[2];                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) pa[i] = As[(2 * j + lh) * T256_LD + i * 32];  \
+            _Pragma("unroll") for (int n = 0; n < 2; ++n) pb[n] = Bs[(2 * j + lh) * T64_LD + n * 32];   \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                       \
+                _Pragma("unroll") for (int n = 0; n < 2; ++n)                                   \
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], pb[n], acc[i][n], 0, 0, 0); \
+        }                                                                                       \
+        if ((T) + 1 < nt) { TL_STORE(((T) + 1) & 1, S, (T) + 1) }                               \
+        if ((T) + 3 < nt) { TL_FETCH((T) + 3, S) }                                              \
+        lds_barrier(); /* orders LDS only: the rows of tiles T + 2, T + 3 stay in flight */     \
+    }
+    TL_FETCH(0, 0)
+    TL_STORE(0, 0, 0)
+    if (1 < nt) { TL_FETCH(1, 0) }
+    if (2 < nt) { TL_FETCH(2, 1) }
+    __syncthreads();
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+        TL_STEP(t, 0)
+        TL_STEP(t + 1, 1)
+    }
+    if (t < nt) TL_STEP(t, 0)
+#undef TL_STEP
+#undef TL_STORE
+#undef TL_FETCH
+    if (do_cs) {  // thread tid staged columns 4 (tid % 64) .. +3 (rows tid / 64 + 4u of every k-tile): reduce over the 4 waves
+        float4* red = reinterpret_cast<float4*>(lds);
+        red[wave * 64 + lane] = cs;
+        __syncthreads();
+        if (tid < 64) {
+            const float4 a = red[tid], b = red[64 + tid], c = red[128 + tid], d = red[192 + tid];
+            const float v[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+            float* dst = g.colsum + (int64_t)split * g.M + 4 * tid;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * tid + e < g.M) dst[e] = v[e];
+        }
+    }
+    // partial tile -> workspace.  Lane (li, lh) holds C[wave*64 + i*32 + (r&3) + 8*(r>>2) + 4*lh][n*32 + li].
+    float* Cw = g.C + (int64_t)split * g.split_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = n * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.M && col < g.N) Cw[(int64_t)row * g.N + col] = acc[i][n][r];
+            }
+        }
+}
+
 struct ReduceItem {
     const float* ws;       // [splits][M*N] partial outputs
     const float* cs_ws;    // [cs_splits][M] partial column sums or nullptr
@@ -842,7 +963,7 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
     split_k = (int)((K + kc - 1) / kc);
     // Products with 128 < M, N <= 256 (the hidden-layer gradients) take the one-tile-per-workgroup kernel: exactly one
     // workgroup per (product, K slice), one workgroup per CU, so the slice count is chosen to fill 256 CUs once.
-    int big_products = 0;
+    int big_products = 0, tall_products = 0;
     for (int i = 0; i < n_items; ++i) {
         const PsnGemmTnItem& it = items[i];
         PSN_CHECK_ARG(it.A && it.B && it.C && it.M > 0 && it.N > 0, "gemm_tn_grouped: item %d has a null operand or empty shape", i);
@@ -850,6 +971,7 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         const bool vec = (((uintptr_t)it.A | (uintptr_t)it.B | (uintptr_t)it.A2 | (uintptr_t)it.B2) & 15) == 0 && it.lda % 4 == 0 &&
                          it.ldb % 4 == 0 && it.lda >= 4 && it.ldb >= 4 && (!it.A2 || (it.lda2 % 4 == 0 && it.ldb2 % 4 == 0 && it.lda2 >= 4 && it.ldb2 >= 4));
         if (vec && it.b_div == 0 && it.M > 128 && it.N > 128 && it.M <= T256 && it.N <= T256) big_products += it.A2 ? 2 : 1;
+        if (vec && it.b_div == 0 && it.M > 128 && it.M <= T256 && it.N <= T64) tall_products += it.A2 ? 2 : 1;
         PSN_CHECK_ARG(it.b_div == 0 || (it.b_div > 0 && it.b_mod > 0 && !it.A2), "gemm_tn_grouped: item %d bad table mapping", i);
         PSN_CHECK_ARG(it.B_tab2 == nullptr || (it.b_div > 0 && it.b2_div > 0 && it.b2_mod > 0 && it.b_split > 0 && it.b_split % 4 == 0 &&
                                                 it.b_split < it.N), "gemm_tn_grouped: item %d bad second table", i);
@@ -863,10 +985,20 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         kc_big = ((kc_big + BK - 1) / BK) * BK;
         split_big = (int)((K + kc_big - 1) / kc_big);
     }
-    GroupedArgs gg, gb;
+    // 256 x (<= 64) products (input-block gradients): HBM-bound, three workgroups per CU
+    int split_tall = 1, kc_tall = 0;
+    if (tall_products > 0) {
+        int64_t want = 768 / tall_products;
+        if (want < 1) want = 1;
+        if (want > K / 256) want = K / 256 > 0 ? K / 256 : 1;
+        kc_tall = (int)((K + want - 1) / want);
+        kc_tall = ((kc_tall + BK - 1) / BK) * BK;
+        split_tall = (int)((K + kc_tall - 1) / kc_tall);
+    }
+    GroupedArgs gg, gb, gt;
     GroupedReduceArgs ra;
-    gg.n = gb.n = 0;
-    int64_t blocks = 0, blocks_big = 0, ws_off = 0;
+    gg.n = gb.n = gt.n = 0;
+    int64_t blocks = 0, blocks_big = 0, blocks_tall = 0, ws_off = 0;
     int max_rblocks = 1;
     for (int i = 0; i < n_items; ++i) {
         const PsnGemmTnItem& it = items[i];
@@ -874,8 +1006,9 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         const bool vec = (((uintptr_t)it.A | (uintptr_t)it.B | (uintptr_t)it.A2 | (uintptr_t)it.B2) & 15) == 0 && it.lda % 4 == 0 &&
                          it.ldb % 4 == 0 && it.lda >= 4 && it.ldb >= 4 && (!it.A2 || (it.lda2 % 4 == 0 && it.ldb2 % 4 == 0 && it.lda2 >= 4 && it.ldb2 >= 4));
         const bool big = vec && it.b_div == 0 && it.M > 128 && it.N > 128 && it.M <= T256 && it.N <= T256;
-        const int sk = big ? split_big : split_k;
-        GemmArgs& g = big ? gb.g[gb.n] : gg.g[gg.n];
+        const bool tall = vec && it.b_div == 0 && it.M > 128 && it.M <= T256 && it.N <= T64;
+        const int sk = big ? split_big : tall ? split_tall : split_k;
+        GemmArgs& g = big ? gb.g[gb.n] : tall ? gt.g[gt.n] : gg.g[gg.n];
         g.M = it.M; g.N = it.N; g.K = (int)K; g.A = it.A; g.lda = it.lda; g.B = it.B; g.ldb = it.ldb;
         g.A2 = it.A2; g.lda2 = it.lda2; g.B2 = it.B2; g.ldb2 = it.ldb2;
         // a modulo that cannot wrap ((K - 1) / div < mod) is passed as 0 = identity
@@ -884,9 +1017,9 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         g.b2_mod = (it.b2_div > 0 && (K - 1) / it.b2_div < it.b2_mod) ? 0 : (int)it.b2_mod;
         g.bias = nullptr; g.epi = PSN_EPI_NONE; g.aux_in = g.aux_in2 = nullptr; g.aux_out = nullptr;
         g.ld_aux_in = g.ld_aux_in2 = g.ld_aux_out = 0;
-        g.tiles_n = big ? 1 : (it.N + 127) / 128;
-        g.n_tiles = big ? 1 : (int64_t)((it.M + BM - 1) / BM) * g.tiles_n;
-        g.k_chunk = big ? kc_big : kc;
+        g.tiles_n = (big || tall) ? 1 : (it.N + 127) / 128;
+        g.n_tiles = (big || tall) ? 1 : (int64_t)((it.M + BM - 1) / BM) * g.tiles_n;
+        g.k_chunk = big ? kc_big : tall ? kc_tall : kc;
         g.split_k = sk * n_seg;
         g.seg_splits = sk;
         g.a_vec = (((uintptr_t)it.A & 15) == 0) && (it.lda % 4 == 0) && (!it.A2 || ((((uintptr_t)it.A2 & 15) == 0) && (it.lda2 % 4 == 0)));
@@ -913,6 +1046,9 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         if (big) {
             gb.block_start[gb.n++] = blocks_big;
             blocks_big += g.split_k;
+        } else if (tall) {
+            gt.block_start[gt.n++] = blocks_tall;
+            blocks_tall += g.split_k;
         } else {
             gg.block_start[gg.n++] = blocks;
             blocks += (g.n_tiles * g.split_k + 7) / 8 * 8;
@@ -920,12 +1056,17 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
     }
     gg.block_start[gg.n] = blocks;
     gb.block_start[gb.n] = blocks_big;
+    gt.block_start[gt.n] = blocks_tall;
     PSN_CHECK_ARG(ws_off <= workspace_floats, "gemm_tn_grouped: workspace too small (%lld floats needed)", (long long)ws_off);
-    PSN_CHECK_ARG(blocks < (1ll << 31) && blocks_big < (1ll << 31), "gemm_tn_grouped: too many blocks");
+    PSN_CHECK_ARG(blocks < (1ll << 31) && blocks_big < (1ll << 31) && blocks_tall < (1ll << 31), "gemm_tn_grouped: too many blocks");
     hipStream_t st = (hipStream_t)stream;
     if (gb.n > 0) {
         hipLaunchKernelGGL(gemm_tn256_grouped_kernel, dim3((unsigned)blocks_big), dim3(256), T256_BUF * 2 * sizeof(float), st, gb);
         PSN_CHECK_LAUNCH("gemm_tn_grouped (256 x 256 tiles)");
+    }
+    if (gt.n > 0) {
+        hipLaunchKernelGGL(gemm_tn_tall_grouped_kernel, dim3((unsigned)blocks_tall), dim3(256), 0, st, gt);
+        PSN_CHECK_LAUNCH("gemm_tn_grouped (256 x 64 tiles)");
     }
     if (gg.n > 0) {
         hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gg);

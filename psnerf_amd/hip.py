@@ -486,6 +486,14 @@ def _tn_is_big(it):
             and all(ok(it.get(k)) for k in ('A', 'B', 'A2', 'B2')))
 
 
+def _tn_is_tall(it):
+    """Products that psn_gemm_tn_grouped sends to its 256 x (<= 64)-tile kernel (input-block gradients)."""
+    def ok(t):
+        return t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(0) >= 4)
+    return (not it.get('b_div') and not it.get('b_mod') and 128 < it['A'].shape[1] <= 256 and it['B'].shape[1] <= 64
+            and it.get('B_tab2') is None and all(ok(it.get(k)) for k in ('A', 'B', 'A2', 'B2')))
+
+
 def gemm_tn_grouped(items, split_k=None):
     """Weight gradients of one backward pass in one launch.  items: list of dicts with A [K,M], B [K,N] (row-major
     views, row stride allowed), optional A2 / B2 (second product summed into the same result), optional out [M,N]
@@ -498,7 +506,7 @@ def gemm_tn_grouped(items, split_k=None):
     if split_k is None:
         work = 0
         for it in items:
-            if not _tn_is_big(it):
+            if not _tn_is_big(it) and not _tn_is_tall(it):
                 tiles = ((it['A'].shape[1] + 127) // 128) * ((it['B'].shape[1] + 127) // 128)
                 work += tiles * (2 if it.get('A2') is not None else 1)
         want = max(1, (1024 + work - 1) // max(work, 1))
@@ -517,6 +525,13 @@ def gemm_tn_grouped(items, split_k=None):
             kc = -(-K // want)
             kc = (kc + 15) // 16 * 16
             split_big = -(-K // kc)
+        n_tall = sum((2 if it.get('A2') is not None else 1) for it in chunk if _tn_is_tall(it))
+        split_tall = 1
+        if n_tall:
+            want = max(1, min(768 // n_tall, K // 256 if K >= 256 else 1))
+            kc = -(-K // want)
+            kc = (kc + 15) // 16 * 16
+            split_tall = -(-K // kc)
         for i, it in enumerate(chunk):
             A, B = it['A'], it['B']
             b_div, b_mod = int(it.get('b_div', 0)), int(it.get('b_mod', 0))
@@ -548,7 +563,7 @@ def gemm_tn_grouped(items, split_k=None):
                 e.B_tab2, e.ldb_tab2 = _mat_ptr(Bt2, 'B_tab2'), _ld(Bt2)
                 e.b2_div, e.b2_mod, e.b_split = int(it['b2_div']), int(it.get('b2_mod', Bt2.shape[0])), B.shape[1]
             e.colsum_a = None if cs is None else cs.data_ptr()
-            sk = max(split_k, split_big) if is_big(it) else split_k
+            sk = max(split_k, split_big) if is_big(it) else (max(split_k, split_tall) if _tn_is_tall(it) else split_k)
             need += (2 if A2 is not None else 1) * sk * M * N + sk * M + 16
             keep.append((C, cs))
         ws = workspace(need, dev)

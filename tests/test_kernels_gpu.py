@@ -257,6 +257,37 @@ def test_gemm_tn_grouped_tile256_edges(cuda, Q):
     assert_close(res[1][1].cpu(), D(A2[:, :130]).sum(0), 1e-5, 'tile256 colsum 1')
 
 
+@pytest.mark.parametrize('Q', [7, 100, 4099, 70001])
+def test_gemm_tn_grouped_tall_tile_edges(cuda, Q):
+    """The 256 x (<= 64)-tile path (128 < M <= 256, N <= 64: the input-block gradients of the stage-1 networks) on awkward
+    shapes: K not a multiple of the k-tile, ragged M and N, column slices, two products, next to items of the other paths."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(Q)
+    A = torch.randn(Q, 256, generator=g)
+    A2 = torch.randn(Q, 132, generator=g)  # M = 130 of a 132-wide buffer
+    pe = torch.randn(Q, 64, generator=g)
+    x = torch.randn(Q, 36, generator=g)    # N = 33 of a 36-wide buffer
+    d = lambda t: t.to(cuda)
+    Ad, A2d, ped, xd = d(A), d(A2), d(pe), d(x)
+    items = [dict(A=Ad, B=ped[:, :39], A2=Ad[:, :256], B2=ped[:, 4:43], colsum=True),   # two products, N = 39
+             dict(A=A2d[:, :130], B=xd[:, :33], colsum=True),                          # ragged M and N
+             dict(A=Ad, B=ped),                                                        # N = 64 exactly
+             dict(A=Ad[:, :129], B=ped[:, :1]),                                        # N = 1
+             dict(A=Ad, B=Ad, colsum=True),                                            # 256 x 256 path in the same group
+             dict(A=Ad[:, :100], B=ped[:, :39])]                                       # M <= 128: the 128 x 128 tiles
+    res = hip.gemm_tn_grouped(items)
+    D = lambda t: t.double()
+    refs = [D(A).t() @ D(pe[:, :39]) + D(A).t() @ D(pe[:, 4:43]), D(A2[:, :130]).t() @ D(x[:, :33]), D(A).t() @ D(pe),
+            D(A[:, :129]).t() @ D(pe[:, :1]), D(A).t() @ D(A), D(A[:, :100]).t() @ D(pe[:, :39])]
+    for i, ((C, cs), ref) in enumerate(zip(res, refs)):
+        assert C.shape == ref.shape
+        assert_close(C.cpu(), ref, 1e-5, 'tall dW %d (Q=%d)' % (i, Q))
+    assert_close(res[0][1].cpu(), D(A).sum(0), 1e-5, 'tall colsum 0')
+    assert_close(res[1][1].cpu(), D(A2[:, :130]).sum(0), 1e-5, 'tall colsum 1')
+    res2 = hip.gemm_tn_grouped(items)
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(res, res2))  # deterministic
+
+
 def test_fused_visibility_mlp(cuda):
     """mlp_infer on the stage2 visibility net == oracle MLP (stage2/model/renderer.py:191-200)."""
     from psnerf_amd import hip, fused
