@@ -642,27 +642,37 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_tall_grouped_kernel(GroupedArg
     store_tile<false, T256>(lds + (BUF) * TALL_BUF, tid, ra[S]);                                \
     *reinterpret_cast<float4*>(lds + (BUF) * TALL_BUF + BK * T256_LD + (tid >> 4) * T64_LD + (tid & 15) * 4) = rb[S];
     // step T: multiply tile T out of buffer T & 1; register set S = T & 1 holds tile T + 1 (requested two steps ago): write
-    // it to the other buffer and re-use the set for tile T + 3
+    // it to the other buffer and re-use the set for tile T + 3.  No branches around the staging (addresses are clamped,
+    // rows beyond the slice are masked to zero): with the loads of tiles T + 2 and T + 3 in ONE basic block the compiler
+    // counts its vmcnt waits instead of draining the queue, i.e. two tiles really stay in flight.  MFMA operands of k-pair
+    // j + 1 are read from LDS while the MFMAs of k-pair j execute (two register sets, order pinned).
 #define TL_STEP(T, S)                                                                           \
     {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
         const float* As = lds + ((T) & 1) * TALL_BUF + wave * 64 + li;                          \
         const float* Bs = lds + ((T) & 1) * TALL_BUF + BK * T256_LD + li;                       \
+        float pa[2][2], pb[2][2];                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) pa[0][i] = As[lh * T256_LD + i * 32];     \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) pb[0][n] = Bs[lh * T64_LD + n * 32];      \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                         \
-            float pa[2], pb[2];                                                                 \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) pa[i] = As[(2 * j + lh) * T256_LD + i * 32];  \
-            _Pragma("unroll") for (int n = 0; n < 2; ++n) pb[n] = Bs[(2 * j + lh) * T64_LD + n * 32];   \
+            if (j < 7) {                                                                        \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) pa[(j + 1) & 1][i] = As[(2 * j + 2 + lh) * T256_LD + i * 32]; \
+                _Pragma("unroll") for (int n = 0; n < 2; ++n) pb[(j + 1) & 1][n] = Bs[(2 * j + 2 + lh) * T64_LD + n * 32];  \
+            }                                                                                   \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                       \
                 _Pragma("unroll") for (int n = 0; n < 2; ++n)                                   \
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i], pb[n], acc[i][n], 0, 0, 0); \
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j & 1][i], pb[j & 1][n], acc[i][n], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
         }                                                                                       \
-        if ((T) + 1 < nt) { TL_STORE(((T) + 1) & 1, S, (T) + 1) }                               \
-        if ((T) + 3 < nt) { TL_FETCH((T) + 3, S) }                                              \
+        TL_STORE(((T) + 1) & 1, S, (T) + 1)                                                     \
+        TL_FETCH((T) + 3, S)                                                                    \
         lds_barrier(); /* orders LDS only: the rows of tiles T + 2, T + 3 stay in flight */     \
     }
     TL_FETCH(0, 0)
     TL_STORE(0, 0, 0)
-    if (1 < nt) { TL_FETCH(1, 0) }
-    if (2 < nt) { TL_FETCH(2, 1) }
+    TL_FETCH(1, 0)
+    TL_FETCH(2, 1)
     __syncthreads();
     int t = 0;
     for (; t + 1 < nt; t += 2) {
@@ -985,10 +995,10 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         kc_big = ((kc_big + BK - 1) / BK) * BK;
         split_big = (int)((K + kc_big - 1) / kc_big);
     }
-    // 256 x (<= 64) products (input-block gradients): HBM-bound, three workgroups per CU
+    // 256 x (<= 64) products (input-block gradients): HBM- / MFMA-co-limited, about one workgroup per CU in total
     int split_tall = 1, kc_tall = 0;
     if (tall_products > 0) {
-        int64_t want = 768 / tall_products;
+        int64_t want = 256 / tall_products;  // measured 192 ... 1024: 256 - 512 are best (kernel + reduction of the partial tiles)
         if (want < 1) want = 1;
         if (want > K / 256) want = K / 256 > 0 ? K / 256 : 1;
         kc_tall = (int)((K + want - 1) / want);

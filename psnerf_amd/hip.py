@@ -528,7 +528,7 @@ def gemm_tn_grouped(items, split_k=None):
         n_tall = sum((2 if it.get('A2') is not None else 1) for it in chunk if _tn_is_tall(it))
         split_tall = 1
         if n_tall:
-            want = max(1, min(768 // n_tall, K // 256 if K >= 256 else 1))
+            want = max(1, min(256 // n_tall, K // 256 if K >= 256 else 1))
             kc = -(-K // want)
             kc = (kc + 15) // 16 * 16
             split_tall = -(-K // kc)
