@@ -28,6 +28,7 @@
 // Roofline: MFMA-bound.  Per stage and wave: 128 MFMAs (4096 cycles) vs 32 ds_read_b128.  Measured (lean variant,
 // visibility net): 0.96-0.97 of the dense fp32-MFMA peak algorithmic, matrix pipe 88 % busy at 2.30 GHz.
 #include "common.h"
+#include <stdlib.h>
 
 namespace psn {
 
@@ -610,6 +611,164 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     }
 }
 
+// ---- fused secant root finder, feature-parallel form ---------------------------------------------------------------------
+// The row-parallel engine above needs one serial pass through the network per secant iteration whatever the ray count
+// (a wave owns 16 rays x all 256 outputs: 128 MFMAs = 4096 matrix-pipe cycles per weight stage and SIMD), and 4096 rays
+// are only 64 workgroups: 1.25 ms per train step on a quarter of the chip.  Here a workgroup owns 16 rays and its four
+// waves split the OUTPUT tiles (wave w: tiles 4w .. 4w+3, 32 MFMAs per stage), so 4096 rays are 256 workgroups and a
+// pass is four times shorter.  The price is an activation exchange per layer (16 rays x 256 features through LDS, one
+// barrier); the weights of a wave are private to it, so they go straight from L2 to registers (8 x 1 KB per stage and
+// wave, requested one stage ahead) -- no LDS staging, no stage barriers.  Arithmetic and its order per output element
+// are those of mlp_infer_kernel<false, 16, 1> (same packed weights, same MFMA, K order, softplus, encoding): the
+// refined depths are bit-identical.
+constexpr int kFpLd = 260;  // floats per ray in the exchange buffer (256 + 4: rows 16 B aligned, bank offset 4 per ray)
+__global__ __launch_bounds__(256) void root_find_fp_kernel(InferArgs g) {
+    __shared__ __attribute__((aligned(16))) float xbuf[2][16 * kFpLd];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lg = lane >> 4;
+    const int64_t row = (int64_t)blockIdx.x * 16 + lj;
+    const int64_t rowc = row < g.n_rows ? row : g.n_rows - 1;
+    const int n_layers = g.d.n_layers, n_hidden = n_layers - 1;
+    const float4* W4 = reinterpret_cast<const float4*>(g.w);
+
+    // fragment (e, m) of stage s of the layer at float offset w_off: float4 index w_off / 4 + s * 2048 + (e * 16 + 4 wave + m) * 64 + lane
+    auto frag_ptr = [&](int64_t w_off, int s) { return W4 + w_off / 4 + (int64_t)s * 2048 + (4 * wave) * 64 + lane; };
+    auto load_frags = [&](const float4* p, float4 (&f)[8]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) f[e * 4 + m] = p[(e * 16 + m) * 64];
+    };
+    floatx4 acc[4];
+    auto stage_mma = [&](const float4 (&f)[8], const floatx4& b0, const floatx4& b1) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const floatx4& bs = e ? b1 : b0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[e * 4 + m].x, bs[0], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[e * 4 + m].y, bs[1], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[e * 4 + m].z, bs[2], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[e * 4 + m].w, bs[3], acc[m], 0, 0, 0);
+        }
+    };
+
+    // ray, bracket and first estimate (rendering.py:526), replicated over the lane groups and waves
+    const float ox = g.ray_o[rowc * 3 + 0], oy = g.ray_o[rowc * 3 + 1], oz = g.ray_o[rowc * 3 + 2];
+    const float vx = g.ray_d[rowc * 3 + 0], vy = g.ray_d[rowc * 3 + 1], vz = g.ray_d[rowc * 3 + 2];
+    float dl = g.bracket[rowc], dh = g.bracket[g.n_rows + rowc], fl = g.bracket[2 * g.n_rows + rowc], fh = g.bracket[3 * g.n_rows + rowc];
+    float dp = (-fl) * (dh - dl) / (fh - fl) + dl;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    // positional encoding of the query point in B-operand layout: the expressions of mlp_infer_kernel / pe_encode_kernel
+    auto compute_xin = [&](floatx4 (&xin)[4]) {
+        const int width = 3 + 6 * g.pe_octaves;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = 0.0f;
+                const int col = 16 * t + 4 * lg + r;
+                if (col < 3) {
+                    v = (col == 0 ? qx : (col == 1 ? qy : qz)) * g.pe_scale;
+                } else if (col < width) {
+                    const int q = col - 3;
+                    const int f = q / 6, w = q - 6 * f;
+                    const int c = w % 3;
+                    const float arg = ldexpf((c == 0 ? qx : (c == 1 ? qy : qz)) * g.pe_scale, f);
+                    v = (w >= 3) ? cosf(arg) : sinf(arg);
+                }
+                xin[t][r] = v;
+            }
+        }
+    };
+
+    float4 fa[8], fb[8];  // weight fragments of the current / next stage (roles alternate; every layer has an even stage count)
+    load_frags(frag_ptr(g.d.layers[0].w_off, 0), fa);
+    for (int iter = 0; iter < g.n_iter; ++iter) {
+        qx = ox + dp * vx; qy = oy + dp * vy; qz = oz + dp * vz;  // rendering.py:531
+        for (int li = 0; li < n_hidden; ++li) {
+            const PsnMlpLayer L = g.d.layers[li];
+            const int n_st = L.n_kt_in + L.n_kt_act;
+            const float4* next_first = frag_ptr(g.d.layers[li + 1 < n_hidden ? li + 1 : 0].w_off, 0);  // (after the last hidden layer: layer 0 of the next iteration)
+            {  // bias -> accumulators of this wave's four output tiles
+                const float* bp = g.b + L.b_off + 64 * wave + 4 * lg;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bp + 16 * m);
+                    acc[m][0] = bv.x; acc[m][1] = bv.y; acc[m][2] = bv.z; acc[m][3] = bv.w;
+                }
+            }
+            const float* xr = &xbuf[(li + 1) & 1][lj * kFpLd + 4 * lg];  // activations of the previous layer (written under parity (li - 1) & 1)
+#define FP_STAGE2(B0a, B1a, B0b, B1b, S0)                                                             \
+            {                                                                                         \
+                load_frags((S0) + 1 < n_st ? frag_ptr(L.w_off, (S0) + 1) : next_first, fb);           \
+                stage_mma(fa, B0a, B1a);                                                              \
+                load_frags((S0) + 2 < n_st ? frag_ptr(L.w_off, (S0) + 2) : next_first, fa);           \
+                stage_mma(fb, B0b, B1b);                                                              \
+            }
+            if (L.n_kt_act > 0) {
+#pragma unroll
+                for (int kt = 0; kt < 8; kt += 2) {
+                    const floatx4 a0 = ld4(xr + 32 * kt), a1 = ld4(xr + 32 * kt + 16), a2 = ld4(xr + 32 * kt + 32), a3 = ld4(xr + 32 * kt + 48);
+                    FP_STAGE2(a0, a1, a2, a3, kt)
+                }
+            }
+            if (L.n_kt_in > 0) {
+                floatx4 xin[4];
+                compute_xin(xin);
+                FP_STAGE2(xin[0], xin[1], xin[2], xin[3], L.n_kt_act)
+            }
+#undef FP_STAGE2
+            // activation, then this wave's 64 features of its 16 rays into the exchange buffer
+            float* xw = &xbuf[li & 1][lj * kFpLd + 64 * wave + 4 * lg];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                floatx4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = acc[m][r];
+                    o[r] = L.act == PSN_ACT_SOFTPLUS100 ? softplus100(z) : (L.act == PSN_ACT_RELU ? relu1(z) : z);
+                }
+                st4(xw + 16 * m, o);
+            }
+            __syncthreads();
+        }
+        // final layer: output row 0 (the occupancy logit) of the 32-wide final tile pair; every wave evaluates it for
+        // its own copy of the bracket -- 64 MFMAs instead of a broadcast and another barrier
+        {
+            const PsnMlpLayer L = g.d.layers[n_hidden];
+            const float* xr = &xbuf[(n_hidden + 1) & 1][lj * kFpLd + 4 * lg];
+            const float4* wf = W4 + L.w_off / 4 + lane;  // k-tile kt, half e, tile 0: float4 index kt * 256 + e * 128 + lane
+            const float4 bv = *reinterpret_cast<const float4*>(g.b + L.b_off + 4 * lg);
+            floatx4 c;
+            c[0] = bv.x; c[1] = bv.y; c[2] = bv.z; c[3] = bv.w;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float4 a = wf[kt * 256 + e * 128];
+                    const floatx4 b = ld4(xr + 32 * kt + 16 * e);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[3], c, 0, 0, 0);
+                }
+            }
+            // occupancy of ray lj sits in the lane group lg == 0 (output feature 0): rendering.py:537-548
+            float fm = sigmoidf_(c[0] * -10.0f) - g.tau;
+            fm = __shfl(fm, lj);
+            if (fm < 0.0f) { dl = dp; fl = fm; } else { dh = dp; fh = fm; }
+            dp = (-fl) * (dh - dl) / (fh - fl) + dl;
+        }
+        if (n_hidden & 1) __syncthreads();  // odd depth: layer 0 of the next iteration writes the buffer the final layer has just read
+    }
+    if (wave == 0 && row < g.n_rows && lg == 0) g.out[row] = dp;
+}
+
 // W[rows][cols] (or its transpose in memory), zero-extended to [n_mt*32][k_tiles*32] -> stage order
 // [kt32][e(2)][mt16][lane][4]:
 //   lane (i = lane & 15, g = lane >> 4), component c  <-  W[16*mt16 + i][32*kt32 + 16*e + 4*g + c]
@@ -818,7 +977,19 @@ extern "C" int psn_root_find(const PsnMlpDesc* desc, const float* packed_w, cons
     const int64_t blocks = (n_rays + kWaves * 16 - 1) / (kWaves * 16);
     PSN_CHECK_ARG(blocks < (1ll << 31), "root_find: too many rays");
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
-    hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 1>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    // feature-parallel form whenever the network has the shape it is written for (even stage counts per layer: the
+    // 64-column encoding = 2 input k-tiles, 8 activation k-tiles); the row-parallel engine otherwise
+    bool fp = d.n_layers >= 2;
+    for (int l = 0; l < d.n_layers - 1; ++l) fp = fp && (d.layers[l].n_kt_in == 0 || d.layers[l].n_kt_in == 2) && (d.layers[l].n_kt_act == 0 || d.layers[l].n_kt_act == 8);
+    fp = fp && d.layers[d.n_layers - 1].n_kt_act == 8 && d.layers[d.n_layers - 1].n_kt_in == 0;
+    if (const char* ev = getenv("PSN_ROOT_FIND_ROW_PARALLEL")) fp = fp && ev[0] != '1';  // test hook: both forms must agree bit for bit
+    if (fp) {
+        const int64_t blocks16 = (n_rays + 15) / 16;
+        PSN_CHECK_ARG(blocks16 < (1ll << 31), "root_find: too many rays");
+        hipLaunchKernelGGL(root_find_fp_kernel, dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 1>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    }
     PSN_CHECK_LAUNCH("root_find");
     return PSN_OK;
 }

@@ -284,10 +284,19 @@ def test_root_finder_and_crossing_vs_stepwise_formulation(cuda):
         # -- fused vs step-by-step secant
         d_fused = ren._march_finish(st, 8)
         d_step = ren._march_finish_compact(st, 8)
+        # -- the feature-parallel root finder (16 rays per workgroup, output tiles split over the waves) vs the row-parallel
+        #    engine: same arithmetic in the same order per output element, so the depths agree bit for bit
+        import os
+        os.environ['PSN_ROOT_FIND_ROW_PARALLEL'] = '1'
+        try:
+            d_rowpar = ren._march_finish(st, 8)
+        finally:
+            del os.environ['PSN_ROOT_FIND_ROW_PARALLEL']
     fin = torch.isfinite(d_step)
     assert torch.equal(fin, torch.isfinite(d_fused)) and int(m.sum()) > 20
     assert torch.equal(d_step == 0, d_fused == 0)
     assert_close(d_fused[fin].cpu(), d_step[fin].cpu(), 1e-6, 'fused vs step-by-step secant', atol=1e-6)
+    assert torch.equal(d_fused, d_rowpar), 'feature-parallel vs row-parallel root finder'
 
 
 def test_shadow_ray_compaction_is_bit_identical(cuda):
