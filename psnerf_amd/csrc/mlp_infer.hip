@@ -51,6 +51,12 @@ struct InferArgs {
     const float* aux2[PSN_MLP_MAX_LAYERS];  // aux2: second row-major operand (PSN_ACT_MUL2 / PSN_ACT_SOFTPLUS_BWD)
     float* save2[PSN_MLP_MAX_LAYERS];       // second dump (sigmoid of PSN_ACT_SOFTPLUS100, raw acc of MUL_AUX, acc*aux2 of MUL2)
     const float* act_init;                  // optional row-major [n_rows, 256] initial activations (chains that start from a tensor)
+    // rank-k init (k <= 4): the layers with init_off >= 0 additionally start from sum_c rk_coef[row, c] * rk_basis[c, init_off + f]
+    // -- the init table of a backward chain, d h = g_out W_last with 1..3 outputs, formed in registers instead of being
+    // written to HBM by a K = 3 GEMM / a broadcast product and read back (1 KB per row each way)
+    const float* rk_coef;   // [n_rows, rk_k]
+    const float* rk_basis;  // [rk_k, init_stride]
+    int rk_k;
     // SRC == 1 (fused secant root finder, psn_root_find): the rows are rays, the network input is computed in the kernel
     const float* ray_o;      // [n_rows, 3]
     const float* ray_d;      // [n_rows, 3]
@@ -476,6 +482,22 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                         acc[mt][3] += u.w;
                     }
                 }
+                if constexpr (CHAIN) {
+                    if (g.rk_coef != nullptr) {
+                        for (int c = 0; c < g.rk_k; ++c) {
+                            const float cf = g.rk_coef[rowc * g.rk_k + c];
+                            const float* bp2 = g.rk_basis + (int64_t)c * g.d.init_stride + L.init_off + 4 * lg;
+#pragma unroll
+                            for (int mt = 0; mt < NMT; ++mt) {
+                                const float4 u = *reinterpret_cast<const float4*>(bp2 + mt * 16);
+                                acc[mt][0] = fmaf(cf, u.x, acc[mt][0]);
+                                acc[mt][1] = fmaf(cf, u.y, acc[mt][1]);
+                                acc[mt][2] = fmaf(cf, u.z, acc[mt][2]);
+                                acc[mt][3] = fmaf(cf, u.w, acc[mt][3]);
+                            }
+                        }
+                    }
+                }
             }
         }
         // K tiles from the previous activations first, then from the input features (matches the packer): once the
@@ -860,7 +882,8 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
                              int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                              const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
                              const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
-                             const float* act_init, int64_t n_rows, float* out, void* stream) {
+                             const float* act_init, const float* rk_coef, const float* rk_basis, int rk_k, int64_t n_rows,
+                             float* out, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(desc && packed_w && packed_b && (out || desc->n_out == 0), "mlp_infer: null pointer");
     const PsnMlpDesc& d = *desc;
@@ -872,7 +895,10 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         uses_init = uses_init || d.layers[l].init_off >= 0;
     }
     PSN_CHECK_ARG(!uses_in || (tab_a && d.in_kt_a >= 1 && (d.in_kt_b == 0 || tab_b)), "mlp_infer: input table missing");
-    PSN_CHECK_ARG(!uses_init || (init_a && d.init_stride >= 64 && d.init_stride % 4 == 0), "mlp_infer: init table missing");
+    PSN_CHECK_ARG((rk_coef == nullptr) == (rk_basis == nullptr) && (rk_coef == nullptr ? rk_k == 0 : (rk_k >= 1 && rk_k <= 4)),
+                  "mlp_infer: rank-k init needs coefficients, basis and 1 <= k <= 4 (k=%d)", rk_k);
+    PSN_CHECK_ARG(!uses_init || ((init_a || rk_coef) && d.init_stride >= 64 && d.init_stride % 4 == 0), "mlp_infer: init table missing");
+    PSN_CHECK_ARG((((uintptr_t)rk_basis) & 15) == 0, "mlp_infer: rk_basis must be 16-byte aligned");
     PSN_CHECK_ARG((((uintptr_t)init_a | (uintptr_t)init_b) & 15) == 0, "mlp_infer: init tables must be 16-byte aligned");
     PSN_CHECK_ARG(d.n_out >= 0 && d.n_out <= 32, "mlp_infer: n_out=%d", d.n_out);
     PSN_CHECK_ARG(a_div >= 1 && a_mod >= 1 && (d.in_kt_b == 0 || (b_div >= 1 && b_mod >= 1)), "mlp_infer: bad index map");
@@ -927,8 +953,9 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer: too many rows");
     a.act_init = act_init;
+    a.rk_coef = rk_coef; a.rk_basis = rk_basis; a.rk_k = rk_k;
     PSN_CHECK_ARG((((uintptr_t)act_init) & 15) == 0, "mlp_infer: act_init must be 16-byte aligned");
-    bool chain = act_init != nullptr;
+    bool chain = act_init != nullptr || rk_coef != nullptr;
     for (int l = 0; l < d.n_layers; ++l)
         chain = chain || d.layers[l].act > PSN_ACT_SOFTPLUS100 || a.save2[l] != nullptr || a.mask[l] != nullptr || a.aux2[l] != nullptr;
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);

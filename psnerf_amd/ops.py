@@ -594,13 +594,13 @@ class VisibilityPair(torch.autograd.Function):
         g = g.contiguous()
 
         # last layer (out = 1): dW = g^T h ; d h_{n-2} = g w  (rank-1, feeds the fused backward chain)
-        dh_last = hip.gemm(g, Ws[n - 1].contiguous())  # [Q,256]
         # d z_l = d h_l * relu'(h_l), d h_{l-1} = W_l[:, :256]^T d z_l for l = n-2 .. 0 in ONE register-resident
         # launch (transposed weight packs, activations re-read as masks, every d z_l dumped for the weight GEMMs)
         chain = fused.pack_relu_bwd(list(Ws), ctx.skip_at)
         DZ = [torch.empty(Q, 256, device=g.device) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
-        chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh_last, mask=[H[n - 2 - j] for j in range(n - 1)],
-              save=DZ, save_row0=0)
+        # (the rank-1 init table d h_{n-2} = g w is formed inside the chain kernel: hip.mlp_infer rank_init)
+        chain(None, Q, a_div=1, a_mod=Q, rank_init=(g.reshape(Q, 1), Ws[n - 1].reshape(1, -1).contiguous()),
+              mask=[H[n - 2 - j] for j in range(n - 1)], save=DZ, save_row0=0)
         # Every weight gradient in one grouped launch.  The input block [PE(x_n) | PE(l_v)] of row k = v Ns + n is never
         # expanded: its two halves are TABLES read as pe_x[k % Ns] and pe_lv[k // Ns] by the GEMM itself, side by side in
         # one 128-column product.
@@ -733,9 +733,9 @@ class GeoFieldFused(torch.autograd.Function):
 
         # adjoint of the value pass: dz_l = s_l da_l + 100 (1 - s_l) E_l
         dZ = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]  # dZ[l] = d loss / d z_l
-        init = (d_logit * w_row).contiguous()  # [Q,256] rank-1 term of W_last^T d_out
         key = 'value_bwd' if sweep else 'value_bwd_nosweep'
-        chains[key](None, Q, a_div=1, a_mod=Q, init_a_direct=init, act_init=d_feat,
+        # the rank-1 term d_logit (x) w_row of W_last^T d_out is formed inside the chain kernel (rank_init)
+        chains[key](None, Q, a_div=1, a_mod=Q, rank_init=(d_logit.reshape(Q, 1).contiguous(), w_row), act_init=d_feat,
                     mask=[S[n - 2 - j] for j in range(n - 1)],
                     aux2=[E[n - 2 - j] for j in range(n - 1)] if sweep else None,
                     save=[dZ[n - 2 - j] for j in range(n - 1)])
@@ -795,10 +795,11 @@ class AppNetFused(torch.autograd.Function):
         Ws = sv[2 + n - 1:]
         Q, dev = x.shape[0], x.device
         g = g.contiguous()
-        dh = hip.gemm(g, Ws[n - 1].contiguous())  # [Q,256]
         DZ = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
         d_feat = torch.empty(Q, 256, device=dev)
-        chains['bwd'](None, Q, a_div=1, a_mod=Q, init_a_direct=dh, mask=[H[n - 2 - j] for j in range(n - 1)] + [None],
+        # d h_{n-2} = g W_last (3 colours): a rank-3 init formed inside the chain kernel instead of a K = 3 GEMM that
+        # writes [Q, 256] to HBM for the chain to read back
+        chains['bwd'](None, Q, a_div=1, a_mod=Q, rank_init=(g, Ws[n - 1].contiguous()), mask=[H[n - 2 - j] for j in range(n - 1)] + [None],
                       save=DZ + [d_feat])
         dz0 = DZ[n - 2]
         d_normal = hip.gemm(dz0, Ws[0][:, d_x - 3:d_x].contiguous())  # [Q,3]
@@ -854,10 +855,13 @@ class FusedReluNet(torch.autograd.Function):
         g = g.contiguous()
         if final_sigmoid:
             g = g * out * (1.0 - out)
-        dh = hip.gemm(g, Ws[n - 1].contiguous())  # [Q, width]
         chain = fused.pack_relu_bwd(list(Ws), skip_at, width=width)
         DZ = [torch.empty(Q, width, device=dev) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
-        chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh, mask=[H[n - 2 - j] for j in range(n - 1)], save=DZ)
+        if Ws[n - 1].shape[0] <= 4:  # d h_{n-2} = g W_last as a rank-k init inside the kernel (albedo / normal nets: 3 outputs)
+            chain(None, Q, a_div=1, a_mod=Q, rank_init=(g, Ws[n - 1].contiguous()), mask=[H[n - 2 - j] for j in range(n - 1)], save=DZ)
+        else:
+            dh = hip.gemm(g, Ws[n - 1].contiguous())  # [Q, width]
+            chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh, mask=[H[n - 2 - j] for j in range(n - 1)], save=DZ)
         x_in = pe[:, :din]
         items = [dict(A=g, B=H[n - 2], colsum=True)]
         where = [(n - 1, 'w')]
