@@ -869,6 +869,50 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         }
     }
 }
+// The same with 16-byte loads: a thread owns 4 consecutive columns and every fourth row of the slab (64 threads x 16 B =
+// one 1 KB row piece per wave and load, four rows of a thread in flight through the unrolled loop); the four row phases
+// are combined through LDS in a fixed order.  The one-column-per-thread kernel above is latency-bound (one dependent
+// load -> multiply -> add chain per thread: 1.5 TB/s on [524288, 256]); this one streams.
+template <int NW>
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                                 int64_t ldw, int64_t M, int N, int64_t ldx,
+                                                                 int64_t rows_per_block, float* __restrict__ partial) {
+    constexpr int NW1 = NW > 0 ? NW : 1;
+    __shared__ float4 red[3][NW1][64];
+    const int c4 = (threadIdx.x & 63) * 4, rsub = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    float4 s[NW1];
+#pragma unroll
+    for (int j = 0; j < NW1; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < N) {
+#pragma unroll 4
+        for (int64_t m = r0 + rsub; m < r1; m += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(X + m * ldx + c4);
+#pragma unroll
+            for (int j = 0; j < NW1; ++j) {
+                const float wj = NW > 0 ? w[m * ldw + j] : 1.0f;
+                if (NW > 0) { s[j].x += wj * x.x; s[j].y += wj * x.y; s[j].z += wj * x.z; s[j].w += wj * x.w; }
+                else { s[j].x += x.x; s[j].y += x.y; s[j].z += x.z; s[j].w += x.w; }
+            }
+        }
+    }
+    if (rsub > 0) {
+#pragma unroll
+        for (int j = 0; j < NW1; ++j) red[rsub - 1][j][threadIdx.x & 63] = s[j];
+    }
+    __syncthreads();
+    if (rsub == 0 && c4 < N) {
+#pragma unroll
+        for (int j = 0; j < NW1; ++j) {
+            const float4 a = red[0][j][threadIdx.x], b = red[1][j][threadIdx.x], c = red[2][j][threadIdx.x];
+            float4 t;
+            t.x = (s[j].x + a.x) + (b.x + c.x); t.y = (s[j].y + a.y) + (b.y + c.y);
+            t.z = (s[j].z + a.z) + (b.z + c.z); t.w = (s[j].w + a.w) + (b.w + c.w);
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * NW1 + j) * N + c4) = t;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int N, int NW,
                                                            int accumulate, float* __restrict__ out) {
     __shared__ float red[4];
@@ -1113,6 +1157,16 @@ extern "C" int psn_colsum(const float* X, const float* row_weight, int n_w, int6
     if (nblocks < 1) nblocks = 1;
     int64_t rpb = (M + nblocks - 1) / nblocks;
     if (rpb < 1) rpb = 1;
+    const bool vec = N <= 256 && N % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)X | (uintptr_t)workspace) & 15) == 0;
+    if (vec) {
+        switch (n_w) {
+            case 0: hipLaunchKernelGGL(colsum_partial_vec_kernel<0>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
+            case 1: hipLaunchKernelGGL(colsum_partial_vec_kernel<1>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
+            case 2: hipLaunchKernelGGL(colsum_partial_vec_kernel<2>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
+            case 3: hipLaunchKernelGGL(colsum_partial_vec_kernel<3>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
+            default: hipLaunchKernelGGL(colsum_partial_vec_kernel<4>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
+        }
+    } else
     switch (n_w) {
         case 0: hipLaunchKernelGGL(colsum_partial_kernel<0>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;
         case 1: hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(nblocks), dim3(256), 0, st, X, row_weight, ldw, M, N, ldx, rpb, workspace); break;

@@ -257,6 +257,29 @@ def test_gemm_tn_grouped_tile256_edges(cuda, Q):
     assert_close(res[1][1].cpu(), D(A2[:, :130]).sum(0), 1e-5, 'tile256 colsum 1')
 
 
+@pytest.mark.parametrize('M,N', [(5000, 256), (70001, 256), (333, 128), (999, 64), (1234, 39), (3, 256)])
+def test_colsum_weighted_and_plain(cuda, M, N):
+    """psn_colsum: plain column sums and the n_w <= 4 weighted form (g^T H of a head with <= 4 outputs), on the 16-byte
+    path (N % 4 == 0) and the scalar fallback, strided X, accumulation."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(M + N)
+    X = torch.randn(M, N + 4, generator=g)
+    W = torch.randn(M, 4, generator=g)
+    Xd, Wd = X.to(cuda), W.to(cuda)
+    D = lambda t: t.double()
+    for xv, xr in ((Xd[:, :N], X[:, :N]), (Xd[:, 4:], X[:, 4:])):       # row stride N + 4; the second view is 16 B aligned too
+        assert_close(hip.colsum(xv).cpu(), D(xr).sum(0), 1e-5, 'plain colsum')
+        for nw in (1, 3, 4):
+            out = hip.colsum(xv, row_weight=Wd[:, :nw])
+            assert out.shape == (nw, N)
+            assert_close(out.cpu(), D(W[:, :nw]).t() @ D(xr), 1e-5, 'weighted colsum n_w=%d' % nw)
+        acc = torch.ones(N, device=cuda)
+        hip.colsum(xv, out=acc, accumulate=True)
+        assert_close(acc.cpu(), 1.0 + D(xr).sum(0), 1e-5, 'accumulating colsum')
+    one = hip.colsum(Xd[:, :N], row_weight=Wd[:, 0].contiguous())      # a 1-D weight counts as one column
+    assert_close(one.cpu(), (D(W[:, :1]).t() @ D(X[:, :N])), 1e-5, '1-D row weight')
+
+
 @pytest.mark.parametrize('Q', [7, 100, 4099, 70001])
 def test_gemm_tn_grouped_tall_tile_edges(cuda, Q):
     """The 256 x (<= 64)-tile path (128 < M <= 256, N <= 64: the input-block gradients of the stage-1 networks) on awkward
