@@ -445,7 +445,7 @@ def pack_app_chains(weights, biases, d_x):
     whose input is cat[x (points, view encoding, normal: d_x <= 64 columns), 256 geometry features].  The features
     enter the first layer as the chain's initial activations (act_init), x as input-feature k-tiles.
     Returns dict(fwd, bwd): fwd dumps the hidden activations, bwd = ReLU backward chain over transposed packs that
-    ends with a HEAD layer producing d features."""
+    ends with a HEAD layer producing d features and a 3-output final layer producing d normal."""
     n = len(weights)
     dev = weights[0].device
     W = [w.detach() for w in weights]
@@ -462,5 +462,8 @@ def pack_app_chains(weights, biases, d_x):
     for l in range(n - 2, 0, -1):
         ls.append(dict(w_act=_t(W[l]), bias=zeros, act=hip.ACT_RELU_MASK))
     ls.append(dict(w_act=_t(W[0][:, d_x:]), bias=zeros, act=hip.ACT_HEAD))
-    bwd = pack_layers(ls, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
+    # final layer of the backward chain: d normal = d z_0 W_0[:, d_x-3:d_x] (the HEAD layer leaves d z_0 in the
+    # activation registers), so the [Q, 256] x [256, 3] product needs no pass over the dumped d z_0
+    ls.append(dict(w_act=_t(W[0][:, d_x - 3:d_x]), bias=_zeros(32, dev), act=hip.ACT_NONE))
+    bwd = pack_layers(ls, ka, 0, 3, hip.OUT_NONE, dev)
     return dict(fwd=fwd, bwd=bwd)

@@ -799,10 +799,9 @@ class AppNetFused(torch.autograd.Function):
         d_feat = torch.empty(Q, 256, device=dev)
         # d h_{n-2} = g W_last (3 colours): a rank-3 init formed inside the chain kernel instead of a K = 3 GEMM that
         # writes [Q, 256] to HBM for the chain to read back
-        chains['bwd'](None, Q, a_div=1, a_mod=Q, rank_init=(g, Ws[n - 1].contiguous()), mask=[H[n - 2 - j] for j in range(n - 1)] + [None],
-                      save=DZ + [d_feat])
+        d_normal = chains['bwd'](None, Q, a_div=1, a_mod=Q, rank_init=(g, Ws[n - 1].contiguous()),
+                                 mask=[H[n - 2 - j] for j in range(n - 1)] + [None, None], save=DZ + [d_feat])  # [Q,3] = d z_0 W_0[:, normal columns]
         dz0 = DZ[n - 2]
-        d_normal = hip.gemm(dz0, Ws[0][:, d_x - 3:d_x].contiguous())  # [Q,3]
         items = [dict(A=dz0, B=x[:, :d_x], colsum=True), dict(A=dz0, B=feat)]
         items += [dict(A=DZ[n - 2 - l], B=H[l - 1], colsum=True) for l in range(1, n - 1)]
         res = hip.gemm_tn_grouped(items)
