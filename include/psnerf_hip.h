@@ -238,13 +238,16 @@ int psn_mlp_pack_layers(int n_items, const PsnPackItem* items, void* stream);
  * init_off >= 0 additionally start from sum_c rk_coef[row, c] * rk_basis[c, init_off + f].  This is the init table of a
  * backward chain whose network has 1..4 outputs, d h = g_out W_last (stage1/model/network.py:104-106 colour head,
  * :93-95 occupancy logit; stage2/model/renderer.py:47-49), formed in registers instead of a [n_rows, 256] tensor.
+ * dump_tiles (HOST array of 2 * PSN_MLP_MAX_LAYERS words, or NULL = everything): bit mt of word l / word
+ * PSN_MLP_MAX_LAYERS + l set = the 16-column tile mt of layer l's first / second dump is written; for dumps of which only
+ * a column range is read afterwards (the raw sweep values that feed d logit / d pe, network.py:108-120).
  * out [n_rows, n_out]. */
 int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                   int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                   const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
                   const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
-                  const float* act_init, const float* rk_coef, const float* rk_basis, int rk_k, int64_t n_rows,
-                  float* out, void* stream);
+                  const float* act_init, const float* rk_coef, const float* rk_basis, int rk_k,
+                  const uint32_t* dump_tiles, int64_t n_rows, float* out, void* stream);
 
 /* Dense per-pixel outputs of the stage-2 model, stage2/model/renderer.py:145-152,204-264: dense [B, N, C] = fill
  * everywhere except dense[b, idx[r], c] = rows[(b Ns + r) row_stride + c col_stride] (light-major surface rows;

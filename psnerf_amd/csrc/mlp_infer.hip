@@ -54,6 +54,10 @@ struct InferArgs {
     // rank-k init (k <= 4): the layers with init_off >= 0 additionally start from sum_c rk_coef[row, c] * rk_basis[c, init_off + f]
     // -- the init table of a backward chain, d h = g_out W_last with 1..3 outputs, formed in registers instead of being
     // written to HBM by a K = 3 GEMM / a broadcast product and read back (1 KB per row each way)
+    // dump tile masks (chain variant): bit mt set = the 16-feature tile mt of the layer's first / second dump is written.
+    // A dump of which only a column range is ever read (the raw sweep values of the skip layer and of layer 0: 39 of 256
+    // columns each, 1 GB per 524k points) is written for those tiles only.
+    uint32_t save_tiles[PSN_MLP_MAX_LAYERS], save2_tiles[PSN_MLP_MAX_LAYERS];
     const float* rk_coef;   // [n_rows, rk_k]
     const float* rk_basis;  // [rk_k, init_stride]
     int rk_k;
@@ -230,7 +234,8 @@ __device__ __forceinline__ void st4(float* p, const floatx4& v) { *reinterpret_c
 // the next layer's MFMAs.  p1 / p2 are non-null whenever CODE needs them (validated on the host).
 template <int CODE, int NMT>
 __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&act)[NMT], const float* __restrict__ p1,
-                                                 const float* __restrict__ p2, float* __restrict__ d1, float* __restrict__ d2) {
+                                                 const float* __restrict__ p2, float* __restrict__ d1, float* __restrict__ d2,
+                                                 const uint32_t m1, const uint32_t m2) {
     constexpr bool kNeed1 = CODE == PSN_ACT_RELU_MASK || CODE == PSN_ACT_MUL_AUX || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD;
     constexpr bool kNeed2 = CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD;
     constexpr bool kSecond = CODE == PSN_ACT_SOFTPLUS100 || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_MUL_AUX;
@@ -246,7 +251,8 @@ __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&
     if constexpr (CODE == PSN_ACT_HEAD) {  // side output: dump z, the activations stay for the next layer
         if (d1 != nullptr) {
 #pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) st4(d1 + mt * 16, acc[mt]);
+            for (int mt = 0; mt < NMT; ++mt)
+                if ((m1 >> mt) & 1) st4(d1 + mt * 16, acc[mt]);
         }
         return;
     }
@@ -268,9 +274,9 @@ __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&
             else o[r] = z;
         }
         act[mt] = o;
-        if (d1 != nullptr) st4(d1 + mt * 16, o);
+        if (d1 != nullptr && ((m1 >> mt) & 1)) st4(d1 + mt * 16, o);
         if constexpr (kSecond) {
-            if (d2 != nullptr) st4(d2 + mt * 16, o2);
+            if (d2 != nullptr && ((m2 >> mt) & 1)) st4(d2 + mt * 16, o2);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -561,7 +567,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             float* d1 = (g.save[li] != nullptr && dump_row) ? g.save[li] + (row - g.save_row0) * W + 4 * lg : nullptr;
             float* d2 = (g.save2[li] != nullptr && dump_row) ? g.save2[li] + (row - g.save_row0) * W + 4 * lg : nullptr;
             // one straight-line body per code (operand loads batched up front, results stored tile by tile)
-#define PSN_CASE(C) case C: chain_activation<C, NMT>(acc, act, p1, p2, d1, d2); break;
+            const uint32_t m1 = g.save_tiles[li], m2 = g.save2_tiles[li];
+#define PSN_CASE(C) case C: chain_activation<C, NMT>(acc, act, p1, p2, d1, d2, m1, m2); break;
             switch (L.act) {
                 PSN_CASE(PSN_ACT_RELU)
                 PSN_CASE(PSN_ACT_SOFTPLUS100)
@@ -570,10 +577,14 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                 PSN_CASE(PSN_ACT_MUL2)
                 PSN_CASE(PSN_ACT_SOFTPLUS_BWD)
                 PSN_CASE(PSN_ACT_HEAD)
-                default: chain_activation<PSN_ACT_NONE, NMT>(acc, act, p1, p2, d1, d2); break;
+                default: chain_activation<PSN_ACT_NONE, NMT>(acc, act, p1, p2, d1, d2, m1, m2); break;
             }
 #undef PSN_CASE
-            pending_dump = wave_dumps ? (g.save[li] != nullptr ? NMT : 0) + (g.save2[li] != nullptr ? NMT : 0) : 0;
+            // (a partially masked dump issues fewer stores than the counted wait of the next stage would leave room for:
+            //  that wait then drains the queue instead -- at most two layers per launch)
+            const uint32_t all_ = (1u << NMT) - 1u;
+            const bool partial = (g.save[li] != nullptr && (m1 & all_) != all_) || (g.save2[li] != nullptr && (m2 & all_) != all_);
+            pending_dump = (wave_dumps && !partial) ? (g.save[li] != nullptr ? NMT : 0) + (g.save2[li] != nullptr ? NMT : 0) : 0;
             pending_stages = pending_dump > 0 ? 1 : 0;
         }
     }
@@ -882,8 +893,8 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
                              int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                              const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
                              const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
-                             const float* act_init, const float* rk_coef, const float* rk_basis, int rk_k, int64_t n_rows,
-                             float* out, void* stream) {
+                             const float* act_init, const float* rk_coef, const float* rk_basis, int rk_k,
+                             const uint32_t* dump_tiles, int64_t n_rows, float* out, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(desc && packed_w && packed_b && (out || desc->n_out == 0), "mlp_infer: null pointer");
     const PsnMlpDesc& d = *desc;
@@ -954,8 +965,12 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer: too many rows");
     a.act_init = act_init;
     a.rk_coef = rk_coef; a.rk_basis = rk_basis; a.rk_k = rk_k;
+    for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) {
+        a.save_tiles[l] = dump_tiles ? dump_tiles[l] : 0xFFFFFFFFu;
+        a.save2_tiles[l] = dump_tiles ? dump_tiles[PSN_MLP_MAX_LAYERS + l] : 0xFFFFFFFFu;
+    }
     PSN_CHECK_ARG((((uintptr_t)act_init) & 15) == 0, "mlp_infer: act_init must be 16-byte aligned");
-    bool chain = act_init != nullptr || rk_coef != nullptr;
+    bool chain = act_init != nullptr || rk_coef != nullptr || dump_tiles != nullptr;
     for (int l = 0; l < d.n_layers; ++l)
         chain = chain || d.layers[l].act > PSN_ACT_SOFTPLUS100 || a.save2[l] != nullptr || a.mask[l] != nullptr || a.aux2[l] != nullptr;
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);

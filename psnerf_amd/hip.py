@@ -101,7 +101,8 @@ SIGNATURES = {
                                c_f, c_f, c_f]),
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
                             ctypes.POINTER(ctypes.c_void_p), i64, ctypes.POINTER(ctypes.c_void_p),
-                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f, c_f, c_f, i32, i64, c_f, c_f]),
+                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f, c_f, c_f, i32,
+                            ctypes.POINTER(ctypes.c_uint32), i64, c_f, c_f]),
     'psn_scatter_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_gather_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_secant_step': (i32, [c_f, f32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, c_f]),
@@ -621,10 +622,17 @@ def mlp_pack_layers(plan):
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
               init_b=None, save=None, save_row0=0, mask=None, aux2=None, save2=None, act_init=None, macs_per_row=None,
-              rank_init=None):
+              rank_init=None, save_tiles=None, save2_tiles=None):
     """save: list (one entry per hidden layer, None allowed) of [n_rows - save_row0, 256] tensors that receive the
     post-activation outputs of the rows >= save_row0.
     rank_init = (coef [n_rows, k], basis [k, init_stride]), k <= 4: rank-k init of the layers with init_off >= 0."""
+    tiles_arr = None
+    if save_tiles is not None or save2_tiles is not None:  # per layer: bit mt = the 16-column tile mt of the dump is written
+        tiles_arr = (ctypes.c_uint32 * (2 * MAX_LAYERS))(*([0xFFFFFFFF] * (2 * MAX_LAYERS)))
+        for base, lst in ((0, save_tiles), (MAX_LAYERS, save2_tiles)):
+            for l, m in enumerate(lst or []):
+                if m is not None:
+                    tiles_arr[base + l] = int(m)
     rk_coef = rk_basis = None
     rk_k = 0
     if rank_init is not None:
@@ -650,14 +658,14 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
         assert len(save) == n_hidden
         save_arr = (ctypes.c_void_p * len(save))(*[None if t is None else _ptr(t, 'save') for t in save])
     # 'mlp_infer' = the lean engine, 'mlp_chain' = the chain engine (same dispatch rule as psn_mlp_infer)
-    chain = act_init is not None or rank_init is not None or mask is not None or aux2 is not None or save2 is not None or any(
+    chain = act_init is not None or rank_init is not None or tiles_arr is not None or mask is not None or aux2 is not None or save2 is not None or any(
         desc.layers[l].act > ACT_SOFTPLUS100 for l in range(desc.n_layers))
     with _Prof('mlp_chain' if chain else 'mlp_infer', n_rows, None if macs_per_row is None else 2.0 * macs_per_row * n_rows):
         _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
                                   _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,
                                   _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), save_arr, save_row0, mask_arr,
                                   aux2_arr, save2_arr, _ptr(act_init, 'act_init', True), _ptr(rk_coef, 'rk_coef', True),
-                                  _ptr(rk_basis, 'rk_basis', True), rk_k, n_rows, _ptr(out, 'out', True), _stream()), 'mlp_infer')
+                                  _ptr(rk_basis, 'rk_basis', True), rk_k, tiles_arr, n_rows, _ptr(out, 'out', True), _stream()), 'mlp_infer')
     return out
 
 
