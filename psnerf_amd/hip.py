@@ -428,8 +428,9 @@ def root_find(desc, packed_w, packed_b, origin, direction, bracket, tau, n_iter,
 
 
 def workspace(n_floats, device):
-    """Per-device scratch buffer (grown on demand, reused across calls on the same stream)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Scratch buffer per (device, stream), grown on demand: launches on one stream are ordered, so they may share it;
+    two streams (the small stage-2 networks run beside the visibility launch on a side stream) must not."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < n_floats:
         buf = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)

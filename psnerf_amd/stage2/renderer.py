@@ -18,6 +18,8 @@ MI355X mapping:
   * SG / GGX shading -> ops.sg_shade / ops.mf_shade (fused forward / backward kernels);
   * the dense [B, N, C] output dictionary -> one psn_scatter_rows launch (ops.ScatterRows).
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -183,6 +185,12 @@ class PSNetwork(nn.Module):
         # it): during training, the L shading-light visibility rows -- which only enter the loss detached,
         # renderer.py:197 -- are evaluated on the bf16 engine (max |d| ~ 2e-3 on the visibility value).
         self.train_vis_bf16 = conf.get_bool('train.vis_bf16', default=False)
+        # The BRDF / normal networks of a training forward (and, through autograd, their backward) run on a side stream
+        # beside the visibility launch (20 of the 27 ms of a step; it is issued first and needs none of their results):
+        # Ns-row launches of 25 - 70 us each, latency-bound on their own, fill the gaps of the big launch instead of
+        # following it.  Off: everything on the caller's stream.
+        self.overlap_small_nets = conf.get_bool('train.overlap_small_nets', default=True)
+        self._side = {}
         self.visibility = conf.get_bool('train.visibility', default=False)
         self.light_vis_detach = conf.get_bool('train.light_vis_detach', default=False)
         if self.visibility:
@@ -351,6 +359,7 @@ class PSNetwork(nn.Module):
         pe_x = None
         vis_pair = None
         vis_bf16 = None
+        side = None
         if ns > 0 and self.visibility:
             lv0 = input.get('light_vis_train')
             ld0 = input['light_direction']
@@ -358,6 +367,13 @@ class PSNetwork(nn.Module):
                     and self.visibility_net.width == 256 and torch.is_grad_enabled()
                     and (self.light_vis_detach or not (ld0.requires_grad or lv0.requires_grad))):
                 pe_x = self._pe(surf, self.n_freqs)
+                if self.overlap_small_nets and surf.is_cuda:
+                    # fork BEFORE the big launch is queued: the side stream waits for everything issued so far (inputs,
+                    # encodings, the optimiser step of the previous iteration), not for the visibility kernel
+                    side = self._side.get(device)
+                    if side is None:
+                        side = self._side[device] = torch.cuda.Stream(device=device)
+                    side.wait_stream(torch.cuda.current_stream(device))
                 if self.train_vis_bf16:
                     # opt-in (train.vis_bf16): the L shading rows enter the loss detached (renderer.py:197), so they can
                     # run on the bf16 engine; the V supervised rows stay on the exact fp32 path with their dumps
@@ -365,9 +381,11 @@ class PSNetwork(nn.Module):
                     vis_pair = self._visibility_pair_launch(pe_x, ld0[:0], lv0)
                 else:
                     vis_pair = self._visibility_pair_launch(pe_x, ld0, lv0)
+        on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
         if self.normal_mlp:  # renderer.py:127-143
             normal_pred = ones3()
             if ns > 0:
+              with on_side():
                 cols_n = self._cols(self.n_freqs_n, device)
                 normal_s = self._memo('normal', input, lambda: F.normalize(
                     self.normal_net(self._pe(surf, self.n_freqs_n), cols_n), dim=-1))
@@ -401,7 +419,8 @@ class PSNetwork(nn.Module):
             # evaluation: rows [0, Ns) = PE(x), rows [Ns, 2 Ns) = PE(x + noise).  Row-wise identical results, half the
             # (latency-bound, Ns-row) GEMM launches in forward and backward.
             pe_j = None
-            if self.xyz_jitter_std > 0:
+            with on_side():
+              if self.xyz_jitter_std > 0:
                 nz = noise.get('xyz')
                 if nz is None:
                     nz = torch.randn_like(surf) * self.xyz_jitter_std  # = torch.normal(0, std) without its host-side std >= 0 check
@@ -411,11 +430,11 @@ class PSNetwork(nn.Module):
                 albedo_both, rough_both = self._memo('brdf_both', input, brdf_both)
                 albedo, albedo_j = albedo_both[:ns], albedo_both[ns:]
                 rough, rough_j = rough_both[:ns], rough_both[ns:]
-            else:
+              else:
                 albedo, rough = self._memo('brdf', input, lambda: (self.albedo_net(pe_x, cols), self.rough_net(pe_x, cols)))
-            if albedo_new is not None:
+              if albedo_new is not None:
                 albedo = torch.from_numpy(albedo_new).to(device)[None].expand_as(albedo)
-            if sg:
+              if sg:
                 weights = F.relu(rough)
                 if basis_new is not None:  # material editing (eval.py:233-312)
                     wn = torch.zeros_like(weights)
@@ -425,6 +444,15 @@ class PSNetwork(nn.Module):
                         wn.view(-1, 1, self.nbasis)[:, :, basis_new] = 2 ** basis_new / 100
                     weights = wn.reshape(-1, self.nbasis)
                 weight_values = scatter(weight_values, weights)
+            if side is not None:
+                # join: everything below (shading, dense outputs, losses) reads the small networks' outputs on the caller's
+                # stream.  Their memory came from the side stream's pool: tell the allocator about the second user.
+                main = torch.cuda.current_stream(device)
+                main.wait_stream(side)
+                for t_ in (normal_s, albedo_both if self.xyz_jitter_std > 0 else albedo, rough_both if self.xyz_jitter_std > 0 else rough,
+                           weights if sg else None, out_n.get('normal_jitter').rows if 'normal_jitter' in out_n else None):
+                    if torch.is_tensor(t_):
+                        t_.record_stream(main)
             light_int = input.get('light_intensity', self.light_int)
             vis = None
             vis_for_rgb = None

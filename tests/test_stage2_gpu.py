@@ -154,6 +154,49 @@ def test_train_steps_match_oracle(cuda):
     assert_close(step.light_inten_para.weight.detach().cpu(), ostep.light_inten_para.weight.detach(), 1e-4, 'light int')
 
 
+def test_side_stream_overlap_is_bit_identical(cuda):
+    """The BRDF / normal networks on a side stream beside the visibility launch (train.overlap_small_nets, default on)
+    change WHEN kernels run, never what they compute: six optimisation steps (both train_fix phases, 20k pixels so that
+    the launches really overlap) give bit-identical losses, parameters, light tables and Adam states with the overlap
+    switched off."""
+    import psnerf_amd.stage2 as s2
+    conf = s2.bear_conf()
+    sd = stage2_state_dict(conf, seed=9)
+    N, L, V, NL = 20000, 12, 4, 40
+    light_init = torch.nn.functional.normalize(torch.randn(NL, 3, generator=torch.Generator().manual_seed(3)), dim=-1)
+    res = {}
+    for overlap in (True, False):
+        net = s2.PSNetwork(conf)
+        net.load_state_dict(sd)
+        net.to(cuda)
+        assert net.overlap_small_nets is True  # default
+        net.overlap_small_nets = overlap
+        step = s2.TrainStep(net, conf, NL, light_init.to(cuda), cuda)
+        step.cur_iter = 4997
+        step._ori = (1.0, 0.05, 0.01, 1)  # the state train_fix left at iteration 0 (as in test_train_steps_match_oracle)
+        step.loss.sg_rgb_weight, step.loss.albedo_smooth_weight, step.loss.rough_smooth_weight, step.loss.vis_weight = 0, 0, 0, 10
+        step.model.albedo_net.eval().requires_grad_(False)
+        step.model.rough_net.eval().requires_grad_(False)
+        step.light_para.requires_grad_(False)
+        step.light_inten_para.requires_grad_(False)
+        losses = []
+        for it in range(6):
+            inp, gt = stage2_inputs(N, L, V, seed=100 + it)
+            l_slt = torch.randperm(NL, generator=torch.Generator().manual_seed(it))[:L]
+            nz = torch.randn(int(inp['surface_mask'].sum()), 3, generator=torch.Generator().manual_seed(50 + it)) * 0.01
+            pt, _ = step.step({k: v.to(cuda) for k, v in inp.items()}, {k: v.to(cuda) for k, v in gt.items()},
+                              l_slt.to(cuda), noise={'xyz': nz.to(cuda)})
+            losses.append(pt['total'].detach().clone())
+        torch.cuda.synchronize()
+        res[overlap] = (torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in net.state_dict().items()},
+                        step.light_para.weight.detach().cpu().clone(), step.light_inten_para.weight.detach().cpu().clone())
+    (l1, p1, a1, b1), (l0, p0, a0, b0) = res[True], res[False]
+    assert torch.equal(l1, l0), (l1, l0)
+    for k in p1:
+        assert torch.equal(p1[k], p0[k]), k
+    assert torch.equal(a1, a0) and torch.equal(b1, b0)
+
+
 def test_psnetwork_microfacet_golden(cuda):
     """train.render_model = microfacet (GGX, stage2/model/microfacet.py) through the fused mf_shade kernel."""
     import psnerf_amd.stage2 as s2
