@@ -433,7 +433,7 @@ int psn_bf16_pack_group_bias(const float* V, int64_t n, uint16_t* dst, void* str
  * vis [L*Ns] or NULL.  rgb [L*Ns,3]; spec [L*Ns,3] (specular_rgb) or [L*Ns].
  * Backward: g_rgb [L*Ns,3], g_spec like spec or NULL -> d_albedo [Ns,3], d_weights like weights,
  * d_normal [Ns,3], d_vis [L*Ns] or NULL, d_light_dir [L,3], d_light_int [L] or NULL;
- * workspace >= ceil(Ns/256)*L*4 floats.
+ * workspace >= ceil(Ns/64)*L*4 floats.
  * ---------------------------------------------------------------------- */
 int psn_sg_shade_fwd(const float* light_dir, const float* view, const float* normal, const float* albedo,
                      const float* weights, const float* lobe, const float* light_int, int int_ch, float light_int_scalar,
@@ -449,7 +449,7 @@ int psn_sg_shade_bwd(const float* light_dir, const float* view, const float* nor
  * GGX microfacet shading (train.render_model = microfacet): stage2/model/microfacet.py:35-114 followed by
  * stage2/model/renderer.py:187-204, same row layout as psn_sg_shade_*.  rough [Ns] (sigmoid output of rough_net),
  * f0 = brdf.fresnel_f0.  rgb [L*Ns,3].  Backward: d_albedo [Ns,3], d_rough [Ns], d_normal [Ns,3], d_vis [L*Ns] or
- * NULL, d_light_dir [L,3], d_light_int [L] or NULL; workspace >= ceil(Ns/256)*L*4 floats.
+ * NULL, d_light_dir [L,3], d_light_int [L] or NULL; workspace >= ceil(Ns/64)*L*4 floats.
  * ---------------------------------------------------------------------- */
 int psn_mf_shade_fwd(const float* light_dir, const float* view, const float* normal, const float* albedo,
                      const float* rough, const float* light_int, float light_int_scalar, float f0, const float* vis,

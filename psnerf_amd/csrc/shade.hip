@@ -12,6 +12,11 @@
 
 namespace psn {
 
+// One wave per workgroup: the kernels below give a thread one surface point and loop over the lights, so a launch has
+// only Ns threads -- 29,487 at bear.conf sizes = 116 workgroups of 256 threads on 256 CUs.  With 64-thread workgroups the
+// same launch spreads over every CU (461 workgroups) and the per-light block reduction is a single wave reduction.
+constexpr int kShadeThreads = 64;
+
 constexpr int kMaxBasis = 9;
 
 struct ShadeArgs {
@@ -101,14 +106,19 @@ __device__ __forceinline__ void shade_one(const ShadeArgs& a, const PointCtx& p,
     }
 }
 
-__global__ __launch_bounds__(256) void sg_shade_fwd_kernel(ShadeArgs a, float* __restrict__ rgb, float* __restrict__ spec) {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// SG kernels: a workgroup = 64 points x kSgPhases light phases (wave w takes the lights l = w, w + 4, ...): four times the
+// waves of the one-thread-per-point form (1844 instead of 461 on 1024 SIMDs at bear.conf sizes), which is what the
+// latency of the per-(point, light) arithmetic (9 exponentials, a normalisation) needs.
+constexpr int kSgPhases = 4;
+__global__ __launch_bounds__(kShadeThreads * kSgPhases) void sg_shade_fwd_kernel(ShadeArgs a, float* __restrict__ rgb, float* __restrict__ spec) {
+    const int64_t n = (int64_t)blockIdx.x * kShadeThreads + (threadIdx.x & (kShadeThreads - 1));
+    const int phase = threadIdx.x / kShadeThreads;
     const bool ok = n < a.Ns;
     PointCtx p;
     load_point(a, n, ok, p);
     const bool has_vis = a.vis != nullptr;
     const int sc = a.specular_rgb ? 3 : 1;
-    for (int l = 0; l < a.L; ++l) {
+    for (int l = phase; l < a.L; l += kSgPhases) {
         float ld[3] = {a.light_dir[l * 3 + 0], a.light_dir[l * 3 + 1], a.light_dir[l * 3 + 2]};
         float I[3];
 #pragma unroll
@@ -133,15 +143,15 @@ __global__ __launch_bounds__(256) void sg_shade_fwd_kernel(ShadeArgs a, float* _
 }
 
 // d_light_partial [n_blocks, L, 4] = (d_dir xyz, d_intensity) per workgroup
-__global__ __launch_bounds__(256) void sg_shade_bwd_kernel(ShadeArgs a, const float* __restrict__ g_rgb,
+__global__ __launch_bounds__(kShadeThreads * kSgPhases) void sg_shade_bwd_kernel(ShadeArgs a, const float* __restrict__ g_rgb,
                                                            const float* __restrict__ g_spec,
                                                            float* __restrict__ d_albedo, float* __restrict__ d_weights,
                                                            float* __restrict__ d_normal, float* __restrict__ d_vis,
                                                            float* __restrict__ d_light_partial) {
-    __shared__ float red[4][4];
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)blockIdx.x * kShadeThreads + (threadIdx.x & (kShadeThreads - 1));
+    const int phase = threadIdx.x / kShadeThreads;
     const bool ok = n < a.Ns;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     PointCtx p;
     load_point(a, n, ok, p);
     const bool has_vis = a.vis != nullptr;
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256) void sg_shade_bwd_kernel(ShadeArgs a, const fl
 #pragma unroll
         for (int k = 0; k < kMaxBasis; ++k) dw[c][k] = 0.f;
 
-    for (int l = 0; l < a.L; ++l) {
+    for (int l = phase; l < a.L; l += kSgPhases) {
         float ld[3] = {a.light_dir[l * 3 + 0], a.light_dir[l * 3 + 1], a.light_dir[l * 3 + 2]};
         float I[3];
 #pragma unroll
@@ -207,20 +217,35 @@ __global__ __launch_bounds__(256) void sg_shade_bwd_kernel(ShadeArgs a, const fl
         }
         // per-light gradients: wave reduce, then one partial per workgroup (deterministic)
         float r0 = wave_sum_f(dl[0]), r1 = wave_sum_f(dl[1]), r2 = wave_sum_f(dl[2]), r3 = wave_sum_f(dI);
-        if (lane == 0) {
-            red[wave][0] = r0;
-            red[wave][1] = r1;
-            red[wave][2] = r2;
-            red[wave][3] = r3;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-            d_light_partial[((int64_t)blockIdx.x * a.L + l) * 4 + threadIdx.x] = t;
-        }
-        __syncthreads();
+        if (lane == 0) *reinterpret_cast<float4*>(d_light_partial + ((int64_t)blockIdx.x * a.L + l) * 4) = make_float4(r0, r1, r2, r3);
     }
-    if (ok) {
+    // per-point gradients: the four light phases of a point are summed through LDS in a fixed order (deterministic)
+    __shared__ float pred[kSgPhases - 1][6 + 3 * kMaxBasis][kShadeThreads];
+    if (phase > 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pred[phase - 1][c][lane] = dalb[c];
+            pred[phase - 1][3 + c][lane] = dn[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < kMaxBasis; ++k) pred[phase - 1][6 + c * kMaxBasis + k][lane] = dw[c][k];
+    }
+    __syncthreads();
+    if (phase == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dalb[c] = (dalb[c] + pred[0][c][lane]) + (pred[1][c][lane] + pred[2][c][lane]);
+            dn[c] = (dn[c] + pred[0][3 + c][lane]) + (pred[1][3 + c][lane] + pred[2][3 + c][lane]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < kMaxBasis; ++k)
+                dw[c][k] = (dw[c][k] + pred[0][6 + c * kMaxBasis + k][lane]) + (pred[1][6 + c * kMaxBasis + k][lane] + pred[2][6 + c * kMaxBasis + k][lane]);
+    }
+    if (ok && phase == 0) {
         const int nw = a.specular_rgb ? 3 * a.nb : a.nb;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -244,10 +269,17 @@ __global__ __launch_bounds__(256) void sg_shade_bwd_kernel(ShadeArgs a, const fl
 __global__ __launch_bounds__(256) void sg_light_reduce_kernel(const float* __restrict__ partial, int n_blocks, int L,
                                                               float* __restrict__ d_light_dir,
                                                               float* __restrict__ d_light_int) {
-    const int i = blockIdx.x * 256 + threadIdx.x;  // over L*4
-    if (i >= L * 4) return;
+    // 64 outputs (of the L * 4) per workgroup, each summed by four threads over every fourth partial (four independent,
+    // pipelined load -> add chains instead of one n_blocks long), combined in a fixed order: deterministic
+    __shared__ float red[3][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
     float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * L * 4 + i];
+    if (i < L * 4)
+        for (int b = ph; b < n_blocks; b += 4) s += partial[(int64_t)b * L * 4 + i];
+    if (ph > 0) red[ph - 1][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph > 0 || i >= L * 4) return;
+    s = (s + red[0][threadIdx.x]) + (red[1][threadIdx.x] + red[2][threadIdx.x]);
     const int l = i >> 2, c = i & 3;
     if (c < 3) d_light_dir[l * 3 + c] = s;
     else if (d_light_int != nullptr) d_light_int[l] = s;
@@ -354,8 +386,8 @@ __device__ __forceinline__ void mf_one(const float l[3], const float vh[3], cons
     f.vcl = has_vis ? fminf(fmaxf(vis, 0.0f), 1.0f) : 1.0f;
 }
 
-__global__ __launch_bounds__(256) void mf_shade_fwd_kernel(MfArgs a, float* __restrict__ rgb) {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(kShadeThreads) void mf_shade_fwd_kernel(MfArgs a, float* __restrict__ rgb) {
+    const int64_t n = (int64_t)blockIdx.x * kShadeThreads + threadIdx.x;
     const bool ok = n < a.Ns;
     float v[3], nr[3], alb[3], vh[3], nh[3], inv;
 #pragma unroll
@@ -386,15 +418,14 @@ __global__ __launch_bounds__(256) void mf_shade_fwd_kernel(MfArgs a, float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void mf_shade_bwd_kernel(MfArgs a, const float* __restrict__ g_rgb,
+__global__ __launch_bounds__(kShadeThreads) void mf_shade_bwd_kernel(MfArgs a, const float* __restrict__ g_rgb,
                                                            float* __restrict__ d_albedo, float* __restrict__ d_rough,
                                                            float* __restrict__ d_normal, float* __restrict__ d_vis,
                                                            float* __restrict__ d_light_partial) {
-    __shared__ float red[4][4];
     const float PI = 3.14159265358979323846f;
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)blockIdx.x * kShadeThreads + threadIdx.x;
     const bool ok = n < a.Ns;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     float v[3], nr[3], alb[3], vh[3], nh[3], inv_v, inv_n;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -503,15 +534,7 @@ __global__ __launch_bounds__(256) void mf_shade_bwd_kernel(MfArgs a, const float
             if (d_vis != nullptr) d_vis[row] = (vis >= 0.0f && vis <= 1.0f) ? dvcl : 0.0f;
         }
         float r0 = wave_sum_f(dl[0]), r1 = wave_sum_f(dl[1]), r2 = wave_sum_f(dl[2]), r3 = wave_sum_f(dI);
-        if (lane == 0) {
-            red[wave][0] = r0; red[wave][1] = r1; red[wave][2] = r2; red[wave][3] = r3;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-            d_light_partial[((int64_t)blockIdx.x * a.L + l) * 4 + threadIdx.x] = t;
-        }
-        __syncthreads();
+        if (lane == 0) *reinterpret_cast<float4*>(d_light_partial + ((int64_t)blockIdx.x * a.L + l) * 4) = make_float4(r0, r1, r2, r3);
     }
     if (ok) {
         float dn_from_nh[3];
@@ -549,7 +572,7 @@ extern "C" int psn_sg_shade_fwd(const float* light_dir, const float* view, const
     if (rc) return rc;
     PSN_CHECK_ARG(rgb && spec, "sg_shade_fwd: null output");
     if (Ns == 0) return PSN_OK;
-    hipLaunchKernelGGL(sg_shade_fwd_kernel, dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, rgb, spec);
+    hipLaunchKernelGGL(sg_shade_fwd_kernel, dim3((unsigned)((Ns + kShadeThreads - 1) / kShadeThreads)), dim3(kShadeThreads * kSgPhases), 0, (hipStream_t)stream, a, rgb, spec);
     PSN_CHECK_LAUNCH("sg_shade_fwd");
     return PSN_OK;
 }
@@ -566,11 +589,11 @@ extern "C" int psn_sg_shade_bwd(const float* light_dir, const float* view, const
     if (rc) return rc;
     PSN_CHECK_ARG(g_rgb && d_albedo && d_weights && d_normal && d_light_dir && workspace, "sg_shade_bwd: null pointer");
     if (Ns == 0) return PSN_OK;
-    const int n_blocks = (int)((Ns + 255) / 256);
-    hipLaunchKernelGGL(sg_shade_bwd_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, a, g_rgb, g_spec, d_albedo,
+    const int n_blocks = (int)((Ns + kShadeThreads - 1) / kShadeThreads);
+    hipLaunchKernelGGL(sg_shade_bwd_kernel, dim3(n_blocks), dim3(kShadeThreads * kSgPhases), 0, (hipStream_t)stream, a, g_rgb, g_spec, d_albedo,
                        d_weights, d_normal, d_vis, workspace);
     PSN_CHECK_LAUNCH("sg_shade_bwd");
-    hipLaunchKernelGGL(sg_light_reduce_kernel, dim3((L * 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
+    hipLaunchKernelGGL(sg_light_reduce_kernel, dim3((L * 4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, workspace,
                        n_blocks, L, d_light_dir, d_light_int);
     PSN_CHECK_LAUNCH("sg_shade_bwd light reduce");
     return PSN_OK;
@@ -584,7 +607,7 @@ extern "C" int psn_mf_shade_fwd(const float* light_dir, const float* view, const
     PSN_CHECK_ARG(L >= 1 && Ns >= 0, "mf_shade_fwd: L=%d", L);
     if (Ns == 0) return PSN_OK;
     MfArgs a{light_dir, view, normal, albedo, rough, light_int, light_int_scalar, f0, vis, L, Ns};
-    hipLaunchKernelGGL(mf_shade_fwd_kernel, dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, rgb);
+    hipLaunchKernelGGL(mf_shade_fwd_kernel, dim3((unsigned)((Ns + kShadeThreads - 1) / kShadeThreads)), dim3(kShadeThreads), 0, (hipStream_t)stream, a, rgb);
     PSN_CHECK_LAUNCH("mf_shade_fwd");
     return PSN_OK;
 }
@@ -600,11 +623,11 @@ extern "C" int psn_mf_shade_bwd(const float* light_dir, const float* view, const
     PSN_CHECK_ARG(L >= 1 && Ns >= 0, "mf_shade_bwd: L=%d", L);
     if (Ns == 0) return PSN_OK;
     MfArgs a{light_dir, view, normal, albedo, rough, light_int, light_int_scalar, f0, vis, L, Ns};
-    const int n_blocks = (int)((Ns + 255) / 256);
-    hipLaunchKernelGGL(mf_shade_bwd_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, a, g_rgb, d_albedo, d_rough,
+    const int n_blocks = (int)((Ns + kShadeThreads - 1) / kShadeThreads);
+    hipLaunchKernelGGL(mf_shade_bwd_kernel, dim3(n_blocks), dim3(kShadeThreads), 0, (hipStream_t)stream, a, g_rgb, d_albedo, d_rough,
                        d_normal, d_vis, workspace);
     PSN_CHECK_LAUNCH("mf_shade_bwd");
-    hipLaunchKernelGGL(sg_light_reduce_kernel, dim3((L * 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
+    hipLaunchKernelGGL(sg_light_reduce_kernel, dim3((L * 4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, workspace,
                        n_blocks, L, d_light_dir, d_light_int);
     PSN_CHECK_LAUNCH("mf_shade_bwd light reduce");
     return PSN_OK;

@@ -791,7 +791,7 @@ def sg_shade_bwd(light_dir, view, normal, albedo, weights, lobe, light_int, ligh
     d_vis = torch.empty(L * Ns, device=dev) if want_vis else None
     d_ldir = torch.empty(L, 3, device=dev)
     d_lint = torch.empty(L, device=dev) if light_int is not None else None
-    ws = workspace(((Ns + 255) // 256) * L * 4, dev)
+    ws = workspace(((Ns + 63) // 64) * L * 4, dev)
     _check(_lib.psn_sg_shade_bwd(_ptr(light_dir, 'light_dir'), _ptr(view, 'view'), _ptr(normal, 'normal'),
                                  _ptr(albedo, 'albedo'), _ptr(weights, 'weights'), _ptr(lobe, 'lobe'),
                                  _ptr(light_int, 'light_int', True), float(light_int_scalar), _ptr(vis, 'vis', True),
@@ -822,7 +822,7 @@ def mf_shade_bwd(light_dir, view, normal, albedo, rough, light_int, light_int_sc
     d_vis = torch.empty(L * Ns, device=dev) if want_vis else None
     d_ldir = torch.empty(L, 3, device=dev)
     d_lint = torch.empty(L, device=dev) if light_int is not None else None
-    ws = workspace(((Ns + 255) // 256) * L * 4, dev)
+    ws = workspace(((Ns + 63) // 64) * L * 4, dev)
     _check(_lib.psn_mf_shade_bwd(_ptr(light_dir, 'light_dir'), _ptr(view, 'view'), _ptr(normal, 'normal'),
                                  _ptr(albedo, 'albedo'), _ptr(rough, 'rough'), _ptr(light_int, 'light_int', True),
                                  float(light_int_scalar), float(f0), _ptr(vis, 'vis', True), L, Ns, _ptr(g_rgb, 'g_rgb'),
