@@ -126,29 +126,38 @@ struct ScatterArgs {
     int64_t N, Ns;
     int n;
 };
+// One thread per (b, pixel) -- not per element: the index arithmetic (one 32-bit division) is paid once per pixel and
+// the C values of a pixel are written as one contiguous run.  (The per-element form spent its time in three 64-bit
+// integer divisions per float: 109 us for the 113 MB of a bear.conf step; this one is HBM-bound.)
 __global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterArgs a) {
     int i = 0;
     while (i + 1 < a.n && (int64_t)blockIdx.x >= a.start[i + 1]) ++i;
     const PsnScatterItem it = a.it[i];
-    const int64_t e = ((int64_t)blockIdx.x - a.start[i]) * 256 + threadIdx.x;  // element of dense [B, N, C]
-    if (e >= (int64_t)it.B * a.N * it.C) return;
-    const int c = (int)(e % it.C);
-    const int64_t bn = e / it.C;
-    const int64_t n = bn % a.N, b = bn / a.N;
+    const uint32_t bn = (uint32_t)(((int64_t)blockIdx.x - a.start[i]) * 256 + threadIdx.x);  // (b, pixel): B * N < 2^31 (host check)
+    const uint32_t N = (uint32_t)a.N;
+    if (bn >= (uint32_t)it.B * N) return;
+    const uint32_t b = bn / N, n = bn - b * N;
     const int r = a.inv[n];
-    it.dense[e] = r >= 0 ? it.rows[(b * a.Ns + r) * it.row_stride + c * it.col_stride] : it.fill;
+    float* dst = it.dense + (int64_t)bn * it.C;
+    if (r >= 0) {
+        const float* src = it.rows + ((int64_t)b * a.Ns + r) * it.row_stride;
+        for (int c = 0; c < it.C; ++c) dst[c] = src[(int64_t)c * it.col_stride];
+    } else {
+        for (int c = 0; c < it.C; ++c) dst[c] = it.fill;
+    }
 }
-// adjoint: rows_grad[(b Ns + r), c] = dense_grad[b, idx[r], c]
+// adjoint: rows_grad[(b Ns + r), c] = dense_grad[b, idx[r], c]; one thread per element (coalesced writes), 32-bit index
+// arithmetic (B * Ns * C < 2^31, host check)
 __global__ __launch_bounds__(256) void gather_rows_kernel(ScatterArgs a) {
     int i = 0;
     while (i + 1 < a.n && (int64_t)blockIdx.x >= a.start[i + 1]) ++i;
     const PsnScatterItem it = a.it[i];
-    const int64_t e = ((int64_t)blockIdx.x - a.start[i]) * 256 + threadIdx.x;  // element of rows_grad [B Ns, C]
-    if (e >= (int64_t)it.B * a.Ns * it.C) return;
-    const int c = (int)(e % it.C);
-    const int64_t br = e / it.C;
-    const int64_t r = br % a.Ns, b = br / a.Ns;
-    const_cast<float*>(it.rows)[e] = it.dense[(b * a.N + a.idx[r]) * it.C + c];
+    const uint32_t e = (uint32_t)(((int64_t)blockIdx.x - a.start[i]) * 256 + threadIdx.x);  // element of rows_grad [B Ns, C]
+    const uint32_t Ns = (uint32_t)a.Ns, C = (uint32_t)it.C;
+    if (e >= (uint32_t)it.B * Ns * C) return;
+    const uint32_t br = e / C, c = e - br * C;
+    const uint32_t b = br / Ns, r = br - b * Ns;
+    const_cast<float*>(it.rows)[e] = it.dense[((int64_t)b * a.N + a.idx[r]) * it.C + c];
 }
 
 static int launch_scatter(int n_items, const PsnScatterItem* items, const int* inv, const int64_t* idx, int64_t N, int64_t Ns,
@@ -163,8 +172,9 @@ static int launch_scatter(int n_items, const PsnScatterItem* items, const int* i
         const PsnScatterItem& it = items[i];
         PSN_CHECK_ARG(it.dense && (it.rows || Ns == 0) && it.B >= 1 && it.C >= 1, "scatter_rows: item %d: null pointer or empty shape", i);
         a.it[i] = it;
-        const int64_t elems = (int64_t)it.B * (gather ? Ns : N) * it.C;
-        a.start[i + 1] = a.start[i] + (elems + 255) / 256;
+        const int64_t threads = gather ? (int64_t)it.B * Ns * it.C : (int64_t)it.B * N;  // per element / per (b, pixel)
+        PSN_CHECK_ARG(threads < (1ll << 31), "scatter_rows: item %d: B * N (scatter) / B * Ns * C (gather) must stay below 2^31", i);
+        a.start[i + 1] = a.start[i] + (threads + 255) / 256;
     }
     if (a.start[n_items] == 0) return PSN_OK;
     PSN_CHECK_ARG(a.start[n_items] < (1ll << 31), "scatter_rows: too many elements");
