@@ -627,10 +627,13 @@ class VisibilityPair(torch.autograd.Function):
                 else:
                     dz3 = dz.view(V, Ns, dz.shape[1])
                     dz_x, dz_l = dz3.sum(0), dz3.sum(1)
-                sk_x = _split_k_for(Ns, 256, pe_x.shape[1])
-                dWx = hip.gemm(dz_x, pe_x, trans_a=True, split_k=sk_x)          # [256, 64]
                 dWl = hip.gemm(dz_l, pe_lv.contiguous(), trans_a=True)          # [256, 64]
-                xl[li] = (dWx, dWl, dz_l.sum(0) if li == 0 else None)
+                xl[li] = [dz_x, dWl, dz_l.sum(0) if li == 0 else None]
+        # d W_x of both input layers (K = Ns, 256 x 64 outputs) in ONE launch of the 256 x 64-tile kernel + one reduction
+        # (were a split-K GEMM + reduction each)
+        lis = sorted(xl)
+        for li, (C, _cs) in zip(lis, hip.gemm_tn_grouped([dict(A=xl[li][0], B=pe_x) for li in lis])):
+            xl[li][0] = C
         parts = {}
         if items:
             for (li, kind), (C, cs) in zip(where, hip.gemm_tn_grouped(items)):
