@@ -10,8 +10,9 @@ __global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict_
                                                         float scale, float* __restrict__ out, int out_stride) {
     const int64_t total = n * out_stride;
     const int width = 3 + 6 * n_freqs;
+    const bool pow64 = out_stride == 64;  // the usual table width: shift / mask instead of a 64-bit division per element
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        int64_t row = e / out_stride;
+        int64_t row = pow64 ? (e >> 6) : e / out_stride;
         int col = (int)(e - row * out_stride);
         float v = 0.0f;
         if (col < 3) {
@@ -32,8 +33,9 @@ __global__ __launch_bounds__(256) void pe_encode_jvp_kernel(const float* __restr
                                                             float* __restrict__ out, int out_stride) {
     const int64_t total = n * out_stride;
     const int width = 3 + 6 * n_freqs;
+    const bool pow64 = out_stride == 64;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        int64_t row = e / out_stride;
+        int64_t row = pow64 ? (e >> 6) : e / out_stride;
         int col = (int)(e - row * out_stride);
         float v = 0.0f;
         if (col < 3) {
