@@ -59,9 +59,10 @@ int psn_pe_encode(const float* x, int64_t n, int n_freqs, float scale, float* ou
  * psn_pe_encode_bwd; needed for the backward of the gradient sweep) */
 int psn_pe_encode_jvp(const float* x, const float* t, int64_t n, int n_freqs, float scale, float* out, int out_stride,
                       void* stream);
-/* d_out [n, out_stride] -> d_x [n,3] (chain rule through sin/cos; x is re-read) */
+/* d_out [n, out_stride] -> d_x [n,3] (chain rule through sin/cos; x is re-read).  d_out2 (or NULL): a second gradient of
+ * the encoding, row stride out2_stride, added column by column first (both may be column ranges of wider tensors). */
 int psn_pe_encode_bwd(const float* x, const float* d_out, int64_t n, int n_freqs, float scale, int out_stride,
-                      float* d_x, void* stream);
+                      const float* d_out2, int out2_stride, float* d_x, void* stream);
 
 /* ------------------------------------------------------------------------
  * fp32-MFMA GEMM with fused epilogues: the torch.nn.Linear / addmm / mm calls

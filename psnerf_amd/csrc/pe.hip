@@ -52,21 +52,28 @@ __global__ __launch_bounds__(256) void pe_encode_jvp_kernel(const float* __restr
     }
 }
 
+// d_out2 (or nullptr): a second gradient of the encoding that is ADDED column by column before the chain rule (the sweep
+// of the stage-1 geometry network delivers d logit / d pe in two pieces: the layer-0 columns of one dump and the skip
+// layer's columns of another; reading both here saves a [Q, 64] copy and a [Q, 39] add per call)
 __global__ __launch_bounds__(256) void pe_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ d_out,
                                                             int64_t n, int n_freqs, float scale, int out_stride,
+                                                            const float* __restrict__ d_out2, int out2_stride,
                                                             float* __restrict__ d_x) {
     const int64_t total = n * 3;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         int64_t row = e / 3;
         int c = (int)(e - row * 3);
         const float* g = d_out + row * out_stride;
+        const float* g2 = d_out2 != nullptr ? d_out2 + row * out2_stride : nullptr;
         float xs = x[e] * scale;
-        float acc = g[c];
+        float acc = g2 != nullptr ? g[c] + g2[c] : g[c];
         for (int f = 0; f < n_freqs; ++f) {
             float arg = ldexpf(xs, f);
             float s, co;
             sincosf(arg, &s, &co);
-            acc += ldexpf(co * g[3 + 6 * f + c] - s * g[3 + 6 * f + 3 + c], f);
+            float gs = g[3 + 6 * f + c], gc = g[3 + 6 * f + 3 + c];
+            if (g2 != nullptr) { gs += g2[3 + 6 * f + c]; gc += g2[3 + 6 * f + 3 + c]; }
+            acc += ldexpf(co * gs - s * gc, f);
         }
         d_x[e] = acc * scale;
     }
@@ -103,14 +110,16 @@ extern "C" int psn_pe_encode_jvp(const float* x, const float* t, int64_t n, int 
 }
 
 extern "C" int psn_pe_encode_bwd(const float* x, const float* d_out, int64_t n, int n_freqs, float scale, int out_stride,
-                                 float* d_x, void* stream) {
+                                 const float* d_out2, int out2_stride, float* d_x, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(x && d_out && d_x, "pe_encode_bwd: null pointer");
+    PSN_CHECK_ARG(d_out2 == nullptr || out2_stride >= 3 + 6 * n_freqs, "pe_encode_bwd: out2_stride=%d", out2_stride);
     PSN_CHECK_ARG(n_freqs >= 0 && n_freqs <= 16 && out_stride >= 3 + 6 * n_freqs, "pe_encode_bwd: n_freqs=%d out_stride=%d", n_freqs, out_stride);
     if (n <= 0) return PSN_OK;
     int64_t blocks = (n * 3 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(pe_encode_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, d_out, n, n_freqs, scale, out_stride, d_x);
+    hipLaunchKernelGGL(pe_encode_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, d_out, n, n_freqs, scale, out_stride, d_out2,
+                       out2_stride, d_x);
     PSN_CHECK_LAUNCH("pe_encode_bwd");
     return PSN_OK;
 }

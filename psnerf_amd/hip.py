@@ -83,7 +83,7 @@ SIGNATURES = {
     'psn_composite_fwd': (i32, [c_f, c_f, i64, i32, i32, c_f, c_f, c_f, c_f]),
     'psn_composite_bwd': (i32, [c_f, c_f, c_f, c_f, i64, i32, i32, c_f, c_f, c_f]),
     'psn_pe_encode': (i32, [c_f, i64, i32, f32, c_f, i32, c_f]),
-    'psn_pe_encode_bwd': (i32, [c_f, c_f, i64, i32, f32, i32, c_f, c_f]),
+    'psn_pe_encode_bwd': (i32, [c_f, c_f, i64, i32, f32, i32, c_f, i32, c_f, c_f]),
     'psn_pe_encode_jvp': (i32, [c_f, c_f, i64, i32, f32, c_f, i32, c_f]),
     'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, c_f, i64,
                        i32, c_f, c_f, c_f]),
@@ -229,10 +229,14 @@ def pe_encode_jvp(x, t, n_freqs, out_stride, scale=1.0):
     return out
 
 
-def pe_encode_bwd(x, d_out, n_freqs, scale=1.0):
+def pe_encode_bwd(x, d_out, n_freqs, scale=1.0, add=None):
+    """d_out (and ``add``, a second gradient summed in first): row-major views [n, >= 3 + 6 n_freqs] -- column ranges of
+    wider tensors are fine (row stride = stride(0))."""
     n = x.shape[0]
     d_x = torch.empty_like(x)
-    _check(_lib.psn_pe_encode_bwd(_ptr(x, 'x'), _ptr(d_out, 'd_out'), n, n_freqs, float(scale), d_out.shape[1],
+    assert d_out.shape[1] >= 3 + 6 * n_freqs and (add is None or add.shape[1] >= 3 + 6 * n_freqs)
+    _check(_lib.psn_pe_encode_bwd(_ptr(x, 'x'), _mat_ptr(d_out, 'd_out'), n, n_freqs, float(scale), _ld(d_out),
+                                  None if add is None else _mat_ptr(add, 'add'), 0 if add is None else _ld(add),
                                   _ptr(d_x, 'd_x'), _stream()), 'pe_encode_bwd')
     return d_x
 

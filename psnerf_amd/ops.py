@@ -9,6 +9,17 @@ import torch
 from . import fused, hip
 
 
+def _rowsum_small(t):
+    """Column sums [C] of a contiguous [Q, C] tensor with C <= 4 (bias gradients of 1- / 3-output heads).  torch's
+    dim-0 reduction of such a shape is pathological (250 us for [524288, 3]); viewed as [Q C / 64 C, 64 C] it is a
+    16-byte-load column sum (psn_colsum) followed by a 64 x C fold."""
+    Q, C = t.shape
+    W = 64 * C
+    if t.is_cuda and t.is_contiguous() and C <= 4 and Q >= 4096 and (Q * C) % W == 0:
+        return hip.colsum(t.view(-1, W)).view(64, C).sum(0)
+    return t.sum(0)
+
+
 def _split_k_for(rows, out_rows=256, out_cols=256):
     """Split-K factor for a weight-gradient GEMM [out_rows, rows] x [rows, out_cols]: enough K slices that
     (output tiles x slices) fills the 256 CUs a few times over, but at least 256 rows per slice."""
@@ -607,7 +618,7 @@ class VisibilityPair(torch.autograd.Function):
         # last layer (one output): dW = g^T h as a weighted column sum, db = sum g -- a 1-row GEMM item would occupy a
         # whole 128-row tile per K slice
         grads[2 * (n - 1)] = hip.colsum(H[n - 2], row_weight=g)  # [1, 256]
-        grads[2 * (n - 1) + 1] = g.sum(0)
+        grads[2 * (n - 1) + 1] = _rowsum_small(g)
         items = []
         where = []
         xl = {}  # layer -> (d W_x [256, 64], d W_l [256, 64], bias gradient or None)
@@ -695,9 +706,8 @@ class GeoFieldFused(torch.autograd.Function):
                             save2=[None] + [r_sk if n - 1 - j == sk else None for j in range(1, n - 1)] + [None],
                             save_tiles=[None] * (n - 1) + [0x000F],
                             save2_tiles=[None] + [t_sk if n - 1 - j == sk else None for j in range(1, n - 1)] + [None])
-            d_pe_t = r0[:, :64].contiguous()
-            d_pe_t[:, :d_pe] += r_sk[:, d_a:d_a + d_pe]
-            grad = hip.pe_encode_bwd(p, d_pe_t, n_octaves, scale)
+            # d logit / d pe = the layer-0 columns of r0 + the skip layer's columns of r_sk: both read in place
+            grad = hip.pe_encode_bwd(p, r0[:, :d_pe], n_octaves, scale, add=r_sk[:, d_a:d_a + d_pe])
         if any(ctx.needs_input_grad):
             ctx.meta = (n, sk, d_pe, d_a, n_octaves, scale, with_grad, chains)
             keep = [p, pe] + Ws + A + S
@@ -765,7 +775,7 @@ class GeoFieldFused(torch.autograd.Function):
         if sweep:
             row0 = row0 + hip.colsum(dR[n - 1])
         dW[n - 1] = torch.cat([row0.unsqueeze(0), res[n - 1][0]], dim=0)
-        db[n - 1] = torch.cat([d_logit.sum(0), res[n - 1][1]])
+        db[n - 1] = torch.cat([_rowsum_small(d_logit), res[n - 1][1]])
         grads = []
         for l in range(n):
             grads += [dW[l], db[l]]
@@ -817,7 +827,7 @@ class AppNetFused(torch.autograd.Function):
         for l in range(1, n - 1):
             grads += [res[l + 1][0], res[l + 1][1]]
         # output layer (3 colours): g^T h as a weighted column sum (a 3-row GEMM item occupies a whole 128-row tile)
-        grads += [hip.colsum(H[n - 2], row_weight=g), g.sum(0)]
+        grads += [hip.colsum(H[n - 2], row_weight=g), _rowsum_small(g)]
         return (None, d_normal, d_feat, None, None) + tuple(grads)
 
 

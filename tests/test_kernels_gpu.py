@@ -91,6 +91,13 @@ def test_pe(cuda, n_freqs, stride):
     (o1.positional_encoding(xg, n_freqs) * d_out[:, :ref.shape[1]].double()).sum().backward()
     dx = hip.pe_encode_bwd(x.to(cuda), d_out.to(cuda), n_freqs).cpu()
     assert_close(dx, xg.grad, 1e-5, 'pe bwd')
+    # the gradient given as two pieces that are column ranges of wider tensors (summed inside the kernel)
+    w = ref.shape[1]
+    wide1, wide2 = torch.randn(1001, 256, generator=g), torch.randn(1001, 256, generator=g)
+    xg2 = x.double().requires_grad_(True)
+    (o1.positional_encoding(xg2, n_freqs) * (wide1[:, :w] + wide2[:, 200 - w:200]).double()).sum().backward()
+    dx2 = hip.pe_encode_bwd(x.to(cuda), wide1.to(cuda)[:, :w], n_freqs, add=wide2.to(cuda)[:, 200 - w:200]).cpu()
+    assert_close(dx2, xg2.grad, 1e-5, 'pe bwd, two strided pieces')
 
 
 @pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
