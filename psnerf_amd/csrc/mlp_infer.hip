@@ -607,8 +607,25 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             // last hidden stage has just released (every wave is past the barrier above)
             if (iter + 1 < n_iter) stage_load<2 * NMT, kAsmDma>(g.w + g.d.layers[0].w_off, smem + ((gstage + 1) & 1) * kStageFloats, wave, lane);
         }
+        if (g.d.n_out <= 16) {
+            // <= 16 outputs (the visibility / occupancy logit, RGB): only output tile 0 of the 32-wide final block is needed --
+            // half the MFMAs of this layer, the same products in the same order for the outputs that exist
 #pragma unroll
-        for (int kt = 0; kt < NMT / 2; ++kt) stage_compute<2, NMT, kAsmDma>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane, [](int) {});
+            for (int kt = 0; kt < NMT / 2; ++kt) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float4 a = wl[kt * 256 + e * 128 + lane];
+                    const floatx4& bs = e ? act[2 * kt + 1] : act[2 * kt];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bs[0], acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bs[1], acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bs[2], acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bs[3], acc[0], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NMT / 2; ++kt) stage_compute<2, NMT, kAsmDma>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 256, lane, [](int) {});
+        }
         if constexpr (SRC == 1) ++gstage;
     }
     if constexpr (SRC == 1) {
