@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 N_PIXELS, N_LIGHTS, N_VIS, N_LIGHTS_TOTAL = 32768, 96, 8, 1920
 STRONG_PIXELS = 8 * N_PIXELS  # fixed global batch of the strong-scaling line (= the weak batch of 8 GPUs)
 VIS_MACS = 523520  # visibility_net MACs per row
-VIS_MACS_ISSUED = 466944  # MACs the kernel issues per row: 523,520 - 2 x 126 x 256 (init tables) + the final layer padded to 32 outputs
+VIS_MACS_ISSUED = 462848  # MACs the kernel issues per row: 523,520 - 2 x 126 x 256 (init tables) + the final layer padded to 16 outputs
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
 
