@@ -183,7 +183,8 @@ enum { PSN_OUT_NONE = 0, PSN_OUT_SIGMOID = 1, PSN_OUT_OCC = 2 /* sigmoid(-10 x),
 
 typedef struct {
     int n_kt_in;   /* 32-wide K tiles taken from the input-feature registers (0..4) */
-    int n_kt_act;  /* 32-wide K tiles taken from the previous layer's activations (0 or the hidden n_mt) */
+    int n_kt_act;  /* 32-wide K tiles taken from the previous layer's activations: 0, the hidden n_mt, or n_mt - 1 when the
+                      last 32 activation columns are padding (7 of 8 behind a 217-output layer) */
     int n_mt;      /* 32-wide output tiles: 8, 4 or 2 (hidden: 256- / 128- / 64-wide network) or 1 (final) */
     int act;       /* PSN_ACT_* applied to this layer's output */
     int64_t w_off; /* float offset of this layer's packed weights */

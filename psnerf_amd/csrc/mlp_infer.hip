@@ -307,7 +307,9 @@ __device__ __forceinline__ void wait_for_weights(int stores) {
 // one update launch per iteration, and a host synchronisation to compact the hit rays first).  A ray's iterations
 // depend on nothing but the ray, so no inter-workgroup exchange is needed; the launch is latency-bound (one
 // workgroup per 64 rays) and costs about one serial pass through the network per iteration.
-template <bool CHAIN, int NMT, int SRC = 0>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
+// TRIM: some layer reads one activation k-tile fewer than the width (a separate instantiation: the conditional last stage costs
+// the untrimmed visibility launch 0.7 %).
+template <bool CHAIN, int NMT, int SRC = 0, bool TRIM = false>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
 __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     constexpr int W = 16 * NMT;
     // LDS-DMA flavour (common.h lds_dma_16): asm pieces + explicit scheduling regions for the lean variant (exact lgkmcnt
@@ -509,9 +511,13 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         // K tiles from the previous activations first, then from the input features (matches the packer): once the
         // activation tiles are consumed their 64 registers are dead, so the (L2-resident) input features are only
         // fetched then -- the two operand sets never compete for registers with the double-buffered weight fragments.
+        // (n_kt_act may be smaller than the width: a layer whose input has 217 real columns -- the one behind the 217-output
+        //  layer of the stage-1 geometry network -- reads 7 of the 8 activation k-tiles; the eighth multiplies zeros.
+        //  Only the LAST k-tile is conditional: a branch around every stage made hipcc generate slower stage code throughout.)
         if (L.n_kt_act > 0) {
 #pragma unroll
-            for (int kt = 0; kt < NMT / 2; ++kt) PSN_STAGE(NMT, act[2 * kt], act[2 * kt + 1], kt)
+            for (int kt = 0; kt < NMT / 2 - 1; ++kt) PSN_STAGE(NMT, act[2 * kt], act[2 * kt + 1], kt)
+            if (!TRIM || L.n_kt_act == NMT / 2) PSN_STAGE(NMT, act[NMT - 2], act[NMT - 1], NMT / 2 - 1)
         }
         if (L.n_kt_in > 0) {
             floatx4 xin[8];
@@ -763,8 +769,16 @@ __global__ __launch_bounds__(256) void root_find_fp_kernel(InferArgs g) {
             if (L.n_kt_act > 0) {
 #pragma unroll
                 for (int kt = 0; kt < 8; kt += 2) {
-                    const floatx4 a0 = ld4(xr + 32 * kt), a1 = ld4(xr + 32 * kt + 16), a2 = ld4(xr + 32 * kt + 32), a3 = ld4(xr + 32 * kt + 48);
-                    FP_STAGE2(a0, a1, a2, a3, kt)
+                    if (kt + 1 < L.n_kt_act) {
+                        const floatx4 a0 = ld4(xr + 32 * kt), a1 = ld4(xr + 32 * kt + 16), a2 = ld4(xr + 32 * kt + 32), a3 = ld4(xr + 32 * kt + 48);
+                        FP_STAGE2(a0, a1, a2, a3, kt)
+                    } else if (kt < L.n_kt_act) {  // odd count (7 k-tiles behind a 217-output layer): one stage, then the sets swap back
+                        const floatx4 a0 = ld4(xr + 32 * kt), a1 = ld4(xr + 32 * kt + 16);
+                        load_frags(kt + 1 < n_st ? frag_ptr(L.w_off, kt + 1) : next_first, fb);
+                        stage_mma(fa, a0, a1);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) fa[i] = fb[i];
+                    }
                 }
             }
             if (L.n_kt_in > 0) {
@@ -943,7 +957,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         PSN_CHECK_ARG(L.n_kt_in >= 0 && L.n_kt_in <= d.in_kt_a + d.in_kt_b, "mlp_infer: layer %d n_kt_in=%d", l, L.n_kt_in);
         PSN_CHECK_ARG(!last || (L.n_kt_in == 0 && L.n_kt_act == hid), "mlp_infer: the final layer reads the hidden activations only");
         PSN_CHECK_ARG(L.b_off == (int64_t)l * width, "mlp_infer: biases must be packed back to back (one hidden width per layer)");
-        PSN_CHECK_ARG(L.n_kt_act == 0 || L.n_kt_act == hid, "mlp_infer: layer %d n_kt_act=%d", l, L.n_kt_act);
+        PSN_CHECK_ARG(L.n_kt_act == 0 || L.n_kt_act == hid || (L.n_kt_act == hid - 1 && hid > 1), "mlp_infer: layer %d n_kt_act=%d (0, n_mt - 1 or n_mt)", l, L.n_kt_act);
         PSN_CHECK_ARG(l > 0 || L.n_kt_act == 0 || act_init != nullptr, "mlp_infer: layer 0 cannot read activations without act_init");
         PSN_CHECK_ARG(L.n_kt_in + L.n_kt_act >= 1 || (l == 0 && L.init_off >= 0 && d.n_layers > 1), "mlp_infer: layer %d has no input", l);
         PSN_CHECK_ARG(L.init_off < 0 || (!last && L.init_off + width <= d.init_stride && L.init_off % 4 == 0), "mlp_infer: layer %d bad init_off", l);
@@ -993,7 +1007,13 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
     const dim3 grid((unsigned)blocks), block(kWaves * 64);
     hipStream_t st = (hipStream_t)stream;
-    if (hid == 8) {
+    bool trim = false;
+    for (int l = 0; l < d.n_layers; ++l) trim = trim || (d.layers[l].n_kt_act > 0 && d.layers[l].n_kt_act < hid);
+    PSN_CHECK_ARG(!trim || hid == 8, "mlp_infer: n_kt_act = n_mt - 1 is built for the 256-wide networks only");
+    if (trim) {
+        if (chain) hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, true>), grid, block, lds_bytes, st, a);
+        else hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 0, true>), grid, block, lds_bytes, st, a);
+    } else if (hid == 8) {
         if (chain) hipLaunchKernelGGL((mlp_infer_kernel<true, 16>), grid, block, lds_bytes, st, a);
         else hipLaunchKernelGGL((mlp_infer_kernel<false, 16>), grid, block, lds_bytes, st, a);
     } else if (hid == 4) {
@@ -1039,7 +1059,7 @@ extern "C" int psn_root_find(const PsnMlpDesc* desc, const float* packed_w, cons
     // feature-parallel form whenever the network has the shape it is written for (even stage counts per layer: the
     // 64-column encoding = 2 input k-tiles, 8 activation k-tiles); the row-parallel engine otherwise
     bool fp = d.n_layers >= 2;
-    for (int l = 0; l < d.n_layers - 1; ++l) fp = fp && (d.layers[l].n_kt_in == 0 || d.layers[l].n_kt_in == 2) && (d.layers[l].n_kt_act == 0 || d.layers[l].n_kt_act == 8);
+    for (int l = 0; l < d.n_layers - 1; ++l) fp = fp && (d.layers[l].n_kt_in == 0 || d.layers[l].n_kt_in == 2) && (d.layers[l].n_kt_act == 0 || d.layers[l].n_kt_act >= 7) && d.layers[l].n_kt_act <= 8;
     fp = fp && d.layers[d.n_layers - 1].n_kt_act == 8 && d.layers[d.n_layers - 1].n_kt_in == 0;
     if (const char* ev = getenv("PSN_ROOT_FIND_ROW_PARALLEL")) fp = fp && ev[0] != '1';  // test hook: both forms must agree bit for bit
     if (fp) {
@@ -1047,7 +1067,7 @@ extern "C" int psn_root_find(const PsnMlpDesc* desc, const float* packed_w, cons
         PSN_CHECK_ARG(blocks16 < (1ll << 31), "root_find: too many rays");
         hipLaunchKernelGGL(root_find_fp_kernel, dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, a);
     } else {
-        hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 1>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 1, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
     }
     PSN_CHECK_LAUNCH("root_find");
     return PSN_OK;

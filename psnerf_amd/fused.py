@@ -81,6 +81,7 @@ def _zeros(shape, device):
     return z
 
 
+TRIM_ACT_KTILES = True  # drop the last activation k-tile of a layer whose input has <= 32 * (n_mt - 1) columns (A/B switch)
 DIRECT_INIT = 'direct'  # layer spec init_a=DIRECT_INIT: the init table is supplied by the caller at call time (no weights)
 
 
@@ -141,9 +142,11 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
         tile = n_mt * 1024  # floats per 32-feature k-tile of this layer
         lay.w_off, lay.b_off = off, b_off
         if L.get('w_act') is not None:  # K order of the packed layer: activation tiles first, input-feature tiles last
-            plan.append((L['w_act'], n_mt, hid, off))
-            n_kt_act = hid
-            off += hid * tile
+            # only the k-tiles that hold real columns (7 of 8 behind the 217-output layer of the stage-1 geometry network);
+            # the final layer always takes the full width (its stage layout is fixed)
+            n_kt_act = hid - 1 if (TRIM_ACT_KTILES and not last and hid > 1 and _src(L['w_act'])[3] <= (hid - 1) * 32) else hid
+            plan.append((L['w_act'], n_mt, n_kt_act, off))
+            off += n_kt_act * tile
         if L.get('w_in') is not None:
             plan.append((L['w_in'], n_mt, kin, off))
             n_kt_in = kin

@@ -63,7 +63,8 @@ best = {}
 REPS = int(os.environ.get('AB_REPS', '3'))
 for rep in range(REPS):  # libraries interleaved, minimum over the rounds: clocks drift by several % within a process
   for path in sys.argv[1:]:
-    use(path)
+    fused.TRIM_ACT_KTILES = not path.endswith('+full')  # 'lib.so+full': every layer reads all activation k-tiles
+    use(path.replace('+full', ''))
     tag = os.path.basename(path)
     res = {}
     T = best.setdefault(tag, {})
