@@ -158,7 +158,7 @@ def stage1_measure(device, steps=6, warmup=2, rays=4096):
     le = [(u, ms, f) for u, ms, f in agg('mlp_infer') if f]
     if le:
         fl, ms = sum(f for _, _, f in le), sum(m for _, m, _ in le)
-        out['occupancy_engine'] = {'bound': 'mfma', 'kernel': 'mlp_infer_kernel<false,16> (march / secant / root finder)',
+        out['occupancy_engine'] = {'bound': 'mfma', 'kernel': 'mlp_infer_kernel<false,16,2> (march sweep, encoding in the prologue)',
                                    'achieved': round(fl / ms * 1e-9, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                    'frac': round(fl / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS, 4), 'ms_per_step': round(ms / steps, 3),
                                    'launches_per_step': round(len(le) / steps, 1)}

@@ -291,6 +291,15 @@ int psn_shadow_points(const float* surf, const float* ldir, int64_t n_surf, int 
                       const float* u, const float* omu, float box, float* pts, int64_t* rows, unsigned long long* counter,
                       void* stream);
 
+/* Positional encoding + network in one launch (stage1/model/network.py:141-150 feeding :85-101; the occupancy queries of
+ * the march sweep, rendering.py:410-470, and of the shadow rays, :378-408): points [n_rows, 3]; the encoding
+ * gamma(pe_scale * p) with pe_octaves bands is formed in the kernel prologue, in registers, with the expressions of
+ * psn_pe_encode -- out equals psn_pe_encode (stride 64) followed by psn_mlp_infer bit for bit, and the [n_rows, 64] table
+ * never exists.  desc / packed_w / packed_b as for psn_mlp_infer, restricted to: 256-wide hidden layers without init tables,
+ * in_kt_a = 2 (one 64-column block), biases packed back to back, n_out <= 32.  out [n_rows, n_out]. */
+int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* points, int64_t n_rows,
+                     int pe_octaves, float pe_scale, float* out, void* stream);
+
 /* Fused secant refinement, stage1/model/rendering.py:525-555: n_iter regula-falsi iterations for every ray inside ONE
  * launch -- query point origin + d_pred * dir, its positional encoding (pe_octaves bands, input scaled by pe_scale), the
  * occupancy network (desc / packed_w / packed_b as for psn_mlp_infer: 256-wide, one output, PSN_OUT_OCC, input block =

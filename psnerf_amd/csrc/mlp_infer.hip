@@ -300,6 +300,8 @@ __device__ __forceinline__ void wait_for_weights(int stores) {
 
 // CHAIN = false: lean inference / forward-with-dump path (NONE / RELU / SOFTPLUS100 activations, one dump per layer).
 // CHAIN = true : general per-layer activation programs with row-major operands and two dumps (training chains).
+// SRC = 2: the rows are points [Q, 3] and the positional encoding is computed in the kernel (psn_mlp_infer_pe: the stage-1
+// occupancy queries of the march sweep and the shadow rays).
 // SRC = 0: input features from tables (everything above).  SRC = 1: the fused secant root finder of the stage-1 ray march
 // (stage1/model/rendering.py:525-555): every row is a ray with a bracket [d_low, d_high] around the first free -> occupied
 // crossing; the kernel iterates  p = o + d_pred dir -> positional encoding -> occupancy network -> regula-falsi update
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     // LDS-DMA flavour (common.h lds_dma_16): asm pieces + explicit scheduling regions for the lean variant (exact lgkmcnt
     // waits: visibility launch +1.9 %, march sweep +4 %), the builtin + scheduling groups for the chain variant (its
     // F2 / B1 / B2 chains measured 1-2 % SLOWER with the regions, with either piece flavour)
-    constexpr bool kAsmDma = !CHAIN && SRC == 0;  // (the root finder is latency-bound and at the register limit: builtin)
+    constexpr bool kAsmDma = !CHAIN && SRC != 1;  // (the root finder is latency-bound and at the register limit: builtin)
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages + all biases
     float* bias_lds = smem + 2 * kStageFloats;
     const int tid = threadIdx.x;
@@ -359,28 +361,31 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     // SRC == 1: the positional encoding of the current query point, straight into the B-operand registers; the same
     // expressions as pe_encode_kernel (csrc/pe.hip), so the values are bit-identical to the table path
     float qx = 0.f, qy = 0.f, qz = 0.f;  // current query point of this lane's ray
-    auto compute_xin = [&](floatx4 (&xin)[8]) {
+    // (one 16-column tile t at a time, right before the stage that consumes it: the whole 64-column block held at once
+    //  costs 32 registers next to the 64 accumulators and the weight fragments, and spilled)
+    auto compute_xin_tile = [&](int t) {
         const int width = 3 + 6 * g.pe_octaves;
+        floatx4 x;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = 0.0f;
-                if (t < 4) {
-                    const int col = 16 * t + 4 * lg + r;
-                    if (col < 3) {
-                        v = (col == 0 ? qx : (col == 1 ? qy : qz)) * g.pe_scale;
-                    } else if (col < width) {
-                        const int q = col - 3;
-                        const int f = q / 6, w = q - 6 * f;
-                        const int c = w % 3;
-                        const float arg = ldexpf((c == 0 ? qx : (c == 1 ? qy : qz)) * g.pe_scale, f);
-                        v = (w >= 3) ? cosf(arg) : sinf(arg);
-                    }
-                }
-                xin[t][r] = v;
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.0f;
+            const int col = 16 * t + 4 * lg + r;
+            if (col < 3) {
+                v = (col == 0 ? qx : (col == 1 ? qy : qz)) * g.pe_scale;
+            } else if (col < width) {
+                const int q = col - 3;
+                const int f = q / 6, w = q - 6 * f;
+                const int c = w % 3;
+                const float arg = ldexpf((c == 0 ? qx : (c == 1 ? qy : qz)) * g.pe_scale, f);
+                // one range reduction for both (the lanes of a wave want different ones, so `w >= 3 ? cosf : sinf` evaluates
+                // both in full); sincosf returns the bits of sinf and cosf (tests: equality with the pe_encode table path)
+                float sn, cs;
+                sincosf(arg, &sn, &cs);
+                v = (w >= 3) ? cs : sn;
             }
+            x[r] = v;
         }
+        return x;
     };
 
     for (int i = tid; i < g.n_bias; i += kWaves * 64) bias_lds[i] = g.b[i];  // visible after the first stage barrier
@@ -445,6 +450,17 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         vx = g.ray_d[rowc * 3 + 0]; vy = g.ray_d[rowc * 3 + 1]; vz = g.ray_d[rowc * 3 + 2];
         dl = g.bracket[rowc]; dh = g.bracket[g.n_rows + rowc]; fl = g.bracket[2 * g.n_rows + rowc]; fh = g.bracket[3 * g.n_rows + rowc];
         dp = (-fl) * (dh - dl) / (fh - fl) + dl;  // rendering.py:526 (same expression as secant_step_kernel)
+    }
+    // SRC == 2 (psn_mlp_infer_pe): the rows are query points, encoded ONCE here -- before accumulators or weight fragments are
+    // live, so the branchy sinf / cosf code has the whole register file -- and the 64 columns stay in 16 registers for the
+    // layers that consume them (layer 0 and the skip layer), which the 232-register lean loop has room for.
+    floatx4 xq[4];
+    if constexpr (SRC == 2) {
+        qx = g.ray_o[rowc * 3 + 0]; qy = g.ray_o[rowc * 3 + 1]; qz = g.ray_o[rowc * 3 + 2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xq[t] = compute_xin_tile(t);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(xq[t]));  // (and the loads behind them) done before the first LDS-DMA pieces
     }
     const int n_iter = SRC == 1 ? g.n_iter : 1;
     for (int iter = 0; iter < n_iter; ++iter) {
@@ -519,10 +535,22 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             for (int kt = 0; kt < NMT / 2 - 1; ++kt) PSN_STAGE(NMT, act[2 * kt], act[2 * kt + 1], kt)
             if (!TRIM || L.n_kt_act == NMT / 2) PSN_STAGE(NMT, act[NMT - 2], act[NMT - 1], NMT / 2 - 1)
         }
-        if (L.n_kt_in > 0) {
+        if constexpr (SRC != 0) {
+            if (L.n_kt_in > 0) {  // == 2 (host check): the 64-column encoding
+                if constexpr (SRC == 2) {
+                    PSN_STAGE(NMT, xq[0], xq[1], L.n_kt_act)
+                    PSN_STAGE(NMT, xq[2], xq[3], L.n_kt_act + 1)
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        const floatx4 x0 = compute_xin_tile(2 * kt), x1 = compute_xin_tile(2 * kt + 1);
+                        PSN_STAGE(NMT, x0, x1, L.n_kt_act + kt)
+                    }
+                }
+            }
+        } else if (L.n_kt_in > 0) {
             floatx4 xin[8];
-            if constexpr (SRC == 1) compute_xin(xin);
-            else {
+            {
                 load_xin(xin);
                 // the features must have arrived BEFORE the stage issues its LDS-DMA pieces: those are asm statements the
                 // compiler's vmcnt bookkeeping does not see, so a wait placed behind them would be a full vmcnt(0)
@@ -1024,6 +1052,44 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         else hipLaunchKernelGGL((mlp_infer_kernel<false, 4>), grid, block, lds_bytes, st, a);
     }
     PSN_CHECK_LAUNCH("mlp_infer");
+    return PSN_OK;
+}
+
+// Lean evaluation of a 256-wide network whose input block is the positional encoding of a 3-vector (the stage-1 occupancy
+// queries, stage1/model/network.py:141-150 + 85-101): `points` [n_rows, 3] in, the encoding gamma(scale * p) is formed
+// in the kernel prologue in the B-operand registers -- the same expressions as pe_encode_kernel, so the result equals
+// psn_pe_encode + psn_mlp_infer bit for bit without the [n_rows, 64] table ever existing in HBM.
+extern "C" int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* points,
+                                int64_t n_rows, int pe_octaves, float pe_scale, float* out, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(desc && packed_w && packed_b && points && out, "mlp_infer_pe: null pointer");
+    const PsnMlpDesc& d = *desc;
+    PSN_CHECK_ARG(d.n_layers >= 2 && d.n_layers <= PSN_MLP_MAX_LAYERS && d.n_out >= 1 && d.n_out <= 32, "mlp_infer_pe: n_layers=%d n_out=%d", d.n_layers, d.n_out);
+    PSN_CHECK_ARG(d.out_act >= PSN_OUT_NONE && d.out_act <= PSN_OUT_OCC, "mlp_infer_pe: out_act=%d", d.out_act);
+    PSN_CHECK_ARG(d.in_kt_a == 2 && d.in_kt_b == 0 && 3 + 6 * pe_octaves <= 64 && pe_octaves >= 0,
+                  "mlp_infer_pe: the input block is one 64-column positional encoding (in_kt_a = 2), got in_kt_a=%d octaves=%d", d.in_kt_a, pe_octaves);
+    PSN_CHECK_ARG(d.layers[0].n_kt_in == 2 && d.layers[0].n_kt_act == 0, "mlp_infer_pe: layer 0 reads the encoding as k-tiles");
+    for (int l = 0; l < d.n_layers; ++l) {
+        const PsnMlpLayer& L = d.layers[l];
+        const bool last = l == d.n_layers - 1;
+        PSN_CHECK_ARG(L.n_mt == (last ? 1 : 8) && L.init_off < 0, "mlp_infer_pe: layer %d: 256-wide hidden layers without init tables only", l);
+        PSN_CHECK_ARG(L.act == PSN_ACT_SOFTPLUS100 || L.act == PSN_ACT_RELU || L.act == PSN_ACT_NONE, "mlp_infer_pe: layer %d activation", l);
+        PSN_CHECK_ARG(L.b_off == (int64_t)l * 256, "mlp_infer_pe: biases must be packed back to back");
+        PSN_CHECK_ARG(L.n_kt_in == 0 || L.n_kt_in == 2, "mlp_infer_pe: layer %d n_kt_in=%d", l, L.n_kt_in);
+        PSN_CHECK_ARG(last ? (L.n_kt_act == 8 && L.n_kt_in == 0) : (L.n_kt_act == 0 || L.n_kt_act == 7 || L.n_kt_act == 8), "mlp_infer_pe: layer %d n_kt_act=%d", l, L.n_kt_act);
+        PSN_CHECK_ARG(L.n_kt_in + L.n_kt_act >= 1, "mlp_infer_pe: layer %d has no input", l);
+    }
+    if (n_rows <= 0) return PSN_OK;
+    InferArgs a = {};
+    a.d = d; a.w = packed_w; a.b = packed_b; a.a_div = 1; a.a_mod = 1; a.b_div = 1; a.b_mod = 1; a.n_rows = n_rows; a.out = out;
+    a.n_bias = (d.n_layers - 1) * 256 + 32;
+    a.ray_o = points; a.pe_scale = pe_scale; a.pe_octaves = pe_octaves;
+    for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) { a.save_tiles[l] = 0xFFFFFFFFu; a.save2_tiles[l] = 0xFFFFFFFFu; }
+    const int64_t blocks = (n_rows + kWaves * 16 - 1) / (kWaves * 16);
+    PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer_pe: too many rows");
+    const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
+    hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 2, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("mlp_infer_pe");
     return PSN_OK;
 }
 

@@ -114,6 +114,7 @@ SIGNATURES = {
     'psn_pair_sums': (i32, [c_f, i32, i64, i32, c_f, c_f, ctypes.POINTER(ctypes.c_int), c_f]),
     'psn_row_adam': (i32, [i32, ctypes.c_void_p, c_f, i32, c_f]),
     'psn_shadow_points': (i32, [c_f, c_f, i64, i32, i32, f32, f32, c_f, c_f, f32, c_f, c_f, c_f, c_f]),
+    'psn_mlp_infer_pe': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i32, f32, c_f, c_f]),
     'psn_root_find': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, i64, f32, i32, i32, f32, c_f, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
@@ -417,6 +418,19 @@ def shadow_points(surf, ldir, n_steps, lnear, lfar, u, omu, box):
                                   _ptr(u, 'u'), _ptr(omu, 'omu'), float(box), pts.data_ptr(), rows.data_ptr(), counter.data_ptr(),
                                   _stream()), 'shadow_points')
     return pts, rows, counter
+
+
+def mlp_infer_pe(desc, packed_w, packed_b, points, pe_octaves, pe_scale, out=None, macs_per_row=None):
+    """Network on gamma(pe_scale * points) with the encoding formed inside the kernel (psn_mlp_infer_pe) -> [Q, n_out]."""
+    Q = points.shape[0]
+    assert points.shape == (Q, 3) and points.is_contiguous()
+    if out is None:
+        out = torch.empty(Q, desc.n_out, device=points.device, dtype=torch.float32)
+    assert out.is_contiguous() and out.numel() == Q * desc.n_out
+    with _Prof('mlp_infer', Q, None if macs_per_row is None else 2.0 * macs_per_row * Q):
+        _check(_lib.psn_mlp_infer_pe(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'), _ptr(points, 'points'),
+                                     Q, int(pe_octaves), float(pe_scale), out.data_ptr(), _stream()), 'mlp_infer_pe')
+    return out
 
 
 def root_find(desc, packed_w, packed_b, origin, direction, bracket, tau, n_iter, pe_octaves, pe_scale):

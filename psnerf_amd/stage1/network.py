@@ -251,10 +251,10 @@ class NeuralNetwork(nn.Module):
         return (torch.tanh(y) * 0.5 + 0.5).reshape(*x.shape[:-1], 3)
 
     def occupancy(self, p_flat):
-        """sigmoid(-10 * logit) for [Q,3] points without a graph: fused register-resident kernel."""
+        """sigmoid(-10 * logit) for [Q,3] points without a graph: fused register-resident kernel, positional encoding in
+        its prologue (network.py:141-150 + 85-101 in one launch; no [Q,64] table in HBM)."""
         packed = self._occupancy_packed()
-        tab = hip.pe_encode(p_flat.contiguous(), self.octaves_pe, 64, 1.0 / self.rescale)
-        return packed(tab, p_flat.shape[0])
+        return packed.on_points(p_flat.contiguous(), self.octaves_pe, 1.0 / self.rescale)
 
     def forward(self, p, ray_d=None, only_occupancy=False, return_logits=False, return_addocc=False, noise=False,
                 **kwargs):

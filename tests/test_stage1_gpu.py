@@ -319,3 +319,24 @@ def test_shadow_ray_compaction_is_bit_identical(cuda):
         alpha = torch.where(inside, alpha, torch.zeros_like(alpha)).contiguous()
         ref = 1 - hip.composite_fwd(alpha, None, False, need_weights=False)[2]
     assert torch.equal(v, ref)
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 5000, 70001])
+def test_occupancy_with_in_kernel_encoding_is_bit_identical(cuda, n):
+    """psn_mlp_infer_pe (positional encoding formed in the kernel prologue, network.py:141-150 + 85-101 in one launch) ==
+    psn_pe_encode + psn_mlp_infer on the [Q,64] table, bit for bit, incl. ragged row counts and far-away points."""
+    from psnerf_amd import hip
+    cfg, net, ren = _renderer(cuda)
+    g = torch.Generator().manual_seed(n)
+    p = ((torch.rand(n, 3, generator=g) - 0.5) * 6.0).to(cuda)
+    if n > 2:
+        p[0] = 0.0
+        p[1] = torch.tensor([250.0, -1e-3, 3.1415927], device=cuda)  # large sin / cos arguments (2^5 * 250 / rescale)
+    net = net.to(cuda)
+    with torch.no_grad():
+        packed = net._occupancy_packed()
+        tab = hip.pe_encode(p, net.octaves_pe, 64, 1.0 / net.rescale)
+        ref = packed(tab, n)
+        got = net.occupancy(p)
+    assert got.shape == ref.shape == (n, 1)
+    assert torch.equal(got, ref)
