@@ -195,7 +195,7 @@ typedef struct {
 
 typedef struct {
     int n_layers;
-    int n_out;    /* real outputs of the final layer (<= 32) */
+    int n_out;    /* real outputs of the final layer (<= 32; <= 64 in a 256-wide chain launch: final n_mt = 2, two weight stages) */
     int out_act;  /* PSN_OUT_* */
     int in_kt_a;  /* K tiles (of 32 floats) per row of feature table A (1..4) */
     int in_kt_b;  /* K tiles per row of table B (0 = unused); in_kt_a + in_kt_b <= 4 */

@@ -622,7 +622,32 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             pending_stages = pending_dump > 0 ? 1 : 0;
         }
     }
-    if (g.d.n_out > 0) {  // final layer: 32 (padded) outputs = two 16-wide tiles; all 8 k-tiles arrive as ONE 32 KB stage
+    bool wide_final = false;
+    if constexpr (CHAIN && NMT == 16) wide_final = g.d.n_out > 32;
+    if (wide_final) {
+        // final layer with 33..64 outputs (the last layer of the stage-1 gradient sweep, W_0^T: 256 -> 39 encoding columns,
+        // which as a hidden-type layer multiplied 16 output tiles to keep 3): four 16-wide output tiles, the 64 KB of weights
+        // as two 32 KB stages of 4 k-tiles each
+        const PsnMlpLayer L = g.d.layers[li];
+        const float* bp = bias_lds + L.b_off;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            float4 bv = *reinterpret_cast<const float4*>(bp + mt * 16 + 4 * lg);
+            acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
+        }
+        wait_for_weights<NMT>(pending_stages > 0 ? pending_dump : 0);
+        asm volatile("s_barrier" ::: "memory");
+        const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
+        stage_load<2 * NMT, kAsmDma>(g.w + L.w_off + kStageFloats, smem + ((gstage + 1) & 1) * kStageFloats, wave, lane);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) stage_compute<4, NMT, kAsmDma>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 512, lane, [](int) {});
+        ++gstage;
+        wait_for_weights<NMT>(0);
+        asm volatile("s_barrier" ::: "memory");
+        wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) stage_compute<4, NMT, kAsmDma>(acc, act[8 + 2 * kt], act[8 + 2 * kt + 1], wl + kt * 512, lane, [](int) {});
+    } else if (g.d.n_out > 0) {  // final layer: 32 (padded) outputs = two 16-wide tiles; all 8 k-tiles arrive as ONE 32 KB stage
         const PsnMlpLayer L = g.d.layers[li];
         const float* bp = bias_lds + L.b_off;
 #pragma unroll
@@ -680,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     if (row < g.n_rows && g.d.n_out > 0) {
         const int n_out = g.d.n_out;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < ((CHAIN && NMT == 16) ? 4 : 2); ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = 16 * mt + 4 * lg + r;
@@ -970,7 +995,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     PSN_CHECK_ARG(!uses_init || ((init_a || rk_coef) && d.init_stride >= 64 && d.init_stride % 4 == 0), "mlp_infer: init table missing");
     PSN_CHECK_ARG((((uintptr_t)rk_basis) & 15) == 0, "mlp_infer: rk_basis must be 16-byte aligned");
     PSN_CHECK_ARG((((uintptr_t)init_a | (uintptr_t)init_b) & 15) == 0, "mlp_infer: init tables must be 16-byte aligned");
-    PSN_CHECK_ARG(d.n_out >= 0 && d.n_out <= 32, "mlp_infer: n_out=%d", d.n_out);
+    PSN_CHECK_ARG(d.n_out >= 0 && d.n_out <= 64, "mlp_infer: n_out=%d", d.n_out);
     PSN_CHECK_ARG(a_div >= 1 && a_mod >= 1 && (d.in_kt_b == 0 || (b_div >= 1 && b_mod >= 1)), "mlp_infer: bad index map");
     PSN_CHECK_ARG((((uintptr_t)tab_a | (uintptr_t)tab_b | (uintptr_t)packed_w | (uintptr_t)packed_b) & 15) == 0,
                   "mlp_infer: buffers must be 16-byte aligned");
@@ -981,7 +1006,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     for (int l = 0; l < d.n_layers; ++l) {
         const PsnMlpLayer& L = d.layers[l];
         const bool last = d.n_out > 0 && l == d.n_layers - 1;
-        PSN_CHECK_ARG(L.n_mt == (last ? 1 : hid), "mlp_infer: layer %d n_mt=%d (hidden layers share one width, final <= 32)", l, L.n_mt);
+        PSN_CHECK_ARG(L.n_mt == (last ? (d.n_out > 32 ? 2 : 1) : hid), "mlp_infer: layer %d n_mt=%d (hidden layers share one width; final: 1, or 2 for 33..64 outputs)", l, L.n_mt);
         PSN_CHECK_ARG(L.n_kt_in >= 0 && L.n_kt_in <= d.in_kt_a + d.in_kt_b, "mlp_infer: layer %d n_kt_in=%d", l, L.n_kt_in);
         PSN_CHECK_ARG(!last || (L.n_kt_in == 0 && L.n_kt_act == hid), "mlp_infer: the final layer reads the hidden activations only");
         PSN_CHECK_ARG(L.b_off == (int64_t)l * width, "mlp_infer: biases must be packed back to back (one hidden width per layer)");
@@ -996,7 +1021,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     a.d = d; a.w = packed_w; a.b = packed_b; a.ta = tab_a; a.a_div = a_div; a.a_mod = a_mod;
     a.tb = tab_b; a.b_div = b_div > 0 ? b_div : 1; a.b_mod = b_mod > 0 ? b_mod : 1; a.n_rows = n_rows; a.out = out;
     a.init_a = init_a; a.init_b = init_b;
-    a.n_bias = d.n_out > 0 ? (d.n_layers - 1) * width + 32 : d.n_layers * width;
+    a.n_bias = d.n_out > 0 ? (d.n_layers - 1) * width + (d.n_out > 32 ? 64 : 32) : d.n_layers * width;
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) a.save[l] = (save_ptrs != nullptr && l < (d.n_out > 0 ? d.n_layers - 1 : d.n_layers)) ? save_ptrs[l] : nullptr;
     a.save_row0 = save_row0;
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) {
@@ -1032,6 +1057,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     bool chain = act_init != nullptr || rk_coef != nullptr || dump_tiles != nullptr;
     for (int l = 0; l < d.n_layers; ++l)
         chain = chain || d.layers[l].act > PSN_ACT_SOFTPLUS100 || a.save2[l] != nullptr || a.mask[l] != nullptr || a.aux2[l] != nullptr;
+    PSN_CHECK_ARG(d.n_out <= 32 || (chain && hid == 8), "mlp_infer: 33..64 outputs are built for the 256-wide chain engine only (n_out=%d)", d.n_out);
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
     const dim3 grid((unsigned)blocks), block(kWaves * 64);
     hipStream_t st = (hipStream_t)stream;

@@ -110,7 +110,7 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     """layers: list of dicts {w_in | init_a/init_b, w_act, bias, act}.
     w_in: [o, <=in_kt*32] consumed as MFMA k-tiles; init_a [o, in_kt_a*32] / init_b [o, in_kt_b*32]: the same
     block evaluated through precomputed tables instead.  Hidden layers have o <= width (zero padded; width = 256 or
-    128, one value per network), the final layer o = n_out <= 32.  w_act / w_in may be any row-major view with unit
+    128, one value per network), the final layer o = n_out <= 32 (<= 64 in a 256-wide chain).  w_act / w_in may be any row-major view with unit
     column stride (column slices of a parameter) or Transposed(w): the pack kernel reads them in place and zero-fills
     the padding, so no padded / concatenated / transposed copies are made on the way."""
     assert width in (64, 128, 256)
@@ -126,7 +126,7 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     off = b_off = 0
     for li, L in enumerate(layers):
         last = has_final and li == len(layers) - 1
-        n_mt = 1 if last else hid
+        n_mt = (2 if n_out > 32 else 1) if last else hid  # final layer: 32 outputs, or 64 (256-wide chain engine only)
         rows = n_mt * 32
         lay = desc.layers[li]
         lay.init_off = -1
@@ -431,8 +431,11 @@ def pack_geo_chains(weights, biases, skips, d_pe):
     layers = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=hip.ACT_MUL_AUX)]
     for l in range(n - 2, 0, -1):
         layers.append(dict(w_act=_t(W[l]), bias=zeros, act=hip.ACT_MUL_AUX))
-    layers.append(dict(w_act=_t(W[0]), bias=zeros, act=hip.ACT_HEAD))
-    sweep = pack_layers(layers, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
+    # ... and ends with r_0 = u_0 W_0 (256 -> d_pe encoding columns) as a 64-output FINAL layer: 4 output tiles instead of the 16
+    # of a hidden-type layer, the [Q, d_pe] result written densely
+    layers.append(dict(w_act=_t(W[0]), bias=_zeros(64, dev), act=hip.ACT_NONE))
+    assert 32 < d_pe <= 64
+    sweep = pack_layers(layers, ka, 0, d_pe, hip.OUT_NONE, dev)
 
     # B1: adjoint of the sweep: du_l = dR_l W_l^T ; dR_{l+1} = du_l * s_l ; dS_l = du_l * R_{l+1}
     layers = [dict(bias=zeros, act=hip.ACT_MUL2, **fwd_in(l)) for l in range(n - 1)]

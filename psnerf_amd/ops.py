@@ -695,19 +695,17 @@ class GeoFieldFused(torch.autograd.Function):
             # Raw sweep values R[l] are NOT dumped (the adjoint chain works from U, see backward) -- except at the skip
             # layer, whose last d_pe columns are the sweep's contribution to d logit / d pe through the skip input.
             r_sk = torch.empty(Q, 256, device=dev)
-            r0 = torch.empty(Q, 256, device=dev)
             w_row = Ws[n - 1][0:1, :].contiguous()
-            # of r0 only the 64 encoding columns are read, of r_sk the d_pe columns behind the skip layer's activations:
-            # the chain writes those 16-column tiles only (1 GB less per 524k points)
+            # of r_sk only the d_pe columns behind the skip layer's activations are read: the chain writes those 16-column
+            # tiles only; r0 = u_0 W_0 [Q, d_pe] is the chain's final layer (64 outputs wide, 4 output tiles)
             t_sk = sum(1 << t for t in range(d_a // 16, (d_a + d_pe - 1) // 16 + 1))
-            chains['sweep'](None, Q, a_div=1, a_mod=1, init_a_direct=w_row,
-                            mask=[S[n - 2 - j] for j in range(n - 1)] + [None],
-                            save=[U[n - 2 - j] for j in range(n - 1)] + [r0],
-                            save2=[None] + [r_sk if n - 1 - j == sk else None for j in range(1, n - 1)] + [None],
-                            save_tiles=[None] * (n - 1) + [0x000F],
-                            save2_tiles=[None] + [t_sk if n - 1 - j == sk else None for j in range(1, n - 1)] + [None])
-            # d logit / d pe = the layer-0 columns of r0 + the skip layer's columns of r_sk: both read in place
-            grad = hip.pe_encode_bwd(p, r0[:, :d_pe], n_octaves, scale, add=r_sk[:, d_a:d_a + d_pe])
+            r0 = chains['sweep'](None, Q, a_div=1, a_mod=1, init_a_direct=w_row,
+                                 mask=[S[n - 2 - j] for j in range(n - 1)] + [None],
+                                 save=[U[n - 2 - j] for j in range(n - 1)],
+                                 save2=[None] + [r_sk if n - 1 - j == sk else None for j in range(1, n - 1)] + [None],
+                                 save2_tiles=[None] + [t_sk if n - 1 - j == sk else None for j in range(1, n - 1)] + [None])
+            # d logit / d pe = r0 + the skip layer's columns of r_sk: both read in place
+            grad = hip.pe_encode_bwd(p, r0, n_octaves, scale, add=r_sk[:, d_a:d_a + d_pe])
         if any(ctx.needs_input_grad):
             ctx.meta = (n, sk, d_pe, d_a, n_octaves, scale, with_grad, chains)
             keep = [p, pe] + Ws + A + S
