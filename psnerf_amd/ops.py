@@ -221,6 +221,25 @@ class FusedPairMLP(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- dense per-pixel outputs
+class SplitRows(torch.autograd.Function):
+    """(t[:k], t[k:]) whose backward is ONE concatenation.  Two plain slices cost two zero fills, two copies and an add in
+    backward (five launch-bound kernels, on the stage-2 side stream each waits for a free CU beside the visibility chain)."""
+
+    @staticmethod
+    def forward(ctx, t, k):
+        ctx.k, ctx.shape = k, t.shape
+        return t[:k], t[k:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        k, shape = ctx.k, ctx.shape
+        if ga is None:
+            ga = gb.new_zeros((k,) + tuple(shape[1:]))
+        if gb is None:
+            gb = ga.new_zeros((shape[0] - k,) + tuple(shape[1:]))
+        return torch.cat([ga, gb], dim=0), None
+
+
 class ScatterRows(torch.autograd.Function):
     """All dense outputs of PSNetwork.forward in one launch: dense_k [B_k, N, C_k] = fill_k everywhere except the surface
     pixels idx, which carry rows_k [B_k*Ns, C_k] (light-major; stage2/model/renderer.py:145-152, 204-264).

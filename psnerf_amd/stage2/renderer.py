@@ -372,7 +372,7 @@ class PSNetwork(nn.Module):
                     # encodings, the optimiser step of the previous iteration), not for the visibility kernel
                     side = self._side.get(device)
                     if side is None:
-                        side = self._side[device] = torch.cuda.Stream(device=device)
+                        side = self._side[device] = torch.cuda.Stream(device=device)  # (a high-priority stream measured the same: +-0.05 ms/step)
                     side.wait_stream(torch.cuda.current_stream(device))
                 if self.train_vis_bf16:
                     # opt-in (train.vis_bf16): the L shading rows enter the loss detached (renderer.py:197), so they can
@@ -428,8 +428,8 @@ class PSNetwork(nn.Module):
                     pe_both = torch.cat([pe_x, self._pe(surf + nz, self.n_freqs)], dim=0)
                     return self.albedo_net(pe_both, cols), self.rough_net(pe_both, cols)
                 albedo_both, rough_both = self._memo('brdf_both', input, brdf_both)
-                albedo, albedo_j = albedo_both[:ns], albedo_both[ns:]
-                rough, rough_j = rough_both[:ns], rough_both[ns:]
+                albedo, albedo_j = ops.SplitRows.apply(albedo_both, ns)
+                rough, rough_j = ops.SplitRows.apply(rough_both, ns)
               else:
                 albedo, rough = self._memo('brdf', input, lambda: (self.albedo_net(pe_x, cols), self.rough_net(pe_x, cols)))
               if albedo_new is not None:

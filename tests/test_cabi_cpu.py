@@ -70,6 +70,42 @@ def test_argument_validation_needs_no_gpu():
     assert rc == -1 and b'null' in lib.psn_last_error()
     rc = lib.psn_mlp_pack_bf16(None, 4, 4, 4, 0, 8, 0, 1, None, None)
     assert rc == -1 and b'null' in lib.psn_last_error()
+    # in-kernel positional encoding: shape rules are checked before any pointer is touched
+    m = hip.PsnMlpDesc()
+    rc = lib.psn_mlp_infer_pe(ctypes.byref(m), None, None, None, 10, 6, 1.0, None, None)
+    assert rc == -1 and b'null' in lib.psn_last_error()
+    dummy = ctypes.c_void_p(64)
+    m.n_layers, m.n_out, m.in_kt_a = 2, 1, 1
+    rc = lib.psn_mlp_infer_pe(ctypes.byref(m), dummy, dummy, dummy, 10, 6, 1.0, dummy, None)
+    assert rc == -1 and b'in_kt_a' in lib.psn_last_error()
+    m.in_kt_a = 2
+    rc = lib.psn_mlp_infer_pe(ctypes.byref(m), dummy, dummy, dummy, 10, 11, 1.0, dummy, None)  # 3 + 6 * 11 > 64 columns
+    assert rc == -1 and b'octaves' in lib.psn_last_error()
+    # 33..64 outputs exist for the 256-wide chain engine only; > 64 nowhere
+    m.n_out = 65
+    m.layers[0].init_off = m.layers[1].init_off = -1
+    rc = lib.psn_mlp_infer(ctypes.byref(m), dummy, dummy, None, 1, 1, None, 1, 1, None, None, None, 0, None, None, None, None, None, None, 0,
+                           None, 10, dummy, None)
+    assert rc == -1 and b'n_out' in lib.psn_last_error()
+
+
+def test_split_rows_backward_is_the_slice_backward():
+    """ops.SplitRows == (t[:k], t[k:]) in value and gradient, incl. an unused half (gradient None -> zeros)."""
+    import torch
+    from psnerf_amd import ops
+    g = torch.Generator().manual_seed(0)
+    t = torch.randn(11, 5, generator=g, requires_grad=True)
+    t2 = t.detach().clone().requires_grad_()
+    wa, wb = torch.randn(4, 5, generator=g), torch.randn(7, 5, generator=g)
+    a, b = ops.SplitRows.apply(t, 4)
+    assert torch.equal(a, t2[:4]) and torch.equal(b, t2[4:])
+    ((a * wa).sum() + (b * wb).sum() * 2).backward()
+    ((t2[:4] * wa).sum() + (t2[4:] * wb).sum() * 2).backward()
+    assert torch.equal(t.grad, t2.grad)
+    t.grad = None
+    a, b = ops.SplitRows.apply(t, 4)
+    (b * wb).sum().backward()
+    assert torch.equal(t.grad[:4], torch.zeros(4, 5)) and torch.equal(t.grad[4:], wb)
 
 
 def test_conf_reader_on_hocon_subset():
