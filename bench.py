@@ -326,7 +326,11 @@ def main():
                     # while the matrix pipe itself runs at issued_frac of its peak.
                     'issued_macs_per_row': VIS_MACS_ISSUED,
                     'issued_tflops': round(achieved * VIS_MACS_ISSUED / VIS_MACS, 2),
-                    'issued_frac': round(achieved * VIS_MACS_ISSUED / VIS_MACS / PEAK_F32_MFMA_TFLOPS, 4)}
+                    'issued_frac': round(achieved * VIS_MACS_ISSUED / VIS_MACS / PEAK_F32_MFMA_TFLOPS, 4),
+                    'note': 'achieved / frac count the reference formulation (SURVEY 8d: 523,520 MAC per row); the kernel takes the '
+                            'point and light halves of the two input blocks from init tables and issues 462,848 MAC per row, so '
+                            'frac may exceed 1 -- the matrix-pipe utilisation is issued_frac (PMC SQ_VALU_MFMA_BUSY_CYCLES: '
+                            'profiles/)'}
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # the CPU oracle is timed at N = 1 only (other ranks would idle behind it)
         cpu = cpu_baseline()
