@@ -191,6 +191,7 @@ class PSNetwork(nn.Module):
         # following it.  Off: everything on the caller's stream.
         self.overlap_small_nets = conf.get_bool('train.overlap_small_nets', default=True)
         self._side = {}
+        self._cols_cache = {}
         self.visibility = conf.get_bool('train.visibility', default=False)
         self.light_vis_detach = conf.get_bool('train.light_vis_detach', default=False)
         if self.visibility:
@@ -219,9 +220,13 @@ class PSNetwork(nn.Module):
         return ops.positional_encoding(x, n_freqs, PE_STRIDE)
 
     def _cols(self, n_freqs, device, pair=False):
-        d = 3 + 6 * n_freqs
-        c = torch.arange(d, device=device)
-        return torch.cat([c, PE_STRIDE + c]) if pair else c
+        key = (n_freqs, str(device), pair)  # constant index lists: built once (4 launch-bound kernels per call otherwise)
+        c = self._cols_cache.get(key)
+        if c is None:
+            d = 3 + 6 * n_freqs
+            c = torch.arange(d, device=device)
+            c = self._cols_cache[key] = torch.cat([c, PE_STRIDE + c]) if pair else c
+        return c
 
     def _visibility_rows(self, pe_x, light_dirs, fused_ok):
         """visibility_net on the light-major rows [pe_x[n] | PE(light[l])], l-major (renderer.py:191-200)."""
@@ -324,7 +329,6 @@ class PSNetwork(nn.Module):
         uv, pose, intr = input['uv'], input['pose'], input['intrinsics']
         object_mask = input['object_mask']
         device = uv.device
-        ray_dirs, _ = camera_rays(uv, pose, intr)
         surface_mask, points, normals = input['surface_mask'], input['points'], input['normal']
         # The index list of the surface pixels: nonzero() is the one data-dependent host synchronisation of the forward.
         # A batch may bring the list along ('surface_idx', int64, ascending = surface_mask[0].nonzero()): the mask is an
@@ -410,7 +414,11 @@ class PSNetwork(nn.Module):
         vis_t_pre = None
         if ns > 0:
             normal = gather(normals) if not self.normal_mlp else normal_s
-            pts2c = -gather(ray_dirs)
+            # camera rays (~15 launch-bound elementwise kernels) are only needed by the shading: queued beside the
+            # visibility launch (side stream), not in front of it
+            with on_side():
+                ray_dirs, _ = camera_rays(uv, pose, intr)
+                pts2c = -gather(ray_dirs)
             light_dir = input['light_direction']
             cols = self._cols(self.n_freqs, device)
             if pe_x is None:
@@ -449,7 +457,7 @@ class PSNetwork(nn.Module):
                 # stream.  Their memory came from the side stream's pool: tell the allocator about the second user.
                 main = torch.cuda.current_stream(device)
                 main.wait_stream(side)
-                for t_ in (normal_s, albedo_both if self.xyz_jitter_std > 0 else albedo, rough_both if self.xyz_jitter_std > 0 else rough,
+                for t_ in (pts2c, normal_s, albedo_both if self.xyz_jitter_std > 0 else albedo, rough_both if self.xyz_jitter_std > 0 else rough,
                            weights if sg else None, out_n.get('normal_jitter').rows if 'normal_jitter' in out_n else None):
                     if torch.is_tensor(t_):
                         t_.record_stream(main)

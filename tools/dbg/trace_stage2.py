@@ -29,6 +29,8 @@ for e in evs:
     if gap > 0:
         gaps += gap
     tot += d
+    if os.environ.get('UNTIL_VIS') == '1' and e.time_range.start - t0 > 450:
+        break
     if d >= float(os.environ.get('MIN_US', '8')) or gap >= 15:
         print('%9.1f  gap %7.1f  %8.1f us  %s' % (e.time_range.start - t0, gap, d, e.name[:100]))
     prev_end = max(prev_end, e.time_range.end)
