@@ -106,13 +106,16 @@ def _src(w):
     return m, False, m.shape[0], m.shape[1]
 
 
-def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True, width=256):
+def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True, width=256, reuse=None):
     """layers: list of dicts {w_in | init_a/init_b, w_act, bias, act}.
     w_in: [o, <=in_kt*32] consumed as MFMA k-tiles; init_a [o, in_kt_a*32] / init_b [o, in_kt_b*32]: the same
     block evaluated through precomputed tables instead.  Hidden layers have o <= width (zero padded; width = 256 or
     128, one value per network), the final layer o = n_out <= 32 (<= 64 in a 256-wide chain).  w_act / w_in may be any row-major view with unit
     column stride (column slices of a parameter) or Transposed(w): the pack kernel reads them in place and zero-fills
-    the padding, so no padded / concatenated / transposed copies are made on the way."""
+    the padding, so no padded / concatenated / transposed copies are made on the way.
+    reuse: the PackedMLP this call site built last time (same network, new parameter values): its zero-padded init-table
+    buffers are written in place -- two slice copies per table instead of a pad (fill + copy) per block and a concatenation.
+    Only for packs that no launch in flight on ANOTHER stream still reads."""
     assert width in (64, 128, 256)
     hid = width // 32
     kin = in_kt_a + in_kt_b
@@ -130,7 +133,8 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
         rows = n_mt * 32
         lay = desc.layers[li]
         lay.init_off = -1
-        bias = _pad_vec(L['bias'].detach().float(), rows)
+        bias = L['bias'].detach().float()
+        bias_pad = rows - bias.shape[0]  # zero entries behind the real ones (appended in the concatenation below)
         if isinstance(L.get('init_a'), str) and L['init_a'] == DIRECT_INIT:
             assert not last and not init_wa and direct_init_off is None
             lay.init_off = 0
@@ -138,11 +142,11 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
         elif L.get('init_a') is not None:
             assert not last
             lay.init_off = width * len(init_wa)
-            init_wa.append(_pad_rows(_pad_cols(L['init_a'], in_kt_a * 32), width))
+            init_wa.append(L['init_a'])
             if L.get('init_b') is not None:
-                init_wb.append(_pad_rows(_pad_cols(L['init_b'], in_kt_b * 32), width))
-            init_bias.append(bias)  # folded into the init table
-            bias = torch.zeros_like(bias)
+                init_wb.append(L['init_b'])
+            init_bias.append(_pad_vec(bias, rows))  # folded into the init table
+            bias, bias_pad = _zeros(rows, device), 0
         n_kt_in = n_kt_act = 0
         tile = n_mt * 1024  # floats per 32-feature k-tile of this layer
         lay.w_off, lay.b_off = off, b_off
@@ -157,10 +161,12 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
             n_kt_in = kin
             off += kin * tile
         biases.append(bias)
+        if bias_pad > 0:
+            biases.append(_zeros(bias_pad, device))
         lay.n_kt_in, lay.n_kt_act, lay.n_mt, lay.act = n_kt_in, n_kt_act, n_mt, L['act']
         b_off += rows
     w_buf = torch.empty(max(off, 4), device=device, dtype=torch.float32)
-    if all(bv.data_ptr() == _zeros(bv.shape[0], device).data_ptr() for bv in biases):
+    if all(bv.data_ptr() == _zeros(bv.shape[0], device).data_ptr() for bv in biases):  # (cached zeros of one size share one tensor)
         b_buf = _zeros(sum(bv.shape[0] for bv in biases), device)  # all-zero biases of a backward chain
     else:
         b_buf = torch.cat(biases).contiguous()
@@ -172,8 +178,15 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     hip.mlp_pack_layers(group)  # every block of the network in one launch
     desc.init_stride = width * len(init_wa) if direct_init_off is None else width
     if init_wa:
-        pk = PackedMLP(desc, w_buf, b_buf, torch.cat(init_wa).contiguous().float(),
-                       torch.cat(init_wb).contiguous().float() if init_wb else None,
+        def stack(blocks, cols, old):  # [len(blocks) * width, cols], zero padded
+            shape = (len(blocks) * width, cols)
+            buf = old if (old is not None and tuple(old.shape) == shape and old.device == w_buf.device) else torch.zeros(shape, device=device)
+            for i, blk in enumerate(blocks):
+                assert blk.shape[0] <= width and blk.shape[1] <= cols
+                buf[i * width:i * width + blk.shape[0], :blk.shape[1]].copy_(blk)
+            return buf
+        pk = PackedMLP(desc, w_buf, b_buf, stack(init_wa, in_kt_a * 32, getattr(reuse, 'init_wa', None)),
+                       stack(init_wb, in_kt_b * 32, getattr(reuse, 'init_wb', None)) if init_wb else None,
                        torch.cat(init_bias).contiguous())
     else:
         pk = PackedMLP(desc, w_buf, b_buf)
@@ -181,7 +194,7 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     return pk
 
 
-def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, precompute=True, width=256):
+def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, precompute=True, width=256, reuse=None):
     """stage2 Network / Normal_Network (stage2/model/renderer.py:17-49) of width 256: ReLU stack, the
     input is concatenated AFTER layer ``skip_at``.  Input row = [table A (din_a real cols, padded to
     a multiple of 32) | table B (din_b)].  precompute=True evaluates the input block of layer 0 and of the
@@ -212,7 +225,7 @@ def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, 
         else:
             layers.append(dict(w_act=W, bias=b, act=act))
     assert all(L['bias'].shape[0] == width for L in layers[:-1]), 'fused path: every hidden layer must have the given width'
-    return pack_layers(layers, ka, kb, weights[-1].shape[0], out_act, weights[0].device, width=width)
+    return pack_layers(layers, ka, kb, weights[-1].shape[0], out_act, weights[0].device, width=width, reuse=reuse)
 
 
 class PackedBf16(object):

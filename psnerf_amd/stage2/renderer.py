@@ -268,7 +268,9 @@ class PSNetwork(nn.Module):
             Ws, bs = net.weights()
             half = 3 + 6 * self.n_freqs
             with torch.no_grad():
-                self._vis_pack = fused.pack_relu_mlp(list(Ws), list(bs), half, half, net._skip_index())
+                # (the previous pack's init-table buffers are rewritten in place: its launches are behind us on this stream)
+                self._vis_pack = fused.pack_relu_mlp(list(Ws), list(bs), half, half, net._skip_index(),
+                                                     reuse=getattr(self, '_vis_pack', None))
             self._vis_pack_key = key
         return self._vis_pack
 
