@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     // LDS-DMA flavour (common.h lds_dma_16): asm pieces + explicit scheduling regions for the lean variant (exact lgkmcnt
     // waits: visibility launch +1.9 %, march sweep +4 %), the builtin + scheduling groups for the chain variant (its
     // F2 / B1 / B2 chains measured 1-2 % SLOWER with the regions, with either piece flavour)
-    constexpr bool kAsmDma = !CHAIN && SRC != 1;  // (the root finder is latency-bound and at the register limit: builtin)
+    constexpr bool kAsmDma = !CHAIN && SRC != 1;  // (chain flavours: 2-4 % slower with asm pieces, re-measured with the V-row chain)  // (the root finder is latency-bound and at the register limit: builtin)
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 32 KB weight stages + all biases
     float* bias_lds = smem + 2 * kStageFloats;
     const int tid = threadIdx.x;

@@ -83,6 +83,16 @@ for rep in range(REPS):  # libraries interleaved, minimum over the rounds: clock
     out16g = torch.empty(Q, 1, device=dev)
     rec('vis bf16 grp', timeit(lambda: p16g(ta16, tb, out=out16g), n=10))
     res['vis16g'] = out16g.clone()
+    # the V-row backward chain of a stage-2 step: 8 visibility lights x 29487 points, ReLU-mask chain over transposed packs
+    Qv = 8 * Ns
+    if 'Hv' not in globals():
+        globals()['Hv'] = [torch.randn(Qv, 256, device=dev) for _ in range(8)]
+        globals()['DZv'] = [torch.empty(Qv, 256, device=dev) for _ in range(8)]
+        globals()['gv'] = torch.randn(Qv, 1, device=dev)
+    chv = fused.pack_relu_bwd(ws, 3)
+    wlast = ws[-1].contiguous()
+    rec('V-row bwd', timeit(lambda: chv(None, Qv, a_div=1, a_mod=Qv, rank_init=(gv, wlast), mask=Hv, save=DZv)))
+    res['dzv'] = DZv[-1].clone()
     occ = fused.pack_geo_occupancy(Wo, bo, [4], 39)
     oo = torch.empty(Qo, 1, device=dev)
     rec('occ march', timeit(lambda: occ(tabo, Qo, out=oo)))
@@ -110,7 +120,7 @@ for rep in range(REPS):  # libraries interleaved, minimum over the rounds: clock
             d = (res[k] - ref[k]).abs().max().item()
             print('   %-22s %-6s max|d| vs first library %.3e (max |ref| %.3e)' % (tag, k, d, ref[k].abs().max().item()))
     hip._lib = orig
-flop = {'vis lean': 2.0 * 523520 * Q, 'vis bf16': 2.0 * 523520 * Q, 'vis bf16 grp': 2.0 * 523520 * Q, 'occ march': 2.0 * (39 * 256 + 6 * 65536 + 256 * 217 + 256 * 256 + 256) * Qo}
+flop = {'V-row bwd': 2.0 * 7 * 65536 * 8 * Ns, 'vis lean': 2.0 * 523520 * Q, 'vis bf16': 2.0 * 523520 * Q, 'vis bf16 grp': 2.0 * 523520 * Q, 'occ march': 2.0 * (39 * 256 + 6 * 65536 + 256 * 217 + 256 * 256 + 256) * Qo}
 for n, m in zip(names, macs):
     flop[n] = 2.0 * m * Qc
 keys = list(next(iter(best.values())).keys())
