@@ -56,22 +56,48 @@ class Trainer(object):
             net.prepack(occupancy=True)  # the next step's ray march starts with this pack: queue it behind the backward
         return terms
 
+    def _upload(self, t):
+        """Host tensor -> device without stalling the host behind the stream: a pageable source makes the copy wait for
+        everything queued before it (the whole previous step), after which the host trails the GPU by its launch latency for
+        the first ~0.3 ms of every step.  Two pinned staging buffers, used alternately; a buffer is rewritten only after the
+        copy that last read it has completed (two steps back: never waits in practice)."""
+        dev = torch.device(self.device)
+        if t.is_cuda or dev.type != 'cuda':
+            return t.to(dev)
+        slot = self._pin_turn = 1 - getattr(self, '_pin_turn', 0)
+        bufs = self.__dict__.setdefault('_pin_bufs', [None, None])
+        buf, ev = bufs[slot] if bufs[slot] is not None else (None, None)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf, ev = torch.empty(t.shape, dtype=t.dtype).pin_memory(), torch.cuda.Event()
+        else:
+            ev.synchronize()
+        buf.copy_(t)
+        out = buf.to(dev, non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        bufs[slot] = (buf, ev)
+        return out
+
     def compute_loss(self, data, eval_mode=False, it=None, pix=None, noise=None):
         dev = self.device
         img = data['img'].to(dev)
         B, _, h, w = img.shape
-        mask_img = data.get('img.mask', torch.ones(B, h, w)).unsqueeze(1).to(dev)
+        def on_dev(key):  # a missing mask is all ones, built ON the device (a host default would be 1.25 MB uploaded per step)
+            t = data.get(key)
+            return torch.ones(B, h, w, device=dev) if t is None else t.to(dev)
+        mask_img = on_dev('img.mask').unsqueeze(1)
         world_mat, camera_mat, scale_mat = (data['img.world_mat'].to(dev), data['img.camera_mat'].to(dev),
                                             data['img.scale_mat'].to(dev))
         normal = data.get('img.normal').to(dev) if self.normal_loss else None
         norm_mask = data.get('img.norm_mask').unsqueeze(1).to(dev) if self.normal_loss else None
-        mask_valid = data.get('img.mask_valid', torch.ones(B, h, w)).unsqueeze(1).to(dev)
+        mask_valid = on_dev('img.mask_valid').unsqueeze(1)
         if pix is None:  # stage1/model/common.py:32-36: x then y, CPU randint
             n = int(self.n_training_points)
             px = torch.randint(0, w, size=(B, n, 1)).float()
             py = torch.randint(0, h, size=(B, n, 1)).float()
             pix = torch.cat([px, py], dim=-1)
-        pix = self.dp.shard_rays(pix.to(dev)) if self.dp.enabled else pix.to(dev)
+        pix = self._upload(pix)
+        if self.dp.enabled:
+            pix = self.dp.shard_rays(pix)
         if self.rendering_technique == 'unisurf' and hasattr(self.model, 'prefetch_surface'):
             self.model.prefetch_surface(pix, camera_mat, world_mat)  # the ray-march sweep runs under the host work below
         mask_gt = gather_pixels(mask_img, pix).bool().reshape(B, -1).to(torch.float32)
