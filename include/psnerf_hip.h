@@ -121,6 +121,7 @@ typedef struct {
     const float* B_tab2; int64_t ldb_tab2;   /* optional second table (needs b_div > 0): the columns b_split .. N-1 of the */
     int64_t b2_div, b2_mod;                  /* virtual B come from B_tab2[(k / b2_div) % b2_mod, n - b_split]           */
     int b_split;                             /* multiple of 4; N = b_split + columns taken from B_tab2                    */
+    int64_t k_rows;                          /* 0 = K; else this product sums over the first k_rows (<= K) rows only       */
 } PsnGemmTnItem;
 int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
                         int64_t workspace_floats, void* stream);
@@ -235,7 +236,9 @@ int psn_mlp_pack_layers(int n_items, const PsnPackItem* items, void* stream);
  * of the layers' activation programs; save2_ptrs: second dumps (same indexing as save_ptrs).  With n_out == 0 there is no final layer and `out` may be NULL: together with
  * transposed weight packs, an init table holding d h of the last hidden layer, masks = the dumped activations and
  * save_ptrs = the d z outputs this runs the ReLU BACKWARD chain d h_{l-1} = W_l^T (d h_l * relu'(h_l)).
- * act_init (or NULL): row-major [n_rows, 256] initial activations, so that layer 0 may already read them.
+ * act_init (or NULL): row-major [act_init_rows, 256] initial activations, so that layer 0 may already read them; rows >=
+ * act_init_rows (1 .. n_rows) start from zeros (a gradient that exists for a row prefix only: the colour network's d features
+ * when the surface-normal points ride behind the render samples, stage1/model/rendering.py:196-212).
  * rk_coef [n_rows, rk_k], rk_basis [rk_k, init_stride] (or NULL, NULL, 0; rk_k <= 4): rank-k init -- the layers with
  * init_off >= 0 additionally start from sum_c rk_coef[row, c] * rk_basis[c, init_off + f].  This is the init table of a
  * backward chain whose network has 1..4 outputs, d h = g_out W_last (stage1/model/network.py:104-106 colour head,
@@ -248,7 +251,7 @@ int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* pa
                   int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                   const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
                   const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
-                  const float* act_init, const float* rk_coef, const float* rk_basis, int rk_k,
+                  const float* act_init, int64_t act_init_rows, const float* rk_coef, const float* rk_basis, int rk_k,
                   const uint32_t* dump_tiles, int64_t n_rows, float* out, void* stream);
 
 /* Dense per-pixel outputs of the stage-2 model, stage2/model/renderer.py:145-152,204-264: dense [B, N, C] = fill

@@ -1076,7 +1076,8 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         const bool tall = vec && it.b_div == 0 && it.M > 128 && it.M <= T256 && it.N <= T64;
         const int sk = big ? split_big : tall ? split_tall : split_k;
         GemmArgs& g = big ? gb.g[gb.n] : tall ? gt.g[gt.n] : gg.g[gg.n];
-        g.M = it.M; g.N = it.N; g.K = (int)K; g.A = it.A; g.lda = it.lda; g.B = it.B; g.ldb = it.ldb;
+        PSN_CHECK_ARG(it.k_rows >= 0 && it.k_rows <= K, "gemm_tn_grouped: item %d k_rows=%lld of K=%lld", i, (long long)it.k_rows, (long long)K);
+        g.M = it.M; g.N = it.N; g.K = (int)(it.k_rows > 0 ? it.k_rows : K); g.A = it.A; g.lda = it.lda; g.B = it.B; g.ldb = it.ldb;
         g.A2 = it.A2; g.lda2 = it.lda2; g.B2 = it.B2; g.ldb2 = it.ldb2;
         // a modulo that cannot wrap ((K - 1) / div < mod) is passed as 0 = identity
         g.b_div = (int)it.b_div; g.b_mod = (it.b_div > 0 && (K - 1) / it.b_div < it.b_mod) ? 0 : (int)it.b_mod;

@@ -50,7 +50,8 @@ struct InferArgs {
     const float* mask[PSN_MLP_MAX_LAYERS];  // aux1: row-major [n_rows, 256] tensor read by the layer's activation
     const float* aux2[PSN_MLP_MAX_LAYERS];  // aux2: second row-major operand (PSN_ACT_MUL2 / PSN_ACT_SOFTPLUS_BWD)
     float* save2[PSN_MLP_MAX_LAYERS];       // second dump (sigmoid of PSN_ACT_SOFTPLUS100, raw acc of MUL_AUX, acc*aux2 of MUL2)
-    const float* act_init;                  // optional row-major [n_rows, 256] initial activations (chains that start from a tensor)
+    const float* act_init;                  // optional row-major [act_init_rows, 256] initial activations (chains that start from a tensor)
+    int64_t act_init_rows;                  // rows >= act_init_rows start from zero activations (a tensor that covers a row prefix only)
     // rank-k init (k <= 4): the layers with init_off >= 0 additionally start from sum_c rk_coef[row, c] * rk_basis[c, init_off + f]
     // -- the init table of a backward chain, d h = g_out W_last with 1..3 outputs, formed in registers instead of being
     // written to HBM by a K = 3 GEMM / a broadcast product and read back (1 KB per row each way)
@@ -398,11 +399,12 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         for (int r = 0; r < 4; ++r) act[mt][r] = 0.f;
     if constexpr (CHAIN) {
         if (g.act_init != nullptr) {
-            const float* ap = g.act_init + rowc * W + 4 * lg;
+            const bool has_row = rowc < g.act_init_rows;
+            const float* ap = g.act_init + (has_row ? rowc : 0) * W + 4 * lg;
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) {
                 float4 t = *reinterpret_cast<const float4*>(ap + mt * 16);
-                act[mt][0] = t.x; act[mt][1] = t.y; act[mt][2] = t.z; act[mt][3] = t.w;
+                act[mt][0] = has_row ? t.x : 0.f; act[mt][1] = has_row ? t.y : 0.f; act[mt][2] = has_row ? t.z : 0.f; act[mt][3] = has_row ? t.w : 0.f;
             }
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) asm volatile("" : "+v"(act[mt]));  // arrived before the first stage's LDS-DMA pieces (see load_xin)
@@ -977,7 +979,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
                              int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                              const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
                              const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
-                             const float* act_init, const float* rk_coef, const float* rk_basis, int rk_k,
+                             const float* act_init, int64_t act_init_rows, const float* rk_coef, const float* rk_basis, int rk_k,
                              const uint32_t* dump_tiles, int64_t n_rows, float* out, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(desc && packed_w && packed_b && (out || desc->n_out == 0), "mlp_infer: null pointer");
@@ -1048,12 +1050,14 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer: too many rows");
     a.act_init = act_init;
+    a.act_init_rows = act_init_rows;
     a.rk_coef = rk_coef; a.rk_basis = rk_basis; a.rk_k = rk_k;
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) {
         a.save_tiles[l] = dump_tiles ? dump_tiles[l] : 0xFFFFFFFFu;
         a.save2_tiles[l] = dump_tiles ? dump_tiles[PSN_MLP_MAX_LAYERS + l] : 0xFFFFFFFFu;
     }
     PSN_CHECK_ARG((((uintptr_t)act_init) & 15) == 0, "mlp_infer: act_init must be 16-byte aligned");
+    PSN_CHECK_ARG(act_init == nullptr || (act_init_rows >= 1 && act_init_rows <= n_rows), "mlp_infer: act_init_rows=%lld of %lld rows", (long long)act_init_rows, (long long)n_rows);
     bool chain = act_init != nullptr || rk_coef != nullptr || dump_tiles != nullptr;
     for (int l = 0; l < d.n_layers; ++l)
         chain = chain || d.layers[l].act > PSN_ACT_SOFTPLUS100 || a.save2[l] != nullptr || a.mask[l] != nullptr || a.aux2[l] != nullptr;

@@ -66,7 +66,7 @@ class PsnGemmTnItem(ctypes.Structure):
                 ('A2', ctypes.c_void_p), ('lda2', i64), ('B2', ctypes.c_void_p), ('ldb2', i64),
                 ('C', ctypes.c_void_p), ('ldc', i64), ('M', i32), ('N', i32), ('accumulate', i32),
                 ('colsum_a', ctypes.c_void_p), ('b_div', i64), ('b_mod', i64),
-                ('B_tab2', ctypes.c_void_p), ('ldb_tab2', i64), ('b2_div', i64), ('b2_mod', i64), ('b_split', i32)]
+                ('B_tab2', ctypes.c_void_p), ('ldb_tab2', i64), ('b2_div', i64), ('b2_mod', i64), ('b_split', i32), ('k_rows', i64)]
 
 
 class PsnRowAdamItem(ctypes.Structure):
@@ -101,7 +101,7 @@ SIGNATURES = {
                                c_f, c_f, c_f]),
     'psn_mlp_infer': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
                             ctypes.POINTER(ctypes.c_void_p), i64, ctypes.POINTER(ctypes.c_void_p),
-                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f, c_f, c_f, i32,
+                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f, i64, c_f, c_f, i32,
                             ctypes.POINTER(ctypes.c_uint32), i64, c_f, c_f]),
     'psn_scatter_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_gather_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
@@ -559,7 +559,8 @@ def gemm_tn_grouped(items, split_k=None):
                 b_div, b_mod = max(b_div, 1), (b_mod if b_mod else B.shape[0])
                 assert A.shape[0] == K and b_mod <= B.shape[0] and it.get('A2') is None
             else:
-                assert A.shape[0] == K and B.shape[0] == K, 'gemm_tn_grouped: all products share K'
+                # a product may cover a row PREFIX of the pass (operands with fewer rows than items[0]): k_rows
+                assert A.shape[0] == B.shape[0] <= K, 'gemm_tn_grouped: a product has at most the K rows of the first one'
             M, N = A.shape[1], B.shape[1]
             Bt2 = it.get('B_tab2')
             if Bt2 is not None:  # second table side by side: columns N .. N + Bt2.shape[1] - 1 of the virtual operand
@@ -583,11 +584,12 @@ def gemm_tn_grouped(items, split_k=None):
                 e.B_tab2, e.ldb_tab2 = _mat_ptr(Bt2, 'B_tab2'), _ld(Bt2)
                 e.b2_div, e.b2_mod, e.b_split = int(it['b2_div']), int(it.get('b2_mod', Bt2.shape[0])), B.shape[1]
             e.colsum_a = None if cs is None else cs.data_ptr()
+            e.k_rows = 0 if A.shape[0] == K else A.shape[0]
             sk = max(split_k, split_big) if is_big(it) else (max(split_k, split_tall) if _tn_is_tall(it) else split_k)
             need += (2 if A2 is not None else 1) * sk * M * N + sk * M + 16
             keep.append((C, cs))
         ws = workspace(need, dev)
-        flops = sum(2.0 * K * arr[i].M * arr[i].N * (2 if chunk[i].get('A2') is not None else 1) for i in range(len(chunk)))
+        flops = sum(2.0 * (arr[i].k_rows or K) * arr[i].M * arr[i].N * (2 if chunk[i].get('A2') is not None else 1) for i in range(len(chunk)))
         with _Prof('gemm_tn_grouped', flops):
             _check(_lib.psn_gemm_tn_grouped(len(chunk), ctypes.addressof(arr), K, split_k, ws.data_ptr(), ws.numel(), _stream()),
                    'gemm_tn_grouped')
@@ -641,10 +643,11 @@ def mlp_pack_layers(plan):
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
               init_b=None, save=None, save_row0=0, mask=None, aux2=None, save2=None, act_init=None, macs_per_row=None,
-              rank_init=None, save_tiles=None, save2_tiles=None):
+              rank_init=None, save_tiles=None, save2_tiles=None, act_init_rows=None):
     """save: list (one entry per hidden layer, None allowed) of [n_rows - save_row0, 256] tensors that receive the
     post-activation outputs of the rows >= save_row0.
-    rank_init = (coef [n_rows, k], basis [k, init_stride]), k <= 4: rank-k init of the layers with init_off >= 0."""
+    rank_init = (coef [n_rows, k], basis [k, init_stride]), k <= 4: rank-k init of the layers with init_off >= 0.
+    act_init [act_init_rows (default n_rows), width]: initial activations; the rows behind them start from zeros."""
     tiles_arr = None
     if save_tiles is not None or save2_tiles is not None:  # per layer: bit mt = the 16-column tile mt of the dump is written
         tiles_arr = (ctypes.c_uint32 * (2 * MAX_LAYERS))(*([0xFFFFFFFF] * (2 * MAX_LAYERS)))
@@ -660,6 +663,10 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
         assert rk_coef.shape == (n_rows, rk_k) and rk_coef.is_contiguous() and rk_basis.is_contiguous() and 1 <= rk_k <= 4
         assert rk_basis.shape[1] == desc.init_stride, 'rank_init: the basis rows are init_stride floats'
 
+    ai_rows = 0
+    if act_init is not None:
+        ai_rows = n_rows if act_init_rows is None else act_init_rows
+        assert act_init.is_contiguous() and act_init.shape[0] >= ai_rows, 'act_init: fewer rows than act_init_rows'
     if out is None and desc.n_out > 0:
         out = torch.empty(n_rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
     n_hidden = desc.n_layers - 1 if desc.n_out > 0 else desc.n_layers
@@ -683,7 +690,7 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
         _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
                                   _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,
                                   _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), save_arr, save_row0, mask_arr,
-                                  aux2_arr, save2_arr, _ptr(act_init, 'act_init', True), _ptr(rk_coef, 'rk_coef', True),
+                                  aux2_arr, save2_arr, _ptr(act_init, 'act_init', True), int(ai_rows), _ptr(rk_coef, 'rk_coef', True),
                                   _ptr(rk_basis, 'rk_basis', True), rk_k, tiles_arr, n_rows, _ptr(out, 'out', True), _stream()), 'mlp_infer')
     return out
 

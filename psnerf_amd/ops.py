@@ -690,14 +690,19 @@ class GeoFieldFused(torch.autograd.Function):
     split-K weight-gradient GEMMs.  The Linear / softplus / elementwise traffic of 34 GEMM launches never
     round-trips through HBM as GEMM operands.  256-wide networks with one skip layer only (fallback: GeoField).
 
-    Returns (logit [Q,1], feat [Q,256], grad [Q,3]).  ``chains`` = fused.pack_geo_chains(...) (cached per step)."""
+    Returns (logit [Q,1], feat [Q,256], grad [Q,3]).  ``chains`` = fused.pack_geo_chains(...) (cached per step).
+    ``feat_rows`` (None = Q): only the features of the first feat_rows rows are returned / receive a gradient -- the points
+    behind them are evaluated for their gradient alone (the surface-normal points of rendering.py:200-212 riding behind
+    the render samples: one set of launches instead of two, and no [Q,256] zero-padded d feat in backward)."""
 
     @staticmethod
-    def forward(ctx, p, n_octaves, scale, skips, with_grad, chains, *params):
+    def forward(ctx, p, n_octaves, scale, skips, with_grad, chains, feat_rows, *params):
         Ws = [w for w in params[0::2]]
         n = len(Ws)
         p = p.contiguous()
         Q, dev = p.shape[0], p.device
+        feat_rows = Q if feat_rows is None else int(feat_rows)  # rows whose features are returned (and receive a gradient)
+        assert 1 <= feat_rows <= Q
         d_pe = 3 + 6 * n_octaves
         d_a = chains['d_a']
         sk = skips[0]
@@ -726,7 +731,7 @@ class GeoFieldFused(torch.autograd.Function):
             # d logit / d pe = r0 + the skip layer's columns of r_sk: both read in place
             grad = hip.pe_encode_bwd(p, r0, n_octaves, scale, add=r_sk[:, d_a:d_a + d_pe])
         if any(ctx.needs_input_grad):
-            ctx.meta = (n, sk, d_pe, d_a, n_octaves, scale, with_grad, chains)
+            ctx.meta = (n, sk, d_pe, d_a, n_octaves, scale, with_grad, chains, feat_rows)
             keep = [p, pe] + Ws + A + S
             if with_grad:
                 keep += U
@@ -734,11 +739,11 @@ class GeoFieldFused(torch.autograd.Function):
         if grad is None:
             grad = torch.zeros(Q, 3, device=dev)
             ctx.mark_non_differentiable(grad)
-        return logit, feat, grad
+        return logit, (feat if feat_rows == Q else feat[:feat_rows]), grad
 
     @staticmethod
     def backward(ctx, d_logit, d_feat, d_grad):
-        n, sk, d_pe, d_a, n_octaves, scale, with_grad, chains = ctx.meta
+        n, sk, d_pe, d_a, n_octaves, scale, with_grad, chains, feat_rows = ctx.meta
         sv = list(ctx.saved_tensors)
         p, pe = sv[0], sv[1]
         Ws = sv[2:2 + n]
@@ -747,7 +752,7 @@ class GeoFieldFused(torch.autograd.Function):
         Q, dev = p.shape[0], p.device
         sweep = with_grad and d_grad is not None
         d_logit = torch.zeros(Q, 1, device=dev) if d_logit is None else d_logit.contiguous()
-        d_feat = torch.zeros(Q, 256, device=dev) if d_feat is None else d_feat.contiguous()
+        d_feat = torch.zeros(feat_rows, 256, device=dev) if d_feat is None else d_feat.contiguous()  # [feat_rows, 256]
         w_row = Ws[n - 1][0:1, :].contiguous()
         dW = [None] * n
         db = [None] * n
@@ -770,7 +775,7 @@ class GeoFieldFused(torch.autograd.Function):
         dZ = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]  # dZ[l] = d loss / d z_l
         key = 'value_bwd' if sweep else 'value_bwd_nosweep'
         # the rank-1 term d_logit (x) w_row of W_last^T d_out is formed inside the chain kernel (rank_init)
-        chains[key](None, Q, a_div=1, a_mod=Q, rank_init=(d_logit.reshape(Q, 1).contiguous(), w_row), act_init=d_feat,
+        chains[key](None, Q, a_div=1, a_mod=Q, rank_init=(d_logit.reshape(Q, 1).contiguous(), w_row), act_init=d_feat, act_init_rows=feat_rows,
                     mask=[S[n - 2 - j] for j in range(n - 1)],
                     aux2=[E[n - 2 - j] for j in range(n - 1)] if sweep else None,
                     save=[dZ[n - 2 - j] for j in range(n - 1)])
@@ -784,7 +789,7 @@ class GeoFieldFused(torch.autograd.Function):
             if sweep:
                 it['A2'], it['B2'] = U[l][:, :o], dd_pe[:, :d_pe] if l == 0 else dR[l][:, :i_w]
             items.append(it)
-        items.append(dict(A=d_feat, B=a_last, colsum=True))
+        items.append(dict(A=d_feat, B=a_last[:feat_rows], colsum=True))  # the rows behind feat_rows have no d feat
         res = hip.gemm_tn_grouped(items)
         for l in range(n - 1):
             dW[l], db[l] = res[l]
@@ -796,7 +801,7 @@ class GeoFieldFused(torch.autograd.Function):
         grads = []
         for l in range(n):
             grads += [dW[l], db[l]]
-        return (None, None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None, None) + tuple(grads)
 
 
 # --------------------------------------------------------------------------- stage-1 appearance network, fused chains

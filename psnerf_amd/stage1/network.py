@@ -141,10 +141,11 @@ class NeuralNetwork(nn.Module):
             self._chains_key = key
         return self._chains
 
-    def _geo_call(self, p_flat, with_grad, params, chains):
+    def _geo_call(self, p_flat, with_grad, params, chains, feat_rows=None):
         if chains is not None:
             return ops.GeoFieldFused.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad,
-                                           chains, *params)
+                                           chains, feat_rows, *params)
+        assert feat_rows is None
         o, g = ops.GeoField.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad, *params)
         return o[:, :1], o[:, 1:], g
 
@@ -278,6 +279,30 @@ class NeuralNetwork(nn.Module):
             logit, _, _ = self._geo_parts(flat, False)
             return (-1 * logit).reshape(*shp, 1)
         return None
+
+    def render_and_gradient(self, p, ray_d, extra):
+        """``forward(p, ray_d, return_addocc=True)`` and ``gradient(extra)`` from ONE set of geometry-network launches:
+        the ``extra`` points (the surface-normal points of rendering.py:200-212, 2 N next to N S render samples) ride
+        behind the render samples as rows that are evaluated for d logit / d p only.  Same arithmetic per row as the two
+        separate calls; saves four latency-bound chain launches, a weight-gradient launch and the second gradient
+        accumulation of every geometry parameter.  -> (rgb [..., 3], occupancy [..., 1], gradient [Qx, 1, 3])."""
+        shp = p.shape[:-1]
+        flat, ex = p.reshape(-1, 3), extra.reshape(-1, 3)
+        q1 = flat.shape[0]
+        params = self._geo_params()
+        fused_ok = (self.USE_FUSED_CHAINS and self._hidden_is_256() and len(self.skips) == 1 and self.feat_size == 256
+                    and self.n_geo <= 10 and self.d_pe <= 64 and q1 + ex.shape[0] <= self.MAX_ROWS and q1 > 0 and flat.is_cuda)
+        if not fused_ok:
+            rgb, occ = self.forward(p, ray_d, return_addocc=True)
+            return rgb, occ, self.gradient(extra)
+        logit, feat, grad = self._geo_call(torch.cat([flat, ex], dim=0), True, params, self._geo_chains(params), feat_rows=q1)
+        grad_r, grad_x = ops.SplitRows.apply(grad, q1)
+        logit_r, _ = ops.SplitRows.apply(logit, q1)
+        v = ray_d.reshape(-1, 3)
+        v = v / torch.norm(v, dim=-1, keepdim=True)
+        v_pe = ops.positional_encoding(v, self.octaves_pe_views)
+        rgb = self._app_parts(flat, v_pe, grad_r, feat).reshape(*shp, 3)
+        return rgb, torch.sigmoid(logit_r * -10.0).reshape(*shp, 1), grad_x.unsqueeze(1)
 
     def _hidden_is_256(self):
         return self.lin1.weight_v.shape[1] == 256 and all(

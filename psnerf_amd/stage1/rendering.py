@@ -349,10 +349,15 @@ class Renderer(nn.Module):
         p_fg = p_fg.reshape(-1, 3)
         view = (-1 * rays).unsqueeze(-2).expand(-1, full_steps, -1).reshape(-1, 3)
         pp = torch.cat([points, points + (torch.rand_like(points) - 0.5) * 0.01], dim=0)  # every ray; masked below
-        rgb, alpha = self.model(p_fg, view, return_addocc=True)
+        if hasattr(self.model, 'render_and_gradient'):
+            # the 2 N normal points ride behind the N S render samples through the geometry network (one set of launches)
+            rgb, alpha, g = self.model.render_and_gradient(p_fg, view, pp)
+            g = g[:, 0, :]
+        else:
+            rgb, alpha = self.model(p_fg, view, return_addocc=True)
+            g = self.model.gradient(pp)[:, 0, :]
         rgb_values, acc = ops.alpha_composite(alpha.reshape(N, full_steps), rgb.reshape(N, full_steps, 3),
                                               bool(self.white_background))
-        g = self.model.gradient(pp)[:, 0, :]
         nrm = g / (g.norm(2, dim=1).unsqueeze(-1) + 10 ** (-5))
         norm_pred = torch.where(flags.unsqueeze(-1), nrm[:N], torch.zeros_like(nrm[:N]))
         diff_full = torch.norm(nrm[:N] - nrm[N:], dim=-1)

@@ -84,7 +84,7 @@ def test_argument_validation_needs_no_gpu():
     # 33..64 outputs exist for the 256-wide chain engine only; > 64 nowhere
     m.n_out = 65
     m.layers[0].init_off = m.layers[1].init_off = -1
-    rc = lib.psn_mlp_infer(ctypes.byref(m), dummy, dummy, None, 1, 1, None, 1, 1, None, None, None, 0, None, None, None, None, None, None, 0,
+    rc = lib.psn_mlp_infer(ctypes.byref(m), dummy, dummy, None, 1, 1, None, 1, 1, None, None, None, 0, None, None, None, None, 0, None, None, 0,
                            None, 10, dummy, None)
     assert rc == -1 and b'n_out' in lib.psn_last_error()
 

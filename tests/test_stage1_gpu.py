@@ -340,3 +340,34 @@ def test_occupancy_with_in_kernel_encoding_is_bit_identical(cuda, n):
         got = net.occupancy(p)
     assert got.shape == ref.shape == (n, 1)
     assert torch.equal(got, ref)
+
+
+def test_render_and_gradient_matches_the_two_separate_calls(cuda):
+    """NeuralNetwork.render_and_gradient (surface-normal points riding behind the render samples through ONE set of
+    geometry-network launches, features / d features for the render rows only) == forward(..., return_addocc=True) +
+    gradient(extra): identical values (same arithmetic per row), parameter gradients equal to summation order."""
+    from psnerf_amd.stage1 import NeuralNetwork
+    cfg = stage1_cfg('bear')
+    g = torch.Generator().manual_seed(3)
+    p = ((torch.rand(37, 24, 3, generator=g) - 0.5) * 1.6).to(cuda)
+    view = torch.nn.functional.normalize(torch.randn(37, 24, 3, generator=g), dim=-1).to(cuda)
+    extra = ((torch.rand(2 * 37, 3, generator=g) - 0.5) * 1.6).to(cuda)
+    wr, wo, wg = torch.randn(37, 24, 3, generator=g).to(cuda), torch.randn(37, 24, 1, generator=g).to(cuda), torch.randn(74, 1, 3, generator=g).to(cuda)
+    res = []
+    for merged in (False, True):
+        net = NeuralNetwork(cfg)
+        net.load_state_dict(stage1_state_dict(cfg, seed=5))
+        net = net.to(cuda)
+        if merged:
+            rgb, occ, gr = net.render_and_gradient(p, view, extra)
+        else:
+            rgb, occ = net(p, view, return_addocc=True)
+            gr = net.gradient(extra)
+        ((rgb * wr).sum() + (occ * wo).sum() + (gr * wg).sum() * 1e-2).backward()
+        res.append((rgb.detach(), occ.detach(), gr.detach(), {k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None}))
+    (rgb0, occ0, g0, pg0), (rgb1, occ1, g1, pg1) = res
+    assert g1.shape == (74, 1, 3)
+    assert torch.equal(rgb0, rgb1) and torch.equal(occ0, occ1) and torch.equal(g0, g1)
+    assert pg0.keys() == pg1.keys() and len(pg0) > 20
+    for k in pg0:
+        assert_close(pg1[k].cpu(), pg0[k].cpu(), 2e-5, 'd ' + k)  # max-normalised: gradient tensors

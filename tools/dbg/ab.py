@@ -101,7 +101,7 @@ for rep in range(REPS):  # libraries interleaved, minimum over the rounds: clock
     for it in range(4):
         for q in params: q.grad = None
         hip.PROFILE_EVENTS = []
-        logit, feat, grad = ops.GeoFieldFused.apply(pc, 6, 1.0, (4,), True, chains, *params)
+        logit, feat, grad = ops.GeoFieldFused.apply(pc, 6, 1.0, (4,), True, chains, None, *params)
         (logit.sum() + feat.sum() * 0.1 + (grad * grad).sum()).backward()
         torch.cuda.synchronize()
         ev = hip.PROFILE_EVENTS

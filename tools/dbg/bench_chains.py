@@ -21,7 +21,7 @@ for it in range(3):
     torch.cuda.synchronize()
     e0, e1, e2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e0.record()
-    logit, feat, grad = ops.GeoFieldFused.apply(p, 6, 1.0, (4,), True, chains, *params)
+    logit, feat, grad = ops.GeoFieldFused.apply(p, 6, 1.0, (4,), True, chains, None, *params)
     e1.record()
     (logit.sum() + feat.sum() * 0.1 + (grad * grad).sum()).backward()
     e2.record()

@@ -46,3 +46,12 @@ for e in evs:
         print('%9.1f  gap %6.1f  %8.1f us  %s' % (e.time_range.start - t0, gap, d, e.name[:100]))
     prev_end = max(prev_end, e.time_range.end)
 print('kernels %d  busy %.3f ms  idle gaps %.3f ms  span %.3f ms  non-psn kernels %.3f ms' % (len(evs), busy / 1e3, gaps / 1e3, (prev_end - t0) / 1e3, small / 1e3))
+if os.environ.get('NONPSN') == '1':
+    agg = {}
+    for e in evs:
+        if 'psn::' not in e.name:
+            d = e.time_range.end - e.time_range.start
+            k = e.name[:150]
+            a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += d
+    for k, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+        print('%4d  %8.1f us  %s' % (c, d, k))
