@@ -112,7 +112,7 @@ def cpu_baseline(n_pixels=4096, steps=3):
 
 
 # ----------------------------------------------------------------------------------------------- stage 1 (configs[1])
-def stage1_measure(device, steps=6, warmup=2, rays=4096):
+def stage1_measure(device, steps=10, warmup=3, rays=4096):
     """BASELINE configs[1]: stage-1 BEAR train step, 4096 rays x 128 samples (96 inner + 32 outer, it > 5000), 256 march
     steps + 8 secant, geometric-init weights.  Per-kernel numbers from HIP events on the launch stream."""
     import torch
