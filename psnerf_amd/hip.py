@@ -427,6 +427,8 @@ def mlp_infer_pe(desc, packed_w, packed_b, points, pe_octaves, pe_scale, out=Non
     if out is None:
         out = torch.empty(Q, desc.n_out, device=points.device, dtype=torch.float32)
     assert out.is_contiguous() and out.numel() == Q * desc.n_out
+    if Q == 0:
+        return out
     with _Prof('mlp_infer', Q, None if macs_per_row is None else 2.0 * macs_per_row * Q):
         _check(_lib.psn_mlp_infer_pe(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'), _ptr(points, 'points'),
                                      Q, int(pe_octaves), float(pe_scale), out.data_ptr(), _stream()), 'mlp_infer_pe')
