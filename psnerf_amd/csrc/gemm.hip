@@ -393,8 +393,9 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(GroupedArgs gg) {
 // 16-byte aligned, ld % 4 == 0): addresses are clamped into the allocation and out-of-range elements zeroed with
 // selects, so all loads of a k-tile sit in one basic block and the waits on them can be counted (vmcnt(N)) instead of
 // draining the queue -- the condition for keeping two tiles in flight.
+template <int NU>
 __device__ __forceinline__ void fetch_tile256(const float* __restrict__ src, int64_t ld, int n_rows, int k0, int k_end,
-                                              int tid, float4 (&v)[4]) {
+                                              int tid, float4 (&v)[NU]) {
     // clamp to the last 4-column group of the logical matrix: with a 16-byte aligned base and ld % 4 == 0 that group
     // lies inside the row of the underlying buffer even when the operand is a column slice of it
     const int rqc = min((tid & 63) * 4, ((n_rows - 1) >> 2) << 2);
@@ -402,19 +403,20 @@ __device__ __forceinline__ void fetch_tile256(const float* __restrict__ src, int
     // loads of a k-tile cost no vector address arithmetic
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int kc = min(k0 + wave + 4 * u, k_end - 1);
         const float* row = src + (int64_t)kc * ld;
         v[u] = *reinterpret_cast<const float4*>(row + rqc);
     }
 }
 // ... the zeroing happens when the tile is written to LDS (two k-tiles later), never right behind the loads
-__device__ __forceinline__ void mask_tile256(int n_rows, int k0, int k_end, int tid, float4 (&v)[4]) {
+template <int NU>
+__device__ __forceinline__ void mask_tile256(int n_rows, int k0, int k_end, int tid, float4 (&v)[NU]) {
     const int rq = (tid & 63) * 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool c0 = rq + 0 < n_rows, c1 = rq + 1 < n_rows, c2 = rq + 2 < n_rows, c3 = rq + 3 < n_rows;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const bool kin = k0 + wave + 4 * u < k_end;  // wave-uniform
         v[u].x = (kin && c0) ? v[u].x : 0.f;
         v[u].y = (kin && c1) ? v[u].y : 0.f;
@@ -426,16 +428,17 @@ __device__ __forceinline__ void mask_tile256(int n_rows, int k0, int k_end, int 
 // ---- weight gradients with ONE 256 x 256 tile per workgroup ----------------------------------------------------------
 // dW = dZ^T X with M, N <= 256: a workgroup owns the whole output for one K slice, so every operand row is read from
 // L2 exactly once (the 128 x 128 tiles above read each twice and sit at the per-CU streaming limit).  4 waves in a
-// 2 x 2 grid, each 128 x 128 = 4 x 4 MFMA tiles (256 accumulator registers, one wave per SIMD); per 16-row k-tile a
-// wave issues 128 MFMAs (8192 cycles) against 64 ds_read_b32, 8 staged float4 loads and one barrier.
-constexpr int T256 = 256, T256_LD = T256 + 4, T256_BUF = 2 * BK * T256_LD;
+// 2 x 2 grid, each 128 x 128 = 4 x 4 MFMA tiles (256 accumulator registers, one wave per SIMD); per 32-row k-tile a
+// wave issues 256 MFMAs (16384 cycles) against 128 ds_read_b32, 16 staged float4 loads and ONE barrier (16-row tiles:
+// a barrier and an exposed first fragment read per 8192 cycles).
+constexpr int T256 = 256, T256_LD = T256 + 4, TK = 32, T256_BUF = 2 * TK * T256_LD;  // k-tiles of TK = 32 rows: 2 x 66.5 KB of LDS
 // A product that is exactly 256 x 256 (the hidden-layer gradients of the 256-wide networks) takes a fast path: the
 // k-tiles a step stages need no masks except the last two of a K slice (the possibly partial final tile and the
 // overshoot of the prefetch), so the steady-state loop runs mask-free steps and only the last <= 3 steps of a slice
 // the masked ones.  The 32 v_cndmask per k-tile of the general variant cost 4.6 % of the kernel (timing-only build:
 // 129 -> 135 TF incl. the reduction on 16 products at K = 524,288; every vector instruction is paid for in fp32-MFMA time).
 __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs gg) {
-    extern __shared__ __attribute__((aligned(16))) float lds256[];  // 2 x {A[16][260], B[16][260]}
+    extern __shared__ __attribute__((aligned(16))) float lds256[];  // 2 x {A[32][260], B[32][260]}
     int gi = 0;
     while (gi + 1 < gg.n && (int64_t)blockIdx.x >= gg.block_start[gi + 1]) ++gi;
     const GemmArgs g = gg.g[gi];
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
     const int64_t lda = seg2 ? g.lda2 : g.lda, ldb = seg2 ? g.ldb2 : g.ldb;
     const int k_begin = (seg2 ? split - g.seg_splits : split) * g.k_chunk;
     const int k_end = min(g.K, k_begin + g.k_chunk);
-    const int nt = (k_end - k_begin + BK - 1) / BK;
+    const int nt = (k_end - k_begin + TK - 1) / TK;
 
     floatx16 acc[4][4];
 #pragma unroll
@@ -463,22 +466,26 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
     // Two register sets: the operand rows of k-tiles t+2 and t+3 are in flight while tile t is multiplied.  With one
     // workgroup per CU and nothing re-used between workgroups, HBM has to deliver ~2.3 TB/s for the matrix pipe to stay
     // busy; a single 32 KB tile in flight per CU (8 MB on the chip) only sustains about half of that.
-    float4 ra[2][4], rb[2][4];
+    float4 ra[2][8], rb[2][8];
     const bool do_cs = g.colsum != nullptr && !seg2;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #define T_FETCH(T, S)                                                                            \
-    fetch_tile256(Ap, lda, (int)g.M, k_begin + (T) * BK, k_end, tid, ra[S]);                     \
-    fetch_tile256(Bp, ldb, g.N, k_begin + (T) * BK, k_end, tid, rb[S]);
+    fetch_tile256(Ap, lda, (int)g.M, k_begin + (T) * TK, k_end, tid, ra[S]);                     \
+    fetch_tile256(Bp, ldb, g.N, k_begin + (T) * TK, k_end, tid, rb[S]);
 #define T_STORE(BUF, S, T)                                                                       \
-    mask_tile256((int)g.M, k_begin + (T) * BK, k_end, tid, ra[S]);                               \
-    mask_tile256(g.N, k_begin + (T) * BK, k_end, tid, rb[S]);                                    \
+    mask_tile256((int)g.M, k_begin + (T) * TK, k_end, tid, ra[S]);                               \
+    mask_tile256(g.N, k_begin + (T) * TK, k_end, tid, rb[S]);                                    \
     if (do_cs) {                                                                                 \
-        cs.x += (ra[S][0].x + ra[S][1].x) + (ra[S][2].x + ra[S][3].x); cs.y += (ra[S][0].y + ra[S][1].y) + (ra[S][2].y + ra[S][3].y); \
-        cs.z += (ra[S][0].z + ra[S][1].z) + (ra[S][2].z + ra[S][3].z); cs.w += (ra[S][0].w + ra[S][1].w) + (ra[S][2].w + ra[S][3].w); \
+        _Pragma("unroll") for (int u2_ = 0; u2_ < 8; u2_ += 2) {                                 \
+            cs.x += ra[S][u2_].x + ra[S][u2_ + 1].x; cs.y += ra[S][u2_].y + ra[S][u2_ + 1].y;    \
+            cs.z += ra[S][u2_].z + ra[S][u2_ + 1].z; cs.w += ra[S][u2_].w + ra[S][u2_ + 1].w;    \
+        }                                                                                        \
     }                                                                                            \
-    store_tile<false, T256>(lds256 + (BUF) * T256_BUF, tid, ra[S]);                              \
-    store_tile<false, T256>(lds256 + (BUF) * T256_BUF + BK * T256_LD, tid, rb[S]);
-    // Staging item J (0..7) of a step: one float4 of operand A (J < 4, k row wave + 4 J) or B (k row wave + 4 (J - 4)) of
+    _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) {                                           \
+        *reinterpret_cast<float4*>(lds256 + (BUF) * T256_BUF + ((tid >> 6) + 4 * u_) * T256_LD + (tid & 63) * 4) = ra[S][u_]; \
+        *reinterpret_cast<float4*>(lds256 + (BUF) * T256_BUF + TK * T256_LD + ((tid >> 6) + 4 * u_) * T256_LD + (tid & 63) * 4) = rb[S][u_]; \
+    }
+    // Staging item J (0..15) of a step: one float4 of operand A (J < 8, k row wave + 4 J) or B (k row wave + 4 (J - 8)) of
     // tile T+1 is masked, added to the column sums (A; same association as T_STORE), written to the other LDS buffer,
     // and its register receives the same row of tile T+3.  One item rides in the MFMA gaps of each k-pair of T_STEP.
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -486,27 +493,25 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
     const bool am0 = rq_ + 0 < (int)g.M, am1 = rq_ + 1 < (int)g.M, am2 = rq_ + 2 < (int)g.M, am3 = rq_ + 3 < (int)g.M;
     const bool bm0 = rq_ + 0 < g.N, bm1 = rq_ + 1 < g.N, bm2 = rq_ + 2 < g.N, bm3 = rq_ + 3 < g.N;
     const int rqa = min(rq_, (((int)g.M - 1) >> 2) << 2), rqb = min(rq_, ((g.N - 1) >> 2) << 2);
-    float4 cs01 = make_float4(0.f, 0.f, 0.f, 0.f), cs2 = cs01;
+    float4 cs01 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define T_ITEM(BUF, S, T, J, MASKED)                                                             \
     {                                                                                            \
-        constexpr int u_ = (J) & 3;                                                              \
-        constexpr bool isb_ = (J) >= 4;                                                          \
+        constexpr int u_ = (J) & 7;                                                              \
+        constexpr bool isb_ = (J) >= 8;                                                          \
         float4& x_ = isb_ ? rb[S][u_] : ra[S][u_];                                               \
         if (MASKED) {                                                                            \
-            const bool kin_ = k_begin + ((T) + 1) * BK + wave_u + 4 * u_ < k_end;                \
+            const bool kin_ = k_begin + ((T) + 1) * TK + wave_u + 4 * u_ < k_end;                \
             x_.x = (kin_ && (isb_ ? bm0 : am0)) ? x_.x : 0.f;                                    \
             x_.y = (kin_ && (isb_ ? bm1 : am1)) ? x_.y : 0.f;                                    \
             x_.z = (kin_ && (isb_ ? bm2 : am2)) ? x_.z : 0.f;                                    \
             x_.w = (kin_ && (isb_ ? bm3 : am3)) ? x_.w : 0.f;                                    \
         }                                                                                        \
         if (!isb_ && do_cs) {                                                                    \
-            if (u_ == 0) cs01 = x_;                                                              \
-            else if (u_ == 1) { cs01.x += x_.x; cs01.y += x_.y; cs01.z += x_.z; cs01.w += x_.w; } \
-            else if (u_ == 2) cs2 = x_;                                                          \
-            else { cs.x += cs01.x + (cs2.x + x_.x); cs.y += cs01.y + (cs2.y + x_.y); cs.z += cs01.z + (cs2.z + x_.z); cs.w += cs01.w + (cs2.w + x_.w); } \
+            if ((u_ & 1) == 0) cs01 = x_;                                                        \
+            else { cs.x += cs01.x + x_.x; cs.y += cs01.y + x_.y; cs.z += cs01.z + x_.z; cs.w += cs01.w + x_.w; } \
         }                                                                                        \
-        *reinterpret_cast<float4*>(lds256 + (BUF) * T256_BUF + (isb_ ? BK * T256_LD : 0) + (wave_u + 4 * u_) * T256_LD + rq_) = x_; \
-        const int kc_ = min(k_begin + ((T) + 3) * BK + wave_u + 4 * u_, k_end - 1);             \
+        *reinterpret_cast<float4*>(lds256 + (BUF) * T256_BUF + (isb_ ? TK * T256_LD : 0) + (wave_u + 4 * u_) * T256_LD + rq_) = x_; \
+        const int kc_ = min(k_begin + ((T) + 3) * TK + wave_u + 4 * u_, k_end - 1);             \
         x_ = *reinterpret_cast<const float4*>((isb_ ? Bp + (int64_t)kc_ * ldb + rqb : Ap + (int64_t)kc_ * lda + rqa)); \
     }
     // one wave per SIMD: nothing else hides latencies or the staging work, so every k-pair j of a step is its own
@@ -515,18 +520,20 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
     {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         const float* As = lds256 + ((T) & 1) * T256_BUF + wr * 128 + li;                         \
-        const float* Bs = lds256 + ((T) & 1) * T256_BUF + BK * T256_LD + wc * 128 + li;          \
+        const float* Bs = lds256 + ((T) & 1) * T256_BUF + TK * T256_LD + wc * 128 + li;          \
         float pa[2][4], pb[2][4];                                                                \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) pa[0][i] = As[lh * T256_LD + i * 32];      \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) pb[0][n] = Bs[lh * T256_LD + n * 32];      \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         T_PAIR(T, S, 0, MASKED) T_PAIR(T, S, 1, MASKED) T_PAIR(T, S, 2, MASKED) T_PAIR(T, S, 3, MASKED)  \
         T_PAIR(T, S, 4, MASKED) T_PAIR(T, S, 5, MASKED) T_PAIR(T, S, 6, MASKED) T_PAIR(T, S, 7, MASKED)  \
+        T_PAIR(T, S, 8, MASKED) T_PAIR(T, S, 9, MASKED) T_PAIR(T, S, 10, MASKED) T_PAIR(T, S, 11, MASKED)  \
+        T_PAIR(T, S, 12, MASKED) T_PAIR(T, S, 13, MASKED) T_PAIR(T, S, 14, MASKED) T_PAIR(T, S, 15, MASKED)  \
         lds_barrier(); /* NOT __syncthreads(): the operand rows of tile T + 3 stay in flight across the barrier */ \
     }
 #define T_PAIR(T, S, J, MASKED)                                                                  \
     {                                                                                            \
-        if ((J) < 7) {                                                                           \
+        if ((J) < 15) {                                                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) pa[((J) + 1) & 1][i] = As[(2 * (J) + 2 + lh) * T256_LD + i * 32]; \
             _Pragma("unroll") for (int n = 0; n < 4; ++n) pb[((J) + 1) & 1][n] = Bs[(2 * (J) + 2 + lh) * T256_LD + n * 32]; \
         }                                                                                        \
@@ -534,7 +541,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
             _Pragma("unroll") for (int n = 0; n < 4; ++n)                                        \
                 acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(J) & 1][i], pb[(J) & 1][n], acc[i][n], 0, 0, 0); \
         T_ITEM(((T) + 1) & 1, S, T, J, MASKED)                                                   \
-        if ((J) < 7) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                          \
+        if ((J) < 15) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                         \
         _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                       \
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                   \
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                   \
@@ -1049,7 +1056,7 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
         if (want < 1) want = 1;
         if (want > K / 256) want = K / 256 > 0 ? K / 256 : 1;
         kc_big = (int)((K + want - 1) / want);
-        kc_big = ((kc_big + BK - 1) / BK) * BK;
+        kc_big = ((kc_big + TK - 1) / TK) * TK;
         split_big = (int)((K + kc_big - 1) / kc_big);
     }
     // 256 x (<= 64) products (input-block gradients): HBM- / MFMA-co-limited, about one workgroup per CU in total

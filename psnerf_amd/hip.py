@@ -545,7 +545,7 @@ def gemm_tn_grouped(items, split_k=None):
         if n_big:
             want = max(1, min(256 // n_big, K // 256 if K >= 256 else 1))
             kc = -(-K // want)
-            kc = (kc + 15) // 16 * 16
+            kc = (kc + 15) // 16 * 16  # (the kernel rounds its K chunk to 32-row k-tiles: never more slices than this bound)
             split_big = -(-K // kc)
         n_tall = sum((2 if it.get('A2') is not None else 1) for it in chunk if _tn_is_tall(it))
         split_tall = 1
