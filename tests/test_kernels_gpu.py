@@ -477,6 +477,37 @@ def test_mlp_chain_activation_programs(cuda):
     r0 = torch.where(D(h5) > 0, r0, torch.zeros_like(r0))
     assert_close(dumps[0].cpu(), r0, 2e-5, 'act_init + init table')
     assert_close(dumps[1].cpu(), r0 @ D(W[2]).t(), 2e-5, 'second chain layer')
+    # act_init for a row PREFIX only (act_init_rows): the rows behind it start from zero activations -- bit-identical to
+    # the launch that reads a zero-padded tensor
+    for q1 in (1, 63, 64, Q - 1):
+        pad = torch.cat([d(act0)[:q1], torch.zeros(Q - q1, 256, device=cuda)], 0)
+        ref_d = [torch.empty(Q, 256, device=cuda) for _ in range(2)]
+        pk(None, Q, a_div=1, a_mod=Q, init_a_direct=d(init), act_init=pad, mask=[d(h5), None], save=ref_d)
+        got_d = [torch.empty(Q, 256, device=cuda) for _ in range(2)]
+        pk(None, Q, a_div=1, a_mod=Q, init_a_direct=d(init), act_init=d(act0)[:q1].contiguous(), act_init_rows=q1,
+           mask=[d(h5), None], save=got_d)
+        assert torch.equal(got_d[0], ref_d[0]) and torch.equal(got_d[1], ref_d[1]), 'act_init_rows=%d' % q1
+
+
+def test_gemm_tn_grouped_row_prefix_products(cuda):
+    """PsnGemmTnItem.k_rows: a product of the group may sum over a row PREFIX of the pass (operands with fewer rows than the
+    first item) -- on the 256 x 256, the 256 x 64 and the 128 x 128 tile paths, incl. prefixes that leave whole K slices empty."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(21)
+    K = 9000
+    mk = lambda r, c: torch.randn(r, c, generator=g).to(cuda)
+    for k1 in (1, 500, 4097, K - 1):
+        items = [dict(A=mk(K, 256), B=mk(K, 256), colsum=True),              # full pass, 256 x 256 tiles
+                 dict(A=mk(k1, 256), B=mk(k1, 256), colsum=True),            # prefix, 256 x 256 tiles
+                 dict(A=mk(k1, 200), B=mk(k1, 39), colsum=True),             # prefix, 256 x 64 tiles
+                 dict(A=mk(k1, 96), B=mk(k1, 128), colsum=True),             # prefix, 128 x 128 tiles
+                 dict(A=mk(K, 96), B=mk(K, 70))]
+        res = hip.gemm_tn_grouped(items)
+        for i, (it, (C, cs)) in enumerate(zip(items, res)):
+            ref = it['A'].double().t() @ it['B'].double()
+            assert_close(C.double().cpu(), ref.cpu(), 2e-5, 'k_rows=%d item %d' % (k1, i))
+            if cs is not None:
+                assert_close(cs.double().cpu(), it['A'].double().sum(0).cpu(), 2e-5, 'k_rows=%d item %d column sums' % (k1, i))
 
 
 @pytest.mark.parametrize('with_outer,with_noise', [(False, False), (True, True), (False, True)])
