@@ -52,6 +52,10 @@ class Trainer(object):
             self.dp.allreduce_grads(trainable)
         self.optimizer.step()
         net = getattr(self.model, 'model', None)
+        if hasattr(net, 'invalidate_packs'):
+            # the weight packs are keyed on the parameters' version counters, which a fused / capturable optimiser
+            # implementation (torch.optim.Adam(fused=True): verified) does NOT bump: after a step they are stale by definition
+            net.invalidate_packs()
         if hasattr(net, 'prepack'):
             net.prepack(occupancy=True)  # the next step's ray march starts with this pack: queue it behind the backward
         return terms

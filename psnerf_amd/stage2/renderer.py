@@ -200,13 +200,17 @@ class PSNetwork(nn.Module):
                                       skip_at=[conf.get_int('visibility.net.mlp_skip_at')])
 
     # -- helpers ---------------------------------------------------------------------------------
-    def invalidate_packs(self):
+    def invalidate_packs(self, trainable_only=False):
         """Drop every cached weight pack of the model (call after editing parameters through ``.data``: such edits
-        change neither the version counters nor the storage addresses the caches are keyed on)."""
-        self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1
-        for m in self.modules():
-            if isinstance(m, MLP):
-                m.invalidate_packs()
+        change neither the version counters nor the storage addresses the caches are keyed on).  trainable_only: keep the
+        packs of networks without a trainable parameter (what TrainStep calls after every optimiser step: a fused
+        optimiser implementation does not bump version counters either)."""
+        mlps = [m for m in self.modules() if isinstance(m, MLP)]
+        live = [m for m in mlps if not trainable_only or any(q.requires_grad for q in m.parameters())]
+        if live:
+            self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1  # (the model-level epoch keys the visibility packs)
+        for m in live:
+            m.invalidate_packs()
 
     def _apply(self, fn, *a, **k):
         self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1

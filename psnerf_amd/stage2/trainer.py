@@ -166,6 +166,9 @@ class TrainStep(object):
         if self.dp.enabled:
             self.dp.allreduce_grads(trainable)
         self.sg_optimizer.step()
+        if hasattr(self.model, 'invalidate_packs'):
+            # packs are keyed on the parameters' version counters; fused / capturable optimiser implementations do not bump them
+            self.model.invalidate_packs(trainable_only=True)
         if train_light:
             self.light_optimizer.step(rows=l_slt)
         self.cur_iter += 1

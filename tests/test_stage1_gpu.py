@@ -374,3 +374,29 @@ def test_render_and_gradient_matches_the_two_separate_calls(cuda):
     assert pg0.keys() == pg1.keys() and len(pg0) > 20
     for k in pg0:
         assert_close(pg1[k].cpu(), pg0[k].cpu(), 2e-5, 'd ' + k)  # max-normalised: gradient tensors
+
+
+def test_fused_optimizer_does_not_leave_stale_weight_packs(cuda):
+    """torch.optim.Adam(fused=True) updates the parameters WITHOUT bumping their version counters, on which the weight-pack
+    caches are keyed: the trainer invalidates the packs after every optimiser step, so three steps with the fused
+    implementation follow the foreach implementation (same update rule; last-bit differences of the fused arithmetic only)."""
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.synthetic import stage1_batch
+    cfg = stage1_cfg('bunny', **{'training.n_training_points': 256})
+    batch = {k: v.to(cuda) for k, v in stage1_batch(cfg, h=48, w=64, seed=1).items()}
+    g = torch.Generator().manual_seed(4)
+    pix = torch.stack([torch.randint(0, 64, (256,), generator=g).float(), torch.randint(0, 48, (256,), generator=g).float()], -1)[None]
+    losses = {}
+    for fused in (False, True):
+        net = NeuralNetwork(cfg)
+        net.load_state_dict(stage1_state_dict(cfg, seed=5))
+        torch.manual_seed(0)
+        tr = Trainer(Renderer(net, cfg, device=cuda), torch.optim.Adam(net.parameters(), lr=1e-3, fused=fused), cfg, device=cuda)
+        losses[fused] = []
+        for it in range(3):
+            torch.manual_seed(100 + it)
+            losses[fused].append(float(tr.train_step(batch, it=6000, pix=pix.clone())['loss'].detach()))
+    assert losses[False][0] == losses[True][0]
+    assert losses[False][2] != losses[False][0], 'the steps must move the loss for this test to mean anything'
+    for a, b in zip(losses[False], losses[True]):
+        assert abs(a - b) <= 1e-4 * abs(a), (losses[False], losses[True])
