@@ -84,6 +84,10 @@ def _zeros(shape, device):
     z = _ZEROS.get(key)
     if z is None:
         z = _ZEROS[key] = torch.zeros(*key[0], device=device)
+        if z.is_cuda:
+            # shared by every stream from now on (the stage-2 renderer packs on two): the fill must have happened before any of
+            # them reads it -- one host wait per distinct size, ever
+            torch.cuda.current_stream(z.device).synchronize()
     return z
 
 

@@ -230,6 +230,8 @@ class PSNetwork(nn.Module):
             d = 3 + 6 * n_freqs
             c = torch.arange(d, device=device)
             c = self._cols_cache[key] = torch.cat([c, PE_STRIDE + c]) if pair else c
+            if c.is_cuda:
+                torch.cuda.current_stream(c.device).synchronize()  # read on both streams from now on: written before either does
         return c
 
     def _visibility_rows(self, pe_x, light_dirs, fused_ok):
