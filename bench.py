@@ -203,7 +203,7 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=200)  # 5 s of timed steps: long enough for 5-second SMI sampling to see the GPU busy
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--pixels', type=int, default=N_PIXELS, help='pixels per GPU of the weak-scaling headline')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
