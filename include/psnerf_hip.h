@@ -55,6 +55,12 @@ int psn_composite_bwd(const float* alpha, const float* rgb, const float* d_rgb_o
  * rest zero-filled up to out_stride).  `scale` multiplies x first (1/rescale).
  * ---------------------------------------------------------------------- */
 int psn_pe_encode(const float* x, int64_t n, int n_freqs, float scale, float* out, int out_stride, void* stream);
+/* Input table of the stage-1 appearance network, stage1/model/network.py:128-138 (infer_app: cat[p, gamma(view), normal,
+ * features]; gamma from :141-150 on the normalised view direction, rendering.py:185-190): out [n, 64] row r =
+ * [p (3) | v / |v| (3) | sin, cos bands of v / |v| (6 n_freqs) | normal (3) | zeros].  The 256 features are not part of the
+ * table: they are the fused chain's initial activations (psn_mlp_infer act_init). */
+int psn_app_input(const float* p, const float* v, const float* normal, int64_t n, int n_freqs, float* out, void* stream);
+
 /* forward-mode: t [n,3] tangent of x -> d(encoding) [n, out_stride] = J_PE(x) t  (the transpose of
  * psn_pe_encode_bwd; needed for the backward of the gradient sweep) */
 int psn_pe_encode_jvp(const float* x, const float* t, int64_t n, int n_freqs, float scale, float* out, int out_stride,

@@ -95,6 +95,52 @@ extern "C" int psn_pe_encode(const float* x, int64_t n, int n_freqs, float scale
     return PSN_OK;
 }
 
+// Input table of the stage-1 appearance network (stage1/model/network.py:128-138: cat[p, gamma(v / |v|), n, features] -- the
+// features enter the fused chain as initial activations, the rest as this 64-column table): row r = [p (3) | v^ (3) |
+// sin / cos bands of v^ (6 n_freqs) | n (3) | 0 ...] with v^ = v / |v|, in ONE launch instead of a zero fill, three strided
+// copies, the norm / division kernels and the encoding.  Same expressions as pe_encode_kernel for the bands.
+__global__ __launch_bounds__(256) void app_input_kernel(const float* __restrict__ p, const float* __restrict__ v,
+                                                        const float* __restrict__ nrm, int64_t n, int n_freqs,
+                                                        float* __restrict__ out) {
+    const int64_t total = n * 64;
+    const int dv = 3 + 6 * n_freqs;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e >> 6;
+        const int col = (int)(e & 63);
+        float o = 0.0f;
+        if (col < 3) {
+            o = p[row * 3 + col];
+        } else if (col < 3 + dv) {
+            const float vx = v[row * 3 + 0], vy = v[row * 3 + 1], vz = v[row * 3 + 2];
+            const float len = sqrtf(vx * vx + vy * vy + vz * vz);  // torch.norm(v, dim=-1)
+            const int q = col - 3;
+            if (q < 3) {
+                o = (q == 0 ? vx : (q == 1 ? vy : vz)) / len;
+            } else {
+                const int f = (q - 3) / 6, w = (q - 3) - 6 * f;
+                const int c = w % 3;
+                const float arg = ldexpf((c == 0 ? vx : (c == 1 ? vy : vz)) / len, f);
+                o = (w >= 3) ? cosf(arg) : sinf(arg);
+            }
+        } else if (col < 6 + dv) {
+            o = nrm[row * 3 + (col - 3 - dv)];
+        }
+        out[e] = o;
+    }
+}
+
+extern "C" int psn_app_input(const float* p, const float* v, const float* normal, int64_t n, int n_freqs, float* out, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(p && v && normal && out, "app_input: null pointer");
+    PSN_CHECK_ARG(n_freqs >= 0 && 9 + 6 * n_freqs <= 64, "app_input: n_freqs=%d (3 + (3 + 6 n_freqs) + 3 columns must fit 64)", n_freqs);
+    if (n <= 0) return PSN_OK;
+    int64_t blocks = (n * 64 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(app_input_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, v, normal, n, n_freqs, out);
+    PSN_CHECK_LAUNCH("app_input");
+    return PSN_OK;
+}
+
 extern "C" int psn_pe_encode_jvp(const float* x, const float* t, int64_t n, int n_freqs, float scale, float* out,
                                  int out_stride, void* stream) {
     using namespace psn;

@@ -84,6 +84,7 @@ SIGNATURES = {
     'psn_composite_bwd': (i32, [c_f, c_f, c_f, c_f, i64, i32, i32, c_f, c_f, c_f]),
     'psn_pe_encode': (i32, [c_f, i64, i32, f32, c_f, i32, c_f]),
     'psn_pe_encode_bwd': (i32, [c_f, c_f, i64, i32, f32, i32, c_f, i32, c_f, c_f]),
+    'psn_app_input': (i32, [c_f, c_f, c_f, i64, i32, c_f, c_f]),
     'psn_pe_encode_jvp': (i32, [c_f, c_f, i64, i32, f32, c_f, i32, c_f]),
     'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, c_f, i64,
                        i32, c_f, c_f, c_f]),
@@ -218,6 +219,18 @@ def pe_encode(x, n_freqs, out_stride=None, scale=1.0):
     out = torch.empty(n, out_stride, device=x.device, dtype=torch.float32)
     _check(_lib.psn_pe_encode(_ptr(x, 'x'), n, n_freqs, float(scale), _ptr(out, 'out'), out_stride, _stream()),
            'pe_encode')
+    return out
+
+
+def app_input(p, v, normal, n_freqs):
+    """[Q, 64] input table of the stage-1 appearance chain: [p | gamma(v / |v|) | normal | 0] (psn_app_input)."""
+    Q = p.shape[0]
+    assert p.shape == v.shape == normal.shape == (Q, 3)
+    out = torch.empty(Q, 64, device=p.device, dtype=torch.float32)
+    p, v, normal = p.contiguous(), v.contiguous(), normal.contiguous()
+    if Q:
+        _check(_lib.psn_app_input(_ptr(p, 'p'), _ptr(v, 'v'), _ptr(normal, 'normal'), Q, int(n_freqs), out.data_ptr(), _stream()),
+               'app_input')
     return out
 
 

@@ -224,18 +224,18 @@ class NeuralNetwork(nn.Module):
             self._app_key = key
         return self._app_packed
 
-    def _app_parts(self, points, v_pe, normal, feat):
-        """Colour from (point, view encoding, normal, geometry features) = infer_app without the 289-wide concat:
-        256-wide networks run as fused chains (ops.AppNetFused)."""
+    def _app_parts(self, points, view, normal, feat):
+        """Colour from (point, raw view direction, normal, geometry features) = infer_app (network.py:128-138) on the
+        normalised, encoded view direction without the 289-wide concat: 256-wide networks run as fused chains
+        (ops.AppNetFused) whose 64-column input table [p | gamma(v / |v|) | n] is written by one launch (psn_app_input)."""
         d_x = 3 + self.d_view + 3
         Ws, bs = self._app_params()
         if not (self.USE_FUSED_CHAINS and self.feat_size == 256 and d_x <= 64 and Ws[0].shape[0] == 256
-                and all(w.shape == (256, 256) for w in Ws[1:-1]) and self.n_app <= 10):
+                and all(w.shape == (256, 256) for w in Ws[1:-1]) and self.n_app <= 10 and points.is_cuda):
+            v = view / torch.norm(view, dim=-1, keepdim=True)
+            v_pe = ops.positional_encoding(v, self.octaves_pe_views)
             return self._app(torch.cat([points, v_pe, normal, feat], dim=-1))
-        x = torch.zeros(points.shape[0], 64, device=points.device)
-        x[:, :3] = points
-        x[:, 3:3 + self.d_view] = v_pe
-        x[:, d_x - 3:d_x] = normal.detach()
+        x = hip.app_input(points.detach(), view.detach(), normal.detach(), self.octaves_pe_views)
         params = []
         for W, b in zip(Ws, bs):
             params += [W, b]
@@ -268,10 +268,7 @@ class NeuralNetwork(nn.Module):
             return torch.sigmoid(logit * -10.0).reshape(*shp, 1)
         if ray_d is not None:
             logit, feat, grad = self._geo_parts(flat, True)
-            v = ray_d.reshape(-1, 3)
-            v = v / torch.norm(v, dim=-1, keepdim=True)
-            v_pe = ops.positional_encoding(v, self.octaves_pe_views)
-            rgb = self._app_parts(flat, v_pe, grad, feat).reshape(*shp, 3)
+            rgb = self._app_parts(flat, ray_d.reshape(-1, 3), grad, feat).reshape(*shp, 3)
             if return_addocc:
                 return rgb, torch.sigmoid(logit * -10.0).reshape(*shp, 1)
             return rgb
@@ -298,10 +295,7 @@ class NeuralNetwork(nn.Module):
         logit, feat, grad = self._geo_call(torch.cat([flat, ex], dim=0), True, params, self._geo_chains(params), feat_rows=q1)
         grad_r, grad_x = ops.SplitRows.apply(grad, q1)
         logit_r, _ = ops.SplitRows.apply(logit, q1)
-        v = ray_d.reshape(-1, 3)
-        v = v / torch.norm(v, dim=-1, keepdim=True)
-        v_pe = ops.positional_encoding(v, self.octaves_pe_views)
-        rgb = self._app_parts(flat, v_pe, grad_r, feat).reshape(*shp, 3)
+        rgb = self._app_parts(flat, ray_d.reshape(-1, 3), grad_r, feat).reshape(*shp, 3)
         return rgb, torch.sigmoid(logit_r * -10.0).reshape(*shp, 1), grad_x.unsqueeze(1)
 
     def _hidden_is_256(self):

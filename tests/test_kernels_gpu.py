@@ -672,3 +672,22 @@ def test_row_adam_kernel_matches_sparse_adam(cuda):
         assert_close(a1.weight.detach().cpu(), ref1.weight.detach(), 1e-6, 'intensity table it%d' % it, atol=1e-7)
     st = o_a.state[a3.weight]
     assert int(st['step']) == 5 and set(st.keys()) == {'step', 'exp_avg', 'exp_avg_sq'}
+
+
+@pytest.mark.parametrize('Q', [1, 257, 40000])
+def test_app_input_table(cuda, Q):
+    """psn_app_input == the torch formulation of the appearance network's input (network.py:128-138, 141-150): columns
+    [p | gamma(v / |v|) | normal | 0], bands bit-identical to psn_pe_encode of the normalised direction."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(Q)
+    p = torch.randn(Q, 3, generator=g).to(cuda)
+    v = (torch.randn(Q, 3, generator=g) * 3.0).to(cuda)
+    n = torch.randn(Q, 3, generator=g).to(cuda)
+    x = hip.app_input(p, v, n, 4)
+    vn = v / torch.norm(v, dim=-1, keepdim=True)
+    pe = hip.pe_encode(vn.contiguous(), 4, 27, 1.0)
+    assert x.shape == (Q, 64)
+    assert torch.equal(x[:, :3], p) and torch.equal(x[:, 30:33], n) and torch.equal(x[:, 33:], torch.zeros(Q, 31, device=cuda))
+    assert_close(x[:, 3:30].cpu(), pe.cpu(), 1e-6, 'view encoding', atol=1e-6)  # |v| by sqrtf(x^2 + y^2 + z^2) vs torch.norm: last bits
+    ref = torch.cat([vn, *[f(vn * 2 ** k) for k in range(4) for f in (torch.sin, torch.cos)]], dim=-1)
+    assert_close(x[:, 3:30].double().cpu(), ref.double().cpu(), 1e-5, 'view encoding vs torch', atol=1e-6)
