@@ -95,6 +95,7 @@ extern "C" int psn_pe_encode(const float* x, int64_t n, int n_freqs, float scale
     return PSN_OK;
 }
 
+namespace psn {
 // Input table of the stage-1 appearance network (stage1/model/network.py:128-138: cat[p, gamma(v / |v|), n, features] -- the
 // features enter the fused chain as initial activations, the rest as this 64-column table): row r = [p (3) | v^ (3) |
 // sin / cos bands of v^ (6 n_freqs) | n (3) | 0 ...] with v^ = v / |v|, in ONE launch instead of a zero fill, three strided
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void app_input_kernel(const float* __restrict_
         out[e] = o;
     }
 }
+}  // namespace psn
 
 extern "C" int psn_app_input(const float* p, const float* v, const float* normal, int64_t n, int n_freqs, float* out, void* stream) {
     using namespace psn;

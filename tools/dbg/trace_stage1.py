@@ -55,3 +55,11 @@ if os.environ.get('NONPSN') == '1':
             a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += d
     for k, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
         print('%4d  %8.1f us  %s' % (c, d, k))
+if os.environ.get('NONPSN_LIST') == '1':
+    prev = ''
+    for e in evs:
+        d = e.time_range.end - e.time_range.start
+        if 'psn::' in e.name:
+            prev = e.name[:40]
+        elif d >= 9:
+            print('%8.1f us  after %-40s %s' % (d, prev, e.name[:120]))
