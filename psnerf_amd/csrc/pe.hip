@@ -103,30 +103,40 @@ namespace psn {
 __global__ __launch_bounds__(256) void app_input_kernel(const float* __restrict__ p, const float* __restrict__ v,
                                                         const float* __restrict__ nrm, int64_t n, int n_freqs,
                                                         float* __restrict__ out) {
-    const int64_t total = n * 64;
+    const int64_t total = n * 16;  // one thread per four consecutive columns (one 16-byte store)
     const int dv = 3 + 6 * n_freqs;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t row = e >> 6;
-        const int col = (int)(e & 63);
-        float o = 0.0f;
-        if (col < 3) {
-            o = p[row * 3 + col];
-        } else if (col < 3 + dv) {
-            const float vx = v[row * 3 + 0], vy = v[row * 3 + 1], vz = v[row * 3 + 2];
-            const float len = sqrtf(vx * vx + vy * vy + vz * vz);  // torch.norm(v, dim=-1)
-            const int q = col - 3;
-            if (q < 3) {
-                o = (q == 0 ? vx : (q == 1 ? vy : vz)) / len;
-            } else {
-                const int f = (q - 3) / 6, w = (q - 3) - 6 * f;
-                const int c = w % 3;
-                const float arg = ldexpf((c == 0 ? vx : (c == 1 ? vy : vz)) / len, f);
-                o = (w >= 3) ? cosf(arg) : sinf(arg);
+        const int64_t row = e >> 4;
+        const int c0 = (int)(e & 15) * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c0 < 6 + dv) {
+            float vx = 0.f, vy = 0.f, vz = 0.f, len = 1.f;
+            if (c0 + 3 >= 3 && c0 < 3 + dv) {
+                vx = v[row * 3 + 0]; vy = v[row * 3 + 1]; vz = v[row * 3 + 2];
+                len = sqrtf(vx * vx + vy * vy + vz * vz);  // torch.norm(v, dim=-1)
             }
-        } else if (col < 6 + dv) {
-            o = nrm[row * 3 + (col - 3 - dv)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = c0 + i;
+                if (col < 3) {
+                    o[i] = p[row * 3 + col];
+                } else if (col < 3 + dv) {
+                    const int q = col - 3;
+                    if (q < 3) {
+                        o[i] = (q == 0 ? vx : (q == 1 ? vy : vz)) / len;
+                    } else {
+                        const int f = (q - 3) / 6, w = (q - 3) - 6 * f;
+                        const int c = w % 3;
+                        float sn, cs;  // one range reduction for both: the same bits as sinf / cosf (mlp_infer.hip, SRC == 2)
+                        sincosf(ldexpf((c == 0 ? vx : (c == 1 ? vy : vz)) / len, f), &sn, &cs);
+                        o[i] = (w >= 3) ? cs : sn;
+                    }
+                } else if (col < 6 + dv) {
+                    o[i] = nrm[row * 3 + (col - 3 - dv)];
+                }
+            }
         }
-        out[e] = o;
+        *reinterpret_cast<float4*>(out + row * 64 + c0) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 }  // namespace psn
@@ -136,7 +146,7 @@ extern "C" int psn_app_input(const float* p, const float* v, const float* normal
     PSN_CHECK_ARG(p && v && normal && out, "app_input: null pointer");
     PSN_CHECK_ARG(n_freqs >= 0 && 9 + 6 * n_freqs <= 64, "app_input: n_freqs=%d (3 + (3 + 6 n_freqs) + 3 columns must fit 64)", n_freqs);
     if (n <= 0) return PSN_OK;
-    int64_t blocks = (n * 64 + 255) / 256;
+    int64_t blocks = (n * 16 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(app_input_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, v, normal, n, n_freqs, out);
     PSN_CHECK_LAUNCH("app_input");
