@@ -52,6 +52,46 @@ __global__ __launch_bounds__(256) void pe_encode_jvp_kernel(const float* __restr
     }
 }
 
+// The 64-column table forms of the two kernels above (the width every fused engine reads): one thread per four consecutive
+// columns -- the point is loaded once per thread, sincosf shares the range reduction of the band's sin and cos (the same bits
+// as sinf / cosf: tests compare the table path with the in-kernel encoding of mlp_infer.hip bit for bit), 16-byte stores.
+template <bool JVP>
+__global__ __launch_bounds__(256) void pe_encode64_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t n,
+                                                          int n_freqs, float scale, float* __restrict__ out) {
+    const int64_t total = n * 16;
+    const int width = 3 + 6 * n_freqs;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e >> 4;
+        const int c0 = (int)(e & 15) * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c0 < width) {
+            const float x0 = x[row * 3 + 0] * scale, x1 = x[row * 3 + 1] * scale, x2 = x[row * 3 + 2] * scale;
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+            if constexpr (JVP) { t0 = t[row * 3 + 0] * scale; t1 = t[row * 3 + 1] * scale; t2 = t[row * 3 + 2] * scale; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = c0 + i;
+                if (col < 3) {
+                    o[i] = JVP ? (col == 0 ? t0 : (col == 1 ? t1 : t2)) : (col == 0 ? x0 : (col == 1 ? x1 : x2));
+                } else if (col < width) {
+                    const int q = col - 3;
+                    const int f = q / 6, w = q - 6 * f;
+                    const int c = w % 3;
+                    float sn, cs;
+                    sincosf(ldexpf(c == 0 ? x0 : (c == 1 ? x1 : x2), f), &sn, &cs);
+                    if constexpr (JVP) {
+                        const float d = (w >= 3) ? -sn : cs;
+                        o[i] = ldexpf(d * (c == 0 ? t0 : (c == 1 ? t1 : t2)), f);
+                    } else {
+                        o[i] = (w >= 3) ? cs : sn;
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(out + row * 64 + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // d_out2 (or nullptr): a second gradient of the encoding that is ADDED column by column before the chain rule (the sweep
 // of the stage-1 geometry network delivers d logit / d pe in two pieces: the layer-0 columns of one dump and the skip
 // layer's columns of another; reading both here saves a [Q, 64] copy and a [Q, 39] add per call)
@@ -90,7 +130,13 @@ extern "C" int psn_pe_encode(const float* x, int64_t n, int n_freqs, float scale
     int64_t total = n * out_stride;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(pe_encode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, n_freqs, scale, out, out_stride);
+    if (out_stride == 64 && (((uintptr_t)out) & 15) == 0) {
+        int64_t b4 = (n * 16 + 255) / 256;
+        if (b4 > 256 * 32) b4 = 256 * 32;
+        hipLaunchKernelGGL(pe_encode64_kernel<false>, dim3((unsigned)b4), dim3(256), 0, (hipStream_t)stream, x, nullptr, n, n_freqs, scale, out);
+    } else {
+        hipLaunchKernelGGL(pe_encode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, n_freqs, scale, out, out_stride);
+    }
     PSN_CHECK_LAUNCH("pe_encode");
     return PSN_OK;
 }
@@ -162,7 +208,13 @@ extern "C" int psn_pe_encode_jvp(const float* x, const float* t, int64_t n, int 
     int64_t total = n * out_stride;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(pe_encode_jvp_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, t, n, n_freqs, scale, out, out_stride);
+    if (out_stride == 64 && (((uintptr_t)out) & 15) == 0) {
+        int64_t b4 = (n * 16 + 255) / 256;
+        if (b4 > 256 * 32) b4 = 256 * 32;
+        hipLaunchKernelGGL(pe_encode64_kernel<true>, dim3((unsigned)b4), dim3(256), 0, (hipStream_t)stream, x, t, n, n_freqs, scale, out);
+    } else {
+        hipLaunchKernelGGL(pe_encode_jvp_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, t, n, n_freqs, scale, out, out_stride);
+    }
     PSN_CHECK_LAUNCH("pe_encode_jvp");
     return PSN_OK;
 }
