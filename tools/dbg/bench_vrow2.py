@@ -1,4 +1,6 @@
-"""V-row backward chain: chain engine (mlp_infer_kernel<true,16>) vs the two-row-groups kernel (relu_chain2_kernel)."""
+"""V-row backward chain: chain engine (mlp_infer_kernel<true,16>) vs the two-row-groups prototype (relu_chain2_kernel).
+Needs tools/dbg/experiments/relu_chain2_two_row_groups.patch applied to csrc/mlp_infer.hip (PSN_RELU_CHAIN2=0/1 selects the
+kernel); without it both columns time the chain engine."""
 import os, sys
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 import torch
