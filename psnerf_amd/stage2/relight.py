@@ -2,16 +2,20 @@
 
 Reference: stage2/eval.py:99-112 (16 x 32 lat-long light grid), :173-231 (light batches x pixel chunks,
 sum over lights WITHOUT solid-angle weights, clip), stage2/utils/eval_utils.py:61-99 (gen_light_xyz),
-stage2/utils/general.py:23-52 (split_input / merge_output).  Environment maps are taken as arrays
-([h, 2h, 3] float, already resized); an .npy path is accepted (cv2 / OpenEXR are not dependencies).
+stage2/utils/general.py:23-52 (split_input / merge_output).  Environment maps: arrays ([h, 2h, 3] float), .npy files, or the
+reference's Radiance .hdr / OpenEXR .exr files through the readers of envmap_io.py (cv2 / OpenEXR are not dependencies).
 
 On MI355X the 1024-pixel chunking of the reference is unnecessary (activations never reach HBM in the fused
 visibility kernel), so ``pixel_chunk`` defaults to the whole image; the helpers keep the reference's
 signatures for callers that still split.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
+
+from . import envmap_io
 
 
 def gen_light_xyz(envmap_h, envmap_w, envmap_radius=1e2):
@@ -29,8 +33,21 @@ def gen_light_xyz(envmap_h, envmap_w, envmap_radius=1e2):
 
 
 def load_light(path_or_array, light_h=None):
-    """[h, 2h, 3] float32 environment map from an array or .npy file; block-averaged down to light_h rows."""
-    arr = np.load(path_or_array) if isinstance(path_or_array, str) else np.asarray(path_or_array)
+    """[h, 2h, 3] float32 RGB environment map from an array, a .npy file or the reference's own formats -- Radiance .hdr and
+    OpenEXR .exr (eval_utils.py:11-38; decoded by stage2/envmap_io.py, no cv2) --, resized to light_h rows with the bilinear
+    half-pixel rule of cv2.resize(..., INTER_LINEAR) (eval_utils.py:19)."""
+    if isinstance(path_or_array, str):
+        ext = os.path.basename(path_or_array).split('.')[-1].lower()
+        if ext == 'npy':
+            arr = np.load(path_or_array)
+        elif ext == 'exr':
+            arr = envmap_io.read_exr(path_or_array)
+        elif ext == 'hdr':
+            arr = envmap_io.read_hdr(path_or_array)
+        else:
+            raise NotImplementedError(ext)  # eval_utils.py:17
+    else:
+        arr = np.asarray(path_or_array)
     arr = arr.astype(np.float32)
     if light_h and arr.shape[0] != light_h:
         t = torch.from_numpy(arr).permute(2, 0, 1)[None]
