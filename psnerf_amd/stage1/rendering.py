@@ -10,8 +10,9 @@ profiles, stratified jitter and sample points are psn_sample_points launches.  C
 a handful of elementwise torch ops on [N, 3] tensors.  The ray march never synchronises with the host; the training
 forward does not either when the Trainer selects Renderer._unisurf_sync_free.
 
-All random draws can be injected (``noise={'miss','hit','nbr'}``) for parity tests; by default they are
-drawn on the device.
+All random draws can be injected for parity tests -- ``noise={'miss','hit','nbr'}`` (group-sized tables in the reference's
+draw order: the reference-shaped path) or ``noise={'full': [N, S], 'nbr_full': [N, 3]}`` (one row per RAY: the sync-free
+training forward, see sync_free_noise_for_reference) --; by default they are drawn on the device.
 """
 import numpy as np
 import torch
@@ -49,6 +50,26 @@ def sphere_intersection(cam_loc, ray_dirs, r=1.0):
 
 def finite_mask(t):
     return (t.abs() != np.inf) & ~torch.isnan(t)
+
+
+def is_per_ray_noise(noise):
+    """True when the injected draws (if any) are the per-ray tables of the sync-free forward."""
+    return not noise or all(k in ('full', 'nbr_full') for k in noise)
+
+
+def sync_free_noise_for_reference(noise, hit_mask):
+    """Per-ray tables {'full': [N, S], 'nbr_full': [N, 3]} -> the group-sized tables of the reference's draw order
+    (rendering.py:139 miss rays, :163 hit rays, :204 neighbour offsets of the hit points), i.e. the draws that make the
+    reference-shaped path / the oracle use the same number for the same (ray, sample) as the sync-free forward."""
+    hit = hit_mask.reshape(-1).bool()
+    out = {}
+    if noise.get('full') is not None:
+        full = noise['full'].reshape(hit.shape[0], -1)
+        out['miss'] = full[~hit].unsqueeze(0)
+        out['hit'] = full[hit].unsqueeze(0)
+    if noise.get('nbr_full') is not None:
+        out['nbr'] = noise['nbr_full'][hit]
+    return out
 
 
 class Renderer(nn.Module):
@@ -247,13 +268,15 @@ class Renderer(nn.Module):
 
         cam, rays, dists, obj_mask, points = self._surface(pixels, camera_mat, world_mat, cfg['ray_marching_steps'])
         far = self._last_far  # = sphere_intersection(cam, rays, r)[..., 1], already computed for the sweep
-        if self.sync_free and not eval_ and not noise and near > 0 and pixels.is_cuda:
-            return self._unisurf_sync_free(cam, rays, dists, obj_mask, points, far, it, add_noise)
+        if self.sync_free and not eval_ and is_per_ray_noise(noise) and near > 0 and pixels.is_cuda:
+            return self._unisurf_sync_free(cam, rays, dists, obj_mask, points, far, it, add_noise, noise)
 
         # hit / miss ray lists ONCE (two nonzero() = the data-dependent host synchronisations of this function); every
         # gather / scatter below is an index op with them instead of a boolean mask (each of which would sync again)
         hit_idx = obj_mask.nonzero(as_tuple=True)[0]
         miss_idx = (~obj_mask).nonzero(as_tuple=True)[0]
+        if 'full' in noise or 'nbr_full' in noise:  # per-ray tables (the sync-free forward's form) -> group-sized tables
+            noise = dict(noise, **sync_free_noise_for_reference(noise, obj_mask))
         delta = float(torch.max(cfg['interval_start'] * torch.exp(-1 * cfg['interval_decay'] * it * torch.ones(1)),
                                 cfg['interval_end'] * torch.ones(1)))  # fp32 like rendering.py:116-117
         if near > 0:
@@ -319,7 +342,7 @@ class Renderer(nn.Module):
 
     sync_free = False  # set by the Trainer: training forward without host synchronisation (see _unisurf_sync_free)
 
-    def _unisurf_sync_free(self, cam, rays, dists, obj_mask, points, far, it, add_noise):
+    def _unisurf_sync_free(self, cam, rays, dists, obj_mask, points, far, it, add_noise, noise=None):
         """The training forward of unisurf() (rendering.py:110-224) without a single host synchronisation.  The
         reference-shaped path above needs the hit / miss ray LISTS (two nonzero() calls) because it samples the two
         groups separately, evaluates the surface normals on the compacted hit points and returns a compact
@@ -327,8 +350,11 @@ class Renderer(nn.Module):
         (psn_sample_points_flagged), the normals are evaluated for ALL rays (2 N instead of 2 N_hit points next to N S
         render samples: +1 %) and masked, and the smoothness term is returned as ``diff_norm_full [N]`` + ``mask_pred``
         for a masked sum over a device-resident count (Loss).  Same arithmetic per ray; the random draws have the
-        reference's distribution but not its stream order (group-sized draws need the group sizes on the host) --
-        parity tests inject their noise and therefore take the reference-shaped path."""
+        reference's distribution but not its stream order (group-sized draws need the group sizes on the host).
+        ``noise={'full': [N, S] stratified-jitter table, 'nbr_full': [N, 3] neighbour offsets}`` injects the draws, one row
+        per ray; ``sync_free_noise_for_reference`` turns such tables into the group-sized tables ('miss', 'hit', 'nbr') that
+        make the reference / the oracle draw the same numbers for the same rays."""
+        noise = noise or {}
         cfg = self.cfg
         dev = cam.device
         N = cam.shape[0]
@@ -337,7 +363,15 @@ class Renderer(nn.Module):
         delta = float(torch.max(cfg['interval_start'] * torch.exp(-1 * cfg['interval_decay'] * it * torch.ones(1)),
                                 cfg['interval_end'] * torch.ones(1)))
         full_steps = steps + steps_out if it > 5000 else steps  # near > 0: (dnp != 0).all() holds (rendering.py:124)
-        nz = torch.rand(N * full_steps, device=dev) if add_noise else None
+        nz = None
+        if add_noise:
+            nz = noise.get('full')
+            if nz is None:
+                nz = torch.rand(N * full_steps, device=dev)
+            else:
+                if nz.numel() != N * full_steps:
+                    raise ValueError("noise['full'] must hold N x S = %d x %d values, got %s" % (N, full_steps, tuple(nz.shape)))
+                nz = nz.to(dev, torch.float32).reshape(-1).contiguous()
         p_fg = torch.empty(N, full_steps, 3, device=dev)
         flags = obj_mask.contiguous()
         if full_steps != steps:
@@ -348,7 +382,12 @@ class Renderer(nn.Module):
                                       self._u(full_steps, dev), noise=nz)
         p_fg = p_fg.reshape(-1, 3)
         view = (-1 * rays).unsqueeze(-2).expand(-1, full_steps, -1).reshape(-1, 3)
-        pp = torch.cat([points, points + (torch.rand_like(points) - 0.5) * 0.01], dim=0)  # every ray; masked below
+        nbr = noise.get('nbr_full')
+        if nbr is None:
+            nbr = torch.rand_like(points)
+        elif tuple(nbr.shape) != tuple(points.shape):
+            raise ValueError("noise['nbr_full'] must be [N, 3] = %s, got %s" % (tuple(points.shape), tuple(nbr.shape)))
+        pp = torch.cat([points, points + (nbr.to(dev) - 0.5) * 0.01], dim=0)  # every ray; masked below
         if hasattr(self.model, 'render_and_gradient'):
             # the 2 N normal points ride behind the N S render samples through the geometry network (one set of launches)
             rgb, alpha, g = self.model.render_and_gradient(p_fg, view, pp)

@@ -6,6 +6,7 @@ import torch
 
 from ..dist import DataParallel
 from .losses import Loss
+from .rendering import is_per_ray_noise
 
 
 def gather_pixels(img, pix):
@@ -23,6 +24,7 @@ class Trainer(object):
         cfg = cfg_all['training']
         self.model, self.optimizer, self.device, self.cfg = model, optimizer, device, cfg
         self.n_training_points = cfg['n_training_points']
+        self.n_eval_points = cfg['n_training_points']  # training.py:27 reads the same key
         self.normal_loss = cfg.get('normal_loss', False)
         self.normal_after = cfg.get('normal_after', -1)
         self.angle = cfg.get('normal_angle', None)
@@ -82,9 +84,22 @@ class Trainer(object):
         return out
 
     def compute_loss(self, data, eval_mode=False, it=None, pix=None, noise=None):
+        """training.py:141-198.  ``eval_mode`` renders with ``eval_=True`` (no neighbour points, ``diff_norm`` None, hence
+        no smoothness term) on ``n_eval_points`` pixels.  ``pix`` / ``noise`` inject the random draws (tests)."""
         dev = self.device
         img = data['img'].to(dev)
         B, _, h, w = img.shape
+        n_points = self.n_eval_points if eval_mode else self.n_training_points
+        m_in = data.get('img.mask')
+        assert (m_in is None or (h, w) == tuple(m_in.shape[-2:])) and n_points > 0  # training.py:156
+        if pix is None and n_points >= h * w:
+            # training.py:159-165 (whole image: int64 x-major arange_pixels, masks reshaped row-major).  The reference cannot
+            # complete this branch: after the forward pass get_tensor_values (common.py:195) hands the int64 pixel grid to
+            # grid_sample, which raises.  Same exception type and message here, before the forward instead of after it.
+            raise RuntimeError('expected scalar type Float but found Long (n_training_points >= h*w selects the full-image '
+                               'branch of compute_loss, stage1/model/training.py:159-165, whose int64 arange_pixels grid the '
+                               'reference passes to grid_sample, common.py:195; render whole images through '
+                               'handoff.arange_pixels chunks as training.py:74-90 / shape_extract.py:112-139 do)')
         def on_dev(key):  # a missing mask is all ones, built ON the device (a host default would be 1.25 MB uploaded per step)
             t = data.get(key)
             return torch.ones(B, h, w, device=dev) if t is None else t.to(dev)
@@ -95,7 +110,7 @@ class Trainer(object):
         norm_mask = data.get('img.norm_mask').unsqueeze(1).to(dev) if self.normal_loss else None
         mask_valid = on_dev('img.mask_valid').unsqueeze(1)
         if pix is None:  # stage1/model/common.py:32-36: x then y, CPU randint
-            n = int(self.n_training_points)
+            n = int(n_points)
             px = torch.randint(0, w, size=(B, n, 1)).float()
             py = torch.randint(0, h, size=(B, n, 1)).float()
             pix = torch.cat([px, py], dim=-1)
@@ -121,7 +136,7 @@ class Trainer(object):
             Rf = world_mat[:, :3, :3] * flip  # rotation as broadcast products (no library GEMM on the path)
             normal_gt = (normal_gt[..., 0:1] * Rf[:, None, :, 0] + normal_gt[..., 1:2] * Rf[:, None, :, 1]
                          + normal_gt[..., 2:3] * Rf[:, None, :, 2])
-        sync_free = (self.sync_free and not noise and not eval_mode and self.rendering_technique == 'unisurf'
+        sync_free = (self.sync_free and is_per_ray_noise(noise) and not eval_mode and self.rendering_technique == 'unisurf'
                      and hasattr(self.model, '_unisurf_sync_free') and pix.is_cuda)
         if hasattr(self.model, 'sync_free'):
             self.model.sync_free = sync_free

@@ -147,3 +147,20 @@ def assert_outputs_close(key, a, b, rtol=1e-4, prefix=''):
     if atol == 'max':
         atol = rtol * float(np.abs(np.asarray(b, dtype=np.float64)).max())
     assert_close(a, b, rtol, prefix + key, atol=atol, outliers=STAGE2_OUTLIERS.get(key))
+
+
+COMPUTE_LOSS_CASES = {'train': {}, 'eval': {}, 'mask': {'training.mask_loss': True, 'training.normal_after': 2000}}
+
+
+def compute_loss_case(g, tag):
+    """(cfg, data dict, pix, noise, it, eval_mode) of one case of tests/golden/stage1_compute_loss.npz -- the synthetic data
+    dict is regenerated from its seeds exactly as tools/gen_golden.py built it for the reference's own Trainer."""
+    from psnerf_amd.synthetic import stage1_batch
+    cfg = stage1_cfg('bunny', **dict({'training.n_training_points': int(g['n_points'])}, **COMPUTE_LOSS_CASES[tag]))
+    hb, wb = (int(v) for v in g['hw'])
+    data = stage1_batch(cfg, h=hb, w=wb, seed=int(g['batch_seed']))
+    data['img.mask_valid'] = (torch.rand(1, hb, wb, generator=torch.Generator().manual_seed(int(g['mask_valid_seed']))) > 0.1).float()
+    if tag == 'mask':
+        data['img.mask'] = torch.from_numpy(g['mask_img'].astype(np.float32))[None]
+    noise = {k: torch.from_numpy(g['%s_nz_%s' % (tag, k)]) for k in ('miss', 'hit', 'nbr') if '%s_nz_%s' % (tag, k) in g.files}
+    return cfg, data, torch.from_numpy(g[tag + '_pix']), noise, int(g[tag + '_it']), bool(g[tag + '_eval'])

@@ -140,3 +140,60 @@ def test_stage1_benchmark_size_properties(cuda):
     assert np.array_equal(o_ref['mask_pred'].numpy(), mask[lo:hi].numpy())
     for k in ('rgb', 'normal_pred', 'acc_map'):
         assert_close(out[k].detach()[:, lo:hi].cpu(), o_ref[k], 1e-4, 'full-size rows vs oracle: ' + k, atol=ATOL_UNIT)
+
+
+def test_stage1_benchmark_size_sync_free_with_jitter(cuda):
+    """configs[1] through the forward the bench times: Renderer._unisurf_sync_free at 4096 rays x 128 samples with the
+    stratified jitter ON (one [N, S] table + [N, 3] neighbour offsets injected).  Size-independent properties: the rows of a
+    128-ray sub-batch evaluated on its own with ITS rows of the tables reproduce the full launch (row independence across
+    the 262144-row chunk boundary), and the same 128 rays on the CPU oracle -- which draws per hit / miss GROUP -- with the
+    tables split by the hit mask (sync_free_noise_for_reference) agree to the north-star tolerance."""
+    from oracle import stage1 as o1
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer
+    from psnerf_amd.stage1.rendering import sync_free_noise_for_reference
+    from psnerf_amd.synthetic import stage1_camera
+    over = {'rendering.num_points_in': 96, 'rendering.num_points_out': 32}
+    cfg = stage1_cfg('bear', **over)
+    sd = stage1_state_dict(cfg, seed=11)
+    net = NeuralNetwork(cfg)
+    net.load_state_dict(sd)
+    net.MAX_ROWS = 1 << 18
+    ren = Renderer(net, cfg, device=cuda)
+    ren.sync_free = True
+    h, w = 96, 128
+    K, c2w, S = stage1_camera(cfg, h=h, w=w)
+    gen = torch.Generator().manual_seed(3)
+    n_rays, n_s = 4096, 128
+    pix = torch.stack([torch.randint(0, w, (n_rays,), generator=gen).float(),
+                       torch.randint(0, h, (n_rays,), generator=gen).float()], -1)[None]
+    noise = {'full': torch.rand(n_rays, n_s, generator=gen), 'nbr_full': torch.rand(n_rays, 3, generator=gen)}
+    args = (K.to(cuda), c2w.to(cuda), S.to(cuda), 'unisurf')
+    out = ren(pix.to(cuda), *args, add_noise=True, eval_=False, it=6000, noise={k: v.to(cuda) for k, v in noise.items()})
+    assert out.get('diff_norm_full') is not None, 'not the sync-free forward'
+    mask = out['mask_pred'].cpu()
+    assert 0 < int(mask.sum()) < n_rays
+    acc = out['acc_map'].detach()
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-3
+    (out['rgb'].sum() + torch.where(out['mask_pred'], out['diff_norm_full'], torch.zeros_like(out['diff_norm_full'])).sum()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+    lo, hi = 1984, 2112  # straddles query row 262144 = ray 2048 * 128
+    sub_noise = {'full': noise['full'][lo:hi], 'nbr_full': noise['nbr_full'][lo:hi]}
+    with torch.no_grad():
+        o_sub = ren(pix[:, lo:hi].to(cuda), *args, add_noise=True, eval_=False, it=6000,
+                    noise={k: v.to(cuda) for k, v in sub_noise.items()})
+    assert torch.equal(o_sub['mask_pred'].cpu(), mask[lo:hi])
+    for k in ('rgb', 'normal_pred', 'acc_map'):
+        assert_close(o_sub[k].cpu(), out[k].detach()[:, lo:hi].cpu(), 1e-5, 'row independence: ' + k, atol=ATOL_UNIT)
+    assert float((o_sub['diff_norm_full'].cpu() - out['diff_norm_full'].detach()[lo:hi].cpu())[mask[lo:hi]].abs().max()) < 1e-5
+
+    onet = o1.NeuralNetwork(cfg)
+    onet.load_state_dict(sd)
+    with torch.no_grad():
+        o_ref = o1.Renderer(onet, cfg)(pix[:, lo:hi], K, c2w, S, 'unisurf', add_noise=True, eval_=False, it=6000,
+                                       noise=sync_free_noise_for_reference(sub_noise, mask[lo:hi]))
+    assert np.array_equal(o_ref['mask_pred'].numpy(), mask[lo:hi].numpy())
+    for k in ('rgb', 'normal_pred', 'acc_map'):
+        assert_close(out[k].detach()[:, lo:hi].cpu(), o_ref[k], 1e-4, 'full-size rows vs oracle: ' + k, atol=ATOL_UNIT)
+    d_full = out['diff_norm_full'].detach()[lo:hi].cpu()[mask[lo:hi]]
+    assert float((d_full - o_ref['diff_norm']).abs().max()) < 1e-4

@@ -6,8 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import (GOLDEN, assert_close, grad_digest, stage1_state_dict, stage2_state_dict,
-                           state_dict_digest, stage1_cfg)
+from tests.helpers import (COMPUTE_LOSS_CASES, GOLDEN, assert_close, compute_loss_case, grad_digest, stage1_state_dict,
+                           stage2_state_dict, state_dict_digest, stage1_cfg)
 from oracle import stage1 as o1
 from oracle import stage2 as o2
 from psnerf_amd.synthetic import stage2_inputs
@@ -101,6 +101,62 @@ def test_march_and_light_visibility():
     assert_close(d[fin], ref[fin], 2e-6, 'd_i')
     lv = ren.light_visibility(surf=T(g['surf']), light_dir=T(g['ldir']))
     assert_close(lv, g['light_vis'], 1e-5, 'light_vis')
+
+
+def test_shape_extract_vs_reference():
+    """Renderer.shape_extract (rendering.py:297-376) on an int64 x-major pixel chunk with shadow-ray visibility, as
+    stage1/shape_extract.py:112-139 calls it; fixture = the reference's own outputs."""
+    g = load('stage1_shape_extract.npz')
+    cfg, net, ren = _stage1_renderer()
+    assert state_dict_digest(net.state_dict()) == str(g['sd_digest'])
+    pix = T(g['pix'])
+    assert pix.dtype == torch.int64
+    out = ren(pix, T(g['K']), T(g['c2w']), torch.eye(4)[None], 'shape_extract', visibility=True, light_dir=T(g['ldir']))
+    assert np.array_equal(out['mask'].numpy(), g['mask'])
+    for k in ('normal', 'points', 'visibility'):
+        assert_close(out[k], g[k], 1e-5, k)
+
+
+def test_arange_pixels_is_x_major_int64():
+    p = o1.arange_pixels((3, 4))
+    assert p.dtype == torch.int64 and p.shape == (1, 12, 2)
+    assert p[0, :4].tolist() == [[0, 0], [0, 1], [0, 2], [1, 0]]  # x is the slow axis (common.py:73)
+
+
+@pytest.mark.parametrize('tag', sorted(COMPUTE_LOSS_CASES))
+def test_compute_loss_vs_reference_trainer(tag):
+    """Trainer.compute_loss (training.py:141-198) against the reference's OWN Trainer: training mode with the normal loss,
+    eval_mode (eval_=True: no smoothness term), and the mask loss (BCE of acc_map over mask_valid)."""
+    g = load('stage1_compute_loss.npz')
+    cfg, data, pix, noise, it, eval_mode = compute_loss_case(g, tag)
+    net = o1.NeuralNetwork(cfg)
+    net.load_state_dict(stage1_state_dict(cfg, seed=11))
+    tr = o1.Trainer(o1.Renderer(net, cfg), None, cfg)
+    assert tr.n_eval_points == tr.n_training_points == 160
+    terms = tr.compute_loss(data, eval_mode=eval_mode, it=it, pix=pix, noise=noise)
+    assert sorted(terms) == [str(k) for k in g[tag + '_loss_names']]
+    for k, v in zip(g[tag + '_loss_names'], g[tag + '_loss_vals']):
+        assert_close(float(terms[str(k)]), v, 5e-5 if str(k) in ('grad_loss', 'mask_loss') else 5e-6, str(k))
+    if eval_mode:
+        assert float(terms['grad_loss']) == 0.0
+    terms['loss'].backward()
+    names, norms, projs = grad_digest({k: v.grad for k, v in net.named_parameters()})
+    assert names == list(g[tag + '_grad_names'])
+    assert_close(norms, g[tag + '_grad_norms'], 2e-5, 'grad norms')
+    assert_close(projs, g[tag + '_grad_projs'], 1e-4, 'grad projs')
+
+
+def test_compute_loss_full_image_branch_fails_like_the_reference():
+    """training.py:159-165: with n_training_points >= h*w the reference walks the whole image with int64 pixel locations
+    and then raises inside grid_sample (common.py:195) -- the fixture holds the reference's own exception."""
+    from psnerf_amd.synthetic import stage1_batch
+    g = load('stage1_compute_loss.npz')
+    cfg = stage1_cfg('bunny', **{'training.n_training_points': 48})
+    net = o1.NeuralNetwork(cfg)
+    tr = o1.Trainer(o1.Renderer(net, cfg), None, cfg)
+    with pytest.raises(RuntimeError) as e:
+        tr.compute_loss(stage1_batch(cfg, h=6, w=8, seed=6), it=0)
+    assert 'RuntimeError: ' + str(e.value) == str(g['full_image_error'][0])
 
 
 @pytest.mark.parametrize('it', [0, 6000])

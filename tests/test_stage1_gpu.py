@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import ATOL_DEPTH, ATOL_LOGIT, ATOL_UNIT, GOLDEN, assert_close, grad_digest, stage1_state_dict, state_dict_digest, stage1_cfg
+from tests.helpers import (ATOL_DEPTH, ATOL_LOGIT, ATOL_UNIT, COMPUTE_LOSS_CASES, GOLDEN, assert_close, compute_loss_case, grad_digest,
+                           stage1_state_dict, state_dict_digest, stage1_cfg)
 
 pytestmark = pytest.mark.gpu
 
@@ -241,6 +242,162 @@ def test_sync_free_training_forward_matches_reference_shaped_path(cuda, monkeypa
             assert_close(float(t1[k].detach()), float(t0[k].detach()), 1e-5, '%s it%d' % (k, it), atol=0.0)
         for k in g0:
             assert_close(g1[k].cpu(), g0[k].cpu(), 1e-4, 'grad %s it%d' % (k, it))
+
+
+@pytest.mark.parametrize('it', [100, 6000])
+def test_sync_free_forward_with_jitter_vs_oracle(cuda, it):
+    """The forward the bench and the Trainer actually run -- Renderer._unisurf_sync_free: one flagged sampling launch, one
+    [N, S] jitter table, normals of every ray -- against the ORACLE with the stratified jitter ON: the per-ray tables are
+    split by the hit mask into the group-sized tables of the reference's draw order (sync_free_noise_for_reference), so
+    both sides use the same draw for the same (ray, sample).  Outputs, loss terms and every parameter gradient."""
+    from oracle import stage1 as o1
+    from psnerf_amd.stage1 import Loss, NeuralNetwork, Renderer
+    from psnerf_amd.stage1.rendering import sync_free_noise_for_reference
+    from psnerf_amd.synthetic import stage1_camera
+    cfg = stage1_cfg('bunny')
+    sd = stage1_state_dict(cfg, seed=11)
+    h, w = 48, 64
+    K, c2w, S = stage1_camera(cfg, h=h, w=w)
+    gen = torch.Generator().manual_seed(50 + it)
+    n = 200
+    pix = torch.stack([torch.randint(0, w, (n,), generator=gen).float(), torch.randint(0, h, (n,), generator=gen).float()], -1)[None]
+    rgb_gt = torch.rand(1, n, 3, generator=gen)
+    ngt = torch.nn.functional.normalize(torch.randn(1, n, 3, generator=gen), dim=-1)
+    nmask = torch.rand(1, n, generator=gen) > 0.3
+    full_steps = 96 if it > 5000 else 64
+    noise = {'full': torch.rand(n, full_steps, generator=gen), 'nbr_full': torch.rand(n, 3, generator=gen)}
+    net = NeuralNetwork(cfg)
+    net.load_state_dict(sd)
+    ren = Renderer(net, cfg, device=cuda)
+    ren.sync_free = True
+    out = ren(pix.to(cuda), K.to(cuda), c2w.to(cuda), S.to(cuda), 'unisurf', add_noise=True, eval_=False, it=it,
+              noise={k: v.to(cuda) for k, v in noise.items()})
+    assert out.get('diff_norm_full') is not None and out['diff_norm'] is None, 'not the sync-free forward'
+    hit = out['mask_pred'].cpu()
+    assert 20 < int(hit.sum()) < n - 20
+    onet = o1.NeuralNetwork(cfg)
+    onet.load_state_dict(sd)
+    o = o1.Renderer(onet, cfg)(pix, K, c2w, S, 'unisurf', add_noise=True, eval_=False, it=it,
+                               noise=sync_free_noise_for_reference(noise, hit))
+    assert torch.equal(o['mask_pred'], hit)
+    for k in ('rgb', 'normal_pred', 'acc_map'):
+        assert_close(out[k].detach().cpu(), o[k].detach(), 1e-4, k, atol=ATOL_UNIT)
+    # diff_norm is a difference of nearly equal unit normals: compare on the normals' scale (1.0)
+    assert float((out['diff_norm_full'].detach().cpu()[hit] - o['diff_norm'].detach()).abs().max()) < 1e-4
+    terms = Loss(1.0, 0.005, 0.05, 1.0, device=cuda)(out, rgb_gt.to(cuda), ngt.to(cuda), nmask.to(cuda))
+    oterms = o1.Loss(1.0, 0.005, 0.05, 1.0)(o, rgb_gt, ngt, nmask)
+    assert sorted(terms) == sorted(oterms)
+    for k in oterms:
+        assert_close(float(terms[k].detach()), float(oterms[k].detach()), 1e-3 if k == 'grad_loss' else 1e-4, k, atol=0.0)
+    terms['loss'].backward()
+    oterms['loss'].backward()
+    names, norms, projs = grad_digest({k: v.grad for k, v in net.named_parameters()})
+    onames, onorms, oprojs = grad_digest({k: v.grad for k, v in onet.named_parameters()})
+    assert names == onames
+    assert_close(norms, onorms, 1e-3, 'grad norms')
+    assert_close(projs, oprojs, 2e-3, 'grad projs')
+    # the same tables through the reference-shaped path of the product (index lists, compact diff_norm): same rays, same draws
+    net2 = NeuralNetwork(cfg)
+    net2.load_state_dict(sd)
+    ren2 = Renderer(net2, cfg, device=cuda)
+    with torch.no_grad():
+        out2 = ren2(pix.to(cuda), K.to(cuda), c2w.to(cuda), S.to(cuda), 'unisurf', add_noise=True, eval_=False, it=it,
+                    noise={k: v.to(cuda) for k, v in noise.items()})
+    assert out2['diff_norm'] is not None
+    for k in ('rgb', 'acc_map', 'normal_pred'):
+        assert_close(out2[k].cpu(), out[k].detach().cpu(), 1e-6, 'reference-shaped vs sync-free ' + k, atol=ATOL_UNIT)
+
+
+def test_sync_free_train_steps_vs_oracle_with_jitter(cuda):
+    """Trainer.train_step on its default (sync-free) path, jitter ON, two Adam steps across nothing but the per-ray tables:
+    loss terms and parameters after the steps against the oracle's Trainer."""
+    from oracle import stage1 as o1
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.stage1.rendering import sync_free_noise_for_reference
+    from psnerf_amd.synthetic import stage1_batch
+    cfg = stage1_cfg('bunny', **{'training.n_training_points': 128})
+    sd = stage1_state_dict(cfg, seed=21)
+    onet = o1.NeuralNetwork(cfg)
+    onet.load_state_dict(sd)
+    otr = o1.Trainer(o1.Renderer(onet, cfg), torch.optim.Adam(onet.parameters(), lr=1e-4), cfg)
+    net = NeuralNetwork(cfg)
+    net.load_state_dict(sd)
+    ren = Renderer(net, cfg, device=cuda)
+    tr = Trainer(ren, torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=cuda)
+    calls = []
+    inner = ren._unisurf_sync_free
+    ren._unisurf_sync_free = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+    batch = stage1_batch(cfg, h=48, w=64, seed=4)
+    for it in (1000, 1001):
+        gen = torch.Generator().manual_seed(it)
+        pix = torch.stack([torch.randint(0, 64, (128,), generator=gen).float(),
+                           torch.randint(0, 48, (128,), generator=gen).float()], -1)[None]
+        with torch.no_grad():  # the hit mask of the CURRENT weights splits the per-ray tables for the oracle
+            dry = o1.Renderer(onet, cfg)(pix, batch['img.camera_mat'], batch['img.world_mat'], batch['img.scale_mat'],
+                                         'unisurf', add_noise=False, eval_=True, it=it)
+        noise = {'full': torch.rand(128, 64, generator=gen), 'nbr_full': torch.rand(128, 3, generator=gen)}
+        ot = otr.train_step(batch, it=it, pix=pix, noise=sync_free_noise_for_reference(noise, dry['mask_pred']))
+        pt = tr.train_step(batch, it=it, pix=pix, noise={k: v.to(cuda) for k, v in noise.items()})
+        assert sorted(ot) == sorted(pt)
+        for k in ot:
+            assert_close(float(pt[k].detach()), float(ot[k].detach()), 1e-3 if k == 'grad_loss' else 2e-4, '%s it%d' % (k, it), atol=0.0)
+    assert len(calls) == 2, 'the trainer did not take the sync-free forward'
+    osd = onet.state_dict()
+    for k, v in net.state_dict().items():
+        d = (v.cpu() - osd[k]).abs()
+        assert float(d.max()) <= 2 * 2 * 1e-4 + 1e-6, 'param %s max diff %.3e' % (k, float(d.max()))
+        assert float(d.mean()) <= 1e-5, 'param %s mean diff %.3e' % (k, float(d.mean()))
+
+
+def test_shape_extract_golden(cuda):
+    """Renderer.shape_extract on an int64 x-major pixel chunk with shadow-ray visibility (stage1/shape_extract.py:112-139)
+    against the reference's own outputs (tests/golden/stage1_shape_extract.npz)."""
+    g = np.load(os.path.join(GOLDEN, 'stage1_shape_extract.npz'))
+    cfg, net, ren = _renderer(cuda)
+    assert state_dict_digest(stage1_state_dict(cfg, seed=11)) == str(g['sd_digest'])
+    pix = T(g['pix'], cuda)
+    assert pix.dtype == torch.int64
+    out = ren(pix, T(g['K'], cuda), T(g['c2w'], cuda), torch.eye(4, device=cuda)[None], 'shape_extract', visibility=True,
+              light_dir=T(g['ldir'], cuda))
+    assert np.array_equal(out['mask'].cpu().numpy(), g['mask'])
+    assert_close(out['normal'].cpu(), g['normal'], 1e-4, 'normal', atol=ATOL_UNIT)
+    assert_close(out['points'].cpu(), g['points'], 1e-4, 'points', atol=ATOL_DEPTH)
+    assert_close(out['visibility'].cpu(), g['visibility'], 1e-4, 'visibility', atol=ATOL_UNIT)
+
+
+@pytest.mark.parametrize('tag', sorted(COMPUTE_LOSS_CASES))
+def test_compute_loss_golden(cuda, tag):
+    """Trainer.compute_loss against the reference's OWN Trainer (tests/golden/stage1_compute_loss.npz): training mode with
+    the normal loss, eval_mode, mask loss; loss terms and parameter-gradient digests."""
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    g = np.load(os.path.join(GOLDEN, 'stage1_compute_loss.npz'))
+    cfg, data, pix, noise, it, eval_mode = compute_loss_case(g, tag)
+    net = NeuralNetwork(cfg)
+    net.load_state_dict(stage1_state_dict(cfg, seed=11))
+    tr = Trainer(Renderer(net, cfg, device=cuda), None, cfg, device=cuda)
+    assert tr.n_eval_points == tr.n_training_points == 160
+    terms = tr.compute_loss(data, eval_mode=eval_mode, it=it, pix=pix, noise={k: v.to(cuda) for k, v in noise.items()})
+    assert sorted(terms) == [str(k) for k in g[tag + '_loss_names']]
+    for k, v in zip(g[tag + '_loss_names'], g[tag + '_loss_vals']):
+        assert_close(float(terms[str(k)].detach()), v, 1e-3 if str(k) == 'grad_loss' else 1e-4, str(k), atol=0.0)
+    terms['loss'].backward()
+    names, norms, projs = grad_digest({k: v.grad for k, v in net.named_parameters()})
+    assert names == list(g[tag + '_grad_names'])
+    assert_close(norms, g[tag + '_grad_norms'], 1e-3, 'grad norms')
+    assert_close(projs, g[tag + '_grad_projs'], 2e-3, 'grad projs')
+
+
+def test_compute_loss_full_image_branch_fails_like_the_reference(cuda):
+    """n_training_points >= h*w: the reference raises RuntimeError from grid_sample on its int64 pixel grid
+    (training.py:159-165 -> common.py:195; the fixture holds its exception); so does the product, before the forward."""
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.synthetic import stage1_batch
+    g = np.load(os.path.join(GOLDEN, 'stage1_compute_loss.npz'))
+    cfg = stage1_cfg('bunny', **{'training.n_training_points': 48})
+    tr = Trainer(Renderer(NeuralNetwork(cfg), cfg, device=cuda), None, cfg, device=cuda)
+    with pytest.raises(RuntimeError) as e:
+        tr.compute_loss(stage1_batch(cfg, h=6, w=8, seed=6), it=0)
+    assert ('RuntimeError: ' + str(e.value)).startswith(str(g['full_image_error'][0]))
 
 
 def test_root_finder_and_crossing_vs_stepwise_formulation(cuda):

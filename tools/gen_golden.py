@@ -222,6 +222,115 @@ def gen_stage1():
             rgb_gt=np_(rgb_gt), normal_gt=np_(ngt), norm_mask=np_(nmask),
             loss_names=np.array(sorted(tr.keys())), loss_vals=np.array([float(tr[k]) for k in sorted(tr.keys())]),
             grad_names=np.array(names), grad_norms=norms, grad_projs=projs)
+    # --- Renderer.shape_extract (rendering.py:297-376) as stage1/shape_extract.py:112-139 calls it: a chunk of the INT64
+    #     x-major arange_pixels grid, 512 march steps, normals with tflag=False, shadow-ray visibility per 96-light batch
+    from model.common import arange_pixels as r_arange
+    hs, ws = 40, 48
+    Ks, c2ws, Ss = stage1_camera(cfg, h=hs, w=ws)
+    p_loc = r_arange(resolution=(hs, ws))[0]
+    assert p_loc.dtype == torch.int64 and torch.equal(p_loc, o1.arange_pixels((hs, ws)))
+    chunk = p_loc[:, 16 * hs + 8: 16 * hs + 8 + 200]  # 200 pixels out of the x-major walk (5 image columns)
+    ldir_s = torch.nn.functional.normalize(torch.randn(5, 3, generator=torch.Generator().manual_seed(12)), dim=-1)
+    with torch.no_grad():
+        se_r = rren(chunk, Ks, c2ws, Ss, 'shape_extract', add_noise=False, eval_=True, it=100000, visibility=True, light_dir=ldir_s)
+    se_o = oren(chunk, Ks, c2ws, Ss, 'shape_extract', visibility=True, light_dir=ldir_s)
+    assert torch.equal(se_r['mask'], se_o['mask']) and 10 < int(se_r['mask'].sum()) < 200
+    for k in ('normal', 'points', 'visibility'):
+        check('shape_extract %s' % k, se_o[k], se_r[k], 5e-6)
+    rnet.train(); onet.train()  # shape_extract leaves the model in eval mode (rendering.py:311); no effect on these modules
+    np.savez_compressed(os.path.join(GOLDEN, 'stage1_shape_extract.npz'), sd_digest=state_dict_digest(sd), hw=np.array([hs, ws]),
+                        pix=np_(chunk), K=np_(Ks), c2w=np_(c2ws), ldir=np_(ldir_s), mask=np_(se_r['mask']),
+                        normal=np_(se_r['normal']), points=np_(se_r['points']), visibility=np_(se_r['visibility']))
+
+    # --- Trainer.compute_loss (training.py:141-198): the reference's OWN trainer on a synthetic data dict; the pixel draw
+    #     (common.py:32-35) and the renderer's draws are captured by replaying the RNG stream in the reference's order
+    cl = {}
+    hb, wb = 48, 64
+    for tag, over, it, eval_mode in (('train', {}, 1500, False), ('eval', {}, 1500, True),
+                                     ('mask', {'training.mask_loss': True, 'training.normal_after': 2000}, 1500, False)):
+        cfg_t = stage1_cfg('bunny', **dict({'training.n_training_points': 160}, **over))
+        data = stage1_batch(cfg_t, h=hb, w=wb, seed=6)
+        data['img.mask_valid'] = (torch.rand(1, hb, wb, generator=torch.Generator().manual_seed(13)) > 0.1).float()
+        if tag == 'mask':
+            # BCE(acc, mask) with a mask that CONTRADICTS the geometry (acc ~ 1 where mask = 0) is -log(1 - acc) at the edge
+            # of fp32 (gradient 1 / (1 - acc)): the reference's own value is then an accident of its summation order.  The
+            # silhouette of the shape itself (dry march over the whole image, stored in the fixture) is what real masks are.
+            ys, xs = torch.meshgrid(torch.arange(hb), torch.arange(wb), indexing='ij')
+            allpix = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1).float()[None]
+            onet.load_state_dict(sd)
+            with torch.no_grad():
+                sil = torch.cat([o1.Renderer(onet, cfg_t)(c, data['img.camera_mat'], data['img.world_mat'], data['img.scale_mat'],
+                                                          'unisurf', add_noise=False, eval_=True, it=it)['mask_pred']
+                                 for c in torch.split(allpix, 1024, dim=1)])
+            data['img.mask'] = sil.reshape(1, hb, wb).float()
+            cl['mask_img'] = np_(sil.reshape(hb, wb))
+        res = {}
+        for who, net, Ren, Tr in (('ref', rnet, lambda n: rmdl.Renderer(n, cfg_t, device=torch.device('cpu')), None),
+                                  ('ora', onet, lambda n: o1.Renderer(n, cfg_t), None)):
+            net.load_state_dict(sd)
+            net.zero_grad()
+            ren_t = Ren(net)
+            seed = 300 + it + int(eval_mode)
+            if who == 'ref':
+                trn = rmdl.Trainer(ren_t, torch.optim.Adam(net.parameters(), lr=1e-4), cfg_t, device=torch.device('cpu'))
+                torch.manual_seed(seed)
+                terms = trn.compute_loss(data, eval_mode=eval_mode, it=it)
+                # replay the stream: px, py (common.py:32-35), randint (rendering.py:441), rand miss / hit (:139, :163),
+                # rand_like neighbours (:204, training forward only)
+                torch.manual_seed(seed)
+                n = 160
+                px = torch.randint(0, wb, size=(1, n, 1)).float()
+                py = torch.randint(0, hb, size=(1, n, 1)).float()
+                pix_t = torch.cat([px, py], dim=-1)
+                torch.randint(256, 257, (1,))
+                with torch.no_grad():
+                    dry = o1.Renderer(onet, cfg_t)(pix_t, data['img.camera_mat'], data['img.world_mat'], data['img.scale_mat'],
+                                                   'unisurf', add_noise=False, eval_=True, it=it)
+                n_hit = int(dry['mask_pred'].sum())
+                # the dry run consumed one randint: restore the stream position behind the reference's randint
+                torch.manual_seed(seed)
+                torch.randint(0, wb, size=(1, n, 1)); torch.randint(0, hb, size=(1, n, 1)); torch.randint(256, 257, (1,))
+                S_t = 64
+                noise_t = {'miss': torch.rand(1, n - n_hit, S_t), 'hit': torch.rand(1, n_hit, S_t)}
+                if not eval_mode:
+                    noise_t['nbr'] = torch.rand(n_hit, 3)
+                assert 10 < n_hit < n - 10
+            else:
+                trn = o1.Trainer(ren_t, torch.optim.Adam(net.parameters(), lr=1e-4), cfg_t)
+                terms = trn.compute_loss(data, eval_mode=eval_mode, it=it, pix=pix_t, noise=noise_t)
+            if terms['loss'].requires_grad:
+                terms['loss'].backward()
+            res[who] = (terms, grad_digest({k: v.grad for k, v in net.named_parameters()}))
+        (tr_, (names, norms, projs)), (to_, (_, onorms, oprojs)) = res['ref'], res['ora']
+        assert sorted(tr_.keys()) == sorted(to_.keys()), (sorted(tr_.keys()), sorted(to_.keys()))
+        for k in tr_:
+            # grad_loss = mean |n - n'| (cancellation); mask_loss = BCE(acc): -log(1 - acc) near acc = 1 amplifies the 5e-7
+            # weight_norm residue of acc by 1 / (1 - acc)
+            check('compute_loss[%s] %s' % (tag, k), to_[k], tr_[k],
+                  2e-5 if (k in ('grad_loss', 'mask_loss') or (k == 'loss' and 'mask_loss' in tr_)) else 2e-6)
+        check('compute_loss[%s] grad norms' % tag, onorms, norms, 2e-5)
+        check('compute_loss[%s] grad projs' % tag, oprojs, projs, 1e-4)
+        lk = sorted(tr_.keys())
+        cl.update({tag + '_pix': np_(pix_t), tag + '_it': it, tag + '_eval': eval_mode, tag + '_loss_names': np.array(lk),
+                   tag + '_loss_vals': np.array([float(tr_[k]) for k in lk]), tag + '_grad_names': np.array(names),
+                   tag + '_grad_norms': norms, tag + '_grad_projs': projs, tag + '_over': np.array(sorted(over.items()), dtype=object) if False else np.array([str(sorted(over.items()))])})
+        cl.update({tag + '_nz_' + k: np_(v) for k, v in noise_t.items()})
+    # the full-image branch (training.py:159-165): the reference itself cannot complete it -- record HOW it fails
+    cfg_f = stage1_cfg('bunny', **{'training.n_training_points': 6 * 8})
+    data_f = stage1_batch(cfg_f, h=6, w=8, seed=6)
+    errs = []
+    for trn in (rmdl.Trainer(rmdl.Renderer(rnet, cfg_f, device=torch.device('cpu')), None, cfg_f, device=torch.device('cpu')),
+                o1.Trainer(o1.Renderer(onet, cfg_f), None, cfg_f)):
+        try:
+            trn.compute_loss(data_f, it=0)
+            errs.append('')
+        except Exception as e:  # noqa: BLE001
+            errs.append('%s: %s' % (type(e).__name__, e))
+    print('  full-image branch: reference -> %r' % errs[0])
+    assert errs[0] == errs[1] and errs[0].startswith('RuntimeError: expected scalar type Float but found Long'), errs
+    cl['full_image_error'] = np.array([errs[0]])
+    np.savez_compressed(os.path.join(GOLDEN, 'stage1_compute_loss.npz'), sd_digest=state_dict_digest(sd), hw=np.array([hb, wb]),
+                        batch_seed=6, mask_valid_seed=13, n_points=160, **cl)
     print('stage1 goldens written')
 
 
