@@ -133,20 +133,63 @@ STAGE2_ATOL = {
 }
 
 
-# The two outputs that contain the specular lobes may have a FEW highlight-peak elements beyond the bound: the lobe
-# argument lambda_k (h.n - 1) multiplies the fp32 noise of the predicted normal n (observed 4e-6 absolute, the GEMM
-# summation order of normal_net) by lambda_k <= 22026, i.e. a highlight element carries up to w_k lambda_k dn ~ 0.02 *
-# 22026 * 4e-6 = 2e-3 of conditioning error in ANY fp32 evaluation whose normal differs in the last bits.  Measured on
-# the full-size batch (110592 elements, round 2): 1 element of sg_rgb_values at 3.4 x the bound, specular at 3.0 x.
-# Allowed: <= 1e-3 of the elements, none beyond 5 x the bound (everything else is held to the plain bound).
-STAGE2_OUTLIERS = {'sg_rgb_values': (1e-3, 5.0), 'sg_specular_rgb_values': (1e-3, 5.0)}
+# The two outputs that contain the specular lobes: the lobe argument lambda_k (h.n - 1) multiplies the fp32 noise of the
+# predicted normal n (GEMM summation order of normal_net) and of h.n itself by lambda_k <= 22026, so a highlight-peak element
+# carries conditioning error in ANY fp32 evaluation -- the reference's own included.  How much is MEASURED, not assumed:
+# stage2_truth() evaluates the oracle (= the reference arithmetic, pinned by the goldens) in float64 on the same inputs, and
+# a check that is handed this ``truth`` compares BOTH fp32 evaluations with it under the same elementwise bound:
+#     r_ref = |reference fp32 - truth| / bound,   r_hip = |HIP - truth| / bound,   bound = rtol |truth| + atol
+#   * HIP may have as many elements beyond the bound as the reference arithmetic has beyond HALF of it, and
+#   * its worst element may be at most twice as far out as the reference's worst (never less than the bound itself):
+# a second fp32 evaluation with independent rounding differs from the first by up to the sum of the two errors.  Without a
+# ``truth`` the plain bound applies to every element (round 2 used a hand-set allowance of 1e-3 of the elements up to 5 x;
+# measured on the 110,592-element full-size sub-batch the reference arithmetic itself has 1 element at 2.2 x / 2.0 x).
+SPECULAR_KEYS = ('sg_rgb_values', 'sg_specular_rgb_values')
 
 
-def assert_outputs_close(key, a, b, rtol=1e-4, prefix=''):
+def stage2_truth(onet, inp, **fwd_kw):
+    """float64 evaluation of the oracle network ``onet`` (a copy; same weights) on the fp32 inputs ``inp`` cast up: the
+    'exact' value of the reference formulas for these inputs.  Returns {key: float64 ndarray}."""
+    import copy
+    net64 = copy.deepcopy(onet).double()
+    up = lambda v: v.detach().cpu().double() if (torch.is_tensor(v) and v.dtype == torch.float32) else (
+        v.detach().cpu() if torch.is_tensor(v) else v)
+    inp64 = {k: up(v) for k, v in inp.items()}
+    kw64 = {k: ({kk: up(vv) for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in fwd_kw.items()}
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)  # the oracle allocates its dense outputs with the default dtype
+    try:
+        with torch.no_grad():
+            out = net64(inp64, **kw64)
+    finally:
+        torch.set_default_dtype(old)
+    return {k: v.numpy() for k, v in out.items() if torch.is_tensor(v) and v.dtype == torch.float64}
+
+
+def _np64(x):
+    return np.asarray(x.detach().cpu() if torch.is_tensor(x) else x, dtype=np.float64)
+
+
+def assert_outputs_close(key, a, b, rtol=1e-4, prefix='', truth=None):
+    """a = the HIP output, b = the reference fp32 value (golden fixture or oracle); ``truth`` = stage2_truth(...) enables
+    the measured allowance for the two specular keys (see above)."""
     atol = STAGE2_ATOL.get(key, ATOL_UNIT)
+    if key in SPECULAR_KEYS and truth is not None and not _REPORT:
+        t, a64, b64 = truth[key], _np64(a), _np64(b)
+        assert t.shape == a64.shape == b64.shape, '%s%s: shapes %s %s %s' % (prefix, key, t.shape, a64.shape, b64.shape)
+        at = rtol * float(np.abs(t).max()) if atol == 'max' else atol
+        bound = rtol * np.abs(t) + at
+        r_ref, r_hip = np.abs(b64 - t) / bound, np.abs(a64 - t) / bound
+        n_allowed, worst_allowed = int((r_ref > 0.5).sum()), max(1.0, 2.0 * float(r_ref.max()))
+        n_out, worst = int((r_hip > 1.0).sum()), float(r_hip.max())
+        assert n_out <= n_allowed and worst <= worst_allowed, (
+            '%s%s vs float64 truth: %d elements beyond the bound, worst x%.2f; the reference arithmetic itself: %d beyond half '
+            'the bound, worst x%.2f -> allowed %d, x%.2f' % (prefix, key, n_out, worst, n_allowed, float(r_ref.max()),
+                                                             n_allowed, worst_allowed))
+        return
     if atol == 'max':
         atol = rtol * float(np.abs(np.asarray(b, dtype=np.float64)).max())
-    assert_close(a, b, rtol, prefix + key, atol=atol, outliers=STAGE2_OUTLIERS.get(key))
+    assert_close(a, b, rtol, prefix + key, atol=atol)
 
 
 COMPUTE_LOSS_CASES = {'train': {}, 'eval': {}, 'mask': {'training.mask_loss': True, 'training.normal_after': 2000}}

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import GOLDEN, assert_close, assert_outputs_close, grad_digest, stage2_state_dict, state_dict_digest
+from tests.helpers import GOLDEN, assert_close, assert_outputs_close, grad_digest, stage2_state_dict, stage2_truth, state_dict_digest
 from psnerf_amd.synthetic import stage2_inputs
 
 pytestmark = pytest.mark.gpu
@@ -38,6 +38,16 @@ def _run(net, MainLoss, NormalLoss, inp, gt, phase, noise, dev):
     return out, t, gr
 
 
+def _truth(conf, sd, inp, nz):
+    """float64 oracle evaluation of what _run feeds the model (light directions normalised in fp32 first)."""
+    from oracle import stage2 as o2
+    onet = o2.PSNetwork(conf)
+    onet.load_state_dict(sd)
+    inp = dict(inp)
+    inp['light_direction'] = torch.nn.functional.normalize(inp['light_direction'], p=2, dim=-1)
+    return stage2_truth(onet, inp, noise={'xyz': nz})
+
+
 @pytest.mark.parametrize('L', [1, 10])
 @pytest.mark.parametrize('phase', [1, 2])
 def test_psnetwork_golden(cuda, L, phase):
@@ -52,9 +62,10 @@ def test_psnetwork_golden(cuda, L, phase):
     net.to(cuda)
     inp, gt = stage2_inputs(int(g['N']), L, int(g['V']), seed=int(g['input_seed']))
     out, t, gr = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, phase, torch.from_numpy(g['nz_xyz']), cuda)
+    truth = _truth(o2.bear_conf(), sd, inp, torch.from_numpy(g['nz_xyz']))
     for k in g.files:
         if k.startswith('out_'):
-            assert_outputs_close(k[4:], out[k[4:]].detach().cpu(), g[k])
+            assert_outputs_close(k[4:], out[k[4:]].detach().cpu(), g[k], truth=truth)
     for k, v in zip(g['loss_names'], g['loss_vals']):
         assert_close(float(t[str(k)].detach()), v, 1e-4, str(k), atol=0.0)
     names, norms, projs = grad_digest(gr)
@@ -82,9 +93,10 @@ def test_psnetwork_vs_oracle(cuda, N, L, V):
     nz = torch.randn(ns, 3, generator=torch.Generator().manual_seed(1)) * 0.01
     o_out, o_t, o_g = _run(onet, o2.MainLoss, o2.NormalLoss, inp, gt, 2, nz, 'cpu')
     out, t, gr = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, 2, nz, cuda)
+    truth = _truth(o2.bear_conf(), sd, inp, nz)
     for k in o_out:
         if torch.is_tensor(o_out[k]) and o_out[k].dtype.is_floating_point:
-            assert_outputs_close(k, out[k].detach().cpu(), o_out[k].detach())
+            assert_outputs_close(k, out[k].detach().cpu(), o_out[k].detach(), truth=truth)
     for k in o_t:
         if o_t[k] is not None:
             assert_close(float(t[k]), float(o_t[k]), 1e-4, k, atol=0.0)
