@@ -17,8 +17,14 @@ WEAK scaling (32768 px per GPU; the reference trains on all ~10^5 in-mask pixels
 ``strong`` object on the same line times a FIXED global batch of 262144 pixels split N ways.
 
 Extra objects on the JSON line (all measured after the headline's timed region):
-  roofline      dominant kernel (fused 256-wide visibility MLP, MFMA-bound, 2 * 523,520 MAC per row), HIP events on the
-                launch stream
+  roofline      dominant kernel (fused 256-wide visibility MLP, MFMA-bound), HIP events on the launch stream from a SECOND,
+                separately instrumented pass (the headline's timed region records nothing).  ``achieved`` / ``frac`` count the
+                flops the kernel's own algorithm needs (2 x 462,848 MAC per row: the two input-block layers are factorised into
+                per-point / per-light tables computed by separate small GEMMs), so frac <= 1; ``algorithmic_frac`` prices the
+                reference's unfactorised 523,520 MAC per row at the same duration and may pass 1
+  reference_dict  the same step fed the reference's dictionary WITHOUT 'surface_idx' (the index list is then rebuilt from
+                the mask inside the timed step: one nonzero() = one host synchronisation per step)
+  launches_per_step  device kernel launches of one steady-state step (torch.profiler), hand-written HIP vs torch-eager
   cpu_baseline  the CPU oracle (oracle/stage2.py, a verified restatement of the reference) on this host, N = 1 only
   strong        strong-scaling measurement (fixed global batch)
   allreduce_ms  average time of one gradient all-reduce of the step's bucket size (N > 1)
@@ -216,10 +222,17 @@ def main():
     ap.add_argument('--single-device', action='store_true', help='dry run: every rank uses cuda:0')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    import torch  # (device_count() does not initialise the GPU on this image: the parent stays exec-safe)
+    have = torch.cuda.device_count()
+    if not args.single_device and have < args.gpus:
+        # fail fast and loudly instead of hanging in a rendezvous that can never complete
+        print('bench.py: --gpus %d requested but only %d GPU(s) are visible on this node' % (args.gpus, have), file=sys.stderr, flush=True)
+        raise SystemExit(2)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(args.gpus))
 
-    import torch
     import torch.distributed as dist
     from psnerf_amd import dist as pdist, hip
     from psnerf_amd.synthetic import stage2_inputs
@@ -235,11 +248,11 @@ def main():
     step = make_step(device)
     l_slt = torch.arange(N_LIGHTS, device=device) + 96 * 3  # the 96 lights of one view
 
-    def timed(inp, gt, steps, warmup, profile=False):
-        """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+    def timed(inp, gt, steps, warmup):
+        """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks.  Nothing is recorded inside."""
         for _ in range(warmup):
             step.step(inp, gt, l_slt, train_order=False)
-        hip.PROFILE_EVENTS = [] if profile else None
+        hip.PROFILE_EVENTS = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -250,13 +263,38 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        events, hip.PROFILE_EVENTS = hip.PROFILE_EVENTS, None
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         ns = torch.tensor([int(inp['surface_mask'].sum())], device=device, dtype=torch.int64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(ns, op=dist.ReduceOp.SUM)
-        return float(t.item()), int(ns.item()), terms, events
+        return float(t.item()), int(ns.item()), terms
+
+    def instrumented(inp, gt, steps):
+        """Per-kernel durations: HIP events around every C-ABI launch on its launch stream (hip._Prof), in a pass of its own."""
+        hip.PROFILE_EVENTS = ev = []
+        for _ in range(steps):
+            step.step(inp, gt, l_slt, train_order=False)
+        torch.cuda.synchronize()
+        hip.PROFILE_EVENTS = None
+        return ev
+
+    def count_launches(inp, gt):
+        """Device kernel launches of ONE steady-state step, split into the hand-written HIP kernels (namespace psn) and the
+        rest (torch-eager at::native / foreach kernels, memsets); None when the profiler is unavailable."""
+        try:
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                step.step(inp, gt, l_slt, train_order=False)
+                torch.cuda.synchronize()
+            names = [e.name for e in prof.events() if getattr(e, 'device_type', None) is not None
+                     and 'cuda' in str(e.device_type).lower()]
+            if not names:
+                return None
+            ours = sum(1 for n in names if 'psn::' in n)
+            return {'total': len(names), 'hip_hand_written': ours, 'other': len(names) - ours}
+        except Exception as e:  # noqa: BLE001
+            return {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
 
     def weak_batch():
         return stage2_inputs(args.pixels, N_LIGHTS, N_VIS, seed=100 + rank, device=device, with_surface_idx=True)
@@ -267,8 +305,21 @@ def main():
 
     head_batch, other_batch = (weak_batch, strong_batch) if args.scaling == 'weak' else (strong_batch, weak_batch)
     inp, gt = head_batch()
-    dt, ns_total, terms, events = timed(inp, gt, args.steps, args.warmup, profile=(rank == 0))
+    dt, ns_total, terms = timed(inp, gt, args.steps, args.warmup)
     px_local = inp['uv'].shape[1]
+    events = instrumented(inp, gt, min(args.steps, 10)) if rank == 0 else []
+    launches = count_launches(inp, gt) if (rank == 0 and not args.no_extra) else None
+    ref_dict = None
+    if not args.no_extra and world == 1:
+        # the drop-in number: the reference's own dictionary, no 'surface_idx' -- PSNetwork.forward then builds the index list
+        # from surface_mask itself (nonzero(): a host synchronisation inside the step)
+        inp_ref = {k: v for k, v in inp.items() if k != 'surface_idx'}
+        k3 = max(3, min(args.steps, 20))
+        dt3, ns3, _ = timed(inp_ref, gt, k3, 2)
+        ref_dict = {'value': round(ns3 * N_LIGHTS / (dt3 / k3), 1), 'unit': 'ray-samples/s', 'ms_per_step': round(dt3 / k3 * 1e3, 3),
+                    'steps': k3, 'warmup': 2, 'batch': "the reference's model_input keys only (stage2/model/renderer.py:110-125); the "
+                    "surface index list is built inside the step"}
+        del inp_ref
     del inp, gt
     ms_per_step = dt / args.steps * 1e3
     value = ns_total * N_LIGHTS / (dt / args.steps)
@@ -278,7 +329,7 @@ def main():
     if not args.no_extra:
         inp, gt = other_batch()
         k2 = max(3, min(args.steps, 10 if args.scaling == 'weak' else 20))
-        dt2, ns2, _, _ = timed(inp, gt, k2, 2)
+        dt2, ns2, _ = timed(inp, gt, k2, 2)
         other = {'scaling': 'strong' if args.scaling == 'weak' else 'weak', 'value': round(ns2 * N_LIGHTS / (dt2 / k2), 1),
                  'unit': 'ray-samples/s', 'ms_per_step': round(dt2 / k2 * 1e3, 3), 'steps': k2, 'warmup': 2,
                  'pixels_per_gpu': inp['uv'].shape[1], 'surface_pixels_total': ns2,
@@ -307,30 +358,32 @@ def main():
     roofline = None
     if durs:
         avg_ms = sum(durs) / len(durs)
-        achieved = 2.0 * VIS_MACS * top / (avg_ms * 1e-3) / 1e12
-        traffic = None
+        algo = 2.0 * VIS_MACS * top / (avg_ms * 1e-3) / 1e12       # the reference's unfactorised formulation
+        issued = 2.0 * VIS_MACS_ISSUED * top / (avg_ms * 1e-3) / 1e12  # the flops of the algorithm this kernel runs
+        traffic = comp = busy = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and px_local == N_PIXELS:
             try:
-                traffic = json.load(open(pmc)).get('mlp_infer_kernel_bytes_per_launch')
+                j = json.load(open(pmc))
+                traffic, comp, busy = j.get('hbm_side_bytes_per_launch'), j.get('compulsory_bytes_per_launch'), j.get('mfma_busy_frac')
             except Exception:
                 traffic = None
-        roofline = {'bound': 'mfma', 'kernel': 'mlp_infer_kernel', 'achieved': round(achieved, 2),
-                    'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    'traffic': traffic if px_local == N_PIXELS else None, 'rows_per_launch': top,
-                    'avg_launch_ms': round(avg_ms, 3), 'launches': len(durs),
-                    'share_of_step': round(avg_ms * len(durs) / args.steps / ms_per_step, 3),
-                    # 'achieved' / 'frac' count the ALGORITHMIC MACs of the reference network.  The kernel
-                    # issues fewer: the two layers that read the input block start from per-point / per-light init
-                    # tables (W [pe(x) | pe(l)] = W_a pe(x) + W_b pe(l)), so frac can pass 1.0
-                    # while the matrix pipe itself runs at issued_frac of its peak.
-                    'issued_macs_per_row': VIS_MACS_ISSUED,
-                    'issued_tflops': round(achieved * VIS_MACS_ISSUED / VIS_MACS, 2),
-                    'issued_frac': round(achieved * VIS_MACS_ISSUED / VIS_MACS / PEAK_F32_MFMA_TFLOPS, 4),
-                    'note': 'achieved / frac count the reference formulation (SURVEY 8d: 523,520 MAC per row); the kernel takes the '
-                            'point and light halves of the two input blocks from init tables and issues 462,848 MAC per row, so '
-                            'frac may exceed 1 -- the matrix-pipe utilisation is issued_frac (PMC SQ_VALU_MFMA_BUSY_CYCLES: '
-                            'profiles/)'}
+        roofline = {'bound': 'mfma', 'kernel': 'mlp_infer_kernel<false,16,0>', 'achieved': round(issued, 2),
+                    'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(issued / PEAK_F32_MFMA_TFLOPS, 4),
+                    'flops_per_row': 2 * VIS_MACS_ISSUED, 'rows_per_launch': top, 'avg_launch_ms': round(avg_ms, 3),
+                    'launches': len(durs), 'share_of_step': round(avg_ms / ms_per_step, 3),
+                    'algorithmic_flops_per_row': 2 * VIS_MACS, 'algorithmic_achieved': round(algo, 2),
+                    'algorithmic_frac': round(algo / PEAK_F32_MFMA_TFLOPS, 4),
+                    'traffic': traffic, 'algorithmic_bytes': comp,
+                    'traffic_over_algorithmic': round(traffic / comp, 2) if (traffic and comp) else None,
+                    'pmc_mfma_busy_frac': busy,
+                    'note': 'achieved = 2 x 462,848 MAC per row x rows / avg launch duration (HIP events, second pass): the two layers '
+                            'that read [pe(x) | pe(l)] start from per-point / per-light tables, W [pe(x) | pe(l)] = W_a pe(x) + W_b pe(l), '
+                            'computed once per point / light by separate small GEMMs (DESIGN.md 3).  algorithmic_* prices the '
+                            "reference's 523,520 MAC per row at the same duration.  traffic = 2 x FETCH_SIZE + WRITE_SIZE of the "
+                            'dispatch (rocprofv3 PMC, profiles/pmc_traffic.json; Infinity-Cache hits included), algorithmic_bytes = '
+                            'compulsory HBM bytes (tables and weights once, outputs, activation dumps of the V supervised rows); the '
+                            'ratio is re-read traffic of the init tables served by L2 / MALL on an MFMA-bound kernel'}
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # the CPU oracle is timed at N = 1 only (other ranks would idle behind it)
         cpu = cpu_baseline()
@@ -345,7 +398,7 @@ def main():
                    'vis_lights': N_VIS, 'parallelism': 'pixel-dp%d' % world,
                    'batch': "ViewSampler.batch layout: reference dictionary + 'surface_idx' (host-built index list of the surface mask)"},
         'loss': round(float(terms['total'].detach()), 6),
-        'roofline': roofline, 'cpu_baseline': cpu,
+        'roofline': roofline, 'cpu_baseline': cpu, 'reference_dict': ref_dict, 'launches_per_step': launches,
         ('strong' if args.scaling == 'weak' else 'weak'): other,
         'allreduce_ms': allreduce_ms, 'allreduce_bytes': bucket_bytes if world > 1 else None,
         'stage1': stage1,

@@ -21,12 +21,16 @@ PIXEL_KEYS_DIM1 = ('uv', 'object_mask', 'surface_mask', 'points', 'normal', 'vis
 
 
 class DataParallel(object):
-    def __init__(self, device=None):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    def __init__(self, device=None, force=False):
+        """``force``: take the data-parallel code path (bucket views, collectives) even in a world of ONE rank -- the
+        collectives are then identities, which is how the RCCL path is exercised on a single-GPU box."""
+        up = dist.is_available() and dist.is_initialized()
+        self.enabled = up and (dist.get_world_size() > 1 or bool(force))
         self.world = dist.get_world_size() if self.enabled else 1
         self.rank = dist.get_rank() if self.enabled else 0
         self.device = device
         self._buckets = {}
+        self.global_rays = None  # ray count of the last stage-1 batch BEFORE sharding (identical on every rank)
         self.n_allreduce = 0
         self.allreduce_bytes = 0
 
@@ -52,9 +56,23 @@ class DataParallel(object):
         return mi, gt
 
     def shard_rays(self, pixels):
-        """stage-1: rank slice of the sampled pixel list [1,N,2]."""
+        """stage-1: rank slice of the sampled pixel list [1,N,2].  The GLOBAL ray count -- the denominator of the rgb loss
+        (losses.py:17-19) -- is remembered here: it is known arithmetically on every rank, no collective needed."""
+        self.global_rays = int(pixels.shape[1])
         lo, hi = self.slice_bounds(pixels.shape[1])
         return pixels[:, lo:hi].contiguous()
+
+    def shard_ray_noise(self, noise, n_rays):
+        """Rank slice of injected PER-RAY draw tables ('full' [N, S], 'nbr_full' [N, 3]; Renderer._unisurf_sync_free) that
+        were made for the whole ray set; group-sized tables (the reference's draw order) are the caller's to slice."""
+        if not noise:
+            return noise
+        lo, hi = self.slice_bounds(n_rays)
+        out = dict(noise)
+        for k in ('full', 'nbr_full'):
+            if out.get(k) is not None and out[k].reshape(-1, out[k].shape[-1]).shape[0] == n_rays:
+                out[k] = out[k].reshape(n_rays, -1)[lo:hi].contiguous()
+        return out
 
     # ---- loss denominators ----------------------------------------------------------------------
     def new_step(self):
@@ -90,6 +108,10 @@ class DataParallel(object):
         tensors before nor ~50 copy kernels after it."""
         key = tuple(id(p) for p in params)
         b = self._buckets.get(key)
+        if b is not None and not all(r() is p for r, p in zip(b[2], params)):
+            b = None  # ids are reused once a model is freed: the bucket belongs to THESE parameter objects (weak references)
+        if len(self._buckets) > 8:  # train_fix phases x (dense, light tables): a handful; anything more is a leak
+            self._buckets = {k: v for k, v in self._buckets.items() if all(r() is not None for r in v[2])}
         if b is None:
             total = sum(p.numel() for p in params)
             flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
@@ -97,18 +119,23 @@ class DataParallel(object):
             for p in params:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-            b = self._buckets[key] = (flat, views)
+            import weakref
+            b = self._buckets[key] = (flat, views, [weakref.ref(p) for p in params])
         return b
 
     def prepare_grads(self, params):
         """Replaces ``optimizer.zero_grad()`` under data parallelism: ONE memset of the flat bucket, and every
         ``p.grad`` (re)attached to its view, so that autograd accumulates straight into the bucket."""
+        for p in params:
+            if not p.requires_grad:
+                p.grad = None  # a parameter frozen since the last step must not keep its last all-reduced gradient (a view
+                               # of a bucket that is no longer reduced): optimisers skip None, like after zero_grad()
         params = [p for p in params if p.requires_grad]
         if not self.enabled or not params:
             for p in params:
                 p.grad = None
             return
-        flat, views = self._bucket(params)
+        flat, views = self._bucket(params)[:2]
         flat.zero_()
         for p, v in zip(params, views):
             p.grad = v
@@ -123,7 +150,7 @@ class DataParallel(object):
             return
         params = [p for p in params if p.requires_grad]
         if params:
-            flat, views = self._bucket(params)
+            flat, views = self._bucket(params)[:2]
             for p, v in zip(params, views):
                 if p.grad is None:
                     v.zero_()
@@ -166,12 +193,13 @@ class DataParallel(object):
             dist.barrier()
 
 
-def init_from_env(backend=None, set_device=True):
-    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+def init_from_env(backend=None, set_device=True, force=False):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  ``force``: create the
+    process group even for a world of one rank (the single-GPU RCCL smoke test; see DataParallel(force=True))."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if world <= 1 and not force:
         return 0, 0, 1
-    rank = int(os.environ['RANK'])
+    rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', rank))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')

@@ -943,7 +943,12 @@ class Stage2Losses(torch.autograd.Function):
         ts = [c(t) for t in (rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j)]
         ma, mb = mask_a.contiguous(), mask_b.contiguous()
         out = hip.stage2_loss_fwd(*ts, ma, mb, l2, inv_denom, weight, count_dev)
-        ctx.ts, ctx.masks, ctx.l2, ctx.count_dev = ts, (ma, mb), l2, count_dev
+        # save_for_backward (not plain ctx attributes): autograd then detects an in-place edit of any input between forward and
+        # backward and the tensors go through the saved-tensor hooks; None slots are remembered by position
+        slots = ts + [ma, mb, count_dev]
+        ctx.present = [t is not None for t in slots]
+        ctx.save_for_backward(*[t for t in slots if t is not None])
+        ctx.l2 = l2
         ctx.k = [w * d for w, d in zip(weight, inv_denom)]
         ctx.need = ctx.needs_input_grad
         terms = out[:6]
@@ -952,7 +957,9 @@ class Stage2Losses(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
-        rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j = ctx.ts
+        saved = iter(ctx.saved_tensors)
+        slots = [next(saved) if here else None for here in ctx.present]
+        rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, count_dev = slots
         k, ng = ctx.k, ctx.need
         need = set()
         if rgb is not None and ng[0] and k[0] != 0.0: need.add('rgb')
@@ -963,7 +970,7 @@ class Stage2Losses(torch.autograd.Function):
         d = {}
         if need:
             d = hip.stage2_loss_bwd(g_total.reshape(1).contiguous(), rgb, rgb_gt, k[0], alb, alb_j, k[1], wgt, wgt_j, k[2], vis, vis_gt,
-                                    k[3], nrm, nrm_gt, nrm_j, k[4], k[5], ctx.masks[0], ctx.masks[1], ctx.l2, need, ctx.count_dev)
+                                    k[3], nrm, nrm_gt, nrm_j, k[4], k[5], mask_a, mask_b, ctx.l2, need, count_dev)
         g = d.get
         return (g('rgb'), None, g('alb'), g('alb_j'), g('wgt'), g('wgt_j'), g('vis'), None, g('nrm'), None, g('nrm_j'),
                 None, None, None, None, None, None)

@@ -22,6 +22,7 @@ class RowSparseAdam(torch.optim.Optimizer):
         items = []
         for group in self.param_groups:
             b1, b2 = group['betas']
+            assert not group.get('maximize', False), 'RowSparseAdam: maximize is not supported (param_group edited after construction)'
             for p in group['params']:
                 if p.grad is None:
                     continue

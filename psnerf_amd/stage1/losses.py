@@ -15,7 +15,8 @@ class Loss(nn.Module):
         self.device = device
         self.global_sum = None  # callable(int) -> int summed over ranks (set by the DP trainer)
         self.global_count = None  # callable(bool mask) -> device float [1], summed over ranks (sync-free path)
-        self._rays_global = {}    # local ray count -> ray count summed over ranks
+        self.global_rays = None   # callable() -> ray count of the batch BEFORE sharding (set by the DP trainer; arithmetic,
+                                  # identical on every rank: no collective, so ranks cannot diverge on it -- ADVICE r2)
 
     def _g(self, n):
         return n if self.global_sum is None else self.global_sum(n)
@@ -36,11 +37,8 @@ class Loss(nn.Module):
         zero = torch.zeros((), device=dev)  # a fill kernel: torch.tensor(0.0, device=...) is a pageable H2D copy = a stream sync
         rgb_gt = rgb_gt.to(dev)
         if self.full_weight != 0.0:
-            # (the ray count of a shard is fixed by n_training_points and the world size: its global sum is exchanged once)
-            n_local = rgb.shape[1]
-            if n_local not in self._rays_global:
-                self._rays_global[n_local] = self._g(n_local)
-            l_rgb = (rgb - rgb_gt).abs().sum() / float(self._rays_global[n_local])
+            n_rays = rgb.shape[1] if self.global_rays is None else self.global_rays()
+            l_rgb = (rgb - rgb_gt).abs().sum() / float(n_rays)
         else:
             l_rgb = zero
         dev_counts = out_dict.get('diff_norm_full') is not None  # the renderer's sync-free training forward

@@ -36,6 +36,7 @@ class Trainer(object):
         if self.dp.enabled:
             self.loss.global_sum = self.dp.global_sum_int
             self.loss.global_count = self.dp.global_count_tensor
+            self.loss.global_rays = lambda: self.dp.global_rays
         # training forward without host synchronisation (Renderer._unisurf_sync_free); a caller that injects noise or
         # needs the reference-shaped out_dict (compact diff_norm) gets the reference-shaped path
         self.sync_free = bool(kwargs.get('sync_free', True))
@@ -44,7 +45,8 @@ class Trainer(object):
         self.model.train()
         if self.dp.enabled:
             trainable = [p for p in self.model.parameters() if p.requires_grad]
-            self.dp.prepare_grads(trainable)  # one memset; every .grad becomes a view into the flat all-reduce bucket
+            # one memset; every trainable .grad becomes a view into the flat all-reduce bucket, frozen parameters lose theirs
+            self.dp.prepare_grads(list(self.model.parameters()))
         else:
             self.optimizer.zero_grad()
         terms = self.compute_loss(data, it=it, pix=pix, noise=noise)
@@ -116,6 +118,7 @@ class Trainer(object):
             pix = torch.cat([px, py], dim=-1)
         pix = self._upload(pix)
         if self.dp.enabled:
+            noise = self.dp.shard_ray_noise(noise, pix.shape[1])
             pix = self.dp.shard_rays(pix)
         if self.rendering_technique == 'unisurf' and hasattr(self.model, 'prefetch_surface'):
             self.model.prefetch_surface(pix, camera_mat, world_mat)  # the ray-march sweep runs under the host work below

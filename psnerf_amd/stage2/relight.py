@@ -49,7 +49,7 @@ def load_light(path_or_array, light_h=None):
     else:
         arr = np.asarray(path_or_array)
     arr = arr.astype(np.float32)
-    if light_h and arr.shape[0] != light_h:
+    if light_h and tuple(arr.shape[:2]) != (light_h, 2 * light_h):  # eval_utils.py:19 resizes whenever light_h is given
         t = torch.from_numpy(arr).permute(2, 0, 1)[None]
         arr = F.interpolate(t, size=(light_h, 2 * light_h), mode='bilinear', align_corners=False)[0].permute(1, 2, 0).numpy()
     return arr

@@ -154,7 +154,8 @@ class TrainStep(object):
         if self.dp.enabled:
             trainable = [p for p in self.model.parameters() if p.requires_grad] \
                 + ([self.light_para.weight, self.light_inten_para.weight] if train_light else [])
-            self.dp.prepare_grads(trainable)  # one memset; every .grad becomes a view into the flat all-reduce bucket
+            # one memset; every trainable .grad becomes a view into the flat all-reduce bucket, frozen parameters lose theirs
+            self.dp.prepare_grads(list(self.model.parameters()) + [self.light_para.weight, self.light_inten_para.weight])
         else:
             self.sg_optimizer.zero_grad()
             if train_light:

@@ -128,6 +128,26 @@ def _stage1(rank, dev, checks):
     mine = {'miss': full['miss'][:, ms], 'hit': full['hit'][:, hs], 'nbr': full['nbr'][hs]}
     terms = tr.train_step(batch, it=it, pix=pix, noise={k: v.to(dev) for k, v in mine.items()})
     grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+    # The path the Trainer takes by default and the bench times: the SYNC-FREE forward (device-resident counts all-reduced as
+    # tensors, rgb denominator = the pre-shard ray count), jitter ON through per-ray tables made for the WHOLE ray set (the
+    # trainer slices them with the pixels).  Two steps whose global sizes differ while rank 0's shard keeps its size
+    # (129 -> 65 / 64, 130 -> 65 / 65): the rgb denominator used to be cached by local size with the collective skipped on a hit.
+    sf = []
+    net_s, ren_s, tr_s = fresh(pdist.DataParallel(dev))
+    calls = []
+    inner = ren_s._unisurf_sync_free
+    ren_s._unisurf_sync_free = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+    steps = []
+    for j, n_j in enumerate((129, 130)):
+        gen_j = torch.Generator().manual_seed(70 + j)
+        pix_j = torch.stack([torch.randint(0, 64, (n_j,), generator=gen_j).float(),
+                             torch.randint(0, 48, (n_j,), generator=gen_j).float()], -1)[None]
+        nz_j = {'full': torch.rand(n_j, S, generator=gen_j), 'nbr_full': torch.rand(n_j, 3, generator=gen_j)}
+        steps.append((pix_j, nz_j))
+        t_j = tr_s.train_step(batch, it=it + j, pix=pix_j, noise={k: v.to(dev) for k, v in nz_j.items()})
+        sf.append(({k: float(v.detach()) for k, v in t_j.items()}, {k: p.grad.detach().clone() for k, p in net_s.named_parameters()}))
+    assert len(calls) == 2, 'the DP trainer did not take the sync-free forward'
     if rank != 0:
         return
     single = pdist.DataParallel(dev)
@@ -140,6 +160,14 @@ def _stage1(rank, dev, checks):
         checks['stage1 grad ' + k] = (_err(grads[k], p.grad), 1e-4)
     for (k, a), (_, b) in zip(net.state_dict().items(), net1.state_dict().items()):
         checks['stage1 param after step ' + k] = (float((a - b).abs().max().cpu()), 2 * 1e-4 + 1e-6)  # |delta| <= 2 lr (Adam, sign flips at the noise floor)
+    net2, _, tr2 = fresh(single)
+    for j, (pix_j, nz_j) in enumerate(steps):
+        tr2.train_step(batch, it=it + j, pix=pix_j, noise={k: v.to(dev) for k, v in nz_j.items()})
+        for k, p in net2.named_parameters():
+            # (second step: the parameters differ by the first Adam step's sign flips at the noise floor, see below)
+            checks['stage1 sync-free step %d grad %s' % (j, k)] = (_err(sf[j][1][k], p.grad), 1e-4 if j == 0 else 5e-3)
+    for (k, a), (_, b) in zip(net_s.state_dict().items(), net2.state_dict().items()):
+        checks['stage1 sync-free param after 2 steps ' + k] = (float((a - b).abs().max().cpu()), 2 * 2 * 1e-4 + 1e-6)
 
 
 def run(rank, port, out_path):

@@ -148,11 +148,22 @@ def _worker_stage1(rank, world, port, tmp):
     out = _stage1_outputs(theta, sh(x))
     loss = Loss(1.0, 0.1, 0.5, 0.7)
     loss.global_sum = dp.global_sum_int
+    loss.global_rays = lambda: dp.global_rays  # what the DP Trainer wires up: the pre-shard ray count, no collective
     terms = loss(out, sh(rgb_gt), sh(normal_gt), sh(norm_mask), out['acc_map'], sh(mask_gt), sh(mask_valid))
     terms['loss'].backward()
     dp.allreduce_grads([theta])
+    grad1 = theta.grad.clone()
+    # A second batch whose GLOBAL size differs while rank 0's LOCAL size stays the same (203 -> 204 rays: 102 / 101, then
+    # 102 / 102): the rgb denominator used to be cached per local count with the all-reduce skipped on a hit -- rank 0
+    # returned the stale 203 without a collective while rank 1 entered one (a hang).  Now no collective at all.
+    x2, rgb2, ngt2, nm2, mg2, mv2, _ = _stage1_case(204)
+    theta.grad = None
+    out2 = _stage1_outputs(theta, sh(x2))
+    t2 = loss(out2, sh(rgb2), sh(ngt2), sh(nm2), out2['acc_map'], sh(mg2), sh(mv2))
+    t2['loss'].backward()
+    dp.allreduce_grads([theta])
     if rank == 0:
-        torch.save({'grad': theta.grad}, tmp)
+        torch.save({'grad': grad1, 'grad2': theta.grad}, tmp)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -170,6 +181,11 @@ def test_stage1_two_rank_loss_gradients(tmp_path):
     terms = Loss(1.0, 0.1, 0.5, 0.7)(out, rgb_gt, normal_gt, norm_mask, out['acc_map'], mask_gt, mask_valid)
     terms['loss'].backward()
     assert_close(got['grad'], theta.grad, 2e-5, 'stage-1 dp grad')
+    x, rgb_gt, normal_gt, norm_mask, mask_gt, mask_valid, _ = _stage1_case(204)
+    theta = theta0.clone().requires_grad_()
+    out = _stage1_outputs(theta, x)
+    Loss(1.0, 0.1, 0.5, 0.7)(out, rgb_gt, normal_gt, norm_mask, out['acc_map'], mask_gt, mask_valid)['loss'].backward()
+    assert_close(got['grad2'], theta.grad, 2e-5, 'stage-1 dp grad, second batch of a different global size')
 
 
 # ---- flat gradient bucket: views, one memset, a rank without a graph ------------------------------------------
@@ -188,7 +204,7 @@ def _worker_bucket(rank, world, port, tmp):
     for step in range(3):
         train = [p for p in ps if p.requires_grad]
         dp.prepare_grads(train)
-        flat, views = dp._bucket(train)
+        flat, views = dp._bucket(train)[:2]
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(train, views)) and float(flat.abs().sum()) == 0.0
         # rank 1 has "no surface pixel" on step 1: its loss has no graph and it skips backward (trainer behaviour)
         if not (rank == 1 and step == 1):
@@ -198,6 +214,15 @@ def _worker_bucket(rank, world, port, tmp):
         dp.allreduce_grads(train)
         log.append([p.grad.clone() for p in train])
     assert dp.n_allreduce == 3 and ps[2].grad is None
+    # a parameter that is frozen AFTER it received an all-reduced gradient must not keep it (an optimiser would go on
+    # stepping on the stale view; zero_grad() sets it to None in the non-DP path): the trainers hand prepare_grads ALL
+    # their parameters, it drops the gradients of the frozen ones
+    ps[1].requires_grad_(False)
+    dp.prepare_grads(ps)
+    assert ps[1].grad is None and ps[0].grad is not None and ps[2].grad is None
+    (ps[0] * 2.0).sum().backward()
+    dp.allreduce_grads([p for p in ps if p.requires_grad])
+    assert torch.allclose(ps[0].grad, torch.full_like(ps[0], 2.0 * world))
     if rank == 0:
         torch.save({'log': log, 'ps': [p.detach() for p in ps]}, tmp)
     dist.barrier()

@@ -7,7 +7,7 @@ import os
 
 import pytest
 
-from tests.conftest import DP_RESULT
+from tests.conftest import DP_RESULT, SESSION_STAMP
 
 pytestmark = pytest.mark.gpu
 
@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 def test_two_rank_hip_gradients_match_single_rank(cuda):
     assert os.path.exists(DP_RESULT), 'the 2-rank worker left no result: %s' % (
         open(DP_RESULT + '.log').read()[-3000:] if os.path.exists(DP_RESULT + '.log') else 'no log')
+    stamp = open(DP_RESULT + '.stamp').read() if os.path.exists(DP_RESULT + '.stamp') else None
+    assert stamp == SESSION_STAMP, 'stale 2-rank result (written by session %r, this is %r): run with -m gpu' % (stamp, SESSION_STAMP)
     res = json.load(open(DP_RESULT))
     assert res['ok'], json.dumps(res, indent=1)[:4000]
     assert res['n_checks'] > 100

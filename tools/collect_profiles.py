@@ -23,6 +23,23 @@ def counter_rows(path):
     return out
 
 
+def byte_model(ns, L, V):
+    """Byte counts of the dominant launch ((L + V) * ns rows of the fused visibility MLP), stated separately:
+    compulsory  what must cross HBM if every table / weight is read once: U [ns, 512] and V [L + V, 512] init tables, ~2 MB of
+                packed weights, 4 B of output per row, and the 9 x 1 KB activation dumps of the V * ns supervised rows;
+    l2_request  what the waves REQUEST: every row reads its 2 KB U row and its 2 KB V row (L2 / Infinity-Cache hits for all
+                but the first use) + output + dumps.  rocprofv3's FETCH_SIZE counts fabric-side requests incl. Infinity-Cache
+                hits, so the measured figure lies between the two."""
+    rows = (L + V) * ns
+    dumps = V * ns * 9 * 1024
+    return {'compulsory_bytes_per_launch': int(ns * 2048 + (L + V) * 2048 + 2 * 2 ** 20 + rows * 4 + dumps),
+            'compulsory_bytes_note': 'U [Ns, 512] + V [L+V, 512] fp32 tables and ~2 MB of packed weights read once, 4 B out per '
+                                     'row, 9 x 1 KB activation dumps for the V*Ns supervised rows (DESIGN.md 5)',
+            'l2_request_bytes_per_launch': int(rows * (4096 + 4) + dumps),
+            'l2_request_bytes_note': 'per row 2 x 2 KB init-table rows as requested by the waves (cache hits for all but the '
+                                     'first use) + 4 B out; + the dumps'}
+
+
 def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, 'gpurun_out', tag)
@@ -57,11 +74,11 @@ def main():
         'FETCH_SIZE_KB_raw': f_kb, 'WRITE_SIZE_KB_raw': w_kb,
     }
     if f_kb is not None and w_kb is not None:
-        res['mlp_infer_kernel_bytes_per_launch'] = int(2 * f_kb * 1024 + w_kb * 1024)
+        res['hbm_side_bytes_per_launch'] = int(2 * f_kb * 1024 + w_kb * 1024)
     ns, L, V = bench['config']['surface_pixels_total'], bench['config']['lights'], bench['config']['vis_lights']
-    res['algorithmic_bytes_per_launch'] = int((L + V) * ns * (4096 + 4) + V * ns * 9 * 1024)
-    res['algorithmic_bytes_note'] = ('per row 2 x 2 KB init-table rows (U[point], V[light]; L2 / Infinity-Cache hits for all but the '
-                                     'first use) + 4 B output; the V*Ns supervised rows also dump 9 x 1 KB of activations')
+    res.update(byte_model(ns, L, V))
+    if res.get('hbm_side_bytes_per_launch'):
+        res['traffic_over_compulsory'] = round(res['hbm_side_bytes_per_launch'] / res['compulsory_bytes_per_launch'], 2)
     mb = [(v.get('SQ_VALU_MFMA_BUSY_CYCLES'), v.get('GRBM_GUI_ACTIVE')) for (d, k), v in busy.items() if 'mlp_infer_kernel<false' in k]
     mb = [x for x in mb if x[0] and x[1]]
     if mb:
