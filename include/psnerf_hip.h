@@ -309,6 +309,18 @@ int psn_shadow_points(const float* surf, const float* ldir, int64_t n_surf, int 
 int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* points, int64_t n_rows,
                      int pe_octaves, float pe_scale, float* out, void* stream);
 
+/* Ray-march sweep, stage1/model/rendering.py:447-462 (+ the early termination its consumer :472-504 allows): the occupancy
+ * sigmoid(-10 logit) of n_steps proposal points per ray, p = origin + dir * (near (1 - u_m) + far u_m), generated and
+ * encoded inside the kernel -- no [n_rays, n_steps, 3] point tensor, same bits as psn_sample_points + psn_mlp_infer_pe.
+ * One workgroup = 64 consecutive steps of one ray (n_steps % 64 == 0), workgroups in block-major order.  skip: int32
+ * [n_rays], ZEROED by the caller, or NULL: a block that contains a sign change of (occ - tau) between neighbouring steps
+ * (or a ray whose first value is not free) raises the ray's flag and the ray's later blocks are not evaluated -- their
+ * entries of occ stay untouched; every value up to and including the pair of the FIRST sign change is always written,
+ * which is all psn_first_crossing reads.  desc / packed_w / packed_b as for psn_root_find.  occ [n_rays, n_steps]. */
+int psn_march_sweep(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* origin, const float* dir,
+                    const float* far, const float* u, const float* omu, float near, int64_t n_rays, int n_steps, float tau,
+                    int pe_octaves, float pe_scale, int* skip, float* occ, void* stream);
+
 /* Fused secant refinement, stage1/model/rendering.py:525-555: n_iter regula-falsi iterations for every ray inside ONE
  * launch -- query point origin + d_pred * dir, its positional encoding (pe_octaves bands, input scaled by pe_scale), the
  * occupancy network (desc / packed_w / packed_b as for psn_mlp_infer: 256-wide, one output, PSN_OUT_OCC, input block =

@@ -68,6 +68,13 @@ struct InferArgs {
     const float* bracket;    // [4, n_rows]: d_low, d_high, f_low, f_high
     float tau, pe_scale;
     int n_iter, pe_octaves;
+    // SRC == 3 (ray-march sweep, psn_march_sweep): the rows are (ray, step) pairs, the query point is generated in the kernel
+    const float* far;        // [n_rays] sphere exit depth
+    const float* u;          // [n_steps] linspace(0, 1, n_steps)
+    const float* omu;        // [n_steps] 1 - u
+    float near;
+    int n_steps;
+    int* skip;               // [n_rays] or nullptr: != 0 = an earlier block of this ray already holds its first sign change
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -310,6 +317,13 @@ __device__ __forceinline__ void wait_for_weights(int stores) {
 // one update launch per iteration, and a host synchronisation to compact the hit rays first).  A ray's iterations
 // depend on nothing but the ray, so no inter-workgroup exchange is needed; the launch is latency-bound (one
 // workgroup per 64 rays) and costs about one serial pass through the network per iteration.
+// SRC = 3: the ray-march sweep of stage1/model/rendering.py:447-462 (psn_march_sweep): row = (ray, step), a workgroup = the
+// 64 consecutive steps of ONE ray (block b of the ray), workgroups in BLOCK-MAJOR order (block 0 of every ray first).  The
+// point ray0 + dir * (near (1 - u_m) + far u_m) is formed in the prologue (the expressions of sample_points_kernel, bit-identical)
+// and encoded as for SRC = 2.  The reference's result depends only on the values up to the FIRST sign change of a ray
+// (rendering.py:472-504): a block that contains one (or a ray that starts inside the object) raises the ray's flag, and the
+// workgroups of the ray's later blocks -- dispatched thousands of workgroups later -- leave in their prologue.  The flag is a
+// hint: only pairs inside one block are examined, whoever misses it evaluates values that nothing reads.
 // TRIM: some layer reads one activation k-tile fewer than the width (a separate instantiation: the conditional last stage costs
 // the untrimmed visibility launch 0.7 %).
 template <bool CHAIN, int NMT, int SRC = 0, bool TRIM = false>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
@@ -325,7 +339,19 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: keeps the LDS-DMA bases in SGPRs
     const int lj = lane & 15, lg = lane >> 4;
-    const int64_t row = (int64_t)blockIdx.x * (kWaves * 16) + wave * 16 + lj;
+    int64_t row_ = (int64_t)blockIdx.x * (kWaves * 16) + wave * 16 + lj;
+    int64_t m_ray = 0;  // SRC == 3: this workgroup's ray and the step of this lane's row
+    int m_step = 0;
+    if constexpr (SRC == 3) {
+        const int64_t n_rays = g.n_rows / g.n_steps;
+        m_ray = (int64_t)blockIdx.x % n_rays;
+        const int blk = (int)((int64_t)blockIdx.x / n_rays);
+        // (agent scope: the flag was raised by a workgroup that may have run on another XCD, whose L2 is not coherent with ours)
+        if (blk > 0 && g.skip != nullptr && __hip_atomic_load(g.skip + m_ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        m_step = blk * (kWaves * 16) + wave * 16 + lj;
+        row_ = m_ray * g.n_steps + m_step;
+    }
+    const int64_t row = row_;
     const int64_t rowc = row < g.n_rows ? row : g.n_rows - 1;
     const int n_layers = g.d.n_layers;
 
@@ -457,8 +483,17 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     // live, so the branchy sinf / cosf code has the whole register file -- and the 64 columns stay in 16 registers for the
     // layers that consume them (layer 0 and the skip layer), which the 232-register lean loop has room for.
     floatx4 xq[4];
-    if constexpr (SRC == 2) {
-        qx = g.ray_o[rowc * 3 + 0]; qy = g.ray_o[rowc * 3 + 1]; qz = g.ray_o[rowc * 3 + 2];
+    if constexpr (SRC == 2 || SRC == 3) {
+        if constexpr (SRC == 3) {
+            // sample_points_kernel (csrc/sample.hip), miss profile: d = near (1 - u) + far u, p = origin + dir d; products and
+            // sums rounded separately (-ffp-contract=off), so the point has the bits of the table the two-launch path wrote
+            const float d = g.near * g.omu[m_step] + g.far[m_ray] * g.u[m_step];
+            qx = g.ray_o[m_ray * 3 + 0] + g.ray_d[m_ray * 3 + 0] * d;
+            qy = g.ray_o[m_ray * 3 + 1] + g.ray_d[m_ray * 3 + 1] * d;
+            qz = g.ray_o[m_ray * 3 + 2] + g.ray_d[m_ray * 3 + 2] * d;
+        } else {
+            qx = g.ray_o[rowc * 3 + 0]; qy = g.ray_o[rowc * 3 + 1]; qz = g.ray_o[rowc * 3 + 2];
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) xq[t] = compute_xin_tile(t);
 #pragma unroll
@@ -539,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         }
         if constexpr (SRC != 0) {
             if (L.n_kt_in > 0) {  // == 2 (host check): the 64-column encoding
-                if constexpr (SRC == 2) {
+                if constexpr (SRC == 2 || SRC == 3) {
                     PSN_STAGE(NMT, xq[0], xq[1], L.n_kt_act)
                     PSN_STAGE(NMT, xq[2], xq[3], L.n_kt_act + 1)
                 } else {
@@ -717,6 +752,20 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                     else if (g.d.out_act == PSN_OUT_OCC) v = sigmoidf_(v * -10.0f);
                     g.out[row * n_out + f] = v;
                 }
+            }
+        }
+    }
+    if constexpr (SRC == 3) {
+        if (g.skip != nullptr) {
+            // val_m = occupancy - tau of this block's 64 steps (first_crossing_kernel's expression), exchanged through LDS (behind
+            // the bias block: nothing else lives there); a negative product of neighbours = the ray's first sign change lies in
+            // this block or before it, and a ray whose first value is not free is decided as well (rendering.py:466,522)
+            float* xch = bias_lds + PSN_MLP_MAX_LAYERS * 256;
+            if (lg == 0) xch[wave * 16 + lj] = sigmoidf_(acc[0][0] * -10.0f) - g.tau;
+            __syncthreads();
+            if (tid < kWaves * 16 - 1) {
+                const bool hit = (xch[tid] * xch[tid + 1] < 0.0f) || (tid == 0 && m_step == 0 && !(xch[0] < 0.0f));
+                if (hit) __hip_atomic_store(g.skip + m_ray, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1120,6 +1169,47 @@ extern "C" int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, c
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
     hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 2, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer_pe");
+    return PSN_OK;
+}
+
+// Ray-march sweep (stage1/model/rendering.py:447-462): the occupancy of n_steps proposal points per ray, points generated and
+// encoded in the kernel (no [N, M, 3] point tensor), with early termination behind a ray's first sign change when `skip`
+// (int32 [n_rays], ZEROED by the caller) is given.  occ [n_rays, n_steps]: every value up to and including the pair of the
+// first sign change is written -- exactly the values psn_first_crossing reads; values of skipped blocks are left untouched.
+extern "C" int psn_march_sweep(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* origin,
+                               const float* dir, const float* far, const float* u, const float* omu, float near, int64_t n_rays,
+                               int n_steps, float tau, int pe_octaves, float pe_scale, int* skip, float* occ, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(desc && packed_w && packed_b && origin && dir && far && u && omu && occ, "march_sweep: null pointer");
+    const PsnMlpDesc& d = *desc;
+    PSN_CHECK_ARG(d.n_layers >= 2 && d.n_layers <= PSN_MLP_MAX_LAYERS && d.n_out == 1 && d.out_act == PSN_OUT_OCC,
+                  "march_sweep: expects an occupancy network (one output, PSN_OUT_OCC)");
+    PSN_CHECK_ARG(d.in_kt_a == 2 && d.in_kt_b == 0 && 3 + 6 * pe_octaves <= 64 && pe_octaves >= 0,
+                  "march_sweep: the input block is one 64-column positional encoding (in_kt_a = 2), got in_kt_a=%d octaves=%d", d.in_kt_a, pe_octaves);
+    PSN_CHECK_ARG(d.layers[0].n_kt_in == 2 && d.layers[0].n_kt_act == 0, "march_sweep: layer 0 reads the encoding as k-tiles");
+    for (int l = 0; l < d.n_layers; ++l) {
+        const PsnMlpLayer& L = d.layers[l];
+        const bool last = l == d.n_layers - 1;
+        PSN_CHECK_ARG(L.n_mt == (last ? 1 : 8) && L.init_off < 0, "march_sweep: layer %d: 256-wide hidden layers without init tables only", l);
+        PSN_CHECK_ARG(L.act == PSN_ACT_SOFTPLUS100 || L.act == PSN_ACT_RELU || L.act == PSN_ACT_NONE, "march_sweep: layer %d activation", l);
+        PSN_CHECK_ARG(L.b_off == (int64_t)l * 256, "march_sweep: biases must be packed back to back");
+        PSN_CHECK_ARG(L.n_kt_in == 0 || L.n_kt_in == 2, "march_sweep: layer %d n_kt_in=%d", l, L.n_kt_in);
+        PSN_CHECK_ARG(last ? (L.n_kt_act == 8 && L.n_kt_in == 0) : (L.n_kt_act == 0 || L.n_kt_act == 7 || L.n_kt_act == 8), "march_sweep: layer %d n_kt_act=%d", l, L.n_kt_act);
+        PSN_CHECK_ARG(L.n_kt_in + L.n_kt_act >= 1, "march_sweep: layer %d has no input", l);
+    }
+    PSN_CHECK_ARG(n_steps >= 64 && n_steps % (kWaves * 16) == 0, "march_sweep: n_steps=%d must be a multiple of 64 (one workgroup = 64 steps of one ray)", n_steps);
+    if (n_rays <= 0) return PSN_OK;
+    InferArgs a = {};
+    a.d = d; a.w = packed_w; a.b = packed_b; a.a_div = 1; a.a_mod = 1; a.b_div = 1; a.b_mod = 1; a.n_rows = n_rays * n_steps; a.out = occ;
+    a.n_bias = (d.n_layers - 1) * 256 + 32;
+    a.ray_o = origin; a.ray_d = dir; a.far = far; a.u = u; a.omu = omu; a.near = near; a.n_steps = n_steps; a.skip = skip; a.tau = tau;
+    a.pe_scale = pe_scale; a.pe_octaves = pe_octaves;
+    for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) { a.save_tiles[l] = 0xFFFFFFFFu; a.save2_tiles[l] = 0xFFFFFFFFu; }
+    const int64_t blocks = n_rays * (n_steps / (kWaves * 16));
+    PSN_CHECK_ARG(blocks < (1ll << 31), "march_sweep: too many rows");
+    const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256 + kWaves * 16) * sizeof(float);
+    hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 3, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("march_sweep");
     return PSN_OK;
 }
 

@@ -117,6 +117,7 @@ SIGNATURES = {
     'psn_shadow_points': (i32, [c_f, c_f, i64, i32, i32, f32, f32, c_f, c_f, f32, c_f, c_f, c_f, c_f]),
     'psn_mlp_infer_pe': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i32, f32, c_f, c_f]),
     'psn_root_find': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, i64, f32, i32, i32, f32, c_f, c_f]),
+    'psn_march_sweep': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, i64, i32, f32, i32, f32, c_f, c_f, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_mlp_pack_bf16': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
@@ -446,6 +447,25 @@ def mlp_infer_pe(desc, packed_w, packed_b, points, pe_octaves, pe_scale, out=Non
         _check(_lib.psn_mlp_infer_pe(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'), _ptr(points, 'points'),
                                      Q, int(pe_octaves), float(pe_scale), out.data_ptr(), _stream()), 'mlp_infer_pe')
     return out
+
+
+def march_sweep(desc, packed_w, packed_b, origin, direction, far, u, omu, near, n_steps, tau, pe_octaves, pe_scale,
+                early_exit=True, macs_per_row=None):
+    """Occupancy of the n_steps sweep points of every ray (psn_march_sweep) -> (occ [N, n_steps], skip flags [N] int32 or None).
+    early_exit: blocks of 64 steps behind a ray's first sign change are not evaluated (their occ entries are uninitialised)."""
+    N = origin.shape[0]
+    assert origin.shape == (N, 3) and direction.shape == (N, 3) and far.shape == (N,) and u.numel() == n_steps == omu.numel()
+    occ = torch.empty(N, n_steps, device=origin.device, dtype=torch.float32)
+    skip = torch.zeros(N, device=origin.device, dtype=torch.int32) if early_exit else None
+    if N == 0:
+        return occ, skip
+    Q = N * n_steps
+    with _Prof('mlp_infer', Q, None if macs_per_row is None else 2.0 * macs_per_row * Q):
+        _check(_lib.psn_march_sweep(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'), _ptr(origin, 'origin'),
+                                    _ptr(direction, 'direction'), _ptr(far, 'far'), _ptr(u, 'u'), _ptr(omu, 'omu'), float(near), N,
+                                    int(n_steps), float(tau), int(pe_octaves), float(pe_scale),
+                                    None if skip is None else skip.data_ptr(), occ.data_ptr(), _stream()), 'march_sweep')
+    return occ, skip
 
 
 def root_find(desc, packed_w, packed_b, origin, direction, bracket, tau, n_iter, pe_octaves, pe_scale):

@@ -120,6 +120,8 @@ class Renderer(nn.Module):
         return self._finish(state, n_secant_steps)
 
     COMPACT_SECANT = False  # True: the round-1 secant (host-synchronised compaction + per-iteration launches)
+    FUSED_SWEEP = True      # False: the two-launch sweep (psn_sample_points + psn_mlp_infer_pe on an [N, M, 3] point tensor)
+    EARLY_EXIT = True       # False: every block of every ray is evaluated (the dense sweep; bit-identity tests)
 
     def _finish(self, state, n_secant_steps):
         return self._march_finish_compact(state, n_secant_steps) if self.COMPACT_SECANT else self._march_finish(state, n_secant_steps)
@@ -132,12 +134,24 @@ class Renderer(nn.Module):
         dev = ray0.device
         n_steps = int(n_steps[0])  # the reference draws randint(n, n+1): a constant
         far = sphere_intersection(ray0[:, 0], ray_direction, r=rad)[0][..., 1].contiguous()
-        # sweep points ray0 + dir * (near (1 - t) + far t), t = linspace(0, 1, n_steps): one launch (csrc/sample.hip)
         u = self._u(n_steps, dev)
-        p_prop = torch.empty(B * N, n_steps, 3, device=dev)
-        hip.sample_points(ray0.reshape(-1, 3).contiguous(), ray_direction.reshape(-1, 3).contiguous(),
-                          far.reshape(-1), p_prop, False, float(depth_range[0]), u)
-        occ = self._occ(p_prop.reshape(-1, 3)).view(B * N, n_steps)
+        m = self.model
+        if (self.FUSED_SWEEP and not clip and n_steps % 64 == 0 and ray0.is_cuda and hasattr(m, '_occupancy_packed')
+                and m._hidden_is_256()):
+            # one launch: sweep points generated and encoded in the occupancy kernel, a workgroup = 64 consecutive steps of
+            # one ray, and the blocks behind a ray's first sign change are not evaluated (psn_march_sweep; the reference's
+            # result depends on nothing behind it, rendering.py:472-504)
+            packed = m._occupancy_packed()
+            occ, _ = hip.march_sweep(packed.desc, packed.w, packed.b, ray0.reshape(-1, 3).contiguous(),
+                                     ray_direction.reshape(-1, 3).contiguous(), far.reshape(-1), u[0], u[1], float(depth_range[0]),
+                                     n_steps, tau, m.octaves_pe, 1.0 / m.rescale, early_exit=self.EARLY_EXIT,
+                                     macs_per_row=getattr(packed, 'macs_per_row', None))
+        else:
+            # sweep points ray0 + dir * (near (1 - t) + far t), t = linspace(0, 1, n_steps): one launch (csrc/sample.hip)
+            p_prop = torch.empty(B * N, n_steps, 3, device=dev)
+            hip.sample_points(ray0.reshape(-1, 3).contiguous(), ray_direction.reshape(-1, 3).contiguous(),
+                              far.reshape(-1), p_prop, False, float(depth_range[0]), u)
+            occ = self._occ(p_prop.reshape(-1, 3)).view(B * N, n_steps)
         if clip:
             pp4 = p_prop.view(B * N, n_steps, 3)
             occ = occ.clone()

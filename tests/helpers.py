@@ -59,6 +59,9 @@ def rel_err(a, b):
 # that corresponds to ITS arithmetic, not a looser one:
 ATOL_UNIT = 1e-6    # quantities in [0, 1] or of unit length: rgb, albedo, alpha / occupancy, acc, visibility, normals
 ATOL_LOGIT = 1e-5   # raw MLP outputs of magnitude O(1..10): logits, features, d occ / d p, SG lobe weights
+ATOL_NORMAL = 1e-5  # stage-1 surface normals: unit vectors evaluated AT the root-found surface point, whose depth two fp32
+                    # evaluations find to ~2e-6 (ATOL_DEPTH allows 1e-4): the normal inherits curvature x that offset (the
+                    # encoding has octaves up to 2^5) on top of its own 1e-6 arithmetic floor
 ATOL_DEPTH = 1e-4   # ray depths d in [28, 35] found by root-finding on an fp32 network (1 ulp of d = 2-4e-6; the secant
                     # update divides by f_high - f_low, which amplifies 1e-6 differences of the occupancy)
 

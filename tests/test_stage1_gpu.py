@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import (ATOL_DEPTH, ATOL_LOGIT, ATOL_UNIT, COMPUTE_LOSS_CASES, GOLDEN, assert_close, compute_loss_case, grad_digest,
+from tests.helpers import (ATOL_DEPTH, ATOL_LOGIT, ATOL_NORMAL, ATOL_UNIT, COMPUTE_LOSS_CASES, GOLDEN, assert_close, compute_loss_case, grad_digest,
                            stage1_state_dict, state_dict_digest, stage1_cfg)
 
 pytestmark = pytest.mark.gpu
@@ -281,7 +281,7 @@ def test_sync_free_forward_with_jitter_vs_oracle(cuda, it):
                                noise=sync_free_noise_for_reference(noise, hit))
     assert torch.equal(o['mask_pred'], hit)
     for k in ('rgb', 'normal_pred', 'acc_map'):
-        assert_close(out[k].detach().cpu(), o[k].detach(), 1e-4, k, atol=ATOL_UNIT)
+        assert_close(out[k].detach().cpu(), o[k].detach(), 1e-4, k, atol=ATOL_NORMAL if k == 'normal_pred' else ATOL_UNIT)
     # diff_norm is a difference of nearly equal unit normals: compare on the normals' scale (1.0)
     assert float((out['diff_norm_full'].detach().cpu()[hit] - o['diff_norm'].detach()).abs().max()) < 1e-4
     terms = Loss(1.0, 0.005, 0.05, 1.0, device=cuda)(out, rgb_gt.to(cuda), ngt.to(cuda), nmask.to(cuda))
@@ -454,6 +454,67 @@ def test_root_finder_and_crossing_vs_stepwise_formulation(cuda):
     assert torch.equal(d_step == 0, d_fused == 0)
     assert_close(d_fused[fin].cpu(), d_step[fin].cpu(), 1e-6, 'fused vs step-by-step secant', atol=1e-6)
     assert torch.equal(d_fused, d_rowpar), 'feature-parallel vs row-parallel root finder'
+
+
+@pytest.mark.parametrize('n_steps,n', [(256, 333), (512, 200), (64, 70), (256, 4096)])
+def test_march_sweep_with_early_exit_is_bit_identical(cuda, n_steps, n):
+    """psn_march_sweep (sweep points generated + encoded in the occupancy kernel, one workgroup = 64 steps of one ray,
+    blocks behind a ray's first sign change not evaluated) against the two-launch dense sweep (psn_sample_points on an
+    [N, M, 3] tensor + psn_mlp_infer_pe): identical occupancies where both evaluate, and -- what the reference's result
+    depends on, rendering.py:472-523 -- bit-identical brackets, masks and refined depths."""
+    from psnerf_amd import hip
+    from psnerf_amd.stage1.rendering import camera_origin, pixel_rays
+    from psnerf_amd.synthetic import stage1_camera
+    cfg, net, ren = _renderer(cuda)
+    h, w = 48, 64
+    K, c2w, S = stage1_camera(cfg, h=h, w=w)
+    gen = torch.Generator().manual_seed(n_steps + n)
+    pix = torch.stack([torch.randint(0, w, (n,), generator=gen).float(), torch.randint(0, h, (n,), generator=gen).float()], -1)[None].to(cuda)
+    cam = camera_origin(n, c2w.to(cuda))
+    rays = pixel_rays(pix, K.to(cuda), c2w.to(cuda))
+    rays = rays / rays.norm(2, 2).unsqueeze(-1)
+    args = (cam, rays, 0.5, [n_steps, n_steps + 1], ren.depth_range, cfg['rendering']['radius'], False)
+    with torch.no_grad():
+        ren.FUSED_SWEEP = False
+        st_ref = ren._march_launch(*args)
+        d_ref = ren._march_finish(st_ref, 8)
+        ren.FUSED_SWEEP, ren.EARLY_EXIT = True, False
+        st_dense = ren._march_launch(*args)
+        ren.EARLY_EXIT = True
+        st = ren._march_launch(*args)
+        d = ren._march_finish(st, 8)
+        # the occupancies themselves: the fused sweep without early exit == the two-launch sweep, bit for bit
+        packed = net._occupancy_packed()
+        u = ren._u(n_steps, cuda)
+        far = st['far'].reshape(-1)
+        occ_dense, _ = hip.march_sweep(packed.desc, packed.w, packed.b, cam.reshape(-1, 3).contiguous(), rays.reshape(-1, 3).contiguous(),
+                                       far, u[0], u[1], float(ren.depth_range[0]), n_steps, 0.5, net.octaves_pe, 1.0 / net.rescale,
+                                       early_exit=False)
+        p_prop = torch.empty(n, n_steps, 3, device=cuda)
+        hip.sample_points(cam.reshape(-1, 3).contiguous(), rays.reshape(-1, 3).contiguous(), far, p_prop, False, float(ren.depth_range[0]), u)
+        occ_two = ren._occ(p_prop.reshape(-1, 3)).view(n, n_steps)
+        occ_early, skip = hip.march_sweep(packed.desc, packed.w, packed.b, cam.reshape(-1, 3).contiguous(), rays.reshape(-1, 3).contiguous(),
+                                          far, u[0], u[1], float(ren.depth_range[0]), n_steps, 0.5, net.octaves_pe, 1.0 / net.rescale,
+                                          early_exit=True)
+    assert torch.equal(occ_dense, occ_two)
+    for key in ('bracket', 'flags'):
+        assert torch.equal(st_ref[key], st_dense[key]) and torch.equal(st_ref[key], st[key]), key
+    assert torch.equal(d_ref, d)
+    hits = (st['flags'] & 1).bool()
+    assert int(hits.sum()) > 10 and int((~hits).sum()) > 10
+    # every value up to and including the pair of the first sign change equals the dense sweep; rays with a sign change (or
+    # an occupied first point) raised their flag unless the change straddles two 64-step blocks
+    val = occ_dense - 0.5
+    neg = (val[:, :-1] * val[:, 1:]) < 0
+    first = torch.where(neg.any(1), neg.float().argmax(1), torch.full((n,), n_steps - 2, device=cuda, dtype=torch.long))
+    cols = torch.arange(n_steps, device=cuda)[None]
+    needed = cols <= (first[:, None] + 1)
+    needed &= (val[:, :1] < 0) | (cols < 64)  # a ray that starts inside the object is decided by its first block (rendering.py:522)
+    assert torch.equal(occ_early[needed], occ_dense[needed])
+    in_block = neg.any(1) & ((first % 64) != 63)
+    assert bool((skip[in_block] != 0).all())
+    if n_steps > 64:
+        assert int((skip != 0).sum()) > 0
 
 
 def test_shadow_ray_compaction_is_bit_identical(cuda):
