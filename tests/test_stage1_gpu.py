@@ -360,7 +360,7 @@ def test_shape_extract_golden(cuda):
     out = ren(pix, T(g['K'], cuda), T(g['c2w'], cuda), torch.eye(4, device=cuda)[None], 'shape_extract', visibility=True,
               light_dir=T(g['ldir'], cuda))
     assert np.array_equal(out['mask'].cpu().numpy(), g['mask'])
-    assert_close(out['normal'].cpu(), g['normal'], 1e-4, 'normal', atol=ATOL_UNIT)
+    assert_close(out['normal'].cpu(), g['normal'], 1e-4, 'normal', atol=ATOL_NORMAL)
     assert_close(out['points'].cpu(), g['points'], 1e-4, 'points', atol=ATOL_DEPTH)
     assert_close(out['visibility'].cpu(), g['visibility'], 1e-4, 'visibility', atol=ATOL_UNIT)
 
@@ -379,6 +379,9 @@ def test_compute_loss_golden(cuda, tag):
     terms = tr.compute_loss(data, eval_mode=eval_mode, it=it, pix=pix, noise={k: v.to(cuda) for k, v in noise.items()})
     assert sorted(terms) == [str(k) for k in g[tag + '_loss_names']]
     for k, v in zip(g[tag + '_loss_names'], g[tag + '_loss_vals']):
+        if float(v) == 0.0:  # eval_mode: no smoothness term at all (diff_norm is None, losses.py:41-44)
+            assert float(terms[str(k)].detach()) == 0.0, k
+            continue
         assert_close(float(terms[str(k)].detach()), v, 1e-3 if str(k) == 'grad_loss' else 1e-4, str(k), atol=0.0)
     terms['loss'].backward()
     names, norms, projs = grad_digest({k: v.grad for k, v in net.named_parameters()})
