@@ -377,6 +377,40 @@ typedef struct {
 int psn_row_adam(int n_items, const PsnRowAdamItem* items, const int64_t* idx, int n_idx, void* stream);
 
 /* ------------------------------------------------------------------------
+ * The launch-bound tail of a stage-2 train step as single kernels (csrc/small.hip).
+ *
+ * psn_normalize_rows_{fwd,bwd}: torch.nn.functional.normalize(x, p=2, dim=-1, eps) of [n, 3] rows, y = x / max(|x|, eps),
+ *   and autograd's backward of it (div -> clamp_min -> norm); stage2/model/renderer.py:129,137 (the predicted normals).
+ * psn_light_rows_{fwd,bwd}: the light-table lookups of a step, stage2/trainer.py:376-379: dir_out [n_idx, 3] =
+ *   normalize(dir_table[idx]), int_out [n_idx] = int_table[idx] (int_table / int_out may both be NULL).  Backward writes
+ *   the DENSE table gradients d_dir_table [n_rows, 3], d_int_table [n_rows] (every row: zeros where untouched, duplicate
+ *   indices summed in list order -- what nn.Embedding(sparse=False) + F.normalize produce); a NULL gradient pair is skipped.
+ * psn_camera_rays: stage2/utils/rend_util.py:90-147 for a 4 x 4 pose: out[i] = scale * normalize(R [(u - cx) / fx,
+ *   (v - cy) / fy, 1]) for pixel idx[i] (idx NULL: pixel i) of uv [N, 2]; pose / intrinsics: 16 floats each, row-major, on
+ *   the device.
+ * psn_adam_flat: torch.optim.Adam's update (torch/optim/adam.py::_multi_tensor_adam; amsgrad off, weight_decay 0;
+ *   stage2/trainer.py:126-133) over ranges of one flat parameter / gradient / exp_avg / exp_avg_sq allocation:
+ *   m += (1 - beta1)(g - m); v = v beta2 + (1 - beta2) g g; p += neg_step_size * m / (sqrt(v) / bias_correction2_sqrt + eps),
+ *   neg_step_size = -lr / (1 - beta1^t) per range (parameters that joined the optimisation later have their own t).
+ * ---------------------------------------------------------------------- */
+int psn_normalize_rows_fwd(const float* x, int64_t n, float eps, float* y, void* stream);
+int psn_normalize_rows_bwd(const float* x, const float* g, int64_t n, float eps, float* dx, void* stream);
+int psn_light_rows_fwd(const float* dir_table, const float* int_table, const int64_t* idx, int n_idx, float eps, float* dir_out,
+                       float* int_out, void* stream);
+int psn_light_rows_bwd(const float* dir_table, const int64_t* idx, int n_idx, int64_t n_rows, float eps, const float* g_dir,
+                       const float* g_int, float* d_dir_table, float* d_int_table, void* stream);
+int psn_camera_rays(const float* uv, const float* pose, const float* intrinsics, const int64_t* idx, int64_t n, float scale,
+                    float* out, void* stream);
+#define PSN_ADAM_MAX_SEGS 16
+typedef struct {
+    int64_t offset, grad_offset, n;    /* elements [offset, offset + n) of param / exp_avg / exp_avg_sq, [grad_offset, ..+n) of grad */
+    float neg_step_size;               /* -lr / (1 - beta1^t) */
+    float bias_correction2_sqrt;       /* sqrt(1 - beta2^t) */
+} PsnAdamSeg;
+int psn_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n_segs, const PsnAdamSeg* segs,
+                  float one_minus_beta1, float beta2, float one_minus_beta2, float eps, void* stream);
+
+/* ------------------------------------------------------------------------
  * Weight normalisation of up to PSN_WN_MAX_ITEMS layers in one launch: nn.utils.weight_norm(nn.Linear) as used by every
  * layer of stage1/model/network.py:37-66 (state_dict keys weight_g [rows,1], weight_v [rows,cols]).
  *   fwd: w = v * (g / |v|_row) [* scale]       (scale = 1/sqrt(2) folds the cat[x, pe]/sqrt(2) of network.py:90-91)

@@ -69,6 +69,13 @@ class PsnGemmTnItem(ctypes.Structure):
                 ('B_tab2', ctypes.c_void_p), ('ldb_tab2', i64), ('b2_div', i64), ('b2_mod', i64), ('b_split', i32), ('k_rows', i64)]
 
 
+class PsnAdamSeg(ctypes.Structure):
+    _fields_ = [('offset', i64), ('grad_offset', i64), ('n', i64), ('neg_step_size', f32), ('bias_correction2_sqrt', f32)]
+
+
+ADAM_MAX_SEGS = 16
+
+
 class PsnRowAdamItem(ctypes.Structure):
     _fields_ = [('param', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p), ('exp_avg_sq', ctypes.c_void_p),
                 ('rows', i64), ('cols', i32), ('one_minus_beta1', f32), ('one_minus_beta2', f32), ('eps', f32), ('step_size', f32)]
@@ -118,6 +125,12 @@ SIGNATURES = {
     'psn_mlp_infer_pe': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i32, f32, c_f, c_f]),
     'psn_root_find': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, i64, f32, i32, i32, f32, c_f, c_f]),
     'psn_march_sweep': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, i64, i32, f32, i32, f32, c_f, c_f, c_f]),
+    'psn_normalize_rows_fwd': (i32, [c_f, i64, f32, c_f, c_f]),
+    'psn_normalize_rows_bwd': (i32, [c_f, c_f, i64, f32, c_f, c_f]),
+    'psn_light_rows_fwd': (i32, [c_f, c_f, c_f, i32, f32, c_f, c_f, c_f]),
+    'psn_light_rows_bwd': (i32, [c_f, c_f, i32, i64, f32, c_f, c_f, c_f, c_f, c_f]),
+    'psn_camera_rays': (i32, [c_f, c_f, c_f, c_f, i64, f32, c_f, c_f]),
+    'psn_adam_flat': (i32, [c_f, c_f, c_f, c_f, i32, ctypes.c_void_p, f32, f32, f32, f32, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_mlp_pack_bf16': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
@@ -418,6 +431,75 @@ def row_adam(items, idx):
         e.rows, e.cols, e.one_minus_beta1, e.one_minus_beta2, e.eps, e.step_size = p2.shape[0], p2.shape[1], 1 - b1, 1 - b2, eps, ss
     assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()
     _check(_lib.psn_row_adam(len(items), ctypes.addressof(arr), idx.data_ptr(), idx.numel(), _stream()), 'row_adam')
+
+
+def normalize_rows_fwd(x, eps=1e-12):
+    """F.normalize(x, dim=-1) for [n, 3] rows in one launch."""
+    assert x.dim() == 2 and x.shape[1] == 3 and x.is_contiguous()
+    y = torch.empty_like(x)
+    _check(_lib.psn_normalize_rows_fwd(_ptr(x, 'x'), x.shape[0], float(eps), y.data_ptr(), _stream()), 'normalize_rows_fwd')
+    return y
+
+
+def normalize_rows_bwd(x, g, eps=1e-12):
+    assert x.shape == g.shape and x.shape[1] == 3 and x.is_contiguous() and g.is_contiguous()
+    dx = torch.empty_like(x)
+    _check(_lib.psn_normalize_rows_bwd(_ptr(x, 'x'), _ptr(g, 'g'), x.shape[0], float(eps), dx.data_ptr(), _stream()), 'normalize_rows_bwd')
+    return dx
+
+
+def light_rows_fwd(dir_table, int_table, idx, eps=1e-12):
+    """(normalize(dir_table[idx]) [L, 3], int_table[idx] [L, 1] or None) in one launch (stage2/trainer.py:376-379)."""
+    L = idx.shape[0]
+    assert dir_table.dim() == 2 and dir_table.shape[1] == 3 and dir_table.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous()
+    d = torch.empty(L, 3, device=dir_table.device, dtype=torch.float32)
+    it = None
+    if int_table is not None:
+        assert int_table.shape == (dir_table.shape[0], 1) and int_table.is_contiguous()
+        it = torch.empty(L, 1, device=dir_table.device, dtype=torch.float32)
+    _check(_lib.psn_light_rows_fwd(_ptr(dir_table, 'dir_table'), _ptr(int_table, 'int_table', True), _ptr(idx, 'idx'), L, float(eps),
+                                   d.data_ptr(), None if it is None else it.data_ptr(), _stream()), 'light_rows_fwd')
+    return d, it
+
+
+def light_rows_bwd(dir_table, idx, g_dir, g_int, eps=1e-12):
+    """Dense table gradients ([n, 3] or None, [n, 1] or None) of light_rows_fwd, one launch, no separate zero fill."""
+    n = dir_table.shape[0]
+    dd = torch.empty(n, 3, device=dir_table.device, dtype=torch.float32) if g_dir is not None else None
+    di = torch.empty(n, 1, device=dir_table.device, dtype=torch.float32) if g_int is not None else None
+    for t in (g_dir, g_int):
+        assert t is None or t.is_contiguous()
+    _check(_lib.psn_light_rows_bwd(_ptr(dir_table, 'dir_table'), _ptr(idx, 'idx'), idx.shape[0], n, float(eps), _ptr(g_dir, 'g_dir', True),
+                                   _ptr(g_int, 'g_int', True), None if dd is None else dd.data_ptr(), None if di is None else di.data_ptr(),
+                                   _stream()), 'light_rows_bwd')
+    return dd, di
+
+
+def camera_rays(uv, pose, intrinsics, idx=None, scale=1.0):
+    """Normalised camera rays (rend_util.py:90-147, 4 x 4 pose) of the pixels idx (all when None) -> [n, 3], times scale."""
+    assert uv.dim() == 3 and uv.shape[0] == 1 and uv.shape[2] == 2 and uv.is_contiguous()
+    assert pose.shape == (1, 4, 4) and intrinsics.shape[0] == 1 and intrinsics.shape[1:] == (4, 4) and pose.is_contiguous() and intrinsics.is_contiguous()
+    n = uv.shape[1] if idx is None else idx.shape[0]
+    out = torch.empty(n, 3, device=uv.device, dtype=torch.float32)
+    _check(_lib.psn_camera_rays(_ptr(uv, 'uv'), _ptr(pose, 'pose'), _ptr(intrinsics, 'intrinsics'), _ptr(idx, 'idx', True), n, float(scale),
+                                out.data_ptr(), _stream()), 'camera_rays')
+    return out
+
+
+def adam_flat(param, grad, exp_avg, exp_avg_sq, segs, beta1, beta2, eps):
+    """segs: [(offset, grad_offset, n, neg_step_size, bias_correction2_sqrt)] ranges of the flat buffers (psn_adam_flat);
+    more than ADAM_MAX_SEGS ranges go out in several launches."""
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.dim() == 1 and t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
+    assert exp_avg.numel() == exp_avg_sq.numel() == param.numel()
+    for s0 in range(0, len(segs), ADAM_MAX_SEGS):
+        part = segs[s0:s0 + ADAM_MAX_SEGS]
+        arr = (PsnAdamSeg * len(part))()
+        for a, (off, goff, n, ns, bc) in zip(arr, part):
+            assert 0 <= off and off + n <= param.numel() and 0 <= goff and goff + n <= grad.numel()
+            a.offset, a.grad_offset, a.n, a.neg_step_size, a.bias_correction2_sqrt = int(off), int(goff), int(n), float(ns), float(bc)
+        _check(_lib.psn_adam_flat(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), len(part), arr,
+                                  float(1 - beta1), float(beta2), float(1 - beta2), float(eps), _stream()), 'adam_flat')
 
 
 def shadow_points(surf, ldir, n_steps, lnear, lfar, u, omu, box):

@@ -974,3 +974,49 @@ class Stage2Losses(torch.autograd.Function):
         g = d.get
         return (g('rgb'), None, g('alb'), g('alb_j'), g('wgt'), g('wgt_j'), g('vis'), None, g('nrm'), None, g('nrm_j'),
                 None, None, None, None, None, None)
+
+
+# --------------------------------------------------------------------------- launch-bound row ops, fused (csrc/small.hip)
+class NormalizeRows(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=-1) for [n, 3] rows: one launch forward (norm, clamp_min, div), one backward (autograd's
+    chain through div / clamp_min / norm is 14 launches)."""
+
+    @staticmethod
+    def forward(ctx, x, eps=1e-12):
+        xc = x.detach().contiguous()
+        ctx.save_for_backward(xc)
+        ctx.eps = float(eps)
+        return hip.normalize_rows_fwd(xc, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return hip.normalize_rows_bwd(x, g.contiguous(), ctx.eps), None
+
+
+def normalize_rows(x, eps=1e-12):
+    """F.normalize(x, dim=-1); the fused form for fp32 [n, 3] device tensors, the torch formulation otherwise."""
+    if x.is_cuda and x.dim() == 2 and x.shape[1] == 3 and x.dtype == torch.float32:
+        return NormalizeRows.apply(x, eps)
+    return torch.nn.functional.normalize(x, p=2, dim=-1, eps=eps)
+
+
+class LightRows(torch.autograd.Function):
+    """The light-table lookups of a stage-2 step (stage2/trainer.py:376-379): F.normalize(dir_table[idx]) and int_table[idx]
+    in one launch; backward = the DENSE table gradients (as nn.Embedding(sparse=False) produces them) in one launch, without
+    zero fills.  apply(dir_table [n, 3], int_table [n, 1], idx [L] int64) -> (dir [L, 3], inten [L, 1])."""
+
+    @staticmethod
+    def forward(ctx, dir_table, int_table, idx):
+        dt, it, ix = dir_table.detach().contiguous(), int_table.detach().contiguous(), idx.contiguous()
+        ctx.save_for_backward(dt, ix)
+        d, i = hip.light_rows_fwd(dt, it, ix)
+        return d, i
+
+    @staticmethod
+    def backward(ctx, g_dir, g_int):
+        dt, ix = ctx.saved_tensors
+        need_d, need_i = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dd, di = hip.light_rows_bwd(dt, ix, g_dir.contiguous() if (need_d and g_dir is not None) else None,
+                                    g_int.contiguous() if (need_i and g_int is not None) else None)
+        return dd, di, None

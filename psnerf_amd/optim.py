@@ -82,3 +82,147 @@ class RowSparseAdam(torch.optim.Optimizer):
                 v.add_(g.pow(2).sub_(v).mul_(1 - beta2).mul_(touched))
                 step_size = group['lr'] * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
                 p.add_(m.div(v.sqrt().add_(group['eps'])).mul_(-step_size).mul_(touched))
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (amsgrad off, no weight decay: what stage2/trainer.py:126-133 constructs) over ONE flat fp32 buffer.
+
+    Parameters, moments and -- when the trainer attaches them as views of a flat bucket (dist.DataParallel.prepare_grads,
+    also used on a single GPU) -- gradients are contiguous allocations, so a step is one launch of psn_adam_flat with torch's
+    arithmetic (seven foreach launches there).  ``param.data`` of every parameter is re-pointed into the flat buffer at
+    construction (values preserved; in-place loads such as load_state_dict keep working, and a parameter whose storage was
+    replaced from outside is detected and re-attached).  State layout and keys are torch.optim.Adam's (``step``,
+    ``exp_avg``, ``exp_avg_sq`` per parameter; the same param_group keys), so optimiser checkpoints are interchangeable;
+    parameters without a gradient are skipped, and parameters that start training later have their own step count.
+    CPU / non-fp32 parameters fall back to the same update written with torch ops."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if not 0.0 <= lr:
+            raise ValueError('Invalid learning rate: %r' % (lr,))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None))
+        self._flat = None
+
+    # ---- flat storage -----------------------------------------------------------------------------------------------
+    def _all_params(self):
+        return [p for g in self.param_groups for p in g['params']]
+
+    def _attach(self):
+        ps = self._all_params()
+        ok = all(p.is_cuda and p.dtype == torch.float32 for p in ps) and len(ps) > 0
+        if not ok:
+            self._flat = False
+            return
+        total = sum(p.numel() for p in ps)
+        dev = ps[0].device
+        old = self._flat if isinstance(self._flat, dict) else None
+        flat = torch.empty(total, device=dev, dtype=torch.float32)
+        m, v = torch.zeros(total, device=dev), torch.zeros(total, device=dev)
+        offs, off = {}, 0
+        with torch.no_grad():
+            for p in ps:
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1))
+                st = self.state.get(p, {})
+                for key, buf in (('exp_avg', m), ('exp_avg_sq', v)):
+                    if key in st:
+                        buf[off:off + n].copy_(st[key].reshape(-1))
+                        st[key] = buf[off:off + n].view_as(p)
+                p.data = flat[off:off + n].view_as(p)
+                offs[p] = off
+                off += n
+        self._flat = dict(p=flat, m=m, v=v, off=offs)
+        del old
+
+    def _attached(self):
+        if self._flat is None:
+            self._attach()
+        if not self._flat:
+            return False
+        f = self._flat
+        base = f['p'].data_ptr()
+        if any(p.data_ptr() != base + 4 * f['off'][p] for p in self._all_params()):
+            self._attach()  # a storage was replaced from outside (.to(), assign-style load): take the values over again
+        return bool(self._flat)
+
+    def attach_grads(self):
+        """Replaces ``zero_grad()``: ONE memset of a flat gradient buffer laid out like the parameters, every trainable
+        parameter's ``.grad`` (re)attached to its view (autograd accumulates in place), frozen parameters' set to None.
+        Returns False (after a plain zero_grad) when the parameters cannot be flat (CPU / non-fp32)."""
+        if not self._attached():
+            self.zero_grad()
+            return False
+        f = self._flat
+        if f.get('g') is None:
+            f['g'] = torch.zeros_like(f['p'])
+        else:
+            f['g'].zero_()
+        for p in self._all_params():
+            if p.requires_grad:
+                o = f['off'][p]
+                p.grad = f['g'][o:o + p.numel()].view_as(p)
+            else:
+                p.grad = None
+        return True
+
+    # ---- checkpoints: never serialise views of the whole flat allocation ----------------------------------------------
+    def state_dict(self):
+        sd = super().state_dict()
+        for st in sd['state'].values():
+            for k, t in list(st.items()):
+                if torch.is_tensor(t):
+                    st[k] = t.detach().clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat = None  # moments were replaced by loaded copies: re-attach (values are taken over) at the next step
+
+    # ---- the update ---------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self):
+        import math
+        from . import hip
+        flat_ok = self._attached()
+        for group in self.param_groups:
+            assert not group.get('maximize', False) and not group.get('amsgrad', False) and group.get('weight_decay', 0) == 0, \
+                'FlatAdam: plain Adam only'
+            b1, b2 = group['betas']
+            lr, eps = group['lr'], group['eps']
+            segs, gbuf = [], None
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    if flat_ok:
+                        f, o, n = self._flat, self._flat['off'][p], p.numel()
+                        st['exp_avg'], st['exp_avg_sq'] = f['m'][o:o + n].view_as(p), f['v'][o:o + n].view_as(p)
+                        st['exp_avg'].zero_()
+                        st['exp_avg_sq'].zero_()
+                    else:
+                        st['exp_avg'], st['exp_avg_sq'] = torch.zeros_like(p), torch.zeros_like(p)
+                st['step'] += 1
+                t = int(st['step'])
+                neg_step, bc2s = -(lr / (1 - b1 ** t)), math.sqrt(1 - b2 ** t)
+                g = p.grad
+                base = g._base if (torch.is_tensor(g) and not g.is_sparse) else None
+                if (flat_ok and base is not None and base.dim() == 1 and base.is_contiguous() and g.is_contiguous() and base.dtype == torch.float32
+                        and (gbuf is None or (base.data_ptr() == gbuf.data_ptr() and base.numel() == gbuf.numel()))):
+                    # the gradient is a view of ONE flat allocation (attach_grads, or the data-parallel bucket): a range of the launch
+                    gbuf = base
+                    o, go, n = self._flat['off'][p], (g.data_ptr() - base.data_ptr()) // 4, p.numel()
+                    if segs and segs[-1][0] + segs[-1][2] == o and segs[-1][1] + segs[-1][2] == go and segs[-1][3:] == (neg_step, bc2s):
+                        segs[-1] = (segs[-1][0], segs[-1][1], segs[-1][2] + n, neg_step, bc2s)
+                    else:
+                        segs.append((o, go, n, neg_step, bc2s))
+                    continue
+                # torch's formulation for whatever is not in the flat layout
+                m, v = st['exp_avg'], st['exp_avg_sq']
+                m.lerp_(g, 1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                p.addcdiv_(m, (v.sqrt() / bc2s).add_(eps), value=neg_step)
+            if segs:
+                f = self._flat
+                hip.adam_flat(f['p'], gbuf, f['m'], f['v'], segs, b1, b2, eps)

@@ -399,15 +399,15 @@ class PSNetwork(nn.Module):
             if ns > 0:
               with on_side():
                 cols_n = self._cols(self.n_freqs_n, device)
-                normal_s = self._memo('normal', input, lambda: F.normalize(
-                    self.normal_net(self._pe(surf, self.n_freqs_n), cols_n), dim=-1))
+                normal_s = self._memo('normal', input, lambda: ops.normalize_rows(
+                    self.normal_net(self._pe(surf, self.n_freqs_n), cols_n)))
                 normal_pred = scatter(normal_pred, normal_s)
                 if self.normal_jitter_std > 0:
                     nz = noise.get('normal')
                     if nz is None:
                         nz = torch.randn_like(surf) * self.normal_jitter_std  # = torch.normal(0, std) without its host-side std >= 0 check
-                    nj = self._memo('normal_jitter', input, lambda: F.normalize(
-                        self.normal_net(self._pe(surf + nz, self.n_freqs_n), cols_n), dim=-1))
+                    nj = self._memo('normal_jitter', input, lambda: ops.normalize_rows(
+                        self.normal_net(self._pe(surf + nz, self.n_freqs_n), cols_n)))
                     out_n['normal_jitter'] = scatter(ones3(), nj)
             out_n['normal_pred'] = normal_pred
 
@@ -425,8 +425,12 @@ class PSNetwork(nn.Module):
             # camera rays (~15 launch-bound elementwise kernels) are only needed by the shading: queued beside the
             # visibility launch (side stream), not in front of it
             with on_side():
-                ray_dirs, _ = camera_rays(uv, pose, intr)
-                pts2c = -gather(ray_dirs)
+                if uv.is_cuda and uv.shape[0] == 1 and uv.dtype == torch.float32:
+                    # rays of the surface pixels only, normalised and negated, in one launch (psn_camera_rays)
+                    pts2c = hip.camera_rays(uv.contiguous(), pose.contiguous().float(), intr.contiguous().float(), idx, scale=-1.0)
+                else:
+                    ray_dirs, _ = camera_rays(uv, pose, intr)
+                    pts2c = -gather(ray_dirs)
             light_dir = input['light_direction']
             cols = self._cols(self.n_freqs, device)
             if pe_x is None:

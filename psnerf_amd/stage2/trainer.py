@@ -8,7 +8,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..dist import DataParallel
-from ..optim import RowSparseAdam
+from .. import ops
+from ..optim import FlatAdam, RowSparseAdam
 from .loss import MainLoss, NormalLoss, fused_losses
 
 
@@ -66,7 +67,10 @@ class TrainStep(object):
             self.loss.global_count = self.dp.global_count
             self.loss_n.global_count = self.dp.global_count
         gamma = conf.get_float('train.sg_sched_factor', default=0.0)
-        self.sg_optimizer = torch.optim.Adam(model.parameters(), lr=conf.get_float('train.sg_learning_rate'))
+        # Adam over one flat parameter / moment / gradient allocation: one launch per step (optim.FlatAdam = torch.optim.Adam's
+        # arithmetic and state layout); torch's own implementation for parameters that are not fp32 device tensors
+        on_gpu = all(p.is_cuda and p.dtype == torch.float32 for p in model.parameters())
+        self.sg_optimizer = (FlatAdam if on_gpu else torch.optim.Adam)(model.parameters(), lr=conf.get_float('train.sg_learning_rate'))
         self.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.sg_optimizer, list(milestones), gamma=gamma)
         # dense gradients + RowSparseAdam = SparseAdam's update of the touched rows without coalesce() (optim.py)
         self.light_para = nn.Embedding(n_lights_total, 3, sparse=False).to(device)
@@ -116,8 +120,13 @@ class TrainStep(object):
             self.train_fix()
         self.dp.new_step()
         model_input = dict(model_input)
-        model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
-        model_input['light_intensity'] = self.light_inten_para(l_slt)
+        if l_slt.is_cuda and self.light_para.weight.is_cuda:
+            # both table lookups + the normalisation in one launch (one more for the dense table gradients in backward)
+            model_input['light_direction'], model_input['light_intensity'] = ops.LightRows.apply(
+                self.light_para.weight, self.light_inten_para.weight, l_slt.long())
+        else:
+            model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
+            model_input['light_intensity'] = self.light_inten_para(l_slt)
         if self.vis_plus is not None and vidx is not None:
             # under data parallelism 'sampling_idx' is this rank's pixel slice (dist.shard_stage2) and every rank draws
             # the same rows from an identically seeded np.random stream
@@ -126,7 +135,11 @@ class TrainStep(object):
                 sidx = sidx[0]  # batch dimension of the collated sample (trainer.py:392)
             model_input['light_vis_train'], model_input['vis_train_gt'] = self.vis_plus.select(vidx, sidx)
         elif 'light_vis_train' not in model_input:
-            model_input['light_vis_train'] = F.normalize(self.light_vis_table[l_slt], p=2, dim=-1)
+            if l_slt.is_cuda and self.light_vis_table.is_cuda:
+                from .. import hip
+                model_input['light_vis_train'] = hip.light_rows_fwd(self.light_vis_table.contiguous(), None, l_slt.long().contiguous())[0]
+            else:
+                model_input['light_vis_train'] = F.normalize(self.light_vis_table[l_slt], p=2, dim=-1)
         # ONE mask count per step (a tiny all-reduce under data parallelism), shared by every loss term.  Both masks
         # are inputs (the model passes them through as 'network_object_mask' / 'object_mask'), so the count -- a host
         # synchronisation -- is taken BEFORE the forward pass: afterwards the host runs ahead of the GPU through
@@ -157,7 +170,10 @@ class TrainStep(object):
             # one memset; every trainable .grad becomes a view into the flat all-reduce bucket, frozen parameters lose theirs
             self.dp.prepare_grads(list(self.model.parameters()) + [self.light_para.weight, self.light_inten_para.weight])
         else:
-            self.sg_optimizer.zero_grad()
+            if isinstance(self.sg_optimizer, FlatAdam):
+                self.sg_optimizer.attach_grads()  # one memset; every .grad a view of one flat buffer laid out like the parameters
+            else:
+                self.sg_optimizer.zero_grad()
             if train_light:
                 self.light_optimizer.zero_grad()
         if loss.requires_grad:

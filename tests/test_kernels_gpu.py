@@ -691,3 +691,120 @@ def test_app_input_table(cuda, Q):
     assert_close(x[:, 3:30].cpu(), pe.cpu(), 1e-6, 'view encoding', atol=1e-6)  # |v| by sqrtf(x^2 + y^2 + z^2) vs torch.norm: last bits
     ref = torch.cat([vn, *[f(vn * 2 ** k) for k in range(4) for f in (torch.sin, torch.cos)]], dim=-1)
     assert_close(x[:, 3:30].double().cpu(), ref.double().cpu(), 1e-5, 'view encoding vs torch', atol=1e-6)
+
+
+def test_small_fused_row_kernels_vs_torch(cuda):
+    """csrc/small.hip against the torch formulations they replace: F.normalize + its autograd backward on [n, 3] rows (incl. a
+    zero row and a row below eps), the light-table lookups of stage2/trainer.py:376-379 with duplicate indices (dense table
+    gradients), and the camera rays of rend_util.py:90-147 for selected pixels."""
+    from psnerf_amd import hip, ops
+    from psnerf_amd.stage2.renderer import camera_rays
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1000, 3, generator=g)
+    x[3] = 0.0
+    x[4] = 1e-14
+    x[5] *= 1e3
+    gy = torch.randn(1000, 3, generator=g)
+    xr = x.clone().requires_grad_()
+    yr = torch.nn.functional.normalize(xr, p=2, dim=-1)
+    yr.backward(gy)
+    xd = x.to(cuda).requires_grad_()
+    yd = ops.normalize_rows(xd)
+    yd.backward(gy.to(cuda))
+    assert_close(yd.detach().cpu(), yr.detach(), 1e-6, 'normalize fwd', atol=1e-7)
+    assert_close(xd.grad.cpu(), xr.grad, 1e-5, 'normalize bwd', atol=1e-6 * float(xr.grad.abs().max()))
+    # light rows: duplicates, both tables
+    NL, L = 40, 17
+    dt, it = torch.randn(NL, 3, generator=g), torch.rand(NL, 1, generator=g) + 1.0
+    idx = torch.randint(0, NL, (L,), generator=g)
+    idx[5] = idx[2]
+    idx[9] = idx[2]
+    gd, gi = torch.randn(L, 3, generator=g), torch.randn(L, 1, generator=g)
+    e1, e2 = torch.nn.Embedding(NL, 3), torch.nn.Embedding(NL, 1)
+    e1.weight.data.copy_(dt)
+    e2.weight.data.copy_(it)
+    ((torch.nn.functional.normalize(e1(idx), p=2, dim=-1) * gd).sum() + (e2(idx) * gi).sum()).backward()
+    dtd, itd = dt.to(cuda).requires_grad_(), it.to(cuda).requires_grad_()
+    d, i = ops.LightRows.apply(dtd, itd, idx.to(cuda))
+    ((d * gd.to(cuda)).sum() + (i * gi.to(cuda)).sum()).backward()
+    assert_close(d.detach().cpu(), torch.nn.functional.normalize(dt[idx], dim=-1), 1e-6, 'light dir', atol=1e-7)
+    assert torch.equal(i.detach().cpu(), it[idx])
+    assert_close(dtd.grad.cpu(), e1.weight.grad, 1e-5, 'd dir table', atol=1e-6)
+    assert_close(itd.grad.cpu(), e2.weight.grad, 1e-6, 'd intensity table', atol=1e-7)
+    untouched = torch.ones(NL, dtype=torch.bool)
+    untouched[idx] = False
+    assert float(dtd.grad.cpu()[untouched].abs().max()) == 0.0
+    # only one table needs a gradient
+    dtd2 = dt.to(cuda).requires_grad_()
+    d2, i2 = ops.LightRows.apply(dtd2, it.to(cuda), idx.to(cuda))
+    (d2 * gd.to(cuda)).sum().backward()
+    assert torch.equal(dtd2.grad, dtd.grad)
+    # camera rays of a pixel subset, negated
+    from psnerf_amd.synthetic import look_at_pose
+    uv = torch.stack([torch.randint(0, 612, (500,), generator=g).float(), torch.randint(0, 512, (500,), generator=g).float()], -1)[None]
+    K = torch.eye(4)[None].clone()
+    K[0, 0, 0], K[0, 1, 1], K[0, 0, 2], K[0, 1, 2] = 3759.0, 3741.5, 306.0, 256.0
+    pose = look_at_pose(31.5, az_deg=40.0, el_deg=-15.0)[None]
+    sel = torch.sort(torch.randperm(500, generator=g)[:123]).values
+    ref = -camera_rays(uv, pose, K)[0][0][sel]
+    got = hip.camera_rays(uv.to(cuda), pose.to(cuda), K.to(cuda), sel.to(cuda), scale=-1.0)
+    assert_close(got.cpu(), ref, 1e-6, 'camera rays', atol=1e-7)
+    assert_close(hip.camera_rays(uv.to(cuda), pose.to(cuda), K.to(cuda)).cpu(), camera_rays(uv, pose, K)[0][0], 1e-6, 'camera rays (all)', atol=1e-7)
+
+
+def test_flat_adam_follows_torch_adam(cuda):
+    """optim.FlatAdam (one psn_adam_flat launch over flat parameter / moment / gradient buffers) against torch.optim.Adam on
+    the same parameter set and gradients: several steps, a parameter that is frozen at first and joins later (its own step
+    count), the MultiStepLR schedule, state_dict round trip into torch.optim.Adam and back."""
+    from psnerf_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(128, 63), (128,), (3, 128), (3,), (64, 5), (7,)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    pa = [t.clone().to(cuda).requires_grad_() for t in init]
+    pb = [t.clone().to(cuda).requires_grad_() for t in init]
+    oa = FlatAdam(pa, lr=5e-4)
+    ob = torch.optim.Adam(pb, lr=5e-4, foreach=True)
+    sa = torch.optim.lr_scheduler.MultiStepLR(oa, [3], gamma=0.5)
+    sb = torch.optim.lr_scheduler.MultiStepLR(ob, [3], gamma=0.5)
+    frozen = 4
+    pa[frozen].requires_grad_(False)
+    pb[frozen].requires_grad_(False)
+    for it in range(6):
+        if it == 2:
+            pa[frozen].requires_grad_(True)
+            pb[frozen].requires_grad_(True)
+        grads = [torch.randn(s, generator=g).to(cuda) * (10.0 ** (it - 3)) for s in shapes]
+        assert oa.attach_grads()
+        ob.zero_grad()
+        for p, q, gr in zip(pa, pb, grads):
+            if p.requires_grad:
+                p.grad.add_(gr)  # accumulates into the flat view, as autograd does
+                q.grad = gr.clone()
+        assert pa[frozen].grad is None or it >= 2
+        oa.step()
+        ob.step()
+        sa.step()
+        sb.step()
+        for k, (p, q) in enumerate(zip(pa, pb)):
+            assert_close(p.detach().cpu(), q.detach().cpu(), 1e-6, 'param %d after step %d' % (k, it), atol=1e-7)
+    assert int(oa.state[pa[frozen]]['step']) == 4 and int(oa.state[pa[0]]['step']) == 6
+    # parameters and moments are views of one allocation each; the state dict is interchangeable with torch.optim.Adam's
+    base = pa[0].data_ptr()
+    off = 0
+    for p in pa:
+        assert p.data_ptr() == base + 4 * off
+        off += p.numel()
+    sd = oa.state_dict()
+    assert all(t._base is None for st in sd['state'].values() for t in st.values() if torch.is_tensor(t))
+    oc = torch.optim.Adam([t.detach().clone().requires_grad_() for t in pa], lr=1.0)
+    oc.load_state_dict(sd)
+    od = FlatAdam([t.detach().clone().requires_grad_() for t in pb], lr=1.0)
+    od.load_state_dict(ob.state_dict())
+    for (p1, p2) in zip(oc.param_groups[0]['params'], od.param_groups[0]['params']):
+        g1 = torch.randn(p1.shape, generator=g).to(cuda)
+        p1.grad = g1.clone()
+        p2.grad = g1.clone()  # not a flat view: the torch formulation inside FlatAdam
+    oc.step()
+    od.step()
+    for p1, p2 in zip(oc.param_groups[0]['params'], od.param_groups[0]['params']):
+        assert_close(p1.detach().cpu(), p2.detach().cpu(), 1e-6, 'after state-dict exchange', atol=1e-7)

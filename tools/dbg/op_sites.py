@@ -1,0 +1,36 @@
+"""aten ops of ONE steady-state stage-2 step in issue order with the psnerf_amd call site (TorchDispatchMode); ops issued
+by the autograd engine show the backward node instead."""
+import os, sys, traceback
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+import torch
+import bench
+from torch.utils._python_dispatch import TorchDispatchMode
+from psnerf_amd.synthetic import stage2_inputs
+dev = torch.device('cuda:0')
+step = bench.make_step(dev)
+inp, gt = stage2_inputs(bench.N_PIXELS, bench.N_LIGHTS, bench.N_VIS, seed=100, device=dev, with_surface_idx=True)
+l_slt = torch.arange(bench.N_LIGHTS, device=dev) + 96 * 3
+for _ in range(3):
+    step.step(inp, gt, l_slt, train_order=False)
+torch.cuda.synchronize()
+log = []
+SKIP = ('aten.view', 'aten.detach', 'aten._unsafe_view', 'aten.expand', 'aten.slice', 'aten.select', 'aten.unsqueeze', 'aten.squeeze',
+        'aten.t.', 'aten.transpose', 'aten.permute', 'aten.alias', 'aten.as_strided', 'aten.reshape', 'aten.unbind', 'aten.split',
+        'aten.is_', 'aten.sym_', 'aten.lift_fresh', 'aten.empty', 'aten._local_scalar', 'aten.stride', 'aten.size', 'aten.numel')
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(SKIP):
+            site = ''
+            for fr in reversed(traceback.extract_stack()):
+                if 'psnerf_amd' in fr.filename and 'op_sites' not in fr.filename:
+                    site = '%s:%d %s' % (fr.filename.split('psnerf_amd/')[-1], fr.lineno, fr.name)
+                    break
+            shp = [tuple(a.shape) for a in args if torch.is_tensor(a)][:2]
+            log.append((name, site, shp))
+        return func(*args, **(kwargs or {}))
+with Log():
+    step.step(inp, gt, l_slt, train_order=False)
+torch.cuda.synchronize()
+for i, (n, s, shp) in enumerate(log):
+    print('%3d %-40s %-60s %s' % (i, n[:40], s[:60], shp))
