@@ -189,6 +189,17 @@ def _ptr(t, name, allow_none=False):
     return t.data_ptr()
 
 
+def _iptr(t, name, allow_none=False):
+    """Device pointer of an int64 index tensor."""
+    if t is None:
+        if allow_none:
+            return None
+        raise RuntimeError('%s: tensor required' % name)
+    if not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous():
+        raise RuntimeError('%s: must be a contiguous int64 HIP device tensor' % name)
+    return t.data_ptr()
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -457,7 +468,7 @@ def light_rows_fwd(dir_table, int_table, idx, eps=1e-12):
     if int_table is not None:
         assert int_table.shape == (dir_table.shape[0], 1) and int_table.is_contiguous()
         it = torch.empty(L, 1, device=dir_table.device, dtype=torch.float32)
-    _check(_lib.psn_light_rows_fwd(_ptr(dir_table, 'dir_table'), _ptr(int_table, 'int_table', True), _ptr(idx, 'idx'), L, float(eps),
+    _check(_lib.psn_light_rows_fwd(_ptr(dir_table, 'dir_table'), _ptr(int_table, 'int_table', True), _iptr(idx, 'idx'), L, float(eps),
                                    d.data_ptr(), None if it is None else it.data_ptr(), _stream()), 'light_rows_fwd')
     return d, it
 
@@ -469,7 +480,7 @@ def light_rows_bwd(dir_table, idx, g_dir, g_int, eps=1e-12):
     di = torch.empty(n, 1, device=dir_table.device, dtype=torch.float32) if g_int is not None else None
     for t in (g_dir, g_int):
         assert t is None or t.is_contiguous()
-    _check(_lib.psn_light_rows_bwd(_ptr(dir_table, 'dir_table'), _ptr(idx, 'idx'), idx.shape[0], n, float(eps), _ptr(g_dir, 'g_dir', True),
+    _check(_lib.psn_light_rows_bwd(_ptr(dir_table, 'dir_table'), _iptr(idx, 'idx'), idx.shape[0], n, float(eps), _ptr(g_dir, 'g_dir', True),
                                    _ptr(g_int, 'g_int', True), None if dd is None else dd.data_ptr(), None if di is None else di.data_ptr(),
                                    _stream()), 'light_rows_bwd')
     return dd, di
@@ -481,7 +492,7 @@ def camera_rays(uv, pose, intrinsics, idx=None, scale=1.0):
     assert pose.shape == (1, 4, 4) and intrinsics.shape[0] == 1 and intrinsics.shape[1:] == (4, 4) and pose.is_contiguous() and intrinsics.is_contiguous()
     n = uv.shape[1] if idx is None else idx.shape[0]
     out = torch.empty(n, 3, device=uv.device, dtype=torch.float32)
-    _check(_lib.psn_camera_rays(_ptr(uv, 'uv'), _ptr(pose, 'pose'), _ptr(intrinsics, 'intrinsics'), _ptr(idx, 'idx', True), n, float(scale),
+    _check(_lib.psn_camera_rays(_ptr(uv, 'uv'), _ptr(pose, 'pose'), _ptr(intrinsics, 'intrinsics'), _iptr(idx, 'idx', True), n, float(scale),
                                 out.data_ptr(), _stream()), 'camera_rays')
     return out
 
