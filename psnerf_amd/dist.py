@@ -113,12 +113,13 @@ class DataParallel(object):
         if len(self._buckets) > 8:  # train_fix phases x (dense, light tables): a handful; anything more is a leak
             self._buckets = {k: v for k, v in self._buckets.items() if all(r() is not None for r in v[2])}
         if b is None:
-            total = sum(p.numel() for p in params)
+            pad = lambda n: (n + 63) // 64 * 64  # views start on 256-byte boundaries, the layout optim.FlatAdam gives the parameters
+            total = sum(pad(p.numel()) for p in params)
             flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
             views, off = [], 0
             for p in params:
                 views.append(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+                off += pad(p.numel())
             import weakref
             b = self._buckets[key] = (flat, views, [weakref.ref(p) for p in params])
         return b

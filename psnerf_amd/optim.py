@@ -84,6 +84,10 @@ class RowSparseAdam(torch.optim.Optimizer):
                 p.add_(m.div(v.sqrt().add_(group['eps'])).mul_(-step_size).mul_(touched))
 
 
+def _pad64(n):
+    return (int(n) + 63) // 64 * 64
+
+
 class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam (amsgrad off, no weight decay: what stage2/trainer.py:126-133 constructs) over ONE flat fp32 buffer.
 
@@ -113,10 +117,12 @@ class FlatAdam(torch.optim.Optimizer):
         if not ok:
             self._flat = False
             return
-        total = sum(p.numel() for p in ps)
+        # every parameter starts on a 256-byte boundary, like an allocation of its own would (kernels read weights with 16-byte
+        # loads); the gaps hold zeros in all four buffers, and Adam maps zeros to zeros there
+        total = sum(_pad64(p.numel()) for p in ps)
         dev = ps[0].device
         old = self._flat if isinstance(self._flat, dict) else None
-        flat = torch.empty(total, device=dev, dtype=torch.float32)
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
         m, v = torch.zeros(total, device=dev), torch.zeros(total, device=dev)
         offs, off = {}, 0
         with torch.no_grad():
@@ -130,7 +136,7 @@ class FlatAdam(torch.optim.Optimizer):
                         st[key] = buf[off:off + n].view_as(p)
                 p.data = flat[off:off + n].view_as(p)
                 offs[p] = off
-                off += n
+                off += _pad64(n)
         self._flat = dict(p=flat, m=m, v=v, off=offs)
         del old
 
@@ -213,8 +219,10 @@ class FlatAdam(torch.optim.Optimizer):
                     # the gradient is a view of ONE flat allocation (attach_grads, or the data-parallel bucket): a range of the launch
                     gbuf = base
                     o, go, n = self._flat['off'][p], (g.data_ptr() - base.data_ptr()) // 4, p.numel()
-                    if segs and segs[-1][0] + segs[-1][2] == o and segs[-1][1] + segs[-1][2] == go and segs[-1][3:] == (neg_step, bc2s):
-                        segs[-1] = (segs[-1][0], segs[-1][1], segs[-1][2] + n, neg_step, bc2s)
+                    gap = o - (segs[-1][0] + segs[-1][2]) if segs else -1
+                    if segs and 0 <= gap < 64 and gap == go - (segs[-1][1] + segs[-1][2]) and segs[-1][3:] == (neg_step, bc2s):
+                        # the next parameter of both layouts, behind the same (zero-filled) alignment gap: one range
+                        segs[-1] = (segs[-1][0], segs[-1][1], segs[-1][2] + gap + n, neg_step, bc2s)
                     else:
                         segs.append((o, go, n, neg_step, bc2s))
                     continue
