@@ -791,9 +791,9 @@ def test_flat_adam_follows_torch_adam(cuda):
     # parameters and moments are views of one allocation each; the state dict is interchangeable with torch.optim.Adam's
     base = pa[0].data_ptr()
     off = 0
-    for p in pa:
-        assert p.data_ptr() == base + 4 * off
-        off += p.numel()
+    for p in pa:  # one allocation, every parameter on a 256-byte boundary
+        assert p.data_ptr() == base + 4 * off and p.data_ptr() % 256 == 0
+        off += (p.numel() + 63) // 64 * 64
     sd = oa.state_dict()
     assert all(t._base is None for st in sd['state'].values() for t in st.values() if torch.is_tensor(t))
     oc = torch.optim.Adam([t.detach().clone().requires_grad_() for t in pa], lr=1.0)
