@@ -432,8 +432,7 @@ __device__ __forceinline__ void mask_tile256(int n_rows, int k0, int k_end, int 
 // wave issues 256 MFMAs (16384 cycles) against 128 ds_read_b32, 16 staged float4 loads and ONE barrier (16-row tiles:
 // a barrier and an exposed first fragment read per 8192 cycles).
 constexpr int T256 = 256, T256_LD = T256 + 4, TK = 32, T256_BUF = 2 * TK * T256_LD;  // k-tiles of TK = 32 rows: 2 x 66.5 KB of LDS
-// A product that is exactly 256 x 256 (the hidden-layer gradients of the 256-wide networks) takes a fast path: the
-// k-tiles a step stages need no masks except the last two of a K slice (the possibly partial final tile and the
+// The k-tiles a step stages need no masks except the last two of a K slice (the possibly partial final tile and the
 // overshoot of the prefetch), so the steady-state loop runs mask-free steps and only the last <= 3 steps of a slice
 // the masked ones.  The 32 v_cndmask per k-tile of the general variant cost 4.6 % of the kernel (timing-only build:
 // 129 -> 135 TF incl. the reduction on 16 products at K = 524,288; every vector instruction is paid for in fp32-MFMA time).
@@ -494,8 +493,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
     const bool bm0 = rq_ + 0 < g.N, bm1 = rq_ + 1 < g.N, bm2 = rq_ + 2 < g.N, bm3 = rq_ + 3 < g.N;
     const int rqa = min(rq_, (((int)g.M - 1) >> 2) << 2), rqb = min(rq_, ((g.N - 1) >> 2) << 2);
     float4 cs01 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define T_ITEM(BUF, S, T, J, MASKED)                                                             \
-    {                                                                                            \
+#define T_ITEM(BUF, S, T, J, MASKED, BD)                                                         \
+    if (!((BD) && (J) >= 8)) {                                                                   \
         constexpr int u_ = (J) & 7;                                                              \
         constexpr bool isb_ = (J) >= 8;                                                          \
         float4& x_ = isb_ ? rb[S][u_] : ra[S][u_];                                               \
@@ -516,22 +515,26 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
     }
     // one wave per SIMD: nothing else hides latencies or the staging work, so every k-pair j of a step is its own
     // scheduling region: operand reads of k-pair j+1 first, then the 16 MFMAs of k-pair j with staging item j in their gaps
-#define T_STEP(T, S, MASKED)                                                                     \
+#define T_STEP(T, S, MASKED, BD)                                                                 \
     {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (BD) { T_DMA_B(((T) + 1) & 1, (T) + 1) __builtin_amdgcn_sched_barrier(0); }           \
         const float* As = lds256 + ((T) & 1) * T256_BUF + wr * 128 + li;                         \
         const float* Bs = lds256 + ((T) & 1) * T256_BUF + TK * T256_LD + wc * 128 + li;          \
         float pa[2][4], pb[2][4];                                                                \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) pa[0][i] = As[lh * T256_LD + i * 32];      \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) pb[0][n] = Bs[lh * T256_LD + n * 32];      \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        T_PAIR(T, S, 0, MASKED) T_PAIR(T, S, 1, MASKED) T_PAIR(T, S, 2, MASKED) T_PAIR(T, S, 3, MASKED)  \
-        T_PAIR(T, S, 4, MASKED) T_PAIR(T, S, 5, MASKED) T_PAIR(T, S, 6, MASKED) T_PAIR(T, S, 7, MASKED)  \
-        T_PAIR(T, S, 8, MASKED) T_PAIR(T, S, 9, MASKED) T_PAIR(T, S, 10, MASKED) T_PAIR(T, S, 11, MASKED)  \
-        T_PAIR(T, S, 12, MASKED) T_PAIR(T, S, 13, MASKED) T_PAIR(T, S, 14, MASKED) T_PAIR(T, S, 15, MASKED)  \
+        T_PAIR(T, S, 0, MASKED, BD) T_PAIR(T, S, 1, MASKED, BD) T_PAIR(T, S, 2, MASKED, BD) T_PAIR(T, S, 3, MASKED, BD)  \
+        T_PAIR(T, S, 4, MASKED, BD) T_PAIR(T, S, 5, MASKED, BD) T_PAIR(T, S, 6, MASKED, BD) T_PAIR(T, S, 7, MASKED, BD)  \
+        T_PAIR(T, S, 8, MASKED, BD) T_PAIR(T, S, 9, MASKED, BD) T_PAIR(T, S, 10, MASKED, BD) T_PAIR(T, S, 11, MASKED, BD)  \
+        T_PAIR(T, S, 12, MASKED, BD) T_PAIR(T, S, 13, MASKED, BD) T_PAIR(T, S, 14, MASKED, BD) T_PAIR(T, S, 15, MASKED, BD)  \
+        /* this wave's LDS-DMA rows of B tile T + 1 (the 8 oldest outstanding requests) have landed; the 8 younger operand-A \
+           rows of tile T + 3 stay in flight */                                                  \
+        if (BD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                 \
         lds_barrier(); /* NOT __syncthreads(): the operand rows of tile T + 3 stay in flight across the barrier */ \
     }
-#define T_PAIR(T, S, J, MASKED)                                                                  \
+#define T_PAIR(T, S, J, MASKED, BD)                                                              \
     {                                                                                            \
         if ((J) < 15) {                                                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) pa[((J) + 1) & 1][i] = As[(2 * (J) + 2 + lh) * T256_LD + i * 32]; \
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
             _Pragma("unroll") for (int n = 0; n < 4; ++n)                                        \
                 acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(J) & 1][i], pb[(J) & 1][n], acc[i][n], 0, 0, 0); \
-        T_ITEM(((T) + 1) & 1, S, T, J, MASKED)                                                   \
+        T_ITEM(((T) + 1) & 1, S, T, J, MASKED, BD)                                               \
         if ((J) < 15) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                         \
         _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                       \
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                   \
@@ -550,23 +553,66 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
         }                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
-    T_FETCH(0, 0)
-    T_STORE(0, 0, 0)
-    T_FETCH(1, 0)
-    T_FETCH(2, 1)
-    __syncthreads();
+    // Operand B of a product that is exactly 256 x 256 arrives by LDS-DMA (global_load_lds, one 1 KB k row per instruction,
+    // 8 per wave and k-tile, issued at the start of the step that multiplies the PREVIOUS tile): it has no column sums to feed
+    // and needs no masks -- rows behind k_end are clamped duplicates that meet zeroed rows of A --, so its 64 staging
+    // registers, 8 ds_write_b128 and 8 vector loads per step and their waits disappear from the MFMA stream.
+#define T_DMA_B(BUF, T)                                                                          \
+    _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) {                                           \
+        const int kc_ = min(k_begin + (T) * TK + wave_u + 4 * u_, k_end - 1);                    \
+        lds_dma_16<0>(Bp + (int64_t)kc_ * ldb, lds_addr(lds256 + (BUF) * T256_BUF + TK * T256_LD + (wave_u + 4 * u_) * T256_LD), \
+                      (unsigned)(tid & 63) * 16u);                                               \
+    }
+    // Column masks are not needed for correctness in either path: operand columns >= M / >= N are loaded from clamped
+    // (in-bounds) addresses and only ever meet output rows / columns that are not stored.  What must be zeroed are the k rows
+    // behind k_end (clamped duplicates), and only the last <= 3 steps of a slice stage such rows: the steady state of EVERY
+    // product runs the mask-free step (a 217-wide product used to run the masked step throughout: 76 vs 128 TFLOP/s).
     int t = 0;
-    if (g.M == T256 && g.N == T256) {  // (workgroup-uniform) steps <= nt - 3 stage tiles <= nt - 2: complete 16 x 256 tiles
-        for (; t + 3 < nt; t += 2) {
-            T_STEP(t, 0, false)
-            T_STEP(t + 1, 1, false)
+    if (g.N == T256) {  // (workgroup-uniform) full-width rows of B: LDS-DMA
+        T_DMA_B(0, 0)
+        fetch_tile256(Ap, lda, (int)g.M, k_begin, k_end, tid, ra[0]);
+        mask_tile256((int)g.M, k_begin, k_end, tid, ra[0]);
+        if (do_cs) {
+#pragma unroll
+            for (int u2_ = 0; u2_ < 8; u2_ += 2) {
+                cs.x += ra[0][u2_].x + ra[0][u2_ + 1].x; cs.y += ra[0][u2_].y + ra[0][u2_ + 1].y;
+                cs.z += ra[0][u2_].z + ra[0][u2_ + 1].z; cs.w += ra[0][u2_].w + ra[0][u2_ + 1].w;
+            }
         }
+#pragma unroll
+        for (int u_ = 0; u_ < 8; ++u_)
+            *reinterpret_cast<float4*>(lds256 + ((tid >> 6) + 4 * u_) * T256_LD + (tid & 63) * 4) = ra[0][u_];
+        fetch_tile256(Ap, lda, (int)g.M, k_begin + TK, k_end, tid, ra[0]);
+        fetch_tile256(Ap, lda, (int)g.M, k_begin + 2 * TK, k_end, tid, ra[1]);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // the DMA rows of tile 0 (older than the 16 operand-A rows just requested)
+        __syncthreads();
+        // steps <= nt - 3 stage tiles <= nt - 2: complete 16 x 256 tiles, no masks
+        for (; t + 3 < nt; t += 2) {
+            T_STEP(t, 0, false, true)
+            T_STEP(t + 1, 1, false, true)
+        }
+        for (; t + 1 < nt; t += 2) {  // no control flow around the MFMA blocks: 256 accumulators must not meet a merge
+            T_STEP(t, 0, true, true)
+            T_STEP(t + 1, 1, true, true)
+        }
+        if (t < nt) T_STEP(t, 0, true, true)
+    } else {
+        T_FETCH(0, 0)
+        T_STORE(0, 0, 0)
+        T_FETCH(1, 0)
+        T_FETCH(2, 1)
+        __syncthreads();
+        for (; t + 3 < nt; t += 2) {
+            T_STEP(t, 0, false, false)
+            T_STEP(t + 1, 1, false, false)
+        }
+        for (; t + 1 < nt; t += 2) {
+            T_STEP(t, 0, true, false)
+            T_STEP(t + 1, 1, true, false)
+        }
+        if (t < nt) T_STEP(t, 0, true, false)
     }
-    for (; t + 1 < nt; t += 2) {  // no control flow around the MFMA blocks: 256 accumulators must not meet a merge
-        T_STEP(t, 0, true)
-        T_STEP(t + 1, 1, true)
-    }
-    if (t < nt) T_STEP(t, 0, true)
+#undef T_DMA_B
 #undef T_STEP
 #undef T_PAIR
 #undef T_ITEM
