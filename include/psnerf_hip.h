@@ -489,6 +489,28 @@ int psn_mlp_infer_bf16_grouped(const PsnBf16Desc* desc, const uint16_t* packed_w
 int psn_bf16_pack_group_bias(const float* V, int64_t n, uint16_t* dst, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Split-bf16 ("bf16x6") inference engine, csrc/mlp_infer_x3.hip -- EXPERIMENT, opt-in, gradient-free rows only.  The
+ * network of psn_mlp_infer_bf16_grouped with every fp32 operand carried as three bf16 planes (hi / mid / lo, exact sum)
+ * and every product as the six partial products of weight >= 2^-16: fp32-class results from the bf16 matrix pipe.
+ *   psn_x3_pack        W [rows, cols] fp32 -> k-steps [ks0, ks0 + n_ks) as [ks][n_ot tiles][3 planes][64 lanes][8] bf16 (K order
+ *                      as psn_mlp_pack_bf16: natural for the input block, permuted for activations)
+ *   psn_x3_pack_bias   V [n, 256] fp32 -> n bias k-steps [8 tiles][64 lanes][8] bf16 (K slots 0..2 = the three pieces)
+ *   psn_x3_split_table X [n, 64] fp32 -> [n][3 planes][64] bf16
+ *   psn_mlp_infer_x3_grouped: rows (g, n) -> g * rows_per_group + n; packed_w = the weight stream in execution order (48 KB
+ *     stages of 2 k-steps: layer 0 = 4 input k-steps; hidden layer = 16 activation k-steps [+ 4 input k-steps]; final layer =
+ *     one stage [16 k-steps][3 planes], + 56 KB of padding); bias_steps [n_hidden][8 KB] (layers without an input block);
+ *     group_bias [n_groups][n_input_layers][8 KB] = psn_x3_pack_bias(W_b x_g + b); tab_a = psn_x3_split_table of the
+ *     per-row half of the input block.  out [n_groups * rows_per_group, n_out] fp32.
+ * ---------------------------------------------------------------------- */
+int psn_x3_pack(const float* W, int64_t ldw, int rows, int cols, int permuted, int n_ot, int ks0, int n_ks, uint16_t* dst, void* stream);
+int psn_x3_pack_bias(const float* V, int64_t n, uint16_t* dst, void* stream);
+int psn_x3_split_table(const float* X, int64_t n, uint16_t* dst, void* stream);
+int psn_mlp_infer_x3_grouped(const PsnBf16Desc* desc, const uint16_t* packed_w, const uint16_t* bias_steps, const float* final_bias,
+                             const uint16_t* tab_a, int64_t rows_per_group, const uint16_t* group_bias, int64_t n_groups, float* out,
+                             void* stream);
+
+
+/* ------------------------------------------------------------------------
  * Spherical-Gaussian shading over the light-major rows (l, n) -> l*Ns + n:
  * stage2/model/sgbasis.py:16-32 + stage2/model/renderer.py:174-204
  *   h = normalize(l + v); D_k = exp(max(lobe_k,0) (h.n - 1)); spec_c = max(sum_k w_{c,k} D_k, 0)

@@ -1,0 +1,424 @@
+// Split-bf16 ("bf16x6") inference engine for the 256-wide ReLU networks of stage 2: fp32-class accuracy on the bf16 matrix
+// pipe.  EXPERIMENT, opt-in (PSNetwork.inference_precision = 'bf16x6' / conf train.vis_bf16x6), gradient-free rows only: the
+// L shading rows of stage2/model/renderer.py:191-200 (vis.detach() at :197) and the relighting evaluation of
+// stage2/eval.py:199-218.  The exact-fp32 engine of mlp_infer.hip stays the default and the headline.
+//
+// Every fp32 operand is the exact sum of three bf16 numbers, x = x_hi + x_mid + x_lo (8 + 8 + 8 significant bits, each piece
+// the round-to-nearest bf16 of what the previous ones left), and a product is evaluated as the six partial products whose
+// weight is >= 2^-16 of the full one,
+//     w x ~= w_hi x_hi + w_hi x_mid + w_mid x_hi + w_hi x_lo + w_mid x_mid + w_lo x_hi        (fp32 accumulation in the MFMA),
+// dropping w_mid x_lo + w_lo x_mid + w_lo x_lo <= 3 * 2^-24 |w x|: one fp32 ulp per product, i.e. the error of an fp32 FMA
+// chain.  bf16 MFMA runs at 16x the fp32 MFMA rate, so six of them still are 2.7x the fp32 peak on paper.
+//
+// Tiling (v_mfma_f32_32x32x16_bf16: M = 32 features, N = 32 rows, K = 16): a wave owns 32 rows x 256 features = 128 fp32
+// accumulators and keeps the three planes of its activations (3 x 16 k-steps x 4 registers) in registers in the B-operand
+// layout; the C/D registers of a layer, ReLU'd and split, ARE the next layer's B operands through the permuted K order of
+// the bf16 engine (mlp_infer_bf16.hip: feature 32 ot + 16 qp + 8 (j / 4) + 4 h + (j % 4) <-> k-step 2 ot + qp, slot 8 h + j).
+// Workgroup = 4 waves = 128 rows of ONE row group (light), one workgroup per CU (1 wave per SIMD, <= 512 registers).
+// Weights stream L2 -> LDS by LDS-DMA in stages of 2 k-steps x 3 planes x 8 output tiles = 48 KB, double buffered; the bias
+// of a layer (its three pieces in K slots 0..2 of one k-step, against the constant operand (1, 1, 1, 0, ...): exact) rides
+// with the layer's first stage.  Input block: table A (the point's encoding, pre-split into planes) as 4 natural-order
+// k-steps; the group's half W_b pe(l) + b is an fp32 product per (group, input layer) on the host side, folded into that
+// layer's bias -- as in the grouped bf16 engine.
+#include "common.h"
+
+namespace psn {
+
+typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
+typedef float xfloatx2 __attribute__((ext_vector_type(2)));
+typedef int xintx4 __attribute__((ext_vector_type(4)));
+
+struct X3Args {
+    PsnBf16Desc d;
+    const unsigned char* w;        // weight stream in execution order (48 KB stages)
+    const unsigned char* bias;     // [n_hidden][8 KB] bias k-steps of the layers WITHOUT an input block
+    const unsigned char* gbias;    // [n_groups][n_in_layers][8 KB] bias k-steps of the layers that read the input block
+    const float* final_bias;
+    const unsigned char* ta;       // [rows_per_group][3 planes][64] bf16
+    unsigned rows_per_group, tiles_per_group, n_in_layers;
+    float* out;
+};
+
+constexpr int kX3Piece = 1024;
+constexpr int kX3KsBytes = 24 * 1024;        // one k-step: 8 output tiles x 3 planes x 1 KB
+constexpr int kX3StageBytes = 2 * kX3KsBytes;  // 48 KB
+constexpr int kX3BiasBytes = 8 * 1024;
+constexpr int kX3BufBytes = kX3StageBytes + kX3BiasBytes;  // 56 KB per LDS buffer
+constexpr int kX3Waves = 4;
+
+// this wave's share of a stage request: pieces [12 wave, 12 wave + 12) of the 48 KB stream part, and -- with_bias -- pieces
+// [2 wave, 2 wave + 2) of the layer's 8 KB bias k-step
+__device__ __forceinline__ void x3_dma_piece(const unsigned char* __restrict__ gsrc, unsigned char* lds_dst, const unsigned char* __restrict__ bsrc,
+                                             int wave, int lane, int j) {
+    const unsigned voff = lane * 16;
+    if (j < 12) {
+        const int grp = j >> 2;
+        const unsigned char* base = gsrc + wave * (12 * kX3Piece) + grp * 4096;
+        const unsigned lds = lds_addr(lds_dst + wave * (12 * kX3Piece) + grp * 4096);
+        switch (j & 3) {
+            case 0: lds_dma_16<0>(base, lds, voff); break;
+            case 1: lds_dma_16<1024>(base, lds, voff); break;
+            case 2: lds_dma_16<2048>(base, lds, voff); break;
+            default: lds_dma_16<3072>(base, lds, voff); break;
+        }
+    } else {
+        const unsigned char* base = bsrc + wave * 2048;
+        const unsigned lds = lds_addr(lds_dst + kX3StageBytes + wave * 2048);
+        if (j == 12) lds_dma_16<0>(base, lds, voff);
+        else lds_dma_16<1024>(base, lds, voff);
+    }
+}
+
+__device__ __forceinline__ float x3_bf16_to_f32_lo(int packed) { return __builtin_bit_cast(float, packed << 16); }
+__device__ __forceinline__ float x3_bf16_to_f32_hi(int packed) { return __builtin_bit_cast(float, packed & (int)0xFFFF0000); }
+__device__ __forceinline__ int x3_cvt2(float a, float b) {
+    xfloatx2 f;
+    f[0] = a; f[1] = b;
+    return __builtin_bit_cast(int, __builtin_convertvector(f, xbf16x2));  // v_cvt_pk_bf16_f32, round to nearest even
+}
+// two fp32 values -> their hi / mid / lo bf16 pairs (each piece exact in fp32: the residuals have <= 16 significant bits)
+__device__ __forceinline__ void x3_split2(float a, float b, int& hi, int& mid, int& lo) {
+    hi = x3_cvt2(a, b);
+    const float ra = a - x3_bf16_to_f32_lo(hi), rb = b - x3_bf16_to_f32_hi(hi);
+    mid = x3_cvt2(ra, rb);
+    lo = x3_cvt2(ra - x3_bf16_to_f32_lo(mid), rb - x3_bf16_to_f32_hi(mid));
+}
+
+// The six partial products of one (k-step, output tile pair): fragments a[plane][o] (o = tile of the pair), B planes
+// b[plane].  Consecutive MFMAs alternate between the two accumulators, smallest terms first.
+__device__ __forceinline__ void x3_mma_pair(floatx16& c0, floatx16& c1, const xbf16x8 (&a)[3][2], const xbf16x8& bh, const xbf16x8& bm, const xbf16x8& bl) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][0], bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][1], bh, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bl, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], bl, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], bm, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], bm, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], bh, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bm, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], bm, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], bh, c1, 0, 0, 0);
+}
+
+// One 48 KB stage = 2 k-steps against all 8 output tiles: 8 (k-step, tile pair) groups of 12 MFMAs; the 6 fragment reads of
+// group g + 1 are issued at the head of group g, this wave's LDS-DMA pieces of the next stage ride in the first groups.
+template <typename BOp, typename RequestPiece>
+__device__ __forceinline__ void x3_stage_mma(floatx16 (&acc)[8], const xbf16x8* __restrict__ wl, int lane, int n_pieces, BOp bop, RequestPiece request_piece) {
+    xbf16x8 a[2][3][2];
+    auto load_frags = [&](int grp, xbf16x8 (&f)[3][2]) __attribute__((always_inline)) {
+        const int ks = grp >> 2, p = grp & 3;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) f[pl][o] = wl[((ks * 8 + 2 * p + o) * 3 + pl) * 64 + lane];
+    };
+    load_frags(0, a[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int grp = 0; grp < 8; ++grp) {
+        const int ks = grp >> 2, p = grp & 3;
+        if (grp + 1 < 8) {
+            load_frags(grp + 1, a[(grp + 1) & 1]);
+            // the reads are ISSUED here, a whole group (12 MFMAs = 384 cycles) ahead of their use: without the region boundary
+            // the register allocator merges the two fragment sets and sinks the reads behind this group's last MFMAs, and with
+            // one wave per SIMD their latency is then exposed at the head of every group
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        x3_mma_pair(acc[2 * p], acc[2 * p + 1], a[grp & 1], bop(0, ks), bop(1, ks), bop(2, ks));
+        if (grp < 6) { request_piece(2 * grp); request_piece(2 * grp + 1); }   // the 12 stream pieces: unconditional
+        else if (grp == 6 && n_pieces > 12) { request_piece(12); request_piece(13); }  // the bias k-step of the next layer (wave-uniform)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsmem[];  // 2 x (48 KB stage + 8 KB bias k-step)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 31, lh = lane >> 5;
+    const int n_hidden = g.d.n_hidden;
+    const unsigned group = blockIdx.x / g.tiles_per_group;
+    const unsigned tile = blockIdx.x - group * g.tiles_per_group;
+    const unsigned char* gb = g.gbias + (size_t)group * g.n_in_layers * kX3BiasBytes;
+
+    const unsigned char* wptr = g.w;  // the NEXT stage to request
+    int in_idx = 0;                   // input layers seen so far
+    int gstage = 0;
+    // first stage of layer 0 (+ its group bias)
+#pragma unroll
+    for (int j = 0; j < 14; ++j) x3_dma_piece(wptr, xsmem, gb, wave, lane, j);
+    wptr += kX3StageBytes;
+
+    const unsigned n = tile * (unsigned)(kX3Waves * 32) + wave * 32 + ln;
+    const bool valid = n < g.rows_per_group;
+    const unsigned row = group * g.rows_per_group + n;
+    const unsigned char* tap = g.ta + (size_t)(valid ? n : g.rows_per_group - 1) * 384u + lh * 16;
+    xbf16x8 bin[3][4];
+    auto load_in = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bin[pl][s] = *reinterpret_cast<const xbf16x8*>(tap + pl * 128 + s * 32);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(bin[pl][s]));  // arrived before the next LDS-DMA pieces are issued
+    };
+    xbf16x8 ones_b;  // K slots 0..2 (lane half 0) carry the constant 1: the three bias pieces add up exactly
+    {
+        xintx4 o = {lh == 0 ? 0x3F803F80 : 0, lh == 0 ? 0x00003F80 : 0, 0, 0};
+        ones_b = __builtin_bit_cast(xbf16x8, o);
+    }
+
+    floatx16 acc[8];
+    xbf16x8 bact[3][16];
+
+    // One stage: this wave's pieces have landed, barrier, MFMAs with the request for the next stage in their gaps.
+#define X3_STAGE(BOP, NEXT_HAS_BIAS, BSRC)                                                                   \
+    {                                                                                                        \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+        __syncthreads();                                                                                     \
+        const xbf16x8* wl = reinterpret_cast<const xbf16x8*>(xsmem + (gstage & 1) * kX3BufBytes);            \
+        unsigned char* nxt = xsmem + ((gstage + 1) & 1) * kX3BufBytes;                                       \
+        const unsigned char* bsrc_ = (BSRC);                                                                 \
+        x3_stage_mma(acc, wl, lane, (NEXT_HAS_BIAS) ? 14 : 12, BOP,                                          \
+                     [&](int j_) { x3_dma_piece(wptr, nxt, bsrc_, wave, lane, j_); });                       \
+        wptr += kX3StageBytes;                                                                               \
+        ++gstage;                                                                                            \
+    }
+    // bias of the layer whose first stage sits in LDS buffer (gstage & 1): acc = b_hi + b_mid + b_lo (exact)
+    auto init_acc = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const xbf16x8* bl = reinterpret_cast<const xbf16x8*>(xsmem + (gstage & 1) * kX3BufBytes + kX3StageBytes);
+        floatx16 zero;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ot * 64 + lane], ones_b, zero, 0, 0, 0);
+    };
+    // bias source of layer l (requested together with that layer's first stage)
+    auto bias_src = [&](int l, int idx) __attribute__((always_inline)) -> const unsigned char* {
+        if (l >= n_hidden) return g.bias;  // (the final layer's stage carries no bias k-step; any valid address)
+        return g.d.has_in[l] != 0 ? gb + (size_t)idx * kX3BiasBytes : g.bias + (size_t)l * kX3BiasBytes;
+    };
+    // ReLU + split of the finished accumulators into the three B-operand planes of the next layer
+    auto epilogue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) {
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                xintx4 oh, om, ol;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float c0 = relu1(acc[ot][8 * qp + 2 * i]), c1 = relu1(acc[ot][8 * qp + 2 * i + 1]);
+                    int h_, m_, l_;
+                    x3_split2(c0, c1, h_, m_, l_);
+                    oh[i] = h_; om[i] = m_; ol[i] = l_;
+                }
+                bact[0][2 * ot + qp] = __builtin_bit_cast(xbf16x8, oh);
+                bact[1][2 * ot + qp] = __builtin_bit_cast(xbf16x8, om);
+                bact[2][2 * ot + qp] = __builtin_bit_cast(xbf16x8, ol);
+            }
+        }
+    };
+
+    // layer 0: the input block only (2 stages)
+    load_in();
+    ++in_idx;
+    init_acc();
+    X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bin[pl][ks]; }), false, g.bias)
+    X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bin[pl][2 + ks]; }), true, bias_src(1, in_idx))
+    epilogue();
+    for (int li = 1; li < n_hidden; ++li) {
+        const bool has_in = g.d.has_in[li] != 0;
+        if (has_in) { load_in(); ++in_idx; }
+        init_acc();
+#define X3_ACT_STAGE(S, LAST)                                                                                 \
+        X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bact[pl][2 * (S) + ks]; }), (LAST) && !has_in, bias_src(li + 1, in_idx))
+        X3_ACT_STAGE(0, false) X3_ACT_STAGE(1, false) X3_ACT_STAGE(2, false) X3_ACT_STAGE(3, false)
+        X3_ACT_STAGE(4, false) X3_ACT_STAGE(5, false) X3_ACT_STAGE(6, false) X3_ACT_STAGE(7, true)
+#undef X3_ACT_STAGE
+        if (has_in) {
+            X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bin[pl][ks]; }), false, g.bias)
+            X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bin[pl][2 + ks]; }), true, bias_src(li + 1, in_idx))
+        }
+        epilogue();
+    }
+#undef X3_STAGE
+    // final layer: one output tile (n_out <= 32), 16 k-steps x 3 planes in ONE 48 KB stage; four accumulator chains
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const xbf16x8* wl = reinterpret_cast<const xbf16x8*>(xsmem + (gstage & 1) * kX3BufBytes);
+        floatx16 f[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) f[c][i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const xbf16x8 ah = wl[(ks * 3 + 0) * 64 + lane], am = wl[(ks * 3 + 1) * 64 + lane], al = wl[(ks * 3 + 2) * 64 + lane];
+            floatx16& c = f[ks & 3];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bact[0][ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bact[2][ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bact[1][ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bact[0][ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bact[1][ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bact[0][ks], c, 0, 0, 0);
+        }
+        const int n_out = g.d.n_out;
+        if (valid) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = 8 * (v >> 2) + 4 * lh + (v & 3);
+                if (m < n_out) {
+                    float x = (f[0][v] + f[1][v]) + (f[2][v] + f[3][v]) + g.final_bias[m];
+                    if (g.d.out_act == PSN_OUT_SIGMOID) x = sigmoidf_(x);
+                    else if (g.d.out_act == PSN_OUT_OCC) x = sigmoidf_(x * -10.0f);
+                    g.out[(int64_t)row * n_out + m] = x;
+                }
+            }
+        }
+    }
+}
+
+// ---- packers --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void x3_split1(float v, uint16_t (&p)[3]) {
+    float r = v;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const __bf16 b = (__bf16)r;
+        p[i] = __builtin_bit_cast(uint16_t, b);
+        r -= (float)b;
+    }
+}
+// W[rows, cols] (row-major, ldw floats per row), zero-extended, k-steps [ks0, ks0 + n_ks) -> [ks][ot][plane][lane][8] bf16;
+// K order as psn_mlp_pack_bf16 (natural: k = 16 ks + 8 h + j; permuted: k = 32 (ks / 2) + 16 (ks % 2) + 8 (j / 4) + 4 h + (j % 4))
+__global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ W, int64_t ldw, int rows, int cols, int permuted, int n_ot,
+                                                      int ks0, int n_ks, uint16_t* __restrict__ dst) {
+    const int64_t total = (int64_t)n_ks * n_ot * 512;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int j = (int)(e & 7);
+        const int lane = (int)((e >> 3) & 63);
+        const int64_t blk = e >> 9;
+        const int ot = (int)(blk % n_ot);
+        const int ksl = (int)(blk / n_ot);
+        const int ks = ks0 + ksl;
+        const int m = lane & 31, h = lane >> 5;
+        const int r = 32 * ot + m;
+        const int k = permuted ? 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3) : 16 * ks + 8 * h + j;
+        float v = 0.0f;
+        if (r < rows && k < cols) v = W[(int64_t)r * ldw + k];
+        uint16_t p[3];
+        x3_split1(v, p);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[(((int64_t)ksl * n_ot + ot) * 3 + pl) * 512 + lane * 8 + j] = p[pl];
+    }
+}
+// V [n, 256] fp32 -> bias k-steps [n][8 tiles][64 lanes][8] bf16: K slots 0, 1, 2 (lane half 0) = hi, mid, lo of the value
+__global__ __launch_bounds__(256) void x3_pack_bias_kernel(const float* __restrict__ V, int64_t n, uint16_t* __restrict__ dst) {
+    const int64_t total = n * 4096;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int j = (int)(e & 7);
+        const int lane = (int)((e >> 3) & 63);
+        const int ot = (int)((e >> 9) & 7);
+        const int64_t r = e >> 12;
+        const int k = 8 * (lane >> 5) + j;
+        uint16_t o = 0;
+        if (k < 3) {
+            uint16_t p[3];
+            x3_split1(V[r * 256 + 32 * ot + (lane & 31)], p);
+            o = p[k];
+        }
+        dst[e] = o;
+    }
+}
+// X [n, 64] fp32 -> [n][3 planes][64] bf16
+__global__ __launch_bounds__(256) void x3_split_table_kernel(const float* __restrict__ X, int64_t n, uint16_t* __restrict__ dst) {
+    const int64_t total = n * 64;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e >> 6;
+        const int c = (int)(e & 63);
+        uint16_t p[3];
+        x3_split1(X[e], p);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[r * 192 + pl * 64 + c] = p[pl];
+    }
+}
+
+}  // namespace psn
+
+extern "C" int psn_x3_pack(const float* W, int64_t ldw, int rows, int cols, int permuted, int n_ot, int ks0, int n_ks, uint16_t* dst,
+                           void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(W && dst, "x3_pack: null pointer");
+    PSN_CHECK_ARG((n_ot == 8 || n_ot == 1) && ks0 >= 0 && n_ks >= 1 && ks0 + n_ks <= 16, "x3_pack: n_ot=%d ks0=%d n_ks=%d", n_ot, ks0, n_ks);
+    PSN_CHECK_ARG(rows >= 1 && rows <= 32 * n_ot && cols >= 1 && cols <= 256 && ldw >= cols, "x3_pack: %d x %d (ldw %lld) does not fit", rows, cols, (long long)ldw);
+    const int64_t total = (int64_t)n_ks * n_ot * 512;
+    hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, rows, cols, permuted, n_ot, ks0, n_ks, dst);
+    PSN_CHECK_LAUNCH("x3_pack");
+    return PSN_OK;
+}
+
+extern "C" int psn_x3_pack_bias(const float* V, int64_t n, uint16_t* dst, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(V && dst && n >= 1 && n < (1ll << 30), "x3_pack_bias: V / dst / n=%lld", (long long)n);
+    const int64_t total = n * 4096;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(x3_pack_bias_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, V, n, dst);
+    PSN_CHECK_LAUNCH("x3_pack_bias");
+    return PSN_OK;
+}
+
+extern "C" int psn_x3_split_table(const float* X, int64_t n, uint16_t* dst, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(X && dst && n >= 0, "x3_split_table: null pointer");
+    if (n == 0) return PSN_OK;
+    const int64_t total = n * 64;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(x3_split_table_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, n, dst);
+    PSN_CHECK_LAUNCH("x3_split_table");
+    return PSN_OK;
+}
+
+extern "C" int psn_mlp_infer_x3_grouped(const PsnBf16Desc* desc, const uint16_t* packed_w, const uint16_t* bias_steps, const float* final_bias,
+                                        const uint16_t* tab_a, int64_t rows_per_group, const uint16_t* group_bias, int64_t n_groups,
+                                        float* out, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(desc && packed_w && bias_steps && final_bias && tab_a && group_bias && out, "mlp_infer_x3_grouped: null pointer");
+    const PsnBf16Desc& d = *desc;
+    PSN_CHECK_ARG(d.n_hidden >= 1 && d.n_hidden <= PSN_MLP_MAX_LAYERS && d.n_out >= 1 && d.n_out <= 32, "mlp_infer_x3_grouped: n_hidden=%d n_out=%d", d.n_hidden, d.n_out);
+    PSN_CHECK_ARG(d.out_act >= PSN_OUT_NONE && d.out_act <= PSN_OUT_OCC && d.has_in[0] != 0, "mlp_infer_x3_grouped: out_act=%d, layer 0 must read the input block", d.out_act);
+    PSN_CHECK_ARG((((uintptr_t)packed_w | (uintptr_t)bias_steps | (uintptr_t)tab_a | (uintptr_t)group_bias) & 15) == 0, "mlp_infer_x3_grouped: buffers must be 16-byte aligned");
+    PSN_CHECK_ARG(rows_per_group >= 0 && n_groups >= 0 && rows_per_group <= (1ll << 24) && rows_per_group * n_groups < (1ll << 31),
+                  "mlp_infer_x3_grouped: 32-bit index arithmetic: rows per group <= 2^24, rows < 2^31");
+    if (rows_per_group == 0 || n_groups == 0) return PSN_OK;
+    X3Args a = {};
+    a.d = d;
+    a.w = reinterpret_cast<const unsigned char*>(packed_w);
+    a.bias = reinterpret_cast<const unsigned char*>(bias_steps);
+    a.gbias = reinterpret_cast<const unsigned char*>(group_bias);
+    a.final_bias = final_bias;
+    a.ta = reinterpret_cast<const unsigned char*>(tab_a);
+    a.rows_per_group = (unsigned)rows_per_group;
+    a.tiles_per_group = (unsigned)((rows_per_group + kX3Waves * 32 - 1) / (kX3Waves * 32));
+    int n_in = 0;
+    for (int l = 0; l < d.n_hidden; ++l) n_in += d.has_in[l] != 0;
+    a.n_in_layers = (unsigned)n_in;
+    a.out = out;
+    const int64_t blocks = (int64_t)a.tiles_per_group * n_groups;
+    PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer_x3_grouped: too many rows");
+    const size_t lds_bytes = 2 * kX3BufBytes;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_infer_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+        set_error("mlp_infer_x3_grouped: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+        return PSN_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(mlp_infer_x3_kernel, dim3((unsigned)blocks), dim3(kX3Waves * 64), lds_bytes, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("mlp_infer_x3_grouped");
+    return PSN_OK;
+}

@@ -137,6 +137,10 @@ SIGNATURES = {
     'psn_mlp_infer_bf16': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, i64, c_f, c_f]),
     'psn_mlp_infer_bf16_grouped': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, i64, c_f, i64, c_f, c_f]),
     'psn_bf16_pack_group_bias': (i32, [c_f, i64, c_f, c_f]),
+    'psn_x3_pack': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
+    'psn_x3_pack_bias': (i32, [c_f, i64, c_f, c_f]),
+    'psn_x3_split_table': (i32, [c_f, i64, c_f, c_f]),
+    'psn_mlp_infer_x3_grouped': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, c_f, i64, c_f, i64, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library out of date: fail loudly
@@ -916,6 +920,55 @@ def mlp_infer_bf16_grouped(desc, packed_w, final_bias, tab_a, group_bias, n_grou
         _check(_lib.psn_mlp_infer_bf16_grouped(ctypes.byref(desc), packed_w.data_ptr(), _ptr(final_bias, 'final_bias'),
                                                _bf16_table(tab_a, 'tab_a'), rows, group_bias.data_ptr(), n_groups,
                                                _ptr(out, 'out'), _stream()), 'mlp_infer_bf16_grouped')
+    return out
+
+
+# --------------------------------------------------------------------------- split-bf16 ("bf16x6") engine, experiment
+X3_KS = 8 * 3 * 512  # bf16 elements of one hidden-layer k-step: 8 output tiles x 3 planes x 1 KB
+
+
+def x3_pack(W, permuted, n_ot, ks0, n_ks, dst):
+    """k-steps [ks0, ks0 + n_ks) of the fp32 matrix W -> dst (flat bfloat16 view, n_ks * n_ot * 3 * 512 elements): the three
+    bf16 planes of every weight in fragment order of the split engine (psn_x3_pack)."""
+    assert W.dim() == 2 and W.stride(1) == 1 and W.is_cuda and W.dtype == torch.float32
+    assert dst.dtype == torch.bfloat16 and dst.is_contiguous() and dst.numel() == n_ks * n_ot * 3 * 512
+    _check(_lib.psn_x3_pack(W.data_ptr(), W.stride(0), W.shape[0], W.shape[1], int(permuted), n_ot, ks0, n_ks, dst.data_ptr(), _stream()),
+           'x3_pack')
+
+
+def x3_pack_bias(V, dst=None):
+    """V [n, 256] fp32 -> [n, 4096] bfloat16 bias k-steps (K slots 0..2 = hi / mid / lo)."""
+    assert V.is_cuda and V.dtype == torch.float32 and V.is_contiguous() and V.dim() == 2 and V.shape[1] == 256
+    if dst is None:
+        dst = torch.empty(V.shape[0], 4096, device=V.device, dtype=torch.bfloat16)
+    assert dst.dtype == torch.bfloat16 and dst.is_contiguous() and dst.numel() == V.shape[0] * 4096
+    _check(_lib.psn_x3_pack_bias(V.data_ptr(), V.shape[0], dst.data_ptr(), _stream()), 'x3_pack_bias')
+    return dst
+
+
+def x3_split_table(X):
+    """X [n, 64] fp32 -> [n, 3, 64] bfloat16 (the three planes of every feature)."""
+    assert X.is_cuda and X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 2 and X.shape[1] == 64
+    dst = torch.empty(X.shape[0], 3, 64, device=X.device, dtype=torch.bfloat16)
+    _check(_lib.psn_x3_split_table(X.data_ptr(), X.shape[0], dst.data_ptr(), _stream()), 'x3_split_table')
+    return dst
+
+
+def mlp_infer_x3_grouped(desc, packed_w, bias_steps, final_bias, tab_a3, group_bias, n_groups, out=None, macs_per_row=None):
+    """Rows (g, n) -> g * tab_a3.shape[0] + n on the split-bf16 engine (psn_mlp_infer_x3_grouped)."""
+    rows = tab_a3.shape[0]
+    if out is None:
+        out = torch.empty(n_groups * rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
+    n_in = sum(1 for l in range(desc.n_hidden) if desc.has_in[l])
+    for t, nm in ((packed_w, 'packed_w'), (bias_steps, 'bias_steps'), (tab_a3, 'tab_a3'), (group_bias, 'group_bias')):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+            raise RuntimeError('%s: must be a contiguous bfloat16 HIP tensor' % nm)
+    assert tab_a3.shape[1:] == (3, 64) and bias_steps.numel() == desc.n_hidden * 4096 and group_bias.numel() == n_groups * n_in * 4096
+    assert final_bias.numel() == 32 and out.numel() == n_groups * rows * desc.n_out
+    with _Prof('mlp_infer_x3', n_groups * rows, None if macs_per_row is None else 2.0 * macs_per_row * n_groups * rows):
+        _check(_lib.psn_mlp_infer_x3_grouped(ctypes.byref(desc), packed_w.data_ptr(), bias_steps.data_ptr(), _ptr(final_bias, 'final_bias'),
+                                             tab_a3.data_ptr(), rows, group_bias.data_ptr(), n_groups, _ptr(out, 'out'), _stream()),
+               'mlp_infer_x3_grouped')
     return out
 
 

@@ -225,3 +225,42 @@ def test_train_vis_bf16_option(cuda):
     assert l0['vis_loss'] == l1['vis_loss']
     assert abs(l0['sg_rgb_loss'] - l1['sg_rgb_loss']) <= 1e-4 * abs(l0['sg_rgb_loss'])
     assert float((g1 - g0).norm() / g0.norm()) < 1e-3
+
+
+def _ref64(Ws, bs, xa, xb_rows, skip_at, dtype):
+    """The network in plain torch at ``dtype`` on the light-major rows (g, n): input [xa[n] | xb[g]]."""
+    Ws, bs = [w.to(dtype) for w in Ws], [b.to(dtype) for b in bs]
+    x = torch.cat([xa.to(dtype).repeat(xb_rows.shape[0], 1), xb_rows.to(dtype).repeat_interleave(xa.shape[0], dim=0)], dim=1)
+    h = None
+    for li in range(len(Ws) - 1):
+        inp = x if li == 0 else (torch.cat([h, x], dim=1) if li - 1 == skip_at else h)
+        h = torch.relu(inp @ Ws[li].t() + bs[li])
+    return h @ Ws[-1].t() + bs[-1]
+
+
+@pytest.mark.parametrize('nA,nB,depth,skip_at,n_out', [(1000, 7, 9, 4, 1), (129, 3, 9, 4, 1), (37, 2, 5, 1, 3), (4096, 12, 9, 4, 1)])
+def test_split_bf16_engine_has_fp32_class_accuracy(cuda, nA, nB, depth, skip_at, n_out):
+    """csrc/mlp_infer_x3.hip (every operand as three bf16 planes, six partial products per multiply): its distance from the
+    float64 evaluation of the network is that of an fp32 evaluation (compared with torch's own fp32 result on the same rows),
+    and it meets the elementwise parity bound of the exact-fp32 path, 1e-4 |ref| + 1e-5 -- which the plain bf16 engine misses
+    by two orders of magnitude."""
+    from psnerf_amd import fused
+    Ws, bs = _net(63, 63, depth, skip_at, n_out, 5, cuda)
+    xa, xb = _table(nA, 63, 1, cuda), _table(nB, 63, 2, cuda)
+    pk = fused.pack_relu_mlp_x3_grouped(Ws, bs, 63, 63, skip_at)
+    got = pk(xa, xb)
+    ref64 = _ref64(Ws, bs, xa[:, :63], xb[:, :63], skip_at, torch.float64)
+    ref32 = _ref64(Ws, bs, xa[:, :63], xb[:, :63], skip_at, torch.float32)
+    assert got.shape == ref64.shape == (nA * nB, n_out)
+    e_x3 = (got.double() - ref64).abs()
+    e_32 = (ref32.double() - ref64).abs()
+    scale = float(ref64.abs().max())
+    print('max |x3 - f64| %.3e, max |torch fp32 - f64| %.3e, output scale %.3f' % (float(e_x3.max()), float(e_32.max()), scale))
+    assert float(e_x3.max()) <= 4.0 * float(e_32.max()) + 1e-7 * scale, (float(e_x3.max()), float(e_32.max()))
+    assert float(e_x3.mean()) <= 3.0 * float(e_32.mean()) + 1e-8 * scale
+    bound = 1e-4 * ref64.abs() + 1e-5
+    assert bool((e_x3 <= bound).all())
+    # the plain bf16 engine on the same rows, for scale
+    pk16 = fused.pack_relu_mlp_bf16_grouped(Ws, bs, 63, 63, skip_at)
+    e_16 = (pk16(xa.to(torch.bfloat16), xb).double() - ref64).abs()
+    assert float(e_16.max()) > 30.0 * float(e_x3.max())
