@@ -25,6 +25,8 @@ Extra objects on the JSON line (all measured after the headline's timed region):
   reference_dict  the same step fed the reference's dictionary WITHOUT 'surface_idx' (the index list is then rebuilt from
                 the mask inside the timed step: one nonzero() = one host synchronisation per step)
   launches_per_step  device kernel launches of one steady-state step (torch.profiler), hand-written HIP vs torch-eager
+  bf16x6_experiment  opt-in experiment, NOT the headline: the same step with the gradient-free L x Ns visibility rows on the
+                split-bf16 engine (csrc/mlp_infer_x3.hip): f32-class results (same oracle gate) from the bf16 matrix pipe
   cpu_baseline  the CPU oracle (oracle/stage2.py, a verified restatement of the reference) on this host, N = 1 only
   strong        strong-scaling measurement (fixed global batch)
   allreduce_ms  average time of one gradient all-reduce of the step's bucket size (N > 1)
@@ -320,6 +322,30 @@ def main():
                     'steps': k3, 'warmup': 2, 'batch': "the reference's model_input keys only (stage2/model/renderer.py:110-125); the "
                     "surface index list is built inside the step"}
         del inp_ref
+    x6 = None
+    if not args.no_extra and world == 1:
+        # EXPERIMENT, never the headline: the L shading rows (gradient-free: vis.detach(), renderer.py:197) on the split-bf16
+        # engine -- fp32 operands as three bf16 planes, six partial products per multiply, fp32 accumulation -- which passes the
+        # same elementwise oracle gate as the exact-fp32 path (tests/test_bf16_gpu.py).  Separate object, own dtype label.
+        step.model.train_vis_bf16x6 = True
+        try:
+            k4 = max(3, min(args.steps, 30))
+            dt4, ns4, terms4 = timed(inp, gt, k4, 3)
+            ev4 = instrumented(inp, gt, 5)
+            xk = [(r, a.elapsed_time(b)) for (name, r, a, b, _f) in ev4 if name == 'mlp_infer_x3']
+            x6 = {'value': round(ns4 * N_LIGHTS / (dt4 / k4), 1), 'unit': 'ray-samples/s', 'ms_per_step': round(dt4 / k4 * 1e3, 3),
+                  'steps': k4, 'warmup': 3, 'loss': round(float(terms4['total'].detach()), 6),
+                  'dtype': 'f32 emulated on the bf16 matrix pipe (3 x bf16 split operands, 6 partial products, f32 accumulate)',
+                  'scope': 'the L x Ns shading rows of visibility_net only (conf train.vis_bf16x6); V supervised rows, every gradient '
+                           'and all other kernels: exact f32 as in the headline'}
+            if xk:
+                rows_x, ms_x = xk[0][0], sum(t for _, t in xk) / len(xk)
+                eq = 2.0 * VIS_MACS * rows_x / (ms_x * 1e-3) / 1e12
+                x6['kernel'] = {'name': 'mlp_infer_x3_kernel', 'rows_per_launch': rows_x, 'avg_launch_ms': round(ms_x, 3),
+                                'f32_equivalent_tflops': round(eq, 1), 'vs_f32_mfma_peak': round(eq / PEAK_F32_MFMA_TFLOPS, 3),
+                                'bf16_tflops_issued': round(6 * eq, 1), 'bf16_peak': 2500.0, 'bf16_frac': round(6 * eq / 2500.0, 3)}
+        finally:
+            step.model.train_vis_bf16x6 = False
     del inp, gt
     ms_per_step = dt / args.steps * 1e3
     value = ns_total * N_LIGHTS / (dt / args.steps)
@@ -399,6 +425,7 @@ def main():
                    'batch': "ViewSampler.batch layout: reference dictionary + 'surface_idx' (host-built index list of the surface mask)"},
         'loss': round(float(terms['total'].detach()), 6),
         'roofline': roofline, 'cpu_baseline': cpu, 'reference_dict': ref_dict, 'launches_per_step': launches,
+        'bf16x6_experiment': x6,
         ('strong' if args.scaling == 'weak' else 'weak'): other,
         'allreduce_ms': allreduce_ms, 'allreduce_bytes': bucket_bytes if world > 1 else None,
         'stage1': stage1,

@@ -185,6 +185,10 @@ class PSNetwork(nn.Module):
         # it): during training, the L shading-light visibility rows -- which only enter the loss detached,
         # renderer.py:197 -- are evaluated on the bf16 engine (max |d| ~ 2e-3 on the visibility value).
         self.train_vis_bf16 = conf.get_bool('train.vis_bf16', default=False)
+        # opt-in EXPERIMENT (default off; never the headline): the same rows on the split-bf16 engine (csrc/mlp_infer_x3.hip),
+        # i.e. fp32-class arithmetic -- every operand as three bf16 planes, six partial products per multiply -- on the bf16
+        # matrix pipe.  inference_precision = 'bf16x6' selects it for gradient-free evaluations.
+        self.train_vis_bf16x6 = conf.get_bool('train.vis_bf16x6', default=False)
         # The BRDF / normal networks of a training forward (and, through autograd, their backward) run on a side stream
         # beside the visibility launch (20 of the 27 ms of a step; it is issued first and needs none of their results):
         # Ns-row launches of 25 - 70 us each, latency-bound on their own, fill the gaps of the big launch instead of
@@ -241,9 +245,12 @@ class PSNetwork(nn.Module):
         net = self.visibility_net
         Ws, bs = net.weights()
         cols = self._cols(self.n_freqs, pe_x.device, pair=True)
-        if (fused_ok and net.width == 256 and self.inference_precision == 'bf16' and not torch.is_grad_enabled()
+        if (fused_ok and net.width == 256 and self.inference_precision in ('bf16', 'bf16x6') and not torch.is_grad_enabled()
                 and len(Ws) <= 12 and pe_x.is_cuda):
-            # opt-in bf16 MFMA engine (evaluation / relighting; csrc/mlp_infer_bf16.hip)
+            # opt-in bf16 MFMA engines (evaluation / relighting): plain bf16 (csrc/mlp_infer_bf16.hip) or the split form with
+            # fp32-class accuracy (csrc/mlp_infer_x3.hip)
+            if self.inference_precision == 'bf16x6':
+                return self._visibility_rows_x3(pe_x, pe_l)
             return self._visibility_rows_bf16(pe_x, pe_l)
         if fused_ok and net.width == 256:
             params = []
@@ -285,6 +292,19 @@ class PSNetwork(nn.Module):
         """Gradient-free visibility_net rows (light-major) on the bf16 MFMA engine."""
         # grouped form: the light's half of the input block enters as a per-light bias (fp32 product, once per light)
         return self._visibility_prepack_bf16()(pe_x.to(torch.bfloat16), pe_l.contiguous())
+
+    @torch.no_grad()
+    def _visibility_rows_x3(self, pe_x, pe_l):
+        """Gradient-free visibility_net rows (light-major) on the split-bf16 engine (fp32-class accuracy; experiment)."""
+        net = self.visibility_net
+        key = params_key(net.parameters(), getattr(self, '_pack_epoch', 0))
+        if getattr(self, '_vis_packx3_key', None) != key:
+            Ws, bs = net.weights()
+            half = 3 + 6 * self.n_freqs
+            self._vis_packx3 = fused.pack_relu_mlp_x3_grouped(list(Ws), list(bs), half, half, net._skip_index(),
+                                                              hip.OUT_SIGMOID if net.final == 'sigmoid' else hip.OUT_NONE)
+            self._vis_packx3_key = key
+        return self._vis_packx3(pe_x.contiguous(), pe_l.contiguous())
 
     def _memo(self, tag, input, fn):
         """Light-independent intermediate of a gradient-free evaluation, computed once per (pixel set, weights) while a
@@ -386,10 +406,11 @@ class PSNetwork(nn.Module):
                     if side is None:
                         side = self._side[device] = torch.cuda.Stream(device=device)  # (a high-priority stream measured the same: +-0.05 ms/step)
                     side.wait_stream(torch.cuda.current_stream(device))
-                if self.train_vis_bf16:
-                    # opt-in (train.vis_bf16): the L shading rows enter the loss detached (renderer.py:197), so they can
-                    # run on the bf16 engine; the V supervised rows stay on the exact fp32 path with their dumps
-                    vis_bf16 = self._visibility_rows_bf16(pe_x, self._pe(ld0.detach(), self.n_freqs))
+                if self.train_vis_bf16 or self.train_vis_bf16x6:
+                    # opt-in (train.vis_bf16 / train.vis_bf16x6): the L shading rows enter the loss detached (renderer.py:197),
+                    # so they can run on a bf16 engine; the V supervised rows stay on the exact fp32 path with their dumps
+                    pe_l0 = self._pe(ld0.detach(), self.n_freqs)
+                    vis_bf16 = self._visibility_rows_x3(pe_x, pe_l0) if self.train_vis_bf16x6 else self._visibility_rows_bf16(pe_x, pe_l0)
                     vis_pair = self._visibility_pair_launch(pe_x, ld0[:0], lv0)
                 else:
                     vis_pair = self._visibility_pair_launch(pe_x, ld0, lv0)

@@ -264,3 +264,65 @@ def test_split_bf16_engine_has_fp32_class_accuracy(cuda, nA, nB, depth, skip_at,
     pk16 = fused.pack_relu_mlp_bf16_grouped(Ws, bs, 63, 63, skip_at)
     e_16 = (pk16(xa.to(torch.bfloat16), xb).double() - ref64).abs()
     assert float(e_16.max()) > 30.0 * float(e_x3.max())
+
+
+@pytest.mark.parametrize('N,L,V', [(3000, 5, 8), (777, 96, 3)])
+def test_train_vis_bf16x6_passes_the_exact_fp32_parity_gate(cuda, N, L, V):
+    """conf train.vis_bf16x6 (opt-in experiment): the L shading rows of a training forward on the split-bf16 engine.  Gate =
+    the SAME checks as the exact-fp32 path (tests/test_stage2_gpu.py::test_psnetwork_vs_oracle): every output elementwise
+    within 1e-4 |ref| + floor of the CPU oracle (the two specular outputs by the measured float64 allowance), loss terms 1e-4,
+    every parameter gradient 1e-3; the supervised rows stay bit-identical to the fp32 engine's."""
+    import psnerf_amd.stage2 as s2
+    from oracle import stage2 as o2
+    from tests.helpers import assert_close, assert_outputs_close
+    from tests.test_stage2_gpu import _run, _truth
+    sd = stage2_state_dict(o2.bear_conf(), seed=5)
+    onet = o2.PSNetwork(o2.bear_conf())
+    onet.load_state_dict(sd)
+    inp, gt = stage2_inputs(N, L, V, seed=N)
+    ns = int(inp['surface_mask'].sum())
+    nz = torch.randn(ns, 3, generator=torch.Generator().manual_seed(1)) * 0.01
+    o_out, o_t, o_g = _run(onet, o2.MainLoss, o2.NormalLoss, inp, gt, 2, nz, 'cpu')
+    truth = _truth(o2.bear_conf(), sd, inp, nz)
+    outs = {}
+    for flag in (False, True):
+        net = s2.PSNetwork(s2.bear_conf(**{'train.vis_bf16x6': flag}))
+        assert net.train_vis_bf16x6 is flag
+        net.load_state_dict(sd)
+        net.to(cuda)
+        outs[flag] = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, 2, nz, cuda)
+    out, t, gr = outs[True]
+    for k in o_out:
+        if torch.is_tensor(o_out[k]) and o_out[k].dtype.is_floating_point:
+            assert_outputs_close(k, out[k].detach().cpu(), o_out[k].detach(), truth=truth)
+    for k in o_t:
+        if o_t[k] is not None:
+            assert_close(float(t[k]), float(o_t[k]), 1e-4, k, atol=0.0)
+    assert sorted(gr.keys()) == sorted(o_g.keys())
+    for k in o_g:
+        assert_close(gr[k].cpu(), o_g[k], 1e-3, 'grad ' + k)
+    out0 = outs[False][0]
+    assert torch.equal(out['vis_train'], out0['vis_train'])                   # supervised rows: the exact fp32 engine
+    assert not torch.equal(out['visibility'], out0['visibility'])             # the split engine ran for the shading rows
+    m = inp['surface_mask'][0].to(cuda)
+    d = (out['visibility'] - out0['visibility'])[:, m].abs().max()
+    assert float(d) < 2e-6, 'split engine vs fp32 engine on the shading rows: %.3e' % float(d)
+
+
+def test_relight_bf16x6_matches_fp32_render(cuda):
+    """inference_precision = 'bf16x6' for a gradient-free evaluation (relighting): pixel-level agreement with the fp32 render."""
+    import psnerf_amd.stage2 as s2
+    conf = s2.bear_conf()
+    net = s2.PSNetwork(conf)
+    net.load_state_dict(stage2_state_dict(conf, seed=12))
+    net.to(cuda).eval()
+    inp, _ = stage2_inputs(2000, 16, 1, seed=4, device=cuda)
+    res = {}
+    with torch.no_grad():
+        for prec in ('fp32', 'bf16x6', 'bf16'):
+            net.inference_precision = prec
+            res[prec] = net(inp)['sg_rgb_values'].clone()
+    net.inference_precision = 'fp32'
+    d6 = float((res['bf16x6'] - res['fp32']).abs().max())
+    d1 = float((res['bf16'] - res['fp32']).abs().max())
+    assert d6 < 5e-6 and d1 > 20 * d6, (d6, d1)
