@@ -495,19 +495,16 @@ int psn_bf16_pack_group_bias(const float* V, int64_t n, uint16_t* dst, void* str
  *   psn_x3_pack        W [rows, cols] fp32 -> k-steps [ks0, ks0 + n_ks) as [ks][n_ot tiles][3 planes][64 lanes][8] bf16 (K order
  *                      as psn_mlp_pack_bf16: natural for the input block, permuted for activations)
  *   psn_x3_pack_bias   V [n, 256] fp32 -> n bias k-steps [8 tiles][64 lanes][8] bf16 (K slots 0..2 = the three pieces)
- *   psn_x3_split_table X [n, 64] fp32 -> [n][3 planes][64] bf16
  *   psn_mlp_infer_x3_grouped: rows (g, n) -> g * rows_per_group + n; packed_w = the weight stream in execution order (48 KB
- *     stages of 2 k-steps: layer 0 = 4 input k-steps; hidden layer = 16 activation k-steps [+ 4 input k-steps]; final layer =
- *     one stage [16 k-steps][3 planes], + 56 KB of padding); bias_steps [n_hidden][8 KB] (layers without an input block);
- *     group_bias [n_groups][n_input_layers][8 KB] = psn_x3_pack_bias(W_b x_g + b); tab_a = psn_x3_split_table of the
- *     per-row half of the input block.  out [n_groups * rows_per_group, n_out] fp32.
+ *     stages of 2 k-steps: every hidden layer >= 1 = its 16 activation k-steps; final layer = one stage [16 k-steps][3 planes],
+ *     + 56 KB of padding); bias_steps [n_hidden][8 KB] (used for the layers without an input block).  The layers that read
+ *     the input block start from U[n] + V[g] (both fp32, [., n_input_layers * 256]): U = W_a x_n per row, V = W_b x_g + b per
+ *     group, as the init tables of psn_mlp_infer; layer 0 is that sum alone.  out [n_groups * rows_per_group, n_out] fp32.
  * ---------------------------------------------------------------------- */
 int psn_x3_pack(const float* W, int64_t ldw, int rows, int cols, int permuted, int n_ot, int ks0, int n_ks, uint16_t* dst, void* stream);
 int psn_x3_pack_bias(const float* V, int64_t n, uint16_t* dst, void* stream);
-int psn_x3_split_table(const float* X, int64_t n, uint16_t* dst, void* stream);
 int psn_mlp_infer_x3_grouped(const PsnBf16Desc* desc, const uint16_t* packed_w, const uint16_t* bias_steps, const float* final_bias,
-                             const uint16_t* tab_a, int64_t rows_per_group, const uint16_t* group_bias, int64_t n_groups, float* out,
-                             void* stream);
+                             const float* U, int64_t rows_per_group, const float* V, int64_t n_groups, float* out, void* stream);
 
 
 /* ------------------------------------------------------------------------

@@ -17,9 +17,10 @@
 // Workgroup = 4 waves = 128 rows of ONE row group (light), one workgroup per CU (1 wave per SIMD, <= 512 registers).
 // Weights stream L2 -> LDS by LDS-DMA in stages of 2 k-steps x 3 planes x 8 output tiles = 48 KB, double buffered; the bias
 // of a layer (its three pieces in K slots 0..2 of one k-step, against the constant operand (1, 1, 1, 0, ...): exact) rides
-// with the layer's first stage.  Input block: table A (the point's encoding, pre-split into planes) as 4 natural-order
-// k-steps; the group's half W_b pe(l) + b is an fp32 product per (group, input layer) on the host side, folded into that
-// layer's bias -- as in the grouped bf16 engine.
+// with the layer's first stage.  Input block: as in the exact-fp32 engine, a layer is linear in it, so W_in [pe(x_n) | pe(l_g)]
+// + b = U[n] + V[g] with U = W_a pe(x) (one fp32 row per point) and V = W_b pe(l) + b (one per group) computed by two small
+// fp32 GEMMs on the host side; the layers that read the input block START their accumulators from U[n] + V[g] (fp32 adds,
+// the row of U prefetched under the previous layer's epilogue) and spend no MFMA on it: layer 0 is that sum alone.
 #include "common.h"
 
 namespace psn {
@@ -33,9 +34,9 @@ struct X3Args {
     PsnBf16Desc d;
     const unsigned char* w;        // weight stream in execution order (48 KB stages)
     const unsigned char* bias;     // [n_hidden][8 KB] bias k-steps of the layers WITHOUT an input block
-    const unsigned char* gbias;    // [n_groups][n_in_layers][8 KB] bias k-steps of the layers that read the input block
     const float* final_bias;
-    const unsigned char* ta;       // [rows_per_group][3 planes][64] bf16
+    const float* U;                // [rows_per_group][n_in_layers * 256] fp32: W_a pe(x_n) of every input layer
+    const float* V;                // [n_groups][n_in_layers * 256] fp32: W_b pe(l_g) + b
     unsigned rows_per_group, tiles_per_group, n_in_layers;
     float* out;
 };
@@ -142,31 +143,23 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
     const int n_hidden = g.d.n_hidden;
     const unsigned group = blockIdx.x / g.tiles_per_group;
     const unsigned tile = blockIdx.x - group * g.tiles_per_group;
-    const unsigned char* gb = g.gbias + (size_t)group * g.n_in_layers * kX3BiasBytes;
+    const unsigned init_stride = g.n_in_layers * 256u;
+    const float* vrow = g.V + (size_t)group * init_stride + 4 * lh;
 
     const unsigned char* wptr = g.w;  // the NEXT stage to request
     int in_idx = 0;                   // input layers seen so far
     int gstage = 0;
-    // first stage of layer 0 (+ its group bias)
+    // first stage of layer 1 (layer 0 has no weights of its own left) + that layer's bias k-step unless it reads the input block
+    const bool l1_bias = n_hidden > 1 && g.d.has_in[1] == 0;
 #pragma unroll
-    for (int j = 0; j < 14; ++j) x3_dma_piece(wptr, xsmem, gb, wave, lane, j);
+    for (int j = 0; j < 12; ++j) x3_dma_piece(wptr, xsmem, g.bias + kX3BiasBytes, wave, lane, j);
+    if (l1_bias) { x3_dma_piece(wptr, xsmem, g.bias + kX3BiasBytes, wave, lane, 12); x3_dma_piece(wptr, xsmem, g.bias + kX3BiasBytes, wave, lane, 13); }
     wptr += kX3StageBytes;
 
     const unsigned n = tile * (unsigned)(kX3Waves * 32) + wave * 32 + ln;
     const bool valid = n < g.rows_per_group;
     const unsigned row = group * g.rows_per_group + n;
-    const unsigned char* tap = g.ta + (size_t)(valid ? n : g.rows_per_group - 1) * 384u + lh * 16;
-    xbf16x8 bin[3][4];
-    auto load_in = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) bin[pl][s] = *reinterpret_cast<const xbf16x8*>(tap + pl * 128 + s * 32);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(bin[pl][s]));  // arrived before the next LDS-DMA pieces are issued
-    };
+    const float* urow = g.U + (size_t)(valid ? n : g.rows_per_group - 1) * init_stride + 4 * lh;
     xbf16x8 ones_b;  // K slots 0..2 (lane half 0) carry the constant 1: the three bias pieces add up exactly
     {
         xintx4 o = {lh == 0 ? 0x3F803F80 : 0, lh == 0 ? 0x00003F80 : 0, 0, 0};
@@ -175,6 +168,23 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
 
     floatx16 acc[8];
     xbf16x8 bact[3][16];
+    // lane (n, h), tile ot, register v = 4 q + r  <->  feature 32 ot + 8 q + 4 h + r: four consecutive floats per (ot, q).
+    // acc = U[n] + V[g] (fp32).  (Requesting the U row ahead of the preceding epilogue needs 128 more registers than the
+    // 512 a wave has -- measured: scratch spills --, so its latency is exposed once per input layer: ~1 % of a pass.)
+    auto init_acc_uv = [&](int idx) __attribute__((always_inline)) {
+        const float* pu = urow + idx * 256;
+        const float* pv = vrow + idx * 256;
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 u = *reinterpret_cast<const float4*>(pu + 32 * ot + 8 * q);
+                const float4 t = *reinterpret_cast<const float4*>(pv + 32 * ot + 8 * q);
+                acc[ot][4 * q] = u.x + t.x; acc[ot][4 * q + 1] = u.y + t.y; acc[ot][4 * q + 2] = u.z + t.z; acc[ot][4 * q + 3] = u.w + t.w;
+            }
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) asm volatile("" : "+v"(acc[ot]));  // complete before the next LDS-DMA pieces are issued (asm: invisible to vmcnt)
+    };
 
     // One stage: this wave's pieces have landed, barrier, MFMAs with the request for the next stage in their gaps.
 #define X3_STAGE(BOP, NEXT_HAS_BIAS, BSRC)                                                                   \
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
         ++gstage;                                                                                            \
     }
     // bias of the layer whose first stage sits in LDS buffer (gstage & 1): acc = b_hi + b_mid + b_lo (exact)
-    auto init_acc = [&]() __attribute__((always_inline)) {
+    auto init_acc_bias = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const xbf16x8* bl = reinterpret_cast<const xbf16x8*>(xsmem + (gstage & 1) * kX3BufBytes + kX3StageBytes);
@@ -199,11 +209,6 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
         for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
 #pragma unroll
         for (int ot = 0; ot < 8; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ot * 64 + lane], ones_b, zero, 0, 0, 0);
-    };
-    // bias source of layer l (requested together with that layer's first stage)
-    auto bias_src = [&](int l, int idx) __attribute__((always_inline)) -> const unsigned char* {
-        if (l >= n_hidden) return g.bias;  // (the final layer's stage carries no bias k-step; any valid address)
-        return g.d.has_in[l] != 0 ? gb + (size_t)idx * kX3BiasBytes : g.bias + (size_t)l * kX3BiasBytes;
     };
     // ReLU + split of the finished accumulators into the three B-operand planes of the next layer
     auto epilogue = [&]() __attribute__((always_inline)) {
@@ -226,28 +231,23 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
         }
     };
 
-    // layer 0: the input block only (2 stages)
-    load_in();
+    // layer 0: U[n] + V[g] alone
+    init_acc_uv(0);
     ++in_idx;
-    init_acc();
-    X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bin[pl][ks]; }), false, g.bias)
-    X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bin[pl][2 + ks]; }), true, bias_src(1, in_idx))
-    epilogue();
     for (int li = 1; li < n_hidden; ++li) {
         const bool has_in = g.d.has_in[li] != 0;
-        if (has_in) { load_in(); ++in_idx; }
-        init_acc();
+        epilogue();                   // of layer li - 1
+        if (has_in) { init_acc_uv(in_idx); ++in_idx; }
+        else init_acc_bias();
+        const bool next_bias = li + 1 < n_hidden && g.d.has_in[li + 1] == 0;
+        const unsigned char* next_bsrc = g.bias + (size_t)(li + 1 < n_hidden ? li + 1 : 0) * kX3BiasBytes;
 #define X3_ACT_STAGE(S, LAST)                                                                                 \
-        X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bact[pl][2 * (S) + ks]; }), (LAST) && !has_in, bias_src(li + 1, in_idx))
+        X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bact[pl][2 * (S) + ks]; }), (LAST) && next_bias, next_bsrc)
         X3_ACT_STAGE(0, false) X3_ACT_STAGE(1, false) X3_ACT_STAGE(2, false) X3_ACT_STAGE(3, false)
         X3_ACT_STAGE(4, false) X3_ACT_STAGE(5, false) X3_ACT_STAGE(6, false) X3_ACT_STAGE(7, true)
 #undef X3_ACT_STAGE
-        if (has_in) {
-            X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bin[pl][ks]; }), false, g.bias)
-            X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bin[pl][2 + ks]; }), true, bias_src(li + 1, in_idx))
-        }
-        epilogue();
     }
+    epilogue();
 #undef X3_STAGE
     // final layer: one output tile (n_out <= 32), 16 k-steps x 3 planes in ONE 48 KB stage; four accumulator chains
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -337,19 +337,6 @@ __global__ __launch_bounds__(256) void x3_pack_bias_kernel(const float* __restri
         dst[e] = o;
     }
 }
-// X [n, 64] fp32 -> [n][3 planes][64] bf16
-__global__ __launch_bounds__(256) void x3_split_table_kernel(const float* __restrict__ X, int64_t n, uint16_t* __restrict__ dst) {
-    const int64_t total = n * 64;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t r = e >> 6;
-        const int c = (int)(e & 63);
-        uint16_t p[3];
-        x3_split1(X[e], p);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) dst[r * 192 + pl * 64 + c] = p[pl];
-    }
-}
-
 }  // namespace psn
 
 extern "C" int psn_x3_pack(const float* W, int64_t ldw, int rows, int cols, int permuted, int n_ot, int ks0, int n_ks, uint16_t* dst,
@@ -374,26 +361,14 @@ extern "C" int psn_x3_pack_bias(const float* V, int64_t n, uint16_t* dst, void* 
     return PSN_OK;
 }
 
-extern "C" int psn_x3_split_table(const float* X, int64_t n, uint16_t* dst, void* stream) {
-    using namespace psn;
-    PSN_CHECK_ARG(X && dst && n >= 0, "x3_split_table: null pointer");
-    if (n == 0) return PSN_OK;
-    const int64_t total = n * 64;
-    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(x3_split_table_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, n, dst);
-    PSN_CHECK_LAUNCH("x3_split_table");
-    return PSN_OK;
-}
-
 extern "C" int psn_mlp_infer_x3_grouped(const PsnBf16Desc* desc, const uint16_t* packed_w, const uint16_t* bias_steps, const float* final_bias,
-                                        const uint16_t* tab_a, int64_t rows_per_group, const uint16_t* group_bias, int64_t n_groups,
-                                        float* out, void* stream) {
+                                        const float* U, int64_t rows_per_group, const float* V, int64_t n_groups, float* out, void* stream) {
     using namespace psn;
-    PSN_CHECK_ARG(desc && packed_w && bias_steps && final_bias && tab_a && group_bias && out, "mlp_infer_x3_grouped: null pointer");
+    PSN_CHECK_ARG(desc && packed_w && bias_steps && final_bias && U && V && out, "mlp_infer_x3_grouped: null pointer");
     const PsnBf16Desc& d = *desc;
-    PSN_CHECK_ARG(d.n_hidden >= 1 && d.n_hidden <= PSN_MLP_MAX_LAYERS && d.n_out >= 1 && d.n_out <= 32, "mlp_infer_x3_grouped: n_hidden=%d n_out=%d", d.n_hidden, d.n_out);
+    PSN_CHECK_ARG(d.n_hidden >= 2 && d.n_hidden <= PSN_MLP_MAX_LAYERS && d.n_out >= 1 && d.n_out <= 32, "mlp_infer_x3_grouped: n_hidden=%d n_out=%d", d.n_hidden, d.n_out);
     PSN_CHECK_ARG(d.out_act >= PSN_OUT_NONE && d.out_act <= PSN_OUT_OCC && d.has_in[0] != 0, "mlp_infer_x3_grouped: out_act=%d, layer 0 must read the input block", d.out_act);
-    PSN_CHECK_ARG((((uintptr_t)packed_w | (uintptr_t)bias_steps | (uintptr_t)tab_a | (uintptr_t)group_bias) & 15) == 0, "mlp_infer_x3_grouped: buffers must be 16-byte aligned");
+    PSN_CHECK_ARG((((uintptr_t)packed_w | (uintptr_t)bias_steps | (uintptr_t)U | (uintptr_t)V) & 15) == 0, "mlp_infer_x3_grouped: buffers must be 16-byte aligned");
     PSN_CHECK_ARG(rows_per_group >= 0 && n_groups >= 0 && rows_per_group <= (1ll << 24) && rows_per_group * n_groups < (1ll << 31),
                   "mlp_infer_x3_grouped: 32-bit index arithmetic: rows per group <= 2^24, rows < 2^31");
     if (rows_per_group == 0 || n_groups == 0) return PSN_OK;
@@ -401,9 +376,8 @@ extern "C" int psn_mlp_infer_x3_grouped(const PsnBf16Desc* desc, const uint16_t*
     a.d = d;
     a.w = reinterpret_cast<const unsigned char*>(packed_w);
     a.bias = reinterpret_cast<const unsigned char*>(bias_steps);
-    a.gbias = reinterpret_cast<const unsigned char*>(group_bias);
     a.final_bias = final_bias;
-    a.ta = reinterpret_cast<const unsigned char*>(tab_a);
+    a.U = U; a.V = V;
     a.rows_per_group = (unsigned)rows_per_group;
     a.tiles_per_group = (unsigned)((rows_per_group + kX3Waves * 32 - 1) / (kX3Waves * 32));
     int n_in = 0;

@@ -501,22 +501,19 @@ def pack_app_chains(weights, biases, d_x):
 
 class PackedX3Grouped(object):
     """A 256-wide ReLU network packed for the split-bf16 ("bf16x6") engine (csrc/mlp_infer_x3.hip; experiment): rows
-    (g, n) -> g * Ns + n, input block [table A row n | group features of g]; the group's part of every input layer is an
-    fp32 product per call, V[g, i] = W_b,i @ x_g + b_i, folded into that layer's (exact, three-piece) bias."""
+    (g, n) -> g * Ns + n, input block [table A row n | group features of g].  As in the exact-fp32 engine the layers that read
+    the input block start from the fp32 init tables U[n] = W_a x_n and V[g] = W_b x_g + b (two small GEMMs per call)."""
 
-    def __init__(self, desc, w, bias_steps, final_bias, wb_t, b_in, macs_per_row):
+    def __init__(self, desc, w, bias_steps, final_bias, init_wa, init_wb, init_bias, macs_per_row):
         self.desc, self.w, self.bias_steps, self.final_bias = desc, w, bias_steps, final_bias
-        self.wb_t, self.b_in = wb_t, b_in
+        self.init_wa, self.init_wb, self.init_bias = init_wa, init_wb, init_bias
         self.macs_per_row = macs_per_row  # the reference network's MACs per row (what an fp32 evaluation multiplies)
-
-    def group_bias(self, tab_b):
-        V = hip.gemm(tab_b, self.wb_t, bias=self.b_in, epi=hip.EPI_BIAS)  # [n_groups, n_in * 256] fp32
-        return hip.x3_pack_bias(V.view(-1, 256))
 
     def __call__(self, tab_a, tab_b, out=None):
         """tab_a [Ns, 64] fp32, tab_b [n_groups, 64] fp32 -> [n_groups * Ns, n_out] fp32 (group-major rows)."""
-        return hip.mlp_infer_x3_grouped(self.desc, self.w, self.bias_steps, self.final_bias, hip.x3_split_table(tab_a.contiguous()),
-                                        self.group_bias(tab_b.contiguous()), tab_b.shape[0], out=out, macs_per_row=self.macs_per_row)
+        U = hip.gemm(tab_a, self.init_wa, trans_b=True)
+        V = hip.gemm(tab_b, self.init_wb, trans_b=True, bias=self.init_bias, epi=hip.EPI_BIAS)
+        return hip.mlp_infer_x3_grouped(self.desc, self.w, self.bias_steps, self.final_bias, U, V, out=out, macs_per_row=self.macs_per_row)
 
 
 def pack_relu_mlp_x3_grouped(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE):
@@ -524,42 +521,37 @@ def pack_relu_mlp_x3_grouped(weights, biases, din_a, din_b, skip_at, out_act=hip
     execution order (include/psnerf_hip.h, psn_mlp_infer_x3_grouped)."""
     n = len(weights)
     dev = weights[0].device
-    assert n - 1 <= hip.MAX_LAYERS and din_a <= 64 and 0 < din_b <= 64
+    assert 3 <= n <= hip.MAX_LAYERS + 1 and din_a <= 64 and 0 < din_b <= 64
     assert all(w.shape[0] == 256 for w in weights[:-1]) and weights[-1].shape[0] <= 32
     desc = hip.PsnBf16Desc()
     desc.n_hidden, desc.n_out, desc.out_act = n - 1, weights[-1].shape[0], out_act
     KS = hip.X3_KS
-    sizes = []
-    for li in range(n - 1):
-        has_in = li == 0 or li - 1 == skip_at
-        desc.has_in[li] = int(has_in)
-        sizes.append(4 * KS if li == 0 else (16 + (4 if has_in else 0)) * KS)
     final_elems = 16 * 3 * 512
-    buf = torch.zeros(sum(sizes) + final_elems + 56 * 512, device=dev, dtype=torch.bfloat16)  # (+ 56 KB: the last request over-reads)
+    buf = torch.zeros((n - 2) * 16 * KS + final_elems + 56 * 512, device=dev, dtype=torch.bfloat16)  # (+ 56 KB: the last request over-reads)
     bias_steps = torch.zeros(n - 1, 4096, device=dev, dtype=torch.bfloat16)
-    wb, b_in = [], []
+    wa, wb, b_in = [], [], []
     off = 0
     macs = 0
     for li in range(n - 1):
         W = weights[li].detach().float()
         macs += W.shape[0] * W.shape[1]
-        dst = buf[off:off + sizes[li]]
-        if li == 0:
-            hip.x3_pack(W[:, :din_a], False, 8, 0, 4, dst[:4 * KS])
-            wb.append(W[:, din_a:din_a + din_b]); b_in.append(biases[li].detach().float())
+        has_in = li == 0 or li - 1 == skip_at
+        desc.has_in[li] = int(has_in)
+        c0 = 0 if li == 0 else 256
+        if li > 0:
+            hip.x3_pack(W[:, :256], True, 8, 0, 16, buf[off:off + 16 * KS])
+            off += 16 * KS
+        if has_in:
+            wa.append(W[:, c0:c0 + din_a]); wb.append(W[:, c0 + din_a:c0 + din_a + din_b]); b_in.append(biases[li].detach().float())
         else:
-            hip.x3_pack(W[:, :256], True, 8, 0, 16, dst[:16 * KS])
-            if desc.has_in[li]:
-                hip.x3_pack(W[:, 256:256 + din_a], False, 8, 0, 4, dst[16 * KS:20 * KS])
-                wb.append(W[:, 256 + din_a:256 + din_a + din_b]); b_in.append(biases[li].detach().float())
-            else:
-                hip.x3_pack_bias(biases[li].detach().float().view(1, 256).contiguous(), bias_steps[li:li + 1])
-        off += sizes[li]
+            hip.x3_pack_bias(biases[li].detach().float().view(1, 256).contiguous(), bias_steps[li:li + 1])
     macs += weights[-1].shape[0] * weights[-1].shape[1]
     hip.x3_pack(weights[-1].detach().float(), True, 1, 0, 16, buf[off:off + final_elems])
     fb = torch.zeros(32, device=dev)
     fb[:weights[-1].shape[0]] = biases[-1].detach().float()
-    wb_t = torch.zeros(64, len(wb) * 256, device=dev)
-    for i, w in enumerate(wb):
-        wb_t[:din_b, i * 256:(i + 1) * 256] = w.t()
-    return PackedX3Grouped(desc, buf, bias_steps, fb, wb_t, torch.cat(b_in).contiguous(), macs)
+    init_wa = torch.zeros(len(wa) * 256, 64, device=dev)
+    init_wb = torch.zeros(len(wb) * 256, 64, device=dev)
+    for i, (a_, b_) in enumerate(zip(wa, wb)):
+        init_wa[i * 256:(i + 1) * 256, :din_a] = a_
+        init_wb[i * 256:(i + 1) * 256, :din_b] = b_
+    return PackedX3Grouped(desc, buf, bias_steps, fb, init_wa, init_wb, torch.cat(b_in).contiguous(), macs)

@@ -139,7 +139,6 @@ SIGNATURES = {
     'psn_bf16_pack_group_bias': (i32, [c_f, i64, c_f, c_f]),
     'psn_x3_pack': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
     'psn_x3_pack_bias': (i32, [c_f, i64, c_f, c_f]),
-    'psn_x3_split_table': (i32, [c_f, i64, c_f, c_f]),
     'psn_mlp_infer_x3_grouped': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, c_f, i64, c_f, i64, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
@@ -946,29 +945,21 @@ def x3_pack_bias(V, dst=None):
     return dst
 
 
-def x3_split_table(X):
-    """X [n, 64] fp32 -> [n, 3, 64] bfloat16 (the three planes of every feature)."""
-    assert X.is_cuda and X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 2 and X.shape[1] == 64
-    dst = torch.empty(X.shape[0], 3, 64, device=X.device, dtype=torch.bfloat16)
-    _check(_lib.psn_x3_split_table(X.data_ptr(), X.shape[0], dst.data_ptr(), _stream()), 'x3_split_table')
-    return dst
-
-
-def mlp_infer_x3_grouped(desc, packed_w, bias_steps, final_bias, tab_a3, group_bias, n_groups, out=None, macs_per_row=None):
-    """Rows (g, n) -> g * tab_a3.shape[0] + n on the split-bf16 engine (psn_mlp_infer_x3_grouped)."""
-    rows = tab_a3.shape[0]
+def mlp_infer_x3_grouped(desc, packed_w, bias_steps, final_bias, U, V, out=None, macs_per_row=None):
+    """Rows (g, n) -> g * U.shape[0] + n on the split-bf16 engine (psn_mlp_infer_x3_grouped); U [Ns, n_in * 256], V [G, n_in * 256]
+    fp32 init tables of the layers that read the input block."""
+    rows, n_groups = U.shape[0], V.shape[0]
     if out is None:
         out = torch.empty(n_groups * rows, desc.n_out, device=packed_w.device, dtype=torch.float32)
     n_in = sum(1 for l in range(desc.n_hidden) if desc.has_in[l])
-    for t, nm in ((packed_w, 'packed_w'), (bias_steps, 'bias_steps'), (tab_a3, 'tab_a3'), (group_bias, 'group_bias')):
+    for t, nm in ((packed_w, 'packed_w'), (bias_steps, 'bias_steps')):
         if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
             raise RuntimeError('%s: must be a contiguous bfloat16 HIP tensor' % nm)
-    assert tab_a3.shape[1:] == (3, 64) and bias_steps.numel() == desc.n_hidden * 4096 and group_bias.numel() == n_groups * n_in * 4096
+    assert U.shape[1] == V.shape[1] == n_in * 256 and bias_steps.numel() == desc.n_hidden * 4096
     assert final_bias.numel() == 32 and out.numel() == n_groups * rows * desc.n_out
     with _Prof('mlp_infer_x3', n_groups * rows, None if macs_per_row is None else 2.0 * macs_per_row * n_groups * rows):
         _check(_lib.psn_mlp_infer_x3_grouped(ctypes.byref(desc), packed_w.data_ptr(), bias_steps.data_ptr(), _ptr(final_bias, 'final_bias'),
-                                             tab_a3.data_ptr(), rows, group_bias.data_ptr(), n_groups, _ptr(out, 'out'), _stream()),
-               'mlp_infer_x3_grouped')
+                                             _ptr(U, 'U'), rows, _ptr(V, 'V'), n_groups, _ptr(out, 'out'), _stream()), 'mlp_infer_x3_grouped')
     return out
 
 
