@@ -128,8 +128,12 @@ __device__ __forceinline__ void x3_stage_mma(floatx16 (&acc)[8], const xbf16x8* 
             __builtin_amdgcn_sched_barrier(0);
         }
         x3_mma_pair(acc[2 * p], acc[2 * p + 1], a[grp & 1], bop(0, ks), bop(1, ks), bop(2, ks));
-        if (grp < 6) { request_piece(2 * grp); request_piece(2 * grp + 1); }   // the 12 stream pieces: unconditional
-        else if (grp == 6 && n_pieces > 12) { request_piece(12); request_piece(13); }  // the bias k-step of the next layer (wave-uniform)
+        // the next stage's pieces go out in the first two groups: a stage lasts only 96 MFMAs = 3072 cycles, and a piece issued
+        // in its second half lands after the stage has ended (an L2 round trip is ~1500 cycles)
+        if (grp < 2) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) request_piece(6 * grp + j);
+        } else if (grp == 2 && n_pieces > 12) { request_piece(12); request_piece(13); }  // the bias k-step of the next layer (wave-uniform)
         __builtin_amdgcn_sched_barrier(0);
     }
 }

@@ -12,6 +12,8 @@ Ws = [(torch.rand(o, i, device=dev) * 2 - 1) * (1.7 / i ** 0.5) for o, i in dims
 bs = [(torch.rand(o, device=dev) * 2 - 1) * (1.0 / i ** 0.5) for o, i in dims]
 xa = hip.pe_encode(torch.rand(Ns, 3, device=dev) * 1.2 - 0.6, 10, 64)
 xb = hip.pe_encode(torch.nn.functional.normalize(torch.randn(L, 3, device=dev), dim=-1), 10, 64)
+if os.environ.get('ZERO') == '1':  # power test: no toggling in the multipliers
+    Ws = [w * 0 for w in Ws]; bs = [b * 0 for b in bs]; xa = xa * 0; xb = xb * 0
 macs = sum(o * i for o, i in dims)
 rows = Ns * L
 
