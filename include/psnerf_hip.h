@@ -316,10 +316,11 @@ int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, const float*
  * [n_rays], ZEROED by the caller, or NULL: a block that contains a sign change of (occ - tau) between neighbouring steps
  * (or a ray whose first value is not free) raises the ray's flag and the ray's later blocks are not evaluated -- their
  * entries of occ stay untouched; every value up to and including the pair of the FIRST sign change is always written,
- * which is all psn_first_crossing reads.  desc / packed_w / packed_b as for psn_root_find.  occ [n_rays, n_steps]. */
+ * which is all psn_first_crossing reads.  n_blocks: NULL, or a device counter that receives the number of 64-step blocks
+ * evaluated (measurement).  desc / packed_w / packed_b as for psn_root_find.  occ [n_rays, n_steps]. */
 int psn_march_sweep(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* origin, const float* dir,
                     const float* far, const float* u, const float* omu, float near, int64_t n_rays, int n_steps, float tau,
-                    int pe_octaves, float pe_scale, int* skip, float* occ, void* stream);
+                    int pe_octaves, float pe_scale, int* skip, unsigned long long* n_blocks, float* occ, void* stream);
 
 /* Fused secant refinement, stage1/model/rendering.py:525-555: n_iter regula-falsi iterations for every ray inside ONE
  * launch -- query point origin + d_pred * dir, its positional encoding (pe_octaves bands, input scaled by pe_scale), the

@@ -75,6 +75,7 @@ struct InferArgs {
     float near;
     int n_steps;
     int* skip;               // [n_rays] or nullptr: != 0 = an earlier block of this ray already holds its first sign change
+    unsigned long long* n_blocks;  // optional: counts the 64-step blocks that were evaluated (measurement only)
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         if (blk > 0 && g.skip != nullptr && __hip_atomic_load(g.skip + m_ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
         m_step = blk * (kWaves * 16) + wave * 16 + lj;
         row_ = m_ray * g.n_steps + m_step;
+        if (g.n_blocks != nullptr && threadIdx.x == 0) atomicAdd(g.n_blocks, 1ull);
     }
     const int64_t row = row_;
     const int64_t rowc = row < g.n_rows ? row : g.n_rows - 1;
@@ -1178,7 +1180,7 @@ extern "C" int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, c
 // first sign change is written -- exactly the values psn_first_crossing reads; values of skipped blocks are left untouched.
 extern "C" int psn_march_sweep(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* origin,
                                const float* dir, const float* far, const float* u, const float* omu, float near, int64_t n_rays,
-                               int n_steps, float tau, int pe_octaves, float pe_scale, int* skip, float* occ, void* stream) {
+                               int n_steps, float tau, int pe_octaves, float pe_scale, int* skip, unsigned long long* n_blocks, float* occ, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(desc && packed_w && packed_b && origin && dir && far && u && omu && occ, "march_sweep: null pointer");
     const PsnMlpDesc& d = *desc;
@@ -1202,7 +1204,7 @@ extern "C" int psn_march_sweep(const PsnMlpDesc* desc, const float* packed_w, co
     InferArgs a = {};
     a.d = d; a.w = packed_w; a.b = packed_b; a.a_div = 1; a.a_mod = 1; a.b_div = 1; a.b_mod = 1; a.n_rows = n_rays * n_steps; a.out = occ;
     a.n_bias = (d.n_layers - 1) * 256 + 32;
-    a.ray_o = origin; a.ray_d = dir; a.far = far; a.u = u; a.omu = omu; a.near = near; a.n_steps = n_steps; a.skip = skip; a.tau = tau;
+    a.ray_o = origin; a.ray_d = dir; a.far = far; a.u = u; a.omu = omu; a.near = near; a.n_steps = n_steps; a.skip = skip; a.n_blocks = n_blocks; a.tau = tau;
     a.pe_scale = pe_scale; a.pe_octaves = pe_octaves;
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) { a.save_tiles[l] = 0xFFFFFFFFu; a.save2_tiles[l] = 0xFFFFFFFFu; }
     const int64_t blocks = n_rays * (n_steps / (kWaves * 16));

@@ -124,7 +124,7 @@ SIGNATURES = {
     'psn_shadow_points': (i32, [c_f, c_f, i64, i32, i32, f32, f32, c_f, c_f, f32, c_f, c_f, c_f, c_f]),
     'psn_mlp_infer_pe': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i32, f32, c_f, c_f]),
     'psn_root_find': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, i64, f32, i32, i32, f32, c_f, c_f]),
-    'psn_march_sweep': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, i64, i32, f32, i32, f32, c_f, c_f, c_f]),
+    'psn_march_sweep': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, i64, i32, f32, i32, f32, c_f, c_f, c_f, c_f]),
     'psn_normalize_rows_fwd': (i32, [c_f, i64, f32, c_f, c_f]),
     'psn_normalize_rows_bwd': (i32, [c_f, c_f, i64, f32, c_f, c_f]),
     'psn_light_rows_fwd': (i32, [c_f, c_f, c_f, i32, f32, c_f, c_f, c_f]),
@@ -556,11 +556,15 @@ def march_sweep(desc, packed_w, packed_b, origin, direction, far, u, omu, near, 
     if N == 0:
         return occ, skip
     Q = N * n_steps
-    with _Prof('mlp_infer', Q, None if macs_per_row is None else 2.0 * macs_per_row * Q):
+    # measurement runs (PROFILE_EVENTS set) count the 64-step blocks that were really evaluated: the event carries the device
+    # counter and the flops of ONE block, so that the reader prices evaluated work, not the N x M rows of the dense sweep
+    count = torch.zeros(1, device=origin.device, dtype=torch.int64) if PROFILE_EVENTS is not None else None
+    with _Prof('march_sweep', Q, None if (macs_per_row is None or count is None) else (count, 2.0 * macs_per_row * 64)):
         _check(_lib.psn_march_sweep(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'), _ptr(origin, 'origin'),
                                     _ptr(direction, 'direction'), _ptr(far, 'far'), _ptr(u, 'u'), _ptr(omu, 'omu'), float(near), N,
                                     int(n_steps), float(tau), int(pe_octaves), float(pe_scale),
-                                    None if skip is None else skip.data_ptr(), occ.data_ptr(), _stream()), 'march_sweep')
+                                    None if skip is None else skip.data_ptr(), None if count is None else count.data_ptr(),
+                                    occ.data_ptr(), _stream()), 'march_sweep')
     return occ, skip
 
 

@@ -7,11 +7,22 @@ import bench
 from torch.utils._python_dispatch import TorchDispatchMode
 from psnerf_amd.synthetic import stage2_inputs
 dev = torch.device('cuda:0')
-step = bench.make_step(dev)
-inp, gt = stage2_inputs(bench.N_PIXELS, bench.N_LIGHTS, bench.N_VIS, seed=100, device=dev, with_surface_idx=True)
-l_slt = torch.arange(bench.N_LIGHTS, device=dev) + 96 * 3
+if len(sys.argv) > 1 and sys.argv[1] == 'stage1':
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.synthetic import stage1_batch, stage1_cfg
+    cfg = stage1_cfg('bear', **{'rendering.num_points_in': 96, 'rendering.num_points_out': 32, 'training.n_training_points': 4096})
+    batch = {k: v.to(dev) for k, v in stage1_batch(cfg, h=512, w=612, seed=0).items()}
+    torch.manual_seed(42)
+    net = NeuralNetwork(cfg)
+    tr = Trainer(Renderer(net, cfg, device=dev), torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=dev)
+    run = lambda: tr.train_step(batch, it=6000)
+else:
+    step = bench.make_step(dev)
+    inp, gt = stage2_inputs(bench.N_PIXELS, bench.N_LIGHTS, bench.N_VIS, seed=100, device=dev, with_surface_idx=True)
+    l_slt = torch.arange(bench.N_LIGHTS, device=dev) + 96 * 3
+    run = lambda: step.step(inp, gt, l_slt, train_order=False)
 for _ in range(3):
-    step.step(inp, gt, l_slt, train_order=False)
+    run()
 torch.cuda.synchronize()
 log = []
 SKIP = ('aten.view', 'aten.detach', 'aten._unsafe_view', 'aten.expand', 'aten.slice', 'aten.select', 'aten.unsqueeze', 'aten.squeeze',
@@ -30,7 +41,7 @@ class Log(TorchDispatchMode):
             log.append((name, site, shp))
         return func(*args, **(kwargs or {}))
 with Log():
-    step.step(inp, gt, l_slt, train_order=False)
+    run()
 torch.cuda.synchronize()
 for i, (n, s, shp) in enumerate(log):
     print('%3d %-40s %-60s %s' % (i, n[:40], s[:60], shp))

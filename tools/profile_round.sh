@@ -24,4 +24,15 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     # keep the header and the fused-MLP dispatches only (the full table is large)
     (head -1 $F; grep mlp_infer_kernel $F) > $O/pmc_$N.csv
 done
+# round 3 additions: per-experiment evidence (each a JSON / text file of its own)
+python3 $R/tools/dbg/bench_march.py 2>/dev/null | tail -1 > $O/march_sweep.json
+python3 $R/tools/dbg/bench_x3.py 2>/dev/null | tail -1 > $O/bf16x6_kernel.json
+ZERO=1 python3 $R/tools/dbg/bench_x3.py 2>/dev/null | tail -1 > $O/bf16x6_kernel_zero_operands.json
+python3 $R/tools/dbg/ab_tn256.py $R/psnerf_amd/libpsnerf_hip.so 2>/dev/null | grep -v amdgpu > $O/tn256.txt
+python3 $R/tools/bench_shadow.py 2>/dev/null | tail -1 > $O/shadow_visibility.json
+python3 $R/tools/bench_composite.py 2>/dev/null | tail -1 > $O/composite.json
+# matrix-pipe occupancy of the split-bf16 engine (own PMC pass, --kernel-trace only)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d /tmp/pmc_x3 -o c -- python3 $R/tools/dbg/bench_x3.py > /dev/null 2>&1
+F=$(find /tmp/pmc_x3 -name '*counter_collection*' | head -1)
+(head -1 $F; grep "mlp_infer_x3_kernel\|mlp_infer_bf16_kernel" $F | head -40) > $O/pmc_x3.csv
 ls -la $O
