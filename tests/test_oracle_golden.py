@@ -305,3 +305,52 @@ def test_stage2_psnetwork_normal_jitter():
     assert names == list(g['grad_names'])
     assert_close(norms, g['grad_norms'], 2e-5, 'grad norms')
     assert_close(projs, g['grad_projs'], 1e-4, 'grad projs')
+
+
+def _trainer_golden_steps(make_step, dev='cpu'):
+    """Replay tests/golden/stage2_trainer.npz -- six iterations of the reference's OWN TrainRunner.run across the
+    iteration-5000 train_fix switch -- through a TrainStep built by ``make_step(conf, sd, NL, light_init)``."""
+    g = load('stage2_trainer.npz')
+    conf = o2.bear_conf()
+    sd = stage2_state_dict(conf, seed=41)
+    assert state_dict_digest(sd) == str(g['sd_digest'])
+    N, L, V, NL = (int(g[k]) for k in ('N', 'L', 'V', 'NL'))
+    step = make_step(sd, NL, T(g['light_init']))
+    step.cur_iter = 0
+    step.train_fix()                       # trainer.py:486-504: the state iteration 0 leaves behind
+    step.cur_iter = int(g['first_iter'])
+    names = [str(k) for k in g['loss_names']]
+    logs = []
+    for i in range(6):
+        inp, gt = stage2_inputs(N, L, V, seed=int(g['input_seeds'][i % 3]))
+        inp = {k: v.to(dev) for k, v in inp.items() if k not in ('light_intensity', 'light_vis_train', 'vis_train_gt')}
+        terms, _ = step.step(inp, {'rgb': gt['rgb'].to(dev)}, T(g['l_slt'][i]).to(dev), train_order=True,
+                             noise={'xyz': T(g['noise%d' % i]).to(dev)})
+        logs.append(terms)
+    return g, names, logs, step
+
+
+def test_train_step_reproduces_the_reference_trainer_run():
+    """a24: the oracle's TrainStep against the reference's own TrainRunner.run / train_fix (stage2/trainer.py:355-410,
+    462-464, 485-513), six iterations across the switch at iteration 5000 (two with the BRDF nets and the light tables frozen
+    and vis_weight 10, four with everything training): every loss term of every iteration, the final light tables and the
+    final network parameters."""
+    def make(sd, NL, light_init):
+        net = o2.PSNetwork(o2.bear_conf())
+        net.load_state_dict(sd)
+        return o2.TrainStep(net, o2.bear_conf(), NL, light_init)
+    g, names, logs, step = _trainer_golden_steps(make)
+    for i in range(6):
+        for k, v in zip(names, g['loss_vals'][i]):
+            if np.isnan(v):
+                assert logs[i][k] is None, (i, k)
+            else:
+                assert_close(float(logs[i][k]), float(v), 2e-6, 'it %d %s' % (4998 + i, k))
+    assert_close(step.light_para.weight.detach(), g['light_para'], 1e-6, 'light table')
+    assert_close(step.light_inten_para.weight.detach(), g['light_inten_para'], 1e-6, 'light intensity')
+    sd_end = step.model.state_dict()
+    _, norms, projs = grad_digest(sd_end)
+    assert sorted(sd_end) == [str(k) for k in g['param_names']]
+    assert_close(norms, g['param_norms'], 1e-6, 'parameter norms')
+    for k, v in sd_end.items():
+        assert_close(v.reshape(-1)[:2048], g['p_' + k], 1e-5, 'parameter ' + k)

@@ -426,3 +426,38 @@ def test_surface_idx_from_the_data_pipeline(cuda):
     step.cur_iter = 5001
     t1, _ = step.step(inp2, gt, torch.arange(4, device=cuda), train_order=False, noise={'xyz': nz})
     assert bool(torch.isfinite(t1['total']))
+
+
+def test_train_step_vs_reference_trainer_run(cuda):
+    """a24 against the reference's OWN trainer: tests/golden/stage2_trainer.npz holds six iterations of TrainRunner.run
+    (stage2/trainer.py:355-410,462-464) across the train_fix switch at iteration 5000 (:485-513), produced by calling the
+    reference's methods on a duck-typed runner (tools/gen_golden.py trainer).  The HIP TrainStep replays them: loss terms of
+    every iteration, final light tables, final parameters (Adam: an element whose gradient sits at the fp32 noise floor may
+    step the other way, so the maximum is bounded by 2 lr per step and the bulk must agree tightly)."""
+    import psnerf_amd.stage2 as s2
+    from tests.test_oracle_golden import _trainer_golden_steps
+
+    def make(sd, NL, light_init):
+        net = s2.PSNetwork(s2.bear_conf())
+        net.load_state_dict(sd)
+        net.to(cuda)
+        return s2.TrainStep(net, s2.bear_conf(), NL, light_init.to(cuda), cuda)
+    g, names, logs, step = _trainer_golden_steps(make, dev=cuda)
+    for i in range(6):
+        for k, v in zip(names, g['loss_vals'][i]):
+            got = logs[i].get(k)
+            if np.isnan(v):
+                assert got is None or float(got) == 0.0, (i, k, got)
+            else:
+                assert_close(float(got.detach()), float(v), 1e-4 if i == 0 else 1e-3, 'it %d %s' % (4998 + i, k), atol=0.0)
+    # phase switch happened: BRDF nets and light tables train from iteration 5000 on
+    assert step.loss.sg_rgb_weight == 1.0 and step.light_para.weight.requires_grad
+    lr, lr_int, n_light_steps = 5e-4, 1e-3, 4
+    d = (step.light_para.weight.detach().cpu() - torch.from_numpy(g['light_para'])).abs()
+    assert float(d.max()) <= 2 * n_light_steps * lr + 1e-6 and float(d.mean()) <= 2e-5, (float(d.max()), float(d.mean()))
+    d = (step.light_inten_para.weight.detach().cpu() - torch.from_numpy(g['light_inten_para'])).abs()
+    assert float(d.max()) <= 2 * n_light_steps * lr_int + 1e-6 and float(d.mean()) <= 4e-5, (float(d.max()), float(d.mean()))
+    for k, v in step.model.state_dict().items():
+        d = (v.detach().cpu().reshape(-1)[:2048] - torch.from_numpy(g['p_' + k])).abs()
+        assert float(d.max()) <= 2 * 6 * lr + 1e-6, 'param %s max diff %.3e' % (k, float(d.max()))
+        assert float(d.mean()) <= 2e-5, 'param %s mean diff %.3e' % (k, float(d.mean()))

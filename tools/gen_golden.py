@@ -3,7 +3,7 @@
 /root/reference) on seeded inputs, and cross-check the oracle against it.
 
 Runs only in the build container (the reference never travels to the GPU box).
-Usage:  python tools/gen_golden.py stage1 | stage2 | all
+Usage:  python tools/gen_golden.py stage1 | stage2 | trainer | all
 
 Weights are not stored for full-width nets: tests regenerate them from seeds
 (tests/helpers.py) and compare the sha256 stored in the fixture.
@@ -569,12 +569,183 @@ def gen_stage2():
     print('stage2 goldens written')
 
 
+# ---------------------------------------------------------------------------
+def gen_trainer():
+    """stage2/trainer.py: the reference's OWN TrainRunner.run / train_fix (the step body :355-410,462-464 and the schedule
+    :485-513) driven for six iterations across the iteration-5000 switch.  The module imports with empty placeholders for
+    the third-party packages this image lacks (pyhocon, tensorboardX, imageio, cv2, skimage, plotly, GPUtil, trimesh: none is
+    touched by the step body; likewise torchvision, which utils/plots.py imports), and ``run`` is called on a duck-typed ``self`` that carries exactly the attributes the loop
+    reads: a list as the data loader, the reference's model / loss classes, torch's Adam / SparseAdam as trainer.py:126-168
+    constructs them.  No reference edits.  Writes tests/golden/stage2_trainer.npz."""
+    import tempfile
+    import types
+    from oracle import stage2 as o2
+    for name in ('imageio', 'imageio.plugins', 'imageio.plugins.freeimage', 'skimage', 'skimage.measure', 'cv2', 'pyhocon', 'tensorboardX',
+                 'plotly', 'plotly.graph_objs', 'plotly.offline', 'plotly.subplots', 'GPUtil', 'trimesh', 'torchvision'):
+        if name not in sys.modules:
+            try:
+                __import__(name)  # whatever the image does have is used as it is
+            except Exception:  # noqa: BLE001
+                sys.modules[name] = types.ModuleType(name)
+    sys.modules['pyhocon'].ConfigFactory = object
+    sys.modules['tensorboardX'].SummaryWriter = object
+    sys.modules['imageio'].plugins = sys.modules['imageio.plugins']
+    sys.modules['imageio.plugins'].freeimage = sys.modules['imageio.plugins.freeimage']
+    sys.modules['imageio.plugins.freeimage'].download = lambda *a, **k: None
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, os.path.join(REF, 'stage2'))
+    import trainer as RT
+    assert os.path.realpath(RT.__file__).startswith(os.path.realpath(REF)), RT.__file__
+    from model.renderer import PSNetwork as RPS
+    from model.loss import MainLoss as RMain, NormalLoss as RNormal
+
+    conf = o2.bear_conf()
+    sd = stage2_state_dict(conf, seed=41)
+    N, L, V, NL = 360, 4, 3, 12
+    light_slt = [list(range(5)), list(range(7))]          # two views with 5 and 7 lights: rows 0..4 and 5..11 of the tables
+    g = torch.Generator().manual_seed(17)
+    light_init = [torch.nn.functional.normalize(torch.randn(len(ls), 3, generator=g), dim=-1) * 1.3 for ls in light_slt]  # un-normalised on purpose
+    batches = []
+    for b in range(3):
+        inp, gt = stage2_inputs(N, L, V, seed=200 + b)
+        view = b % 2
+        lidx = torch.randperm(len(light_slt[view]), generator=g)[:L]
+        mi = {k: inp[k] for k in ('intrinsics', 'uv', 'pose', 'object_mask', 'surface_mask', 'points', 'normal')}
+        mi['light_direction'] = inp['light_direction'][None]          # collated: batch dimension (trainer.py:366 strips it)
+        mi['visibility'] = inp['visibility'][None]
+        mi['lidx'] = lidx[None]
+        batches.append((torch.tensor([view]), mi, {'rgb': gt['rgb'][None]}))
+
+    class Recorder(object):   # the reference's loss module, every call logged
+        def __init__(self, inner):
+            self.inner, self.log = inner, []
+        def __getattr__(self, k):
+            return getattr(self.__dict__['inner'], k)
+        def __setattr__(self, k, v):
+            if k in ('inner', 'log'):
+                self.__dict__[k] = v
+            else:
+                setattr(self.__dict__['inner'], k, v)
+        def __call__(self, *a, **k):
+            out = self.inner(*a, **k)
+            self.log.append({kk: (float(vv.detach()) if vv is not None else None) for kk, vv in out.items()})
+            return out
+
+    rnet = RPS(conf)
+    rnet.load_state_dict(sd)
+    ns = types.SimpleNamespace()
+    ns.conf, ns.device = conf, torch.device('cpu')
+    ns.model = rnet
+    ns.loss = Recorder(RMain(loss_type='L1', sg_rgb_weight=1.0, albedo_smooth_weight=0.05, rough_smooth_weight=0.01, vis_weight=1))
+    ns.loss_n = Recorder(RNormal(1, 0.05))
+    ns.normal_train, ns.multi_light, ns.light_train, ns.light_inten_train = True, True, True, True
+    ns.visibility, ns.vis_loss, ns.vis_plus, ns.ana_fixlight, ns.light_decay, ns.train_order = True, True, False, False, False, True
+    # learning rates of stage2/confs/bear.conf:19-20,48-50 (the milestones lie beyond these iterations)
+    ns.sg_optimizer = torch.optim.Adam(rnet.parameters(), lr=5e-4)
+    ns.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(ns.sg_optimizer, [], gamma=0.5)
+    ns.light_para = torch.nn.Embedding(NL, 3, sparse=True)
+    ns.light_para.weight.data.copy_(torch.cat(light_init, dim=0))
+    ns.light_vis_train = [li.clone() for li in light_init]
+    ns.light_inten_para = torch.nn.Embedding(NL, 1, sparse=True)
+    torch.nn.init.constant_(ns.light_inten_para.weight, rnet.light_int)
+    ns.light_optimizer = torch.optim.SparseAdam(
+        [{'params': list(ns.light_para.parameters())},
+         {'params': list(ns.light_inten_para.parameters()), 'lr': 1e-3}], lr=5e-4)
+    ns.light_scheduler = None
+    class Loader(object):   # a DataLoader hands out fresh dictionaries every epoch (the loop edits them in place, trainer.py:365-367)
+        def __len__(self):
+            return len(batches)
+        def __iter__(self):
+            for idx, mi, gt in batches:
+                yield idx, dict(mi), dict(gt)
+    ns.train_dataloader = Loader()
+    ns.train_dataset = types.SimpleNamespace(change_sampling_idx=lambda n: None, view_idx=[0, 1], light_slt=light_slt,
+                                             light_direction=[torch.nn.functional.normalize(li, dim=-1) for li in light_init])
+    ns.num_pixels, ns.start_epoch, ns.nepochs = N, 1666, 1667      # cur_iter = 1666 * 3 = 4998 ... 5003: two epochs of three batches
+    ns.ckpt_freq = ns.plot_freq = 10 ** 9
+    ns.save_checkpoints, ns.plot_to_disk = (lambda e: None), (lambda: None)
+    ns.obj_name, ns.expname = 'golden', 'golden'
+    ns.writer = types.SimpleNamespace(add_scalar=lambda *a, **k: None)
+    tmp = tempfile.mkdtemp()
+    ns.checkpoints_path, ns.plots_dir = os.path.join(tmp, 'ckpt'), os.path.join(tmp, 'plots')
+    os.makedirs(ns.checkpoints_path); os.makedirs(ns.plots_dir)
+    ns.train_fix = lambda: RT.TrainRunner.train_fix(ns)
+    # the state train_fix left at iteration 0 (trainer.py:486-504), produced by the reference's own method
+    ns.cur_iter = 0
+    RT.TrainRunner.train_fix(ns)
+    assert ns.loss.vis_weight == 10 and ns.loss.sg_rgb_weight == 0 and not ns.light_para.weight.requires_grad \
+        and not any(q.requires_grad for q in rnet.albedo_net.parameters()) and any(q.requires_grad for q in rnet.visibility_net.parameters())
+    seed = 91
+    torch.manual_seed(seed)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        RT.TrainRunner.run(ns)
+    assert ns.cur_iter == 5004 and len(ns.loss.log) == 6
+    assert ns.loss.sg_rgb_weight == 1.0 and ns.light_para.weight.requires_grad and all(q.requires_grad for q in rnet.albedo_net.parameters())
+
+    # the draws of the six forward passes (renderer.py:212: one torch.normal per step; normal jitter is off in bear.conf)
+    torch.manual_seed(seed)
+    noises = [torch.normal(0, torch.ones(int(batches[i % 3][1]['surface_mask'].sum()), 3) * 0.01) for i in range(6)]
+
+    # oracle: the same six steps
+    onet = o2.PSNetwork(conf)
+    onet.load_state_dict(sd)
+    ostep = o2.TrainStep(onet, conf, NL, torch.cat(light_init, dim=0))
+    ostep.cur_iter = 0
+    ostep.train_fix()
+    ostep.cur_iter = 4998
+    accu = [len(l) for l in light_slt]
+    olog, l_slts = [], []
+    for i in range(6):
+        idx, mi, gt = batches[i % 3]
+        view = int(idx[0])
+        l_slt = sum(accu[:view]) + mi['lidx'][0]
+        l_slts.append(l_slt)
+        inp_o = {k: v for k, v in mi.items() if k != 'lidx'}
+        inp_o['light_direction'], inp_o['visibility'] = mi['light_direction'][0], mi['visibility'][0]
+        t, _ = ostep.step(inp_o, {'rgb': gt['rgb'][0]}, l_slt, train_order=True, noise={'xyz': noises[i]})
+        olog.append(t)
+    keys = sorted(ns.loss.log[0])
+    assert ns.loss.log[0]['albedo_smooth_loss'] is None and ns.loss.log[3]['albedo_smooth_loss'] is not None  # weight 0 before 5000
+    for i in range(6):
+        for k in keys:
+            if ns.loss.log[i][k] is None:
+                assert olog[i][k] is None, (i, k)
+                continue
+            check('trainer it %d %s' % (4998 + i, k), float(olog[i][k]), ns.loss.log[i][k], 2e-6)
+        check('trainer it %d normal_loss' % (4998 + i), float(olog[i]['normal_loss']), ns.loss_n.log[i]['normal_loss'], 2e-6)
+    rsd, osd = rnet.state_dict(), onet.state_dict()
+    # after Adam steps an element whose gradient sits at the fp32 noise floor may step the other way (|delta| <= 2 lr per step)
+    for k in rsd:
+        d = (rsd[k] - osd[k]).abs()
+        assert float(d.max()) <= 2 * 6 * 5e-4 + 1e-6 and float(d.mean()) <= 2e-5, (k, float(d.max()), float(d.mean()))
+    check('trainer light table', ostep.light_para.weight.detach(), ns.light_para.weight.detach(), 1e-3)
+    check('trainer light intensity', ostep.light_inten_para.weight.detach(), ns.light_inten_para.weight.detach(), 1e-3)
+    moved = (sd['albedo_net.linears.0.weight'] - rsd['albedo_net.linears.0.weight']).abs().max()
+    assert float(moved) > 0, 'the BRDF nets must have started training at iteration 5000'
+    lk = sorted(keys)
+    np.savez_compressed(
+        os.path.join(GOLDEN, 'stage2_trainer.npz'), sd_digest=state_dict_digest(sd), N=N, L=L, V=V, NL=NL, input_seeds=np.array([200, 201, 202]),
+        light_init=np_(torch.cat(light_init, dim=0)), l_slt=np.stack([np_(x) for x in l_slts]), first_iter=4998,
+        noise0=np_(noises[0]), noise1=np_(noises[1]), noise2=np_(noises[2]), noise3=np_(noises[3]), noise4=np_(noises[4]), noise5=np_(noises[5]),
+        loss_names=np.array(lk + ['normal_loss']),
+        loss_vals=np.array([[(np.nan if ns.loss.log[i][k] is None else ns.loss.log[i][k]) for k in lk] + [ns.loss_n.log[i]['normal_loss']]
+                            for i in range(6)]),  # nan = the reference returned None (term switched off)
+        light_para=np_(ns.light_para.weight.detach()), light_inten_para=np_(ns.light_inten_para.weight.detach()),
+        # final parameters: the first 2048 elements of every tensor (element-level check) + whole-tensor digests
+        param_names=np.array(sorted(rsd)), param_norms=grad_digest(rsd)[1], param_projs=grad_digest(rsd)[2],
+        **{('p_' + k): np_(v.reshape(-1)[:2048]) for k, v in rsd.items()})
+    print('stage2 trainer golden written')
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     os.makedirs(GOLDEN, exist_ok=True)
     if what == 'all':  # separate processes: stage1 and stage2 both own a top-level ``utils``/``model`` package
-        for s in ('stage1', 'stage2'):
+        for s in ('stage1', 'stage2', 'trainer'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), s])
+    elif what == 'trainer':
+        gen_trainer()
     elif what == 'stage1':
         gen_stage1()
     elif what == 'stage2':
