@@ -728,6 +728,8 @@ def gen_trainer():
         os.path.join(GOLDEN, 'stage2_trainer.npz'), sd_digest=state_dict_digest(sd), N=N, L=L, V=V, NL=NL, input_seeds=np.array([200, 201, 202]),
         light_init=np_(torch.cat(light_init, dim=0)), l_slt=np.stack([np_(x) for x in l_slts]), first_iter=4998,
         noise0=np_(noises[0]), noise1=np_(noises[1]), noise2=np_(noises[2]), noise3=np_(noises[3]), noise4=np_(noises[4]), noise5=np_(noises[5]),
+        # 'total' = what trainer.py:396-399 backpropagates (and, `loss += ...` being in place, what loss_output['loss'] holds afterwards)
+        total=np.array([ns.loss.log[i]['loss'] + ns.loss_n.log[i]['loss'] for i in range(6)]),
         loss_names=np.array(lk + ['normal_loss']),
         loss_vals=np.array([[(np.nan if ns.loss.log[i][k] is None else ns.loss.log[i][k]) for k in lk] + [ns.loss_n.log[i]['normal_loss']]
                             for i in range(6)]),  # nan = the reference returned None (term switched off)
