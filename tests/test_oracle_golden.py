@@ -354,3 +354,34 @@ def test_train_step_reproduces_the_reference_trainer_run():
     assert_close(norms, g['param_norms'], 1e-6, 'parameter norms')
     for k, v in sd_end.items():
         assert_close(v.reshape(-1)[:2048], g['p_' + k], 1e-5, 'parameter ' + k)
+
+
+def _stage1_train_step_golden(make_trainer, dev='cpu'):
+    """Replay tests/golden/stage1_train_step.npz (two steps of the reference's own Trainer.train_step, training.py:46-60)."""
+    from psnerf_amd.synthetic import stage1_batch
+    g = load('stage1_train_step.npz')
+    cfg = stage1_cfg('bunny', **{'training.n_training_points': int(g['n_points'])})
+    sd = stage1_state_dict(cfg, seed=11)
+    assert state_dict_digest(sd) == str(g['sd_digest'])
+    hb, wb = (int(v) for v in g['hw'])
+    data = stage1_batch(cfg, h=hb, w=wb, seed=int(g['batch_seed']))
+    net, tr = make_trainer(cfg, sd)
+    logs = []
+    for j in range(2):
+        noise = {k: T(g['s%d_nz_%s' % (j, k)]).to(dev) for k in ('miss', 'hit', 'nbr')}
+        logs.append(tr.train_step(data, it=int(g['s%d_it' % j]), pix=T(g['s%d_pix' % j]), noise=noise))
+    return g, net, logs
+
+
+def test_stage1_train_step_reproduces_the_reference_trainer():
+    def make(cfg, sd):
+        net = o1.NeuralNetwork(cfg)
+        net.load_state_dict(sd)
+        return net, o1.Trainer(o1.Renderer(net, cfg), torch.optim.Adam(net.parameters(), lr=1e-4), cfg)
+    g, net, logs = _stage1_train_step_golden(make)
+    for j in range(2):
+        for k, v in zip(g['s%d_loss_names' % j], g['s%d_loss_vals' % j]):
+            assert_close(float(logs[j][str(k)]), float(v), (5e-5 if str(k) == 'grad_loss' else 5e-6) * (1 if j == 0 else 50), '%s step %d' % (k, j))
+    for k, v in net.state_dict().items():  # Adam: sign flips at the fp32 noise floor move an element by up to 2 lr per step
+        d = (v.reshape(-1)[:1024] - T(g['p_' + k])).abs()
+        assert float(d.max()) <= 2 * 2 * 1e-4 + 1e-6 and float(d.mean()) <= 1e-5, (k, float(d.max()), float(d.mean()))

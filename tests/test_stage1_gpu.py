@@ -390,6 +390,26 @@ def test_compute_loss_golden(cuda, tag):
     assert_close(projs, g[tag + '_grad_projs'], 2e-3, 'grad projs')
 
 
+def test_train_step_vs_reference_trainer(cuda):
+    """Two optimisation steps of the reference's OWN Trainer.train_step (training.py:46-60; tests/golden/stage1_train_step.npz)
+    replayed by the HIP Trainer: loss terms of both steps and the parameters after them."""
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from tests.test_oracle_golden import _stage1_train_step_golden
+
+    def make(cfg, sd):
+        net = NeuralNetwork(cfg)
+        net.load_state_dict(sd)
+        return net, Trainer(Renderer(net, cfg, device=cuda), torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=cuda)
+    g, net, logs = _stage1_train_step_golden(make, dev=cuda)
+    for j in range(2):
+        for k, v in zip(g['s%d_loss_names' % j], g['s%d_loss_vals' % j]):
+            assert_close(float(logs[j][str(k)].detach()), float(v), 1e-3 if (str(k) == 'grad_loss' or j > 0) else 1e-4, '%s step %d' % (k, j), atol=0.0)
+    for k, v in net.state_dict().items():
+        d = (v.detach().cpu().reshape(-1)[:1024] - torch.from_numpy(g['p_' + k])).abs()
+        assert float(d.max()) <= 2 * 2 * 1e-4 + 1e-6, 'param %s max diff %.3e' % (k, float(d.max()))
+        assert float(d.mean()) <= 1e-5, 'param %s mean diff %.3e' % (k, float(d.mean()))
+
+
 def test_compute_loss_full_image_branch_fails_like_the_reference(cuda):
     """n_training_points >= h*w: the reference raises RuntimeError from grid_sample on its int64 pixel grid
     (training.py:159-165 -> common.py:195; the fixture holds its exception); so does the product, before the forward."""

@@ -331,6 +331,49 @@ def gen_stage1():
     cl['full_image_error'] = np.array([errs[0]])
     np.savez_compressed(os.path.join(GOLDEN, 'stage1_compute_loss.npz'), sd_digest=state_dict_digest(sd), hw=np.array([hb, wb]),
                         batch_seed=6, mask_valid_seed=13, n_points=160, **cl)
+    # --- Trainer.train_step (training.py:46-60): two optimisation steps of the reference's OWN trainer (Adam, lr 1e-4), the
+    #     draws of each step replayed in the reference's order; the hit count that sizes the tables comes from a dry march
+    #     with the weights the step starts from
+    cfg_s = stage1_cfg('bunny', **{'training.n_training_points': 160})
+    data_s = stage1_batch(cfg_s, h=hb, w=wb, seed=8)
+    rnet.load_state_dict(sd)
+    onet.load_state_dict(sd)
+    rtr = rmdl.Trainer(rmdl.Renderer(rnet, cfg_s, device=torch.device('cpu')), torch.optim.Adam(rnet.parameters(), lr=1e-4), cfg_s,
+                       device=torch.device('cpu'))
+    otr = o1.Trainer(o1.Renderer(onet, cfg_s), torch.optim.Adam(onet.parameters(), lr=1e-4), cfg_s)
+    ts = {}
+    for j, it in enumerate((1500, 1501)):
+        seed = 700 + j
+        n = 160
+        torch.manual_seed(seed)
+        px = torch.randint(0, wb, size=(1, n, 1)).float()
+        py = torch.randint(0, hb, size=(1, n, 1)).float()
+        pix_s = torch.cat([px, py], dim=-1)
+        with torch.no_grad():
+            dry = o1.Renderer(onet, cfg_s)(pix_s, data_s['img.camera_mat'], data_s['img.world_mat'], data_s['img.scale_mat'], 'unisurf',
+                                           add_noise=False, eval_=True, it=it)
+        n_hit = int(dry['mask_pred'].sum())
+        torch.manual_seed(seed)
+        tr_ = rtr.train_step(data_s, it=it)
+        torch.manual_seed(seed)
+        torch.randint(0, wb, size=(1, n, 1)); torch.randint(0, hb, size=(1, n, 1)); torch.randint(256, 257, (1,))
+        noise_s = {'miss': torch.rand(1, n - n_hit, 64), 'hit': torch.rand(1, n_hit, 64), 'nbr': torch.rand(n_hit, 3)}
+        to_ = otr.train_step(data_s, it=it, pix=pix_s, noise=noise_s)
+        assert sorted(tr_) == sorted(to_)
+        for k in tr_:
+            check('train_step %d %s' % (j, k), to_[k], tr_[k], (2e-5 if k == 'grad_loss' else 2e-6) * (1 if j == 0 else 50))  # step 2 starts from Adam-updated weights
+        lk = sorted(tr_)
+        ts.update({'s%d_pix' % j: np_(pix_s), 's%d_it' % j: it, 's%d_loss_names' % j: np.array(lk),
+                   's%d_loss_vals' % j: np.array([float(tr_[k]) for k in lk])})
+        ts.update({'s%d_nz_%s' % (j, k): np_(v) for k, v in noise_s.items()})
+    rsd2, osd2 = rnet.state_dict(), onet.state_dict()
+    for k in rsd2:
+        d = (rsd2[k] - osd2[k]).abs()
+        assert float(d.max()) <= 2 * 2 * 1e-4 + 1e-6 and float(d.mean()) <= 1e-5, (k, float(d.max()), float(d.mean()))
+    assert float((rsd2['lin0.weight_v'] - sd['lin0.weight_v']).abs().max()) > 0
+    np.savez_compressed(os.path.join(GOLDEN, 'stage1_train_step.npz'), sd_digest=state_dict_digest(sd), hw=np.array([hb, wb]), batch_seed=8,
+                        n_points=160, param_names=np.array(sorted(rsd2)), param_norms=grad_digest(rsd2)[1],
+                        **ts, **{('p_' + k): np_(v.reshape(-1)[:1024]) for k, v in rsd2.items()})
     print('stage1 goldens written')
 
 
