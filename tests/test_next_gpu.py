@@ -125,3 +125,30 @@ def test_material_editing_vs_oracle(cuda):
             out = net(inp_d, **kw)
         for k in ('sg_rgb_values', 'sg_diffuse_albedo_values', 'sg_specular_rgb_values', 'sg_weight'):
             assert_outputs_close(k, out[k].cpu(), ref[k], prefix='%s: ' % sorted(kw))
+
+
+def test_envmap_relight_vs_reference_pieces(cuda):
+    """relight.render_envmap against tests/golden/stage2_relight.npz: the light-batch / pixel-chunk loop of stage2/eval.py:173-218
+    re-assembled from the reference's OWN PSNetwork, gen_light_xyz, split_input and merge_output (tools/gen_golden.py), 4 x 8
+    environment lights over a 30 x 40 view, RGB light intensities, light batches of 10 vs 7 here, pixel chunks."""
+    import os
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.stage2 import relight
+    from oracle import stage2 as o2
+    from tests.helpers import GOLDEN, state_dict_digest
+    g = np.load(os.path.join(GOLDEN, 'stage2_relight.npz'))
+    sd = stage2_state_dict(o2.bear_conf(), seed=12)
+    assert state_dict_digest(sd) == str(g['sd_digest'])
+    net = s2.PSNetwork(s2.bear_conf())
+    net.load_state_dict(sd)
+    net.to(cuda).eval()
+    hr, wr = (int(v) for v in g['hw'])
+    inp, _ = stage2_inputs(hr * wr, 1, 1, seed=int(g['input_seed']), h=hr, w=wr)
+    base = {'object_mask': torch.ones(1, hr * wr, dtype=torch.bool), 'uv': torch.from_numpy(g['uv'])[None], 'intrinsics': inp['intrinsics'],
+            'pose': inp['pose'], 'normal': torch.ones(1, hr * wr, 3), 'points': inp['points'], 'surface_mask': inp['surface_mask']}
+    base = {k: v.to(cuda) for k, v in base.items()}
+    rgb, vis = relight.render_envmap(net, base, g['env'], light_h=int(g['light_h']), light_batch=7, pixel_chunk=500, visibility=True)
+    assert_close(rgb.cpu().reshape(hr, wr, 3), g['rgb'], 1e-4, 'relit rgb', atol=ATOL_UNIT)
+    assert_close(vis.cpu().reshape(hr, wr, 3), g['visibility'], 1e-4, 'light-averaged visibility', atol=1e-5)
+    rgb6 = relight.render_envmap(net, base, g['env'], light_h=int(g['light_h']), light_batch=32, precision='bf16x6')
+    assert_close(rgb6.cpu().reshape(hr, wr, 3), g['rgb'], 1e-4, 'relit rgb (bf16x6 experiment)', atol=ATOL_UNIT)

@@ -385,3 +385,23 @@ def test_stage1_train_step_reproduces_the_reference_trainer():
     for k, v in net.state_dict().items():  # Adam: sign flips at the fp32 noise floor move an element by up to 2 lr per step
         d = (v.reshape(-1)[:1024] - T(g['p_' + k])).abs()
         assert float(d.max()) <= 2 * 2 * 1e-4 + 1e-6 and float(d.mean()) <= 1e-5, (k, float(d.max()), float(d.mean()))
+
+
+def test_relight_loop_vs_reference_pieces():
+    """The oracle network under the relighting loop of eval.py:173-218 (fixture assembled from the reference's own pieces)."""
+    g = load('stage2_relight.npz')
+    conf = o2.bear_conf()
+    net = o2.PSNetwork(conf)
+    net.load_state_dict(stage2_state_dict(conf, seed=12))
+    hr, wr = (int(v) for v in g['hw'])
+    inp, _ = stage2_inputs(hr * wr, 1, 1, seed=int(g['input_seed']), h=hr, w=wr)
+    from psnerf_amd.stage2.relight import gen_light_xyz
+    lxyz = gen_light_xyz(int(g['light_h']), 2 * int(g['light_h']), envmap_radius=1)[0].reshape(-1, 3)
+    mi = {'object_mask': torch.ones(1, hr * wr, dtype=torch.bool), 'uv': T(g['uv'])[None], 'intrinsics': inp['intrinsics'], 'pose': inp['pose'],
+          'normal': torch.ones(1, hr * wr, 3), 'points': inp['points'], 'surface_mask': inp['surface_mask'],
+          'light_direction': torch.nn.functional.normalize(torch.tensor(lxyz).float(), p=2, dim=-1),
+          'light_intensity': T(g['env']).reshape(-1, 3)}
+    with torch.no_grad():
+        out = net(mi)
+    assert_close(out['sg_rgb_values'].sum(0).clamp(0, 1).reshape(hr, wr, 3), g['rgb'], 5e-6, 'relit rgb')
+    assert_close(out['visibility'].mean(0).reshape(hr, wr, 3), g['visibility'], 5e-6, 'visibility')

@@ -439,6 +439,51 @@ def gen_stage2():
     np.savez_compressed(os.path.join(GOLDEN, 'stage2_light_xyz.npz'), xyz=xyz_r, areas=areas_r)
     print('  [ok ] relight helpers == reference eval_utils.gen_light_xyz / general.split_input / merge_output')
 
+    # ---- environment-map relighting (stage2/eval.py:173-218): the loop of evaluate() over light batches and pixel chunks,
+    #      re-assembled from the reference's OWN pieces -- PSNetwork, eval_utils.gen_light_xyz, general.split_input /
+    #      merge_output -- in the order eval.py runs them (evaluate() itself is one function around datasets and checkpoints)
+    conf_r = o2.bear_conf()
+    sd_r = stage2_state_dict(conf_r, seed=12)
+    rnet_r = RPS(conf_r)
+    rnet_r.load_state_dict(sd_r)
+    rnet_r.eval()
+    hr, wr, lh_r, lbatch = 30, 40, 4, 10
+    inp_r, _ = stage2_inputs(hr * wr, 1, 1, seed=3, h=hr, w=wr)
+    uv_r = np.mgrid[0:hr, 0:wr].astype(np.int32)                      # eval.py:178-180
+    uv_r = torch.from_numpy(np.flip(uv_r, axis=0).copy()).float().reshape(2, -1).transpose(1, 0)
+    mi_r = {'object_mask': torch.ones(1, hr * wr), 'uv': uv_r[None], 'intrinsics': inp_r['intrinsics'], 'pose': inp_r['pose'],
+            'normal': torch.ones(1, hr * wr, 3), 'points': inp_r['points'], 'surface_mask': inp_r['surface_mask']}
+    env_r = np.random.RandomState(5).rand(lh_r, 2 * lh_r, 3).astype(np.float32) * 0.3
+    lxyz_r = REVAL.gen_light_xyz(lh_r, 2 * lh_r, envmap_radius=1)[0].reshape(-1, 3)
+    envf = env_r.reshape(-1, 3)
+    rgb_all, vis_all = [], []
+    with torch.no_grad():
+        for lstart in range(0, lh_r ** 2 * 2, lbatch):                # eval.py:196-213
+            lend = min(lh_r ** 2 * 2, lstart + lbatch)
+            mi_r['light_direction'] = torch.nn.functional.normalize(torch.tensor(lxyz_r[lstart:lend]).float(), p=2, dim=-1)
+            mi_r['light_intensity'] = torch.tensor(envf[lstart:lend]).float()
+            res = []
+            for sp in RGEN.split_input(mi_r, hr * wr):
+                out = rnet_r(sp)
+                res.append({'sg_rgb_values': out['sg_rgb_values'].detach(), 'visibility': out.get('visibility', torch.ones_like(out['points'])).detach()})
+            mo = RGEN.merge_output(res, hr * wr, 1)
+            rgb_all.append(np_(mo['sg_rgb_values'].reshape(-1, hr, wr, 3)))
+            vis_all.append(np_(mo['visibility'].reshape(-1, hr, wr, 3)))
+    rgb_ref = np.concatenate(rgb_all, 0).sum(0).clip(0, 1)             # eval.py:214
+    vis_ref = np.concatenate(vis_all, 0).mean(0)                       # eval.py:220
+    onet_r = o2.PSNetwork(conf_r)
+    onet_r.load_state_dict(sd_r)
+    with torch.no_grad():
+        mi_o = {k: v for k, v in mi_r.items() if k not in ('light_direction', 'light_intensity')}
+        mi_o['object_mask'] = mi_o['object_mask'].bool()
+        mi_o['light_direction'] = torch.nn.functional.normalize(torch.tensor(lxyz_r).float(), p=2, dim=-1)
+        mi_o['light_intensity'] = torch.tensor(envf).float()
+        oo = onet_r(mi_o)
+    check('relight rgb', oo['sg_rgb_values'].sum(0).clamp(0, 1).reshape(hr, wr, 3), rgb_ref, 2e-6)
+    check('relight visibility', oo['visibility'].mean(0).reshape(hr, wr, 3), vis_ref, 2e-6)
+    np.savez_compressed(os.path.join(GOLDEN, 'stage2_relight.npz'), sd_digest=state_dict_digest(sd_r), hw=np.array([hr, wr]), light_h=lh_r,
+                        input_seed=3, uv=np_(uv_r), env=env_r, rgb=rgb_ref.astype(np.float32), visibility=vis_ref.astype(np.float32))
+
     # ---- normal jitter > 0 (renderer.py:133-140; bear.conf has 0): TWO torch.normal draws, normal jitter first
     conf_j = o2.bear_conf(**{'normal.net.xyz_jitter_std': 0.02})
     sd_j = stage2_state_dict(conf_j, seed=35)
