@@ -307,15 +307,25 @@ def test_stage2_psnetwork_normal_jitter():
     assert_close(projs, g['grad_projs'], 1e-4, 'grad projs')
 
 
-def _trainer_golden_steps(make_step, dev='cpu'):
-    """Replay tests/golden/stage2_trainer.npz -- six iterations of the reference's OWN TrainRunner.run across the
-    iteration-5000 train_fix switch -- through a TrainStep built by ``make_step(conf, sd, NL, light_init)``."""
-    g = load('stage2_trainer.npz')
+def _trainer_golden_steps(make_step, dev='cpu', vis_plus=False):
+    """Replay tests/golden/stage2_trainer[_visplus].npz -- six iterations of the reference's OWN TrainRunner.run across the
+    iteration-5000 train_fix switch, without / with the train.vis_plus supervision draw -- through a TrainStep built by
+    ``make_step(sd, NL, light_init, tables)``; tables = None or the vis_plus tables (per view: 'vis_plus' [P, hw],
+    'vis_plus_light' [P, 3], 'visibility' [L_v, hw]; + the per-view initial light estimates and vnum)."""
+    g = load('stage2_trainer_visplus.npz' if vis_plus else 'stage2_trainer.npz')
     conf = o2.bear_conf()
     sd = stage2_state_dict(conf, seed=41)
     assert state_dict_digest(sd) == str(g['sd_digest'])
     N, L, V, NL = (int(g[k]) for k in ('N', 'L', 'V', 'NL'))
-    step = make_step(sd, NL, T(g['light_init']))
+    light_init = T(g['light_init'])
+    tables = None
+    if vis_plus:
+        n0 = int(g['light_split'][0])
+        views = [{'vis_plus': T(g['vp_vis'][v]).float(), 'vis_plus_light': T(g['vp_light'][v]), 'visibility': T(g['view_vis%d' % v]).float()}
+                 for v in range(2)]
+        tables = dict(views=views, view_light=[light_init[:n0], light_init[n0:]], vnum=int(g['vnum']))
+        np.random.seed(int(g['np_seed']))
+    step = make_step(sd, NL, light_init, tables)
     step.cur_iter = 0
     step.train_fix()                       # trainer.py:486-504: the state iteration 0 leaves behind
     step.cur_iter = int(g['first_iter'])
@@ -324,22 +334,31 @@ def _trainer_golden_steps(make_step, dev='cpu'):
     for i in range(6):
         inp, gt = stage2_inputs(N, L, V, seed=int(g['input_seeds'][i % 3]))
         inp = {k: v.to(dev) for k, v in inp.items() if k not in ('light_intensity', 'light_vis_train', 'vis_train_gt')}
+        vidx = None
+        if vis_plus:
+            vidx = int(g['views'][i % 3])
+            inp['sampling_idx'] = T(g['sampling_idx'][i % 3])[None].to(dev)
         terms, _ = step.step(inp, {'rgb': gt['rgb'].to(dev)}, T(g['l_slt'][i]).to(dev), train_order=True,
-                             noise={'xyz': T(g['noise%d' % i]).to(dev)})
+                             noise={'xyz': T(g['noise%d' % i]).to(dev)}, vidx=vidx)
         logs.append(terms)
     return g, names, logs, step
 
 
-def test_train_step_reproduces_the_reference_trainer_run():
+@pytest.mark.parametrize('vis_plus', [False, True])
+def test_train_step_reproduces_the_reference_trainer_run(vis_plus):
     """a24: the oracle's TrainStep against the reference's own TrainRunner.run / train_fix (stage2/trainer.py:355-410,
     462-464, 485-513), six iterations across the switch at iteration 5000 (two with the BRDF nets and the light tables frozen
-    and vis_weight 10, four with everything training): every loss term of every iteration, the final light tables and the
-    final network parameters."""
-    def make(sd, NL, light_init):
+    and vis_weight 10, four with everything training), without and with the train.vis_plus draw (:384-392): every loss term of
+    every iteration, the final light tables and the final network parameters."""
+    def make(sd, NL, light_init, tables):
         net = o2.PSNetwork(o2.bear_conf())
         net.load_state_dict(sd)
-        return o2.TrainStep(net, o2.bear_conf(), NL, light_init)
-    g, names, logs, step = _trainer_golden_steps(make)
+        vp = None
+        if tables is not None:
+            vp = dict(light=[v['vis_plus_light'] for v in tables['views']], vis=[v['vis_plus'] for v in tables['views']],
+                      view_light=tables['view_light'], view_vis=[v['visibility'] for v in tables['views']], vnum=tables['vnum'])
+        return o2.TrainStep(net, o2.bear_conf(), NL, light_init, vis_plus=vp)
+    g, names, logs, step = _trainer_golden_steps(make, vis_plus=vis_plus)
     for i in range(6):
         for k, v in zip(names, g['loss_vals'][i]):
             if np.isnan(v):

@@ -658,7 +658,7 @@ def gen_stage2():
 
 
 # ---------------------------------------------------------------------------
-def gen_trainer():
+def gen_trainer(vis_plus=False):
     """stage2/trainer.py: the reference's OWN TrainRunner.run / train_fix (the step body :355-410,462-464 and the schedule
     :485-513) driven for six iterations across the iteration-5000 switch.  The module imports with empty placeholders for
     the third-party packages this image lacks (pyhocon, tensorboardX, imageio, cv2, skimage, plotly, GPUtil, trimesh: none is
@@ -687,7 +687,7 @@ def gen_trainer():
     from model.renderer import PSNetwork as RPS
     from model.loss import MainLoss as RMain, NormalLoss as RNormal
 
-    conf = o2.bear_conf()
+    conf = o2.bear_conf(**{'train.vis_train_num': 5})
     sd = stage2_state_dict(conf, seed=41)
     N, L, V, NL = 360, 4, 3, 12
     light_slt = [list(range(5)), list(range(7))]          # two views with 5 and 7 lights: rows 0..4 and 5..11 of the tables
@@ -703,6 +703,19 @@ def gen_trainer():
         mi['visibility'] = inp['visibility'][None]
         mi['lidx'] = lidx[None]
         batches.append((torch.tensor([view]), mi, {'rgb': gt['rgb'][None]}))
+
+    # train.vis_plus (trainer.py:209-214, 384-392): per view P extra directions with their stage-1 visibility maps over the WHOLE
+    # view (hw pixels) + the view's own lights / visibility; every step draws vnum of the P + L_v rows with np.random.choice
+    # and looks the sampled pixels up through model_input['sampling_idx']
+    P, hw, vnum = 6, 900, 5
+    vp_light = [torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1) for _ in light_slt]
+    vp_vis = [(torch.rand(P, hw, generator=g) > 0.3).float() for _ in light_slt]
+    view_vis = [(torch.rand(len(ls), hw, generator=g) > 0.3).float() for ls in light_slt]
+    samp = [torch.randperm(hw, generator=g)[:N] for _ in range(3)]
+    if vis_plus:
+        for b, (idx, mi, gt) in enumerate(batches):
+            view = int(idx[0])
+            mi['vidx'], mi['vidx_ori'], mi['sampling_idx'] = torch.tensor([view]), torch.tensor([view]), samp[b][None]
 
     class Recorder(object):   # the reference's loss module, every call logged
         def __init__(self, inner):
@@ -727,7 +740,9 @@ def gen_trainer():
     ns.loss = Recorder(RMain(loss_type='L1', sg_rgb_weight=1.0, albedo_smooth_weight=0.05, rough_smooth_weight=0.01, vis_weight=1))
     ns.loss_n = Recorder(RNormal(1, 0.05))
     ns.normal_train, ns.multi_light, ns.light_train, ns.light_inten_train = True, True, True, True
-    ns.visibility, ns.vis_loss, ns.vis_plus, ns.ana_fixlight, ns.light_decay, ns.train_order = True, True, False, False, False, True
+    ns.visibility, ns.vis_loss, ns.vis_plus, ns.ana_fixlight, ns.light_decay, ns.train_order = True, True, bool(vis_plus), False, False, True
+    ns.vis_plus_light = {'view_%02d' % (v + 1): vp_light[v].numpy().tolist() for v in range(2)}      # vis_plus/light_dir.json
+    ns.vis_plus_all = {'view_%02d' % (v + 1): vp_vis[v].numpy().reshape(P, 30, 30) for v in range(2)}   # vis_plus/view_XX.npy
     # learning rates of stage2/confs/bear.conf:19-20,48-50 (the milestones lie beyond these iterations)
     ns.sg_optimizer = torch.optim.Adam(rnet.parameters(), lr=5e-4)
     ns.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(ns.sg_optimizer, [], gamma=0.5)
@@ -747,7 +762,7 @@ def gen_trainer():
             for idx, mi, gt in batches:
                 yield idx, dict(mi), dict(gt)
     ns.train_dataloader = Loader()
-    ns.train_dataset = types.SimpleNamespace(change_sampling_idx=lambda n: None, view_idx=[0, 1], light_slt=light_slt,
+    ns.train_dataset = types.SimpleNamespace(change_sampling_idx=lambda n: None, view_idx=[0, 1], light_slt=light_slt, visibility=view_vis,
                                              light_direction=[torch.nn.functional.normalize(li, dim=-1) for li in light_init])
     ns.num_pixels, ns.start_epoch, ns.nepochs = N, 1666, 1667      # cur_iter = 1666 * 3 = 4998 ... 5003: two epochs of three batches
     ns.ckpt_freq = ns.plot_freq = 10 ** 9
@@ -765,6 +780,7 @@ def gen_trainer():
         and not any(q.requires_grad for q in rnet.albedo_net.parameters()) and any(q.requires_grad for q in rnet.visibility_net.parameters())
     seed = 91
     torch.manual_seed(seed)
+    np.random.seed(seed)
     import io, contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         RT.TrainRunner.run(ns)
@@ -778,7 +794,9 @@ def gen_trainer():
     # oracle: the same six steps
     onet = o2.PSNetwork(conf)
     onet.load_state_dict(sd)
-    ostep = o2.TrainStep(onet, conf, NL, torch.cat(light_init, dim=0))
+    o_vp = dict(light=vp_light, vis=vp_vis, view_light=light_init, view_vis=view_vis, vnum=vnum) if vis_plus else None
+    ostep = o2.TrainStep(onet, conf, NL, torch.cat(light_init, dim=0), vis_plus=o_vp)
+    np.random.seed(seed)
     ostep.cur_iter = 0
     ostep.train_fix()
     ostep.cur_iter = 4998
@@ -789,9 +807,9 @@ def gen_trainer():
         view = int(idx[0])
         l_slt = sum(accu[:view]) + mi['lidx'][0]
         l_slts.append(l_slt)
-        inp_o = {k: v for k, v in mi.items() if k != 'lidx'}
+        inp_o = {k: v for k, v in mi.items() if k not in ('lidx', 'vidx', 'vidx_ori')}
         inp_o['light_direction'], inp_o['visibility'] = mi['light_direction'][0], mi['visibility'][0]
-        t, _ = ostep.step(inp_o, {'rgb': gt['rgb'][0]}, l_slt, train_order=True, noise={'xyz': noises[i]})
+        t, _ = ostep.step(inp_o, {'rgb': gt['rgb'][0]}, l_slt, train_order=True, noise={'xyz': noises[i]}, vidx=view if vis_plus else None)
         olog.append(t)
     keys = sorted(ns.loss.log[0])
     assert ns.loss.log[0]['albedo_smooth_loss'] is None and ns.loss.log[3]['albedo_smooth_loss'] is not None  # weight 0 before 5000
@@ -812,8 +830,14 @@ def gen_trainer():
     moved = (sd['albedo_net.linears.0.weight'] - rsd['albedo_net.linears.0.weight']).abs().max()
     assert float(moved) > 0, 'the BRDF nets must have started training at iteration 5000'
     lk = sorted(keys)
+    extra = {}
+    if vis_plus:
+        extra = dict(np_seed=seed, vnum=vnum, views=np.array([int(b[0][0]) for b in batches]), sampling_idx=np.stack([np_(x) for x in samp]),
+                     vp_light=np.stack([np_(x) for x in vp_light]), vp_vis=np.stack([np_(x) for x in vp_vis]).astype(np.uint8),
+                     view_vis0=np_(view_vis[0]).astype(np.uint8), view_vis1=np_(view_vis[1]).astype(np.uint8))
     np.savez_compressed(
-        os.path.join(GOLDEN, 'stage2_trainer.npz'), sd_digest=state_dict_digest(sd), N=N, L=L, V=V, NL=NL, input_seeds=np.array([200, 201, 202]),
+        os.path.join(GOLDEN, 'stage2_trainer_visplus.npz' if vis_plus else 'stage2_trainer.npz'), **extra,
+        sd_digest=state_dict_digest(sd), N=N, L=L, V=V, NL=NL, input_seeds=np.array([200, 201, 202]), light_split=np.array([len(l) for l in light_slt]),
         light_init=np_(torch.cat(light_init, dim=0)), l_slt=np.stack([np_(x) for x in l_slts]), first_iter=4998,
         noise0=np_(noises[0]), noise1=np_(noises[1]), noise2=np_(noises[2]), noise3=np_(noises[3]), noise4=np_(noises[4]), noise5=np_(noises[5]),
         # 'total' = what trainer.py:396-399 backpropagates (and, `loss += ...` being in place, what loss_output['loss'] holds afterwards)
@@ -825,7 +849,7 @@ def gen_trainer():
         # final parameters: the first 2048 elements of every tensor (element-level check) + whole-tensor digests
         param_names=np.array(sorted(rsd)), param_norms=grad_digest(rsd)[1], param_projs=grad_digest(rsd)[2],
         **{('p_' + k): np_(v.reshape(-1)[:2048]) for k, v in rsd.items()})
-    print('stage2 trainer golden written')
+    print('stage2 trainer golden written (vis_plus=%s)' % vis_plus)
 
 
 if __name__ == '__main__':
@@ -835,7 +859,8 @@ if __name__ == '__main__':
         for s in ('stage1', 'stage2', 'trainer'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), s])
     elif what == 'trainer':
-        gen_trainer()
+        gen_trainer(False)
+        gen_trainer(True)
     elif what == 'stage1':
         gen_stage1()
     elif what == 'stage2':
