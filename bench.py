@@ -280,20 +280,27 @@ def main():
         return float(t.item()), int(ns.item()), terms
 
     def instrumented(inp, gt, steps):
-        """Per-kernel durations: HIP events around every C-ABI launch on its launch stream (hip._Prof), in a pass of its own."""
-        hip.PROFILE_EVENTS = ev = []
+        """Per-kernel durations: HIP events around every C-ABI launch on its launch stream (hip._Prof), in a pass of its own.
+        EVERY rank runs the steps (they contain the data-parallel collectives); only rank 0 records."""
+        hip.PROFILE_EVENTS = ev = ([] if rank == 0 else None)
         for _ in range(steps):
             step.step(inp, gt, l_slt, train_order=False)
         torch.cuda.synchronize()
         hip.PROFILE_EVENTS = None
-        return ev
+        return ev or []
 
     def count_launches(inp, gt):
         """Device kernel launches of ONE steady-state step, split into the hand-written HIP kernels (namespace psn) and the
         rest (torch-eager at::native / foreach kernels, memsets); None when the profiler is unavailable."""
+        if rank != 0:  # the step contains collectives: every rank runs it, rank 0 under the profiler
+            step.step(inp, gt, l_slt, train_order=False)
+            torch.cuda.synchronize()
+            return None
+        ran = False
         try:
             from torch.profiler import profile, ProfilerActivity
             with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                ran = True
                 step.step(inp, gt, l_slt, train_order=False)
                 torch.cuda.synchronize()
             names = [e.name for e in prof.events() if getattr(e, 'device_type', None) is not None
@@ -303,6 +310,9 @@ def main():
             ours = sum(1 for n in names if 'psn::' in n)
             return {'total': len(names), 'hip_hand_written': ours, 'other': len(names) - ours}
         except Exception as e:  # noqa: BLE001
+            if not ran:  # the other ranks are inside the step's collectives: join them whatever the profiler did
+                step.step(inp, gt, l_slt, train_order=False)
+                torch.cuda.synchronize()
             return {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
 
     def weak_batch():
@@ -316,8 +326,8 @@ def main():
     inp, gt = head_batch()
     dt, ns_total, terms = timed(inp, gt, args.steps, args.warmup)
     px_local = inp['uv'].shape[1]
-    events = instrumented(inp, gt, min(args.steps, 10)) if rank == 0 else []
-    launches = count_launches(inp, gt) if (rank == 0 and not args.no_extra) else None
+    events = instrumented(inp, gt, min(args.steps, 10))
+    launches = count_launches(inp, gt) if not args.no_extra else None
     ref_dict = None
     if not args.no_extra and world == 1:
         # the drop-in number: the reference's own dictionary, no 'surface_idx' -- PSNetwork.forward then builds the index list
