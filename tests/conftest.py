@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 DP_RESULT = os.path.join(ROOT, 'gpurun_out', 'dp_gpu_result.json')
 NCCL_RESULT = os.path.join(ROOT, 'gpurun_out', 'nccl_gpu_result.json')
+BENCH2_RESULT = os.path.join(ROOT, 'gpurun_out', 'bench2_gpu_result.json')
 # one stamp per pytest process, whichever module instance of this file asks (pytest may import it under two names)
 SESSION_STAMP = os.environ.setdefault('PSN_TEST_SESSION', '%d-%d' % (os.getpid(), int(__import__('time').time())))
 
@@ -28,7 +29,8 @@ def pytest_collection_modifyitems(session, config, items):
     result file.  The result carries this session's stamp; the test rejects a file left behind by another session."""
     if config.getoption('collectonly'):
         return
-    jobs = [(res, worker) for key, res, worker in (('test_dp_gpu', DP_RESULT, 'dp_gpu_worker.py'), ('test_nccl_gpu', NCCL_RESULT, 'nccl_gpu_worker.py'))
+    jobs = [(res, worker) for key, res, worker in (('test_dp_gpu', DP_RESULT, 'dp_gpu_worker.py'), ('test_nccl_gpu', NCCL_RESULT, 'nccl_gpu_worker.py'),
+                                   ('test_bench_multirank_gpu', BENCH2_RESULT, 'bench2_gpu_worker.py'))
             if any(key in it.nodeid for it in items)]
     if not jobs:
         return
