@@ -126,6 +126,7 @@ def stage1_measure(device, steps=10, warmup=3, rays=4096):
     import torch
     from psnerf_amd import hip
     from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.optim import FlatAdam
     from psnerf_amd.synthetic import stage1_batch, stage1_cfg
     cfg = stage1_cfg('bear', **{'rendering.num_points_in': 96, 'rendering.num_points_out': 32,
                                 'training.n_training_points': rays})
@@ -133,7 +134,8 @@ def stage1_measure(device, steps=10, warmup=3, rays=4096):
     batch = {k: v.to(device) for k, v in stage1_batch(cfg, h=512, w=612, seed=0).items()}
     torch.manual_seed(42)
     net = NeuralNetwork(cfg)
-    tr = Trainer(Renderer(net, cfg, device=device), torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=device)
+    ren = Renderer(net, cfg, device=device)
+    tr = Trainer(ren, FlatAdam(net.parameters(), lr=1e-4), cfg, device=device)
     for _ in range(warmup):
         tr.train_step(batch, it=it)
     torch.cuda.synchronize()

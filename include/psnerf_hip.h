@@ -358,6 +358,38 @@ int psn_stage2_loss_bwd(const float* g_total, const float* rgb, const float* rgb
                         float k_nrmj, float* d_nrm, float* d_nrm_j, const unsigned char* mask_a, const unsigned char* mask_b,
                         int64_t N, int l2, const float* count_dev, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Stage-1 losses of the sync-free training forward, stage1/model/losses.py:24-70, over per-ray tensors ([N] / [N, 3]):
+ *   sums[0] = sum |rgb - rgb_gt|                               sums[4] = #hit
+ *   sums[1] = sum over hit rays of diff (smoothness)           sums[5] = #norm_mask
+ *   sums[2] = sum over norm_mask of |normal - normal_gt|       sums[6] = #mask_valid
+ *   sums[3] = sum over mask_valid of BCE(clamp(acc, 0, 1), mask_gt) with the log terms clamped at -100
+ * terms[0..3] = sums[0] / n_rays, sums[1] / max(sums[4], 1), sums[2] / max(sums[5], 1), sums[3] / max(sums[6], 1);
+ * terms[4] = weights[0] terms[0] + weights[1] terms[1] (+ weights[2] terms[2]) (+ weights[3] terms[3]), a term with NULL
+ * inputs (or weight 0 for the first two) being skipped.  weights: HOST array [4] (full, grad, norm, mask).  n_rays: the
+ * ray count of the whole batch (all ranks).  psn_stage1_loss_fwd with terms == NULL stops after the sums, so that the caller
+ * can all-reduce sums[4..6] over ranks and finish with psn_stage1_loss_terms.  partial: device workspace of
+ * psn_stage1_loss_partial_floats() floats.  Deterministic summation order.
+ * psn_stage1_loss_bwd: d terms[4] / d input * g_loss[0] for every non-NULL d_* (counts read from sums on the device).
+ * psn_surface_normals_{fwd,bwd}: stage1/model/rendering.py:200-212 for g [2 N, 3] (gradients of the geometry field at the N
+ * surface points and at their N jittered neighbours): n = g / (|g| + eps); norm_pred [N, 3] = hit ? n[:N] : 0;
+ * diff [N] = |n[:N] - n[N:]|; backward: dg [2 N, 3] from d_norm_pred / d_diff (either may be NULL). */
+int psn_stage1_loss_partial_floats(void);
+int psn_stage1_loss_fwd(const float* rgb, const float* rgb_gt, const float* diff, const unsigned char* hit, const float* normal,
+                        const float* normal_gt, const unsigned char* norm_mask, const float* acc, const float* mask_gt,
+                        const unsigned char* mask_valid, int64_t N, int64_t n_rays, const float* weights, float* partial,
+                        float* sums, float* terms, void* stream);
+int psn_stage1_loss_terms(const float* sums, int64_t n_rays, const float* weights, int has_grad, int has_norm, int has_mask,
+                          float* terms, void* stream);
+int psn_stage1_loss_bwd(const float* g_loss, const float* sums, const float* rgb, const float* rgb_gt, const unsigned char* hit,
+                        const float* normal, const float* normal_gt, const unsigned char* norm_mask, const float* acc,
+                        const float* mask_gt, const unsigned char* mask_valid, int64_t N, int64_t n_rays, const float* weights,
+                        float* d_rgb, float* d_diff, float* d_normal, float* d_acc, void* stream);
+int psn_surface_normals_fwd(const float* g, const unsigned char* hit, int64_t N, float eps, float* norm_pred, float* diff,
+                            void* stream);
+int psn_surface_normals_bwd(const float* g, const unsigned char* hit, int64_t N, float eps, const float* d_norm_pred,
+                            const float* d_diff, float* dg, void* stream);
+
 /* Sums of x [V, Ns, C] (C <= 256, V <= PSN_PAIR_SUMS_MAX_V) over V and over Ns in one pass: sx [Ns, C] = sum_v x and
  * sl_part [*n_chunks, V, C] = per-chunk partial sums over Ns (the caller adds the chunks; at most PSN_PAIR_SUMS_MAX_CHUNKS).
  * Used for the separable weight gradient of a layer whose input block is [table(x_n) | table(l_v)]. */
@@ -389,6 +421,18 @@ int psn_row_adam(int n_items, const PsnRowAdamItem* items, const int64_t* idx, i
  * psn_camera_rays: stage2/utils/rend_util.py:90-147 for a 4 x 4 pose: out[i] = scale * normalize(R [(u - cx) / fx,
  *   (v - cy) / fy, 1]) for pixel idx[i] (idx NULL: pixel i) of uv [N, 2]; pose / intrinsics: 16 floats each, row-major, on
  *   the device.
+ * psn_stage1_rays: the ray set-up of a stage-1 batch (batch size 1) in one launch: cam[i] = world_mat[:3, 3]
+ *   (stage1/model/common.py:205-207), rays[i] = normalize(R [(px - cx) / fx, (py - cy) / fx, 1]) (common.py:210-226: BOTH
+ *   axes over fx = K[0][0], the reference's quirk; rendering.py:64-65), far[i] = the sphere exit depth max(sqrt(b^2 - (|cam|^2 -
+ *   radius2)) - b, 0), 0 for rays that miss the sphere (rendering.py:576-596).  camera_mat: k_ld x k_ld row-major (3 or 4),
+ *   world_mat 4 x 4, both on the device.
+ * psn_surface_points: rendering.py:516-522 + :84-108 -- d = flags & 1 ? d_pred : inf; d = flags & 2 ? d : 0 (d_i, optional
+ *   output); obj_mask = finite(d) & d != 0; dists = obj_mask ? d : (d == 0 ? 0 : 1); points = cam + rays * dists.
+ * psn_stage1_targets: the ground truth of the sampled pixels, stage1/model/common.py:172-202 (nearest-neighbour
+ *   grid_sample, align_corners, at x = 2 px / w - 1, y = 2 py / h - 1) applied to the image [3, h, w], the masks [h, w] (a NULL
+ *   mask / mask_valid image is all ones; outputs: mask_gt float 0/1, mask_valid_out / norm_mask_out bytes 0/1 = torch.bool
+ *   storage) and the normal map [3, h, w] (training.py:176-191: norm_mask cleared where the UNROTATED n_z < cos_thresh when
+ *   use_angle, then normal_gt = R diag(1, -1, -1) n with R = world_mat[:3, :3]).  Optional outputs may be NULL.
  * psn_adam_flat: torch.optim.Adam's update (torch/optim/adam.py::_multi_tensor_adam; amsgrad off, weight_decay 0;
  *   stage2/trainer.py:126-133) over ranges of one flat parameter / gradient / exp_avg / exp_avg_sq allocation:
  *   m += (1 - beta1)(g - m); v = v beta2 + (1 - beta2) g g; p += neg_step_size * m / (sqrt(v) / bias_correction2_sqrt + eps),
@@ -402,6 +446,14 @@ int psn_light_rows_bwd(const float* dir_table, const int64_t* idx, int n_idx, in
                        const float* g_int, float* d_dir_table, float* d_int_table, void* stream);
 int psn_camera_rays(const float* uv, const float* pose, const float* intrinsics, const int64_t* idx, int64_t n, float scale,
                     float* out, void* stream);
+int psn_stage1_rays(const float* pix, const float* camera_mat, int k_ld, const float* world_mat, float radius2, int64_t n,
+                    float* cam, float* rays, float* far, void* stream);
+int psn_surface_points(const float* d_pred, const int* flags, const float* cam, const float* rays, int64_t n, float* d_i,
+                       float* dists, unsigned char* obj_mask, float* points, void* stream);
+int psn_stage1_targets(const float* pix, int64_t n, int h, int w, const float* img, const float* mask, const float* mask_valid,
+                       const float* normal, const float* norm_mask, const float* world_mat, int use_angle, float cos_thresh,
+                       float* rgb_gt, float* mask_gt, unsigned char* mask_valid_out, float* normal_gt,
+                       unsigned char* norm_mask_out, void* stream);
 #define PSN_ADAM_MAX_SEGS 16
 typedef struct {
     int64_t offset, grad_offset, n;    /* elements [offset, offset + n) of param / exp_avg / exp_avg_sq, [grad_offset, ..+n) of grad */

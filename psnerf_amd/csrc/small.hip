@@ -213,3 +213,139 @@ extern "C" int psn_adam_flat(float* param, const float* grad, float* exp_avg, fl
     PSN_CHECK_LAUNCH("adam_flat");
     return PSN_OK;
 }
+
+// ---- stage-1 per-ray glue (round 3): the ~100 elementwise launches on [N] / [N, 3] tensors around the ray march ------------
+//   psn_stage1_rays      common.py:205-226 + rendering.py:576-596: camera origin, normalised ray directions, sphere exit depth
+//   psn_surface_points   rendering.py:516-522 + :84-108: d_i from (root-finder depth, crossing flags), masks, surface points
+//   psn_stage1_targets   common.py:172-202 x 5 + training.py:176-191: nearest-pixel ground truth of the sampled pixels
+// Arithmetic in the op order of the torch formulations they replace (products and sums rounded separately): same bits.
+namespace psn {
+
+__global__ __launch_bounds__(256) void stage1_rays_kernel(const float* __restrict__ pix, const float* __restrict__ K, int k_ld,
+                                                          const float* __restrict__ W, float radius2, int64_t n, float* __restrict__ cam, float* __restrict__ rays,
+                                                          float* __restrict__ far) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float fx = K[0], cx = K[2], cy = K[k_ld + 2];
+    const float qx = (pix[2 * i] - cx) / fx, qy = (pix[2 * i + 1] - cy) / fx;   // both axes over fx: the reference's quirk (common.py:220)
+    float d[3], c[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        d[r] = qx * W[4 * r] + qy * W[4 * r + 1] + W[4 * r + 2];
+        c[r] = W[4 * r + 3];
+    }
+    const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { d[r] = d[r] / nrm; rays[3 * i + r] = d[r]; cam[3 * i + r] = c[r]; }
+    // rendering.py:576-596: b = ray . cam, under = b^2 - (|cam|^2 - r^2), far = max(sqrt(under) - b, 0) where under > 0
+    const float b = d[0] * c[0] + d[1] * c[1] + d[2] * c[2];
+    const float cn = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const float under = b * b - (cn * cn - radius2);
+    float f = 0.0f;
+    if (under > 0.0f) {
+        f = sqrtf(under) - b;
+        f = f < 0.0f ? 0.0f : f;
+    }
+    far[i] = f;
+}
+
+__global__ __launch_bounds__(256) void surface_points_kernel(const float* __restrict__ d_pred, const int* __restrict__ flags,
+                                                             const float* __restrict__ cam, const float* __restrict__ rays, int64_t n,
+                                                             float* __restrict__ d_i, float* __restrict__ dists,
+                                                             unsigned char* __restrict__ obj_mask, float* __restrict__ points) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int fl = flags[i];
+    float d = (fl & 1) ? d_pred[i] : __builtin_inff();   // rendering.py:519-521
+    d = (fl & 2) ? d : 0.0f;                             // :522
+    const bool zero_occ = d == 0.0f;
+    const bool ok = !(fabsf(d) == __builtin_inff()) && !(d != d);
+    float dist = ok ? d : 1.0f;
+    dist = zero_occ ? 0.0f : dist;
+    if (d_i != nullptr) d_i[i] = d;
+    dists[i] = dist;
+    obj_mask[i] = (ok && !zero_occ) ? 1 : 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) points[3 * i + c] = cam[3 * i + c] + rays[3 * i + c] * dist;
+}
+
+// nearest-neighbour grid_sample(align_corners=True, zeros padding) at x = 2 px / w - 1, y = 2 py / h - 1 (common.py:190-195):
+// ATen: ix = ((x + 1) / 2) * (W - 1), nearbyint, in-bounds or 0
+__device__ __forceinline__ bool nearest_index(float px, float py, int h, int w, int& iy, int& ix) {
+    // tensor / python scalar on the GPU is a multiplication by the fp32 reciprocal (ATen div_true_kernel_cuda)
+    const float x = 2.0f * px * (1.0f / (float)w) - 1.0f, y = 2.0f * py * (1.0f / (float)h) - 1.0f;
+    const float fx = ((x + 1.0f) / 2.0f) * (float)(w - 1), fy = ((y + 1.0f) / 2.0f) * (float)(h - 1);
+    const float rx = rintf(fx), ry = rintf(fy);
+    ix = (int)rx; iy = (int)ry;
+    return rx >= 0.0f && rx <= (float)(w - 1) && ry >= 0.0f && ry <= (float)(h - 1);
+}
+struct TargetArgs {
+    const float* pix; const float* img; const float* mask; const float* mask_valid; const float* normal; const float* norm_mask;
+    const float* W;   // world_mat [4, 4] (rotation of the normal ground truth, training.py:191) or nullptr
+    float cos_thresh; int use_angle; int h, w; int64_t n;
+    float* rgb_gt; float* mask_gt; unsigned char* mask_valid_out; float* normal_gt; unsigned char* norm_mask_out;
+};
+__global__ __launch_bounds__(256) void stage1_targets_kernel(TargetArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    int iy, ix;
+    const bool in = nearest_index(a.pix[2 * i], a.pix[2 * i + 1], a.h, a.w, iy, ix);
+    const int64_t hw = (int64_t)a.h * a.w, o = in ? (int64_t)iy * a.w + ix : 0;
+    auto at = [&](const float* p, int c) -> float { return in ? p[c * hw + o] : 0.0f; };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.rgb_gt[3 * i + c] = at(a.img, c);
+    if (a.mask_gt != nullptr) a.mask_gt[i] = (a.mask != nullptr ? at(a.mask, 0) : 1.0f) != 0.0f ? 1.0f : 0.0f;
+    if (a.mask_valid_out != nullptr) a.mask_valid_out[i] = (a.mask_valid != nullptr ? at(a.mask_valid, 0) : 1.0f) != 0.0f ? 1 : 0;
+    bool nm = a.norm_mask != nullptr ? at(a.norm_mask, 0) != 0.0f : false;
+    if (a.normal_gt != nullptr) {
+        const float n0 = at(a.normal, 0), n1 = at(a.normal, 1), n2 = at(a.normal, 2);
+        if (a.use_angle && n2 < a.cos_thresh) nm = false;   // training.py:189-190: on the UNROTATED normal
+        // training.py:191: R diag(1, -1, -1) n, the products of the broadcast formulation summed left to right
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            a.normal_gt[3 * i + r] = n0 * (a.W[4 * r] * 1.0f) + n1 * (a.W[4 * r + 1] * -1.0f) + n2 * (a.W[4 * r + 2] * -1.0f);
+    }
+    if (a.norm_mask_out != nullptr) a.norm_mask_out[i] = nm ? 1 : 0;
+}
+
+}  // namespace psn
+
+extern "C" int psn_stage1_rays(const float* pix, const float* camera_mat, int k_ld, const float* world_mat, float radius2, int64_t n,
+                               float* cam, float* rays, float* far, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(pix && camera_mat && world_mat && cam && rays && far && n >= 0, "stage1_rays: null pointer");
+    PSN_CHECK_ARG(k_ld == 3 || k_ld == 4, "stage1_rays: camera_mat is 3 x 3 or 4 x 4, row-major");
+    if (n == 0) return PSN_OK;
+    hipLaunchKernelGGL(stage1_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pix, camera_mat, k_ld,
+                       world_mat, radius2, n, cam, rays, far);
+    PSN_CHECK_LAUNCH("stage1_rays");
+    return PSN_OK;
+}
+
+extern "C" int psn_surface_points(const float* d_pred, const int* flags, const float* cam, const float* rays, int64_t n, float* d_i,
+                                  float* dists, unsigned char* obj_mask, float* points, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(d_pred && flags && cam && rays && dists && obj_mask && points && n >= 0, "surface_points: null pointer");
+    if (n == 0) return PSN_OK;
+    hipLaunchKernelGGL(surface_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_pred, flags, cam, rays, n,
+                       d_i, dists, obj_mask, points);
+    PSN_CHECK_LAUNCH("surface_points");
+    return PSN_OK;
+}
+
+extern "C" int psn_stage1_targets(const float* pix, int64_t n, int h, int w, const float* img, const float* mask, const float* mask_valid,
+                                  const float* normal, const float* norm_mask, const float* world_mat, int use_angle, float cos_thresh,
+                                  float* rgb_gt, float* mask_gt, unsigned char* mask_valid_out, float* normal_gt,
+                                  unsigned char* norm_mask_out, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(pix && img && rgb_gt && n >= 0 && h >= 1 && w >= 1, "stage1_targets: null pointer / empty image");
+    PSN_CHECK_ARG(normal_gt == nullptr || (normal && world_mat), "stage1_targets: the normal ground truth needs the normal image and world_mat");
+    if (n == 0) return PSN_OK;
+    TargetArgs a = {};
+    a.pix = pix; a.img = img; a.mask = mask; a.mask_valid = mask_valid; a.normal = normal; a.norm_mask = norm_mask; a.W = world_mat;
+    a.cos_thresh = cos_thresh; a.use_angle = use_angle; a.h = h; a.w = w; a.n = n;
+    a.rgb_gt = rgb_gt; a.mask_gt = mask_gt; a.mask_valid_out = mask_valid_out; a.normal_gt = normal_gt; a.norm_mask_out = norm_mask_out;
+    hipLaunchKernelGGL(stage1_targets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("stage1_targets");
+    return PSN_OK;
+}

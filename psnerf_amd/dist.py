@@ -95,6 +95,12 @@ class DataParallel(object):
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         return c
 
+    def all_reduce_sum_(self, t):
+        """Sum a small device tensor over ranks in place (the mask counts of a step in ONE collective); returns it."""
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
     def global_sum_int(self, value):
         t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
         if self.enabled:

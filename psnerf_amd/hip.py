@@ -130,6 +130,15 @@ SIGNATURES = {
     'psn_light_rows_fwd': (i32, [c_f, c_f, c_f, i32, f32, c_f, c_f, c_f]),
     'psn_light_rows_bwd': (i32, [c_f, c_f, i32, i64, f32, c_f, c_f, c_f, c_f, c_f]),
     'psn_camera_rays': (i32, [c_f, c_f, c_f, c_f, i64, f32, c_f, c_f]),
+    'psn_stage1_loss_partial_floats': (i32, []),
+    'psn_stage1_loss_fwd': (i32, [c_f] * 10 + [i64, i64, ctypes.c_void_p, c_f, c_f, c_f, c_f]),
+    'psn_stage1_loss_terms': (i32, [c_f, i64, ctypes.c_void_p, i32, i32, i32, c_f, c_f]),
+    'psn_stage1_loss_bwd': (i32, [c_f] * 11 + [i64, i64, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_f]),
+    'psn_surface_normals_fwd': (i32, [c_f, c_f, i64, f32, c_f, c_f, c_f]),
+    'psn_surface_normals_bwd': (i32, [c_f, c_f, i64, f32, c_f, c_f, c_f, c_f]),
+    'psn_stage1_rays': (i32, [c_f, c_f, i32, c_f, f32, i64, c_f, c_f, c_f, c_f]),
+    'psn_surface_points': (i32, [c_f, c_f, c_f, c_f, i64, c_f, c_f, c_f, c_f, c_f]),
+    'psn_stage1_targets': (i32, [c_f, i64, i32, i32, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, c_f, c_f, c_f]),
     'psn_adam_flat': (i32, [c_f, c_f, c_f, c_f, i32, ctypes.c_void_p, f32, f32, f32, f32, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
@@ -498,6 +507,122 @@ def camera_rays(uv, pose, intrinsics, idx=None, scale=1.0):
     _check(_lib.psn_camera_rays(_ptr(uv, 'uv'), _ptr(pose, 'pose'), _ptr(intrinsics, 'intrinsics'), _iptr(idx, 'idx', True), n, float(scale),
                                 out.data_ptr(), _stream()), 'camera_rays')
     return out
+
+
+def _w4(weights):
+    return ctypes.cast((ctypes.c_float * 4)(*[float(x) for x in weights]), ctypes.c_void_p)
+
+
+def stage1_loss_fwd(rgb, rgb_gt, diff, hit, normal, normal_gt, norm_mask, acc, mask_gt, mask_valid, n_rays, weights, finish=True):
+    """(sums [8], terms [5] or None) of psn_stage1_loss_fwd; ``finish=False`` stops after the sums (data parallelism: the
+    caller all-reduces sums[4:7] and calls stage1_loss_terms)."""
+    N = rgb.shape[0]
+    dev = rgb.device
+    sums = torch.empty(8, device=dev, dtype=torch.float32)
+    terms = torch.empty(5, device=dev, dtype=torch.float32) if finish else None
+    partial = workspace(_lib.psn_stage1_loss_partial_floats(), dev)
+    _check(_lib.psn_stage1_loss_fwd(_ptr(rgb, 'rgb'), _ptr(rgb_gt, 'rgb_gt'), _fp(diff), _bp(hit) if hit is not None else None, _fp(normal),
+                                    _fp(normal_gt), _bp(norm_mask) if norm_mask is not None else None, _fp(acc), _fp(mask_gt),
+                                    _bp(mask_valid) if mask_valid is not None else None, N, int(n_rays), _w4(weights), partial.data_ptr(),
+                                    sums.data_ptr(), None if terms is None else terms.data_ptr(), _stream()), 'stage1_loss_fwd')
+    return sums, terms
+
+
+def stage1_loss_terms(sums, n_rays, weights, has_grad, has_norm, has_mask):
+    terms = torch.empty(5, device=sums.device, dtype=torch.float32)
+    _check(_lib.psn_stage1_loss_terms(_ptr(sums, 'sums'), int(n_rays), _w4(weights), int(has_grad), int(has_norm), int(has_mask),
+                                      terms.data_ptr(), _stream()), 'stage1_loss_terms')
+    return terms
+
+
+def stage1_loss_bwd(g_loss, sums, rgb, rgb_gt, hit, normal, normal_gt, norm_mask, acc, mask_gt, mask_valid, n_rays, weights, need):
+    """Gradients named in ``need`` (subset of 'rgb', 'diff', 'normal', 'acc') -> dict."""
+    N = rgb.shape[0]
+    dev = rgb.device
+    d = {}
+    if 'rgb' in need: d['rgb'] = torch.empty_like(rgb)
+    if 'diff' in need: d['diff'] = torch.empty(N, device=dev, dtype=torch.float32)
+    if 'normal' in need: d['normal'] = torch.empty_like(normal)
+    if 'acc' in need: d['acc'] = torch.empty_like(acc)
+    g = lambda k: None if k not in d else d[k].data_ptr()
+    b = lambda t: None if t is None else _bp(t)
+    _check(_lib.psn_stage1_loss_bwd(_ptr(g_loss, 'g_loss'), _ptr(sums, 'sums'), _ptr(rgb, 'rgb'), _ptr(rgb_gt, 'rgb_gt'), b(hit), _fp(normal),
+                                    _fp(normal_gt), b(norm_mask), _fp(acc), _fp(mask_gt), b(mask_valid), N, int(n_rays), _w4(weights),
+                                    g('rgb'), g('diff'), g('normal'), g('acc'), _stream()), 'stage1_loss_bwd')
+    return d
+
+
+def surface_normals_fwd(g, hit, eps=1e-5):
+    """(norm_pred [N, 3], diff [N]) from g [2 N, 3] and the hit flags [N] bool (psn_surface_normals_fwd)."""
+    N = hit.shape[0]
+    assert g.shape == (2 * N, 3)
+    norm_pred = torch.empty(N, 3, device=g.device, dtype=torch.float32)
+    diff = torch.empty(N, device=g.device, dtype=torch.float32)
+    _check(_lib.psn_surface_normals_fwd(_ptr(g, 'g'), _bp(hit), N, float(eps), norm_pred.data_ptr(), diff.data_ptr(), _stream()),
+           'surface_normals_fwd')
+    return norm_pred, diff
+
+
+def surface_normals_bwd(g, hit, d_norm_pred, d_diff, eps=1e-5):
+    N = hit.shape[0]
+    dg = torch.empty_like(g)
+    _check(_lib.psn_surface_normals_bwd(_ptr(g, 'g'), _bp(hit), N, float(eps), _ptr(d_norm_pred, 'd_norm_pred', True),
+                                        _ptr(d_diff, 'd_diff', True), dg.data_ptr(), _stream()), 'surface_normals_bwd')
+    return dg
+
+
+def stage1_rays(pix, camera_mat, world_mat, radius):
+    """Camera origins [n, 3], normalised ray directions [n, 3] and sphere exit depths [n] of the pixels pix [n, 2]
+    (stage1/model/common.py:205-226, rendering.py:576-596), one launch; camera_mat [3|4, 3|4], world_mat [4, 4] on the device."""
+    assert pix.dim() == 2 and pix.shape[1] == 2 and world_mat.shape == (4, 4) and camera_mat.shape in ((3, 3), (4, 4))
+    assert world_mat.is_contiguous() and camera_mat.is_contiguous()
+    n = pix.shape[0]
+    cam, rays = (torch.empty(n, 3, device=pix.device, dtype=torch.float32) for _ in range(2))
+    far = torch.empty(n, device=pix.device, dtype=torch.float32)
+    _check(_lib.psn_stage1_rays(_ptr(pix, 'pix'), _ptr(camera_mat, 'camera_mat'), camera_mat.shape[0], _ptr(world_mat, 'world_mat'),
+                                float(radius ** 2), n, cam.data_ptr(), rays.data_ptr(), far.data_ptr(), _stream()), 'stage1_rays')
+    return cam, rays, far
+
+
+def surface_points(d_pred, flags, cam, rays, want_d=False):
+    """(dists [n], obj_mask [n] bool, points [n, 3][, d_i [n]]) from the root finder's depths and the crossing flags
+    (stage1/model/rendering.py:516-522, 84-108), one launch."""
+    n = d_pred.shape[0]
+    assert flags.dtype == torch.int32 and flags.shape == (n,) and flags.is_contiguous() and cam.shape == (n, 3) and rays.shape == (n, 3)
+    dev = d_pred.device
+    dists = torch.empty(n, device=dev, dtype=torch.float32)
+    obj = torch.empty(n, device=dev, dtype=torch.bool)
+    pts = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    d_i = torch.empty(n, device=dev, dtype=torch.float32) if want_d else None
+    _check(_lib.psn_surface_points(_ptr(d_pred, 'd_pred'), flags.data_ptr(), _ptr(cam, 'cam'), _ptr(rays, 'rays'), n,
+                                   None if d_i is None else d_i.data_ptr(), dists.data_ptr(), obj.data_ptr(), pts.data_ptr(),
+                                   _stream()), 'surface_points')
+    return (dists, obj, pts, d_i) if want_d else (dists, obj, pts)
+
+
+def stage1_targets(pix, img, mask=None, mask_valid=None, normal=None, norm_mask=None, world_mat=None, cos_thresh=None,
+                   want_normal=False):
+    """Ground truth of the sampled pixels pix [n, 2] (stage1/model/common.py:172-202, training.py:166-191), one launch:
+    (rgb_gt [n, 3], mask_gt [n] float, mask_valid [n] bool, norm_mask_gt [n] bool or None, normal_gt [n, 3] or None)."""
+    n = pix.shape[0]
+    assert pix.dim() == 2 and pix.shape[1] == 2 and img.dim() == 3 and img.shape[0] == 3
+    h, w = int(img.shape[1]), int(img.shape[2])
+    for t in (mask, mask_valid, norm_mask):
+        assert t is None or tuple(t.shape) == (h, w)
+    assert normal is None or tuple(normal.shape) == (3, h, w)
+    dev = pix.device
+    rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    mask_gt = torch.empty(n, device=dev, dtype=torch.float32)
+    valid = torch.empty(n, device=dev, dtype=torch.bool)
+    nmask = torch.empty(n, device=dev, dtype=torch.bool) if norm_mask is not None else None
+    ngt = torch.empty(n, 3, device=dev, dtype=torch.float32) if want_normal else None
+    _check(_lib.psn_stage1_targets(_ptr(pix, 'pix'), n, h, w, _ptr(img, 'img'), _ptr(mask, 'mask', True), _ptr(mask_valid, 'mask_valid', True),
+                                   _ptr(normal, 'normal', True) if want_normal else None, _ptr(norm_mask, 'norm_mask', True),
+                                   _ptr(world_mat, 'world_mat', True) if want_normal else None, int(cos_thresh is not None),
+                                   float(cos_thresh if cos_thresh is not None else 0.0), rgb.data_ptr(), mask_gt.data_ptr(), valid.data_ptr(),
+                                   None if ngt is None else ngt.data_ptr(), None if nmask is None else nmask.data_ptr(), _stream()),
+           'stage1_targets')
+    return rgb, mask_gt, valid, nmask, ngt
 
 
 def adam_flat(param, grad, exp_avg, exp_avg_sq, segs, beta1, beta2, eps):

@@ -976,6 +976,67 @@ class Stage2Losses(torch.autograd.Function):
                 None, None, None, None, None, None)
 
 
+class SurfaceNormals(torch.autograd.Function):
+    """stage1/model/rendering.py:200-212 in one launch each way (csrc/loss1.hip): apply(g [2 N, 3], hit [N] bool) ->
+    (normal_pred [N, 3], diff_norm [N])."""
+
+    @staticmethod
+    def forward(ctx, g, hit):
+        gc, hc = g.detach().contiguous(), hit.contiguous()
+        ctx.save_for_backward(gc, hc)
+        return hip.surface_normals_fwd(gc, hc)
+
+    @staticmethod
+    def backward(ctx, d_norm_pred, d_diff):
+        g, hit = ctx.saved_tensors
+        c = lambda t: None if t is None else t.contiguous()
+        return hip.surface_normals_bwd(g, hit, c(d_norm_pred), c(d_diff)), None
+
+
+class Stage1Losses(torch.autograd.Function):
+    """stage1/model/losses.py:24-70 over the outputs of the sync-free training forward (csrc/loss1.hip): two launches
+    forward, one backward.  apply(rgb [N, 3], rgb_gt, diff [N] | None, hit [N] bool | None, normal [N, 3] | None, normal_gt,
+    norm_mask [N] bool, acc [N] | None, mask_gt [N], mask_valid [N] bool, n_rays, weights (full, grad, norm, mask),
+    reduce_counts) -> (loss (0-dim), terms [5] = colour / smoothness / normal / mask term and the total; no gradient).
+    ``reduce_counts``: None, or callable(tensor [3]) summing the hit / norm_mask / mask_valid counts over ranks in place."""
+
+    @staticmethod
+    def forward(ctx, rgb, rgb_gt, diff, hit, normal, normal_gt, norm_mask, acc, mask_gt, mask_valid, n_rays, weights, reduce_counts=None):
+        c = lambda t: None if t is None else t.detach().contiguous()
+        rgb, rgb_gt, diff, normal, normal_gt, acc, mask_gt = (c(t) for t in (rgb, rgb_gt, diff, normal, normal_gt, acc, mask_gt))
+        hit, norm_mask, mask_valid = (c(t) for t in (hit, norm_mask, mask_valid))
+        sums, terms = hip.stage1_loss_fwd(rgb, rgb_gt, diff, hit, normal, normal_gt, norm_mask, acc, mask_gt, mask_valid, n_rays, weights,
+                                          finish=reduce_counts is None)
+        if reduce_counts is not None:
+            reduce_counts(sums[4:7])
+            terms = hip.stage1_loss_terms(sums, n_rays, weights, diff is not None and weights[1] != 0.0, normal is not None, acc is not None)
+        slots = [rgb, rgb_gt, hit, normal, normal_gt, norm_mask, acc, mask_gt, mask_valid, sums]
+        ctx.present = [t is not None for t in slots]
+        ctx.save_for_backward(*[t for t in slots if t is not None])
+        ctx.n_rays, ctx.weights, ctx.has_diff = n_rays, tuple(float(w) for w in weights), diff is not None
+        ctx.need = ctx.needs_input_grad
+        loss = terms[4]
+        ctx.mark_non_differentiable(terms)
+        return loss, terms
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        saved = iter(ctx.saved_tensors)
+        rgb, rgb_gt, hit, normal, normal_gt, norm_mask, acc, mask_gt, mask_valid, sums = (next(saved) if here else None for here in ctx.present)
+        w, ng = ctx.weights, ctx.need
+        need = set()
+        if ng[0] and w[0] != 0.0: need.add('rgb')
+        if ctx.has_diff and ng[2] and w[1] != 0.0: need.add('diff')
+        if normal is not None and ng[4] and w[2] != 0.0: need.add('normal')
+        if acc is not None and ng[7] and w[3] != 0.0: need.add('acc')
+        d = {}
+        if need:
+            d = hip.stage1_loss_bwd(g_loss.reshape(1).contiguous(), sums, rgb, rgb_gt, hit, normal, normal_gt, norm_mask, acc, mask_gt,
+                                    mask_valid, ctx.n_rays, w, need)
+        g = d.get
+        return g('rgb'), None, g('diff'), None, g('normal'), None, None, g('acc'), None, None, None, None, None
+
+
 # --------------------------------------------------------------------------- launch-bound row ops, fused (csrc/small.hip)
 class NormalizeRows(torch.autograd.Function):
     """F.normalize(x, p=2, dim=-1) for [n, 3] rows: one launch forward (norm, clamp_min, div), one backward (autograd's

@@ -15,6 +15,8 @@ class Loss(nn.Module):
         self.device = device
         self.global_sum = None  # callable(int) -> int summed over ranks (set by the DP trainer)
         self.global_count = None  # callable(bool mask) -> device float [1], summed over ranks (sync-free path)
+        self.global_counts = None  # callable(device float tensor [k]) summing it over ranks IN PLACE (one collective for all masks)
+        self.fused = True          # sync-free outputs on the GPU: csrc/loss1.hip (False: the torch formulation below)
         self.global_rays = None   # callable() -> ray count of the batch BEFORE sharding (set by the DP trainer; arithmetic,
                                   # identical on every rank: no collective, so ranks cannot diverge on it -- ADVICE r2)
 
@@ -27,6 +29,28 @@ class Loss(nn.Module):
             return self.global_count(mask)
         return mask.sum().to(torch.float32).reshape(1)
 
+    def _forward_fused(self, out_dict, rgb_gt, normal_gt, norm_mask, mask, mask_gt, mask_valid):
+        """The sync-free branch of forward() as ops.Stage1Losses (two launches, one backward; same terms, same counts)."""
+        from .. import ops
+        rgb, normal = out_dict['rgb'], out_dict.get('normal_pred')
+        n_rays = rgb.shape[1] if self.global_rays is None else self.global_rays()
+        with_norm = normal is not None and normal_gt is not None
+        with_mask = mask is not None and mask_gt is not None
+        flat3 = lambda t: t.reshape(-1, 3)
+        loss, terms = ops.Stage1Losses.apply(
+            flat3(rgb), flat3(rgb_gt), out_dict['diff_norm_full'].reshape(-1), out_dict['mask_pred'].reshape(-1),
+            flat3(normal) if with_norm else None, flat3(normal_gt) if with_norm else None,
+            norm_mask.reshape(-1).bool() if with_norm else None, mask.reshape(-1) if with_mask else None,
+            mask_gt.reshape(-1) if with_mask else None, mask_valid.reshape(-1).bool() if with_mask else None, int(n_rays),
+            (self.full_weight, self.grad_weight, self.norm_weight, self.mask_weight), self.global_counts)
+        out = {'fullrgb_loss': terms[0], 'grad_loss': terms[1]}
+        if with_norm:
+            out['normal_loss'] = terms[2]
+        if with_mask:
+            out['mask_loss'] = terms[3]
+        out['loss'] = loss
+        return out
+
     def forward(self, out_dict, rgb_gt, normal_gt=None, norm_mask=None, mask=None, mask_gt=None, mask_valid=None,
                 norm_count=None, valid_count=None):
         """``norm_count`` / ``valid_count``: local counts of ``norm_mask`` / ``mask_valid`` when the caller already has
@@ -34,6 +58,9 @@ class Loss(nn.Module):
         sits between forward and backward)."""
         rgb, diff_norm, normal = out_dict['rgb'], out_dict['diff_norm'], out_dict.get('normal_pred')
         dev = rgb.device
+        if (self.fused and rgb.is_cuda and out_dict.get('diff_norm_full') is not None and rgb.shape[0] == 1 and norm_count is None
+                and valid_count is None and (self.global_count is None or self.global_counts is not None)):
+            return self._forward_fused(out_dict, rgb_gt.to(dev), normal_gt, norm_mask, mask, mask_gt, mask_valid)
         zero = torch.zeros((), device=dev)  # a fill kernel: torch.tensor(0.0, device=...) is a pageable H2D copy = a stream sync
         rgb_gt = rgb_gt.to(dev)
         if self.full_weight != 0.0:

@@ -127,13 +127,15 @@ class Renderer(nn.Module):
         return self._march_finish_compact(state, n_secant_steps) if self.COMPACT_SECANT else self._march_finish(state, n_secant_steps)
 
     @torch.no_grad()
-    def _march_launch(self, ray0, ray_direction, tau, n_steps, depth_range, rad, clip):
+    def _march_launch(self, ray0, ray_direction, tau, n_steps, depth_range, rad, clip, far=None):
         """First half of ray_marching (rendering.py:410-480): everything up to the first-crossing mask -- all of it
-        asynchronous device work (the 256-step occupancy sweep is one fused launch), no host synchronisation."""
+        asynchronous device work (the 256-step occupancy sweep is one fused launch), no host synchronisation.  ``far``:
+        the sphere exit depths when the caller has them already (psn_stage1_rays)."""
         B, N, _ = ray0.shape
         dev = ray0.device
         n_steps = int(n_steps[0])  # the reference draws randint(n, n+1): a constant
-        far = sphere_intersection(ray0[:, 0], ray_direction, r=rad)[0][..., 1].contiguous()
+        if far is None:
+            far = sphere_intersection(ray0[:, 0], ray_direction, r=rad)[0][..., 1].contiguous()
         u = self._u(n_steps, dev)
         m = self.model
         if (self.FUSED_SWEEP and not clip and n_steps % 64 == 0 and ray0.is_cuda and hasattr(m, '_occupancy_packed')
@@ -172,11 +174,16 @@ class Renderer(nn.Module):
         B, N, _ = ray0.shape
         mask = (st['flags'] & 1).bool()
         first_free = (st['flags'] & 2).bool()
-        d_pred = self._root_find(st['bracket'], ray0.reshape(-1, 3).contiguous(), ray_direction.reshape(-1, 3).contiguous(),
-                                 st['tau'], n_secant_steps)
+        d_pred = self._march_root(st, n_secant_steps)
         out = torch.where(mask, d_pred, torch.full_like(d_pred, float('inf')))
         out = torch.where(first_free, out, torch.zeros_like(out))
         return out.view(B, N)
+
+    @torch.no_grad()
+    def _march_root(self, st, n_secant_steps):
+        """Refined depth of every ray's bracket (meaningful where flags & 1)."""
+        return self._root_find(st['bracket'], st['ray0'].reshape(-1, 3).contiguous(), st['ray_direction'].reshape(-1, 3).contiguous(),
+                               st['tau'], n_secant_steps)
 
     @torch.no_grad()
     def _march_finish_compact(self, st, n_secant_steps):
@@ -231,13 +238,22 @@ class Renderer(nn.Module):
             d_pred = -f_low * (d_high - d_low) / (f_high - f_low) + d_low
         return d_pred
 
+    FUSED_GLUE = True  # False: the torch formulation of the per-ray set-up / surface points (tests compare the two)
+
     def _surface_launch(self, pixels, camera_mat, world_mat, ray_steps):
         B, N, _ = pixels.shape
-        cam = camera_origin(N, world_mat)
-        rays = pixel_rays(pixels, camera_mat, world_mat)
-        rays = rays / rays.norm(2, 2).unsqueeze(-1)
+        far = None
+        if (self.FUSED_GLUE and pixels.is_cuda and B == 1 and tuple(world_mat.shape[1:]) == (4, 4) and pixels.dtype == torch.float32
+                and pixels.is_contiguous()):
+            # origins, normalised directions and sphere exit depths in one launch (psn_stage1_rays) instead of ~25
+            cam, rays, far = hip.stage1_rays(pixels[0], camera_mat[0].contiguous(), world_mat[0].contiguous(), self.cfg['radius'])
+            cam, rays, far = cam.unsqueeze(0), rays.unsqueeze(0), far.unsqueeze(0)
+        else:
+            cam = camera_origin(N, world_mat)
+            rays = pixel_rays(pixels, camera_mat, world_mat)
+            rays = rays / rays.norm(2, 2).unsqueeze(-1)
         state = self._march_launch(cam, rays, 0.5, [int(ray_steps), int(ray_steps) + 1], self.depth_range,
-                                   self.cfg['radius'], False)
+                                   self.cfg['radius'], False, far=far)
         return cam, rays, state
 
     @torch.no_grad()
@@ -258,6 +274,13 @@ class Renderer(nn.Module):
             cam, rays, state = pref[2]  # requested earlier by prefetch_surface: the sweep is already running
         else:
             cam, rays, state = self._surface_launch(pixels, camera_mat, world_mat, ray_steps)
+        self._last_far = state['far'].reshape(-1)  # sphere exit depth per ray (rendering.py:576-596), reused by unisurf
+        if self.FUSED_GLUE and pixels.is_cuda and B == 1 and not self.COMPACT_SECANT:
+            # d_i, its masks and the surface points in one launch (psn_surface_points) instead of ~18
+            cam, rays = cam.reshape(-1, 3), rays.reshape(-1, 3)
+            with torch.no_grad():
+                dists, obj_mask, points = hip.surface_points(self._march_root(state, 8), state['flags'], cam, rays)
+            return cam, rays, dists, obj_mask, points
         d_i = self._finish(state, 8)
         zero_occ = d_i == 0
         ok = finite_mask(d_i)
@@ -268,7 +291,6 @@ class Renderer(nn.Module):
         cam = cam.reshape(-1, 3)
         rays = rays.reshape(-1, 3)
         points = (cam + rays * dists.unsqueeze(-1)).view(-1, 3)
-        self._last_far = state['far'].reshape(-1)  # sphere exit depth per ray (rendering.py:576-596), reused by unisurf
         return cam, rays, dists, obj_mask, points
 
     # ---- stage1/model/rendering.py:50-226 --------------------------------------------------------
@@ -411,9 +433,12 @@ class Renderer(nn.Module):
             g = self.model.gradient(pp)[:, 0, :]
         rgb_values, acc = ops.alpha_composite(alpha.reshape(N, full_steps), rgb.reshape(N, full_steps, 3),
                                               bool(self.white_background))
-        nrm = g / (g.norm(2, dim=1).unsqueeze(-1) + 10 ** (-5))
-        norm_pred = torch.where(flags.unsqueeze(-1), nrm[:N], torch.zeros_like(nrm[:N]))
-        diff_full = torch.norm(nrm[:N] - nrm[N:], dim=-1)
+        if self.FUSED_GLUE and g.is_cuda:
+            norm_pred, diff_full = ops.SurfaceNormals.apply(g, flags)  # one launch each way instead of ~10 / ~25
+        else:
+            nrm = g / (g.norm(2, dim=1).unsqueeze(-1) + 10 ** (-5))
+            norm_pred = torch.where(flags.unsqueeze(-1), nrm[:N], torch.zeros_like(nrm[:N]))
+            diff_full = torch.norm(nrm[:N] - nrm[N:], dim=-1)
         return {'rgb': rgb_values.reshape(1, -1, 3), 'mask_pred': obj_mask, 'diff_norm': None, 'diff_norm_full': diff_full,
                 'normal_pred': norm_pred.reshape(1, -1, 3), 'acc_map': acc.reshape(1, -1)}
 

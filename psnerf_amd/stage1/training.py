@@ -4,7 +4,9 @@ sampled pixels of the same view and the gradients are summed with one flat-bucke
 import numpy as np
 import torch
 
+from .. import hip
 from ..dist import DataParallel
+from ..optim import FlatAdam
 from .losses import Loss
 from .rendering import is_per_ray_noise
 
@@ -37,6 +39,7 @@ class Trainer(object):
             self.loss.global_sum = self.dp.global_sum_int
             self.loss.global_count = self.dp.global_count_tensor
             self.loss.global_rays = lambda: self.dp.global_rays
+            self.loss.global_counts = self.dp.all_reduce_sum_
         # training forward without host synchronisation (Renderer._unisurf_sync_free); a caller that injects noise or
         # needs the reference-shaped out_dict (compact diff_norm) gets the reference-shaped path
         self.sync_free = bool(kwargs.get('sync_free', True))
@@ -47,6 +50,8 @@ class Trainer(object):
             trainable = [p for p in self.model.parameters() if p.requires_grad]
             # one memset; every trainable .grad becomes a view into the flat all-reduce bucket, frozen parameters lose theirs
             self.dp.prepare_grads(list(self.model.parameters()))
+        elif isinstance(self.optimizer, FlatAdam):
+            self.optimizer.attach_grads()  # one memset; every .grad a view of one flat buffer laid out like the parameters
         else:
             self.optimizer.zero_grad()
         terms = self.compute_loss(data, it=it, pix=pix, noise=noise)
@@ -85,6 +90,27 @@ class Trainer(object):
         bufs[slot] = (buf, ev)
         return out
 
+    FUSED_TARGETS = True  # False: the torch formulation of the ground-truth lookups (tests compare the two)
+
+    def _targets_torch(self, img, mask_img, mask_valid, normal, norm_mask, world_mat, pix, want_normal):
+        """training.py:166-191 as torch ops (any device, any batch size)."""
+        B, dev = img.shape[0], img.device
+        mask_gt = gather_pixels(mask_img, pix).bool().reshape(B, -1).to(torch.float32)
+        mask_valid = gather_pixels(mask_valid * 1.0, pix).bool().reshape(B, -1)
+        norm_mask_gt = gather_pixels(norm_mask, pix).bool().squeeze(-1) if self.normal_loss else None
+        rgb_gt = gather_pixels(img, pix)
+        normal_gt = None
+        if want_normal:
+            normal_gt = gather_pixels(normal, pix)
+            if self.angle is not None:
+                norm_mask_gt[normal_gt[..., -1] < np.cos(np.deg2rad(self.angle))] = False
+            flip = torch.ones(1, 1, 3, device=dev)
+            flip[..., 1:] = -1.0  # (1, -1, -1) without a host-to-device copy
+            Rf = world_mat[:, :3, :3] * flip  # rotation as broadcast products (no library GEMM on the path)
+            normal_gt = (normal_gt[..., 0:1] * Rf[:, None, :, 0] + normal_gt[..., 1:2] * Rf[:, None, :, 1]
+                         + normal_gt[..., 2:3] * Rf[:, None, :, 2])
+        return rgb_gt, mask_gt, mask_valid, norm_mask_gt, normal_gt
+
     def compute_loss(self, data, eval_mode=False, it=None, pix=None, noise=None):
         """training.py:141-198.  ``eval_mode`` renders with ``eval_=True`` (no neighbour points, ``diff_norm`` None, hence
         no smoothness term) on ``n_eval_points`` pixels.  ``pix`` / ``noise`` inject the random draws (tests)."""
@@ -105,12 +131,10 @@ class Trainer(object):
         def on_dev(key):  # a missing mask is all ones, built ON the device (a host default would be 1.25 MB uploaded per step)
             t = data.get(key)
             return torch.ones(B, h, w, device=dev) if t is None else t.to(dev)
-        mask_img = on_dev('img.mask').unsqueeze(1)
         world_mat, camera_mat, scale_mat = (data['img.world_mat'].to(dev), data['img.camera_mat'].to(dev),
                                             data['img.scale_mat'].to(dev))
         normal = data.get('img.normal').to(dev) if self.normal_loss else None
         norm_mask = data.get('img.norm_mask').unsqueeze(1).to(dev) if self.normal_loss else None
-        mask_valid = on_dev('img.mask_valid').unsqueeze(1)
         if pix is None:  # stage1/model/common.py:32-36: x then y, CPU randint
             n = int(n_points)
             px = torch.randint(0, w, size=(B, n, 1)).float()
@@ -122,23 +146,24 @@ class Trainer(object):
             pix = self.dp.shard_rays(pix)
         if self.rendering_technique == 'unisurf' and hasattr(self.model, 'prefetch_surface'):
             self.model.prefetch_surface(pix, camera_mat, world_mat)  # the ray-march sweep runs under the host work below
-        mask_gt = gather_pixels(mask_img, pix).bool().reshape(B, -1).to(torch.float32)
-        mask_valid = gather_pixels(mask_valid * 1.0, pix).bool().reshape(B, -1)
-        norm_mask_gt = gather_pixels(norm_mask, pix).bool().squeeze(-1) if self.normal_loss else None
-        # everything that depends on the data only -- ground-truth gathers, masks and their COUNTS (host
-        # synchronisations) -- comes before the network call; afterwards the host runs ahead of the GPU through the
-        # forward chains, the loss and the backward pass
-        rgb_gt = gather_pixels(img, pix)
-        normal_gt = None
-        if self.normal_loss and it >= self.normal_after:
-            normal_gt = gather_pixels(normal, pix)
-            if self.angle is not None:
-                norm_mask_gt[normal_gt[..., -1] < np.cos(np.deg2rad(self.angle))] = False
-            flip = torch.ones(1, 1, 3, device=dev)
-            flip[..., 1:] = -1.0  # (1, -1, -1) without a host-to-device copy
-            Rf = world_mat[:, :3, :3] * flip  # rotation as broadcast products (no library GEMM on the path)
-            normal_gt = (normal_gt[..., 0:1] * Rf[:, None, :, 0] + normal_gt[..., 1:2] * Rf[:, None, :, 1]
-                         + normal_gt[..., 2:3] * Rf[:, None, :, 2])
+        want_normal = bool(self.normal_loss and it >= self.normal_after)
+        if self.FUSED_TARGETS and pix.is_cuda and B == 1 and pix.dtype == torch.float32 and pix.is_contiguous():
+            # every ground-truth lookup of the batch in one launch (psn_stage1_targets) instead of ~55
+            def plane(key):
+                t = data.get(key)
+                return None if t is None else t.to(dev).reshape(h, w).float().contiguous()
+            cos_t = float(np.cos(np.deg2rad(self.angle))) if (want_normal and self.angle is not None) else None
+            rgb_gt, mask_gt, mask_valid, norm_mask_gt, normal_gt = hip.stage1_targets(
+                pix[0], img[0].contiguous(), plane('img.mask'), plane('img.mask_valid'),
+                normal[0].contiguous() if want_normal else None, norm_mask.reshape(h, w).float().contiguous() if self.normal_loss else None,
+                world_mat[0].contiguous() if want_normal else None, cos_t, want_normal)
+            rgb_gt, mask_gt, mask_valid = rgb_gt.unsqueeze(0), mask_gt.unsqueeze(0), mask_valid.unsqueeze(0)
+            norm_mask_gt = norm_mask_gt.unsqueeze(0) if norm_mask_gt is not None else None
+            normal_gt = normal_gt.unsqueeze(0) if normal_gt is not None else None
+        else:
+            rgb_gt, mask_gt, mask_valid, norm_mask_gt, normal_gt = self._targets_torch(
+                img, on_dev('img.mask').unsqueeze(1), on_dev('img.mask_valid').unsqueeze(1), normal, norm_mask, world_mat, pix,
+                want_normal)
         sync_free = (self.sync_free and is_per_ray_noise(noise) and not eval_mode and self.rendering_technique == 'unisurf'
                      and hasattr(self.model, '_unisurf_sync_free') and pix.is_cuda)
         if hasattr(self.model, 'sync_free'):

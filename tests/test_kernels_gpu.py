@@ -808,3 +808,198 @@ def test_flat_adam_follows_torch_adam(cuda):
     od.step()
     for p1, p2 in zip(oc.param_groups[0]['params'], od.param_groups[0]['params']):
         assert_close(p1.detach().cpu(), p2.detach().cpu(), 1e-6, 'after state-dict exchange', atol=1e-7)
+
+
+@pytest.mark.parametrize('h,w', [(512, 612), (23, 37), (64, 64)])
+def test_stage1_targets_equal_torch_formulation(cuda, h, w):
+    """psn_stage1_targets against the torch formulation of training.py:166-191 (five nearest grid_samples, the angle mask on
+    the unrotated normal, the rotation): pure gathers and exact products -> identical bits, every pixel of the image
+    (incl. the x = w/2 tie of even widths) plus out-of-range positions."""
+    from psnerf_amd import hip
+    from psnerf_amd.stage1.training import Trainer
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    img = torch.rand(1, 3, h, w, generator=g).to(cuda)
+    mask = (torch.rand(1, 1, h, w, generator=g) > 0.4).float().to(cuda)
+    valid = (torch.rand(1, 1, h, w, generator=g) > 0.1).float().to(cuda)
+    nmask = (torch.rand(1, 1, h, w, generator=g) > 0.3).float().to(cuda)
+    normal = torch.nn.functional.normalize(torch.randn(1, 3, h, w, generator=g), dim=1).to(cuda)
+    world = torch.eye(4).unsqueeze(0)
+    world[0, :3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    world = world.to(cuda)
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    pix = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1).float()
+    extra = torch.tensor([[-1.0, 0.0], [w * 1.0, 3.0], [2.0, h * 1.0], [w + 5.0, -3.0], [0.4, 0.6], [w - 1.4, h - 1.5]])
+    pix = torch.cat([pix, extra]).unsqueeze(0).to(cuda).contiguous()
+    for angle, want_normal in ((None, True), (70.0, True), (70.0, False)):
+        t = Trainer.__new__(Trainer)
+        t.normal_loss, t.angle = True, angle
+        ref = t._targets_torch(img, mask, valid, normal, nmask, world, pix, want_normal)
+        cos_t = float(np.cos(np.deg2rad(angle))) if (angle is not None and want_normal) else None
+        got = hip.stage1_targets(pix[0], img[0], mask[0, 0], valid[0, 0], normal[0] if want_normal else None, nmask[0, 0],
+                                 world[0] if want_normal else None, cos_t, want_normal)
+        rgb, mask_gt, mask_valid, norm_mask_gt, normal_gt = got
+        assert torch.equal(rgb, ref[0][0]) and torch.equal(mask_gt, ref[1][0]) and torch.equal(mask_valid, ref[2][0])
+        assert mask_valid.dtype == torch.bool and norm_mask_gt.dtype == torch.bool
+        assert torch.equal(norm_mask_gt, ref[3][0])
+        if want_normal:
+            assert torch.equal(normal_gt, ref[4][0])
+            assert 0 < int(norm_mask_gt.sum()) < norm_mask_gt.numel()
+        else:
+            assert normal_gt is None and ref[4] is None
+    # absent mask images are all ones
+    rgb, mask_gt, mask_valid, norm_mask_gt, normal_gt = hip.stage1_targets(pix[0], img[0])
+    assert bool(mask_gt.min() == 1) and bool(mask_valid.all()) and norm_mask_gt is None and normal_gt is None
+
+
+def test_stage1_rays_and_surface_points_vs_torch_formulation(cuda):
+    """psn_stage1_rays / psn_surface_points against the torch formulations they replace (rendering.py pixel_rays,
+    sphere_intersection, _march_finish + _surface) and against the oracle on the CPU."""
+    from psnerf_amd import hip
+    from psnerf_amd.stage1 import rendering as R
+    from oracle import stage1 as o1
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 5000, 512, 612
+    pix = torch.stack([torch.randint(0, w, (n,), generator=g), torch.randint(0, h, (n,), generator=g)], -1).float().unsqueeze(0)
+    K = torch.eye(4).unsqueeze(0)
+    K[0, 0, 0], K[0, 1, 1], K[0, 0, 2], K[0, 1, 2] = 1200.0, 1190.0, 306.0, 256.0
+    ang = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    W = torch.eye(4).unsqueeze(0)
+    W[0, :3, :3] = ang
+    W[0, :3, 3] = -ang[:, 2] * 3.0 + torch.tensor([0.05, -0.02, 0.1])  # camera 3 units out, looking roughly at the origin
+    for radius in (2.0, 1.0, 0.1):  # 0.1: most rays miss the sphere
+        cam_t = R.camera_origin(n, W.to(cuda))
+        rays_t = R.pixel_rays(pix.to(cuda), K.to(cuda), W.to(cuda))
+        rays_t = rays_t / rays_t.norm(2, 2).unsqueeze(-1)
+        far_t, hit_t = R.sphere_intersection(cam_t[:, 0], rays_t, r=radius)
+        cam, rays, far = hip.stage1_rays(pix[0].to(cuda), K[0].to(cuda), W[0].to(cuda), radius)
+        cam3, rays3, far3 = hip.stage1_rays(pix[0].to(cuda), K[0, :3, :3].contiguous().to(cuda), W[0].to(cuda), radius)
+        assert torch.equal(cam, cam_t[0]) and torch.equal(cam, cam3) and torch.equal(rays, rays3) and torch.equal(far, far3)
+        assert_close(rays.cpu(), rays_t[0].cpu(), 1e-6, 'rays')
+        assert int(((far > 0) != (far_t[0, :, 1] > 0)).sum()) <= 2  # grazing rays may flip with the last bit of b
+        if radius == 0.1:
+            assert int((far == 0).sum()) > n // 2
+        # the oracle's chain on the CPU (float64: the kernel's rounding against the exact value)
+        rays_o = o1.pixel_rays(pix.double(), K.double(), W.double())
+        rays_o = rays_o / rays_o.norm(2, 2).unsqueeze(-1)
+        far_o, hit_o = o1.sphere_intersection(W[:, :3, 3].double(), rays_o, r=radius)
+        assert_close(rays.cpu(), rays_o[0].float(), 1e-6, 'rays vs oracle')
+        both = (far.cpu() > 0) & hit_o[0]
+        assert int(((far.cpu() > 0) != hit_o[0]).sum()) <= 2
+        # far = sqrt(under) - b with under = b^2 - (|c|^2 - r^2) a difference of O(10) numbers: fp32 rounding of under (~4e-6)
+        # reaches far as 4e-6 / (2 sqrt(under)) -- the bound follows the conditioning (grazing rays), for the kernel and for
+        # the torch formulation alike
+        c64 = W[0, :3, 3].double()
+        b64 = (rays_o[0] * c64).sum(-1)
+        under64 = (b64 ** 2 - (c64.norm() ** 2 - radius ** 2))[both]
+        bound = 1e-5 + 4e-6 / under64.sqrt()
+        for name, f in (('kernel', far.cpu()), ('torch formulation', far_t[0, :, 1].cpu())):
+            err = (f[both].double() - far_o[0, :, 1][both]).abs()
+            assert bool((err <= bound).all()), '%s: far off by %.2e x its conditioning bound' % (name, float((err / bound).max()))
+    # surface points: every flag combination, crossing depths incl. 0, inf, nan
+    d_pred = torch.rand(4096, generator=g) * 3
+    d_pred[::17] = 0.0
+    d_pred[5::19] = float('inf')
+    d_pred[7::23] = float('nan')
+    flags = torch.randint(0, 4, (4096,), generator=g, dtype=torch.int32)
+    cam4, rays4 = torch.randn(4096, 3, generator=g), torch.nn.functional.normalize(torch.randn(4096, 3, generator=g), dim=-1)
+    d_pred, flags, cam4, rays4 = (t.to(cuda) for t in (d_pred, flags, cam4, rays4))
+    out = torch.where((flags & 1).bool(), d_pred, torch.full_like(d_pred, float('inf')))
+    d_ref = torch.where((flags & 2).bool(), out, torch.zeros_like(out))
+    zero_occ, ok = d_ref == 0, R.finite_mask(d_ref)
+    dists_ref = torch.where(zero_occ, torch.zeros_like(d_ref), torch.where(ok, d_ref, torch.ones_like(d_ref)))
+    dists, obj, pts, d_i = hip.surface_points(d_pred, flags, cam4, rays4, want_d=True)
+    assert torch.equal(torch.nan_to_num(d_i, nan=-7.0), torch.nan_to_num(d_ref, nan=-7.0))
+    assert torch.equal(dists, dists_ref) and torch.equal(obj, ok & ~zero_occ) and obj.dtype == torch.bool
+    assert torch.equal(pts, cam4 + rays4 * dists_ref.unsqueeze(-1))
+
+
+def _stage1_loss_inputs(n, dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)
+    rgb, rgb_gt = r(n, 3), r(n, 3)
+    gfield = torch.randn(2 * n, 3, generator=g)
+    gfield[n:] = gfield[:n] + 0.05 * torch.randn(n, 3, generator=g)
+    gfield[3] = 0.0            # |g| = 0: the norm's gradient is 0 there
+    gfield[n + 5] = gfield[5]  # identical normals: |a - b| = 0, its gradient 0
+    hit = r(n) > 0.3
+    normal_gt = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    norm_mask = r(n) > 0.5
+    acc = r(n) * 1.2 - 0.1     # some values outside [0, 1]: clamp, zero gradient there
+    acc[7], acc[8] = 0.0, 1.0  # log terms clamped at -100
+    mask_gt = (r(n) > 0.5).float()
+    mask_valid = r(n) > 0.2
+    return [t.to(dev) for t in (rgb, rgb_gt, gfield, hit, normal_gt, norm_mask, acc, mask_gt, mask_valid)]
+
+
+@pytest.mark.parametrize('n,terms_on', [(4096, 'all'), (777, 'all'), (4096, 'rgb_grad'), (300, 'no_mask'), (64, 'empty_masks')])
+def test_stage1_fused_losses_and_surface_normals_vs_torch_formulation(cuda, n, terms_on):
+    """ops.SurfaceNormals + ops.Stage1Losses (csrc/loss1.hip) against the torch formulation they replace (rendering.py:200-212
+    as written in Renderer._unisurf_sync_free, losses.py:24-70 as written in Loss.forward): every loss term and the gradients
+    with respect to colours, field gradients and accumulated opacity."""
+    from psnerf_amd import ops
+    from psnerf_amd.stage1 import Loss
+    rgb, rgb_gt, gfield, hit, normal_gt, norm_mask, acc, mask_gt, mask_valid = _stage1_loss_inputs(n, cuda, seed=n)
+    if terms_on == 'empty_masks':
+        hit, norm_mask, mask_valid = torch.zeros_like(hit), torch.zeros_like(norm_mask), torch.zeros_like(mask_valid)
+    with_norm, with_mask = terms_on in ('all', 'empty_masks'), terms_on in ('all', 'empty_masks')
+    if terms_on == 'no_mask':
+        with_norm = True
+    res = {}
+    for fused in (False, True):
+        leaves = [t.clone().requires_grad_(True) for t in (rgb, gfield, acc)]
+        c, gf, a = leaves
+        if fused:
+            norm_pred, diff = ops.SurfaceNormals.apply(gf, hit)
+        else:
+            nrm = gf / (gf.norm(2, dim=1).unsqueeze(-1) + 10 ** (-5))
+            norm_pred = torch.where(hit.unsqueeze(-1), nrm[:n], torch.zeros_like(nrm[:n]))
+            diff = torch.norm(nrm[:n] - nrm[n:], dim=-1)
+        out = {'rgb': c.reshape(1, n, 3), 'mask_pred': hit, 'diff_norm': None, 'diff_norm_full': diff,
+               'normal_pred': norm_pred.reshape(1, n, 3), 'acc_map': a.reshape(1, n)}
+        loss = Loss(1.0, 0.005, 0.05, 1.0, device=cuda)
+        loss.fused = fused
+        terms = loss(out, rgb_gt.reshape(1, n, 3), normal_gt.reshape(1, n, 3) if with_norm else None, norm_mask.reshape(1, n),
+                     a.reshape(1, n) if with_mask else None, mask_gt.reshape(1, n) if with_mask else None, mask_valid.reshape(1, n))
+        terms['loss'].backward()
+        res[fused] = ({k: float(v.detach()) for k, v in terms.items()}, [torch.zeros_like(t) if t.grad is None else t.grad.clone() for t in leaves],
+                      norm_pred.detach(), diff.detach())
+    assert set(res[True][0]) == set(res[False][0])
+    for k, v in res[False][0].items():
+        assert abs(res[True][0][k] - v) <= 2e-6 * max(abs(v), 1e-3), '%s: %r vs %r' % (k, res[True][0][k], v)
+    assert_close(res[True][2].cpu(), res[False][2].cpu(), 1e-6, 'normal_pred')
+    assert float((res[True][3] - res[False][3]).abs().max()) <= 5e-7, 'diff_norm'
+    for name, a_, b_ in zip(('d rgb', 'd field gradient', 'd acc'), res[True][1], res[False][1]):
+        assert torch.isfinite(a_).all()
+        assert_close(a_.cpu(), b_.cpu(), 2e-5, name)
+    if terms_on == 'empty_masks':
+        assert res[True][0]['grad_loss'] == 0.0 and res[True][0]['normal_loss'] == 0.0 and res[True][0]['mask_loss'] == 0.0
+
+
+def test_stage1_fused_losses_global_counts_hook(cuda):
+    """reduce_counts (the data-parallel hook) sees the three mask counts and its result is what the terms and the gradients
+    divide by: doubling the counts halves the masked terms and their gradients."""
+    from psnerf_amd import ops
+    n = 512
+    rgb, rgb_gt, gfield, hit, normal_gt, norm_mask, acc, mask_gt, mask_valid = _stage1_loss_inputs(n, cuda, seed=1)
+    seen = {}
+
+    def double(t):
+        seen['counts'] = t.clone()
+        t.mul_(2.0)
+        return t
+    outs = []
+    diff0, normal0 = torch.rand(n, device=cuda), torch.randn(n, 3, device=cuda)
+    for hook in (None, double):
+        a = acc.clone().requires_grad_(True)
+        diff, normal = diff0.clone().requires_grad_(True), normal0.clone().requires_grad_(True)
+        loss, terms = ops.Stage1Losses.apply(rgb, rgb_gt, diff, hit, normal, normal_gt, norm_mask, a, mask_gt, mask_valid, 2 * n,
+                                             (1.0, 0.5, 0.25, 2.0), hook)
+        loss.backward()
+        outs.append((terms.clone(), diff.grad.clone(), normal.grad.clone(), a.grad.clone()))
+    assert seen['counts'].tolist() == [float(hit.sum()), float(norm_mask.sum()), float(mask_valid.sum())]
+    t0, t1 = outs[0][0], outs[1][0]
+    assert float(t0[0]) == float(t1[0])  # colour term: divided by n_rays, not by a count
+    for i in (1, 2, 3):
+        assert abs(float(t1[i]) * 2 - float(t0[i])) <= 1e-6 * abs(float(t0[i]))
+    for a_, b_ in zip(outs[0][1:], outs[1][1:]):
+        assert_close((b_ * 2).cpu(), a_.cpu(), 1e-6, 'gradient under doubled counts')

@@ -390,16 +390,20 @@ def test_compute_loss_golden(cuda, tag):
     assert_close(projs, g[tag + '_grad_projs'], 2e-3, 'grad projs')
 
 
-def test_train_step_vs_reference_trainer(cuda):
+@pytest.mark.parametrize('flat', [False, True])
+def test_train_step_vs_reference_trainer(cuda, flat):
     """Two optimisation steps of the reference's OWN Trainer.train_step (training.py:46-60; tests/golden/stage1_train_step.npz)
-    replayed by the HIP Trainer: loss terms of both steps and the parameters after them."""
+    replayed by the HIP Trainer: loss terms of both steps and the parameters after them.  flat: optim.FlatAdam (one launch
+    per step over flat parameter / gradient / moment buffers) instead of torch.optim.Adam."""
+    from psnerf_amd.optim import FlatAdam
     from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
     from tests.test_oracle_golden import _stage1_train_step_golden
 
     def make(cfg, sd):
         net = NeuralNetwork(cfg)
         net.load_state_dict(sd)
-        return net, Trainer(Renderer(net, cfg, device=cuda), torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=cuda)
+        ren = Renderer(net, cfg, device=cuda)
+        return net, Trainer(ren, (FlatAdam if flat else torch.optim.Adam)(net.parameters(), lr=1e-4), cfg, device=cuda)
     g, net, logs = _stage1_train_step_golden(make, dev=cuda)
     for j in range(2):
         for k, v in zip(g['s%d_loss_names' % j], g['s%d_loss_vals' % j]):

@@ -31,12 +31,13 @@ def main():
     out = {}
     if torch.cuda.is_available():
         from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+        from psnerf_amd.optim import FlatAdam
         dev = torch.device('cuda:0')
         torch.manual_seed(42)
         net = NeuralNetwork(cfg)
         ren = Renderer(net, cfg, device=dev)
         ren.COMPACT_SECANT = args.compact_secant
-        tr = Trainer(ren, torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=dev)
+        tr = Trainer(ren, FlatAdam(net.parameters(), lr=1e-4), cfg, device=dev)
         batch_d = {k: v.to(dev) for k, v in batch.items()}
         for _ in range(args.warmup):
             terms = tr.train_step(batch_d, it=it)

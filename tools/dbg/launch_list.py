@@ -8,12 +8,14 @@ from torch.profiler import profile, ProfilerActivity
 dev = torch.device('cuda:0')
 if len(sys.argv) > 1 and sys.argv[1] == 'stage1':
     from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.optim import FlatAdam
     from psnerf_amd.synthetic import stage1_batch, stage1_cfg
     cfg = stage1_cfg('bear', **{'rendering.num_points_in': 96, 'rendering.num_points_out': 32, 'training.n_training_points': 4096})
     batch = {k: v.to(dev) for k, v in stage1_batch(cfg, h=512, w=612, seed=0).items()}
     torch.manual_seed(42)
     net = NeuralNetwork(cfg)
-    tr = Trainer(Renderer(net, cfg, device=dev), torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=dev)
+    ren = Renderer(net, cfg, device=dev)
+    tr = Trainer(ren, FlatAdam(net.parameters(), lr=1e-4), cfg, device=dev)
     run = lambda: tr.train_step(batch, it=6000)
 else:
     from psnerf_amd.synthetic import stage2_inputs

@@ -64,6 +64,7 @@ def main():
     import torch
     from psnerf_amd import dist as pdist, handoff, metrics
     from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.optim import FlatAdam
     from psnerf_amd.synthetic import stage1_camera, stage1_cfg, look_at_pose
     import psnerf_amd.stage2 as s2
     from psnerf_amd.stage2 import relight
@@ -94,7 +95,7 @@ def main():
     # ------------------------------------------------------------------ stage 1 (a16): train on the mean-light image
     net1 = NeuralNetwork(cfg)
     ren = Renderer(net1, cfg, device=dev)
-    tr1 = Trainer(ren, torch.optim.Adam(net1.parameters(), lr=1e-4), cfg, device=dev)
+    tr1 = Trainer(ren, FlatAdam(net1.parameters(), lr=1e-4), cfg, device=dev)
     batches = []
     for v in range(args.views):
         mean_img = images[v].mean(0).reshape(h, w, 3).permute(2, 0, 1)[None]
