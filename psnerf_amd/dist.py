@@ -109,9 +109,8 @@ class DataParallel(object):
 
     # ---- gradients ------------------------------------------------------------------------------
     def _bucket(self, params):
-        """The persistent flat fp32 gradient bucket of this parameter set: every ``p.grad`` is a VIEW into one
-        contiguous buffer (like DDP's gradient_as_bucket_view), so the all-reduce needs neither a torch.cat of ~50
-        tensors before nor ~50 copy kernels after it."""
+        """The persistent flat fp32 gradient bucket of this parameter set: after allreduce_grads every ``p.grad`` is a VIEW
+        into one contiguous buffer (like DDP's gradient_as_bucket_view): one multi-tensor copy in, nothing out."""
         key = tuple(id(p) for p in params)
         b = self._buckets.get(key)
         if b is not None and not all(r() is p for r, p in zip(b[2], params)):
@@ -131,25 +130,15 @@ class DataParallel(object):
         return b
 
     def prepare_grads(self, params):
-        """Replaces ``optimizer.zero_grad()`` under data parallelism: ONE memset of the flat bucket, and every
-        ``p.grad`` (re)attached to its view, so that autograd accumulates straight into the bucket."""
+        """Replaces ``optimizer.zero_grad()`` under data parallelism: every ``.grad`` is dropped (no launch), so autograd hands
+        each parameter its gradient tensor instead of adding it to a zero-filled one (one ``add_`` launch per parameter);
+        ``allreduce_grads`` gathers them into the flat bucket with one multi-tensor copy."""
         for p in params:
-            if not p.requires_grad:
-                p.grad = None  # a parameter frozen since the last step must not keep its last all-reduced gradient (a view
-                               # of a bucket that is no longer reduced): optimisers skip None, like after zero_grad()
-        params = [p for p in params if p.requires_grad]
-        if not self.enabled or not params:
-            for p in params:
-                p.grad = None
-            return
-        flat, views = self._bucket(params)[:2]
-        flat.zero_()
-        for p, v in zip(params, views):
-            p.grad = v
+            p.grad = None  # also for a parameter frozen since the last step: optimisers skip None, like after zero_grad()
 
     def allreduce_grads(self, params, sparse_params=()):
-        """One flat-bucket all-reduce(SUM) over every dense .grad (in place when prepare_grads attached the views;
-        gradients that autograd allocated itself are first copied into the bucket).  Coalesced values of sparse .grad
+        """One flat-bucket all-reduce(SUM) over every dense .grad (the tensors autograd produced are first copied into the
+        bucket -- one multi-tensor launch --; afterwards every ``.grad`` is its view of the reduced bucket).  Coalesced values of sparse .grad
         (CPU / oracle embeddings; the HIP trainers use dense tables + RowSparseAdam, whose [n_lights, 4] floats ride
         in the bucket whole: 30 KB of a 2.7 MB message, cheaper than four gather / scatter launches) go out as a second
         small message.  A parameter without a gradient on this rank (an empty pixel slice) contributes zeros."""
@@ -158,11 +147,15 @@ class DataParallel(object):
         params = [p for p in params if p.requires_grad]
         if params:
             flat, views = self._bucket(params)[:2]
+            have = [(p, v) for p, v in zip(params, views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+            none = [v for p, v in zip(params, views) if p.grad is None]
+            if len(none) == len(params):
+                flat.zero_()  # a rank without a graph (an empty pixel slice) contributes zeros
+            elif none:
+                torch._foreach_zero_(none)
+            if have:  # one multi-tensor copy for all parameters (the alignment gaps of the bucket stay zero)
+                torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
             for p, v in zip(params, views):
-                if p.grad is None:
-                    v.zero_()
-                elif p.grad.data_ptr() != v.data_ptr():
-                    v.copy_(p.grad)
                 p.grad = v
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             self.n_allreduce += 1

@@ -91,9 +91,9 @@ def _pad64(n):
 class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam (amsgrad off, no weight decay: what stage2/trainer.py:126-133 constructs) over ONE flat fp32 buffer.
 
-    Parameters, moments and -- when the trainer attaches them as views of a flat bucket (dist.DataParallel.prepare_grads,
-    also used on a single GPU) -- gradients are contiguous allocations, so a step is one launch of psn_adam_flat with torch's
-    arithmetic (seven foreach launches there).  ``param.data`` of every parameter is re-pointed into the flat buffer at
+    Parameters and moments are contiguous allocations; the gradients autograd produced are gathered into a third one by one
+    multi-tensor copy at the start of ``step()`` (under data parallelism they already are views of the all-reduced bucket),
+    so a step is one launch of psn_adam_flat with torch's arithmetic (seven foreach launches there).  ``param.data`` of every parameter is re-pointed into the flat buffer at
     construction (values preserved; in-place loads such as load_state_dict keep working, and a parameter whose storage was
     replaced from outside is detected and re-attached).  State layout and keys are torch.optim.Adam's (``step``,
     ``exp_avg``, ``exp_avg_sq`` per parameter; the same param_group keys), so optimiser checkpoints are interchangeable;
@@ -152,24 +152,33 @@ class FlatAdam(torch.optim.Optimizer):
         return bool(self._flat)
 
     def attach_grads(self):
-        """Replaces ``zero_grad()``: ONE memset of a flat gradient buffer laid out like the parameters, every trainable
-        parameter's ``.grad`` (re)attached to its view (autograd accumulates in place), frozen parameters' set to None.
-        Returns False (after a plain zero_grad) when the parameters cannot be flat (CPU / non-fp32)."""
-        if not self._attached():
-            self.zero_grad()
-            return False
+        """Replaces ``zero_grad()``: every ``.grad`` is dropped (no launch); autograd then HANDS each parameter its gradient
+        instead of adding it to a zero-filled view (one ``add_`` launch per parameter), and ``step()`` gathers the
+        gradients into the flat buffer with one multi-tensor copy.  Returns whether the parameters are flat."""
+        self.zero_grad(set_to_none=True)
+        return self._attached()
+
+    def _gather_grads(self):
+        """Copies every dense fp32 gradient that is not yet a view of a flat allocation into this optimiser's flat gradient
+        buffer (laid out like the parameters; alignment gaps stay zero) and re-points ``.grad`` at the views."""
         f = self._flat
+        loose = []
+        for p in self._all_params():
+            g = p.grad
+            if g is None or g.is_sparse or g.dtype != torch.float32 or not g.is_cuda:
+                continue
+            base = g._base
+            if base is not None and base.dim() == 1 and base.is_contiguous() and g.is_contiguous():
+                continue  # already a view of a flat buffer (this one, or the data-parallel bucket)
+            loose.append(p)
+        if not loose:
+            return
         if f.get('g') is None:
             f['g'] = torch.zeros_like(f['p'])
-        else:
-            f['g'].zero_()
-        for p in self._all_params():
-            if p.requires_grad:
-                o = f['off'][p]
-                p.grad = f['g'][o:o + p.numel()].view_as(p)
-            else:
-                p.grad = None
-        return True
+        views = [f['g'][f['off'][p]:f['off'][p] + p.numel()].view_as(p) for p in loose]
+        torch._foreach_copy_(views, [p.grad for p in loose])
+        for p, v in zip(loose, views):
+            p.grad = v
 
     # ---- checkpoints: never serialise views of the whole flat allocation ----------------------------------------------
     def state_dict(self):
@@ -190,6 +199,8 @@ class FlatAdam(torch.optim.Optimizer):
         import math
         from . import hip
         flat_ok = self._attached()
+        if flat_ok:
+            self._gather_grads()
         for group in self.param_groups:
             assert not group.get('maximize', False) and not group.get('amsgrad', False) and group.get('weight_decay', 0) == 0, \
                 'FlatAdam: plain Adam only'

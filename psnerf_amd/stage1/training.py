@@ -48,10 +48,10 @@ class Trainer(object):
         self.model.train()
         if self.dp.enabled:
             trainable = [p for p in self.model.parameters() if p.requires_grad]
-            # one memset; every trainable .grad becomes a view into the flat all-reduce bucket, frozen parameters lose theirs
+            # every .grad dropped; allreduce_grads gathers what autograd hands over into the flat bucket (one multi-tensor copy)
             self.dp.prepare_grads(list(self.model.parameters()))
         elif isinstance(self.optimizer, FlatAdam):
-            self.optimizer.attach_grads()  # one memset; every .grad a view of one flat buffer laid out like the parameters
+            self.optimizer.attach_grads()  # grads dropped (no launch); step() gathers what autograd hands over with one multi-tensor copy
         else:
             self.optimizer.zero_grad()
         terms = self.compute_loss(data, it=it, pix=pix, noise=noise)

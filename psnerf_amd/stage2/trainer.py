@@ -167,11 +167,11 @@ class TrainStep(object):
         if self.dp.enabled:
             trainable = [p for p in self.model.parameters() if p.requires_grad] \
                 + ([self.light_para.weight, self.light_inten_para.weight] if train_light else [])
-            # one memset; every trainable .grad becomes a view into the flat all-reduce bucket, frozen parameters lose theirs
+            # every .grad dropped; allreduce_grads gathers what autograd hands over into the flat bucket (one multi-tensor copy)
             self.dp.prepare_grads(list(self.model.parameters()) + [self.light_para.weight, self.light_inten_para.weight])
         else:
             if isinstance(self.sg_optimizer, FlatAdam):
-                self.sg_optimizer.attach_grads()  # one memset; every .grad a view of one flat buffer laid out like the parameters
+                self.sg_optimizer.attach_grads()  # grads dropped (no launch); step() gathers what autograd hands over with one multi-tensor copy
             else:
                 self.sg_optimizer.zero_grad()
             if train_light:

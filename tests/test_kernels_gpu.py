@@ -778,10 +778,12 @@ def test_flat_adam_follows_torch_adam(cuda):
         ob.zero_grad()
         for p, q, gr in zip(pa, pb, grads):
             if p.requires_grad:
-                p.grad.add_(gr)  # accumulates into the flat view, as autograd does
+                assert p.grad is None
+                p.grad = gr.clone()  # a tensor of its own, as autograd hands it over; step() gathers them (one multi-tensor copy)
                 q.grad = gr.clone()
         assert pa[frozen].grad is None or it >= 2
         oa.step()
+        assert all(p.grad is None or (p.grad._base is not None and p.grad._base.data_ptr() == pa[0].grad._base.data_ptr()) for p in pa)
         ob.step()
         sa.step()
         sb.step()
@@ -803,7 +805,7 @@ def test_flat_adam_follows_torch_adam(cuda):
     for (p1, p2) in zip(oc.param_groups[0]['params'], od.param_groups[0]['params']):
         g1 = torch.randn(p1.shape, generator=g).to(cuda)
         p1.grad = g1.clone()
-        p2.grad = g1.clone()  # not a flat view: the torch formulation inside FlatAdam
+        p2.grad = g1.clone()
     oc.step()
     od.step()
     for p1, p2 in zip(oc.param_groups[0]['params'], od.param_groups[0]['params']):
