@@ -893,7 +893,7 @@ class FusedReluNet(torch.autograd.Function):
         Q, dev = pe.shape[0], pe.device
         g = g.contiguous()
         if final_sigmoid:
-            g = g * out * (1.0 - out)
+            g = torch.ops.aten.sigmoid_backward(g, out)  # g * (1 - out) * out, one launch
         chain = fused.pack_relu_bwd(list(Ws), skip_at, width=width)
         DZ = [torch.empty(Q, width, device=dev) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
         if Ws[n - 1].shape[0] <= 4:  # d h_{n-2} = g W_last as a rank-k init inside the kernel (albedo / normal nets: 3 outputs)

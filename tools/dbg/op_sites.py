@@ -14,7 +14,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'stage1':
     batch = {k: v.to(dev) for k, v in stage1_batch(cfg, h=512, w=612, seed=0).items()}
     torch.manual_seed(42)
     net = NeuralNetwork(cfg)
-    tr = Trainer(Renderer(net, cfg, device=dev), torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=dev)
+    from psnerf_amd.optim import FlatAdam
+    ren = Renderer(net, cfg, device=dev)
+    tr = Trainer(ren, FlatAdam(net.parameters(), lr=1e-4), cfg, device=dev)
     run = lambda: tr.train_step(batch, it=6000)
 else:
     step = bench.make_step(dev)
