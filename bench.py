@@ -150,6 +150,18 @@ def stage1_measure(device, steps=10, warmup=3, rays=4096):
         tr.train_step(batch, it=it)
     torch.cuda.synchronize()
     hip.PROFILE_EVENTS = None
+    launches = None
+    try:  # device launches of one steady-state step (as launches_per_step of the headline)
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            tr.train_step(batch, it=it)
+            torch.cuda.synchronize()
+        names = [e.name for e in prof.events() if getattr(e, 'device_type', None) is not None and 'cuda' in str(e.device_type).lower()]
+        if names:
+            ours = sum(1 for n in names if 'psn::' in n)
+            launches = {'total': len(names), 'hip_hand_written': ours, 'other': len(names) - ours}
+    except Exception as e:  # noqa: BLE001
+        launches = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
 
     def agg(name):
         sel = [(u, a.elapsed_time(b), f) for (k, u, a, b, f) in ev if k == name]
@@ -158,6 +170,7 @@ def stage1_measure(device, steps=10, warmup=3, rays=4096):
     out = {'workload': 'stage1 BEAR train step (BASELINE configs[1]): %d rays x %d samples, 256 march steps + 8 secant, '
                        'full step (march, render fwd, loss, double backward, Adam)' % (rays, S),
            'value': round(rays * S / dt, 1), 'unit': 'ray-samples/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps,
+           'launches_per_step': launches,
            'warmup': warmup, 'loss': round(float(terms['loss'].detach()), 6), 'dtype': 'f32', 'data': 'synthetic'}
     ch = [(u, ms, f) for u, ms, f in agg('mlp_chain') if f]
     if ch:

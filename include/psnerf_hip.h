@@ -308,6 +308,13 @@ int psn_shadow_points(const float* surf, const float* ldir, int64_t n_surf, int 
  * in_kt_a = 2 (one 64-column block), biases packed back to back, n_out <= 32.  out [n_rows, n_out]. */
 int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* points, int64_t n_rows,
                      int pe_octaves, float pe_scale, float* out, void* stream);
+/* psn_mlp_infer_pe over a compacted point list whose length lives on the device (the counter psn_shadow_points writes): the
+ * grid covers `capacity` rows, workgroups behind *n_rows_dev leave at once; with out_rows, row r's outputs go to
+ * out[out_rows[r] * n_out ...] (scatter).  The shadow-ray visibility of stage1/model/rendering.py:378-408 without a host
+ * synchronisation between the +-1.1 box test (:400-401) and the occupancy network. */
+int psn_mlp_infer_pe_indirect(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* points,
+                              int64_t capacity, const long long* n_rows_dev, const int64_t* out_rows, int pe_octaves,
+                              float pe_scale, float* out, void* stream);
 
 /* Ray-march sweep, stage1/model/rendering.py:447-462 (+ the early termination its consumer :472-504 allows): the occupancy
  * sigmoid(-10 logit) of n_steps proposal points per ray, p = origin + dir * (near (1 - u_m) + far u_m), generated and

@@ -63,6 +63,8 @@ struct InferArgs {
     const float* rk_basis;  // [rk_k, init_stride]
     int rk_k;
     // SRC == 1 (fused secant root finder, psn_root_find): the rows are rays, the network input is computed in the kernel
+    const long long* n_rows_dev;  // SRC == 2, optional: the row count lives on the device (n_rows = capacity = grid size)
+    const int64_t* out_rows;      // SRC == 2, optional: row r's outputs go to out[out_rows[r] * n_out ...] (scatter)
     const float* ray_o;      // [n_rows, 3]
     const float* ray_d;      // [n_rows, 3]
     const float* bracket;    // [4, n_rows]: d_low, d_high, f_low, f_high
@@ -354,7 +356,16 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         if (g.n_blocks != nullptr && threadIdx.x == 0) atomicAdd(g.n_blocks, 1ull);
     }
     const int64_t row = row_;
-    const int64_t rowc = row < g.n_rows ? row : g.n_rows - 1;
+    int64_t n_rows_eff = g.n_rows;
+    if constexpr (SRC == 2) {
+        // indirect launch (psn_mlp_infer_pe_indirect): the grid covers the capacity of a compacted point list whose length only
+        // the device knows; workgroups behind it leave here (uniformly, before any barrier)
+        if (g.n_rows_dev != nullptr) {
+            n_rows_eff = (int64_t)*g.n_rows_dev;
+            if ((int64_t)blockIdx.x * (kWaves * 16) >= n_rows_eff) return;
+        }
+    }
+    const int64_t rowc = row < n_rows_eff ? row : n_rows_eff - 1;
     const int n_layers = g.d.n_layers;
 
     {  // prefetch the first weight stage (layer 0 may be evaluated entirely through the init tables)
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     int gstage = 0;  // global stage counter -> LDS buffer parity
     int pending_dump = 0;  // activation-dump stores (0 / 16 / 32) issued after the last LDS-DMA batch
     int pending_stages = 0;  // stage starts (0 or 1) that may leave `pending_dump` stores in flight
-    const bool dump_row = row < g.n_rows && row >= g.save_row0;
+    const bool dump_row = row < n_rows_eff && row >= g.save_row0;
     // A wave none of whose rows is dumped skips the store instructions altogether (s_cbranch_execz), so it must not
     // leave room for them in its counted waits -- it would then not wait for its LDS-DMA pieces either.
     const bool wave_dumps = __builtin_amdgcn_ballot_w64(dump_row) != 0;
@@ -741,8 +752,12 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     }
 
     // ---- output: feature f = 16*mt + 4*g + r of the final layer ---------------------------------
-    if (row < g.n_rows && g.d.n_out > 0) {
+    if (row < n_rows_eff && g.d.n_out > 0) {
         const int n_out = g.d.n_out;
+        int64_t orow = row;
+        if constexpr (SRC == 2) {
+            if (g.out_rows != nullptr) orow = g.out_rows[row];
+        }
 #pragma unroll
         for (int mt = 0; mt < ((CHAIN && NMT == 16) ? 4 : 2); ++mt) {
 #pragma unroll
@@ -752,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                     float v = acc[mt][r];
                     if (g.d.out_act == PSN_OUT_SIGMOID) v = sigmoidf_(v);
                     else if (g.d.out_act == PSN_OUT_OCC) v = sigmoidf_(v * -10.0f);
-                    g.out[row * n_out + f] = v;
+                    g.out[orow * n_out + f] = v;
                 }
             }
         }
@@ -1140,8 +1155,9 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
 // queries, stage1/model/network.py:141-150 + 85-101): `points` [n_rows, 3] in, the encoding gamma(scale * p) is formed
 // in the kernel prologue in the B-operand registers -- the same expressions as pe_encode_kernel, so the result equals
 // psn_pe_encode + psn_mlp_infer bit for bit without the [n_rows, 64] table ever existing in HBM.
-extern "C" int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* points,
-                                int64_t n_rows, int pe_octaves, float pe_scale, float* out, void* stream) {
+static int mlp_infer_pe_impl(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* points,
+                             int64_t n_rows, const long long* n_rows_dev, const int64_t* out_rows, int pe_octaves, float pe_scale,
+                             float* out, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(desc && packed_w && packed_b && points && out, "mlp_infer_pe: null pointer");
     const PsnMlpDesc& d = *desc;
@@ -1164,7 +1180,7 @@ extern "C" int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, c
     InferArgs a = {};
     a.d = d; a.w = packed_w; a.b = packed_b; a.a_div = 1; a.a_mod = 1; a.b_div = 1; a.b_mod = 1; a.n_rows = n_rows; a.out = out;
     a.n_bias = (d.n_layers - 1) * 256 + 32;
-    a.ray_o = points; a.pe_scale = pe_scale; a.pe_octaves = pe_octaves;
+    a.ray_o = points; a.pe_scale = pe_scale; a.pe_octaves = pe_octaves; a.n_rows_dev = n_rows_dev; a.out_rows = out_rows;
     for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) { a.save_tiles[l] = 0xFFFFFFFFu; a.save2_tiles[l] = 0xFFFFFFFFu; }
     const int64_t blocks = (n_rows + kWaves * 16 - 1) / (kWaves * 16);
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer_pe: too many rows");
@@ -1172,6 +1188,23 @@ extern "C" int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, c
     hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 2, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer_pe");
     return PSN_OK;
+}
+
+extern "C" int psn_mlp_infer_pe(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* points,
+                                int64_t n_rows, int pe_octaves, float pe_scale, float* out, void* stream) {
+    return mlp_infer_pe_impl(desc, packed_w, packed_b, points, n_rows, nullptr, nullptr, pe_octaves, pe_scale, out, stream);
+}
+
+// The same network over a COMPACTED point list whose length only the device knows (psn_shadow_points' counter): the grid
+// covers `capacity` rows, workgroups behind *n_rows_dev leave in their prologue, and row r's outputs are written to
+// out[out_rows[r]] when out_rows is given -- the shadow-ray path of stage1/model/rendering.py:378-408 without a host
+// synchronisation between the box test and the network, and without a separate scatter of the occupancies.
+extern "C" int psn_mlp_infer_pe_indirect(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* points,
+                                         int64_t capacity, const long long* n_rows_dev, const int64_t* out_rows, int pe_octaves,
+                                         float pe_scale, float* out, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(n_rows_dev != nullptr, "mlp_infer_pe_indirect: n_rows_dev is required");
+    return mlp_infer_pe_impl(desc, packed_w, packed_b, points, capacity, n_rows_dev, out_rows, pe_octaves, pe_scale, out, stream);
 }
 
 // Ray-march sweep (stage1/model/rendering.py:447-462): the occupancy of n_steps proposal points per ray, points generated and

@@ -32,10 +32,12 @@ class PackedMLP(object):
         self.init_wa, self.init_wb, self.init_bias = init_wa, init_wb, init_bias
         self.macs_per_row = None  # algorithmic MACs per row inside the kernel (true, unpadded block shapes)
 
-    def on_points(self, points, pe_octaves, pe_scale, out=None):
+    def on_points(self, points, pe_octaves, pe_scale, out=None, n_rows_dev=None, out_rows=None):
         """The network on gamma(pe_scale * points), [Q, 3] -> [Q, n_out], the encoding formed in the kernel prologue
-        (hip.mlp_infer_pe): for packs whose input block is one positional encoding and that use no init tables."""
-        return hip.mlp_infer_pe(self.desc, self.w, self.b, points, pe_octaves, pe_scale, out=out, macs_per_row=self.macs_per_row)
+        (hip.mlp_infer_pe): for packs whose input block is one positional encoding and that use no init tables.
+        n_rows_dev / out_rows: a compacted list with a device-resident length, outputs scattered (see hip.mlp_infer_pe)."""
+        return hip.mlp_infer_pe(self.desc, self.w, self.b, points, pe_octaves, pe_scale, out=out, macs_per_row=self.macs_per_row,
+                                n_rows_dev=n_rows_dev, out_rows=out_rows)
 
     def __call__(self, tab_a, n_rows, a_div=1, a_mod=None, tab_b=None, b_div=1, b_mod=1, out=None, save=None,
                  save_row0=0, mask=None, init_a_direct=None, aux2=None, save2=None, act_init=None, rank_init=None,

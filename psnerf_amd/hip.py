@@ -123,6 +123,7 @@ SIGNATURES = {
     'psn_row_adam': (i32, [i32, ctypes.c_void_p, c_f, i32, c_f]),
     'psn_shadow_points': (i32, [c_f, c_f, i64, i32, i32, f32, f32, c_f, c_f, f32, c_f, c_f, c_f, c_f]),
     'psn_mlp_infer_pe': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i32, f32, c_f, c_f]),
+    'psn_mlp_infer_pe_indirect': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, c_f, c_f, i32, f32, c_f, c_f]),
     'psn_root_find': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, i64, f32, i32, i32, f32, c_f, c_f]),
     'psn_march_sweep': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, i64, i32, f32, i32, f32, c_f, c_f, c_f, c_f]),
     'psn_normalize_rows_fwd': (i32, [c_f, i64, f32, c_f, c_f]),
@@ -655,15 +656,30 @@ def shadow_points(surf, ldir, n_steps, lnear, lfar, u, omu, box):
     return pts, rows, counter
 
 
-def mlp_infer_pe(desc, packed_w, packed_b, points, pe_octaves, pe_scale, out=None, macs_per_row=None):
-    """Network on gamma(pe_scale * points) with the encoding formed inside the kernel (psn_mlp_infer_pe) -> [Q, n_out]."""
+def mlp_infer_pe(desc, packed_w, packed_b, points, pe_octaves, pe_scale, out=None, macs_per_row=None, n_rows_dev=None, out_rows=None):
+    """Network on gamma(pe_scale * points) with the encoding formed inside the kernel (psn_mlp_infer_pe) -> [Q, n_out].
+    ``n_rows_dev`` (int64 [1] on the device): only the first n_rows_dev[0] points are valid (psn_mlp_infer_pe_indirect; the
+    grid covers all Q); ``out_rows`` (int64 [Q]): row r is written to out[out_rows[r]] -- ``out`` is then required."""
     Q = points.shape[0]
     assert points.shape == (Q, 3) and points.is_contiguous()
+    indirect = n_rows_dev is not None
     if out is None:
+        assert out_rows is None, 'a scatter needs its destination'
         out = torch.empty(Q, desc.n_out, device=points.device, dtype=torch.float32)
-    assert out.is_contiguous() and out.numel() == Q * desc.n_out
+    assert out.is_contiguous() and (out_rows is not None or out.numel() == Q * desc.n_out)
     if Q == 0:
         return out
+    if indirect:
+        assert n_rows_dev.dtype == torch.int64 and n_rows_dev.is_cuda and n_rows_dev.numel() == 1
+        assert out_rows is None or (out_rows.dtype == torch.int64 and out_rows.is_cuda and out_rows.is_contiguous() and out_rows.numel() >= Q)
+        # (no flop count for the profile: how many rows were evaluated is known to the device only)
+        with _Prof('mlp_infer', Q, None):
+            _check(_lib.psn_mlp_infer_pe_indirect(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
+                                                  _ptr(points, 'points'), Q, n_rows_dev.data_ptr(),
+                                                  None if out_rows is None else out_rows.data_ptr(), int(pe_octaves), float(pe_scale),
+                                                  out.data_ptr(), _stream()), 'mlp_infer_pe_indirect')
+        return out
+    assert out_rows is None
     with _Prof('mlp_infer', Q, None if macs_per_row is None else 2.0 * macs_per_row * Q):
         _check(_lib.psn_mlp_infer_pe(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'), _ptr(points, 'points'),
                                      Q, int(pe_octaves), float(pe_scale), out.data_ptr(), _stream()), 'mlp_infer_pe')

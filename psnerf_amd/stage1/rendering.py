@@ -484,11 +484,25 @@ class Renderer(nn.Module):
             # points of the samples that lie inside the +-1.1 box, compacted (csrc/sample.hip): the others have
             # occupancy 0 by rendering.py:400-401 and never reach the network
             pts, rows, counter = hip.shadow_points(surf, ld, n_steps, lnear, lfar, u[0], u[1], 1.1)
-            n_in = int(counter.item())  # one synchronisation per launch group (this is the extraction path, not training)
             alpha = torch.zeros(n_rays * n_steps, device=dev)
-            if n_in > 0:
-                alpha.index_copy_(0, rows[:n_in], self._occ(pts[:n_in]).reshape(-1))
+            m = self.model
+            if self.SHADOW_SYNC_FREE and hasattr(m, '_occupancy_packed') and m._hidden_is_256():
+                # the network runs over the compacted list straight away: its length stays on the device (workgroups behind it
+                # leave at once) and the occupancies are scattered to their (ray, step) slots by the kernel itself
+                m._occupancy_packed().on_points(pts, m.octaves_pe, 1.0 / m.rescale, out=alpha, n_rows_dev=counter, out_rows=rows)
+            else:
+                n_in = int(counter.item())  # one host synchronisation per launch group
+                if n_in > 0:
+                    alpha.index_copy_(0, rows[:n_in], self._occ(pts[:n_in]).reshape(-1))
             _, _, acc = hip.composite_fwd(alpha.view(n_rays, n_steps), None, False, need_weights=False)
             outs.append(1 - acc)
-            self.last_shadow_stats = (n_in, n_rays * n_steps)
+            self._shadow_stats = (counter, n_rays * n_steps)
         return torch.cat(outs, 0)
+
+    SHADOW_SYNC_FREE = True  # False: host-synchronised launch sizes (one counter.item() per launch group) + index_copy_
+
+    @property
+    def last_shadow_stats(self):
+        """(in-box samples, all samples) of the last launch group of light_visibility (reads the device counter: synchronises)."""
+        counter, n_all = self._shadow_stats
+        return int(counter.item()), n_all

@@ -564,6 +564,38 @@ def test_shadow_ray_compaction_is_bit_identical(cuda):
         alpha = torch.where(inside, alpha, torch.zeros_like(alpha)).contiguous()
         ref = 1 - hip.composite_fwd(alpha, None, False, need_weights=False)[2]
     assert torch.equal(v, ref)
+    # the host-synchronised form (launch sized by counter.item(), index_copy_ of the occupancies) gives the same bits; and a
+    # scene with every sample outside the box (empty compacted list: every workgroup of the indirect launch leaves) is all lit
+    ren.SHADOW_SYNC_FREE = False
+    with torch.no_grad():
+        assert torch.equal(ren.light_visibility(surf=surf, light_dir=ld), v)
+        ren.SHADOW_SYNC_FREE = True
+        far_away = surf * 0 + 5.0
+        assert torch.equal(ren.light_visibility(surf=far_away, light_dir=ld), torch.ones_like(v))
+        assert ren.last_shadow_stats[0] == 0
+
+
+def test_indirect_occupancy_launch_reads_its_row_count_on_the_device(cuda):
+    """psn_mlp_infer_pe_indirect: capacity-sized grid, device-resident length, scattered outputs -- equal to the direct launch
+    on the valid prefix, untouched destinations elsewhere (lengths: 0, inside a workgroup, a workgroup boundary, full)."""
+    cfg, net, ren = _renderer(cuda)
+    g = torch.Generator().manual_seed(4)
+    cap = 1000
+    pts = (torch.rand(cap, 3, generator=g) * 2 - 1).to(cuda)
+    perm = torch.randperm(3 * cap, generator=g)[:cap].to(cuda)
+    packed = net._occupancy_packed()
+    with torch.no_grad():
+        ref = packed.on_points(pts, net.octaves_pe, 1.0 / net.rescale).reshape(-1)
+        for n in (0, 1, 63, 64, 65, 640, cap):
+            out = torch.full((3 * cap,), -7.0, device=cuda)
+            cnt = torch.tensor([n], dtype=torch.int64, device=cuda)
+            packed.on_points(pts, net.octaves_pe, 1.0 / net.rescale, out=out, n_rows_dev=cnt, out_rows=perm)
+            want = torch.full((3 * cap,), -7.0, device=cuda)
+            want[perm[:n]] = ref[:n]
+            assert torch.equal(out, want), n
+            dense = torch.full((cap,), -7.0, device=cuda)
+            packed.on_points(pts, net.octaves_pe, 1.0 / net.rescale, out=dense, n_rows_dev=cnt)
+            assert torch.equal(dense[:n], ref[:n]) and bool((dense[n:] == -7.0).all())
 
 
 @pytest.mark.parametrize('n', [0, 1, 63, 64, 5000, 70001])
