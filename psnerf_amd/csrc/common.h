@@ -84,27 +84,66 @@ __device__ __forceinline__ float log1p_unit(float u, float w, float rw) {  // w 
     return fmaf(__builtin_amdgcn_logf(w), 0.693147182464599609375f, (u - (w - 1.0f)) * rw);
 }
 
-// torch.nn.Softplus(beta=100, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta, evaluated as
-// max(x,0) + log1p(exp(-|beta x|))/beta (identical in exact arithmetic, no overflow, ~25 instructions).
-// Also returns s = sigmoid(beta*x) = d softplus / dx from the same exponential.
+// ---- packed fp32 pairs -----------------------------------------------------------------------------------------------------
+// In the fp32 MFMA kernels every vector instruction costs matrix-pipe time (the softplus of the stage-1 geometry network was
+// ~16 % of the ray-march sweep).  gfx950 executes v_pk_{mul,add,fma}_f32 on TWO values per lane at the rate of the scalar forms,
+// so the element-wise math below works on pairs; only the transcendentals, min / max and selects remain one value at a time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk2(float a) { return f32x2{a, a}; }
+
+// torch.nn.Softplus(beta=100, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta, evaluated for a PAIR as
+//   max(x, 0) + log1p(exp(-|beta x|)) / beta
+// (identical in exact arithmetic; no overflow; no select for the threshold: above it the second term is < 2e-11 and vanishes
+// in the addition, so the result is x exactly, as in torch).  Per pair: 2 x (exp2, log2) + 2 x (min, max) + 15 packed.
+//   u = exp(-|t|):  hi = fl(-|t| log2 e), u = 2^hi (1 + r), r = -|t| - hi ln2 formed with a split ln2 (two FMAs: exact to
+//       ~2^-48 |t|), so u carries the ~1 ulp of v_exp_f32 for |t| <= 100;
+//   log1p(u) = log2(w) ln2 + (u - (w - 1)) / w,  w = fl(1 + u): the classic rounding correction; it is O(2^-24) of the result
+//       unless u is tiny, where w -> 1: 1 / w ~ 1 - c + c^2 / 2 (c = w - 1; exact at c = 0 and c = 1, 6 % off in between,
+//       i.e. < 1e-8 of the result) -- no reciprocal.  Max relative error of the pair 1.5e-7 (tools/dbg/check_log1p.py);
+//   / beta: l * 0.01 with the constant split into two floats (0.01f is 2.2e-8 off 1 / 100).
+// WITH_SIG: also s = sigmoid(beta x) = d softplus / dx from the same exponential (one reciprocal + a Newton step: 0.5 ulp).
+template <bool WITH_SIG>
+__device__ __forceinline__ void softplus100_pair(f32x2 z, f32x2& sp, f32x2& s) {
+    const float L2E = 1.44269502162933349609375f;             // (float) log2(e)
+    const float LN2_HI = 0.693147182464599609375f;            // (float) ln 2
+    const float LN2_LO = -1.904654323148236e-9f;              // ln 2 - LN2_HI
+    const float C_HI = 0.00999999977648258209228515625f;      // (float) 0.01
+    const float C_LO = 2.2351741811588166e-10f;               // 0.01 - C_HI
+    const f32x2 t = z * 100.0f;
+    const f32x2 nat = {fminf(t.x, -t.x), fminf(t.y, -t.y)};  // -|t|
+    const f32x2 hi = nat * L2E;
+    f32x2 r = pk_fma(-hi, pk2(LN2_HI), nat);
+    r = pk_fma(-hi, pk2(LN2_LO), r);
+    const f32x2 u0 = {__builtin_amdgcn_exp2f(hi.x), __builtin_amdgcn_exp2f(hi.y)};
+    const f32x2 u = pk_fma(u0, r, u0);
+    const f32x2 w = u + 1.0f;
+    const f32x2 lw = {__builtin_amdgcn_logf(w.x), __builtin_amdgcn_logf(w.y)};  // log2
+    const f32x2 c = w - 1.0f;
+    const f32x2 d = u - c;
+    f32x2 rw;
+    if constexpr (WITH_SIG) {
+        const f32x2 r0 = {__builtin_amdgcn_rcpf(w.x), __builtin_amdgcn_rcpf(w.y)};   // 1 ulp
+        rw = pk_fma(pk_fma(-w, r0, pk2(1.0f)), r0, r0);                              // one Newton step: 1 / w to ~0.5 ulp
+        const f32x2 ur = u * rw;
+        s = f32x2{t.x >= 0.0f ? rw.x : ur.x, t.y >= 0.0f ? rw.y : ur.y};
+    } else {
+        rw = pk_fma(c, pk_fma(c, pk2(0.5f), pk2(-1.0f)), pk2(1.0f));
+    }
+    const f32x2 l = pk_fma(lw, pk2(LN2_HI), d * rw);
+    const f32x2 zr = {relu1(z.x), relu1(z.y)};
+    sp = pk_fma(l, pk2(C_HI), pk_fma(l, pk2(C_LO), zr));
+}
+// (single-value forms for the few call sites that are not in the per-layer loops)
 __device__ __forceinline__ void softplus100_sig(float z, float& sp, float& s) {
-    float t = z * 100.0f;
-    float u = exp_neg_abs(fabsf(t));
-    const float w = 1.0f + u;
-    const float rw = __builtin_amdgcn_rcpf(w);     // 1 ulp
-    float l = log1p_unit(u, w, rw);
-    float r = fmaf(fmaf(-w, rw, 1.0f), rw, rw);    // one Newton step: 1 / w to ~0.5 ulp without the IEEE division sequence
-    s = t >= 0.0f ? r : u * r;
-    // x / 100 correctly rounded without the IEEE division sequence (its length makes hipcc branch around it)
-    float x = relu1(t) + l;
-    float q = x * 0.01f;
-    q = fmaf(fmaf(-q, 100.0f, x), 0.01f, q);
-    sp = t > 20.0f ? z : q;
+    f32x2 a, b;
+    softplus100_pair<true>(f32x2{z, z}, a, b);
+    sp = a.x; s = b.x;
 }
 __device__ __forceinline__ float softplus100(float z) {
-    float sp, s;
-    softplus100_sig(z, sp, s);
-    return sp;
+    f32x2 a, b;
+    softplus100_pair<false>(f32x2{z, z}, a, b);
+    return a.x;
 }
 __device__ __forceinline__ float sigmoidf_(float x) {
     float u = exp_neg_abs(fabsf(x));

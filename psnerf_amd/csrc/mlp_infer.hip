@@ -272,16 +272,32 @@ __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) {
         floatx4 o, o2;
+        if constexpr (CODE == PSN_ACT_SOFTPLUS100) {  // two packed pairs per tile (common.h)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x2 a, sg;
+                softplus100_pair<true>(f32x2{acc[mt][2 * h], acc[mt][2 * h + 1]}, a, sg);
+                o[2 * h] = a.x; o[2 * h + 1] = a.y; o2[2 * h] = sg.x; o2[2 * h + 1] = sg.y;
+            }
+        } else if constexpr (CODE == PSN_ACT_MUL_AUX || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD) {
+            // packed pairs (same operations in the same order as the element-wise expressions, two values per instruction)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x2 z = {acc[mt][2 * h], acc[mt][2 * h + 1]};
+                const f32x2 a1 = {t1[mt][2 * h], t1[mt][2 * h + 1]};
+                f32x2 a, b = z;
+                if constexpr (CODE == PSN_ACT_MUL_AUX) a = z * a1;
+                else if constexpr (CODE == PSN_ACT_MUL2) { a = z * a1; b = z * f32x2{t2[mt][2 * h], t2[mt][2 * h + 1]}; }
+                else a = pk_fma(a1, z, ((1.0f - a1) * 100.0f) * f32x2{t2[mt][2 * h], t2[mt][2 * h + 1]});  // t1 z + 100 (1 - t1) t2
+                o[2 * h] = a.x; o[2 * h + 1] = a.y; o2[2 * h] = b.x; o2[2 * h + 1] = b.y;
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float z = acc[mt][r];
             o2[r] = z;
             if constexpr (CODE == PSN_ACT_RELU) o[r] = relu1(z);
-            else if constexpr (CODE == PSN_ACT_SOFTPLUS100) { float a, sg; softplus100_sig(z, a, sg); o[r] = a; o2[r] = sg; }
             else if constexpr (CODE == PSN_ACT_RELU_MASK) o[r] = t1[mt][r] > 0.0f ? z : 0.0f;
-            else if constexpr (CODE == PSN_ACT_MUL_AUX) o[r] = z * t1[mt][r];
-            else if constexpr (CODE == PSN_ACT_MUL2) { o[r] = z * t1[mt][r]; o2[r] = z * t2[mt][r]; }
-            else if constexpr (CODE == PSN_ACT_SOFTPLUS_BWD) o[r] = fmaf(t1[mt][r], z, 100.0f * (1.0f - t1[mt][r]) * t2[mt][r]);
             else o[r] = z;
         }
         act[mt] = o;
@@ -627,7 +643,11 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) act[mt][r] = softplus100(acc[mt][r]);
+                    for (int h = 0; h < 2; ++h) {
+                        f32x2 a, unused;
+                        softplus100_pair<false>(f32x2{acc[mt][2 * h], acc[mt][2 * h + 1]}, a, unused);
+                        act[mt][2 * h] = a.x; act[mt][2 * h + 1] = a.y;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -913,10 +933,16 @@ __global__ __launch_bounds__(256) void root_find_fp_kernel(InferArgs g) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 floatx4 o;
+                if (L.act == PSN_ACT_SOFTPLUS100) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float z = acc[m][r];
-                    o[r] = L.act == PSN_ACT_SOFTPLUS100 ? softplus100(z) : (L.act == PSN_ACT_RELU ? relu1(z) : z);
+                    for (int h = 0; h < 2; ++h) {
+                        f32x2 a, unused;
+                        softplus100_pair<false>(f32x2{acc[m][2 * h], acc[m][2 * h + 1]}, a, unused);
+                        o[2 * h] = a.x; o[2 * h + 1] = a.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = L.act == PSN_ACT_RELU ? relu1(acc[m][r]) : acc[m][r];
                 }
                 st4(xw + 16 * m, o);
             }
