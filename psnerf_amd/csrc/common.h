@@ -100,7 +100,7 @@ __device__ __forceinline__ f32x2 pk2(float a) { return f32x2{a, a}; }
 //       ~2^-48 |t|), so u carries the ~1 ulp of v_exp_f32 for |t| <= 100;
 //   log1p(u) = log2(w) ln2 + (u - (w - 1)) / w,  w = fl(1 + u): the classic rounding correction; it is O(2^-24) of the result
 //       unless u is tiny, where w -> 1: 1 / w ~ 1 - c + c^2 / 2 (c = w - 1; exact at c = 0 and c = 1, 6 % off in between,
-//       i.e. < 1e-8 of the result) -- no reciprocal.  Max relative error of the pair 1.5e-7 (tools/dbg/check_log1p.py);
+//       i.e. < 1e-8 of the result) -- no reciprocal (tests/test_kernels_gpu.py::test_softplus100_accuracy_against_float64);
 //   / beta: l * 0.01 with the constant split into two floats (0.01f is 2.2e-8 off 1 / 100).
 // WITH_SIG: also s = sigmoid(beta x) = d softplus / dx from the same exponential (one reciprocal + a Newton step: 0.5 ulp).
 template <bool WITH_SIG>

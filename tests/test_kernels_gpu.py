@@ -1005,3 +1005,32 @@ def test_stage1_fused_losses_global_counts_hook(cuda):
         assert abs(float(t1[i]) * 2 - float(t0[i])) <= 1e-6 * abs(float(t0[i]))
     for a_, b_ in zip(outs[0][1:], outs[1][1:]):
         assert_close((b_ * 2).cpu(), a_.cpu(), 1e-6, 'gradient under doubled counts')
+
+
+def test_softplus100_accuracy_against_float64(cuda):
+    """The device softplus(beta = 100) + sigmoid (csrc/common.h softplus100_pair: packed fp32 pairs, hardware exp2 / log2, no
+    select for the threshold) against float64, next to torch's OWN fp32 softplus on the same inputs: the same error level
+    (both are dominated by the rounding of 100 z), exactly z above the threshold, and -- through the occupancy engine, which
+    uses the value-only form -- agreement of the two forms."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(0)
+    z = torch.cat([torch.rand(1 << 18, generator=g) * 1.3 - 0.8, torch.rand(1 << 18, generator=g) * 0.1 - 0.05,
+                   torch.randn(1 << 17, generator=g), torch.tensor([0.0, 0.2, 0.20000002, 0.19999999, -0.2, 1e-8, -1e-8, 3.0, -0.86])])
+    n = z.numel() // 64 * 64
+    z = z[:n].reshape(-1, 64).contiguous().to(cuda)
+    eye = torch.eye(64, device=cuda)
+    s_out = torch.empty_like(z)
+    sp = hip.gemm(z, eye, trans_b=True, bias=torch.zeros(64, device=cuda), epi=hip.EPI_BIAS_SOFTPLUS, aux_out=s_out)
+    z64 = z.double()
+    ref = torch.where(z64 * 100 > 20, z64, torch.log1p(torch.exp(torch.clamp(z64 * 100, max=50.0))) / 100)
+    ours = ((sp.double() - ref).abs() / ref)
+    theirs = ((torch.nn.functional.softplus(z, beta=100).double() - ref).abs() / ref)
+    ok = ref > 1e-36  # below: exp underflows in fp32, in torch as here
+    assert float(ours[ok].max()) <= 1.15 * float(theirs[ok].max()) + 1e-7, (float(ours[ok].max()), float(theirs[ok].max()))
+    assert float(ours[ok].mean()) <= 1.15 * float(theirs[ok].mean()) + 1e-8
+    above = z * 100 > 20
+    assert torch.equal(sp[above], z[above])  # torch returns x itself above the threshold; so does max(x, 0) + l / 100
+    sig_ref = torch.sigmoid(z64 * 100)
+    k = sig_ref > 1e-36
+    their_sig = ((torch.sigmoid(z * 100).double() - sig_ref).abs() / sig_ref)[k].max()
+    assert float(((s_out.double() - sig_ref).abs() / sig_ref)[k].max()) <= 1.15 * float(their_sig) + 1e-7
