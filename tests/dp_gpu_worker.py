@@ -107,11 +107,12 @@ def _stage1(rank, dev, checks):
     pix = torch.stack([torch.randint(0, 64, (n_rays,), generator=gen).float(),
                        torch.randint(0, 48, (n_rays,), generator=gen).float()], -1)[None]
 
-    def fresh(dp):
+    def fresh(dp, flat=False):
+        from psnerf_amd.optim import FlatAdam
         net = NeuralNetwork(cfg)
         net.load_state_dict(sd)
         ren = Renderer(net, cfg, device=dev)
-        return net, ren, Trainer(ren, torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=dev, dp=dp)
+        return net, ren, Trainer(ren, (FlatAdam if flat else torch.optim.Adam)(net.parameters(), lr=1e-4), cfg, device=dev, dp=dp)
 
     dp = pdist.DataParallel(dev)
     net, ren, tr = fresh(dp)
@@ -134,7 +135,7 @@ def _stage1(rank, dev, checks):
     # trainer slices them with the pixels).  Two steps whose global sizes differ while rank 0's shard keeps its size
     # (129 -> 65 / 64, 130 -> 65 / 65): the rgb denominator used to be cached by local size with the collective skipped on a hit.
     sf = []
-    net_s, ren_s, tr_s = fresh(pdist.DataParallel(dev))
+    net_s, ren_s, tr_s = fresh(pdist.DataParallel(dev), flat=True)  # optim.FlatAdam on the bucket views; the single-process reference below: torch.optim.Adam
     calls = []
     inner = ren_s._unisurf_sync_free
     ren_s._unisurf_sync_free = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
