@@ -246,7 +246,7 @@ class Renderer(nn.Module):
         if (self.FUSED_GLUE and pixels.is_cuda and B == 1 and tuple(world_mat.shape[1:]) == (4, 4) and pixels.dtype == torch.float32
                 and pixels.is_contiguous()):
             # origins, normalised directions and sphere exit depths in one launch (psn_stage1_rays) instead of ~25
-            cam, rays, far = hip.stage1_rays(pixels[0], camera_mat[0].contiguous(), world_mat[0].contiguous(), self.cfg['radius'])
+            cam, rays, far = hip.stage1_rays(pixels[0], camera_mat[0].float().contiguous(), world_mat[0].float().contiguous(), self.cfg['radius'])
             cam, rays, far = cam.unsqueeze(0), rays.unsqueeze(0), far.unsqueeze(0)
         else:
             cam = camera_origin(N, world_mat)

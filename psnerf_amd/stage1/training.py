@@ -154,9 +154,9 @@ class Trainer(object):
                 return None if t is None else t.to(dev).reshape(h, w).float().contiguous()
             cos_t = float(np.cos(np.deg2rad(self.angle))) if (want_normal and self.angle is not None) else None
             rgb_gt, mask_gt, mask_valid, norm_mask_gt, normal_gt = hip.stage1_targets(
-                pix[0], img[0].contiguous(), plane('img.mask'), plane('img.mask_valid'),
-                normal[0].contiguous() if want_normal else None, norm_mask.reshape(h, w).float().contiguous() if self.normal_loss else None,
-                world_mat[0].contiguous() if want_normal else None, cos_t, want_normal)
+                pix[0], img[0].float().contiguous(), plane('img.mask'), plane('img.mask_valid'),
+                normal[0].float().contiguous() if want_normal else None, norm_mask.reshape(h, w).float().contiguous() if self.normal_loss else None,
+                world_mat[0].float().contiguous() if want_normal else None, cos_t, want_normal)
             rgb_gt, mask_gt, mask_valid = rgb_gt.unsqueeze(0), mask_gt.unsqueeze(0), mask_valid.unsqueeze(0)
             norm_mask_gt = norm_mask_gt.unsqueeze(0) if norm_mask_gt is not None else None
             normal_gt = normal_gt.unsqueeze(0) if normal_gt is not None else None
