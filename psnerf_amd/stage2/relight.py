@@ -113,6 +113,11 @@ def render_envmap(model, model_input, env_light, light_h=16, light_batch=64, pix
     # parts (positional encodings, BRDF and normal nets) once per chunk instead of once per (chunk, light batch)
     chunks = [dict(model_input)] if pixel_chunk is None else split_input(model_input, n_pix, pixel_chunk)
     model._eval_cache = {}
+    # only the light sum of the shaded colour (and the visibility, if asked for) is consumed: the model then writes no other
+    # dense [L, N, C] output and reduces the lights on the surface rows (PSNetwork._eval_outputs)
+    fast = hasattr(model, '_eval_outputs')
+    if fast:
+        model._eval_outputs = {'sg_rgb_light_sum'} | ({'visibility'} if visibility else set())
     try:
         for l0 in range(0, n_lights, light_batch):
             light_direction = F.normalize(lxyz[l0:l0 + light_batch], p=2, dim=-1)
@@ -122,11 +127,21 @@ def render_envmap(model, model_input, env_light, light_h=16, light_batch=64, pix
                 s['light_direction'], s['light_intensity'] = light_direction, light_intensity
                 out = model(s)
                 n = s['uv'].shape[1]
-                rgb_sum[p0:p0 + n] += out['sg_rgb_values'].reshape(-1, n, 3).sum(0)
+                if fast:
+                    rows_sum, idx, const = out['sg_rgb_light_sum']
+                    batch_sum = torch.full((n, 3), const, device=dev)  # what out['sg_rgb_values'].sum(0) holds: the fill summed
+                    if rows_sum is not None:                            # over the batch's lights, the row sums at the surface pixels
+                        batch_sum[idx] = rows_sum
+                    rgb_sum[p0:p0 + n] += batch_sum
+                else:
+                    rgb_sum[p0:p0 + n] += out['sg_rgb_values'].reshape(-1, n, 3).sum(0)
                 if visibility:
-                    vis_sum[p0:p0 + n] += out.get('visibility', torch.ones_like(out['sg_rgb_values'])).reshape(-1, n, 3).sum(0)
+                    vis = out.get('visibility')
+                    vis_sum[p0:p0 + n] += vis.reshape(-1, n, 3).sum(0) if vis is not None else float(light_direction.shape[0])
                 p0 += n
     finally:
         model._eval_cache = None
+        if fast:
+            model._eval_outputs = None
     rgb = rgb_sum.clamp(0, 1)
     return (rgb, vis_sum / n_lights) if visibility else rgb

@@ -181,6 +181,7 @@ class PSNetwork(nn.Module):
         # stage2/eval.py:199-218) on the bf16 MFMA engine.  Never used while gradients are enabled.
         self.inference_precision = 'fp32'
         self._eval_cache = None  # dict while an evaluation loop over light batches is running (see _memo)
+        self._eval_outputs = None  # set of output keys while an evaluation loop wants only those (see the end of forward)
         # opt-in, NOT the reference's arithmetic (default off; every parity test and the headline benchmark run without
         # it): during training, the L shading-light visibility rows -- which only enter the loss detached,
         # renderer.py:197 -- are evaluated on the bf16 engine (max |d| ~ 2e-3 on the visibility value).
@@ -563,6 +564,16 @@ class PSNetwork(nn.Module):
                 out['vis_train'] = vt
         if sg:
             out['sg_weight'] = weight_values
+        want = self._eval_outputs
+        if want is not None:
+            # an evaluation loop (relight.render_envmap) that consumes a few outputs only: the others are never written, and
+            # 'sg_rgb_light_sum' = (sum over this batch's lights of the surface rows [Ns, 3], idx [Ns], the constant every
+            # other pixel sums to) replaces the dense [L, N, 3] tensor + its reduction (eval.py:218 sums the lights anyway)
+            if 'sg_rgb_light_sum' in want:
+                v = out['sg_rgb_values']
+                rows_sum = v.rows.reshape(v.B, -1, v.C).sum(0) if v.rows is not None else None
+                out['sg_rgb_light_sum'] = (rows_sum, idx if v.rows is not None else None, v.fill * v.B)
+            out = {k: v for k, v in out.items() if k in want}
         # write every dense output: one launch for those that carry surface rows, constant fills for the others
         lazy = {}  # id -> _Dense (one object may sit under two keys: 'rough_values' of the jitter dict is 'sg_weight')
         for v in out.values():
