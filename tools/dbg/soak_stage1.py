@@ -13,7 +13,9 @@ out = []
 for run in range(2):
     torch.manual_seed(42)
     net = NeuralNetwork(cfg)
-    tr = Trainer(Renderer(net, cfg, device=dev), torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=dev)
+    from psnerf_amd.optim import FlatAdam
+    ren = Renderer(net, cfg, device=dev)
+    tr = Trainer(ren, FlatAdam(net.parameters(), lr=1e-4), cfg, device=dev)
     bd = {k: v.to(dev) for k, v in batch.items()}
     torch.manual_seed(7)
     for i in range(steps):
