@@ -39,6 +39,23 @@ def test_envmap_relight_vs_oracle(cuda):
     out2, vis = relight.render_envmap(net, base_d, env, light_h=lh, light_batch=32, pixel_chunk=256, visibility=True)
     assert_close(out2.cpu(), ref, 1e-4, 'relit rgb (chunked)', atol=ATOL_UNIT)
     assert vis.shape == (N, 3)
+    # the loop's short cut (PSNetwork._eval_outputs: lights summed on the surface rows, no other dense output written) against
+    # the plain formulation (every dense output of the model, out['sg_rgb_values'].sum(0)): same image, same visibility
+    class Plain(object):  # hides _eval_outputs from render_envmap, forwards everything else
+        def __init__(self, m):
+            object.__setattr__(self, 'm', m)
+        def __getattr__(self, k):
+            if k == '_eval_outputs':
+                raise AttributeError(k)
+            return getattr(object.__getattribute__(self, 'm'), k)
+        def __setattr__(self, k, v):
+            setattr(object.__getattribute__(self, 'm'), k, v)
+        def __call__(self, *a, **kw):
+            return object.__getattribute__(self, 'm')(*a, **kw)
+    out3, vis3 = relight.render_envmap(Plain(net), base_d, env, light_h=lh, light_batch=32, pixel_chunk=256, visibility=True)
+    assert net._eval_outputs is None and net._eval_cache is None
+    assert_close(out2.cpu(), out3.cpu(), 1e-6, 'short cut vs plain loop', atol=1e-7)
+    assert torch.equal(vis, vis3)
 
 
 def test_handoff_roundtrip_and_checkpoints(cuda, tmp_path):
