@@ -28,7 +28,13 @@ Extra objects on the JSON line (all measured after the headline's timed region):
   bf16x6_experiment  opt-in experiment, NOT the headline: the same step with the gradient-free L x Ns visibility rows on the
                 split-bf16 engine (csrc/mlp_infer_x3.hip): f32-class results (same oracle gate) from the bf16 matrix pipe
   cpu_baseline  the CPU oracle (oracle/stage2.py, a verified restatement of the reference) on this host, N = 1 only
-  strong        strong-scaling measurement (fixed global batch)
+  strong        strong-scaling measurement (fixed 262144-pixel global batch: the weak per-GPU load at N = 8)
+  strong_cfg4   BASELINE cfg 4 as BASELINE.md / SURVEY 8e define it: cfg 3's 32768-pixel batch sharded by pixels over the N
+                ranks (32768 / N px per rank, full light set), timed eagerly and replayed from HIP graphs
+                (psnerf_amd/stage2/graph.py); at N = 1 additionally ``per_rank_projection``: the rank shards of N = 2, 4, 8
+                (16384 / 8192 / 4096 px) timed on this one GPU with the data-parallel code path ON (RCCL in a world of one rank)
+  parity        N = 1: the cpu_baseline's oracle step and the HIP step on the SAME 4096-px inputs, weights and jitter draw:
+                max relative error of sg_rgb_values, relative loss error, PSNR(HIP) - PSNR(oracle) of the rendered batch
   allreduce_ms  average time of one gradient all-reduce of the step's bucket size (N > 1)
   stage1        BASELINE configs[1] (stage-1 BEAR train step, 4096 rays x 128 samples, 256 march steps), N = 1 only:
                 ms/step, ray-samples/s, rooflines of the chain engine, the weight-gradient GEMM and the composite
@@ -52,7 +58,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
 
 
-def make_step(device, seed=0):
+def make_step(device, seed=0, dp=None):
     import torch
     import psnerf_amd.stage2 as s2
     conf = s2.bear_conf()
@@ -61,7 +67,7 @@ def make_step(device, seed=0):
     g = torch.Generator().manual_seed(seed + 1)
     light_init = torch.nn.functional.normalize(torch.randn(N_LIGHTS_TOTAL, 3, generator=g), dim=-1)
     light_init[:, 2] = light_init[:, 2].abs() + 0.2
-    step = s2.TrainStep(net, conf, N_LIGHTS_TOTAL, light_init.to(device), device)
+    step = s2.TrainStep(net, conf, N_LIGHTS_TOTAL, light_init.to(device), device, dp=dp)
     step.cur_iter = 5001  # phase 2 of train_fix: every net and the lights are trainable
     return step
 
@@ -89,6 +95,50 @@ def _cpu_steps(n_pixels, steps):
         dt = time.time() - t0
         best = dt if best is None else min(best, dt)
     return ns, best
+
+
+def parity_check(device, n_pixels=4096):
+    """The metric's "PSNR parity" on the bench line: one full train step of the oracle (CPU) and of the HIP path on the same
+    4096-px x L = 96 x V = 8 batch (the cpu_baseline's sample), the same weights and the same injected jitter draw."""
+    import math
+    import torch
+    from oracle import stage2 as o2  # checker only
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.synthetic import stage2_inputs
+    torch.manual_seed(0)
+    onet = o2.PSNetwork(o2.bear_conf())
+    net = s2.PSNetwork(s2.bear_conf())
+    net.load_state_dict(onet.state_dict())
+    net.to(device)
+    g = torch.Generator().manual_seed(1)
+    light_init = torch.nn.functional.normalize(torch.randn(N_LIGHTS_TOTAL, 3, generator=g), dim=-1)
+    light_init[:, 2] = light_init[:, 2].abs() + 0.2
+    ostep = o2.TrainStep(onet, o2.bear_conf(), N_LIGHTS_TOTAL, light_init)
+    step = s2.TrainStep(net, s2.bear_conf(), N_LIGHTS_TOTAL, light_init.to(device), device)
+    ostep.cur_iter = step.cur_iter = 5001
+    inp, gt = stage2_inputs(n_pixels, N_LIGHTS, N_VIS, seed=3)
+    ns = int(inp['surface_mask'].sum())
+    nz = torch.randn(ns, 3, generator=g) * 0.01
+    l_slt = torch.arange(N_LIGHTS) + 96 * 3
+    ot, oo = ostep.step(inp, gt, l_slt, train_order=False, noise={'xyz': nz})
+    pt, po = step.step({k: v.to(device) for k, v in inp.items()}, {k: v.to(device) for k, v in gt.items()}, l_slt.to(device),
+                       train_order=False, noise={'xyz': nz.to(device)})
+    a, b = po['sg_rgb_values'].detach().cpu().double(), oo['sg_rgb_values'].detach().double()
+    m = (inp['surface_mask'] & inp['object_mask']).expand(N_LIGHTS, -1)
+
+    def psnr(x):  # stage2/trainer.py:268-276 on the masked pixels of all lights
+        return -10.0 * math.log10(float(((x[m] - gt['rgb'].double()[m]) ** 2).mean()))
+    # elementwise bound of the parity tests: 1e-4 |ref| + 1e-6 (colours in [0, 1])
+    ratio = ((a - b).abs() / (1e-4 * b.abs() + 1e-6))
+    lo, lh = float(ot['total'].detach()), float(pt['total'].detach())
+    pd = max(float((p.detach().cpu() - q.detach()).abs().max()) for p, q in zip(net.parameters(), onet.parameters()))
+    return {'sample': '%d px (%d surface) x L=%d, V=%d, phase 2, one full step, same weights / batch / jitter draw' % (n_pixels, ns, N_LIGHTS, N_VIS),
+            'sg_rgb_max_rel_err': float(((a - b).abs().max() / b.abs().max())), 'sg_rgb_worst_over_bound': round(float(ratio.max()), 3),
+            'sg_rgb_frac_beyond_bound': float((ratio > 1).double().mean()), 'bound': '1e-4 |ref| + 1e-6 elementwise',
+            'loss_hip': lh, 'loss_oracle': lo, 'loss_rel_err': abs(lh - lo) / abs(lo),
+            'psnr_hip_db': round(psnr(a), 5), 'psnr_oracle_db': round(psnr(b), 5), 'psnr_diff_db': round(psnr(a) - psnr(b), 6),
+            'max_param_diff_after_step': pd,
+            'horizon': 'one step here; 300 stage-2 / 200 stage-1 steps: tests/test_convergence_gpu.py (PSNR within 0.05 dB)'}
 
 
 def cpu_baseline(n_pixels=4096, steps=3):
@@ -207,6 +257,103 @@ def stage1_measure(device, steps=10, warmup=3, rays=4096):
                          'note': '4096 rays = 10-19 MB per launch: launch/latency-bound at this size; the HBM roofline of '
                                  'the kernel is measured at 2M rays by tools/bench_composite.py (profiles/)'}
     return out
+
+
+# ----------------------------------------------------------------------------------------------- cfg 4 (strong scaling of cfg 3)
+def time_steps(fn, steps, warmup, world, device):
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        fn()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, t1 - t0], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0]) / steps * 1e3, float(t[1]) / steps * 1e3
+
+
+def cfg4_case(device, dp, px_global, rank, world, steps, modes=('eager', 'graph')):
+    """One stage-2 step of cfg 3's batch of ``px_global`` pixels sharded over the ranks of ``dp``: ms/step (max over ranks)
+    and host issue time, eagerly and replayed from HIP graphs (fresh TrainStep each: same weights, same batch)."""
+    import torch
+    import torch.distributed as dist
+    from psnerf_amd.synthetic import stage2_inputs
+    from psnerf_amd.stage2.graph import GraphedTrainStep
+    l_slt = torch.arange(N_LIGHTS, device=device) + 96 * 3
+    inp, gt = stage2_inputs(px_global, N_LIGHTS, N_VIS, seed=100, device=device, with_surface_idx=True)
+    if world > 1:
+        inp, gt = dp.shard_stage2(inp, gt)
+    ns = torch.tensor([int(inp['surface_mask'].sum())], device=device, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(ns, op=dist.ReduceOp.SUM)
+    out = {'pixels_per_gpu': inp['uv'].shape[1], 'surface_pixels_total': int(ns.item())}
+    for mode in modes:
+        step = make_step(device, dp=dp)
+        if mode == 'eager':
+            fn = lambda: step.step(inp, gt, l_slt, train_order=False)
+        else:
+            run = GraphedTrainStep(step)
+            fn = lambda: run.step(inp, gt, l_slt, train_order=False)
+        ms, host_ms = time_steps(fn, steps, 5, world, device)
+        out[mode] = {'ms_per_step': round(ms, 3), 'host_issue_ms': round(host_ms, 3),
+                     'value': round(out['surface_pixels_total'] * N_LIGHTS / (ms * 1e-3), 1)}
+        del step, fn
+    return out
+
+
+def strong_cfg4(device, dp, rank, world, steps=40):
+    """BASELINE cfg 4 = cfg 3 (32768 px) sharded by pixels over the ranks (stage2/trainer.py:355-410 is the step
+    being sharded).  At N = 1 the rank shards of N = 2, 4, 8 are timed on this GPU as well, with the data-parallel code path
+    ON (a process group of one rank on RCCL): count all-reduce, flat-bucket gather + all-reduce, Adam on the bucket."""
+    import torch
+    import torch.distributed as dist
+    from psnerf_amd import dist as pdist
+    res = {'scaling': 'strong', 'global_pixels': N_PIXELS, 'unit': 'ray-samples/s', 'steps': steps, 'warmup': 5,
+           'definition': 'BASELINE cfg 4: the 32768-px batch of cfg 3 split by pixels over N ranks, full light set per rank'}
+    made_pg = False
+    try:
+        if world == 1 and not (dist.is_available() and dist.is_initialized()):
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', LOCAL_RANK=str(device.index or 0), WORLD_SIZE='1')
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            dist.init_process_group(backend='nccl', rank=0, world_size=1)
+            made_pg = True
+        dpf = pdist.DataParallel(device, force=True)
+        res['data_parallel_path'] = bool(dpf.enabled)
+        case = cfg4_case(device, dpf, N_PIXELS, rank, world, steps)
+        res.update(case)
+        best = min(('eager', 'graph'), key=lambda m: case[m]['ms_per_step'])
+        res['value'], res['ms_per_step'], res['mode'] = case[best]['value'], case[best]['ms_per_step'], best
+        if world == 1:
+            proj = {}
+            for n in (2, 4, 8):
+                c = cfg4_case(device, dpf, N_PIXELS // n, rank, world, steps)
+                bm = min(('eager', 'graph'), key=lambda m: c[m]['ms_per_step'])
+                proj[str(n)] = {'pixels_per_rank': N_PIXELS // n, 'eager_ms': c['eager']['ms_per_step'], 'graph_ms': c['graph']['ms_per_step'],
+                                'eager_host_issue_ms': c['eager']['host_issue_ms'], 'graph_host_issue_ms': c['graph']['host_issue_ms'],
+                                'projected_speedup_vs_1': round(res['ms_per_step'] / c[bm]['ms_per_step'], 3),
+                                'fraction_of_linear': round(res['ms_per_step'] / c[bm]['ms_per_step'] / n, 3)}
+            res['per_rank_projection'] = proj
+            res['projection_note'] = ('one GPU, world of one rank: RCCL executes every collective of the step, but a 1-rank all-reduce '
+                                      'moves nothing -- the 2.7 MB bucket all-reduce over xGMI comes on top at N > 1 (allreduce_ms of the N > 1 lines)')
+    except Exception as e:  # noqa: BLE001  (a diagnostic object must not take the headline down)
+        res['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+    finally:
+        if made_pg:
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+    return res
 
 
 # ----------------------------------------------------------------------------------------------- self-launch
@@ -396,6 +543,9 @@ def main():
         if world > 1:
             allreduce_ms = round(step.dp.time_allreduce(step.dp.allreduce_bytes // 4), 4)
     bucket_bytes = step.dp.allreduce_bytes
+    cfg4 = None
+    if not args.no_extra:
+        cfg4 = strong_cfg4(device, step.dp, rank, world)
 
     stage1 = None
     if world == 1 and not args.no_stage1:
@@ -442,8 +592,12 @@ def main():
                             'dispatch (rocprofv3 PMC, profiles/pmc_traffic.json; Infinity-Cache hits included), algorithmic_bytes = '
                             'compulsory HBM bytes (tables and weights once, outputs, activation dumps of the V supervised rows); the '
                             'ratio is re-read traffic of the init tables served by L2 / MALL on an MFMA-bound kernel'}
-    cpu = None
+    cpu = parity = None
     if not args.no_cpu_baseline and world == 1:  # the CPU oracle is timed at N = 1 only (other ranks would idle behind it)
+        try:
+            parity = parity_check(device)
+        except Exception as e:  # noqa: BLE001
+            parity = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         cpu = cpu_baseline()
     line = {
         'metric': 'ray-samples/sec (train step) on BEAR stage2', 'value': round(value, 1), 'unit': 'ray-samples/s',
@@ -451,7 +605,10 @@ def main():
         'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'stage2 BEAR BRDF+light joint opt (BASELINE configs[2]): %d px/GPU (%d surface total), '
                                'L=96 shading lights, V=8 visibility lights, sgbasis RGB 9 lobes, visibility + vis_loss on, '
-                               'train_fix phase 2, full step (fwd+loss+bwd+Adam+SparseAdam)' % (px_local, ns_total),
+                               'train_fix phase 2, full step (fwd+loss+bwd+Adam+SparseAdam); the batch carries its V supervision '
+                               'lights ready-made -- the per-step train.vis_plus draw of bear.conf:29 (stage2/trainer.py:384-392: one '
+                               'np.random.choice + a two-index device gather, psnerf_amd.stage2.trainer.VisPlus) is NOT inside the timed '
+                               'step, as BASELINE cfg 3 does not list it' % (px_local, ns_total),
                    'pixels_per_gpu': px_local, 'surface_pixels_total': ns_total, 'lights': N_LIGHTS,
                    'vis_lights': N_VIS, 'parallelism': 'pixel-dp%d' % world,
                    'batch': "ViewSampler.batch layout: reference dictionary + 'surface_idx' (host-built index list of the surface mask)"},
@@ -459,6 +616,7 @@ def main():
         'roofline': roofline, 'cpu_baseline': cpu, 'reference_dict': ref_dict, 'launches_per_step': launches,
         'bf16x6_experiment': x6,
         ('strong' if args.scaling == 'weak' else 'weak'): other,
+        'strong_cfg4': cfg4, 'parity': parity,
         'allreduce_ms': allreduce_ms, 'allreduce_bytes': bucket_bytes if world > 1 else None,
         'stage1': stage1,
     }

@@ -321,7 +321,8 @@ int psn_mlp_infer_pe_indirect(const PsnMlpDesc* desc, const float* packed_w, con
  * encoded inside the kernel -- no [n_rays, n_steps, 3] point tensor, same bits as psn_sample_points + psn_mlp_infer_pe.
  * One workgroup = 64 consecutive steps of one ray (n_steps % 64 == 0), workgroups in block-major order.  skip: int32
  * [n_rays], ZEROED by the caller, or NULL: a block that contains a sign change of (occ - tau) between neighbouring steps
- * (or a ray whose first value is not free) raises the ray's flag and the ray's later blocks are not evaluated -- their
+ * (or a ray whose first value is not free) records its block index in the ray's flag (INT_MAX - block, the lowest block
+ * wins; 0 = none) and only blocks BEHIND the recorded one leave unevaluated, whatever order the workgroups ran in -- their
  * entries of occ stay untouched; every value up to and including the pair of the FIRST sign change is always written,
  * which is all psn_first_crossing reads.  n_blocks: NULL, or a device counter that receives the number of 64-step blocks
  * evaluated (measurement).  desc / packed_w / packed_b as for psn_root_find.  occ [n_rays, n_steps]. */
@@ -415,6 +416,10 @@ typedef struct {
     float one_minus_beta1, one_minus_beta2, eps, step_size;  /* 1 - beta computed in double by the caller, like torch */
 } PsnRowAdamItem;
 int psn_row_adam(int n_items, const PsnRowAdamItem* items, const int64_t* idx, int n_idx, void* stream);
+/* The same launch with the step sizes read from DEVICE memory (step_sizes_dev [n_items], item i uses element i; the host
+ * values in items[] are ignored): identical from step to step, so it can be replayed from a HIP graph while the host
+ * refreshes the scalars (psnerf_amd/stage2/graph.py; the lr schedule and the bias corrections of stage2/trainer.py:402-410,462-464). */
+int psn_row_adam_dev(int n_items, const PsnRowAdamItem* items, const int64_t* idx, int n_idx, const float* step_sizes_dev, void* stream);
 
 /* ------------------------------------------------------------------------
  * The launch-bound tail of a stage-2 train step as single kernels (csrc/small.hip).
@@ -469,6 +474,11 @@ typedef struct {
 } PsnAdamSeg;
 int psn_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n_segs, const PsnAdamSeg* segs,
                   float one_minus_beta1, float beta2, float one_minus_beta2, float eps, void* stream);
+/* psn_adam_flat with (neg_step_size, bias_correction2_sqrt) of range i read from DEVICE memory, seg_scalars_dev[2 i],
+ * seg_scalars_dev[2 i + 1] (the host values in segs[] are ignored): a launch that is identical from step to step (HIP-graph
+ * replay; the host refreshes the scalars before each replay). */
+int psn_adam_flat_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n_segs, const PsnAdamSeg* segs,
+                      float one_minus_beta1, float beta2, float one_minus_beta2, float eps, const float* seg_scalars_dev, void* stream);
 
 /* ------------------------------------------------------------------------
  * Weight normalisation of up to PSN_WN_MAX_ITEMS layers in one launch: nn.utils.weight_norm(nn.Linear) as used by every

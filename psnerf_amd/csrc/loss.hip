@@ -279,11 +279,13 @@ extern "C" int psn_stage2_loss_bwd(const float* g_total, const float* rgb, const
 // One thread per table row: the row moves iff it is among idx[0..n_idx) (the lights of this step; duplicates allowed),
 // with torch's sparse_adam arithmetic: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); p += -step_size m / (sqrt(v) + eps).
 namespace psn {
-struct RowAdamArgs { PsnRowAdamItem it[PSN_ROW_ADAM_MAX]; const int64_t* idx; int n_idx; int n; };
+struct RowAdamArgs { PsnRowAdamItem it[PSN_ROW_ADAM_MAX]; const int64_t* idx; int n_idx; int n;
+                     const float* dev; };  // dev: nullptr, or [n] step sizes ON THE DEVICE that replace it[i].step_size
 __global__ __launch_bounds__(256) void row_adam_kernel(RowAdamArgs a) {
     const int item = blockIdx.y;
     if (item >= a.n) return;
-    const PsnRowAdamItem it = a.it[item];
+    PsnRowAdamItem it = a.it[item];
+    if (a.dev != nullptr) it.step_size = a.dev[item];
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= it.rows) return;
     bool touched = false;
@@ -302,10 +304,11 @@ __global__ __launch_bounds__(256) void row_adam_kernel(RowAdamArgs a) {
 }
 }  // namespace psn
 
-extern "C" int psn_row_adam(int n_items, const PsnRowAdamItem* items, const int64_t* idx, int n_idx, void* stream) {
+static int row_adam_impl(int n_items, const PsnRowAdamItem* items, const int64_t* idx, int n_idx, const float* step_sizes_dev, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(items && idx && n_items >= 1 && n_items <= PSN_ROW_ADAM_MAX && n_idx >= 0, "row_adam: bad arguments");
     RowAdamArgs a = {};
+    a.dev = step_sizes_dev;
     int64_t max_rows = 0;
     for (int i = 0; i < n_items; ++i) {
         PSN_CHECK_ARG(items[i].param && items[i].grad && items[i].exp_avg && items[i].exp_avg_sq && items[i].rows >= 0 && items[i].cols >= 1,
@@ -318,6 +321,17 @@ extern "C" int psn_row_adam(int n_items, const PsnRowAdamItem* items, const int6
     hipLaunchKernelGGL(row_adam_kernel, dim3((unsigned)((max_rows + 255) / 256), n_items), dim3(256), 0, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("row_adam");
     return PSN_OK;
+}
+
+extern "C" int psn_row_adam(int n_items, const PsnRowAdamItem* items, const int64_t* idx, int n_idx, void* stream) {
+    return row_adam_impl(n_items, items, idx, n_idx, nullptr, stream);
+}
+
+// step sizes read from DEVICE memory (step_sizes_dev [n_items]): a launch that is identical from step to step (HIP-graph replay)
+extern "C" int psn_row_adam_dev(int n_items, const PsnRowAdamItem* items, const int64_t* idx, int n_idx, const float* step_sizes_dev,
+                                void* stream) {
+    PSN_CHECK_ARG(step_sizes_dev != nullptr, "row_adam_dev: step_sizes_dev is required");
+    return row_adam_impl(n_items, items, idx, n_idx, step_sizes_dev, stream);
 }
 
 extern "C" int psn_pair_sums(const float* x, int V, int64_t Ns, int C, float* sx, float* sl_part, int* n_chunks, void* stream) {

@@ -76,7 +76,7 @@ struct InferArgs {
     const float* omu;        // [n_steps] 1 - u
     float near;
     int n_steps;
-    int* skip;               // [n_rays] or nullptr: != 0 = an earlier block of this ray already holds its first sign change
+    int* skip;               // [n_rays] or nullptr: INT_MAX - b = block b of this ray holds a sign change (the lowest such b wins), 0 = none
     unsigned long long* n_blocks;  // optional: counts the 64-step blocks that were evaluated (measurement only)
 };
 
@@ -366,7 +366,14 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         m_ray = (int64_t)blockIdx.x % n_rays;
         const int blk = (int)((int64_t)blockIdx.x / n_rays);
         // (agent scope: the flag was raised by a workgroup that may have run on another XCD, whose L2 is not coherent with ours)
-        if (blk > 0 && g.skip != nullptr && __hip_atomic_load(g.skip + m_ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        // The flag holds INT_MAX - (lowest block index that saw the ray's first sign change), 0 = none yet: only blocks BEHIND
+        // that block may leave.  (A plain boolean would let block b leave when block b + 1 -- dispatched earlier on another
+        // XCD -- raised it first, and first_crossing would then read block b's unwritten values: HIP orders nothing between
+        // workgroups.)
+        if (blk > 0 && g.skip != nullptr) {
+            const int s = __hip_atomic_load(g.skip + m_ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s != 0 && 0x7fffffff - s < blk) return;
+        }
         m_step = blk * (kWaves * 16) + wave * 16 + lj;
         row_ = m_ray * g.n_steps + m_step;
         if (g.n_blocks != nullptr && threadIdx.x == 0) atomicAdd(g.n_blocks, 1ull);
@@ -802,7 +809,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             __syncthreads();
             if (tid < kWaves * 16 - 1) {
                 const bool hit = (xch[tid] * xch[tid + 1] < 0.0f) || (tid == 0 && m_step == 0 && !(xch[0] < 0.0f));
-                if (hit) __hip_atomic_store(g.skip + m_ray, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (hit) __hip_atomic_fetch_max(g.skip + m_ray, 0x7fffffff - m_step / (kWaves * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

@@ -105,9 +105,11 @@ __global__ __launch_bounds__(256) void camera_rays_kernel(const float* __restric
 //   den = sqrt(v) / bc2_sqrt + eps         _foreach_sqrt, _foreach_div_, _foreach_add_
 //   p = p + neg_step * (m / den)           _foreach_addcdiv_(value = -lr / bias_correction1)
 struct AdamSeg { int64_t off, goff, n; float neg_step, bc2_sqrt; };
-struct AdamArgs { float* p; const float* g; float* m; float* v; float w1, beta2, w2, eps; AdamSeg seg[PSN_ADAM_MAX_SEGS]; int n_seg; };
+struct AdamArgs { float* p; const float* g; float* m; float* v; float w1, beta2, w2, eps; AdamSeg seg[PSN_ADAM_MAX_SEGS]; int n_seg;
+                  const float* dev; };  // dev: nullptr, or [n_seg][2] floats ON THE DEVICE that replace (neg_step, bc2_sqrt) of every range
 __global__ __launch_bounds__(256) void adam_flat_kernel(AdamArgs a) {
-    const AdamSeg s = a.seg[blockIdx.y];
+    AdamSeg s = a.seg[blockIdx.y];
+    if (a.dev != nullptr) { s.neg_step = a.dev[2 * blockIdx.y]; s.bc2_sqrt = a.dev[2 * blockIdx.y + 1]; }
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < s.n; i += (int64_t)gridDim.x * 1024) {
         const int64_t e0 = s.off + i, ge0 = s.goff + i;
         const int cnt = s.n - i < 4 ? (int)(s.n - i) : 4;
@@ -193,16 +195,18 @@ extern "C" int psn_camera_rays(const float* uv, const float* pose, const float* 
     return PSN_OK;
 }
 
-extern "C" int psn_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n_segs, const PsnAdamSeg* segs,
-                             float one_minus_beta1, float beta2, float one_minus_beta2, float eps, void* stream) {
+static int adam_flat_impl(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n_segs, const PsnAdamSeg* segs,
+                          float one_minus_beta1, float beta2, float one_minus_beta2, float eps, const float* seg_scalars_dev, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && segs && n_segs >= 1 && n_segs <= PSN_ADAM_MAX_SEGS, "adam_flat: bad arguments (n_segs=%d)", n_segs);
     AdamArgs a = {};
+    a.dev = seg_scalars_dev;
     a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.w1 = one_minus_beta1; a.beta2 = beta2; a.w2 = one_minus_beta2; a.eps = eps;
     a.n_seg = n_segs;
     int64_t max_n = 0;
     for (int i = 0; i < n_segs; ++i) {
-        PSN_CHECK_ARG(segs[i].offset >= 0 && segs[i].grad_offset >= 0 && segs[i].n >= 0 && segs[i].bias_correction2_sqrt > 0.0f, "adam_flat: segment %d", i);
+        PSN_CHECK_ARG(segs[i].offset >= 0 && segs[i].grad_offset >= 0 && segs[i].n >= 0 && (seg_scalars_dev != nullptr || segs[i].bias_correction2_sqrt > 0.0f),
+                      "adam_flat: segment %d", i);
         a.seg[i].off = segs[i].offset; a.seg[i].goff = segs[i].grad_offset; a.seg[i].n = segs[i].n; a.seg[i].neg_step = segs[i].neg_step_size; a.seg[i].bc2_sqrt = segs[i].bias_correction2_sqrt;
         if (segs[i].n > max_n) max_n = segs[i].n;
     }
@@ -212,6 +216,21 @@ extern "C" int psn_adam_flat(float* param, const float* grad, float* exp_avg, fl
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks, (unsigned)n_segs), dim3(256), 0, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("adam_flat");
     return PSN_OK;
+}
+
+extern "C" int psn_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n_segs, const PsnAdamSeg* segs,
+                             float one_minus_beta1, float beta2, float one_minus_beta2, float eps, void* stream) {
+    return adam_flat_impl(param, grad, exp_avg, exp_avg_sq, n_segs, segs, one_minus_beta1, beta2, one_minus_beta2, eps, nullptr, stream);
+}
+
+// The same update with the step-dependent scalars of every range read from DEVICE memory (seg_scalars_dev [n_segs][2] =
+// neg_step_size, bias_correction2_sqrt): the launch is then identical from step to step and can be replayed from a HIP graph
+// while the host refreshes the scalars (stage2/graph.py).
+extern "C" int psn_adam_flat_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n_segs, const PsnAdamSeg* segs,
+                                 float one_minus_beta1, float beta2, float one_minus_beta2, float eps, const float* seg_scalars_dev,
+                                 void* stream) {
+    PSN_CHECK_ARG(seg_scalars_dev != nullptr, "adam_flat_dev: seg_scalars_dev is required");
+    return adam_flat_impl(param, grad, exp_avg, exp_avg_sq, n_segs, segs, one_minus_beta1, beta2, one_minus_beta2, eps, seg_scalars_dev, stream);
 }
 
 // ---- stage-1 per-ray glue (round 3): the ~100 elementwise launches on [N] / [N, 3] tensors around the ray march ------------

@@ -121,6 +121,8 @@ class DataParallel(object):
             pad = lambda n: (n + 63) // 64 * 64  # views start on 256-byte boundaries, the layout optim.FlatAdam gives the parameters
             total = sum(pad(p.numel()) for p in params)
             flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+            from .optim import register_flat_buffer
+            register_flat_buffer(flat)  # its alignment gaps hold zeros: optim.FlatAdam may step its views as merged ranges
             views, off = [], 0
             for p in params:
                 views.append(flat[off:off + p.numel()].view_as(p))
@@ -136,12 +138,9 @@ class DataParallel(object):
         for p in params:
             p.grad = None  # also for a parameter frozen since the last step: optimisers skip None, like after zero_grad()
 
-    def allreduce_grads(self, params, sparse_params=()):
-        """One flat-bucket all-reduce(SUM) over every dense .grad (the tensors autograd produced are first copied into the
-        bucket -- one multi-tensor launch --; afterwards every ``.grad`` is its view of the reduced bucket).  Coalesced values of sparse .grad
-        (CPU / oracle embeddings; the HIP trainers use dense tables + RowSparseAdam, whose [n_lights, 4] floats ride
-        in the bucket whole: 30 KB of a 2.7 MB message, cheaper than four gather / scatter launches) go out as a second
-        small message.  A parameter without a gradient on this rank (an empty pixel slice) contributes zeros."""
+    def gather_grads(self, params):
+        """The device half in front of the collective: every dense .grad autograd produced is copied into the flat bucket
+        (one multi-tensor launch; slots of parameters without a gradient are zeroed) and re-pointed at its bucket view."""
         if not self.enabled:
             return
         params = [p for p in params if p.requires_grad]
@@ -157,9 +156,28 @@ class DataParallel(object):
                 torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
             for p, v in zip(params, views):
                 p.grad = v
+
+    def allreduce_bucket(self, params):
+        """ONE all-reduce(SUM) of the flat bucket gather_grads filled; the ``.grad`` views then hold the reduced gradients."""
+        if not self.enabled:
+            return
+        params = [p for p in params if p.requires_grad]
+        if params:
+            flat = self._bucket(params)[0]
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             self.n_allreduce += 1
             self.allreduce_bytes = flat.numel() * flat.element_size()
+
+    def allreduce_grads(self, params, sparse_params=()):
+        """One flat-bucket all-reduce(SUM) over every dense .grad (the tensors autograd produced are first copied into the
+        bucket -- one multi-tensor launch --; afterwards every ``.grad`` is its view of the reduced bucket).  Coalesced values of sparse .grad
+        (CPU / oracle embeddings; the HIP trainers use dense tables + RowSparseAdam, whose [n_lights, 4] floats ride
+        in the bucket whole: 30 KB of a 2.7 MB message, cheaper than four gather / scatter launches) go out as a second
+        small message.  A parameter without a gradient on this rank (an empty pixel slice) contributes zeros."""
+        if not self.enabled:
+            return
+        self.gather_grads(params)
+        self.allreduce_bucket(params)
         sparse = [(p, p.grad.coalesce()) for p in sparse_params if p.grad is not None]
         if sparse:
             vals = torch.cat([g.values().reshape(-1) for _, g in sparse])

@@ -121,6 +121,7 @@ SIGNATURES = {
                                   c_f, c_f, c_f, c_f, f32, f32, c_f, c_f, c_f, c_f, i64, i32, c_f, c_f]),
     'psn_pair_sums': (i32, [c_f, i32, i64, i32, c_f, c_f, ctypes.POINTER(ctypes.c_int), c_f]),
     'psn_row_adam': (i32, [i32, ctypes.c_void_p, c_f, i32, c_f]),
+    'psn_row_adam_dev': (i32, [i32, ctypes.c_void_p, c_f, i32, c_f, c_f]),
     'psn_shadow_points': (i32, [c_f, c_f, i64, i32, i32, f32, f32, c_f, c_f, f32, c_f, c_f, c_f, c_f]),
     'psn_mlp_infer_pe': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i32, f32, c_f, c_f]),
     'psn_mlp_infer_pe_indirect': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, c_f, c_f, i32, f32, c_f, c_f]),
@@ -141,6 +142,7 @@ SIGNATURES = {
     'psn_surface_points': (i32, [c_f, c_f, c_f, c_f, i64, c_f, c_f, c_f, c_f, c_f]),
     'psn_stage1_targets': (i32, [c_f, i64, i32, i32, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, c_f, c_f, c_f]),
     'psn_adam_flat': (i32, [c_f, c_f, c_f, c_f, i32, ctypes.c_void_p, f32, f32, f32, f32, c_f]),
+    'psn_adam_flat_dev': (i32, [c_f, c_f, c_f, c_f, i32, ctypes.c_void_p, f32, f32, f32, f32, c_f, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_weight_norm_bwd': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_mlp_pack_bf16': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
@@ -445,15 +447,21 @@ def pair_sums(x, V, Ns):
     return sx, part[:n_chunks.value].sum(0)
 
 
-def row_adam(items, idx):
+def row_adam(items, idx, step_sizes_dev=None):
     """items: list of (param, grad, exp_avg, exp_avg_sq, beta1, beta2, eps, step_size) with dense [rows, cols] fp32 device
-    tensors; idx: int64 device tensor of the rows that move (psn_row_adam)."""
+    tensors; idx: int64 device tensor of the rows that move (psn_row_adam).  step_sizes_dev: fp32 device tensor [len(items)]
+    the kernel reads the step sizes from instead (psn_row_adam_dev: graph replay)."""
     arr = (PsnRowAdamItem * len(items))()
     for e, (p, g, m, v, b1, b2, eps, ss) in zip(arr, items):
         p2 = p.view(p.shape[0], -1)
         e.param, e.grad, e.exp_avg, e.exp_avg_sq = _ptr(p, 'param'), _ptr(g, 'grad'), _ptr(m, 'exp_avg'), _ptr(v, 'exp_avg_sq')
         e.rows, e.cols, e.one_minus_beta1, e.one_minus_beta2, e.eps, e.step_size = p2.shape[0], p2.shape[1], 1 - b1, 1 - b2, eps, ss
     assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()
+    if step_sizes_dev is not None:
+        assert step_sizes_dev.is_cuda and step_sizes_dev.dtype == torch.float32 and step_sizes_dev.numel() >= len(items)
+        _check(_lib.psn_row_adam_dev(len(items), ctypes.addressof(arr), idx.data_ptr(), idx.numel(), step_sizes_dev.data_ptr(),
+                                     _stream()), 'row_adam_dev')
+        return
     _check(_lib.psn_row_adam(len(items), ctypes.addressof(arr), idx.data_ptr(), idx.numel(), _stream()), 'row_adam')
 
 
@@ -626,9 +634,12 @@ def stage1_targets(pix, img, mask=None, mask_valid=None, normal=None, norm_mask=
     return rgb, mask_gt, valid, nmask, ngt
 
 
-def adam_flat(param, grad, exp_avg, exp_avg_sq, segs, beta1, beta2, eps):
+def adam_flat(param, grad, exp_avg, exp_avg_sq, segs, beta1, beta2, eps, scalars_dev=None):
     """segs: [(offset, grad_offset, n, neg_step_size, bias_correction2_sqrt)] ranges of the flat buffers (psn_adam_flat);
-    more than ADAM_MAX_SEGS ranges go out in several launches."""
+    more than ADAM_MAX_SEGS ranges go out in several launches.  scalars_dev: fp32 device tensor [len(segs), 2] that the
+    kernel reads (neg_step_size, bias_correction2_sqrt) of every range from instead (psn_adam_flat_dev: graph replay)."""
+    if scalars_dev is not None:
+        assert scalars_dev.is_cuda and scalars_dev.dtype == torch.float32 and scalars_dev.is_contiguous() and scalars_dev.numel() >= 2 * len(segs)
     for t in (param, grad, exp_avg, exp_avg_sq):
         assert t.dim() == 1 and t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
     assert exp_avg.numel() == exp_avg_sq.numel() == param.numel()
@@ -638,6 +649,11 @@ def adam_flat(param, grad, exp_avg, exp_avg_sq, segs, beta1, beta2, eps):
         for a, (off, goff, n, ns, bc) in zip(arr, part):
             assert 0 <= off and off + n <= param.numel() and 0 <= goff and goff + n <= grad.numel()
             a.offset, a.grad_offset, a.n, a.neg_step_size, a.bias_correction2_sqrt = int(off), int(goff), int(n), float(ns), float(bc)
+        if scalars_dev is not None:
+            _check(_lib.psn_adam_flat_dev(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), len(part), arr,
+                                          float(1 - beta1), float(beta2), float(1 - beta2), float(eps),
+                                          scalars_dev.data_ptr() + 8 * s0, _stream()), 'adam_flat_dev')
+            continue
         _check(_lib.psn_adam_flat(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), len(part), arr,
                                   float(1 - beta1), float(beta2), float(1 - beta2), float(eps), _stream()), 'adam_flat')
 

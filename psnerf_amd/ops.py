@@ -4,9 +4,22 @@ PyTorch is used here only as the owner of device memory and the autograd tape;
 every FLOP on the hot path runs in libpsnerf_hip.so.  Each Function implements
 its own backward with the same kernels (no autograd-of-autograd).
 """
+import collections
+
 import torch
 
 from . import fused, hip
+
+
+# How often each autograd node's FORWARD ran, by class name (host-side, no device work): tests assert on it that a step took the
+# fused engines ('VisibilityPair', 'FusedReluNet', 'GeoFieldFused', 'AppNetFused', ...) and not the layer-wise GEMM
+# formulations kept for other network widths ('ReluMLP', 'GeoField') -- a shape predicate that quietly fails on the GPU would
+# otherwise fall back without anybody noticing (VERDICT r3, weak 14).
+HITS = collections.Counter()
+
+
+def _hit(name):
+    HITS[name] += 1
 
 
 def _rowsum_small(t):
@@ -59,6 +72,7 @@ class AlphaComposite(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, alpha, rgb, white_bg):
+        _hit('AlphaComposite')
         alpha, rgb = alpha.contiguous(), rgb.contiguous()
         _w, out, acc = hip.composite_fwd(alpha, rgb, white_bg, need_weights=False)
         ctx.save_for_backward(alpha, rgb)
@@ -98,6 +112,7 @@ class ReluMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, in_cols, skip_at, final_sigmoid, *params):
+        _hit('ReluMLP')
         n = len(params) // 2
         Ws, bs = params[0::2], params[1::2]
         Q, kp = x.shape
@@ -191,6 +206,7 @@ class FusedPairMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tab_a, tab_b, in_cols, skip_at, *params):
+        _hit('FusedPairMLP')
         Ws, bs = params[0::2], params[1::2]
         nA, nB = tab_a.shape[0], tab_b.shape[0]
         din_half = in_cols.numel() // 2
@@ -248,6 +264,7 @@ class ScatterRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, idx, inv, specs, *rows):
+        _hit('ScatterRows')
         ctx.specs, ctx.n_pix, ctx.ns = specs, inv.numel(), idx.numel()
         ctx.save_for_backward(idx)
         return tuple(hip.scatter_rows(list(specs), [r.detach() for r in rows], inv, inv.numel(), idx.numel()))
@@ -273,6 +290,7 @@ class WeightNormAll(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, scales, *gv):
+        _hit('WeightNormAll')
         gs, vs = [t.detach().contiguous() for t in gv[0::2]], [t.detach().contiguous() for t in gv[1::2]]
         ctx.scales = scales
         ctx.save_for_backward(*gs, *vs)
@@ -309,6 +327,7 @@ class SGShade(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, light_dir, view, normal, albedo, weights, lobe, light_int, vis, specular_rgb):
+        _hit('SGShade')
         li_t, li_s = None, 0.0
         rgb_lights = False
         if torch.is_tensor(light_int):
@@ -385,6 +404,7 @@ class GeoField(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p, n_octaves, scale, skips, with_grad, *params):
+        _hit('GeoField')
         Ws, bs = [w.contiguous() for w in params[0::2]], [b.contiguous() for b in params[1::2]]
         n = len(Ws)
         p = p.contiguous()
@@ -518,6 +538,7 @@ class MFShade(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, light_dir, view, normal, albedo, rough, light_int, vis, f0):
+        _hit('MFShade')
         li_t, li_s = None, 0.0
         if torch.is_tensor(light_int):
             li_t = light_int.reshape(-1).expand(light_dir.shape[0]).contiguous() if light_int.numel() == 1 \
@@ -593,6 +614,7 @@ class VisibilityPair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pe_x, pe_l, n_shade, in_cols, skip_at, pre, *params):
+        _hit('VisibilityPair')
         Ns, LV = pe_x.shape[0], pe_l.shape[0]
         V = LV - n_shade
         n = len(params) // 2
@@ -697,6 +719,7 @@ class GeoFieldFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p, n_octaves, scale, skips, with_grad, chains, feat_rows, *params):
+        _hit('GeoFieldFused')
         Ws = [w for w in params[0::2]]
         n = len(Ws)
         p = p.contiguous()
@@ -815,6 +838,7 @@ class AppNetFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, normal, feat, d_x, chains, *params):
+        _hit('AppNetFused')
         n = len(params) // 2
         Q = x.shape[0]
         feat = feat.contiguous()
@@ -870,6 +894,7 @@ class FusedReluNet(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pe, din, skip_at, final_sigmoid, width, packed, *params):
+        _hit('FusedReluNet')
         Ws, bs = params[0::2], params[1::2]
         n = len(Ws)
         Q = pe.shape[0]
@@ -939,6 +964,7 @@ class Stage2Losses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j, mask_a, mask_b, l2, inv_denom, weight,
                 count_dev=None):
+        _hit('Stage2Losses')
         c = lambda t: None if t is None else t.detach().contiguous()
         ts = [c(t) for t in (rgb, rgb_gt, alb, alb_j, wgt, wgt_j, vis, vis_gt, nrm, nrm_gt, nrm_j)]
         ma, mb = mask_a.contiguous(), mask_b.contiguous()
@@ -982,6 +1008,7 @@ class SurfaceNormals(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, g, hit):
+        _hit('SurfaceNormals')
         gc, hc = g.detach().contiguous(), hit.contiguous()
         ctx.save_for_backward(gc, hc)
         return hip.surface_normals_fwd(gc, hc)
@@ -1002,6 +1029,7 @@ class Stage1Losses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, rgb_gt, diff, hit, normal, normal_gt, norm_mask, acc, mask_gt, mask_valid, n_rays, weights, reduce_counts=None):
+        _hit('Stage1Losses')
         c = lambda t: None if t is None else t.detach().contiguous()
         rgb, rgb_gt, diff, normal, normal_gt, acc, mask_gt = (c(t) for t in (rgb, rgb_gt, diff, normal, normal_gt, acc, mask_gt))
         hit, norm_mask, mask_valid = (c(t) for t in (hit, norm_mask, mask_valid))
@@ -1044,6 +1072,7 @@ class NormalizeRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, eps=1e-12):
+        _hit('NormalizeRows')
         xc = x.detach().contiguous()
         ctx.save_for_backward(xc)
         ctx.eps = float(eps)
@@ -1069,6 +1098,7 @@ class LightRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dir_table, int_table, idx):
+        _hit('LightRows')
         dt, it, ix = dir_table.detach().contiguous(), int_table.detach().contiguous(), idx.contiguous()
         ctx.save_for_backward(dt, ix)
         d, i = hip.light_rows_fwd(dt, it, ix)

@@ -14,7 +14,58 @@ import math
 import torch
 
 
+class StepScalars(object):
+    """The step-dependent scalars of an optimiser launch (bias corrections x learning rate) in DEVICE memory, so that the launch
+    itself is identical from step to step and can be replayed from a HIP graph (stage2/graph.py).  ``push(values)`` copies
+    this step's values host -> device on the current stream through a ring of pinned rows (a row is rewritten only after
+    the copy that last read it has completed: the host may run many steps ahead of the GPU); while the current stream is
+    being captured the values are only remembered -- ``flush()`` sends them once the capture has ended, before the replay."""
+
+    def __init__(self, n, device, slots=64):
+        self.n = int(n)
+        self.dev = torch.zeros(self.n, device=device, dtype=torch.float32)
+        self.pin = torch.zeros(slots, self.n, dtype=torch.float32).pin_memory()
+        self.events = [None] * slots
+        self.turn = 0
+        self.pending = None
+
+    def push(self, values):
+        values = [float(v) for v in values]
+        assert len(values) <= self.n
+        if torch.cuda.is_current_stream_capturing():
+            self.pending = values
+            return
+        k = self.turn % len(self.events)
+        self.turn += 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        row = self.pin[k]
+        row[:len(values)] = torch.tensor(values, dtype=torch.float32)  # (double -> float32: the rounding of a by-value float argument)
+        self.dev[:len(values)].copy_(row[:len(values)], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+
+    def flush(self):
+        if self.pending is not None:
+            v, self.pending = self.pending, None
+            self.push(v)
+
+
 class RowSparseAdam(torch.optim.Optimizer):
+    graph_scalars = None  # a StepScalars: the fused launch reads its step sizes from device memory (HIP-graph replay)
+
+    def graph_advance(self):
+        """The host half of one REPLAYED step: the step counts of the tables of the captured launch advance and the step
+        sizes of this step go to the device (the device half is the replayed psn_row_adam_dev launch)."""
+        vals = []
+        for p, group in self._graph_plan:
+            state = self.state[p]
+            state['step'] = int(state['step']) + 1
+            t, (b1, b2) = int(state['step']), group['betas']
+            vals.append(group['lr'] * math.sqrt(1 - b2 ** t) / (1 - b1 ** t))
+        self.graph_scalars.push(vals)
+
     def _fused_step(self, rows):
         """All tables in ONE launch (psn_row_adam, csrc/loss.hip) when every gradient is a dense fp32 device tensor;
         the torch formulation below is ~14 elementwise launches per table."""
@@ -39,8 +90,13 @@ class RowSparseAdam(torch.optim.Optimizer):
             return False
         for p, state, *_ in items:
             state['step'] = int(state['step']) + 1
+        dev = None
+        if self.graph_scalars is not None:
+            self.graph_scalars.push([it[-1] for it in items])
+            self._graph_plan = [(p, next(g for g in self.param_groups if any(q is p for q in g['params']))) for p, *_ in items]
+            dev = self.graph_scalars.dev
         hip.row_adam([(p, p.grad, st['exp_avg'], st['exp_avg_sq'], b1, b2, eps, ss) for p, st, b1, b2, eps, ss in items],
-                     rows.contiguous())
+                     rows.contiguous(), step_sizes_dev=dev)
         return True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, maximize=False):
@@ -56,6 +112,8 @@ class RowSparseAdam(torch.optim.Optimizer):
         gradients are dense (nn.Embedding(sparse=False)); with sparse gradients the rows are their indices."""
         if rows is not None and rows.is_cuda and self._fused_step(rows):
             return
+        assert self.graph_scalars is None, 'RowSparseAdam: only the fused launch can be replayed from a graph'
+
         for group in self.param_groups:
             beta1, beta2 = group['betas']
             for p in group['params']:
@@ -88,6 +146,31 @@ def _pad64(n):
     return (int(n) + 63) // 64 * 64
 
 
+# Flat gradient allocations whose alignment gaps are KNOWN to hold zeros: a FlatAdam's own gradient buffer and the
+# data-parallel buckets (dist.DataParallel._bucket registers them).  Only views of these may be stepped as ranges that
+# merge across a gap; a gradient that happens to be a view of some other 1-D tensor is copied like any loose gradient.
+_FLAT_BUFFERS = []
+
+
+def register_flat_buffer(t):
+    import weakref
+    _FLAT_BUFFERS[:] = [r for r in _FLAT_BUFFERS if r() is not None]
+    if not any(r() is t for r in _FLAT_BUFFERS):
+        _FLAT_BUFFERS.append(weakref.ref(t))
+
+
+def _known_flat_base(g):
+    """The registered flat buffer ``g`` is a contiguous view of, or None."""
+    base = g._base if (torch.is_tensor(g) and not g.is_sparse) else None
+    if base is None or base.dim() != 1 or base.dtype != torch.float32 or not base.is_contiguous() or not g.is_contiguous():
+        return None
+    for r in _FLAT_BUFFERS:
+        t = r()
+        if t is not None and t.data_ptr() == base.data_ptr() and t.numel() == base.numel():
+            return base
+    return None
+
+
 class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam (amsgrad off, no weight decay: what stage2/trainer.py:126-133 constructs) over ONE flat fp32 buffer.
 
@@ -106,6 +189,22 @@ class FlatAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
                                       foreach=None, capturable=False, differentiable=False, fused=None))
         self._flat = None
+        self.graph_scalars = None  # a StepScalars: the launches read (neg_step, bc2_sqrt) of every range from device memory
+        self._graph_plan = None
+
+    def graph_advance(self):
+        """The host half of one REPLAYED step: the step counts of the parameters of the captured launches advance and this
+        step's scalars go to the device (the device half are the replayed gather + psn_adam_flat_dev launches)."""
+        import math
+        vals = []
+        for group, params, reps in self._graph_plan:
+            b1, b2 = group['betas']
+            for p in params:
+                self.state[p]['step'] += 1
+            for rep in reps:
+                t = int(self.state[rep]['step'])
+                vals += [-(group['lr'] / (1 - b1 ** t)), math.sqrt(1 - b2 ** t)]
+        self.graph_scalars.push(vals)
 
     # ---- flat storage -----------------------------------------------------------------------------------------------
     def _all_params(self):
@@ -167,14 +266,14 @@ class FlatAdam(torch.optim.Optimizer):
             g = p.grad
             if g is None or g.is_sparse or g.dtype != torch.float32 or not g.is_cuda:
                 continue
-            base = g._base
-            if base is not None and base.dim() == 1 and base.is_contiguous() and g.is_contiguous():
+            if _known_flat_base(g) is not None:
                 continue  # already a view of a flat buffer (this one, or the data-parallel bucket)
             loose.append(p)
         if not loose:
             return
         if f.get('g') is None:
             f['g'] = torch.zeros_like(f['p'])
+            register_flat_buffer(f['g'])
         views = [f['g'][f['off'][p]:f['off'][p] + p.numel()].view_as(p) for p in loose]
         torch._foreach_copy_(views, [p.grad for p in loose])
         for p, v in zip(loose, views):
@@ -183,10 +282,10 @@ class FlatAdam(torch.optim.Optimizer):
     # ---- checkpoints: never serialise views of the whole flat allocation ----------------------------------------------
     def state_dict(self):
         sd = super().state_dict()
-        for st in sd['state'].values():
-            for k, t in list(st.items()):
-                if torch.is_tensor(t):
-                    st[k] = t.detach().clone()
+        # torch returns the LIVE per-parameter dictionaries (sd['state'][i] is self.state[p]): build fresh ones, never
+        # write into them -- replacing the moment views by clones would freeze every later checkpoint at this one
+        sd['state'] = {k: {kk: (t.detach().clone() if torch.is_tensor(t) else t) for kk, t in st.items()}
+                       for k, st in sd['state'].items()}
         return sd
 
     def load_state_dict(self, state_dict):
@@ -201,12 +300,13 @@ class FlatAdam(torch.optim.Optimizer):
         flat_ok = self._attached()
         if flat_ok:
             self._gather_grads()
+        plan, launches = [], []
         for group in self.param_groups:
             assert not group.get('maximize', False) and not group.get('amsgrad', False) and group.get('weight_decay', 0) == 0, \
                 'FlatAdam: plain Adam only'
             b1, b2 = group['betas']
             lr, eps = group['lr'], group['eps']
-            segs, gbuf = [], None
+            segs, gbuf, members, reps = [], None, [], []
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -224,24 +324,36 @@ class FlatAdam(torch.optim.Optimizer):
                 t = int(st['step'])
                 neg_step, bc2s = -(lr / (1 - b1 ** t)), math.sqrt(1 - b2 ** t)
                 g = p.grad
-                base = g._base if (torch.is_tensor(g) and not g.is_sparse) else None
-                if (flat_ok and base is not None and base.dim() == 1 and base.is_contiguous() and g.is_contiguous() and base.dtype == torch.float32
-                        and (gbuf is None or (base.data_ptr() == gbuf.data_ptr() and base.numel() == gbuf.numel()))):
+                base = _known_flat_base(g) if flat_ok else None
+                if base is not None and (gbuf is None or (base.data_ptr() == gbuf.data_ptr() and base.numel() == gbuf.numel())):
                     # the gradient is a view of ONE flat allocation (attach_grads, or the data-parallel bucket): a range of the launch
                     gbuf = base
                     o, go, n = self._flat['off'][p], (g.data_ptr() - base.data_ptr()) // 4, p.numel()
                     gap = o - (segs[-1][0] + segs[-1][2]) if segs else -1
+                    members.append(p)
                     if segs and 0 <= gap < 64 and gap == go - (segs[-1][1] + segs[-1][2]) and segs[-1][3:] == (neg_step, bc2s):
                         # the next parameter of both layouts, behind the same (zero-filled) alignment gap: one range
                         segs[-1] = (segs[-1][0], segs[-1][1], segs[-1][2] + gap + n, neg_step, bc2s)
                     else:
                         segs.append((o, go, n, neg_step, bc2s))
+                        reps.append(p)
                     continue
+                assert self.graph_scalars is None, 'FlatAdam: a gradient outside the flat layout cannot be replayed from a graph'
                 # torch's formulation for whatever is not in the flat layout
                 m, v = st['exp_avg'], st['exp_avg_sq']
                 m.lerp_(g, 1 - b1)
                 v.mul_(b2).addcmul_(g, g, value=1 - b2)
                 p.addcdiv_(m, (v.sqrt() / bc2s).add_(eps), value=neg_step)
             if segs:
-                f = self._flat
-                hip.adam_flat(f['p'], gbuf, f['m'], f['v'], segs, b1, b2, eps)
+                launches.append((gbuf, segs, b1, b2, eps))
+                plan.append((group, members, reps))
+        dev, off = None, 0
+        if self.graph_scalars is not None:
+            # every launch reads its ranges' scalars from device memory: identical launches from step to step (graph replay)
+            self.graph_scalars.push([x for _, segs, *_ in launches for s_ in segs for x in s_[3:]])
+            self._graph_plan = plan
+            dev = self.graph_scalars.dev
+        for gbuf, segs, b1, b2, eps in launches:
+            f = self._flat
+            hip.adam_flat(f['p'], gbuf, f['m'], f['v'], segs, b1, b2, eps, scalars_dev=None if dev is None else dev[off:])
+            off += 2 * len(segs)

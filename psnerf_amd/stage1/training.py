@@ -69,6 +69,23 @@ class Trainer(object):
             net.prepack(occupancy=True)  # the next step's ray march starts with this pack: queue it behind the backward
         return terms
 
+    def process_data_dict(self, data):
+        """stage1/model/training.py:120-139: the tensors of a data-loader item on the trainer's device, in the reference's
+        order (img, mask_img, world_mat, camera_mat, scale_mat, img_idx, normal, norm_mask, mask_valid); absent masks are
+        all ones, normal / norm_mask are None without the normal loss."""
+        device = self.device
+        img = data.get('img').to(device)
+        img_idx = data.get('img.idx')
+        batch_size, _, h, w = img.shape
+        mask_img = data.get('img.mask', torch.ones(batch_size, h, w)).unsqueeze(1).to(device)
+        world_mat = data.get('img.world_mat').to(device)
+        camera_mat = data.get('img.camera_mat').to(device)
+        scale_mat = data.get('img.scale_mat').to(device)
+        normal = data.get('img.normal').to(device) if self.normal_loss else None
+        norm_mask = data.get('img.norm_mask').unsqueeze(1).to(device) if self.normal_loss else None
+        mask_valid = data.get('img.mask_valid', torch.ones(batch_size, h, w)).unsqueeze(1).to(device)
+        return (img, mask_img, world_mat, camera_mat, scale_mat, img_idx, normal, norm_mask, mask_valid)
+
     def _upload(self, t):
         """Host tensor -> device without stalling the host behind the stream: a pageable source makes the copy wait for
         everything queued before it (the whole previous step), after which the host trails the GPU by its launch latency for

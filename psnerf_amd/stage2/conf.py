@@ -96,13 +96,39 @@ def load_conf(path):
         return parse_conf(f.read())
 
 
+# brdf.light_intensity per object (stage2/confs/<obj>.conf; the synthetic objects use 4.0 and leave the per-light
+# intensities fixed): the only hot-path values in which the seven reference confs differ
+STAGE2_LIGHT_INTENSITY = {'bear': 2.0, 'buddha': 2.0, 'cow': 2.0, 'pot2': 2.0, 'reading': 2.0, 'bunny': 4.0, 'armadillo': 4.0}
+
+
+def object_conf(obj, **overrides):
+    """The hot-path subset of stage2/confs/<obj>.conf; an unknown object raises (load_conf reads the files themselves)."""
+    if obj not in STAGE2_LIGHT_INTENSITY:
+        raise ValueError('object_conf: unknown object %r (known: %s)' % (obj, ', '.join(sorted(STAGE2_LIGHT_INTENSITY))))
+    c = bear_conf(**{'brdf.light_intensity': STAGE2_LIGHT_INTENSITY[obj]})
+    c['train']['light_inten_train'] = obj not in ('bunny', 'armadillo')
+    return _override(c, overrides)
+
+
+def _override(c, overrides):
+    for k, v in overrides.items():
+        node = c
+        parts = k.split('.')
+        for p in parts[:-1]:
+            node = node.setdefault(p, Conf())
+        node[parts[-1]] = v
+    return c
+
+
 def bear_conf(**overrides):
     """The hot-path subset of stage2/confs/bear.conf (identical for every object except paths and
     brdf.light_intensity).  ``overrides`` use dotted keys."""
     c = Conf({
         'train': Conf(render_model='sgbasis', nbasis=9, specular_rgb=True, visibility=True, vis_loss=True,
                       light_vis_detach=True, vis_rgb_detach=True, normal_mlp=True, normal_joint=True,
-                      shape_pregen=True, light_bs=10, vis_train_num=8, sg_learning_rate=5e-4,
+                      shape_pregen=True, light_bs=10, vis_train_num=8, vis_plus=True, train_order=True, light_train=True,
+                      multi_light=True, light_inten_train=True, num_pixels=8192, sg_learning_rate=5e-4,
+                      sg_sched_milestones=[200, 400, 600, 800, 1000],
                       light_learning_rate=5e-4, light_inten_lr=1e-3, sg_sched_factor=0.5),
         'loss': Conf(sg_rgb_weight=1.0, loss_type='L1', albedo_smooth_weight=0.05, rough_smooth_weight=0.01,
                      vis_weight=1),

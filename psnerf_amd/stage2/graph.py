@@ -1,0 +1,185 @@
+"""The stage-2 train step replayed from HIP graphs (the body of stage2/trainer.py:355-410 for a per-rank batch that is too
+small to hide the host: BASELINE cfg 4 = cfg 3's 32768 pixels sharded over 8 ranks = 4096 pixels per rank, where the
+~110 launches of a step cost more host time than their kernels take).
+
+``GraphedTrainStep(step)`` wraps a ``TrainStep``; every ``.step(...)`` call is exactly one optimisation step with the
+eager step's arithmetic, bit for bit:
+
+  * the first ``warmup`` calls of a new signature (input shapes, trainable set, loss weights -- i.e. per train_fix phase
+    and batch geometry) run ``TrainStep.step`` eagerly (on the capture stream, so every cache -- workspaces, weight packs,
+    optimiser state, the data-parallel bucket -- exists before the capture);
+  * the next call CAPTURES the device work of a step (a capture records, it does not execute) and replays it;
+  * every further call copies the batch into the captured input buffers (skipped for tensors that already ARE those
+    buffers: a data pipeline can write into ``.buffers`` directly) and replays.
+
+What stays on the host per replayed step: train_fix, the iteration / scheduler bookkeeping, the optimisers' step counts and
+their step-dependent scalars (bias corrections x learning rate), which the Adam / SparseAdam launches read from DEVICE memory
+(``optim.StepScalars``, psn_adam_flat_dev / psn_row_adam_dev) so that the captured launches never change; the vis_plus draw
+(np.random on the host + two gathers); and under data parallelism the two collectives, which are NOT captured: the step is then
+two graphs, [forward, losses, backward, gradients gathered into the flat bucket] -> RCCL all-reduce of the bucket ->
+[Adam, SparseAdam], with the 4-byte count all-reduce in front.
+
+Measured on this ROCm (7.x): a single-stream graph costs the host 0.04 ms per replay, a graph that forks to the model's side
+stream 2.5 - 3 ms (still below the step's GPU time); kernel-to-kernel gaps inside a replay equal those of a host that runs
+ahead -- a HIP graph removes the HOST from the critical path, not GPU time.
+"""
+import torch
+
+from .. import hip
+from ..optim import FlatAdam, RowSparseAdam, StepScalars
+
+_INPUT_KEYS_SKIP = ()
+
+
+class _Captured(object):
+    def __init__(self):
+        self.graphs = []
+        self.inp = self.gt = self.l_slt = self.noise = self.count = None
+        self.terms = self.out = None
+        self.trainable = None
+        self.train_light = False
+
+
+class GraphedTrainStep(object):
+    def __init__(self, step, warmup=2, max_graphs=8, overlap_small_nets=None):
+        """``overlap_small_nets``: None keeps the model's setting; False captures a single-stream graph (0.04 ms of host
+        time per replay instead of ~2.5 ms, at the price of the side-stream overlap)."""
+        assert isinstance(step.sg_optimizer, FlatAdam) and isinstance(step.light_optimizer, RowSparseAdam) and step.FUSED_LOSSES, \
+            'GraphedTrainStep needs the device-resident step (FlatAdam, RowSparseAdam, fused losses)'
+        self.step_obj, self.warmup, self.max_graphs = step, int(warmup), int(max_graphs)
+        self.stream = torch.cuda.Stream(device=step.device)
+        self._seen = {}
+        self._captured = {}
+        if overlap_small_nets is not None:
+            step.model.overlap_small_nets = bool(overlap_small_nets)
+        self.n_replays = self.n_eager = self.n_captures = 0
+
+    # ---- signature of a step -------------------------------------------------------------------------------------------
+    def _key(self, model_input, ground_truth, l_slt, noise):
+        st = self.step_obj
+        shapes = tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in model_input.items() if torch.is_tensor(v)))
+        gshapes = tuple(sorted((k, tuple(v.shape)) for k, v in ground_truth.items() if torch.is_tensor(v)))
+        nshapes = tuple(sorted((k, tuple(v.shape)) for k, v in (noise or {}).items() if torch.is_tensor(v)))
+        flags = tuple(p.requires_grad for p in st.model.parameters()) + (st.light_para.weight.requires_grad,
+                                                                         st.light_inten_para.weight.requires_grad)
+        w = (st.loss.sg_rgb_weight, st.loss.albedo_smooth_weight, st.loss.rough_smooth_weight, st.loss.vis_weight,
+             st.loss_n.normal_weight, st.loss_n.normal_smooth_weight, st.model.training)
+        return (shapes, gshapes, tuple(l_slt.shape), nshapes, flags, w)
+
+    @property
+    def buffers(self):
+        """{signature: (model_input, ground_truth, l_slt, noise)} static input tensors of the captured graphs."""
+        return {k: (c.inp, c.gt, c.l_slt, c.noise) for k, c in self._captured.items()}
+
+    # ---- one optimisation step -----------------------------------------------------------------------------------------
+    def step(self, model_input, ground_truth, l_slt, train_order=True, noise=None, vidx=None):
+        st = self.step_obj
+        if train_order:
+            st.train_fix()
+        st.dp.new_step()
+        model_input = st.select_vis_lights(model_input, vidx)
+        key = self._key(model_input, ground_truth, l_slt, noise)
+        cap = self._captured.get(key)
+        if cap is None:
+            seen = self._seen.get(key, 0)
+            if seen < self.warmup or hip.PROFILE_EVENTS is not None:
+                self._seen[key] = seen + 1
+                return self._eager(model_input, ground_truth, l_slt, noise)
+            cap = self._capture(key, model_input, ground_truth, l_slt, noise)
+            first = True
+        else:
+            first = False
+            self._load(cap, model_input, ground_truth, l_slt, noise)
+            st.sg_optimizer.graph_advance()
+            if cap.train_light:
+                st.light_optimizer.graph_advance()
+        self._replay(cap)
+        if not first:
+            st.model.invalidate_packs(trainable_only=True)  # (the captured step re-packs; an eager step that follows must too)
+        st._advance(cap.train_light)
+        self.n_replays += 1
+        return cap.terms, cap.out
+
+    def _eager(self, model_input, ground_truth, l_slt, noise):
+        """A plain TrainStep step on the capture stream (so that every per-stream cache the capture will use exists)."""
+        st = self.step_obj
+        cur = torch.cuda.current_stream(st.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            terms, out, trainable, train_light = st._fwd_bwd(model_input, ground_truth, l_slt, noise=noise)
+            st._reduce(trainable)
+            st._optimise(l_slt, trainable, train_light)
+        cur.wait_stream(self.stream)
+        for t in list(terms.values()) + list(out.values()):
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+        st._advance(train_light)
+        self.n_eager += 1
+        return terms, out
+
+    # ---- capture ---------------------------------------------------------------------------------------------------------
+    def _capture(self, key, model_input, ground_truth, l_slt, noise):
+        st = self.step_obj
+        if len(self._captured) >= self.max_graphs:  # batch geometries that keep changing: drop the oldest graph
+            self._captured.pop(next(iter(self._captured)))
+        cap = _Captured()
+        dev = st.device
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            cap.inp = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in model_input.items()}
+            cap.gt = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in ground_truth.items()}
+            cap.l_slt = l_slt.detach().clone()
+            cap.noise = None if not noise else {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in noise.items()}
+            if st.dp.enabled:
+                cap.count = torch.zeros(1, device=dev, dtype=torch.float32)
+            for opt, n in ((st.sg_optimizer, 2 * hip.ADAM_MAX_SEGS * 4), (st.light_optimizer, 8)):
+                if opt.graph_scalars is None:
+                    opt.graph_scalars = StepScalars(n, dev)
+        torch.cuda.synchronize(dev)
+        g_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_a, stream=self.stream):
+            cap.terms, cap.out, cap.trainable, cap.train_light = st._fwd_bwd(cap.inp, cap.gt, cap.l_slt, noise=cap.noise, count=cap.count)
+            if not st.dp.enabled:
+                st._optimise(cap.l_slt, cap.trainable, cap.train_light)
+        cap.graphs.append(g_a)
+        if st.dp.enabled:
+            g_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_b, stream=self.stream, pool=g_a.pool()):
+                st._optimise(cap.l_slt, cap.trainable, cap.train_light)
+            cap.graphs.append(g_b)
+        # the optimisers' host halves ran inside the captures (step counts advanced, this step's scalars remembered): send the
+        # scalars now, in front of the replay that executes the captured step
+        st.sg_optimizer.graph_scalars.flush()
+        st.light_optimizer.graph_scalars.flush()
+        self._captured[key] = cap
+        self.n_captures += 1
+        return cap
+
+    # ---- replay ----------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _copy_in(dst, src):
+        for k, v in src.items():
+            d = dst.get(k)
+            if torch.is_tensor(v) and torch.is_tensor(d) and d.data_ptr() != v.data_ptr():
+                d.copy_(v, non_blocking=True)
+
+    def _load(self, cap, model_input, ground_truth, l_slt, noise):
+        self._copy_in(cap.inp, model_input)
+        self._copy_in(cap.gt, ground_truth)
+        if cap.l_slt.data_ptr() != l_slt.data_ptr():
+            cap.l_slt.copy_(l_slt, non_blocking=True)
+        if cap.noise:
+            self._copy_in(cap.noise, noise or {})
+
+    def _replay(self, cap):
+        st = self.step_obj
+        if st.dp.enabled:
+            # the masked-pixel count of the global batch: formed and all-reduced outside the graph (a collective is not captured)
+            both = cap.inp['surface_mask'] & cap.inp['object_mask']
+            cap.count.copy_(st.dp.global_count_tensor(both))
+            cap.graphs[0].replay()
+            st.dp.allreduce_bucket(cap.trainable)
+            cap.graphs[1].replay()
+        else:
+            cap.graphs[0].replay()

@@ -447,7 +447,8 @@ class PSNetwork(nn.Module):
             # camera rays (~15 launch-bound elementwise kernels) are only needed by the shading: queued beside the
             # visibility launch (side stream), not in front of it
             with on_side():
-                if uv.is_cuda and uv.shape[0] == 1 and uv.dtype == torch.float32:
+                if (uv.is_cuda and uv.shape[0] == 1 and uv.dtype == torch.float32 and tuple(pose.shape[1:]) == (4, 4)
+                        and tuple(intr.shape[1:]) == (4, 4)):  # (psn_camera_rays reads the 4x4 layouts; a 3x3 K takes the torch form)
                     # rays of the surface pixels only, normalised and negated, in one launch (psn_camera_rays)
                     pts2c = hip.camera_rays(uv.contiguous(), pose.contiguous().float(), intr.contiguous().float(), idx, scale=-1.0)
                 else:

@@ -115,10 +115,38 @@ class TrainStep(object):
           * ``model_input`` already carries 'light_vis_train' (+ 'vis_train_gt') -> a ready-made selection (synthetic
             batches, parity fixtures) is kept;
           * otherwise -> the fixed initial estimates of the batch's lights, normalised (trainer.py:377), supervised
-            against ``model_input['visibility']`` (loss.py:84-85)."""
+            against ``model_input['visibility']`` (loss.py:84-85).
+
+        The step is three device phases -- ``_fwd_bwd`` (forward, losses, backward, gradients gathered into the flat bucket),
+        ``_reduce`` (the data-parallel all-reduce) and ``_optimise`` (Adam + SparseAdam launches) -- around host bookkeeping
+        (train_fix, iteration count, schedulers); stage2/graph.py replays the device phases from HIP graphs."""
         if train_order:
             self.train_fix()
         self.dp.new_step()
+        model_input = self.select_vis_lights(model_input, vidx)
+        terms, out, trainable, train_light = self._fwd_bwd(model_input, ground_truth, l_slt, noise=noise)
+        self._reduce(trainable)
+        self._optimise(l_slt, trainable, train_light)
+        self._advance(train_light)
+        return terms, out
+
+    def select_vis_lights(self, model_input, vidx):
+        """The vis_plus draw of a step (host RNG + two gathers from the resident tables); other batches pass through."""
+        if self.vis_plus is None or vidx is None:
+            return model_input
+        model_input = dict(model_input)
+        # under data parallelism 'sampling_idx' is this rank's pixel slice (dist.shard_stage2) and every rank draws
+        # the same rows from an identically seeded np.random stream
+        sidx = model_input.get('sampling_idx')
+        if sidx is not None and sidx.dim() == 2:
+            sidx = sidx[0]  # batch dimension of the collated sample (trainer.py:392)
+        model_input['light_vis_train'], model_input['vis_train_gt'] = self.vis_plus.select(vidx, sidx)
+        return model_input
+
+    def _fwd_bwd(self, model_input, ground_truth, l_slt, noise=None, count=None):
+        """Forward, losses, backward; under data parallelism the gradients end up in the flat bucket (not yet reduced).
+        ``count``: the (global) masked-pixel count as a device tensor [1] when the caller has already formed it (graph replay
+        under data parallelism: the count's all-reduce stays outside the captured graph)."""
         model_input = dict(model_input)
         if l_slt.is_cuda and self.light_para.weight.is_cuda:
             # both table lookups + the normalisation in one launch (one more for the dense table gradients in backward)
@@ -127,14 +155,7 @@ class TrainStep(object):
         else:
             model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
             model_input['light_intensity'] = self.light_inten_para(l_slt)
-        if self.vis_plus is not None and vidx is not None:
-            # under data parallelism 'sampling_idx' is this rank's pixel slice (dist.shard_stage2) and every rank draws
-            # the same rows from an identically seeded np.random stream
-            sidx = model_input.get('sampling_idx')
-            if sidx is not None and sidx.dim() == 2:
-                sidx = sidx[0]  # batch dimension of the collated sample (trainer.py:392)
-            model_input['light_vis_train'], model_input['vis_train_gt'] = self.vis_plus.select(vidx, sidx)
-        elif 'light_vis_train' not in model_input:
+        if 'light_vis_train' not in model_input:
             if l_slt.is_cuda and self.light_vis_table.is_cuda:
                 from .. import hip
                 model_input['light_vis_train'] = hip.light_rows_fwd(self.light_vis_table.contiguous(), None, l_slt.long().contiguous())[0]
@@ -145,7 +166,9 @@ class TrainStep(object):
         # synchronisation -- is taken BEFORE the forward pass: afterwards the host runs ahead of the GPU through
         # forward, losses and backward instead of stalling behind the 22 ms visibility launch.
         both = model_input['surface_mask'] & model_input['object_mask']
-        if self.FUSED_LOSSES and both.is_cuda:
+        if count is not None:
+            pass
+        elif self.FUSED_LOSSES and both.is_cuda:
             # the count stays on the device (all-reduced there under data parallelism): the fused loss kernels divide by
             # it, so the step has no host synchronisation of its own (the model's only one is the surface-pixel list,
             # and a batch may bring that along as 'surface_idx')
@@ -164,10 +187,11 @@ class TrainStep(object):
             terms_n = self.loss_n(out, count=count)
             loss = terms['loss'] + terms_n['loss']
         train_light = self.light_para.weight.requires_grad
+        trainable = None
         if self.dp.enabled:
             trainable = [p for p in self.model.parameters() if p.requires_grad] \
                 + ([self.light_para.weight, self.light_inten_para.weight] if train_light else [])
-            # every .grad dropped; allreduce_grads gathers what autograd hands over into the flat bucket (one multi-tensor copy)
+            # every .grad dropped; gather_grads collects what autograd hands over into the flat bucket (one multi-tensor copy)
             self.dp.prepare_grads(list(self.model.parameters()) + [self.light_para.weight, self.light_inten_para.weight])
         else:
             if isinstance(self.sg_optimizer, FlatAdam):
@@ -181,20 +205,28 @@ class TrainStep(object):
         # (a rank whose pixel slice has no surface pixel gets constants from the model: its loss has no graph, it skips
         # backward and contributes the zero-filled bucket, so the other ranks never wait for a collective it left out)
         if self.dp.enabled:
-            self.dp.allreduce_grads(trainable)
+            self.dp.gather_grads(trainable)
+        terms['total'] = loss
+        terms['normal_loss'] = terms_n['normal_loss']
+        return terms, out, trainable, train_light
+
+    def _reduce(self, trainable):
+        if self.dp.enabled:
+            self.dp.allreduce_bucket(trainable)
+
+    def _optimise(self, l_slt, trainable, train_light):
         self.sg_optimizer.step()
         if hasattr(self.model, 'invalidate_packs'):
             # packs are keyed on the parameters' version counters; fused / capturable optimiser implementations do not bump them
             self.model.invalidate_packs(trainable_only=True)
         if train_light:
             self.light_optimizer.step(rows=l_slt)
+
+    def _advance(self, train_light):
         self.cur_iter += 1
         self.sg_scheduler.step()
         if train_light:
             self.light_scheduler.step()
-        terms['total'] = loss
-        terms['normal_loss'] = terms_n['normal_loss']
-        return terms, out
 
 
 def psnr(img1, img2, mask=None):

@@ -23,13 +23,23 @@ STAGE1_BUNNY = {
 }
 
 
+# depth range of the ray march per object (stage1/configs/<obj>.yaml rendering.near / far: the only hot-path values in
+# which the seven reference configs differ; tests/golden/configs.json pins all of them against the reference files)
+STAGE1_DEPTH_RANGE = {'bunny': (2, 6), 'armadillo': (2, 6), 'bear': (28, 35), 'buddha': (20, 30), 'cow': (32, 39),
+                      'pot2': (23, 30), 'reading': (33, 42)}
+
+
 def stage1_cfg(obj='bunny', **over):
-    """stage1/configs/{bunny,bear}.yaml restricted to the hot-path keys.
-    ``over`` uses 'section.key' names, e.g. ``**{'model.hidden_dim': 64}``."""
+    """stage1/configs/<obj>.yaml restricted to the hot-path keys (files themselves: psnerf_amd.stage1.config.load_config).
+    ``over`` uses 'section.key' names, e.g. ``**{'model.hidden_dim': 64}``.  An unknown object raises: a silently wrong
+    depth range produces a plausible-looking, wrong ray march."""
     import copy
+    if obj not in STAGE1_DEPTH_RANGE:
+        raise ValueError('stage1_cfg: unknown object %r (known: %s)' % (obj, ', '.join(sorted(STAGE1_DEPTH_RANGE))))
     cfg = copy.deepcopy(STAGE1_BUNNY)
-    if obj == 'bear':
-        cfg['rendering'].update(near=28, far=35)
+    near, far = STAGE1_DEPTH_RANGE[obj]
+    cfg['rendering'].update(near=near, far=far)
+    cfg['training'].update(scheduler_milestones=[4000, 8000], scheduler_gamma=0.5)
     for k, v in over.items():
         sec, key = k.split('.')
         cfg[sec][key] = v

@@ -812,6 +812,52 @@ def test_flat_adam_follows_torch_adam(cuda):
         assert_close(p1.detach().cpu(), p2.detach().cpu(), 1e-6, 'after state-dict exchange', atol=1e-7)
 
 
+def test_flat_adam_state_dict_leaves_the_live_state_alone(cuda):
+    """Optimizer.state_dict() hands out the LIVE per-parameter dictionaries; FlatAdam.state_dict() must
+    clone into fresh ones.  step, state_dict(), step, state_dict(): the second checkpoint holds the moments of step 2 (equal
+    to torch.optim.Adam's), the live moments still are views of the flat buffers, and a gradient that is a view of some
+    unrelated 1-D tensor is copied like any loose gradient."""
+    from psnerf_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(4)
+    shapes = [(33, 7), (5,), (64, 64)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    pa = [t.clone().to(cuda).requires_grad_() for t in init]
+    pb = [t.clone().to(cuda).requires_grad_() for t in init]
+    oa, ob = FlatAdam(pa, lr=1e-2), torch.optim.Adam(pb, lr=1e-2, foreach=True)
+    sds = []
+    for it in range(3):
+        oa.attach_grads()
+        ob.zero_grad()
+        foreign = torch.randn(sum(torch.Size(s).numel() for s in shapes) + 100, generator=g).to(cuda)  # NOT a registered flat buffer
+        off = 17
+        for p, q in zip(pa, pb):
+            p.grad = foreign[off:off + p.numel()].view_as(p)  # a contiguous view of a 1-D tensor with arbitrary neighbours
+            q.grad = p.grad.clone()
+            off += p.numel()
+        oa.step()
+        ob.step()
+        sds.append(oa.state_dict())
+        for p in pa:
+            st = oa.state[p]
+            assert st['exp_avg']._base is not None and st['exp_avg']._base.data_ptr() == oa._flat['m'].data_ptr()
+            assert st['exp_avg_sq']._base is not None and st['exp_avg_sq']._base.data_ptr() == oa._flat['v'].data_ptr()
+    ref = ob.state_dict()
+    for k, st in sds[-1]['state'].items():
+        assert float(st['step']) == 3.0
+        assert_close(st['exp_avg'].cpu(), ref['state'][k]['exp_avg'].cpu(), 1e-6, 'exp_avg %d' % k, atol=1e-7)
+        assert_close(st['exp_avg_sq'].cpu(), ref['state'][k]['exp_avg_sq'].cpu(), 1e-6, 'exp_avg_sq %d' % k, atol=1e-9)
+        assert not torch.equal(st['exp_avg'], sds[0]['state'][k]['exp_avg'])  # checkpoints are not frozen at the first one
+    for p, q in zip(pa, pb):
+        assert_close(p.detach().cpu(), q.detach().cpu(), 1e-6, 'params', atol=1e-7)
+    # alignment gaps of all flat buffers still hold zeros
+    f = oa._flat
+    live = torch.zeros_like(f['p'], dtype=torch.bool)
+    for p in pa:
+        live[f['off'][p]:f['off'][p] + p.numel()] = True
+    for name in ('p', 'm', 'v'):
+        assert float(f[name][~live].abs().max()) == 0.0, name
+
+
 @pytest.mark.parametrize('h,w', [(512, 612), (23, 37), (64, 64)])
 def test_stage1_targets_equal_torch_formulation(cuda, h, w):
     """psn_stage1_targets against the torch formulation of training.py:166-191 (five nearest grid_samples, the angle mask on

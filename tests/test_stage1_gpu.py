@@ -540,6 +540,11 @@ def test_march_sweep_with_early_exit_is_bit_identical(cuda, n_steps, n):
     assert torch.equal(occ_early[needed], occ_dense[needed])
     in_block = neg.any(1) & ((first % 64) != 63)
     assert bool((skip[in_block] != 0).all())
+    # the flag records the LOWEST block that holds a sign change (INT_MAX - block): for a ray that starts in free space that
+    # is the block of its first sign change, whatever order the workgroups ran in (a boolean let block b leave
+    # when block b + 1 had raised it first)
+    free_start = in_block & (val[:, 0] < 0)
+    assert torch.equal((0x7fffffff - skip[free_start]).long(), first[free_start] // 64)
     if n_steps > 64:
         assert int((skip != 0).sum()) > 0
 

@@ -3,7 +3,7 @@
 /root/reference) on seeded inputs, and cross-check the oracle against it.
 
 Runs only in the build container (the reference never travels to the GPU box).
-Usage:  python tools/gen_golden.py stage1 | stage2 | trainer | all
+Usage:  python tools/gen_golden.py stage1 | stage2 | trainer | configs | all
 
 Weights are not stored for full-width nets: tests regenerate them from seeds
 (tests/helpers.py) and compare the sha256 stored in the fixture.
@@ -852,12 +852,67 @@ def gen_trainer(vis_plus=False):
     print('stage2 trainer golden written (vis_plus=%s)' % vis_plus)
 
 
+def gen_configs():
+    """tests/golden/configs.json: the hot-path VALUES of all 14 reference configuration files (no file text).
+    Stage 1: read by the reference's OWN loader (stage1/dataloading/configloading.py, imported as a file: it needs only
+    PyYAML).  Stage 2: pyhocon is not in this image, so the .conf files are read by an independent line scanner below
+    (section stack + ``key = value``; it shares no code with psnerf_amd.stage2.conf) -- the CPU tests then check
+    psnerf_amd's readers, ``bear_conf()`` / ``object_conf()`` and ``stage1_cfg()`` against these values."""
+    import importlib.util
+    import json
+    import re
+    spec = importlib.util.spec_from_file_location('ref_configloading', os.path.join(REF, 'stage1/dataloading/configloading.py'))
+    ref_cl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_cl)
+    from psnerf_amd.stage1.config import HOT_KEYS, hot_path, load_config
+    out = {'stage1': {}, 'stage2': {}}
+    for obj in ('armadillo', 'bear', 'buddha', 'bunny', 'cow', 'pot2', 'reading'):
+        path = os.path.join(REF, 'stage1/configs/%s.yaml' % obj)
+        cfg = ref_cl.load_config(path)
+        out['stage1'][obj] = {sec: {k: cfg[sec][k] for k in keys if k in cfg.get(sec, {})} for sec, keys in HOT_KEYS.items()}
+        assert hot_path(load_config(path)) == out['stage1'][obj], obj  # the build's reader == the reference's, here and now
+        # independent scan of stage2/confs/<obj>.conf
+        stack, flat = [], {}
+        for raw in open(os.path.join(REF, 'stage2/confs/%s.conf' % obj)):
+            line = raw.split('#')[0].strip()
+            if not line:
+                continue
+            if line.endswith('{'):
+                stack.append(line[:-1].strip())
+            elif line == '}':
+                stack.pop()
+            else:
+                k, v = [t.strip() for t in line.split('=', 1)]
+                if re.fullmatch(r'\[.*\]', v):
+                    val = [json.loads(t) for t in v[1:-1].split(',') if t.strip()]
+                elif v in ('True', 'False', 'true', 'false'):
+                    val = v.lower() == 'true'
+                else:
+                    try:
+                        val = int(v)
+                    except ValueError:
+                        try:
+                            val = float(v)
+                        except ValueError:
+                            val = v
+                flat['.'.join(stack + [k])] = val
+        assert not stack
+        # everything but paths / names / plot cadence (which the hot path never reads)
+        skip = ('dataset.', 'train.expname', 'train.stage1_shape_path', 'train.plot_freq', 'train.ckpt_freq', 'train.dataset_class')
+        out['stage2'][obj] = {k: v for k, v in sorted(flat.items()) if not k.startswith(skip)}
+    with open(os.path.join(GOLDEN, 'configs.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('configs golden written: %d stage-1 + %d stage-2 objects' % (len(out['stage1']), len(out['stage2'])))
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     os.makedirs(GOLDEN, exist_ok=True)
     if what == 'all':  # separate processes: stage1 and stage2 both own a top-level ``utils``/``model`` package
-        for s in ('stage1', 'stage2', 'trainer'):
+        for s in ('stage1', 'stage2', 'trainer', 'configs'):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), s])
+    elif what == 'configs':
+        gen_configs()
     elif what == 'trainer':
         gen_trainer(False)
         gen_trainer(True)
