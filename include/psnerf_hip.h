@@ -575,6 +575,17 @@ int psn_x3_pack(const float* W, int64_t ldw, int rows, int cols, int permuted, i
 int psn_x3_pack_bias(const float* V, int64_t n, uint16_t* dst, void* stream);
 int psn_mlp_infer_x3_grouped(const PsnBf16Desc* desc, const uint16_t* packed_w, const uint16_t* bias_steps, const float* final_bias,
                              const float* U, int64_t rows_per_group, const float* V, int64_t n_groups, float* out, void* stream);
+/* The stage-1 occupancy network (stage1/model/network.py:85-101: softplus(beta = 100) stack on the positional encoding of the
+ * point, cat[h, pe] / sqrt(2) in front of the skip layer, output row 0) on the split-bf16 engine, for GRADIENT-FREE queries
+ * (shadow rays rendering.py:378-408, ray march :447-462, shape_extract :297-376): out[r] = sigmoid(-10 logit(points[r])).
+ * desc: n_hidden, n_out = 1, out_act; packed_w: layer 0 as 4 natural-order k-steps of its encoding columns (psn_x3_pack,
+ * permuted = 0), every further hidden layer 16 permuted k-steps (the skip layer as ONE 256-input matrix, scaled by 1 / sqrt(2)),
+ * the final row as one stage; bias_steps [n_hidden][4096] (psn_x3_pack_bias); final_bias [32].  The kernel forms the encoding
+ * (pe_octaves, pe_scale: the expressions of psn_pe_encode) and writes it into input features pe_first .. of layer skip_layer
+ * (-1: none).  n_rows_dev / out_rows: as psn_mlp_infer_pe_indirect (row count on the device, outputs scattered). */
+int psn_mlp_infer_x3_occ(const PsnBf16Desc* desc, const uint16_t* packed_w, const uint16_t* bias_steps, const float* final_bias,
+                         const float* points, int64_t n_rows, const long long* n_rows_dev, const int64_t* out_rows, int pe_octaves,
+                         float pe_scale, int skip_layer, int pe_first, float* out, void* stream);
 
 
 /* ------------------------------------------------------------------------

@@ -39,6 +39,14 @@ struct X3Args {
     const float* V;                // [n_groups][n_in_layers * 256] fp32: W_b pe(l_g) + b
     unsigned rows_per_group, tiles_per_group, n_in_layers;
     float* out;
+    // OCC variant (psn_mlp_infer_x3_occ): rows are query points, encoded in the kernel
+    const float* points;           // [n_rows][3]
+    long long n_rows;              // rows (capacity when n_rows_dev is given)
+    const long long* n_rows_dev;   // optional: the row count lives on the device
+    const int64_t* out_rows;       // optional: row r's occupancy goes to out[out_rows[r]]
+    int pe_octaves; float pe_scale;
+    int skip_layer;                // hidden layer whose input is cat[h, pe] / sqrt(2) (stage1/model/network.py:90-91), -1: none
+    int pe_first;                  // first input feature of that layer that is a positional-encoding column (217)
 };
 
 constexpr int kX3Piece = 1024;
@@ -47,6 +55,8 @@ constexpr int kX3StageBytes = 2 * kX3KsBytes;  // 48 KB
 constexpr int kX3BiasBytes = 8 * 1024;
 constexpr int kX3BufBytes = kX3StageBytes + kX3BiasBytes;  // 56 KB per LDS buffer
 constexpr int kX3Waves = 4;
+constexpr int kX3PeStride = 48;              // OCC: per-row encoding in LDS, 3 natural k-steps of 16 columns (39 real + zeros)
+constexpr int kX3PeBytes = kX3Waves * 32 * kX3PeStride * 4;  // 24 KB behind the two stage buffers
 
 // this wave's share of a stage request: pieces [12 wave, 12 wave + 12) of the 48 KB stream part, and -- with_bias -- pieces
 // [2 wave, 2 wave + 2) of the layer's 8 KB bias k-step
@@ -138,32 +148,72 @@ __device__ __forceinline__ void x3_stage_mma(floatx16 (&acc)[8], const xbf16x8* 
     }
 }
 
+// OCC = false: the grouped ReLU network of stage 2 (input block through the fp32 init tables U / V, see the header comment).
+// OCC = true (psn_mlp_infer_x3_occ): the stage-1 occupancy network (stage1/model/network.py:85-101) on query points -- the
+// positional encoding is formed in the prologue with the expressions of pe_encode / mlp_infer_kernel<SRC = 2> and parked in LDS
+// (48 floats per row); layer 0 multiplies its three planes in natural K order (two 48 KB stages: k-steps 0..3, the fourth all
+// zeros); every layer starts from its bias k-step; the activation is softplus(beta = 100) (common.h softplus100_pair, the
+// exact-fp32 engine's code) before the split; the epilogue IN FRONT of the skip layer writes the encoding columns into the
+// input features >= pe_first (217 ... 255: cat[h, pe] of network.py:90, the 1 / sqrt(2) is folded into the packed weights),
+// so that layer is an ordinary 256-input layer; output = sigmoid(-10 logit), optionally scattered (out_rows) for a row count
+// that lives on the device (n_rows_dev) -- the shadow-ray path of stage1/model/rendering.py:378-408.
+template <bool OCC>
 __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char xsmem[];  // 2 x (48 KB stage + 8 KB bias k-step)
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsmem[];  // 2 x (48 KB stage + 8 KB bias k-step) [+ 24 KB encoding]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 31, lh = lane >> 5;
     const int n_hidden = g.d.n_hidden;
-    const unsigned group = blockIdx.x / g.tiles_per_group;
-    const unsigned tile = blockIdx.x - group * g.tiles_per_group;
+    unsigned group = 0, tile = blockIdx.x;
+    long long n_rows_eff = 0;
+    if constexpr (OCC) {
+        n_rows_eff = g.n_rows;
+        if (g.n_rows_dev != nullptr) { const long long nd = *g.n_rows_dev; n_rows_eff = nd < n_rows_eff ? nd : n_rows_eff; }
+        if ((long long)blockIdx.x * (kX3Waves * 32) >= n_rows_eff) return;  // (wave-uniform: before anything is requested)
+    } else {
+        group = blockIdx.x / g.tiles_per_group;
+        tile = blockIdx.x - group * g.tiles_per_group;
+    }
     const unsigned init_stride = g.n_in_layers * 256u;
-    const float* vrow = g.V + (size_t)group * init_stride + 4 * lh;
+    const float* vrow = OCC ? nullptr : g.V + (size_t)group * init_stride + 4 * lh;
 
     const unsigned char* wptr = g.w;  // the NEXT stage to request
     int in_idx = 0;                   // input layers seen so far
     int gstage = 0;
-    // first stage of layer 1 (layer 0 has no weights of its own left) + that layer's bias k-step unless it reads the input block
-    const bool l1_bias = n_hidden > 1 && g.d.has_in[1] == 0;
+    // OCC = false: first stage of layer 1 (layer 0 has no weights of its own left) + that layer's bias k-step unless it reads
+    // the input block.  OCC = true: first stage of layer 0 + its bias k-step.
+    const bool l1_bias = OCC ? true : (n_hidden > 1 && g.d.has_in[1] == 0);
+    const unsigned char* first_bias = OCC ? g.bias : g.bias + kX3BiasBytes;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) x3_dma_piece(wptr, xsmem, g.bias + kX3BiasBytes, wave, lane, j);
-    if (l1_bias) { x3_dma_piece(wptr, xsmem, g.bias + kX3BiasBytes, wave, lane, 12); x3_dma_piece(wptr, xsmem, g.bias + kX3BiasBytes, wave, lane, 13); }
+    for (int j = 0; j < 12; ++j) x3_dma_piece(wptr, xsmem, first_bias, wave, lane, j);
+    if (l1_bias) { x3_dma_piece(wptr, xsmem, first_bias, wave, lane, 12); x3_dma_piece(wptr, xsmem, first_bias, wave, lane, 13); }
     wptr += kX3StageBytes;
 
     const unsigned n = tile * (unsigned)(kX3Waves * 32) + wave * 32 + ln;
-    const bool valid = n < g.rows_per_group;
-    const unsigned row = group * g.rows_per_group + n;
-    const float* urow = g.U + (size_t)(valid ? n : g.rows_per_group - 1) * init_stride + 4 * lh;
+    const bool valid = OCC ? (long long)n < n_rows_eff : n < g.rows_per_group;
+    const unsigned row = OCC ? n : group * g.rows_per_group + n;
+    const float* urow = OCC ? nullptr : g.U + (size_t)(valid ? n : g.rows_per_group - 1) * init_stride + 4 * lh;
+    float* pe_row = reinterpret_cast<float*>(xsmem + 2 * kX3BufBytes) + (wave * 32 + ln) * kX3PeStride;  // OCC: this lane's row
+    if constexpr (OCC) {
+        // positional encoding of this lane's point (network.py:141-150): [p s, sin(2^f p s), cos(2^f p s)] per octave f; the
+        // two lanes of a row share the 18 (octave, coordinate) sincos pairs; expressions as compute_xin_tile (mlp_infer.hip)
+        float q[3] = {0.f, 0.f, 0.f};
+        if (valid) { q[0] = g.points[(size_t)n * 3]; q[1] = g.points[(size_t)n * 3 + 1]; q[2] = g.points[(size_t)n * 3 + 2]; }
+        const int n_pairs = 3 * g.pe_octaves, half = (n_pairs + 1) / 2;
+        for (int pi = lh * half; pi < (lh == 0 ? half : n_pairs); ++pi) {
+            const int f = pi / 3, c = pi - 3 * f;
+            const float arg = ldexpf((c == 0 ? q[0] : (c == 1 ? q[1] : q[2])) * g.pe_scale, f);
+            float sn, cs;
+            sincosf(arg, &sn, &cs);
+            pe_row[3 + 6 * f + c] = sn;
+            pe_row[3 + 6 * f + 3 + c] = cs;
+        }
+        if (lh == 0) { pe_row[0] = q[0] * g.pe_scale; pe_row[1] = q[1] * g.pe_scale; pe_row[2] = q[2] * g.pe_scale; }
+        else for (int col = 3 + 2 * n_pairs; col < kX3PeStride; ++col) pe_row[col] = 0.0f;
+        // (read back by the same wave only -- layer 0 and the epilogue in front of the skip layer --, behind the barrier of
+        //  the first stage)
+    }
     xbf16x8 ones_b;  // K slots 0..2 (lane half 0) carry the constant 1: the three bias pieces add up exactly
     {
         xintx4 o = {lh == 0 ? 0x3F803F80 : 0, lh == 0 ? 0x00003F80 : 0, 0, 0};
@@ -214,8 +264,10 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
 #pragma unroll
         for (int ot = 0; ot < 8; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ot * 64 + lane], ones_b, zero, 0, 0, 0);
     };
-    // ReLU + split of the finished accumulators into the three B-operand planes of the next layer
-    auto epilogue = [&]() __attribute__((always_inline)) {
+    // ReLU (OCC: softplus) + split of the finished accumulators into the three B-operand planes of the next layer; OCC,
+    // inject: the features >= pe_first take the row's encoding columns instead (the cat[h, pe] in front of the skip layer;
+    // pe_first >= 192, so only output tiles 6 and 7 are concerned)
+    auto epilogue = [&](bool inject) __attribute__((always_inline)) {
 #pragma unroll
         for (int ot = 0; ot < 8; ++ot) {
 #pragma unroll
@@ -223,7 +275,21 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
                 xintx4 oh, om, ol;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float c0 = relu1(acc[ot][8 * qp + 2 * i]), c1 = relu1(acc[ot][8 * qp + 2 * i + 1]);
+                    float c0, c1;
+                    if constexpr (OCC) {
+                        f32x2 sp, unused;
+                        softplus100_pair<false>(f32x2{acc[ot][8 * qp + 2 * i], acc[ot][8 * qp + 2 * i + 1]}, sp, unused);
+                        c0 = sp.x; c1 = sp.y;
+                        if (ot >= 6 && inject) {
+                            const int f0 = 32 * ot + 16 * qp + 8 * ((2 * i) >> 2) + 4 * lh + ((2 * i) & 3);  // feature of slot j = 2 i
+                            const int k0 = f0 - g.pe_first, k1 = f0 + 1 - g.pe_first;
+                            const float p0 = pe_row[k0 < 0 ? 0 : k0], p1 = pe_row[k1 < 0 ? 0 : k1];
+                            c0 = k0 >= 0 ? p0 : c0;
+                            c1 = k1 >= 0 ? p1 : c1;
+                        }
+                    } else {
+                        c0 = relu1(acc[ot][8 * qp + 2 * i]); c1 = relu1(acc[ot][8 * qp + 2 * i + 1]);
+                    }
                     int h_, m_, l_;
                     x3_split2(c0, c1, h_, m_, l_);
                     oh[i] = h_; om[i] = m_; ol[i] = l_;
@@ -235,15 +301,38 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
         }
     };
 
-    // layer 0: U[n] + V[g] alone
-    init_acc_uv(0);
-    ++in_idx;
+    if constexpr (OCC) {
+        // layer 0: bias + W_0 pe(x) on the matrix pipe, natural K order: k-step ks, slot j of lane (n, h) = column 16 ks + 8 h + j
+        init_acc_bias();  // (its barrier also orders the encoding writes above against the reads below)
+        xbf16x8 bin[3][4];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const float4 v0 = *reinterpret_cast<const float4*>(pe_row + 16 * ks + 8 * lh), v1 = *reinterpret_cast<const float4*>(pe_row + 16 * ks + 8 * lh + 4);
+            xintx4 oh, om, ol;
+            int h_, m_, l_;
+            x3_split2(v0.x, v0.y, h_, m_, l_); oh[0] = h_; om[0] = m_; ol[0] = l_;
+            x3_split2(v0.z, v0.w, h_, m_, l_); oh[1] = h_; om[1] = m_; ol[1] = l_;
+            x3_split2(v1.x, v1.y, h_, m_, l_); oh[2] = h_; om[2] = m_; ol[2] = l_;
+            x3_split2(v1.z, v1.w, h_, m_, l_); oh[3] = h_; om[3] = m_; ol[3] = l_;
+            bin[0][ks] = __builtin_bit_cast(xbf16x8, oh); bin[1][ks] = __builtin_bit_cast(xbf16x8, om); bin[2][ks] = __builtin_bit_cast(xbf16x8, ol);
+        }
+        {
+            xintx4 z = {0, 0, 0, 0};
+            bin[0][3] = bin[1][3] = bin[2][3] = __builtin_bit_cast(xbf16x8, z);
+        }
+        X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bin[pl][ks]; }), false, g.bias)
+        X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bin[pl][2 + ks]; }), n_hidden > 1, g.bias + kX3BiasBytes)
+    } else {
+        // layer 0: U[n] + V[g] alone
+        init_acc_uv(0);
+        ++in_idx;
+    }
     for (int li = 1; li < n_hidden; ++li) {
-        const bool has_in = g.d.has_in[li] != 0;
-        epilogue();                   // of layer li - 1
+        const bool has_in = !OCC && g.d.has_in[li] != 0;
+        epilogue(OCC && li == g.skip_layer);                   // of layer li - 1
         if (has_in) { init_acc_uv(in_idx); ++in_idx; }
         else init_acc_bias();
-        const bool next_bias = li + 1 < n_hidden && g.d.has_in[li + 1] == 0;
+        const bool next_bias = li + 1 < n_hidden && (OCC || g.d.has_in[li + 1] == 0);
         const unsigned char* next_bsrc = g.bias + (size_t)(li + 1 < n_hidden ? li + 1 : 0) * kX3BiasBytes;
 #define X3_ACT_STAGE(S, LAST)                                                                                 \
         X3_STAGE(([&](int pl, int ks) -> xbf16x8 { return bact[pl][2 * (S) + ks]; }), (LAST) && next_bias, next_bsrc)
@@ -251,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
         X3_ACT_STAGE(4, false) X3_ACT_STAGE(5, false) X3_ACT_STAGE(6, false) X3_ACT_STAGE(7, true)
 #undef X3_ACT_STAGE
     }
-    epilogue();
+    epilogue(false);
 #undef X3_STAGE
     // final layer: one output tile (n_out <= 32), 16 k-steps x 3 planes in ONE 48 KB stage; four accumulator chains
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -283,7 +372,8 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
                     float x = (f[0][v] + f[1][v]) + (f[2][v] + f[3][v]) + g.final_bias[m];
                     if (g.d.out_act == PSN_OUT_SIGMOID) x = sigmoidf_(x);
                     else if (g.d.out_act == PSN_OUT_OCC) x = sigmoidf_(x * -10.0f);
-                    g.out[(int64_t)row * n_out + m] = x;
+                    const int64_t orow = (OCC && g.out_rows != nullptr) ? g.out_rows[row] : (int64_t)row;
+                    g.out[orow * n_out + m] = x;
                 }
             }
         }
@@ -391,12 +481,47 @@ extern "C" int psn_mlp_infer_x3_grouped(const PsnBf16Desc* desc, const uint16_t*
     const int64_t blocks = (int64_t)a.tiles_per_group * n_groups;
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer_x3_grouped: too many rows");
     const size_t lds_bytes = 2 * kX3BufBytes;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_infer_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_infer_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
         set_error("mlp_infer_x3_grouped: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
         return PSN_E_LAUNCH;
     }
-    hipLaunchKernelGGL(mlp_infer_x3_kernel, dim3((unsigned)blocks), dim3(kX3Waves * 64), lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mlp_infer_x3_kernel<false>, dim3((unsigned)blocks), dim3(kX3Waves * 64), lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer_x3_grouped");
+    return PSN_OK;
+}
+
+// Stage-1 occupancy network on the split-bf16 engine: sigmoid(-10 logit) of n_rows query points, see mlp_infer_x3_kernel<true>.
+extern "C" int psn_mlp_infer_x3_occ(const PsnBf16Desc* desc, const uint16_t* packed_w, const uint16_t* bias_steps, const float* final_bias,
+                                    const float* points, int64_t n_rows, const long long* n_rows_dev, const int64_t* out_rows,
+                                    int pe_octaves, float pe_scale, int skip_layer, int pe_first, float* out, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(desc && packed_w && bias_steps && final_bias && points && out, "mlp_infer_x3_occ: null pointer");
+    const PsnBf16Desc& d = *desc;
+    PSN_CHECK_ARG(d.n_hidden >= 2 && d.n_hidden <= PSN_MLP_MAX_LAYERS && d.n_out >= 1 && d.n_out <= 32, "mlp_infer_x3_occ: n_hidden=%d n_out=%d", d.n_hidden, d.n_out);
+    PSN_CHECK_ARG(d.out_act >= PSN_OUT_NONE && d.out_act <= PSN_OUT_OCC, "mlp_infer_x3_occ: out_act=%d", d.out_act);
+    PSN_CHECK_ARG(pe_octaves >= 0 && 3 + 6 * pe_octaves <= kX3PeStride, "mlp_infer_x3_occ: %d octaves do not fit %d encoding columns", pe_octaves, kX3PeStride);
+    PSN_CHECK_ARG(skip_layer < d.n_hidden && (skip_layer < 1 || (pe_first >= 192 && pe_first + 3 + 6 * pe_octaves <= 256)),
+                  "mlp_infer_x3_occ: skip_layer=%d pe_first=%d (the encoding columns must be input features 192..255 of a layer >= 1)", skip_layer, pe_first);
+    PSN_CHECK_ARG((((uintptr_t)packed_w | (uintptr_t)bias_steps) & 15) == 0, "mlp_infer_x3_occ: buffers must be 16-byte aligned");
+    PSN_CHECK_ARG(n_rows >= 0 && n_rows < (1ll << 31), "mlp_infer_x3_occ: 32-bit row arithmetic: rows < 2^31");
+    if (n_rows == 0) return PSN_OK;
+    X3Args a = {};
+    a.d = d;
+    a.w = reinterpret_cast<const unsigned char*>(packed_w);
+    a.bias = reinterpret_cast<const unsigned char*>(bias_steps);
+    a.final_bias = final_bias;
+    a.points = points; a.n_rows = n_rows; a.n_rows_dev = n_rows_dev; a.out_rows = out_rows;
+    a.pe_octaves = pe_octaves; a.pe_scale = pe_scale; a.skip_layer = skip_layer < 1 ? -1 : skip_layer; a.pe_first = pe_first;
+    a.out = out;
+    const int64_t blocks = (n_rows + kX3Waves * 32 - 1) / (kX3Waves * 32);
+    const size_t lds_bytes = 2 * kX3BufBytes + kX3PeBytes;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_infer_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+        set_error("mlp_infer_x3_occ: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+        return PSN_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(mlp_infer_x3_kernel<true>, dim3((unsigned)blocks), dim3(kX3Waves * 64), lds_bytes, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("mlp_infer_x3_occ");
     return PSN_OK;
 }

@@ -518,6 +518,62 @@ class PackedX3Grouped(object):
         return hip.mlp_infer_x3_grouped(self.desc, self.w, self.bias_steps, self.final_bias, U, V, out=out, macs_per_row=self.macs_per_row)
 
 
+class PackedX3Occ(object):
+    """The stage-1 occupancy network packed for the split-bf16 engine (csrc/mlp_infer_x3.hip, OCC variant; opt-in experiment for
+    GRADIENT-FREE queries: shadow rays, ray march, root finder inputs).  Same call surface as PackedMLP.on_points."""
+
+    def __init__(self, desc, w, bias_steps, final_bias, skip_layer, pe_first, macs_per_row):
+        self.desc, self.w, self.bias_steps, self.final_bias = desc, w, bias_steps, final_bias
+        self.skip_layer, self.pe_first, self.macs_per_row = skip_layer, pe_first, macs_per_row
+
+    def on_points(self, points, pe_octaves, pe_scale, out=None, n_rows_dev=None, out_rows=None):
+        return hip.mlp_infer_x3_occ(self.desc, self.w, self.bias_steps, self.final_bias, points, pe_octaves, pe_scale,
+                                    self.skip_layer, self.pe_first, out=out, n_rows_dev=n_rows_dev, out_rows=out_rows,
+                                    macs_per_row=self.macs_per_row)
+
+
+def pack_geo_occupancy_x3(weights, biases, skips, d_pe):
+    """stage1 occupancy-only network (stage1/model/network.py:85-95,124-125; same arguments as pack_geo_occupancy) for the
+    split-bf16 engine.  Weight stream in execution order: layer 0 = 4 natural-order k-steps of the encoding columns (two 48 KB
+    stages), every further hidden layer 16 permuted k-steps, the final layer's output row 0 as one stage; every hidden layer
+    has a bias k-step.  The skip layer (input cat[h, pe] / sqrt(2)) is an ordinary 256-input layer: its encoding columns are
+    input features pe_first .. pe_first + d_pe - 1, which the kernel fills in (1 / sqrt(2) folded into the weights here)."""
+    n = len(weights)
+    dev = weights[0].device
+    assert len(skips) <= 1 and d_pe <= 48 and 3 <= n <= hip.MAX_LAYERS + 1
+    assert all(w.shape[0] <= 256 for w in weights[:-1]) and weights[0].shape[1] == d_pe
+    desc = hip.PsnBf16Desc()
+    desc.n_hidden, desc.n_out, desc.out_act = n - 1, 1, hip.OUT_OCC
+    KS = hip.X3_KS
+    final_elems = 16 * 3 * 512
+    buf = torch.zeros(4 * KS + (n - 2) * 16 * KS + final_elems + 56 * 512, device=dev, dtype=torch.bfloat16)  # (+ 56 KB: the last request over-reads)
+    bias_steps = torch.zeros(n - 1, 4096, device=dev, dtype=torch.bfloat16)
+    inv = 1.0 / math.sqrt(2.0)
+    off, macs, skip_layer, pe_first = 0, 0, -1, 0
+    for li in range(n - 1):
+        W, b = weights[li].detach().float(), biases[li].detach().float()
+        macs += W.shape[0] * W.shape[1]
+        desc.has_in[li] = int(li == 0)
+        if li == 0:
+            hip.x3_pack(W.contiguous(), False, 8, 0, 4, buf[off:off + 4 * KS])
+            off += 4 * KS
+        else:
+            if li in skips:
+                assert W.shape[1] == 256, 'the skip layer reads cat[h, pe]: 256 input features'
+                W = W * inv
+                skip_layer, pe_first = li, W.shape[1] - d_pe
+            hip.x3_pack(W.contiguous(), True, 8, 0, 16, buf[off:off + 16 * KS])
+            off += 16 * KS
+        bp = torch.zeros(1, 256, device=dev)
+        bp[0, :b.numel()] = b
+        hip.x3_pack_bias(bp, bias_steps[li:li + 1])
+    macs += weights[-1].shape[1]
+    hip.x3_pack(weights[-1].detach().float()[:1].contiguous(), True, 1, 0, 16, buf[off:off + final_elems])
+    fb = torch.zeros(32, device=dev)
+    fb[0] = biases[-1].detach().float()[0]
+    return PackedX3Occ(desc, buf, bias_steps, fb, skip_layer, pe_first, macs)
+
+
 def pack_relu_mlp_x3_grouped(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE):
     """stage2 Network (stage2/model/renderer.py:34-49) of width 256 for the split-bf16 engine, grouped form.  Weight stream in
     execution order (include/psnerf_hip.h, psn_mlp_infer_x3_grouped)."""

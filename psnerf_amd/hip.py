@@ -152,6 +152,7 @@ SIGNATURES = {
     'psn_x3_pack': (i32, [c_f, i64, i32, i32, i32, i32, i32, i32, c_f, c_f]),
     'psn_x3_pack_bias': (i32, [c_f, i64, c_f, c_f]),
     'psn_mlp_infer_x3_grouped': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, c_f, i64, c_f, i64, c_f, c_f]),
+    'psn_mlp_infer_x3_occ': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, c_f, i64, c_f, c_f, i32, f32, i32, i32, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library out of date: fail loudly
@@ -822,7 +823,11 @@ def gemm_tn_grouped(items, split_k=None):
                 tiles = ((it['A'].shape[1] + 127) // 128) * ((it['B'].shape[1] + 127) // 128)
                 work += tiles * (2 if it.get('A2') is not None else 1)
         want = max(1, (1024 + work - 1) // max(work, 1))
-        split_k = int(max(1, min(want, K // 512 if K >= 512 else 1, 256)))
+        # K chunks of at least 512 rows -- for a SHORT product (the 128- / 64-wide BRDF / normal networks of a 4096-pixel rank
+        # shard: K = 7k rows, 5 - 6 tiles) that bound left 84 workgroups of 33 k-steps each on 256 CUs, 100 us per call that
+        # nothing else filled; there a chunk may shrink to 128 rows (8 k-steps): 340 workgroups, the reduction is 20 MB
+        min_rows = 512 if K >= 16384 else 128
+        split_k = int(max(1, min(want, K // min_rows if K >= min_rows else 1, 256)))
     for c0 in range(0, len(items), MAX_GROUP):
         chunk = items[c0:c0 + MAX_GROUP]
         arr = (PsnGemmTnItem * len(chunk))()
@@ -1121,6 +1126,31 @@ def mlp_infer_x3_grouped(desc, packed_w, bias_steps, final_bias, U, V, out=None,
     with _Prof('mlp_infer_x3', n_groups * rows, None if macs_per_row is None else 2.0 * macs_per_row * n_groups * rows):
         _check(_lib.psn_mlp_infer_x3_grouped(ctypes.byref(desc), packed_w.data_ptr(), bias_steps.data_ptr(), _ptr(final_bias, 'final_bias'),
                                              _ptr(U, 'U'), rows, _ptr(V, 'V'), n_groups, _ptr(out, 'out'), _stream()), 'mlp_infer_x3_grouped')
+    return out
+
+
+def mlp_infer_x3_occ(desc, packed_w, bias_steps, final_bias, points, pe_octaves, pe_scale, skip_layer, pe_first, out=None,
+                     n_rows_dev=None, out_rows=None, macs_per_row=None):
+    """sigmoid(-10 logit) of the stage-1 occupancy network for [Q, 3] points on the split-bf16 engine (psn_mlp_infer_x3_occ):
+    the encoding is formed in the kernel, the activation is softplus(beta = 100).  n_rows_dev / out_rows as hip.mlp_infer_pe."""
+    Q = points.shape[0]
+    assert points.dim() == 2 and points.shape[1] == 3
+    if out is None:
+        assert out_rows is None
+        out = torch.empty(Q, desc.n_out, device=points.device, dtype=torch.float32)
+    for t, nm in ((packed_w, 'packed_w'), (bias_steps, 'bias_steps')):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+            raise RuntimeError('%s: must be a contiguous bfloat16 HIP tensor' % nm)
+    assert bias_steps.numel() == desc.n_hidden * 4096 and final_bias.numel() == 32 and desc.n_out == 1
+    if n_rows_dev is not None:
+        assert n_rows_dev.is_cuda and n_rows_dev.dtype == torch.int64 and n_rows_dev.numel() == 1
+    if out_rows is not None:
+        assert out_rows.is_cuda and out_rows.dtype == torch.int64 and out_rows.is_contiguous() and out_rows.numel() >= Q
+    with _Prof('mlp_infer_x3_occ', Q, None if macs_per_row is None else 2.0 * macs_per_row * Q):
+        _check(_lib.psn_mlp_infer_x3_occ(ctypes.byref(desc), packed_w.data_ptr(), bias_steps.data_ptr(), _ptr(final_bias, 'final_bias'),
+                                         _ptr(points, 'points'), Q, None if n_rows_dev is None else n_rows_dev.data_ptr(),
+                                         None if out_rows is None else out_rows.data_ptr(), int(pe_octaves), float(pe_scale),
+                                         int(skip_layer), int(pe_first), _ptr(out, 'out'), _stream()), 'mlp_infer_x3_occ')
     return out
 
 

@@ -83,6 +83,12 @@ class NeuralNetwork(nn.Module):
         self._pack_epoch = 0
         self._packed = None
         self._packed_key = None
+        # 'fp32' (default, exact) or 'bf16x6': GRADIENT-FREE occupancy queries (shadow rays, ray-march sweep, shape_extract;
+        # stage1/model/rendering.py:297-523) on the split-bf16 engine -- fp32-class arithmetic on the bf16 matrix pipe
+        # (csrc/mlp_infer_x3.hip, OCC variant).  Opt-in experiment, never the headline; every training path stays exact fp32.
+        self.inference_precision = 'fp32'
+        self._packed_x3 = None
+        self._packed_x3_key = None
         self._chains = None
         self._chains_key = None
         self._app_packed = None
@@ -185,7 +191,11 @@ class NeuralNetwork(nn.Module):
         logit, feat, grad = self._geo_parts(p_flat, with_grad)
         return torch.cat([logit, feat], dim=1), grad
 
-    def _occupancy_packed(self):
+    def _occupancy_packed(self, allow_x3=False):
+        """The packed occupancy network of the exact-fp32 engine; ``allow_x3``: callers that only use ``.on_points`` get the
+        split-bf16 pack instead when the module's ``inference_precision`` is 'bf16x6' (opt-in, gradient-free queries)."""
+        if allow_x3 and getattr(self, 'inference_precision', 'fp32') == 'bf16x6' and not torch.is_grad_enabled():
+            return self._occupancy_packed_x3()
         key = self._params_key()
         if self._packed is None or self._packed_key != key:
             with torch.no_grad():
@@ -195,6 +205,18 @@ class NeuralNetwork(nn.Module):
                 self._packed = fused.pack_geo_occupancy(Ws, bs, self.skips, self.d_pe)
             self._packed_key = key
         return self._packed
+
+    def _occupancy_packed_x3(self):
+        """The occupancy network for the split-bf16 engine (opt-in: ``inference_precision = 'bf16x6'``; gradient-free queries
+        only -- shadow rays, ray march, shape_extract; rendering.py:378-523): fp32-class arithmetic on the bf16 matrix pipe."""
+        key = self._params_key()
+        if getattr(self, '_packed_x3', None) is None or self._packed_x3_key != key:
+            with torch.no_grad():
+                Ws = self._effective('lin', self.n_geo, [1.0] * self.n_geo)
+                bs = [getattr(self, 'lin%d' % l).bias for l in range(self.n_geo)]
+                self._packed_x3 = fused.pack_geo_occupancy_x3(Ws, bs, self.skips, self.d_pe)
+            self._packed_x3_key = key
+        return self._packed_x3
 
     # ---- reference API ----------------------------------------------------------------------------
     def infer_occ(self, p):
@@ -254,7 +276,7 @@ class NeuralNetwork(nn.Module):
     def occupancy(self, p_flat):
         """sigmoid(-10 * logit) for [Q,3] points without a graph: fused register-resident kernel, positional encoding in
         its prologue (network.py:141-150 + 85-101 in one launch; no [Q,64] table in HBM)."""
-        packed = self._occupancy_packed()
+        packed = self._occupancy_packed(allow_x3=True)
         return packed.on_points(p_flat.contiguous(), self.octaves_pe, 1.0 / self.rescale)
 
     def forward(self, p, ray_d=None, only_occupancy=False, return_logits=False, return_addocc=False, noise=False,

@@ -139,7 +139,8 @@ class Renderer(nn.Module):
         u = self._u(n_steps, dev)
         m = self.model
         if (self.FUSED_SWEEP and not clip and n_steps % 64 == 0 and ray0.is_cuda and hasattr(m, '_occupancy_packed')
-                and m._hidden_is_256()):
+                and m._hidden_is_256() and getattr(m, 'inference_precision', 'fp32') != 'bf16x6'):
+            # (with the opt-in split-bf16 engine the sweep takes the two-launch form below: self._occ -> model.occupancy)
             # one launch: sweep points generated and encoded in the occupancy kernel, a workgroup = 64 consecutive steps of
             # one ray, and the blocks behind a ray's first sign change are not evaluated (psn_march_sweep; the reference's
             # result depends on nothing behind it, rendering.py:472-504)
@@ -489,7 +490,7 @@ class Renderer(nn.Module):
             if self.SHADOW_SYNC_FREE and hasattr(m, '_occupancy_packed') and m._hidden_is_256():
                 # the network runs over the compacted list straight away: its length stays on the device (workgroups behind it
                 # leave at once) and the occupancies are scattered to their (ray, step) slots by the kernel itself
-                m._occupancy_packed().on_points(pts, m.octaves_pe, 1.0 / m.rescale, out=alpha, n_rows_dev=counter, out_rows=rows)
+                m._occupancy_packed(allow_x3=True).on_points(pts, m.octaves_pe, 1.0 / m.rescale, out=alpha, n_rows_dev=counter, out_rows=rows)
             else:
                 n_in = int(counter.item())  # one host synchronisation per launch group
                 if n_in > 0:

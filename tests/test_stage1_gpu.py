@@ -682,3 +682,86 @@ def test_fused_optimizer_does_not_leave_stale_weight_packs(cuda):
     assert losses[False][2] != losses[False][0], 'the steps must move the loss for this test to mean anything'
     for a, b in zip(losses[False], losses[True]):
         assert abs(a - b) <= 1e-4 * abs(a), (losses[False], losses[True])
+
+
+# ---- split-bf16 ("bf16x6") occupancy engine: opt-in, gradient-free queries only (csrc/mlp_infer_x3.hip, OCC variant) -----------
+@pytest.mark.parametrize('n', [1, 127, 128, 129, 5000, 70001])
+def test_x3_occupancy_engine_has_fp32_class_accuracy(cuda, n):
+    """NeuralNetwork.occupancy with inference_precision = 'bf16x6' (every fp32 operand as three bf16 planes, six partial
+    products per multiply, softplus in fp32, encoding formed in the kernel) against the float64 evaluation of the oracle:
+    the SAME elementwise gate the exact engine has to pass (1e-4 |ref| + 1e-6), and an error of the size of the exact-fp32
+    engine's own; ragged row counts, far-away points with large sin / cos arguments."""
+    from oracle import stage1 as o1
+    cfg, net, ren = _renderer(cuda)
+    g = torch.Generator().manual_seed(n)
+    p = ((torch.rand(n, 3, generator=g) - 0.5) * 2.6)
+    if n > 2:
+        p[0] = 0.0
+        p[1] = torch.tensor([250.0, -1e-3, 3.1415927])
+    onet = o1.NeuralNetwork(cfg)
+    onet.load_state_dict(stage1_state_dict(cfg, seed=11))
+    onet.double()
+    with torch.no_grad():
+        truth = onet(p.double(), only_occupancy=True).reshape(-1, 1)
+        assert net.inference_precision == 'fp32'
+        exact = net.occupancy(p.to(cuda)).cpu()
+        net.inference_precision = 'bf16x6'
+        got = net.occupancy(p.to(cuda)).cpu()
+        net.inference_precision = 'fp32'
+    assert got.shape == (n, 1)
+    assert_close(got, truth.float(), 1e-4, 'bf16x6 occupancy vs float64', atol=ATOL_UNIT)
+    e_x3, e_32 = float((got.double() - truth).abs().max()), float((exact.double() - truth).abs().max())
+    assert e_x3 <= 3.0 * e_32 + 2e-7, (e_x3, e_32)
+
+
+def test_x3_occupancy_indirect_form_and_gradient_paths_stay_exact(cuda):
+    """The indirect form (capacity-sized grid, device-resident length, scattered outputs: the shadow-ray path) equals the
+    direct launch on the valid prefix and leaves other destinations alone; with gradients enabled the module ignores the
+    opt-in (training never runs on the split engine)."""
+    cfg, net, ren = _renderer(cuda)
+    g = torch.Generator().manual_seed(4)
+    cap = 1000
+    pts = (torch.rand(cap, 3, generator=g) * 2 - 1).to(cuda)
+    perm = torch.randperm(3 * cap, generator=g)[:cap].to(cuda)
+    net.inference_precision = 'bf16x6'
+    try:
+        with torch.no_grad():
+            packed = net._occupancy_packed(allow_x3=True)
+            assert type(packed).__name__ == 'PackedX3Occ'
+            ref = packed.on_points(pts, net.octaves_pe, 1.0 / net.rescale).reshape(-1)
+            for n in (0, 1, 127, 128, 129, 640, cap):
+                out = torch.full((3 * cap,), -7.0, device=cuda)
+                cnt = torch.tensor([n], dtype=torch.int64, device=cuda)
+                packed.on_points(pts, net.octaves_pe, 1.0 / net.rescale, out=out, n_rows_dev=cnt, out_rows=perm)
+                want = torch.full((3 * cap,), -7.0, device=cuda)
+                want[perm[:n]] = ref[:n]
+                assert torch.equal(out, want), n
+        assert type(net._occupancy_packed(allow_x3=True)).__name__ == 'PackedMLP'  # gradients enabled: the exact engine
+        assert type(net._occupancy_packed()).__name__ == 'PackedMLP'               # march sweep / root finder: always exact
+    finally:
+        net.inference_precision = 'fp32'
+
+
+def test_x3_occupancy_engine_passes_the_march_and_light_visibility_goldens(cuda):
+    """Gates of the opt-in engine: with inference_precision = 'bf16x6' the ray march of the golden case
+    classifies every ray as the reference does (hit / miss / starts-inside masks EQUAL), the refined depths and the
+    shadow-ray light visibility stay within the bounds the exact path is held to."""
+    from psnerf_amd.stage1.rendering import camera_origin, pixel_rays
+    g = np.load(os.path.join(GOLDEN, 'stage1_march.npz'))
+    cfg, net, ren = _renderer(cuda)
+    net.inference_precision = 'bf16x6'
+    try:
+        pix, K, c2w = T(g['pix'], cuda), T(g['K'], cuda), T(g['c2w'], cuda)
+        cam = camera_origin(pix.shape[1], c2w)
+        rays = pixel_rays(pix, K, c2w)
+        rays = rays / rays.norm(2, 2).unsqueeze(-1)
+        d = ren.ray_marching(cam, rays, n_steps=[256, 257], n_secant_steps=8, rad=2.0, depth_range=[2, 6]).cpu()
+        ref = torch.from_numpy(g['d_i'])
+        fin = torch.isfinite(ref)
+        assert torch.equal(fin, torch.isfinite(d)), 'hit / miss classification differs'
+        assert torch.equal(ref == 0, d == 0)
+        assert_close(d[fin], ref[fin], 1e-4, 'd_i', atol=ATOL_DEPTH)
+        lv = ren.light_visibility(surf=T(g['surf'], cuda), light_dir=T(g['ldir'], cuda)).cpu()
+        assert_close(lv, g['light_vis'], 1e-4, 'light visibility', atol=ATOL_UNIT)
+    finally:
+        net.inference_precision = 'fp32'

@@ -56,11 +56,19 @@ def main():
         v_new, t_new = timed(lambda: ren.light_visibility(surf=surf, light_dir=ld))
         n_in, n_all = ren.last_shadow_stats if args.lights * args.points * S <= (1 << 24) else (None, None)
         v_old, t_old = timed(dense)
+        # opt-in split-bf16 ("bf16x6") occupancy engine: fp32-class arithmetic on the bf16 matrix pipe (csrc/mlp_infer_x3.hip)
+        net.inference_precision = 'bf16x6'
+        v_x3, t_x3 = timed(lambda: ren.light_visibility(surf=surf, light_dir=ld))
+        net.inference_precision = 'fp32'
     rows = args.points * args.lights * S
     print(json.dumps({'workload': 'light_visibility: %d surface points x %d lights x %d samples = %.3g rows' % (args.points, args.lights, S, rows),
                       'dense_seconds': round(t_old, 4), 'in_box_seconds': round(t_new, 4), 'speedup': round(t_old / t_new, 2),
                       'max_abs_diff': float((v_new - v_old).abs().max()), 'bit_identical': bool(torch.equal(v_new, v_old)),
-                      'mean_visibility': float(v_new.mean())}))
+                      'mean_visibility': float(v_new.mean()),
+                      'bf16x6_seconds': round(t_x3, 4), 'bf16x6_speedup_vs_in_box': round(t_new / t_x3, 3),
+                      'bf16x6_max_abs_diff_vs_fp32': float((v_x3 - v_new).abs().max()),
+                      'bf16x6_note': 'opt-in (NeuralNetwork.inference_precision = "bf16x6"): same compaction, occupancy network on the '
+                                     'split-bf16 engine; dtype label: f32 emulated on the bf16 matrix pipe, never the headline'}))
 
 
 if __name__ == '__main__':
