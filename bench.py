@@ -302,7 +302,7 @@ def cfg4_case(device, dp, px_global, rank, world, steps, modes=('eager', 'graph'
         if mode == 'eager':
             fn = lambda: step.step(inp, gt, l_slt, train_order=False)
         else:
-            run = GraphedTrainStep(step)
+            run = GraphedTrainStep(step, adopt_inputs=True)
             fn = lambda: run.step(inp, gt, l_slt, train_order=False)
         ms, host_ms = time_steps(fn, steps, 5, world, device)
         out[mode] = {'ms_per_step': round(ms, 3), 'host_issue_ms': round(host_ms, 3),

@@ -466,6 +466,13 @@ int psn_stage1_targets(const float* pix, int64_t n, int h, int w, const float* i
                        const float* normal, const float* norm_mask, const float* world_mat, int use_angle, float cos_thresh,
                        float* rgb_gt, float* mask_gt, unsigned char* mask_valid_out, float* normal_gt,
                        unsigned char* norm_mask_out, void* stream);
+/* Front of a stage-2 step (stage2/trainer.py:355-392, stage2/model/renderer.py:110-152), one launch each:
+ * psn_mask_count: out[0] = #{i : mask_a[i] && mask_b[i]} as a float (masks = torch.bool storage, mask_b may be NULL; n < 2^24) --
+ *   the masked-pixel count that normalises the losses (stage2/model/loss.py:27-38);
+ * psn_inverse_index: inv[p] = position of pixel p in the ascending surface-pixel list idx[0 .. ns), or -1 (the pixel -> row map
+ *   of psn_scatter_rows). */
+int psn_mask_count(const unsigned char* mask_a, const unsigned char* mask_b, int64_t n, float* out, void* stream);
+int psn_inverse_index(const int64_t* idx, int64_t ns, int64_t n_pix, int* inv, void* stream);
 #define PSN_ADAM_MAX_SEGS 16
 typedef struct {
     int64_t offset, grad_offset, n;    /* elements [offset, offset + n) of param / exp_avg / exp_avg_sq, [grad_offset, ..+n) of grad */

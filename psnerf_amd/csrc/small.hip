@@ -195,6 +195,54 @@ extern "C" int psn_camera_rays(const float* uv, const float* pose, const float* 
     return PSN_OK;
 }
 
+// ---- step-front helpers: each replaces three or four launch-bound torch kernels (8 - 10 us apiece inside a replayed graph) ----
+namespace psn {
+// out[0] = number of i with a[i] && (b == nullptr || b[i]) as a float (exact below 2^24): bitwise_and + sum + two casts in torch
+__global__ __launch_bounds__(1024) void mask_count_kernel(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b, int64_t n,
+                                                          float* __restrict__ out) {
+    __shared__ int part[16];
+    int c = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) c += (a[i] != 0 && (b == nullptr || b[i] != 0)) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        out[0] = (float)t;
+    }
+}
+// inv[p] = the position of pixel p in the ASCENDING list idx[0 .. ns), or -1: fill + arange + index_put in torch
+__global__ __launch_bounds__(256) void inverse_index_kernel(const int64_t* __restrict__ idx, int64_t ns, int64_t n_pix, int* __restrict__ inv) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pix) return;
+    int64_t lo = 0, hi = ns;  // first position with idx[pos] >= p
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (idx[mid] < p) lo = mid + 1; else hi = mid;
+    }
+    inv[p] = (lo < ns && idx[lo] == p) ? (int)lo : -1;
+}
+}  // namespace psn
+
+extern "C" int psn_mask_count(const unsigned char* mask_a, const unsigned char* mask_b, int64_t n, float* out, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(mask_a && out && n >= 0 && n < (1ll << 24), "mask_count: bad arguments (n=%lld: the count must be exact in fp32)", (long long)n);
+    hipLaunchKernelGGL(mask_count_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask_a, mask_b, n, out);
+    PSN_CHECK_LAUNCH("mask_count");
+    return PSN_OK;
+}
+
+extern "C" int psn_inverse_index(const int64_t* idx, int64_t ns, int64_t n_pix, int* inv, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG((idx || ns == 0) && inv && ns >= 0 && n_pix >= 0 && ns < (1ll << 31), "inverse_index: bad arguments");
+    if (n_pix == 0) return PSN_OK;
+    hipLaunchKernelGGL(inverse_index_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, ns, n_pix, inv);
+    PSN_CHECK_LAUNCH("inverse_index");
+    return PSN_OK;
+}
+
 static int adam_flat_impl(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n_segs, const PsnAdamSeg* segs,
                           float one_minus_beta1, float beta2, float one_minus_beta2, float eps, const float* seg_scalars_dev, void* stream) {
     using namespace psn;

@@ -95,6 +95,16 @@ class DataParallel(object):
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         return c
 
+    def masked_count_tensor(self, mask_a, mask_b):
+        """global_count_tensor(mask_a & mask_b) with the local count formed by ONE launch (psn_mask_count) on device masks."""
+        if mask_a.is_cuda and mask_a.dtype == torch.bool and mask_b.dtype == torch.bool:
+            from . import hip
+            c = hip.mask_count(mask_a.contiguous(), mask_b.contiguous())
+            if self.enabled:
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            return c
+        return self.global_count_tensor(mask_a & mask_b)
+
     def all_reduce_sum_(self, t):
         """Sum a small device tensor over ranks in place (the mask counts of a step in ONE collective); returns it."""
         if self.enabled:

@@ -141,6 +141,8 @@ SIGNATURES = {
     'psn_stage1_rays': (i32, [c_f, c_f, i32, c_f, f32, i64, c_f, c_f, c_f, c_f]),
     'psn_surface_points': (i32, [c_f, c_f, c_f, c_f, i64, c_f, c_f, c_f, c_f, c_f]),
     'psn_stage1_targets': (i32, [c_f, i64, i32, i32, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, c_f, c_f, c_f]),
+    'psn_mask_count': (i32, [c_f, c_f, i64, c_f, c_f]),
+    'psn_inverse_index': (i32, [c_f, i64, i64, c_f, c_f]),
     'psn_adam_flat': (i32, [c_f, c_f, c_f, c_f, i32, ctypes.c_void_p, f32, f32, f32, f32, c_f]),
     'psn_adam_flat_dev': (i32, [c_f, c_f, c_f, c_f, i32, ctypes.c_void_p, f32, f32, f32, f32, c_f, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
@@ -336,6 +338,25 @@ _ws_cache = {}
 
 
 SCATTER_MAX_ITEMS = 16
+
+
+def mask_count(mask_a, mask_b=None):
+    """Number of elements with mask_a & mask_b (torch.bool tensors of one size) -> float32 device tensor [1], one launch."""
+    assert mask_a.is_cuda and mask_a.dtype == torch.bool and mask_a.is_contiguous()
+    if mask_b is not None:
+        assert mask_b.is_cuda and mask_b.dtype == torch.bool and mask_b.is_contiguous() and mask_b.numel() == mask_a.numel()
+    out = torch.empty(1, device=mask_a.device, dtype=torch.float32)
+    _check(_lib.psn_mask_count(mask_a.data_ptr(), None if mask_b is None else mask_b.data_ptr(), mask_a.numel(), out.data_ptr(), _stream()),
+           'mask_count')
+    return out
+
+
+def inverse_index(idx, n_pixels):
+    """Pixel -> row map of an ascending index list: [n_pixels] int32, -1 where the pixel is not in idx (one launch)."""
+    assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 1
+    inv = torch.empty(n_pixels, device=idx.device, dtype=torch.int32)
+    _check(_lib.psn_inverse_index(idx.data_ptr(), idx.numel(), n_pixels, inv.data_ptr(), _stream()), 'inverse_index')
+    return inv
 
 
 def scatter_rows(specs, rows, inv, n_pixels, n_surf):

@@ -265,6 +265,7 @@ class ScatterRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, idx, inv, specs, *rows):
         _hit('ScatterRows')
+        ctx.set_materialize_grads(False)  # dense outputs nobody differentiates: None, not a zero-filled [B, N, C] + its gather
         ctx.specs, ctx.n_pix, ctx.ns = specs, inv.numel(), idx.numel()
         ctx.save_for_backward(idx)
         return tuple(hip.scatter_rows(list(specs), [r.detach() for r in rows], inv, inv.numel(), idx.numel()))
@@ -625,6 +626,8 @@ class VisibilityPair(torch.autograd.Function):
         if save is not None:
             ctx.save_for_backward(pe_x, pe_l[n_shade:], in_cols, *save, *params)
         ctx.n, ctx.skip_at, ctx.V, ctx.saved = n, skip_at, V, save is not None
+        # the standard column list [0 .. d) + [stride .. stride + d) (PSNetwork._cols): known without reading the device tensor
+        ctx.contiguous_cols = bool(getattr(in_cols, '_psn_contiguous_pair', False))
         vis, vis_t = out[:n_shade * Ns], out[n_shade * Ns:]
         ctx.mark_non_differentiable(vis)
         return vis, vis_t
@@ -642,6 +645,7 @@ class VisibilityPair(torch.autograd.Function):
         Q = V * Ns
         half = in_cols.numel() // 2
         cols_a, cols_b = in_cols[:half], in_cols[half:] - pe_x.shape[1]
+        contiguous_cols = ctx.contiguous_cols
         grads = [None] * (2 * n)
         g = g.contiguous()
 
@@ -696,7 +700,8 @@ class VisibilityPair(torch.autograd.Function):
             blocks = [parts[(li, 'w')]] if (li, 'w') in parts else []
             if li in xl:  # columns: d W_x (table pe_x), d W_l (table pe_lv)
                 dWx, dWl, cs0 = xl[li]
-                blocks += [dWx[:, cols_a], dWl[:, cols_b]]
+                # (the encoding columns of both tables are their leading columns: slices, not index kernels)
+                blocks += [dWx[:, :half] if contiguous_cols else dWx[:, cols_a], dWl[:, :half] if contiguous_cols else dWl[:, cols_b]]
                 if cs0 is not None:
                     grads[2 * li + 1] = cs0
             grads[2 * li] = blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=1)

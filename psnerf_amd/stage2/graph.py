@@ -41,9 +41,12 @@ class _Captured(object):
 
 
 class GraphedTrainStep(object):
-    def __init__(self, step, warmup=2, max_graphs=8, overlap_small_nets=None):
+    def __init__(self, step, warmup=2, max_graphs=8, overlap_small_nets=None, adopt_inputs=False):
         """``overlap_small_nets``: None keeps the model's setting; False captures a single-stream graph (0.04 ms of host
-        time per replay instead of ~2.5 ms, at the price of the side-stream overlap)."""
+        time per replay instead of ~2.5 ms, at the price of the side-stream overlap).  ``adopt_inputs``: the tensors of the
+        batch that is captured BECOME the graph's input buffers (no clones): for a caller that keeps refilling the same
+        tensors -- a data pipeline with fixed staging buffers, the benchmark's resident batch -- a replay then copies
+        nothing (a cloned batch costs ~17 device-to-device copies of 5 us per step)."""
         assert isinstance(step.sg_optimizer, FlatAdam) and isinstance(step.light_optimizer, RowSparseAdam) and step.FUSED_LOSSES, \
             'GraphedTrainStep needs the device-resident step (FlatAdam, RowSparseAdam, fused losses)'
         self.step_obj, self.warmup, self.max_graphs = step, int(warmup), int(max_graphs)
@@ -52,6 +55,7 @@ class GraphedTrainStep(object):
         self._captured = {}
         if overlap_small_nets is not None:
             step.model.overlap_small_nets = bool(overlap_small_nets)
+        self.adopt_inputs = bool(adopt_inputs)
         self.n_replays = self.n_eager = self.n_captures = 0
 
     # ---- signature of a step -------------------------------------------------------------------------------------------
@@ -127,10 +131,11 @@ class GraphedTrainStep(object):
         cur = torch.cuda.current_stream(dev)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            cap.inp = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in model_input.items()}
-            cap.gt = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in ground_truth.items()}
-            cap.l_slt = l_slt.detach().clone()
-            cap.noise = None if not noise else {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in noise.items()}
+            keep = (lambda v: v.detach()) if self.adopt_inputs else (lambda v: v.detach().clone())
+            cap.inp = {k: (keep(v) if torch.is_tensor(v) else v) for k, v in model_input.items()}
+            cap.gt = {k: (keep(v) if torch.is_tensor(v) else v) for k, v in ground_truth.items()}
+            cap.l_slt = keep(l_slt)
+            cap.noise = None if not noise else {k: (keep(v) if torch.is_tensor(v) else v) for k, v in noise.items()}
             if st.dp.enabled:
                 cap.count = torch.zeros(1, device=dev, dtype=torch.float32)
             for opt, n in ((st.sg_optimizer, 2 * hip.ADAM_MAX_SEGS * 4), (st.light_optimizer, 8)):
@@ -176,8 +181,7 @@ class GraphedTrainStep(object):
         st = self.step_obj
         if st.dp.enabled:
             # the masked-pixel count of the global batch: formed and all-reduced outside the graph (a collective is not captured)
-            both = cap.inp['surface_mask'] & cap.inp['object_mask']
-            cap.count.copy_(st.dp.global_count_tensor(both))
+            cap.count.copy_(st.dp.masked_count_tensor(cap.inp['surface_mask'], cap.inp['object_mask']))
             cap.graphs[0].replay()
             st.dp.allreduce_bucket(cap.trainable)
             cap.graphs[1].replay()

@@ -235,6 +235,7 @@ class PSNetwork(nn.Module):
             d = 3 + 6 * n_freqs
             c = torch.arange(d, device=device)
             c = self._cols_cache[key] = torch.cat([c, PE_STRIDE + c]) if pair else c
+            c._psn_contiguous_pair = bool(pair)  # (ops.VisibilityPair: the two halves are the leading columns of their tables)
             if c.is_cuda:
                 torch.cuda.current_stream(c.device).synchronize()  # read on both streams from now on: written before either does
         return c
@@ -583,8 +584,11 @@ class PSNetwork(nn.Module):
         with_rows = [v for v in lazy.values() if v.rows is not None]
         done = {}
         if with_rows:
-            inv = torch.full((n_pix,), -1, dtype=torch.int32, device=device)
-            inv[idx] = torch.arange(ns, dtype=torch.int32, device=device)
+            if idx.is_cuda and idx.dtype == torch.int64:
+                inv = hip.inverse_index(idx.contiguous(), n_pix)  # pixel -> surface row or -1, one launch (idx is ascending)
+            else:
+                inv = torch.full((n_pix,), -1, dtype=torch.int32, device=device)
+                inv[idx] = torch.arange(ns, dtype=torch.int32, device=device)
             specs = tuple((v.B, v.C, v.fill) for v in with_rows)
             dense = ops.ScatterRows.apply(idx, inv, specs, *[v.rows for v in with_rows])
             for v, d in zip(with_rows, dense):

@@ -165,16 +165,16 @@ class TrainStep(object):
         # are inputs (the model passes them through as 'network_object_mask' / 'object_mask'), so the count -- a host
         # synchronisation -- is taken BEFORE the forward pass: afterwards the host runs ahead of the GPU through
         # forward, losses and backward instead of stalling behind the 22 ms visibility launch.
-        both = model_input['surface_mask'] & model_input['object_mask']
+        sm, om = model_input['surface_mask'], model_input['object_mask']
         if count is not None:
             pass
-        elif self.FUSED_LOSSES and both.is_cuda:
+        elif self.FUSED_LOSSES and sm.is_cuda:
             # the count stays on the device (all-reduced there under data parallelism): the fused loss kernels divide by
             # it, so the step has no host synchronisation of its own (the model's only one is the surface-pixel list,
             # and a batch may bring that along as 'surface_idx')
-            count = self.dp.global_count_tensor(both)
+            count = self.dp.masked_count_tensor(sm, om)
         else:
-            count = self.dp.global_count(both)
+            count = self.dp.global_count(sm & om)
         out = self.model(model_input, noise=noise)
         fl = fused_losses(self.loss, self.loss_n, out, ground_truth, model_input, count) if self.FUSED_LOSSES else None
         if fl is None and torch.is_tensor(count):
@@ -201,7 +201,11 @@ class TrainStep(object):
             if train_light:
                 self.light_optimizer.zero_grad()
         if loss.requires_grad:
-            loss.backward()
+            # (the seed of the backward pass is a cached constant: backward() alone launches a ones_like fill per step)
+            seed = getattr(self, '_grad_seed', None)
+            if seed is None or seed.device != loss.device or seed.shape != loss.shape:
+                seed = self._grad_seed = torch.ones_like(loss)
+            loss.backward(seed)
         # (a rank whose pixel slice has no surface pixel gets constants from the model: its loss has no graph, it skips
         # backward and contributes the zero-filled bucket, so the other ranks never wait for a collective it left out)
         if self.dp.enabled:

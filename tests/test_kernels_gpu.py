@@ -1080,3 +1080,22 @@ def test_softplus100_accuracy_against_float64(cuda):
     k = sig_ref > 1e-36
     their_sig = ((torch.sigmoid(z * 100).double() - sig_ref).abs() / sig_ref)[k].max()
     assert float(((s_out.double() - sig_ref).abs() / sig_ref)[k].max()) <= 1.15 * float(their_sig) + 1e-7
+
+
+@pytest.mark.parametrize('n', [1, 63, 1024, 4097, 262144])
+def test_mask_count_and_inverse_index_equal_torch(cuda, n):
+    """psn_mask_count == (a & b).sum() as a float; psn_inverse_index == fill(-1) + index_put(arange) on an ascending index list
+    (the front of a stage-2 step: four + three torch launches -> one each)."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(n)
+    a = (torch.rand(n, generator=g) < 0.9).to(cuda)
+    b = (torch.rand(n, generator=g) < 0.7).to(cuda)
+    assert float(hip.mask_count(a, b)) == float((a & b).sum())
+    assert float(hip.mask_count(a)) == float(a.sum())
+    assert hip.mask_count(a, b).dtype == torch.float32 and hip.mask_count(a, b).shape == (1,)
+    idx = a.nonzero(as_tuple=True)[0]
+    inv = hip.inverse_index(idx, n)
+    ref = torch.full((n,), -1, dtype=torch.int32, device=cuda)
+    ref[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=cuda)
+    assert torch.equal(inv, ref)
+    assert torch.equal(hip.inverse_index(idx[:0], n), torch.full((n,), -1, dtype=torch.int32, device=cuda))

@@ -68,7 +68,7 @@ def main():
             step = make()
             if mode != 'eager':
                 from psnerf_amd.stage2.graph import GraphedTrainStep
-                run = GraphedTrainStep(step, overlap_small_nets=None if mode == 'graph' else False)
+                run = GraphedTrainStep(step, overlap_small_nets=None if mode == 'graph' else False, adopt_inputs=True)
                 fn = lambda: run.step(inp, gt, l_slt, train_order=False)
             else:
                 fn = lambda: step.step(inp, gt, l_slt, train_order=False)
