@@ -404,6 +404,16 @@ int psn_surface_normals_bwd(const float* g, const unsigned char* hit, int64_t N,
 #define PSN_PAIR_SUMS_MAX_V 16
 #define PSN_PAIR_SUMS_MAX_CHUNKS 2048
 int psn_pair_sums(const float* x, int V, int64_t Ns, int C, float* sx, float* sl_part, int* n_chunks, void* stream);
+/* The separable input-block weight gradients of the visibility network's backward (stage2/model/renderer.py:191-200, 251-262:
+ * input row k = v Ns + n is [table(x_n) | table(l_v)]) for up to PSN_PAIR_GROUP_MAX input layers in two launches.  Per item,
+ * with x = d z [V, Ns, C]:  sx [Ns, C] = sum_v x (the K = Ns operand of d W_x);  dWl [C, ld_w] (columns < n_pe written) =
+ * (sum_n x[v])^T pe_l[v] summed over v, pe_l [V, ld_pe];  bias [C] = sum over v and n of x (NULL: not wanted).
+ * workspace: psn_pair_sums_group_workspace(...) floats, 16-byte aligned.  Fixed summation order (deterministic). */
+#define PSN_PAIR_GROUP_MAX 4
+typedef struct { const float* x; float* sx; float* dWl; float* bias; } PsnPairSumsItem;
+int64_t psn_pair_sums_group_workspace(int n_items, int V, int64_t Ns, int C);
+int psn_pair_sums_group(int n_items, const PsnPairSumsItem* items, int V, int64_t Ns, int C, const float* pe_l, int64_t ld_pe, int n_pe,
+                        int64_t ld_w, float* workspace, void* stream);
 
 /* torch.optim.SparseAdam on the touched rows of up to PSN_ROW_ADAM_MAX tables in one launch (the per-light direction
  * [n, 3] and intensity [n, 1] embeddings, stage2/trainer.py:126-168): rows listed in idx [n_idx] int64 (duplicates
@@ -471,6 +481,16 @@ int psn_stage1_targets(const float* pix, int64_t n, int h, int w, const float* i
  *   the masked-pixel count that normalises the losses (stage2/model/loss.py:27-38);
  * psn_inverse_index: inv[p] = position of pixel p in the ascending surface-pixel list idx[0 .. ns), or -1 (the pixel -> row map
  *   of psn_scatter_rows). */
+/* psn_copy2d_group: up to PSN_COPY2D_MAX row-major 2-D copies dst[r][c] = src[r][c] (r < rows, c < cols; row strides ld_*) in
+ *   one launch -- the side tables of a weight pack (init-table column slices of the parameters, bias segments), which were
+ *   a slice copy or a concatenation each.  HOST array of items holding device pointers. */
+#define PSN_COPY2D_MAX 24
+typedef struct {
+    const float* src; int64_t ld_src;
+    float* dst; int64_t ld_dst;
+    int rows, cols;
+} PsnCopy2dItem;
+int psn_copy2d_group(int n_items, const PsnCopy2dItem* items, void* stream);
 int psn_mask_count(const unsigned char* mask_a, const unsigned char* mask_b, int64_t n, float* out, void* stream);
 int psn_inverse_index(const int64_t* idx, int64_t ns, int64_t n_pix, int* inv, void* stream);
 #define PSN_ADAM_MAX_SEGS 16

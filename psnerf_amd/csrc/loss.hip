@@ -144,6 +144,91 @@ __global__ __launch_bounds__(256) void pair_sums_kernel(const float* __restrict_
     }
 }
 
+// ---- the separable input-block weight gradients of ops.VisibilityPair.backward for ALL input layers in two launches -----------
+// (were, per layer: pair_sums + a torch reduction of its partials + a [C, V] x [V, 64] GEMM, + a bias reduction: 7 launches)
+struct PairGroupArgs { PsnPairSumsItem it[PSN_PAIR_GROUP_MAX]; int V; int64_t Ns; int C; int rows_per_block; int chunks; float* part;
+                       const float* pe_l; int64_t ld_pe; int n_pe; int64_t ld_w; };
+// A: as pair_sums_kernel for item blockIdx.y, the four row lanes of a block combined through LDS: part [item][chunk][V][C]
+__global__ __launch_bounds__(256) void pair_group_sums_kernel(PairGroupArgs a) {
+    const PsnPairSumsItem it = a.it[blockIdx.y];
+    const int V = a.V, C = a.C;
+    const int64_t Ns = a.Ns;
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * a.rows_per_block, n1 = min(Ns, n0 + a.rows_per_block);
+    const bool live = 4 * cg < C;
+    float4 sl[PSN_PAIR_SUMS_MAX_V];
+#pragma unroll
+    for (int v = 0; v < PSN_PAIR_SUMS_MAX_V; ++v) sl[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        for (int64_t n = n0 + rl; n < n1; n += 4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int v = 0; v < PSN_PAIR_SUMS_MAX_V; ++v) {
+                if (v < V) {
+                    const float4 t = *reinterpret_cast<const float4*>(it.x + ((int64_t)v * Ns + n) * C + 4 * cg);
+                    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                    sl[v].x += t.x; sl[v].y += t.y; sl[v].z += t.z; sl[v].w += t.w;
+                }
+            }
+            *reinterpret_cast<float4*>(it.sx + n * C + 4 * cg) = acc;
+        }
+    }
+    __shared__ float4 red[3][64];
+    float* dst = a.part + (((int64_t)blockIdx.y * a.chunks + blockIdx.x) * V) * C;
+#pragma unroll
+    for (int v = 0; v < PSN_PAIR_SUMS_MAX_V; ++v) {
+        if (v < V) {
+            __syncthreads();
+            if (rl > 0) red[rl - 1][cg] = sl[v];
+            __syncthreads();
+            if (rl == 0 && live) {
+                float4 t = sl[v];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const float4 o = red[q][cg]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }  // lanes 0 + 1 + 2 + 3: fixed order
+                *reinterpret_cast<float4*>(dst + (int64_t)v * C + 4 * cg) = t;
+            }
+        }
+    }
+}
+// B: block (item, 64-column group), thread (column, v slot): dz_l[v][c] = sum over chunks of part (fixed order), then
+//    dWl[c][k] = sum_v dz_l[v][c] pe_l[v][k] (k < n_pe) and bias[c] = sum_v dz_l[v][c] for the block's 64 columns
+__global__ __launch_bounds__(1024) void pair_group_final_kernel(PairGroupArgs a) {
+    const PsnPairSumsItem it = a.it[blockIdx.y];
+    const int V = a.V, C = a.C;
+    const int c0 = blockIdx.x * 64;
+    const int cl = threadIdx.x & 63, v = threadIdx.x >> 6;  // v < 16
+    __shared__ float dzl[PSN_PAIR_SUMS_MAX_V][64];
+    __shared__ float pel[PSN_PAIR_SUMS_MAX_V][64];
+    float s = 0.0f;
+    if (v < V && c0 + cl < C) {
+        const float* p = a.part + ((int64_t)blockIdx.y * a.chunks * V + v) * C + c0 + cl;
+        const int64_t step = (int64_t)V * C;
+        int ch = 0;
+        for (; ch + 4 <= a.chunks; ch += 4) {
+            const float t0 = p[(int64_t)ch * step], t1 = p[(int64_t)(ch + 1) * step], t2 = p[(int64_t)(ch + 2) * step], t3 = p[(int64_t)(ch + 3) * step];
+            s += t0; s += t1; s += t2; s += t3;
+        }
+        for (; ch < a.chunks; ++ch) s += p[(int64_t)ch * step];
+    }
+    dzl[v][cl] = s;
+    pel[v][cl] = (v < V && cl < a.n_pe) ? a.pe_l[(int64_t)v * a.ld_pe + cl] : 0.0f;
+    __syncthreads();
+    // 64 columns x n_pe (<= 64) outputs over 1024 threads
+    for (int e = threadIdx.x; e < 64 * a.n_pe; e += 1024) {
+        const int c = e / a.n_pe, k = e - c * a.n_pe;
+        if (c0 + c < C) {
+            float w = 0.0f;
+            for (int u = 0; u < V; ++u) w += dzl[u][c] * pel[u][k];
+            it.dWl[(int64_t)(c0 + c) * a.ld_w + k] = w;
+        }
+    }
+    if (it.bias != nullptr && threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+        float b = 0.0f;
+        for (int u = 0; u < V; ++u) b += dzl[u][threadIdx.x];
+        it.bias[c0 + threadIdx.x] = b;
+    }
+}
+
 __global__ __launch_bounds__(256) void stage2_loss_bwd_kernel(LossArgs a) {
     float g = a.g_total[0];
     if (a.count_dev != nullptr) {
@@ -287,10 +372,17 @@ __global__ __launch_bounds__(256) void row_adam_kernel(RowAdamArgs a) {
     PsnRowAdamItem it = a.it[item];
     if (a.dev != nullptr) it.step_size = a.dev[item];
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= it.rows) return;
+    // (the index list through LDS in chunks of 256: a dependent global load per iteration otherwise)
+    __shared__ int64_t sidx[256];
     bool touched = false;
-    for (int i = 0; i < a.n_idx; ++i) touched = touched || a.idx[i] == r;
-    if (!touched) return;
+    for (int i0 = 0; i0 < a.n_idx; i0 += 256) {
+        const int m = a.n_idx - i0 < 256 ? a.n_idx - i0 : 256;
+        __syncthreads();
+        if ((int)threadIdx.x < m) sidx[threadIdx.x] = a.idx[i0 + threadIdx.x];
+        __syncthreads();
+        for (int j = 0; j < m; ++j) touched = touched || sidx[j] == r;
+    }
+    if (r >= it.rows || !touched) return;
     for (int c = 0; c < it.cols; ++c) {
         const int64_t e = r * it.cols + c;
         const float g = it.grad[e];
@@ -332,6 +424,39 @@ extern "C" int psn_row_adam_dev(int n_items, const PsnRowAdamItem* items, const 
                                 void* stream) {
     PSN_CHECK_ARG(step_sizes_dev != nullptr, "row_adam_dev: step_sizes_dev is required");
     return row_adam_impl(n_items, items, idx, n_idx, step_sizes_dev, stream);
+}
+
+extern "C" int64_t psn_pair_sums_group_workspace(int n_items, int V, int64_t Ns, int C) {
+    int rows = 16;
+    int64_t chunks = (Ns + rows - 1) / rows;
+    while (chunks > PSN_PAIR_SUMS_MAX_CHUNKS) { rows *= 2; chunks = (Ns + rows - 1) / rows; }
+    return (int64_t)n_items * (chunks > 0 ? chunks : 1) * V * C;
+}
+
+extern "C" int psn_pair_sums_group(int n_items, const PsnPairSumsItem* items, int V, int64_t Ns, int C, const float* pe_l, int64_t ld_pe,
+                                   int n_pe, int64_t ld_w, float* workspace, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(items && pe_l && workspace && n_items >= 1 && n_items <= PSN_PAIR_GROUP_MAX, "pair_sums_group: bad arguments (n_items=%d)", n_items);
+    PSN_CHECK_ARG(V >= 1 && V <= PSN_PAIR_SUMS_MAX_V && C >= 4 && C <= 256 && C % 4 == 0 && Ns >= 0, "pair_sums_group: V=%d C=%d", V, C);
+    PSN_CHECK_ARG(n_pe >= 1 && n_pe <= 64 && ld_pe >= n_pe && ld_w >= n_pe, "pair_sums_group: n_pe=%d", n_pe);
+    PairGroupArgs a = {};
+    for (int i = 0; i < n_items; ++i) {
+        PSN_CHECK_ARG(items[i].x && items[i].sx && items[i].dWl && ((((uintptr_t)items[i].x | (uintptr_t)items[i].sx)) & 15) == 0, "pair_sums_group: item %d", i);
+        a.it[i] = items[i];
+    }
+    int rows = 16;
+    int64_t chunks = (Ns + rows - 1) / rows;
+    while (chunks > PSN_PAIR_SUMS_MAX_CHUNKS) { rows *= 2; chunks = (Ns + rows - 1) / rows; }
+    a.V = V; a.Ns = Ns; a.C = C; a.rows_per_block = rows; a.chunks = (int)chunks; a.part = workspace;
+    a.pe_l = pe_l; a.ld_pe = ld_pe; a.n_pe = n_pe; a.ld_w = ld_w;
+    PSN_CHECK_ARG((((uintptr_t)workspace) & 15) == 0, "pair_sums_group: workspace must be 16-byte aligned");
+    if (chunks > 0) {
+        hipLaunchKernelGGL(pair_group_sums_kernel, dim3((unsigned)chunks, n_items), dim3(256), 0, (hipStream_t)stream, a);
+        PSN_CHECK_LAUNCH("pair_sums_group (sums)");
+    }
+    hipLaunchKernelGGL(pair_group_final_kernel, dim3((unsigned)((C + 63) / 64), n_items), dim3(1024), 0, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("pair_sums_group (final)");
+    return PSN_OK;
 }
 
 extern "C" int psn_pair_sums(const float* x, int V, int64_t Ns, int C, float* sx, float* sl_part, int* n_chunks, void* stream) {

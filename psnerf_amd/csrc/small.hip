@@ -64,18 +64,30 @@ __global__ __launch_bounds__(256) void light_rows_bwd_kernel(const float* __rest
                                                              int64_t n_rows, float eps, const float* __restrict__ g_dir,
                                                              const float* __restrict__ g_int, float* __restrict__ d_dir,
                                                              float* __restrict__ d_int) {
+    // the index list goes through LDS in chunks of 256: read straight from memory, every one of the n_idx iterations of every
+    // thread waited for its own (dependent, branch-guarded) load -- 44 us for 96 lights, at the very end of a step's backward
+    __shared__ int64_t sidx[256];
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_rows) return;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, ai = 0.f;
-    for (int i = 0; i < n_idx; ++i) {
-        if (idx[i] != r) continue;
-        if (g_dir != nullptr) {
-            float d0, d1, d2;
-            normalize3_bwd(dir_tab[3 * r], dir_tab[3 * r + 1], dir_tab[3 * r + 2], g_dir[3 * i], g_dir[3 * i + 1], g_dir[3 * i + 2], eps, d0, d1, d2);
-            a0 += d0; a1 += d1; a2 += d2;
+    for (int i0 = 0; i0 < n_idx; i0 += 256) {
+        const int m = n_idx - i0 < 256 ? n_idx - i0 : 256;
+        __syncthreads();
+        if ((int)threadIdx.x < m) sidx[threadIdx.x] = idx[i0 + threadIdx.x];
+        __syncthreads();
+        if (r < n_rows) {
+            for (int j = 0; j < m; ++j) {
+                if (sidx[j] != r) continue;
+                const int i = i0 + j;
+                if (g_dir != nullptr) {
+                    float d0, d1, d2;
+                    normalize3_bwd(dir_tab[3 * r], dir_tab[3 * r + 1], dir_tab[3 * r + 2], g_dir[3 * i], g_dir[3 * i + 1], g_dir[3 * i + 2], eps, d0, d1, d2);
+                    a0 += d0; a1 += d1; a2 += d2;
+                }
+                if (g_int != nullptr) ai += g_int[i];
+            }
         }
-        if (g_int != nullptr) ai += g_int[i];
     }
+    if (r >= n_rows) return;
     if (d_dir != nullptr) { d_dir[3 * r] = a0; d_dir[3 * r + 1] = a1; d_dir[3 * r + 2] = a2; }
     if (d_int != nullptr) d_int[r] = ai;
 }
@@ -225,6 +237,37 @@ __global__ __launch_bounds__(256) void inverse_index_kernel(const int64_t* __res
     inv[p] = (lo < ns && idx[lo] == p) ? (int)lo : -1;
 }
 }  // namespace psn
+
+// ---- up to PSN_COPY2D_MAX strided 2-D copies in one launch (weight-pack side tables: init-table slices, bias segments) ----------
+namespace psn {
+struct Copy2dArgs { PsnCopy2dItem it[PSN_COPY2D_MAX]; int64_t start[PSN_COPY2D_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void copy2d_group_kernel(Copy2dArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int64_t)blockIdx.x >= a.start[i + 1]) ++i;
+    const PsnCopy2dItem it = a.it[i];
+    const int64_t e = ((int64_t)blockIdx.x - a.start[i]) * 256 + threadIdx.x;
+    if (e >= (int64_t)it.rows * it.cols) return;
+    const int64_t r = e / it.cols, c = e - r * it.cols;
+    it.dst[r * it.ld_dst + c] = it.src[r * it.ld_src + c];
+}
+}  // namespace psn
+
+extern "C" int psn_copy2d_group(int n_items, const PsnCopy2dItem* items, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(items && n_items >= 1 && n_items <= PSN_COPY2D_MAX, "copy2d_group: n_items=%d", n_items);
+    Copy2dArgs a;
+    a.n = n_items;
+    a.start[0] = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const PsnCopy2dItem& it = items[i];
+        PSN_CHECK_ARG(it.src && it.dst && it.rows >= 1 && it.cols >= 1 && it.ld_src >= it.cols && it.ld_dst >= it.cols, "copy2d_group: item %d", i);
+        a.it[i] = it;
+        a.start[i + 1] = a.start[i] + ((int64_t)it.rows * it.cols + 255) / 256;
+    }
+    hipLaunchKernelGGL(copy2d_group_kernel, dim3((unsigned)a.start[n_items]), dim3(256), 0, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("copy2d_group");
+    return PSN_OK;
+}
 
 extern "C" int psn_mask_count(const unsigned char* mask_a, const unsigned char* mask_b, int64_t n, float* out, void* stream) {
     using namespace psn;

@@ -173,8 +173,18 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
         lay.n_kt_in, lay.n_kt_act, lay.n_mt, lay.act = n_kt_in, n_kt_act, n_mt, L['act']
         b_off += rows
     w_buf = torch.empty(max(off, 4), device=device, dtype=torch.float32)
-    if all(bv.data_ptr() == _zeros(bv.shape[0], device).data_ptr() for bv in biases):  # (cached zeros of one size share one tensor)
-        b_buf = _zeros(sum(bv.shape[0] for bv in biases), device)  # all-zero biases of a backward chain
+    side = []  # (src, dst) copies of the pack's side tables: ONE launch at the end (hip.copy2d_group) when the call site reuses
+    is_zero = [bv.data_ptr() == _zeros(bv.shape[0], device).data_ptr() for bv in biases]  # (cached zeros of one size share one tensor)
+    n_bias = sum(bv.shape[0] for bv in biases)
+    old_b = getattr(reuse, 'b', None)
+    if all(is_zero):
+        b_buf = _zeros(n_bias, device)  # all-zero biases of a backward chain
+    elif old_b is not None and old_b.numel() == n_bias and old_b.device == w_buf.device and getattr(reuse, 'b_zero', None) == is_zero:
+        b_buf, o = old_b, 0  # same layout as last time: the zero segments are in place, the others are rewritten
+        for bv, z in zip(biases, is_zero):
+            if not z:
+                side.append((bv, b_buf[o:o + bv.shape[0]]))
+            o += bv.shape[0]
     else:
         b_buf = torch.cat(biases).contiguous()
     group = []
@@ -190,13 +200,29 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
             buf = old if (old is not None and tuple(old.shape) == shape and old.device == w_buf.device) else torch.zeros(shape, device=device)
             for i, blk in enumerate(blocks):
                 assert blk.shape[0] <= width and blk.shape[1] <= cols
-                buf[i * width:i * width + blk.shape[0], :blk.shape[1]].copy_(blk)
+                side.append((blk if blk.dtype == torch.float32 else blk.float(), buf[i * width:i * width + blk.shape[0], :blk.shape[1]]))
             return buf
+        n_ib = sum(v.shape[0] for v in init_bias)
+        old_ib = getattr(reuse, 'init_bias', None)
+        if old_ib is not None and old_ib.numel() == n_ib and old_ib.device == w_buf.device:
+            ib, o = old_ib, 0
+            for v in init_bias:
+                side.append((v, ib[o:o + v.shape[0]]))
+                o += v.shape[0]
+        else:
+            ib = torch.cat(init_bias).contiguous()
         pk = PackedMLP(desc, w_buf, b_buf, stack(init_wa, in_kt_a * 32, getattr(reuse, 'init_wa', None)),
-                       stack(init_wb, in_kt_b * 32, getattr(reuse, 'init_wb', None)) if init_wb else None,
-                       torch.cat(init_bias).contiguous())
+                       stack(init_wb, in_kt_b * 32, getattr(reuse, 'init_wb', None)) if init_wb else None, ib)
     else:
         pk = PackedMLP(desc, w_buf, b_buf)
+    pk.b_zero = is_zero
+    if side:
+        side = [(a_.detach().contiguous() if a_.dim() == 1 else a_.detach(), d_) for a_, d_ in side]
+        if all(a_.is_cuda for a_, _ in side):
+            hip.copy2d_group(side)  # init-table slices + bias segments: one launch (was a slice copy / a concatenation each)
+        else:
+            for a_, d_ in side:
+                d_.copy_(a_)
     pk.macs_per_row = sum(_src(w)[2] * _src(w)[3] for w, _, _, _ in plan)
     return pk
 

@@ -69,6 +69,17 @@ class PsnGemmTnItem(ctypes.Structure):
                 ('B_tab2', ctypes.c_void_p), ('ldb_tab2', i64), ('b2_div', i64), ('b2_mod', i64), ('b_split', i32), ('k_rows', i64)]
 
 
+class PsnPairSumsItem(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('sx', ctypes.c_void_p), ('dWl', ctypes.c_void_p), ('bias', ctypes.c_void_p)]
+
+
+class PsnCopy2dItem(ctypes.Structure):
+    _fields_ = [('src', ctypes.c_void_p), ('ld_src', i64), ('dst', ctypes.c_void_p), ('ld_dst', i64), ('rows', i32), ('cols', i32)]
+
+
+COPY2D_MAX = 24
+
+
 class PsnAdamSeg(ctypes.Structure):
     _fields_ = [('offset', i64), ('grad_offset', i64), ('n', i64), ('neg_step_size', f32), ('bias_correction2_sqrt', f32)]
 
@@ -120,6 +131,8 @@ SIGNATURES = {
     'psn_stage2_loss_bwd': (i32, [c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, f32, c_f, c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, c_f, i32, f32,
                                   c_f, c_f, c_f, c_f, f32, f32, c_f, c_f, c_f, c_f, i64, i32, c_f, c_f]),
     'psn_pair_sums': (i32, [c_f, i32, i64, i32, c_f, c_f, ctypes.POINTER(ctypes.c_int), c_f]),
+    'psn_pair_sums_group_workspace': (i64, [i32, i32, i64, i32]),
+    'psn_pair_sums_group': (i32, [i32, ctypes.c_void_p, i32, i64, i32, c_f, i64, i32, i64, c_f, c_f]),
     'psn_row_adam': (i32, [i32, ctypes.c_void_p, c_f, i32, c_f]),
     'psn_row_adam_dev': (i32, [i32, ctypes.c_void_p, c_f, i32, c_f, c_f]),
     'psn_shadow_points': (i32, [c_f, c_f, i64, i32, i32, f32, f32, c_f, c_f, f32, c_f, c_f, c_f, c_f]),
@@ -141,6 +154,7 @@ SIGNATURES = {
     'psn_stage1_rays': (i32, [c_f, c_f, i32, c_f, f32, i64, c_f, c_f, c_f, c_f]),
     'psn_surface_points': (i32, [c_f, c_f, c_f, c_f, i64, c_f, c_f, c_f, c_f, c_f]),
     'psn_stage1_targets': (i32, [c_f, i64, i32, i32, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, c_f, c_f, c_f]),
+    'psn_copy2d_group': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_mask_count': (i32, [c_f, c_f, i64, c_f, c_f]),
     'psn_inverse_index': (i32, [c_f, i64, i64, c_f, c_f]),
     'psn_adam_flat': (i32, [c_f, c_f, c_f, c_f, i32, ctypes.c_void_p, f32, f32, f32, f32, c_f]),
@@ -340,6 +354,24 @@ _ws_cache = {}
 SCATTER_MAX_ITEMS = 16
 
 
+def copy2d_group(pairs):
+    """pairs: [(src, dst)] fp32 device tensors of equal shape, 1-D (contiguous) or 2-D with unit column stride (row strides
+    allowed: column slices of a parameter, row blocks of a table) -> dst[...] = src[...], COPY2D_MAX pairs per launch."""
+    for c0 in range(0, len(pairs), COPY2D_MAX):
+        chunk = pairs[c0:c0 + COPY2D_MAX]
+        arr = (PsnCopy2dItem * len(chunk))()
+        for e, (src, dst) in zip(arr, chunk):
+            assert src.shape == dst.shape and src.dtype == dst.dtype == torch.float32 and src.is_cuda and dst.is_cuda and src.numel() > 0
+            if src.dim() == 1:
+                assert src.stride(0) == 1 and dst.stride(0) == 1
+                e.rows, e.cols, e.ld_src, e.ld_dst = 1, src.shape[0], src.shape[0], src.shape[0]
+            else:
+                assert src.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
+                e.rows, e.cols, e.ld_src, e.ld_dst = src.shape[0], src.shape[1], src.stride(0), dst.stride(0)
+            e.src, e.dst = src.data_ptr(), dst.data_ptr()
+        _check(_lib.psn_copy2d_group(len(chunk), ctypes.addressof(arr), _stream()), 'copy2d_group')
+
+
 def mask_count(mask_a, mask_b=None):
     """Number of elements with mask_a & mask_b (torch.bool tensors of one size) -> float32 device tensor [1], one launch."""
     assert mask_a.is_cuda and mask_a.dtype == torch.bool and mask_a.is_contiguous()
@@ -467,6 +499,27 @@ def pair_sums(x, V, Ns):
     n_chunks = ctypes.c_int(0)
     _check(_lib.psn_pair_sums(_ptr(x, 'x'), V, Ns, C, sx.data_ptr(), part.data_ptr(), ctypes.byref(n_chunks), _stream()), 'pair_sums')
     return sx, part[:n_chunks.value].sum(0)
+
+
+def pair_sums_group(xs, V, Ns, pe_l, n_pe, want_bias):
+    """xs: list of d z [V * Ns, C] (light-major rows) of the layers that read the input block [table(x_n) | table(l_v)]; pe_l [V, >= n_pe]
+    the light table.  -> [(sx [Ns, C], dWl [C, 64] with the first n_pe columns written, bias [C] or None)] in two launches
+    (psn_pair_sums_group)."""
+    C = xs[0].shape[1]
+    dev = xs[0].device
+    assert 1 <= len(xs) <= 4 and all(x.shape == (V * Ns, C) and x.is_contiguous() for x in xs) and pe_l.stride(1) == 1 and pe_l.shape[0] == V
+    ws = workspace(int(_lib.psn_pair_sums_group_workspace(len(xs), V, Ns, C)), dev)
+    arr = (PsnPairSumsItem * len(xs))()
+    out = []
+    for e, x, wb in zip(arr, xs, want_bias):
+        sx = torch.empty(Ns, C, device=dev, dtype=torch.float32)
+        dWl = torch.empty(C, 64, device=dev, dtype=torch.float32)  # (columns >= n_pe are never read)
+        b = torch.empty(C, device=dev, dtype=torch.float32) if wb else None
+        e.x, e.sx, e.dWl, e.bias = _ptr(x, 'x'), sx.data_ptr(), dWl.data_ptr(), None if b is None else b.data_ptr()
+        out.append((sx, dWl, b))
+    _check(_lib.psn_pair_sums_group(len(xs), ctypes.addressof(arr), V, Ns, C, _ptr(pe_l, 'pe_l'), pe_l.stride(0), int(n_pe), 64,
+                                    ws.data_ptr(), _stream()), 'pair_sums_group')
+    return out
 
 
 def row_adam(items, idx, step_sizes_dev=None):

@@ -679,12 +679,20 @@ class VisibilityPair(torch.autograd.Function):
                 # two reductions that read dz once each instead of a K = V Ns product on 128-column tiles (which ran at
                 # ~40 TF: the narrow-tile kernel is the slow one of the weight-gradient set).
                 if V <= 16:
-                    dz_x, dz_l = hip.pair_sums(dz, V, Ns)            # [Ns, 256], [V, 256]: one pass over dz
+                    xl[li] = None  # all input layers together below: two launches (psn_pair_sums_group)
                 else:
                     dz3 = dz.view(V, Ns, dz.shape[1])
                     dz_x, dz_l = dz3.sum(0), dz3.sum(1)
-                dWl = hip.gemm(dz_l, pe_lv.contiguous(), trans_a=True)          # [256, 64]
-                xl[li] = [dz_x, dWl, dz_l.sum(0) if li == 0 else None]
+                    dWl = hip.gemm(dz_l, pe_lv.contiguous(), trans_a=True)          # [256, 64]
+                    xl[li] = [dz_x, dWl, dz_l.sum(0) if li == 0 else None]
+        grouped = [li for li in sorted(xl) if xl[li] is None]
+        if grouped:
+            # per layer: sum_v dz (the K = Ns operand of d W_x), d W_l = (sum_n dz[v])^T PE(l_v) and -- layer 0 -- the bias
+            # gradient, every layer in the same two launches (was pair_sums + a reduction of its partials + a small GEMM each)
+            pl = pe_lv.contiguous()
+            for li, r in zip(grouped, hip.pair_sums_group([DZ[n - 2 - li] for li in grouped], V, Ns, pl, pl.shape[1],
+                                                          [li == 0 for li in grouped])):
+                xl[li] = list(r)
         # d W_x of both input layers (K = Ns, 256 x 64 outputs) in ONE launch of the 256 x 64-tile kernel + one reduction
         # (were a split-K GEMM + reduction each)
         lis = sorted(xl)

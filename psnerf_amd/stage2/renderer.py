@@ -422,13 +422,14 @@ class PSNetwork(nn.Module):
             if ns > 0:
               with on_side():
                 cols_n = self._cols(self.n_freqs_n, device)
-                normal_s = self._memo('normal', input, lambda: ops.normalize_rows(
-                    self.normal_net(self._pe(surf, self.n_freqs_n), cols_n)))
+                # (the encoding of the surface points is shared with the visibility / BRDF networks when the octave counts agree)
+                pe_n = (lambda: pe_x) if (pe_x is not None and self.n_freqs_n == self.n_freqs) else (lambda: self._pe(surf, self.n_freqs_n))
+                normal_s = self._memo('normal', input, lambda: ops.normalize_rows(self.normal_net(pe_n(), cols_n)))
                 normal_pred = scatter(normal_pred, normal_s)
                 if self.normal_jitter_std > 0:
                     nz = noise.get('normal')
                     if nz is None:
-                        nz = torch.randn_like(surf) * self.normal_jitter_std  # = torch.normal(0, std) without its host-side std >= 0 check
+                        nz = torch.empty_like(surf).normal_(0.0, self.normal_jitter_std)  # = torch.normal(0, std) without its host-side std >= 0 check (one launch)
                     nj = self._memo('normal_jitter', input, lambda: ops.normalize_rows(
                         self.normal_net(self._pe(surf + nz, self.n_freqs_n), cols_n)))
                     out_n['normal_jitter'] = scatter(ones3(), nj)
@@ -467,19 +468,23 @@ class PSNetwork(nn.Module):
               if self.xyz_jitter_std > 0:
                 nz = noise.get('xyz')
                 if nz is None:
-                    nz = torch.randn_like(surf) * self.xyz_jitter_std  # = torch.normal(0, std) without its host-side std >= 0 check
+                    nz = torch.empty_like(surf).normal_(0.0, self.xyz_jitter_std)  # = torch.normal(0, std) without its host-side std >= 0 check (one launch)
                 def brdf_both():
                     pe_both = torch.cat([pe_x, self._pe(surf + nz, self.n_freqs)], dim=0)
                     return self.albedo_net(pe_both, cols), self.rough_net(pe_both, cols)
                 albedo_both, rough_both = self._memo('brdf_both', input, brdf_both)
                 albedo, albedo_j = ops.SplitRows.apply(albedo_both, ns)
+                if sg:
+                    # SG weights = relu(network output) for both halves (renderer.py:180, 224): ONE clamp on the 2 Ns rows in
+                    # front of the split instead of one per half (and one threshold_backward instead of two)
+                    rough_both = F.relu(rough_both)
                 rough, rough_j = ops.SplitRows.apply(rough_both, ns)
               else:
                 albedo, rough = self._memo('brdf', input, lambda: (self.albedo_net(pe_x, cols), self.rough_net(pe_x, cols)))
               if albedo_new is not None:
                 albedo = torch.from_numpy(albedo_new).to(device)[None].expand_as(albedo)
               if sg:
-                weights = F.relu(rough)
+                weights = rough if self.xyz_jitter_std > 0 else F.relu(rough)  # (already clamped in front of the split)
                 if basis_new is not None:  # material editing (eval.py:233-312)
                     wn = torch.zeros_like(weights)
                     if self.specular_rgb:
@@ -533,7 +538,7 @@ class PSNetwork(nn.Module):
             if self.xyz_jitter_std > 0:  # renderer.py:211-231
                 aj = scatter(ones3(), albedo_j)
                 if sg:
-                    rj = scatter(_Dense(1.0, 1, self.nbasis), F.relu(rough_j))
+                    rj = scatter(_Dense(1.0, 1, self.nbasis), rough_j)  # (= relu of the jittered evaluation, clamped above)
                     r_ori = weight_values
                 else:
                     rj = scatter(ones3(), rough_j.expand(-1, 3))

@@ -1099,3 +1099,24 @@ def test_mask_count_and_inverse_index_equal_torch(cuda, n):
     ref[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=cuda)
     assert torch.equal(inv, ref)
     assert torch.equal(hip.inverse_index(idx[:0], n), torch.full((n,), -1, dtype=torch.int32, device=cuda))
+
+
+@pytest.mark.parametrize('V,Ns,n_items', [(8, 3655, 2), (3, 17, 1), (16, 1000, 2), (1, 64, 2)])
+def test_pair_sums_group_vs_torch(cuda, V, Ns, n_items):
+    """psn_pair_sums_group (the separable input-block gradients of ops.VisibilityPair.backward, every input layer in two launches)
+    against the torch formulation: sum over the lights, (sum over the points)^T PE(l), and the bias sum."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(V * 1000 + Ns)
+    xs = [torch.randn(V * Ns, 256, generator=g).to(cuda) for _ in range(n_items)]
+    pe = torch.randn(V, 64, generator=g).to(cuda)
+    pe[:, 63] = 0
+    res = hip.pair_sums_group(xs, V, Ns, pe, 64, [i == 0 for i in range(n_items)])
+    for i, (x, (sx, dWl, b)) in enumerate(zip(xs, res)):
+        x3 = x.double().view(V, Ns, 256)
+        assert_close(sx.cpu(), x3.sum(0).float().cpu(), 1e-6, 'sx', atol=1e-5)
+        dzl = x3.sum(1)
+        assert_close(dWl.cpu(), (dzl.t() @ pe.double()).float().cpu(), 1e-5, 'dWl')
+        if i == 0:
+            assert_close(b.cpu(), dzl.sum(0).float().cpu(), 1e-5, 'bias')
+        else:
+            assert b is None

@@ -52,6 +52,11 @@ def main():
                 open(os.path.join(dst, '%s_%s' % (tag, name)), 'w').write(lines[-1] + '\n')
             else:
                 shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, name)))
+    for name in ('march_sweep.json', 'bf16x6_kernel.json', 'bf16x6_kernel_zero_operands.json', 'tn256.txt', 'shadow_visibility.json',
+                 'composite.json', 'pmc_x3.csv', 'strong_projection.json', 'x3occ.txt', 'strong4096_kernel_stats.csv'):
+        p = os.path.join(src, name)
+        if os.path.exists(p) and os.path.getsize(p) > 0:
+            shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, name)))
     bench = json.loads(open(os.path.join(dst, '%s_bench_stage2.json' % tag)).read())
     fetch = counter_rows(os.path.join(src, 'pmc_FETCH_SIZE.csv'))
     write = counter_rows(os.path.join(src, 'pmc_WRITE_SIZE.csv'))

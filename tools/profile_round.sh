@@ -35,4 +35,10 @@ python3 $R/tools/bench_composite.py 2>/dev/null | tail -1 > $O/composite.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d /tmp/pmc_x3 -o c -- python3 $R/tools/dbg/bench_x3.py > /dev/null 2>&1
 F=$(find /tmp/pmc_x3 -name '*counter_collection*' | head -1)
 (head -1 $F; grep "mlp_infer_x3_kernel\|mlp_infer_bf16_kernel" $F | head -40) > $O/pmc_x3.csv
+# round 4 additions: the rank shards of BASELINE cfg 4 on one GPU (data-parallel path on, eager / HIP graph, host vs GPU time),
+# the split-bf16 occupancy engine, the kernel timeline of a replayed 4096-px step
+python3 $R/tools/strong_projection.py --graph --queue-ahead --steps 40 --out $O/strong_projection.json > $O/strong_projection.log 2>&1
+python3 $R/tools/dbg/x3occ_probe.py 2>/dev/null | grep -v amdgpu > $O/x3occ.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps4 -o s4 -- python3 $R/tools/strong_projection.py --pixels 4096 --steps 30 --graph --no-profiler --out /tmp/ps4/p.json > /dev/null 2>&1
+cp $(find /tmp/ps4 -name '*kernel_stats*' | head -1) $O/strong4096_kernel_stats.csv
 ls -la $O
