@@ -21,6 +21,7 @@
 // + b = U[n] + V[g] with U = W_a pe(x) (one fp32 row per point) and V = W_b pe(l) + b (one per group) computed by two small
 // fp32 GEMMs on the host side; the layers that read the input block START their accumulators from U[n] + V[g] (fp32 adds,
 // the row of U prefetched under the previous layer's epilogue) and spend no MFMA on it: layer 0 is that sum alone.
+#include <cstdlib>
 #include "common.h"
 
 namespace psn {
@@ -380,6 +381,359 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3_kernel(X3Args g) {
     }
 }
 
+// ============================================================================================================================
+// PIPELINED form (round 4): the epilogue of a layer -- activation + three-way split of 128 accumulators per lane, ~10 k cycles of
+// vector work next to 24.6 k cycles of MFMAs per layer, fully exposed with one wave per SIMD -- runs INSIDE the next layer's MFMA
+// stream.  Stage S of layer l + 1 (k-steps 2 S, 2 S + 1) consumes exactly the features of OUTPUT TILE S of layer l, so only tile
+// 0 has to be ready when the layer starts; the 8 (k-step, tile pair) groups of stage S each carry one eighth of the epilogue of
+// tile S + 1 (one activation pair + its split, ~35 vector instructions in the gaps of 12 MFMAs).  That needs the previous
+// layer's accumulators alive while the new ones accumulate: TWO accumulator sets (256 registers) -- paid for by keeping only
+// TWO tiles of B-operand planes (48 registers instead of 192: a tile is dead once its stage has run).  The last stage of a layer
+// writes its results back into the first set (MFMA with D != C), so the layer loop carries one set and needs no copies.
+// 456 -> ~400 registers, one wave per SIMD as before.
+template <bool OCC>
+__device__ __forceinline__ void x3_epi_job(const floatx16& a, const int j, const int ot, const int lh, const bool inject, const float* pe_row,
+                                           const int pe_first, xintx4 (&st)[3][2]) {
+    const int qp = j >> 2, i = j & 3;
+    float c0, c1;
+    if constexpr (OCC) {
+        f32x2 sp, unused;
+        softplus100_pair<false>(f32x2{a[8 * qp + 2 * i], a[8 * qp + 2 * i + 1]}, sp, unused);
+        c0 = sp.x; c1 = sp.y;
+        if (ot >= 6 && inject) {
+            const int f0 = 32 * ot + 16 * qp + 8 * ((2 * i) >> 2) + 4 * lh + ((2 * i) & 3);  // feature of slot j = 2 i
+            const int k0 = f0 - pe_first, k1 = f0 + 1 - pe_first;
+            const float p0 = pe_row[k0 < 0 ? 0 : k0], p1 = pe_row[k1 < 0 ? 0 : k1];
+            c0 = k0 >= 0 ? p0 : c0;
+            c1 = k1 >= 0 ? p1 : c1;
+        }
+    } else {
+        c0 = relu1(a[8 * qp + 2 * i]); c1 = relu1(a[8 * qp + 2 * i + 1]);
+    }
+    int h_, m_, l_;
+    x3_split2(c0, c1, h_, m_, l_);
+    st[0][qp][i] = h_; st[1][qp][i] = m_; st[2][qp][i] = l_;
+}
+
+// x3_mma_pair whose FIRST product of each chain reads its C operand from (s0, s1) and writes (c0, c1): moves the accumulators
+__device__ __forceinline__ void x3_mma_pair_move(floatx16& c0, floatx16& c1, const floatx16& s0, const floatx16& s1, const xbf16x8 (&a)[3][2],
+                                                 const xbf16x8& bh, const xbf16x8& bm, const xbf16x8& bl) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][0], bh, s0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][1], bh, s1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bl, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], bl, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], bm, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], bm, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], bh, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bm, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], bm, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], bh, c1, 0, 0, 0);
+}
+
+// The epilogue of ONE accumulator pair (x3_epi_job) cut into six phases of <= 8 vector instructions (two quarter-rate
+// transcendentals count as eight), one behind each PAIR of MFMAs of a group: the wave issues in order and a 32 x 32 x 16 MFMA
+// holds the matrix pipe for 32 cycles, so <= 32 cycles of vector work between two MFMAs cost nothing, while the same work as
+// one block behind a group's 12 MFMAs (what hipcc makes of a job handed over whole, with or without sched_group_barrier) runs
+// after the pipe has drained.  Arithmetic: softplus100_pair<false> (common.h) and x3_split2, operation by operation.
+template <bool OCC>
+struct X3EpiPhases {
+    f32x2 z, nat, hi, r, u, w, lw, l, sp;
+    int h_, m_;
+    __device__ __forceinline__ void run(const int k, const floatx16& a, const int j, const int ot, const int lh, const bool inject,
+                                        const float* pe_row, const int pe_first, xintx4 (&st)[3][2]) {
+        const int qp = j >> 2, i = j & 3;
+        if constexpr (OCC) {
+            const float L2E = 1.44269502162933349609375f, LN2_HI = 0.693147182464599609375f, LN2_LO = -1.904654323148236e-9f;
+            const float C_HI = 0.00999999977648258209228515625f, C_LO = 2.2351741811588166e-10f;
+            if (k == 0) {
+                z = f32x2{a[8 * qp + 2 * i], a[8 * qp + 2 * i + 1]};
+                const f32x2 t = z * 100.0f;
+                nat = f32x2{fminf(t.x, -t.x), fminf(t.y, -t.y)};
+                hi = nat * L2E;
+            } else if (k == 1) {
+                r = pk_fma(-hi, pk2(LN2_HI), nat);
+                r = pk_fma(-hi, pk2(LN2_LO), r);
+                u = f32x2{__builtin_amdgcn_exp2f(hi.x), __builtin_amdgcn_exp2f(hi.y)};
+            } else if (k == 2) {
+                u = pk_fma(u, r, u);
+                w = u + 1.0f;
+                lw = f32x2{__builtin_amdgcn_logf(w.x), __builtin_amdgcn_logf(w.y)};
+            } else if (k == 3) {
+                const f32x2 c = w - 1.0f;
+                const f32x2 d = u - c;
+                const f32x2 rw = pk_fma(c, pk_fma(c, pk2(0.5f), pk2(-1.0f)), pk2(1.0f));
+                l = pk_fma(lw, pk2(LN2_HI), d * rw);
+            } else if (k == 4) {
+                const f32x2 zr = {relu1(z.x), relu1(z.y)};
+                sp = pk_fma(l, pk2(C_HI), pk_fma(l, pk2(C_LO), zr));
+                if (ot >= 6 && inject) {
+                    const int f0 = 32 * ot + 16 * qp + 8 * ((2 * i) >> 2) + 4 * lh + ((2 * i) & 3);
+                    const int k0 = f0 - pe_first, k1 = f0 + 1 - pe_first;
+                    const float p0 = pe_row[k0 < 0 ? 0 : k0], p1 = pe_row[k1 < 0 ? 0 : k1];
+                    sp.x = k0 >= 0 ? p0 : sp.x;
+                    sp.y = k1 >= 0 ? p1 : sp.y;
+                }
+                h_ = x3_cvt2(sp.x, sp.y);
+                st[0][qp][i] = h_;
+            } else {
+                const float ra = sp.x - x3_bf16_to_f32_lo(h_), rb = sp.y - x3_bf16_to_f32_hi(h_);
+                m_ = x3_cvt2(ra, rb);
+                st[1][qp][i] = m_;
+                st[2][qp][i] = x3_cvt2(ra - x3_bf16_to_f32_lo(m_), rb - x3_bf16_to_f32_hi(m_));
+            }
+        } else {
+            if (k == 0) {
+                sp = f32x2{relu1(a[8 * qp + 2 * i]), relu1(a[8 * qp + 2 * i + 1])};
+                h_ = x3_cvt2(sp.x, sp.y);
+                st[0][qp][i] = h_;
+            } else if (k == 1) {
+                z = f32x2{sp.x - x3_bf16_to_f32_lo(h_), sp.y - x3_bf16_to_f32_hi(h_)};
+                m_ = x3_cvt2(z.x, z.y);
+                st[1][qp][i] = m_;
+            } else if (k == 2) {
+                st[2][qp][i] = x3_cvt2(z.x - x3_bf16_to_f32_lo(m_), z.y - x3_bf16_to_f32_hi(m_));
+            }
+        }
+    }
+};
+
+// One stage of the pipelined form.  dst / src: the accumulators written / read (the same set, except in a layer's last stage,
+// whose first k-step moves src -> dst).  HAS_JOB: group grp carries accumulator pair grp of tile `job_ot` of the previous
+// layer (job_acc) through its six phases, one behind each pair of MFMAs (the order of the 12 products is x3_mma_pair's).
+template <bool OCC, bool MOVE, bool HAS_JOB, typename BOp, typename RequestPiece>
+__device__ __forceinline__ void x3_stage_mma_p(floatx16 (&dst)[8], floatx16 (&src)[8], const xbf16x8* __restrict__ wl, int lane, int n_pieces, BOp bop,
+                                               RequestPiece request_piece, const floatx16& job_acc, const int job_ot, const int lh, const bool inject,
+                                               const float* pe_row, const int pe_first, xintx4 (&job_st)[3][2]) {
+    xbf16x8 a[2][3][2];
+    auto load_frags = [&](int grp, xbf16x8 (&f)[3][2]) __attribute__((always_inline)) {
+        const int ks = grp >> 2, p = grp & 3;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) f[pl][o] = wl[((ks * 8 + 2 * p + o) * 3 + pl) * 64 + lane];
+    };
+    load_frags(0, a[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int grp = 0; grp < 8; ++grp) {
+        const int ks = grp >> 2, p = grp & 3;
+        if (grp + 1 < 8) {
+            load_frags(grp + 1, a[(grp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);  // (see x3_stage_mma: the reads are issued a whole group ahead of their use)
+        }
+        const xbf16x8 (&fr)[3][2] = a[grp & 1];
+        const xbf16x8 bh = bop(0, ks), bm = bop(1, ks), bl = bop(2, ks);
+        floatx16& c0 = dst[2 * p];
+        floatx16& c1 = dst[2 * p + 1];
+        X3EpiPhases<OCC> ph;
+#define X3P_SUB(K, PL, B)                                                                                              \
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[PL][0], B, (MOVE && ks == 0 && (K) == 0) ? src[2 * p] : c0, 0, 0, 0);      \
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[PL][1], B, (MOVE && ks == 0 && (K) == 0) ? src[2 * p + 1] : c1, 0, 0, 0);  \
+        if constexpr (HAS_JOB) { ph.run(K, job_acc, grp, job_ot, lh, inject, pe_row, pe_first, job_st); __builtin_amdgcn_sched_barrier(0); }
+        X3P_SUB(0, 2, bh) X3P_SUB(1, 0, bl) X3P_SUB(2, 1, bm) X3P_SUB(3, 1, bh) X3P_SUB(4, 0, bm) X3P_SUB(5, 0, bh)
+#undef X3P_SUB
+        if (grp < 2) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) request_piece(6 * grp + j);
+        } else if (grp == 2 && n_pieces > 12) { request_piece(12); request_piece(13); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool OCC>
+__global__ __launch_bounds__(256, 1) void mlp_infer_x3p_kernel(X3Args g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsmem[];  // 2 x (48 KB stage + 8 KB bias k-step) [+ 24 KB encoding]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 31, lh = lane >> 5;
+    const int n_hidden = g.d.n_hidden;
+    unsigned group = 0, tile = blockIdx.x;
+    long long n_rows_eff = 0;
+    if constexpr (OCC) {
+        n_rows_eff = g.n_rows;
+        if (g.n_rows_dev != nullptr) { const long long nd = *g.n_rows_dev; n_rows_eff = nd < n_rows_eff ? nd : n_rows_eff; }
+        if ((long long)blockIdx.x * (kX3Waves * 32) >= n_rows_eff) return;
+    } else {
+        group = blockIdx.x / g.tiles_per_group;
+        tile = blockIdx.x - group * g.tiles_per_group;
+    }
+    const unsigned init_stride = g.n_in_layers * 256u;
+    const float* vrow = OCC ? nullptr : g.V + (size_t)group * init_stride + 4 * lh;
+    const unsigned char* wptr = g.w;
+    int in_idx = 0, gstage = 0;
+    const bool l1_bias = OCC ? true : (n_hidden > 1 && g.d.has_in[1] == 0);
+    const unsigned char* first_bias = OCC ? g.bias : g.bias + kX3BiasBytes;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) x3_dma_piece(wptr, xsmem, first_bias, wave, lane, j);
+    if (l1_bias) { x3_dma_piece(wptr, xsmem, first_bias, wave, lane, 12); x3_dma_piece(wptr, xsmem, first_bias, wave, lane, 13); }
+    wptr += kX3StageBytes;
+
+    const unsigned n = tile * (unsigned)(kX3Waves * 32) + wave * 32 + ln;
+    const bool valid = OCC ? (long long)n < n_rows_eff : n < g.rows_per_group;
+    const unsigned row = OCC ? n : group * g.rows_per_group + n;
+    const float* urow = OCC ? nullptr : g.U + (size_t)(valid ? n : g.rows_per_group - 1) * init_stride + 4 * lh;
+    float* pe_row = reinterpret_cast<float*>(xsmem + 2 * kX3BufBytes) + (wave * 32 + ln) * kX3PeStride;
+    if constexpr (OCC) {
+        float q[3] = {0.f, 0.f, 0.f};
+        if (valid) { q[0] = g.points[(size_t)n * 3]; q[1] = g.points[(size_t)n * 3 + 1]; q[2] = g.points[(size_t)n * 3 + 2]; }
+        const int n_pairs = 3 * g.pe_octaves, half = (n_pairs + 1) / 2;
+        for (int pi = lh * half; pi < (lh == 0 ? half : n_pairs); ++pi) {
+            const int f = pi / 3, c = pi - 3 * f;
+            const float arg = ldexpf((c == 0 ? q[0] : (c == 1 ? q[1] : q[2])) * g.pe_scale, f);
+            float sn, cs;
+            sincosf(arg, &sn, &cs);
+            pe_row[3 + 6 * f + c] = sn;
+            pe_row[3 + 6 * f + 3 + c] = cs;
+        }
+        if (lh == 0) { pe_row[0] = q[0] * g.pe_scale; pe_row[1] = q[1] * g.pe_scale; pe_row[2] = q[2] * g.pe_scale; }
+        else for (int col = 3 + 2 * n_pairs; col < kX3PeStride; ++col) pe_row[col] = 0.0f;
+    }
+    xbf16x8 ones_b;
+    {
+        xintx4 o = {lh == 0 ? 0x3F803F80 : 0, lh == 0 ? 0x00003F80 : 0, 0, 0};
+        ones_b = __builtin_bit_cast(xbf16x8, o);
+    }
+
+    floatx16 cur[8], tmp[8];  // cur: the finished pre-activations of the previous layer (loop-carried); tmp: the layer being accumulated
+    xintx4 st[2][3][2];       // B-operand planes of two output tiles: [ring slot][plane][k-step of the tile]
+
+    auto init_uv = [&](floatx16 (&acc)[8], int idx) __attribute__((always_inline)) {
+        const float* pu = urow + idx * 256;
+        const float* pv = vrow + idx * 256;
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 u = *reinterpret_cast<const float4*>(pu + 32 * ot + 8 * q);
+                const float4 t = *reinterpret_cast<const float4*>(pv + 32 * ot + 8 * q);
+                acc[ot][4 * q] = u.x + t.x; acc[ot][4 * q + 1] = u.y + t.y; acc[ot][4 * q + 2] = u.z + t.z; acc[ot][4 * q + 3] = u.w + t.w;
+            }
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) asm volatile("" : "+v"(acc[ot]));
+    };
+    auto init_bias = [&](floatx16 (&acc)[8]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const xbf16x8* bl = reinterpret_cast<const xbf16x8*>(xsmem + (gstage & 1) * kX3BufBytes + kX3StageBytes);
+        floatx16 zero;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ot * 64 + lane], ones_b, zero, 0, 0, 0);
+    };
+
+#define X3P_STAGE(MOVE, HAS_JOB, DST, SRC, BOP, NEXT_HAS_BIAS, BSRC, JOB_ACC, JOB_OT, JOB_ST)                  \
+    {                                                                                                        \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+        __syncthreads();                                                                                     \
+        const xbf16x8* wl = reinterpret_cast<const xbf16x8*>(xsmem + (gstage & 1) * kX3BufBytes);            \
+        unsigned char* nxt = xsmem + ((gstage + 1) & 1) * kX3BufBytes;                                       \
+        const unsigned char* bsrc_ = (BSRC);                                                                 \
+        x3_stage_mma_p<OCC, MOVE, HAS_JOB>(DST, SRC, wl, lane, (NEXT_HAS_BIAS) ? 14 : 12, BOP,               \
+                                           [&](int j_) { x3_dma_piece(wptr, nxt, bsrc_, wave, lane, j_); },  \
+                                           JOB_ACC, JOB_OT, lh, inject_, pe_row, g.pe_first, JOB_ST);         \
+        wptr += kX3StageBytes;                                                                               \
+        ++gstage;                                                                                            \
+    }
+
+    bool inject_ = false;
+    if constexpr (OCC) {
+        init_bias(cur);
+        xbf16x8 bin[3][4];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const float4 v0 = *reinterpret_cast<const float4*>(pe_row + 16 * ks + 8 * lh), v1 = *reinterpret_cast<const float4*>(pe_row + 16 * ks + 8 * lh + 4);
+            xintx4 oh, om, ol;
+            int h_, m_, l_;
+            x3_split2(v0.x, v0.y, h_, m_, l_); oh[0] = h_; om[0] = m_; ol[0] = l_;
+            x3_split2(v0.z, v0.w, h_, m_, l_); oh[1] = h_; om[1] = m_; ol[1] = l_;
+            x3_split2(v1.x, v1.y, h_, m_, l_); oh[2] = h_; om[2] = m_; ol[2] = l_;
+            x3_split2(v1.z, v1.w, h_, m_, l_); oh[3] = h_; om[3] = m_; ol[3] = l_;
+            bin[0][ks] = __builtin_bit_cast(xbf16x8, oh); bin[1][ks] = __builtin_bit_cast(xbf16x8, om); bin[2][ks] = __builtin_bit_cast(xbf16x8, ol);
+        }
+        {
+            xintx4 z = {0, 0, 0, 0};
+            bin[0][3] = bin[1][3] = bin[2][3] = __builtin_bit_cast(xbf16x8, z);
+        }
+        X3P_STAGE(false, false, cur, cur, ([&](int pl, int ks) -> xbf16x8 { return bin[pl][ks]; }), false, g.bias, cur[0], 0, st[0])
+        X3P_STAGE(false, false, cur, cur, ([&](int pl, int ks) -> xbf16x8 { return bin[pl][2 + ks]; }), n_hidden > 1, g.bias + kX3BiasBytes, cur[0], 0, st[0])
+    } else {
+        init_uv(cur, 0);
+        ++in_idx;
+    }
+    for (int li = 1; li < n_hidden; ++li) {
+        const bool has_in = !OCC && g.d.has_in[li] != 0;
+        const bool inject = OCC && li == g.skip_layer;
+        inject_ = inject;
+        // tile 0 of the previous layer: the only part of its epilogue that nothing hides
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x3_epi_job<OCC>(cur[0], j, 0, lh, inject, pe_row, g.pe_first, st[0]);
+        if (has_in) { init_uv(tmp, in_idx); ++in_idx; }
+        else init_bias(tmp);
+        const bool next_bias = li + 1 < n_hidden && (OCC || g.d.has_in[li + 1] == 0);
+        const unsigned char* next_bsrc = g.bias + (size_t)(li + 1 < n_hidden ? li + 1 : 0) * kX3BiasBytes;
+        // stage S: MFMAs on tile S's planes (ring slot S & 1), the epilogue of tile S + 1 (into the other slot) in their gaps
+#define X3P_ACT(S)                                                                                                           \
+        X3P_STAGE(false, true, tmp, tmp, ([&](int pl, int ks) -> xbf16x8 { return __builtin_bit_cast(xbf16x8, st[(S) & 1][pl][ks]); }),   \
+                  false, next_bsrc, cur[(S) + 1], (S) + 1, st[((S) + 1) & 1])
+        X3P_ACT(0) X3P_ACT(1) X3P_ACT(2) X3P_ACT(3) X3P_ACT(4) X3P_ACT(5) X3P_ACT(6)
+#undef X3P_ACT
+        // last stage: every tile of the previous layer has been consumed -- the results move back into `cur`
+        X3P_STAGE(true, false, cur, tmp, ([&](int pl, int ks) -> xbf16x8 { return __builtin_bit_cast(xbf16x8, st[1][pl][ks]); }),
+                  next_bias, next_bsrc, cur[0], 0, st[0])
+    }
+#undef X3P_STAGE
+    // final layer: the whole epilogue of the last hidden layer (tmp is dead: its registers hold the 16 k-steps of planes),
+    // then one output tile (n_out <= 32), 16 k-steps x 3 planes in ONE 48 KB stage; four accumulator chains
+    xbf16x8 bact[3][16];
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+        xintx4 s8[3][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x3_epi_job<OCC>(cur[ot], j, ot, lh, false, pe_row, g.pe_first, s8);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { bact[pl][2 * ot] = __builtin_bit_cast(xbf16x8, s8[pl][0]); bact[pl][2 * ot + 1] = __builtin_bit_cast(xbf16x8, s8[pl][1]); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const xbf16x8* wl = reinterpret_cast<const xbf16x8*>(xsmem + (gstage & 1) * kX3BufBytes);
+        floatx16 f[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) f[c][i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const xbf16x8 ah = wl[(ks * 3 + 0) * 64 + lane], am = wl[(ks * 3 + 1) * 64 + lane], al = wl[(ks * 3 + 2) * 64 + lane];
+            floatx16& c = f[ks & 3];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bact[0][ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bact[2][ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bact[1][ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bact[0][ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bact[1][ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bact[0][ks], c, 0, 0, 0);
+        }
+        const int n_out = g.d.n_out;
+        if (valid) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = 8 * (v >> 2) + 4 * lh + (v & 3);
+                if (m < n_out) {
+                    float x = (f[0][v] + f[1][v]) + (f[2][v] + f[3][v]) + g.final_bias[m];
+                    if (g.d.out_act == PSN_OUT_SIGMOID) x = sigmoidf_(x);
+                    else if (g.d.out_act == PSN_OUT_OCC) x = sigmoidf_(x * -10.0f);
+                    const int64_t orow = (OCC && g.out_rows != nullptr) ? g.out_rows[row] : (int64_t)row;
+                    g.out[orow * n_out + m] = x;
+                }
+            }
+        }
+    }
+}
+
 // ---- packers --------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void x3_split1(float v, uint16_t (&p)[3]) {
     float r = v;
@@ -433,6 +787,11 @@ __global__ __launch_bounds__(256) void x3_pack_bias_kernel(const float* __restri
 }
 }  // namespace psn
 
+static bool x3_pipelined() {
+    const char* e = getenv("PSN_X3_PIPE");
+    return !(e != nullptr && e[0] == '0');
+}
+
 extern "C" int psn_x3_pack(const float* W, int64_t ldw, int rows, int cols, int permuted, int n_ot, int ks0, int n_ks, uint16_t* dst,
                            void* stream) {
     using namespace psn;
@@ -481,12 +840,14 @@ extern "C" int psn_mlp_infer_x3_grouped(const PsnBf16Desc* desc, const uint16_t*
     const int64_t blocks = (int64_t)a.tiles_per_group * n_groups;
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer_x3_grouped: too many rows");
     const size_t lds_bytes = 2 * kX3BufBytes;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_infer_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    // PSN_X3_PIPE=0 selects the round-3 form (whole epilogue between two layers) for A/B runs; default: the pipelined form
+    const auto kern = x3_pipelined() ? &mlp_infer_x3p_kernel<false> : &mlp_infer_x3_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
         set_error("mlp_infer_x3_grouped: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
         return PSN_E_LAUNCH;
     }
-    hipLaunchKernelGGL(mlp_infer_x3_kernel<false>, dim3((unsigned)blocks), dim3(kX3Waves * 64), lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kX3Waves * 64), lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer_x3_grouped");
     return PSN_OK;
 }
@@ -516,12 +877,13 @@ extern "C" int psn_mlp_infer_x3_occ(const PsnBf16Desc* desc, const uint16_t* pac
     a.out = out;
     const int64_t blocks = (n_rows + kX3Waves * 32 - 1) / (kX3Waves * 32);
     const size_t lds_bytes = 2 * kX3BufBytes + kX3PeBytes;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_infer_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const auto kern = x3_pipelined() ? &mlp_infer_x3p_kernel<true> : &mlp_infer_x3_kernel<true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
         set_error("mlp_infer_x3_occ: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
         return PSN_E_LAUNCH;
     }
-    hipLaunchKernelGGL(mlp_infer_x3_kernel<true>, dim3((unsigned)blocks), dim3(kX3Waves * 64), lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kX3Waves * 64), lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer_x3_occ");
     return PSN_OK;
 }

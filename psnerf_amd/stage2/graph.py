@@ -82,6 +82,11 @@ class GraphedTrainStep(object):
             st.train_fix()
         st.dp.new_step()
         model_input = st.select_vis_lights(model_input, vidx)
+        if 'surface_idx' not in model_input:
+            # the reference's dictionary (no index list of the surface pixels): built here, OUTSIDE the graph -- nonzero() is a
+            # host synchronisation and cannot be captured; its length is part of the graph's signature
+            model_input = dict(model_input)
+            model_input['surface_idx'] = model_input['surface_mask'][0].nonzero(as_tuple=True)[0]
         key = self._key(model_input, ground_truth, l_slt, noise)
         cap = self._captured.get(key)
         if cap is None:
@@ -108,10 +113,21 @@ class GraphedTrainStep(object):
         """A plain TrainStep step on the capture stream (so that every per-stream cache the capture will use exists)."""
         st = self.step_obj
         cur = torch.cuda.current_stream(st.device)
+        # The collectives of a data-parallel step are issued on the CALLER's stream, never on the capture stream: RCCL's work
+        # objects hold events recorded on the stream they were issued from, its watchdog thread polls them for ~100 ms
+        # afterwards, and HIP refuses a query of an event whose stream is capturing by then ("operation not permitted on an
+        # event last recorded in a capturing stream": the exception kills the process from the watchdog thread -- seen once
+        # in bench.py when the capture followed the warm-up steps quickly enough).
+        count = None
+        if st.dp.enabled:
+            count = st.dp.masked_count_tensor(model_input['surface_mask'], model_input['object_mask'])
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            terms, out, trainable, train_light = st._fwd_bwd(model_input, ground_truth, l_slt, noise=noise)
-            st._reduce(trainable)
+            terms, out, trainable, train_light = st._fwd_bwd(model_input, ground_truth, l_slt, noise=noise, count=count)
+        cur.wait_stream(self.stream)
+        st._reduce(trainable)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
             st._optimise(l_slt, trainable, train_light)
         cur.wait_stream(self.stream)
         for t in list(terms.values()) + list(out.values()):

@@ -76,6 +76,36 @@ def main():
         res['stage2_bucket_bytes'] = dp1.allreduce_bytes
         res['allreduce_ms_bucket'] = round(dp1.time_allreduce(dp1.allreduce_bytes // 4), 4)
 
+        # ---- stage 2 replayed from HIP graphs AROUND the RCCL collectives (stage2/graph.py: two graphs per step, the count and
+        # the bucket all-reduce issued eagerly between them on the caller's stream) against the eager data-parallel step ------
+        from psnerf_amd.stage2.graph import GraphedTrainStep
+        g2 = torch.Generator().manual_seed(8)
+        nzs = [(torch.randn(int(inp['surface_mask'].sum()), 3, generator=g2) * 0.01).to(dev) for _ in range(7)]
+        gres = []
+        for graphed in (False, True):
+            dp = pdist.DataParallel(dev, force=True)
+            net = s2.PSNetwork(conf)
+            net.load_state_dict(sd)
+            net.to(dev)
+            st = s2.TrainStep(net, conf, NL, light_init.to(dev), dev, dp=dp)
+            st.cur_iter = 5001
+            run = GraphedTrainStep(st, warmup=2) if graphed else st
+            losses = []
+            for k in range(7):
+                terms, _ = run.step(inp, gt, l_slt, train_order=False, noise={'xyz': nzs[k]})
+                losses.append(float(terms['total'].detach()))
+            torch.cuda.synchronize()
+            if graphed:
+                assert run.n_captures == 1 and run.n_eager == 2 and run.n_replays == 5, (run.n_captures, run.n_eager, run.n_replays)
+                assert len(run._captured[next(iter(run._captured))].graphs) == 2  # [fwd, bwd, gather] + [optimisers]
+            assert dp.n_allreduce == 7, dp.n_allreduce
+            gres.append((losses, {k: v.detach().clone() for k, v in net.state_dict().items()},
+                         st.light_para.weight.detach().clone(), st.light_inten_para.weight.detach().clone()))
+        (le, pe_, ae, be), (lg, pg, ag, bg) = gres
+        checks['stage2 graphed data-parallel steps: losses identical'] = le == lg
+        checks['stage2 graphed data-parallel steps: parameters and light tables identical'] = (
+            all(torch.equal(pe_[k], pg[k]) for k in pe_) and torch.equal(ae, ag) and torch.equal(be, bg))
+
         # ---- stage 1 (sync-free forward: device-resident counts go through RCCL as tensors) ---------------------------
         from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
         n_rays = 160
