@@ -158,15 +158,17 @@ class GraphedTrainStep(object):
                 if opt.graph_scalars is None:
                     opt.graph_scalars = StepScalars(n, dev)
         torch.cuda.synchronize(dev)
+        # capture_error_mode 'thread_local': other threads of the process (RCCL's watchdog and proxy threads, pinned-memory
+        # loaders) keep calling HIP while this thread captures; in the default 'global' mode any such call invalidates the capture
         g_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_a, stream=self.stream):
+        with torch.cuda.graph(g_a, stream=self.stream, capture_error_mode='thread_local'):
             cap.terms, cap.out, cap.trainable, cap.train_light = st._fwd_bwd(cap.inp, cap.gt, cap.l_slt, noise=cap.noise, count=cap.count)
             if not st.dp.enabled:
                 st._optimise(cap.l_slt, cap.trainable, cap.train_light)
         cap.graphs.append(g_a)
         if st.dp.enabled:
             g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_b, stream=self.stream, pool=g_a.pool()):
+            with torch.cuda.graph(g_b, stream=self.stream, pool=g_a.pool(), capture_error_mode='thread_local'):
                 st._optimise(cap.l_slt, cap.trainable, cap.train_light)
             cap.graphs.append(g_b)
         # the optimisers' host halves ran inside the captures (step counts advanced, this step's scalars remembered): send the

@@ -13,17 +13,23 @@ from tests.helpers import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_end_to_end_small(cuda, tmp_path, capsys, monkeypatch):
+@pytest.mark.parametrize('occ', ['fp32', 'bf16x6'])
+def test_end_to_end_small(cuda, tmp_path, capsys, monkeypatch, occ):
     spec = importlib.util.spec_from_file_location('run_e2e', os.path.join(ROOT, 'tools', 'run_e2e.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, 'argv', ['run_e2e.py', '--h', '40', '--w', '40', '--views', '2', '--lights', '5', '--light-bs', '3',
                                       '--vis-plus', '6', '--vis-train-num', '3', '--rays', '192', '--s1-steps', '24',
-                                      '--s2-steps', '32', '--pixels', '600', '--envmap-h', '4', '--out', str(tmp_path / 'shape')])
+                                      '--s2-steps', '32', '--pixels', '600', '--envmap-h', '4', '--out', str(tmp_path / 'shape'),
+                                      '--occ-precision', occ])
     mod.main()
     line = [l for l in capsys.readouterr().out.splitlines() if l.startswith('{')][-1]
     res = json.loads(line)
     assert res['e2e'] == 'ok' and min(res['surface_pixels']) > 0
+    if occ == 'bf16x6':  # the hand-off of the opt-in split-bf16 occupancy engine against the exact extraction (gates in run_e2e.py)
+        assert res['occ_bf16x6']['mask_pixels_differing'] <= 3 and res['occ_bf16x6']['visibility_psnr_vs_exact_db'] >= 80.0
+    else:
+        assert res['occ_bf16x6'] is None
     assert abs(res['relight']['psnr_fp32'] - res['relight']['psnr_bf16']) <= 0.05
     for sub in ('points', 'normal', 'mask', 'visibility', 'vis_plus'):
         assert os.path.exists(os.path.join(str(tmp_path / 'shape'), sub, 'view_01.npy'))

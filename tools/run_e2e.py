@@ -58,6 +58,9 @@ def main():
     ap.add_argument('--pixels', type=int, default=1024, help='stage-2 pixels per step (in-mask sampling)')
     ap.add_argument('--envmap-h', type=int, default=8)
     ap.add_argument('--out', default=None, help='hand-off directory (default: a temporary one)')
+    ap.add_argument('--occ-precision', choices=('fp32', 'bf16x6'), default='fp32',
+                    help="gradient-free occupancy queries of shape_extract (ray march sweep, shadow rays): 'bf16x6' = the opt-in "
+                         'split-bf16 engine; the hand-off is then ALSO extracted with the exact engine and compared')
     args = ap.parse_args()
 
     import numpy as np
@@ -131,6 +134,44 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t_extract = time.time() - t0
+    occ_cmp = None
+    if args.occ_precision == 'bf16x6':
+        # the same extraction on the split-bf16 occupancy engine (opt-in): the stage-2 run below consumes THIS hand-off; gates:
+        # identical masks, surface points / normals / visibility within the exact path's parity bounds, visibility maps > 80 dB apart
+        exact = [handoff.load_view(out_dir, v + 1) for v in range(args.views)]
+        x3_dir = out_dir + '_bf16x6'
+        net1.inference_precision = 'bf16x6'
+        t0 = time.time()
+        if rank == 0:
+            for v in range(args.views):
+                handoff.export_view(ren, K.to(dev), poses[v][None].to(dev), S.to(dev), h, w, x3_dir, v + 1,
+                                    light_dir=lights[v].to(dev), vis_plus_dir=plus_dirs[v].to(dev))
+        net1.inference_precision = 'fp32'
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t_x3 = time.time() - t0
+        got = [handoff.load_view(x3_dir, v + 1) for v in range(args.views)]
+        worst = {'points': 0.0, 'normal': 0.0, 'visibility': 0.0, 'vis_plus': 0.0}
+        vis_psnr = []
+        flips = 0
+        for a, b in zip(exact, got):
+            # a ray whose sweep value sits within 1e-6 of the threshold may be classified the other way: counted, bounded
+            both = (a['surface_mask'] & b['surface_mask']).reshape(-1)
+            flips += int((a['surface_mask'] != b['surface_mask']).sum())
+            for key in worst:
+                x, y = a[key].float(), b[key].float()
+                x, y = (x[0][both], y[0][both]) if key in ('points', 'normal') else (x[:, both], y[:, both])
+                if x.numel():
+                    worst[key] = max(worst[key], float((x - y).abs().max()))
+            vis_psnr.append(metrics.PSNR(b['visibility'].float()[:, both].numpy(), a['visibility'].float()[:, both].numpy()))
+        assert flips <= max(1, int(1e-3 * args.views * h * w)), 'bf16x6 occupancy engine: %d pixels classified differently' % flips
+        assert worst['points'] <= 2e-4 and worst['normal'] <= 2e-3 and worst['visibility'] <= 1e-3 and worst['vis_plus'] <= 1e-3, worst
+        assert min(vis_psnr) >= 80.0, vis_psnr
+        occ_cmp = {'max_abs_diff_vs_exact': {k2: float('%.3g' % v2) for k2, v2 in worst.items()}, 'mask_pixels_differing': flips,
+                   'visibility_psnr_vs_exact_db': round(min(vis_psnr), 1), 'extract_seconds': round(t_x3, 2),
+                   'exact_extract_seconds': round(t_extract, 2)}
+        out_dir = x3_dir
     views = [handoff.load_view(out_dir, v + 1) for v in range(args.views)]
     n_surf = [int(vw['surface_mask'].sum()) for vw in views]
     assert min(n_surf) > 0, 'stage-1 surface is empty in some view'
@@ -190,7 +231,7 @@ def main():
             'e2e': 'ok', 'n_gpus': world, 'image': [h, w], 'views': args.views, 'lights_per_view': args.lights,
             'surface_pixels': n_surf, 'stage1': {'steps': args.s1_steps, 'loss_first': s1_losses[0], 'loss_last': s1_losses[-1],
                                                  'seconds': round(t_s1, 2)},
-            'shape_extract_seconds': round(t_extract, 2), 'handoff_dir': out_dir,
+            'shape_extract_seconds': round(t_extract, 2), 'handoff_dir': out_dir, 'occ_bf16x6': occ_cmp,
             'stage2': {'steps': args.s2_steps, 'switch_at': switch, 'loss_phase1': [ph1[0], ph1[-1]],
                        'loss_phase2': [ph2[0], ph2[-1]], 'seconds': round(t_s2, 2)},
             'relight': {'envmap': [lh, 2 * lh], 'psnr_fp32': round(p32, 4), 'psnr_bf16': round(p16, 4),
