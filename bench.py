@@ -302,9 +302,19 @@ def cfg4_case(device, dp, px_global, rank, world, steps, modes=('eager', 'graph'
         if mode == 'eager':
             fn = lambda: step.step(inp, gt, l_slt, train_order=False)
         else:
-            run = GraphedTrainStep(step, adopt_inputs=True)
+            def agree(ok):  # every rank replays, or none does (a rank whose capture failed would leave the others in a collective)
+                if world == 1:
+                    return ok
+                t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(int(t.item()))
+            run = GraphedTrainStep(step, adopt_inputs=True, agree=agree)
             fn = lambda: run.step(inp, gt, l_slt, train_order=False)
-        ms, host_ms = time_steps(fn, steps, 5, world, device)
+        try:
+            ms, host_ms = time_steps(fn, steps, 5, world, device)
+        except RuntimeError as e:  # (raised on EVERY rank at the same point: see agree)
+            out[mode] = {'error': str(e)[:300]}
+            continue
         torch.cuda.synchronize()
         out[mode] = {'ms_per_step': round(ms, 3), 'host_issue_ms': round(host_ms, 3),
                      'value': round(out['surface_pixels_total'] * N_LIGHTS / (ms * 1e-3), 1)}
@@ -332,15 +342,15 @@ def strong_cfg4(device, dp, rank, world, steps=40):
         res['data_parallel_path'] = bool(dpf.enabled)
         case = cfg4_case(device, dpf, N_PIXELS, rank, world, steps)
         res.update(case)
-        best = min(('eager', 'graph'), key=lambda m: case[m]['ms_per_step'])
+        best = min((m for m in ('eager', 'graph') if 'ms_per_step' in case[m]), key=lambda m: case[m]['ms_per_step'])
         res['value'], res['ms_per_step'], res['mode'] = case[best]['value'], case[best]['ms_per_step'], best
         if world == 1:
             proj = {}
             for n in (2, 4, 8):
                 c = cfg4_case(device, dpf, N_PIXELS // n, rank, world, steps)
-                bm = min(('eager', 'graph'), key=lambda m: c[m]['ms_per_step'])
-                proj[str(n)] = {'pixels_per_rank': N_PIXELS // n, 'eager_ms': c['eager']['ms_per_step'], 'graph_ms': c['graph']['ms_per_step'],
-                                'eager_host_issue_ms': c['eager']['host_issue_ms'], 'graph_host_issue_ms': c['graph']['host_issue_ms'],
+                bm = min((m for m in ('eager', 'graph') if 'ms_per_step' in c[m]), key=lambda m: c[m]['ms_per_step'])
+                proj[str(n)] = {'pixels_per_rank': N_PIXELS // n, 'eager_ms': c['eager'].get('ms_per_step'), 'graph_ms': c['graph'].get('ms_per_step'),
+                                'eager_host_issue_ms': c['eager'].get('host_issue_ms'), 'graph_host_issue_ms': c['graph'].get('host_issue_ms'),
                                 'projected_speedup_vs_1': round(res['ms_per_step'] / c[bm]['ms_per_step'], 3),
                                 'fraction_of_linear': round(res['ms_per_step'] / c[bm]['ms_per_step'] / n, 3)}
             res['per_rank_projection'] = proj

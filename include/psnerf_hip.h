@@ -275,6 +275,8 @@ typedef struct {
 } PsnScatterItem;
 int psn_scatter_rows(int n_items, const PsnScatterItem* items, const int* inv, int64_t N, int64_t Ns, void* stream);
 int psn_gather_rows(int n_items, const PsnScatterItem* items, const int64_t* idx, int64_t N, int64_t Ns, void* stream);
+/* psn_gather_rows for an index list that may be PADDED (psn_surface_index): rows r with inv[idx[r]] != r receive zeros. */
+int psn_gather_rows_valid(int n_items, const PsnScatterItem* items, const int64_t* idx, const int* inv, int64_t N, int64_t Ns, void* stream);
 
 /* One secant (regula falsi) iteration of the surface refinement, stage1/model/rendering.py:525-555, for n hit rays:
  * with occ [n] (occupancy at the current d_pred; NULL for the initial step) the bracket (d_low, d_high, f_low, f_high,
@@ -492,6 +494,12 @@ typedef struct {
 } PsnCopy2dItem;
 int psn_copy2d_group(int n_items, const PsnCopy2dItem* items, void* stream);
 int psn_mask_count(const unsigned char* mask_a, const unsigned char* mask_b, int64_t n, float* out, void* stream);
+/* psn_surface_index: idx[0 .. ns) = ascending positions of the set bytes of mask [n] (= surface_mask[0].nonzero(),
+ *   stage2/model/renderer.py:125, without a host synchronisation), idx[ns .. cap) = idx[ns - 1]: a FIXED-size list whose
+ *   dead tail repeats the last surface pixel (0 for an empty mask); count[0] (may be NULL) = ns as a float.  A list longer than
+ *   cap is truncated.  Kernels that read such a list treat entries behind the first of equal neighbours as dead rows
+ *   (psn_gather_rows_valid); psn_inverse_index maps a pixel to the FIRST of equal entries. */
+int psn_surface_index(const unsigned char* mask, int64_t n, int64_t cap, int64_t* idx, float* count, void* stream);
 int psn_inverse_index(const int64_t* idx, int64_t ns, int64_t n_pix, int* inv, void* stream);
 #define PSN_ADAM_MAX_SEGS 16
 typedef struct {

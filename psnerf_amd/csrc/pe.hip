@@ -278,7 +278,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(ScatterArgs a) {
     if (e >= (uint32_t)it.B * Ns * C) return;
     const uint32_t br = e / C, c = e - br * C;
     const uint32_t b = br / Ns, r = br - b * Ns;
-    const_cast<float*>(it.rows)[e] = it.dense[((int64_t)b * a.N + a.idx[r]) * it.C + c];
+    const int64_t px = a.idx[r];
+    // a PADDED index list (psn_surface_index: the last surface pixel repeated up to a fixed capacity) maps its pixel back to
+    // the FIRST of the equal entries: every later one is a dead row and gets an exact zero, not a second copy of the gradient
+    const bool live = a.inv == nullptr || a.inv[px] == (int)r;
+    const_cast<float*>(it.rows)[e] = live ? it.dense[((int64_t)b * a.N + px) * it.C + c] : 0.0f;
 }
 
 static int launch_scatter(int n_items, const PsnScatterItem* items, const int* inv, const int64_t* idx, int64_t N, int64_t Ns,
@@ -308,6 +312,10 @@ static int launch_scatter(int n_items, const PsnScatterItem* items, const int* i
 
 extern "C" int psn_scatter_rows(int n_items, const PsnScatterItem* items, const int* inv, int64_t N, int64_t Ns, void* stream) {
     return psn::launch_scatter(n_items, items, inv, nullptr, N, Ns, false, stream);
+}
+extern "C" int psn_gather_rows_valid(int n_items, const PsnScatterItem* items, const int64_t* idx, const int* inv, int64_t N, int64_t Ns,
+                                     void* stream) {
+    return psn::launch_scatter(n_items, items, inv, idx, N, Ns, true, stream);
 }
 extern "C" int psn_gather_rows(int n_items, const PsnScatterItem* items, const int64_t* idx, int64_t N, int64_t Ns, void* stream) {
     return psn::launch_scatter(n_items, items, nullptr, idx, N, Ns, true, stream);

@@ -269,6 +269,48 @@ extern "C" int psn_copy2d_group(int n_items, const PsnCopy2dItem* items, void* s
     return PSN_OK;
 }
 
+// idx[0 .. ns) = the positions of the set bytes of mask [n] in ascending order, idx[ns .. cap) = idx[ns - 1] (0 when the mask is
+// empty), count[0] = ns as a float: nonzero() without its host synchronisation, into a FIXED-size list (graph replay).
+namespace psn {
+__global__ __launch_bounds__(1024) void surface_index_kernel(const unsigned char* __restrict__ mask, int64_t n, int64_t cap, int64_t* __restrict__ idx,
+                                                             float* __restrict__ count) {
+    __shared__ int cnt[1024];
+    __shared__ int total, last;
+    const int t = threadIdx.x;
+    const int64_t q = (n + 1023) / 1024, lo = t * q, hi = lo + q < n ? lo + q : n;
+    int c = 0;
+    for (int64_t i = lo; i < hi; ++i) c += mask[i] != 0;
+    cnt[t] = c;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < 1024; ++k) { const int v = cnt[k]; cnt[k] = run; run += v; }
+        total = run;
+        last = 0;
+    }
+    __syncthreads();
+    int64_t pos = cnt[t];
+    for (int64_t i = lo; i < hi; ++i)
+        if (mask[i] != 0) {
+            if (pos < cap) idx[pos] = i;
+            if (pos == (int64_t)total - 1) last = (int)i;
+            ++pos;
+        }
+    __syncthreads();
+    const int ns = total < cap ? total : (int)cap;
+    for (int64_t k = ns + t; k < cap; k += 1024) idx[k] = last;
+    if (t == 0 && count != nullptr) count[0] = (float)total;
+}
+}  // namespace psn
+
+extern "C" int psn_surface_index(const unsigned char* mask, int64_t n, int64_t cap, int64_t* idx, float* count, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(mask && idx && n >= 0 && n < (1ll << 24) && cap >= 1, "surface_index: bad arguments (n=%lld cap=%lld)", (long long)n, (long long)cap);
+    hipLaunchKernelGGL(surface_index_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, n, cap, idx, count);
+    PSN_CHECK_LAUNCH("surface_index");
+    return PSN_OK;
+}
+
 extern "C" int psn_mask_count(const unsigned char* mask_a, const unsigned char* mask_b, int64_t n, float* out, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(mask_a && out && n >= 0 && n < (1ll << 24), "mask_count: bad arguments (n=%lld: the count must be exact in fp32)", (long long)n);

@@ -124,6 +124,8 @@ SIGNATURES = {
                             ctypes.POINTER(ctypes.c_uint32), i64, c_f, c_f]),
     'psn_scatter_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_gather_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
+    'psn_gather_rows_valid': (i32, [i32, ctypes.c_void_p, c_f, c_f, i64, i64, c_f]),
+    'psn_surface_index': (i32, [c_f, i64, i64, c_f, c_f, c_f]),
     'psn_secant_step': (i32, [c_f, f32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, c_f]),
     'psn_first_crossing': (i32, [c_f, c_f, c_f, c_f, f32, f32, i64, i32, c_f, c_f, c_f]),
     'psn_stage2_loss_fwd': (i32, [c_f, c_f, i32, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, i64, i32, c_f, c_f, c_f,
@@ -409,8 +411,19 @@ def scatter_rows(specs, rows, inv, n_pixels, n_surf):
     return dense
 
 
-def gather_rows(specs, dense_grads, idx, n_pixels, n_surf):
-    """Adjoint of scatter_rows for the given dense gradients (contiguous [B, N, C]) -> list of [B*Ns, C] tensors."""
+def surface_index(mask, capacity):
+    """Ascending positions of the True elements of a 1-D bool device tensor in a FIXED-size int64 list [capacity]: entries behind
+    the real ones repeat the last one (psn_surface_index; no host synchronisation).  -> (idx, count float32 [1])."""
+    assert mask.is_cuda and mask.dtype == torch.bool and mask.dim() == 1 and mask.is_contiguous()
+    idx = torch.empty(int(capacity), device=mask.device, dtype=torch.int64)
+    count = torch.empty(1, device=mask.device, dtype=torch.float32)
+    _check(_lib.psn_surface_index(mask.data_ptr(), mask.numel(), int(capacity), idx.data_ptr(), count.data_ptr(), _stream()), 'surface_index')
+    return idx, count
+
+
+def gather_rows(specs, dense_grads, idx, n_pixels, n_surf, inv=None):
+    """Adjoint of scatter_rows for the given dense gradients (contiguous [B, N, C]) -> list of [B*Ns, C] tensors.  inv (the
+    pixel -> row map of the scatter): rows of a padded index list that are not the first of their pixel receive zeros."""
     out = [torch.empty(B * n_surf, C, device=idx.device, dtype=torch.float32) for B, C, _ in specs]
     for c0 in range(0, len(specs), SCATTER_MAX_ITEMS):
         n = min(SCATTER_MAX_ITEMS, len(specs) - c0)
@@ -420,6 +433,11 @@ def gather_rows(specs, dense_grads, idx, n_pixels, n_surf):
             assert g.is_contiguous() and g.shape == (B, n_pixels, C)
             e.rows, e.dense, e.B, e.C = out[c0 + i].data_ptr(), _ptr(g, 'dense_grad'), B, C
         assert idx.dtype == torch.int64 and idx.is_contiguous()
+        if inv is not None:
+            assert inv.dtype == torch.int32 and inv.is_contiguous() and inv.numel() == n_pixels
+            _check(_lib.psn_gather_rows_valid(n, ctypes.addressof(arr), idx.data_ptr(), inv.data_ptr(), n_pixels, n_surf, _stream()),
+                   'gather_rows_valid')
+            continue
         _check(_lib.psn_gather_rows(n, ctypes.addressof(arr), idx.data_ptr(), n_pixels, n_surf, _stream()), 'gather_rows')
     return out
 

@@ -267,16 +267,17 @@ class ScatterRows(torch.autograd.Function):
         _hit('ScatterRows')
         ctx.set_materialize_grads(False)  # dense outputs nobody differentiates: None, not a zero-filled [B, N, C] + its gather
         ctx.specs, ctx.n_pix, ctx.ns = specs, inv.numel(), idx.numel()
-        ctx.save_for_backward(idx)
+        ctx.save_for_backward(idx, inv)
         return tuple(hip.scatter_rows(list(specs), [r.detach() for r in rows], inv, inv.numel(), idx.numel()))
 
     @staticmethod
     def backward(ctx, *grads):
-        idx, = ctx.saved_tensors
+        idx, inv = ctx.saved_tensors
         sel = [k for k, g in enumerate(grads) if g is not None and ctx.needs_input_grad[3 + k]]
         out = [None] * len(grads)
         if sel:
-            got = hip.gather_rows([ctx.specs[k] for k in sel], [grads[k].contiguous() for k in sel], idx, ctx.n_pix, ctx.ns)
+            # (inv: the rows of a padded index list that are not the first of their pixel are dead and receive exact zeros)
+            got = hip.gather_rows([ctx.specs[k] for k in sel], [grads[k].contiguous() for k in sel], idx, ctx.n_pix, ctx.ns, inv=inv)
             for k, g in zip(sel, got):
                 out[k] = g
         return (None, None, None) + tuple(out)

@@ -41,12 +41,20 @@ class _Captured(object):
 
 
 class GraphedTrainStep(object):
-    def __init__(self, step, warmup=2, max_graphs=8, overlap_small_nets=None, adopt_inputs=False):
+    def __init__(self, step, warmup=2, max_graphs=8, overlap_small_nets=None, adopt_inputs=False, agree=None, pad_to_pixels=False):
         """``overlap_small_nets``: None keeps the model's setting; False captures a single-stream graph (0.04 ms of host
         time per replay instead of ~2.5 ms, at the price of the side-stream overlap).  ``adopt_inputs``: the tensors of the
         batch that is captured BECOME the graph's input buffers (no clones): for a caller that keeps refilling the same
         tensors -- a data pipeline with fixed staging buffers, the benchmark's resident batch -- a replay then copies
-        nothing (a cloned batch costs ~17 device-to-device copies of 5 us per step)."""
+        nothing (a cloned batch costs ~17 device-to-device copies of 5 us per step).  ``agree``: callable(bool) -> bool, called
+        right after every capture ATTEMPT with this rank's success and returning the job's verdict (data-parallel jobs pass an
+        all-reduce(MIN)): a rank whose capture failed must not leave the others waiting in the replay's collectives -- either
+        every rank replays or every rank raises.  ``pad_to_pixels``: the surface-pixel list of every batch is built ON THE DEVICE
+        with the fixed length N (psn_surface_index: the real entries, then the last one repeated), so that batches whose surface
+        count differs share ONE graph and the step has no host synchronisation even for the reference's dictionary; the dead rows
+        behind the real ones are evaluated and contribute exact zeros (their dense outputs are never written, their gradients
+        are zeroed by psn_gather_rows_valid) -- (N - Ns) / Ns more rows, and split-K sums in a different order than the
+        unpadded step (equal to rounding, not bit for bit)."""
         assert isinstance(step.sg_optimizer, FlatAdam) and isinstance(step.light_optimizer, RowSparseAdam) and step.FUSED_LOSSES, \
             'GraphedTrainStep needs the device-resident step (FlatAdam, RowSparseAdam, fused losses)'
         self.step_obj, self.warmup, self.max_graphs = step, int(warmup), int(max_graphs)
@@ -56,6 +64,8 @@ class GraphedTrainStep(object):
         if overlap_small_nets is not None:
             step.model.overlap_small_nets = bool(overlap_small_nets)
         self.adopt_inputs = bool(adopt_inputs)
+        self.agree = agree
+        self.pad_to_pixels = bool(pad_to_pixels)
         self.n_replays = self.n_eager = self.n_captures = 0
 
     # ---- signature of a step -------------------------------------------------------------------------------------------
@@ -82,6 +92,10 @@ class GraphedTrainStep(object):
             st.train_fix()
         st.dp.new_step()
         model_input = st.select_vis_lights(model_input, vidx)
+        if self.pad_to_pixels:
+            model_input = dict(model_input)
+            sm = model_input['surface_mask'][0].contiguous()
+            model_input['surface_idx'] = hip.surface_index(sm, sm.numel())[0]
         if 'surface_idx' not in model_input:
             # the reference's dictionary (no index list of the surface pixels): built here, OUTSIDE the graph -- nonzero() is a
             # host synchronisation and cannot be captured; its length is part of the graph's signature
@@ -94,7 +108,17 @@ class GraphedTrainStep(object):
             if seen < self.warmup or hip.PROFILE_EVENTS is not None:
                 self._seen[key] = seen + 1
                 return self._eager(model_input, ground_truth, l_slt, noise)
-            cap = self._capture(key, model_input, ground_truth, l_slt, noise)
+            if self.agree is None:
+                cap = self._capture(key, model_input, ground_truth, l_slt, noise)
+            else:
+                cap, err = None, None
+                try:
+                    cap = self._capture(key, model_input, ground_truth, l_slt, noise)
+                except Exception as e:  # noqa: BLE001  (reported below, on every rank at the same point of the collective sequence)
+                    err = e
+                if not self.agree(err is None):
+                    self._captured.pop(key, None)
+                    raise RuntimeError('GraphedTrainStep: the capture failed on %s rank: %r' % ('this' if err is not None else 'another', err))
             first = True
         else:
             first = False

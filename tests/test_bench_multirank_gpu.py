@@ -23,4 +23,8 @@ def test_bench_two_ranks_on_one_gpu(cuda):
         assert k in line, k
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0 and line['allreduce_bytes'] > 2_000_000
     assert line['config']['parallelism'] == 'pixel-dp2' and line['roofline']['frac'] <= 1.0
+    # BASELINE cfg 4 on the line (32768 px split over the ranks), eagerly AND replayed from HIP graphs around the collectives
+    c4 = line['strong_cfg4']
+    assert 'error' not in c4, c4
+    assert c4['pixels_per_gpu'] == 16384 and c4['eager']['ms_per_step'] > 0 and c4['graph']['ms_per_step'] > 0, c4
     assert res['too_many_gpus_rc'] == 2 and 'GPU(s) are visible' in res['too_many_gpus_msg']

@@ -114,3 +114,87 @@ def test_graphed_step_draws_fresh_jitter_noise_every_replay(cuda):
     torch.cuda.synchronize()
     assert run.n_replays >= 3
     assert not torch.equal(vals[-1], vals[-2]) and not torch.equal(vals[-2], vals[-3])
+
+
+@pytest.mark.parametrize('n', [1, 1000, 4097, 70000])
+def test_surface_index_is_nonzero_padded_with_the_last_entry(cuda, n):
+    """psn_surface_index: ascending positions of the set mask bytes, the tail of the fixed-size list repeating the last one; an
+    empty mask gives zeros; psn_inverse_index maps a pixel to the FIRST of equal entries."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(n)
+    for frac in (0.9, 0.0, 1.0):
+        m = (torch.rand(n, generator=g) < frac).to(cuda)
+        idx, cnt = hip.surface_index(m, n)
+        ref = m.nonzero(as_tuple=True)[0]
+        k = ref.numel()
+        assert float(cnt) == float(k)
+        assert torch.equal(idx[:k], ref)
+        assert bool((idx[k:] == (ref[-1] if k else 0)).all())
+        if k:
+            inv = hip.inverse_index(idx, n)
+            want = torch.full((n,), -1, dtype=torch.int32, device=cuda)
+            want[ref] = torch.arange(k, dtype=torch.int32, device=cuda)
+            assert torch.equal(inv, want)
+
+
+def test_padded_surface_list_gives_the_unpadded_step(cuda):
+    """A surface-pixel list padded to the pixel count (dead rows = the last surface pixel repeated): the dense outputs of the
+    forward are IDENTICAL to the unpadded step's, the losses too, and every gradient agrees to rounding (the dead rows add exact
+    zeros; split-K chunks fall differently)."""
+    from psnerf_amd import hip
+    res = {}
+    for pad in (False, True):
+        step, NL = _make(cuda, 5001)
+        inp, gt, l_slt, nz = _batches(1, 3000, 12, 4, NL, cuda)[0]
+        ns = int(inp['surface_mask'].sum())
+        if pad:
+            inp = dict(inp)
+            inp['surface_idx'] = hip.surface_index(inp['surface_mask'][0].contiguous(), 3000)[0]
+            nzp = torch.zeros(3000, 3, device=cuda)
+            nzp[:ns] = nz['xyz']
+            nz = {'xyz': nzp}
+        terms, out, _, _ = step._fwd_bwd(inp, gt, l_slt, noise=nz)
+        grads = {k: p.grad.detach().clone() for k, p in step.model.named_parameters() if p.grad is not None}
+        grads['__light_dir'] = step.light_para.weight.grad.detach().clone()
+        grads['__light_int'] = step.light_inten_para.weight.grad.detach().clone()
+        res[pad] = ({k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}, {k: float(v.detach()) for k, v in terms.items() if v is not None}, grads)
+    (o0, t0, g0), (o1, t1, g1) = res[False], res[True]
+    for k in o0:
+        assert torch.equal(o0[k], o1[k]), k
+    for k in t0:
+        assert abs(t0[k] - t1[k]) <= 1e-6 * abs(t0[k]), (k, t0[k], t1[k])
+    assert sorted(g0) == sorted(g1)
+    from tests.helpers import assert_close
+    for k in g0:
+        assert_close(g1[k].cpu(), g0[k].cpu(), 1e-5, 'grad ' + k)
+
+
+def test_one_graph_serves_batches_with_different_surface_counts(cuda):
+    """pad_to_pixels: batches whose surface masks (and counts) differ replay ONE captured graph, built from the reference's
+    dictionary (no 'surface_idx': the list is formed on the device); every step's losses agree with the eager, unpadded step
+    from the same state."""
+    from psnerf_amd.stage2.graph import GraphedTrainStep
+    N, L, V, n_it = 2500, 10, 4, 8
+    res = {}
+    for mode in ('eager', 'graph'):
+        step, NL = _make(cuda, 5001)
+        run = GraphedTrainStep(step, warmup=1, pad_to_pixels=True) if mode == 'graph' else step
+        losses, counts = [], []
+        for it in range(n_it):
+            inp, gt = stage2_inputs(N, L, V, seed=400 + it, surface_frac=0.6 + 0.04 * it)  # a different mask every step
+            ns = int(inp['surface_mask'].sum())
+            counts.append(ns)
+            l_slt = torch.randperm(NL, generator=torch.Generator().manual_seed(it))[:L].to(cuda)
+            nz = torch.zeros(N, 3)
+            nz[:ns] = torch.randn(ns, 3, generator=torch.Generator().manual_seed(50 + it)) * 0.01
+            noise = {'xyz': (nz if mode == 'graph' else nz[:ns]).to(cuda)}
+            terms, _ = run.step({k: v.to(cuda) for k, v in inp.items()}, {k: v.to(cuda) for k, v in gt.items()}, l_slt, train_order=False, noise=noise)
+            losses.append(float(terms['total'].detach()))
+        res[mode] = losses
+        if mode == 'graph':
+            assert run.n_captures == 1 and run.n_eager == 1 and run.n_replays == n_it - 1, (run.n_captures, run.n_eager, run.n_replays)
+    assert len(set(counts)) == n_it
+    le, lg = np.array(res['eager']), np.array(res['graph'])
+    assert np.isfinite(lg).all()
+    rel = np.abs(lg - le) / np.abs(le)
+    assert rel[0] <= 1e-6 and rel.max() <= 2e-3, rel  # (one step from a common state: equal; then two fp32 trajectories)

@@ -58,6 +58,9 @@ def main():
     ap.add_argument('--pixels', type=int, default=1024, help='stage-2 pixels per step (in-mask sampling)')
     ap.add_argument('--envmap-h', type=int, default=8)
     ap.add_argument('--out', default=None, help='hand-off directory (default: a temporary one)')
+    ap.add_argument('--graph', action='store_true',
+                    help='stage 2: replay the train step from HIP graphs (psnerf_amd.stage2.graph.GraphedTrainStep, pad_to_pixels: one graph '
+                         'per batch geometry although the surface count of every batch differs)')
     ap.add_argument('--occ-precision', choices=('fp32', 'bf16x6'), default='fp32',
                     help="gradient-free occupancy queries of shape_extract (ray march sweep, shadow rays): 'bf16x6' = the opt-in "
                          'split-bf16 engine; the hand-off is then ALSO extracted with the exact engine and compared')
@@ -189,6 +192,10 @@ def main():
     ds = handoff.ViewSampler(views, images, omasks, lights, poses, K[0], light_bs=args.light_bs, n_pixels=args.pixels)
     switch = args.s2_steps // 2
     step.cur_iter = 0
+    runner = step
+    if args.graph:
+        from psnerf_amd.stage2.graph import GraphedTrainStep
+        runner = GraphedTrainStep(step, warmup=2, pad_to_pixels=True)
     s2_losses, phases = [], []
     t0 = time.time()
     for it in range(args.s2_steps):
@@ -197,7 +204,7 @@ def main():
         vidx, mi, gt, l_slt = ds.batch(it % args.views, device=dev)
         if step.dp.enabled:
             mi, gt = step.dp.shard_stage2(mi, gt)
-        terms, _ = step.step(mi, gt, l_slt, train_order=True, vidx=vidx)
+        terms, _ = runner.step(mi, gt, l_slt, train_order=True, vidx=vidx)
         s2_losses.append(float(terms['total'].detach()))
         phases.append(1 if step.cur_iter <= 5000 else 2)
     torch.cuda.synchronize()
@@ -232,6 +239,7 @@ def main():
             'surface_pixels': n_surf, 'stage1': {'steps': args.s1_steps, 'loss_first': s1_losses[0], 'loss_last': s1_losses[-1],
                                                  'seconds': round(t_s1, 2)},
             'shape_extract_seconds': round(t_extract, 2), 'handoff_dir': out_dir, 'occ_bf16x6': occ_cmp,
+            'stage2_graph': None if not args.graph else {'captures': runner.n_captures, 'replays': runner.n_replays, 'eager_steps': runner.n_eager},
             'stage2': {'steps': args.s2_steps, 'switch_at': switch, 'loss_phase1': [ph1[0], ph1[-1]],
                        'loss_phase2': [ph2[0], ph2[-1]], 'seconds': round(t_s2, 2)},
             'relight': {'envmap': [lh, 2 * lh], 'psnr_fp32': round(p32, 4), 'psnr_bf16': round(p16, 4),
