@@ -95,11 +95,12 @@ class DataParallel(object):
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         return c
 
-    def masked_count_tensor(self, mask_a, mask_b):
-        """global_count_tensor(mask_a & mask_b) with the local count formed by ONE launch (psn_mask_count) on device masks."""
+    def masked_count_tensor(self, mask_a, mask_b, out=None):
+        """global_count_tensor(mask_a & mask_b) with the local count formed by ONE launch (psn_mask_count) on device masks;
+        ``out``: a float32 device tensor [1] that receives it (the count buffer of a captured graph)."""
         if mask_a.is_cuda and mask_a.dtype == torch.bool and mask_b.dtype == torch.bool:
             from . import hip
-            c = hip.mask_count(mask_a.contiguous(), mask_b.contiguous())
+            c = hip.mask_count(mask_a.contiguous(), mask_b.contiguous(), out=out)
             if self.enabled:
                 dist.all_reduce(c, op=dist.ReduceOp.SUM)
             return c

@@ -374,12 +374,14 @@ def copy2d_group(pairs):
         _check(_lib.psn_copy2d_group(len(chunk), ctypes.addressof(arr), _stream()), 'copy2d_group')
 
 
-def mask_count(mask_a, mask_b=None):
+def mask_count(mask_a, mask_b=None, out=None):
     """Number of elements with mask_a & mask_b (torch.bool tensors of one size) -> float32 device tensor [1], one launch."""
     assert mask_a.is_cuda and mask_a.dtype == torch.bool and mask_a.is_contiguous()
     if mask_b is not None:
         assert mask_b.is_cuda and mask_b.dtype == torch.bool and mask_b.is_contiguous() and mask_b.numel() == mask_a.numel()
-    out = torch.empty(1, device=mask_a.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(1, device=mask_a.device, dtype=torch.float32)
+    assert out.is_cuda and out.dtype == torch.float32 and out.numel() == 1
     _check(_lib.psn_mask_count(mask_a.data_ptr(), None if mask_b is None else mask_b.data_ptr(), mask_a.numel(), out.data_ptr(), _stream()),
            'mask_count')
     return out

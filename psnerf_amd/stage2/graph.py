@@ -223,7 +223,7 @@ class GraphedTrainStep(object):
         st = self.step_obj
         if st.dp.enabled:
             # the masked-pixel count of the global batch: formed and all-reduced outside the graph (a collective is not captured)
-            cap.count.copy_(st.dp.masked_count_tensor(cap.inp['surface_mask'], cap.inp['object_mask']))
+            st.dp.masked_count_tensor(cap.inp['surface_mask'], cap.inp['object_mask'], out=cap.count)  # counted and all-reduced in place
             cap.graphs[0].replay()
             st.dp.allreduce_bucket(cap.trainable)
             cap.graphs[1].replay()
