@@ -235,7 +235,9 @@ def _iptr(t, name, allow_none=False):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of the current stream of the current device: torch.cuda.current_stream().cuda_stream builds a Stream object
+    # through three Python layers (11 us; a step asks 30 - 65 times), the two C calls below take ~1 us
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def version():
@@ -835,7 +837,8 @@ def root_find(desc, packed_w, packed_b, origin, direction, bracket, tau, n_iter,
 def workspace(n_floats, device):
     """Scratch buffer per (device, stream), grown on demand: launches on one stream are ordered, so they may share it;
     two streams (the small stage-2 networks run beside the visibility launch on a side stream) must not."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    di = device.index if device.index is not None else torch._C._cuda_getDevice()
+    key = (di, torch._C._cuda_getCurrentRawStream(di))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < n_floats:
         buf = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)
@@ -885,20 +888,21 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, epi=EPI_NONE, aux_in=Non
     return out
 
 
+def _tn_aligned(t):
+    return t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(0) >= 4)
+
+
 def _tn_is_big(it):
     """Products that psn_gemm_tn_grouped sends to its one-256x256-tile-per-workgroup kernel."""
-    def ok(t):
-        return t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(0) >= 4)
     return (not it.get('b_div') and not it.get('b_mod') and 128 < it['A'].shape[1] <= 256 and 128 < it['B'].shape[1] <= 256
-            and all(ok(it.get(k)) for k in ('A', 'B', 'A2', 'B2')))
+            and _tn_aligned(it['A']) and _tn_aligned(it['B']) and _tn_aligned(it.get('A2')) and _tn_aligned(it.get('B2')))
 
 
 def _tn_is_tall(it):
     """Products that psn_gemm_tn_grouped sends to its 256 x (<= 64)-tile kernel (input-block gradients)."""
-    def ok(t):
-        return t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(0) >= 4)
     return (not it.get('b_div') and not it.get('b_mod') and 128 < it['A'].shape[1] <= 256 and it['B'].shape[1] <= 64
-            and it.get('B_tab2') is None and all(ok(it.get(k)) for k in ('A', 'B', 'A2', 'B2')))
+            and it.get('B_tab2') is None
+            and _tn_aligned(it['A']) and _tn_aligned(it['B']) and _tn_aligned(it.get('A2')) and _tn_aligned(it.get('B2')))
 
 
 def gemm_tn_grouped(items, split_k=None):
@@ -910,10 +914,12 @@ def gemm_tn_grouped(items, split_k=None):
     res = []
     K = items[0]['A'].shape[0]
     dev = items[0]['A'].device
+    # which kernel of psn_gemm_tn_grouped a product goes to: decided ONCE per item (the predicates were evaluated four times each)
+    kinds = {id(it): ('big' if _tn_is_big(it) else ('tall' if _tn_is_tall(it) else 'tile')) for it in items}
     if split_k is None:
         work = 0
         for it in items:
-            if not _tn_is_big(it) and not _tn_is_tall(it):
+            if kinds[id(it)] == 'tile':
                 tiles = ((it['A'].shape[1] + 127) // 128) * ((it['B'].shape[1] + 127) // 128)
                 work += tiles * (2 if it.get('A2') is not None else 1)
         want = max(1, (1024 + work - 1) // max(work, 1))
@@ -928,7 +934,7 @@ def gemm_tn_grouped(items, split_k=None):
         need = 0
         keep = []
         # slices per product of the one-tile-per-workgroup path (mirrors psn_gemm_tn_grouped, which re-checks the size)
-        is_big = _tn_is_big
+        is_big = lambda it_: kinds[id(it_)] == 'big'
         n_big = sum((2 if it.get('A2') is not None else 1) for it in chunk if is_big(it))
         split_big = 1
         if n_big:
@@ -936,7 +942,7 @@ def gemm_tn_grouped(items, split_k=None):
             kc = -(-K // want)
             kc = (kc + 15) // 16 * 16  # (the kernel rounds its K chunk to 32-row k-tiles: never more slices than this bound)
             split_big = -(-K // kc)
-        n_tall = sum((2 if it.get('A2') is not None else 1) for it in chunk if _tn_is_tall(it))
+        n_tall = sum((2 if it.get('A2') is not None else 1) for it in chunk if kinds[id(it)] == 'tall')
         split_tall = 1
         if n_tall:
             want = max(1, min(256 // n_tall, K // 256 if K >= 256 else 1))
@@ -976,7 +982,7 @@ def gemm_tn_grouped(items, split_k=None):
                 e.b2_div, e.b2_mod, e.b_split = int(it['b2_div']), int(it.get('b2_mod', Bt2.shape[0])), B.shape[1]
             e.colsum_a = None if cs is None else cs.data_ptr()
             e.k_rows = 0 if A.shape[0] == K else A.shape[0]
-            sk = max(split_k, split_big) if is_big(it) else (max(split_k, split_tall) if _tn_is_tall(it) else split_k)
+            sk = max(split_k, split_big) if is_big(it) else (max(split_k, split_tall) if kinds[id(it)] == 'tall' else split_k)
             need += (2 if A2 is not None else 1) * sk * M * N + sk * M + 16
             keep.append((C, cs))
         ws = workspace(need, dev)

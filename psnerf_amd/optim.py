@@ -266,15 +266,22 @@ class FlatAdam(torch.optim.Optimizer):
             g = p.grad
             if g is None or g.is_sparse or g.dtype != torch.float32 or not g.is_cuda:
                 continue
-            if _known_flat_base(g) is not None:
+            if g._base is not None and _known_flat_base(g) is not None:
                 continue  # already a view of a flat buffer (this one, or the data-parallel bucket)
-            loose.append(p)
+            loose.append(p)  # (a tensor autograd handed over has no base: no registry lookup)
         if not loose:
             return
         if f.get('g') is None:
             f['g'] = torch.zeros_like(f['p'])
+            f['gview'] = {}
             register_flat_buffer(f['g'])
-        views = [f['g'][f['off'][p]:f['off'][p] + p.numel()].view_as(p) for p in loose]
+        gv = f['gview']
+        views = []
+        for p in loose:  # the view of a parameter's slot is made once, not once per step
+            v = gv.get(p)
+            if v is None:
+                v = gv[p] = f['g'][f['off'][p]:f['off'][p] + p.numel()].view_as(p)
+            views.append(v)
         torch._foreach_copy_(views, [p.grad for p in loose])
         for p, v in zip(loose, views):
             p.grad = v
@@ -324,7 +331,10 @@ class FlatAdam(torch.optim.Optimizer):
                 t = int(st['step'])
                 neg_step, bc2s = -(lr / (1 - b1 ** t)), math.sqrt(1 - b2 ** t)
                 g = p.grad
-                base = _known_flat_base(g) if flat_ok else None
+                if flat_ok and self._flat.get('gview') is not None and self._flat['gview'].get(p) is g:
+                    base = self._flat['g']  # this optimiser's own slot view (set by _gather_grads): no registry lookup
+                else:
+                    base = _known_flat_base(g) if flat_ok else None
                 if base is not None and (gbuf is None or (base.data_ptr() == gbuf.data_ptr() and base.numel() == gbuf.numel())):
                     # the gradient is a view of ONE flat allocation (attach_grads, or the data-parallel bucket): a range of the launch
                     gbuf = base

@@ -210,7 +210,9 @@ class PSNetwork(nn.Module):
         change neither the version counters nor the storage addresses the caches are keyed on).  trainable_only: keep the
         packs of networks without a trainable parameter (what TrainStep calls after every optimiser step: a fused
         optimiser implementation does not bump version counters either)."""
-        mlps = [m for m in self.modules() if isinstance(m, MLP)]
+        mlps = self.__dict__.get('_mlp_list')
+        if mlps is None:  # (the module tree is fixed after construction: walked once, not once per optimiser step)
+            mlps = self.__dict__['_mlp_list'] = [m for m in self.modules() if isinstance(m, MLP)]
         live = [m for m in mlps if not trainable_only or any(q.requires_grad for q in m.parameters())]
         if live:
             self._pack_epoch = getattr(self, '_pack_epoch', 0) + 1  # (the model-level epoch keys the visibility packs)
