@@ -282,9 +282,12 @@ def time_steps(fn, steps, warmup, world, device):
     return float(t[0]) / steps * 1e3, float(t[1]) / steps * 1e3
 
 
-def cfg4_case(device, dp, px_global, rank, world, steps, modes=('eager', 'graph')):
+def cfg4_case(device, dp, px_global, rank, world, steps, modes=('eager', 'graph', 'graph_fresh_batches')):
     """One stage-2 step of cfg 3's batch of ``px_global`` pixels sharded over the ranks of ``dp``: ms/step (max over ranks)
-    and host issue time, eagerly and replayed from HIP graphs (fresh TrainStep each: same weights, same batch)."""
+    and host issue time, eagerly and replayed from HIP graphs (fresh TrainStep each: same weights, same batch).
+    'graph_fresh_batches': what a training loop sees -- a DIFFERENT batch every step (four batches with different surface masks
+    and counts, cycled; the reference's dictionary without an index list), copied into the graph's input buffers, the surface
+    list built on the device and padded to the pixel count (GraphedTrainStep(pad_to_pixels=True): one graph, no host sync)."""
     import torch
     import torch.distributed as dist
     from psnerf_amd.synthetic import stage2_inputs
@@ -297,17 +300,38 @@ def cfg4_case(device, dp, px_global, rank, world, steps, modes=('eager', 'graph'
     if world > 1:
         dist.all_reduce(ns, op=dist.ReduceOp.SUM)
     out = {'pixels_per_gpu': inp['uv'].shape[1], 'surface_pixels_total': int(ns.item())}
+
+    def agree(ok):  # every rank replays, or none does (a rank whose capture failed would leave the others in a collective)
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
     for mode in modes:
         step = make_step(device, dp=dp)
+        ns_mode = out['surface_pixels_total']
         if mode == 'eager':
             fn = lambda: step.step(inp, gt, l_slt, train_order=False)
+        elif mode == 'graph_fresh_batches':
+            batches = []
+            for k in range(4):
+                bi, bg = stage2_inputs(px_global, N_LIGHTS, N_VIS, seed=101 + k, device=device, surface_frac=0.86 + 0.02 * k)
+                if world > 1:
+                    bi, bg = dp.shard_stage2(bi, bg)
+                batches.append((bi, bg))
+            nsf = torch.tensor([sum(int(b[0]['surface_mask'].sum()) for b in batches)], device=device, dtype=torch.int64)
+            if world > 1:
+                dist.all_reduce(nsf, op=dist.ReduceOp.SUM)
+            ns_mode = int(nsf.item()) / 4.0  # (mean surface count of the cycled batches, whole job)
+            run = GraphedTrainStep(step, pad_to_pixels=True, agree=agree)
+            it = [0]
+
+            def fn():
+                bi, bg = batches[it[0] % 4]
+                it[0] += 1
+                return run.step(bi, bg, l_slt, train_order=False)
         else:
-            def agree(ok):  # every rank replays, or none does (a rank whose capture failed would leave the others in a collective)
-                if world == 1:
-                    return ok
-                t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                return bool(int(t.item()))
             run = GraphedTrainStep(step, adopt_inputs=True, agree=agree)
             fn = lambda: run.step(inp, gt, l_slt, train_order=False)
         try:
@@ -317,7 +341,9 @@ def cfg4_case(device, dp, px_global, rank, world, steps, modes=('eager', 'graph'
             continue
         torch.cuda.synchronize()
         out[mode] = {'ms_per_step': round(ms, 3), 'host_issue_ms': round(host_ms, 3),
-                     'value': round(out['surface_pixels_total'] * N_LIGHTS / (ms * 1e-3), 1)}
+                     'value': round(ns_mode * N_LIGHTS / (ms * 1e-3), 1)}
+        if mode == 'graph_fresh_batches':
+            out[mode]['mean_surface_pixels_total'] = ns_mode
         del step, fn
     return out
 
@@ -350,6 +376,7 @@ def strong_cfg4(device, dp, rank, world, steps=40):
                 c = cfg4_case(device, dpf, N_PIXELS // n, rank, world, steps)
                 bm = min((m for m in ('eager', 'graph') if 'ms_per_step' in c[m]), key=lambda m: c[m]['ms_per_step'])
                 proj[str(n)] = {'pixels_per_rank': N_PIXELS // n, 'eager_ms': c['eager'].get('ms_per_step'), 'graph_ms': c['graph'].get('ms_per_step'),
+                                'graph_fresh_batches_ms': c['graph_fresh_batches'].get('ms_per_step'),
                                 'eager_host_issue_ms': c['eager'].get('host_issue_ms'), 'graph_host_issue_ms': c['graph'].get('host_issue_ms'),
                                 'projected_speedup_vs_1': round(res['ms_per_step'] / c[bm]['ms_per_step'], 3),
                                 'fraction_of_linear': round(res['ms_per_step'] / c[bm]['ms_per_step'] / n, 3)}

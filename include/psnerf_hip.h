@@ -259,6 +259,18 @@ int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* pa
                   const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
                   const float* act_init, int64_t act_init_rows, const float* rk_coef, const float* rk_basis, int rk_k,
                   const uint32_t* dump_tiles, int64_t n_rows, float* out, void* stream);
+/* psn_mlp_infer (plain forward: no chain operands) over a PADDED row set -- the stage-2 visibility rows of
+ * stage2/model/renderer.py:191-200 when the surface-pixel list has a fixed capacity (psn_surface_index: one captured HIP graph
+ * serves batches with different surface counts).  The rows [0, save_row0) come in groups of live_period rows (one group per
+ * shading light; live_period a multiple of 64, save_row0 a multiple of live_period), of which the first live_count[0] -- a
+ * float ON THE DEVICE, psn_surface_index's count -- are real.  64-row blocks that hold padding only are not evaluated: their
+ * outputs are zeros.  Every other row is evaluated exactly as by psn_mlp_infer (bit-identical), the rows from save_row0 on
+ * (the supervision rows, whose dumps a backward pass reads) all of them.  The grid enumerates the evaluated blocks first, so
+ * that the skipped ones do not unbalance the XCDs. */
+int psn_mlp_infer_padded(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
+                         int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
+                         const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
+                         int64_t n_rows, float* out, const float* live_count, int64_t live_period, void* stream);
 
 /* Dense per-pixel outputs of the stage-2 model, stage2/model/renderer.py:145-152,204-264: dense [B, N, C] = fill
  * everywhere except dense[b, idx[r], c] = rows[(b Ns + r) row_stride + c col_stride] (light-major surface rows;

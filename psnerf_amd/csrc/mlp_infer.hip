@@ -78,6 +78,11 @@ struct InferArgs {
     int n_steps;
     int* skip;               // [n_rays] or nullptr: INT_MAX - b = block b of this ray holds a sign change (the lowest such b wins), 0 = none
     unsigned long long* n_blocks;  // optional: counts the 64-step blocks that were evaluated (measurement only)
+    // SRC == 0, lean variant, optional (psn_mlp_infer_padded): the rows in front of save_row0 come in groups of live_period
+    // (one group per light), of which only the first live_count[0] (a device-side float: psn_surface_index's count) are real;
+    // the all-padding 64-row blocks are not evaluated (zeros)
+    const float* live_count;
+    int64_t live_period;
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -358,7 +363,35 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: keeps the LDS-DMA bases in SGPRs
     const int lj = lane & 15, lg = lane >> 4;
-    int64_t row_ = (int64_t)blockIdx.x * (kWaves * 16) + wave * 16 + lj;
+    int64_t blk_ = (int64_t)blockIdx.x;
+    if constexpr (SRC == 0 && !CHAIN) {
+        // psn_mlp_infer_padded: the rows [0, save_row0) are groups of live_period rows (64 | live_period, 64 | save_row0) of which
+        // the first live_count[0] are real.  The hardware hands workgroup i to XCD i % 8, and the all-padding blocks sit at the END
+        // of every group: skipped where they stand they all fall on the same XCDs while the others carry the full work (measured:
+        // the launch no faster than without the skip).  So the grid enumerates the REAL blocks first, in their order -- workgroup i
+        // is real block i % rb of group i / rb, then come the blocks behind save_row0 -- and the surplus workgroups at the END of
+        // the grid, one per all-padding block, write that block's zeros and leave.
+        if (g.live_count != nullptr) {
+            const int64_t bpg = g.live_period / (kWaves * 16), groups = g.save_row0 / g.live_period;
+            int64_t rb = ((int64_t)*g.live_count + kWaves * 16 - 1) / (kWaves * 16);
+            rb = rb < bpg ? rb : bpg;
+            const int64_t real = groups * rb, tail = (g.n_rows - g.save_row0 + kWaves * 16 - 1) / (kWaves * 16);
+            if (blk_ < real) {
+                blk_ = (blk_ / rb) * bpg + blk_ % rb;
+            } else if (blk_ < real + tail) {
+                blk_ = groups * bpg + (blk_ - real);
+            } else {
+                const int64_t s_ = blk_ - real - tail, db = bpg - rb;  // all-padding block s_ % db of group s_ / db
+                if (db > 0 && s_ < groups * db) {
+                    const int64_t r0 = ((s_ / db) * bpg + rb + s_ % db) * (kWaves * 16);
+                    const int n_out = g.d.n_out;
+                    for (int i = tid; i < kWaves * 16 * n_out; i += kWaves * 64) g.out[r0 * n_out + i] = 0.0f;
+                }
+                return;  // (uniform, before any barrier or LDS-DMA request)
+            }
+        }
+    }
+    int64_t row_ = blk_ * (kWaves * 16) + wave * 16 + lj;
     int64_t m_ray = 0;  // SRC == 3: this workgroup's ray and the step of this lane's row
     int m_step = 0;
     if constexpr (SRC == 3) {
@@ -1074,12 +1107,13 @@ extern "C" int psn_mlp_pack_layer(const float* W, int64_t ldw, int rows, int col
     return PSN_OK;
 }
 
-extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
-                             int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
-                             const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
-                             const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
-                             const float* act_init, int64_t act_init_rows, const float* rk_coef, const float* rk_basis, int rk_k,
-                             const uint32_t* dump_tiles, int64_t n_rows, float* out, void* stream) {
+static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
+                          int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
+                          const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
+                          const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
+                          const float* act_init, int64_t act_init_rows, const float* rk_coef, const float* rk_basis, int rk_k,
+                          const uint32_t* dump_tiles, int64_t n_rows, float* out, const float* live_count, int64_t live_period,
+                          void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(desc && packed_w && packed_b && (out || desc->n_out == 0), "mlp_infer: null pointer");
     const PsnMlpDesc& d = *desc;
@@ -1118,7 +1152,7 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
         PSN_CHECK_ARG((L.w_off % 4) == 0 && (L.b_off % 4) == 0, "mlp_infer: layer %d offsets must be multiples of 4 floats", l);
     }
     if (n_rows <= 0) return PSN_OK;
-    InferArgs a;
+    InferArgs a = {};
     a.d = d; a.w = packed_w; a.b = packed_b; a.ta = tab_a; a.a_div = a_div; a.a_mod = a_mod;
     a.tb = tab_b; a.b_div = b_div > 0 ? b_div : 1; a.b_mod = b_mod > 0 ? b_mod : 1; a.n_rows = n_rows; a.out = out;
     a.init_a = init_a; a.init_b = init_b;
@@ -1161,6 +1195,11 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     for (int l = 0; l < d.n_layers; ++l)
         chain = chain || d.layers[l].act > PSN_ACT_SOFTPLUS100 || a.save2[l] != nullptr || a.mask[l] != nullptr || a.aux2[l] != nullptr;
     PSN_CHECK_ARG(d.n_out <= 32 || (chain && hid == 8), "mlp_infer: 33..64 outputs are built for the 256-wide chain engine only (n_out=%d)", d.n_out);
+    PSN_CHECK_ARG(live_count == nullptr || (!chain && d.n_out >= 1 && live_period >= 64 && live_period % 64 == 0 && save_row0 >= 0 &&
+                                            save_row0 % live_period == 0 && save_row0 <= n_rows),
+                  "mlp_infer_padded: needs the lean variant, outputs, a period that is a multiple of 64 and save_row0 a multiple of the period (period=%lld save_row0=%lld)",
+                  (long long)live_period, (long long)save_row0);
+    a.live_count = live_count; a.live_period = live_period > 0 ? live_period : 1;
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
     const dim3 grid((unsigned)blocks), block(kWaves * 64);
     hipStream_t st = (hipStream_t)stream;
@@ -1182,6 +1221,31 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
     }
     PSN_CHECK_LAUNCH("mlp_infer");
     return PSN_OK;
+}
+
+extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
+                             int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
+                             const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
+                             const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
+                             const float* act_init, int64_t act_init_rows, const float* rk_coef, const float* rk_basis, int rk_k,
+                             const uint32_t* dump_tiles, int64_t n_rows, float* out, void* stream) {
+    return mlp_infer_impl(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, init_a, init_b, save_ptrs, save_row0,
+                          mask_ptrs, aux2_ptrs, save2_ptrs, act_init, act_init_rows, rk_coef, rk_basis, rk_k, dump_tiles, n_rows, out,
+                          nullptr, 0, stream);
+}
+
+// psn_mlp_infer (lean variant: no chain operands) over a PADDED row set: the rows [0, save_row0) come in groups of
+// live_period rows (stage 2: one group per shading light over a surface-pixel list padded to a fixed capacity, so that one
+// captured HIP graph serves batches with different surface counts), of which the first live_count[0] -- a float on the
+// device, psn_surface_index's count -- are real.  Workgroups all of whose 64 rows are padding write zeros and leave; every
+// other row is evaluated as by psn_mlp_infer (bit-identical), the rows from save_row0 on all of them.
+extern "C" int psn_mlp_infer_padded(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
+                                    int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
+                                    const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
+                                    int64_t n_rows, float* out, const float* live_count, int64_t live_period, void* stream) {
+    PSN_CHECK_ARG(live_count != nullptr, "mlp_infer_padded: live_count is null");
+    return mlp_infer_impl(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, init_a, init_b, save_ptrs, save_row0,
+                          nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, n_rows, out, live_count, live_period, stream);
 }
 
 // Lean evaluation of a 256-wide network whose input block is the positional encoding of a 3-vector (the stage-1 occupancy

@@ -41,7 +41,7 @@ class PackedMLP(object):
 
     def __call__(self, tab_a, n_rows, a_div=1, a_mod=None, tab_b=None, b_div=1, b_mod=1, out=None, save=None,
                  save_row0=0, mask=None, init_a_direct=None, aux2=None, save2=None, act_init=None, rank_init=None,
-                 save_tiles=None, save2_tiles=None, act_init_rows=None):
+                 save_tiles=None, save2_tiles=None, act_init_rows=None, live=None):
         if a_mod is None:
             a_mod = tab_a.shape[0] if tab_a is not None else n_rows
         init_a = init_b = None
@@ -61,7 +61,7 @@ class PackedMLP(object):
                              tab_b if uses_in else None, b_div, b_mod, n_rows, out=out, init_a=init_a, init_b=init_b,
                              save=save, save_row0=save_row0, mask=mask, aux2=aux2, save2=save2, act_init=act_init,
                              macs_per_row=self.macs_per_row, rank_init=rank_init, save_tiles=save_tiles, save2_tiles=save2_tiles,
-                             act_init_rows=act_init_rows)
+                             act_init_rows=act_init_rows, live=live)
 
 
 def _pad_cols(w, n):

@@ -122,6 +122,8 @@ SIGNATURES = {
                             ctypes.POINTER(ctypes.c_void_p), i64, ctypes.POINTER(ctypes.c_void_p),
                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f, i64, c_f, c_f, i32,
                             ctypes.POINTER(ctypes.c_uint32), i64, c_f, c_f]),
+    'psn_mlp_infer_padded': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
+                                   ctypes.POINTER(ctypes.c_void_p), i64, i64, c_f, c_f, i64, c_f]),
     'psn_scatter_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_gather_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_gather_rows_valid': (i32, [i32, ctypes.c_void_p, c_f, c_f, i64, i64, c_f]),
@@ -836,14 +838,31 @@ def root_find(desc, packed_w, packed_b, origin, direction, bracket, tau, n_iter,
 
 def workspace(n_floats, device):
     """Scratch buffer per (device, stream), grown on demand: launches on one stream are ordered, so they may share it;
-    two streams (the small stage-2 networks run beside the visibility launch on a side stream) must not."""
+    two streams (the small stage-2 networks run beside the visibility launch on a side stream) must not.  A buffer that a
+    HIP-graph capture has used (``capturing(True)`` ... ``capturing(False)`` around the capture: stage2/graph.py) is never
+    freed when a larger one replaces it -- the captured launches hold its address."""
     di = device.index if device.index is not None else torch._C._cuda_getDevice()
     key = (di, torch._C._cuda_getCurrentRawStream(di))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < n_floats:
+        if buf is not None and key in _ws_pinned:
+            _ws_retired.append(buf)
+            _ws_pinned.discard(key)
         buf = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)
         _ws_cache[key] = buf
+    if _ws_capturing[0]:
+        _ws_pinned.add(key)
     return buf
+
+
+_ws_capturing = [False]
+_ws_pinned = set()
+_ws_retired = []
+
+
+def capturing(on):
+    """Tell the binding that the launches issued from now on are being captured into a HIP graph (or no longer are)."""
+    _ws_capturing[0] = bool(on)
 
 
 def _ld(t):
@@ -1040,11 +1059,13 @@ def mlp_pack_layers(plan):
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
               init_b=None, save=None, save_row0=0, mask=None, aux2=None, save2=None, act_init=None, macs_per_row=None,
-              rank_init=None, save_tiles=None, save2_tiles=None, act_init_rows=None):
+              rank_init=None, save_tiles=None, save2_tiles=None, act_init_rows=None, live=None):
     """save: list (one entry per hidden layer, None allowed) of [n_rows - save_row0, 256] tensors that receive the
     post-activation outputs of the rows >= save_row0.
     rank_init = (coef [n_rows, k], basis [k, init_stride]), k <= 4: rank-k init of the layers with init_off >= 0.
-    act_init [act_init_rows (default n_rows), width]: initial activations; the rows behind them start from zeros."""
+    act_init [act_init_rows (default n_rows), width]: initial activations; the rows behind them start from zeros.
+    live = (count float32 [1] on the device, period): the rows [0, save_row0) are groups of `period` rows of which the first
+    count[0] are real (psn_mlp_infer_padded; plain forward launches only): all-padding workgroups write zeros and leave."""
     tiles_arr = None
     if save_tiles is not None or save2_tiles is not None:  # per layer: bit mt = the 16-column tile mt of the dump is written
         tiles_arr = (ctypes.c_uint32 * (2 * MAX_LAYERS))(*([0xFFFFFFFF] * (2 * MAX_LAYERS)))
@@ -1083,6 +1104,17 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
     # 'mlp_infer' = the lean engine, 'mlp_chain' = the chain engine (same dispatch rule as psn_mlp_infer)
     chain = act_init is not None or rank_init is not None or tiles_arr is not None or mask is not None or aux2 is not None or save2 is not None or any(
         desc.layers[l].act > ACT_SOFTPLUS100 for l in range(desc.n_layers))
+    if live is not None:
+        cnt, period = live
+        if chain:
+            raise RuntimeError('mlp_infer: a device-side live count is for plain forward launches (no chain operands)')
+        assert cnt.is_cuda and cnt.dtype == torch.float32 and cnt.numel() == 1 and int(period) >= 1
+        with _Prof('mlp_infer', n_rows, None if macs_per_row is None else 2.0 * macs_per_row * n_rows):
+            _check(_lib.psn_mlp_infer_padded(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
+                                             _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,
+                                             _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), save_arr, save_row0, n_rows,
+                                             _ptr(out, 'out', True), cnt.data_ptr(), int(period), _stream()), 'mlp_infer_padded')
+        return out
     with _Prof('mlp_chain' if chain else 'mlp_infer', n_rows, None if macs_per_row is None else 2.0 * macs_per_row * n_rows):
         _check(_lib.psn_mlp_infer(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
                                   _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,

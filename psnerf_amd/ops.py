@@ -597,11 +597,14 @@ class VisibilityPair(torch.autograd.Function):
     train.light_vis_detach), n_shade = L, in_cols, skip_at, then W0, b0, ...  Returns (vis [L*Ns,1], vis_t [V*Ns,1])."""
 
     @staticmethod
-    def launch(pe_x, pe_l, n_shade, in_cols, skip_at, params, need_grad, packed=None):
+    def launch(pe_x, pe_l, n_shade, in_cols, skip_at, params, need_grad, packed=None, live_count=None):
         """The fused launch itself, separable from the autograd node: the renderer issues it at the very start of
         the forward pass (it is 60 % of the step and depends on nothing but points and lights) and attaches the
         node later with ``apply(..., pre, *params)``, so that the node keeps a LATE position in the graph and its
-        (large) backward kernels are queued first, ahead of the many small launches of the other networks."""
+        (large) backward kernels are queued first, ahead of the many small launches of the other networks.
+        live_count (float32 [1] on the device): pe_x is a surface list padded to a fixed capacity of which the first
+        live_count[0] rows are real -- the workgroups of the gradient-free shading rows that hold padding only leave early
+        (psn_mlp_infer_padded; their outputs are zeros, which nothing reads: ops.ScatterRows drops the padding rows)."""
         Ws, bs = params[0::2], params[1::2]
         Ns, LV = pe_x.shape[0], pe_l.shape[0]
         V = LV - n_shade
@@ -611,7 +614,8 @@ class VisibilityPair(torch.autograd.Function):
             if packed is None:
                 packed = fused.pack_relu_mlp(list(Ws), list(bs), din_half, din_half, skip_at)
             save = [torch.empty(V * Ns, 256, device=pe_x.device) for _ in range(n - 1)] if (need_grad and V > 0) else None
-            out = packed(pe_x, LV * Ns, a_div=1, a_mod=Ns, tab_b=pe_l, b_div=Ns, b_mod=LV, save=save, save_row0=n_shade * Ns)
+            out = packed(pe_x, LV * Ns, a_div=1, a_mod=Ns, tab_b=pe_l, b_div=Ns, b_mod=LV, save=save, save_row0=n_shade * Ns,
+                         live=None if (live_count is None or Ns % 64 != 0) else (live_count, Ns))  # (64-row blocks must not straddle groups)
         return out, save
 
     @staticmethod

@@ -41,7 +41,10 @@ class _Captured(object):
 
 
 class GraphedTrainStep(object):
-    def __init__(self, step, warmup=2, max_graphs=8, overlap_small_nets=None, adopt_inputs=False, agree=None, pad_to_pixels=False):
+    SKIP_PADDING = True  # pad_to_pixels: hand the device-side surface count to the model (False: the padding rows are evaluated; A/B)
+
+    def __init__(self, step, warmup=2, max_graphs=8, overlap_small_nets=None, adopt_inputs=False, agree=None, pad_to_pixels=False,
+                 pad_multiple=0):
         """``overlap_small_nets``: None keeps the model's setting; False captures a single-stream graph (0.04 ms of host
         time per replay instead of ~2.5 ms, at the price of the side-stream overlap).  ``adopt_inputs``: the tensors of the
         batch that is captured BECOME the graph's input buffers (no clones): for a caller that keeps refilling the same
@@ -52,9 +55,14 @@ class GraphedTrainStep(object):
         every rank replays or every rank raises.  ``pad_to_pixels``: the surface-pixel list of every batch is built ON THE DEVICE
         with the fixed length N (psn_surface_index: the real entries, then the last one repeated), so that batches whose surface
         count differs share ONE graph and the step has no host synchronisation even for the reference's dictionary; the dead rows
-        behind the real ones are evaluated and contribute exact zeros (their dense outputs are never written, their gradients
-        are zeroed by psn_gather_rows_valid) -- (N - Ns) / Ns more rows, and split-K sums in a different order than the
-        unpadded step (equal to rounding, not bit for bit)."""
+        behind the real ones contribute exact zeros (their dense outputs are never written, their gradients are zeroed by
+        psn_gather_rows_valid); the gradient-free shading rows among them -- 92 % of the rows of the BEAR step -- are not even
+        evaluated (the visibility launch reads the count on the device, psn_mlp_infer_padded), the others are: (N - Ns) / Ns
+        more rows in the small networks, the supervision rows, shading and losses, and split-K sums in a different order than
+        the unpadded step (equal to rounding, not bit for bit).  An EMPTY mask renders pixel 0 into the dense outputs (losses
+        and gradients are unaffected: they are masked).  ``pad_multiple`` = k > 0: for batches that bring their 'surface_idx'
+        along (handoff.ViewSampler, the benchmark: the count is then known on the HOST), the list is padded to the next
+        multiple of k instead -- at most k - 1 dead rows, one graph per capacity that occurs (``max_graphs``)."""
         assert isinstance(step.sg_optimizer, FlatAdam) and isinstance(step.light_optimizer, RowSparseAdam) and step.FUSED_LOSSES, \
             'GraphedTrainStep needs the device-resident step (FlatAdam, RowSparseAdam, fused losses)'
         self.step_obj, self.warmup, self.max_graphs = step, int(warmup), int(max_graphs)
@@ -66,6 +74,11 @@ class GraphedTrainStep(object):
         self.adopt_inputs = bool(adopt_inputs)
         self.agree = agree
         self.pad_to_pixels = bool(pad_to_pixels)
+        self.pad_multiple = int(pad_multiple)
+        assert not (self.pad_to_pixels and self.pad_multiple), 'pad_to_pixels and pad_multiple exclude each other'
+        # (a data-parallel job captures on every rank at the same step -- `agree` is a collective; capacities that depend on the
+        #  rank's own surface count would let one rank capture while another replays: such jobs pad to the pixel count)
+        assert not (self.pad_multiple and agree is not None), 'pad_multiple is for single-process jobs; data-parallel jobs use pad_to_pixels'
         self.n_replays = self.n_eager = self.n_captures = 0
 
     # ---- signature of a step -------------------------------------------------------------------------------------------
@@ -95,7 +108,19 @@ class GraphedTrainStep(object):
         if self.pad_to_pixels:
             model_input = dict(model_input)
             sm = model_input['surface_mask'][0].contiguous()
-            model_input['surface_idx'] = hip.surface_index(sm, sm.numel())[0]
+            # (the count stays on the device: the visibility launch skips the shading rows of the padding with it)
+            model_input['surface_idx'], cnt = hip.surface_index(sm, sm.numel())
+            if self.SKIP_PADDING:
+                model_input['surface_count'] = cnt
+        elif self.pad_multiple and model_input.get('surface_idx') is not None and model_input['surface_idx'].numel() > 0:
+            idx = model_input['surface_idx']
+            ns, k = idx.numel(), self.pad_multiple
+            cap = -(-ns // k) * k
+            if cap != ns:
+                model_input = dict(model_input)
+                model_input['surface_idx'] = torch.cat([idx, idx[-1:].expand(cap - ns)])
+                if self.SKIP_PADDING:
+                    model_input['surface_count'] = torch.full((1,), float(ns), device=idx.device, dtype=torch.float32)
         if 'surface_idx' not in model_input:
             # the reference's dictionary (no index list of the surface pixels): built here, OUTSIDE the graph -- nonzero() is a
             # host synchronisation and cannot be captured; its length is part of the graph's signature
@@ -185,16 +210,20 @@ class GraphedTrainStep(object):
         # capture_error_mode 'thread_local': other threads of the process (RCCL's watchdog and proxy threads, pinned-memory
         # loaders) keep calling HIP while this thread captures; in the default 'global' mode any such call invalidates the capture
         g_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_a, stream=self.stream, capture_error_mode='thread_local'):
-            cap.terms, cap.out, cap.trainable, cap.train_light = st._fwd_bwd(cap.inp, cap.gt, cap.l_slt, noise=cap.noise, count=cap.count)
-            if not st.dp.enabled:
-                st._optimise(cap.l_slt, cap.trainable, cap.train_light)
-        cap.graphs.append(g_a)
-        if st.dp.enabled:
-            g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_b, stream=self.stream, pool=g_a.pool(), capture_error_mode='thread_local'):
-                st._optimise(cap.l_slt, cap.trainable, cap.train_light)
-            cap.graphs.append(g_b)
+        hip.capturing(True)  # (scratch buffers the captured launches use stay alive when a later, larger batch replaces them)
+        try:
+            with torch.cuda.graph(g_a, stream=self.stream, capture_error_mode='thread_local'):
+                cap.terms, cap.out, cap.trainable, cap.train_light = st._fwd_bwd(cap.inp, cap.gt, cap.l_slt, noise=cap.noise, count=cap.count)
+                if not st.dp.enabled:
+                    st._optimise(cap.l_slt, cap.trainable, cap.train_light)
+            cap.graphs.append(g_a)
+            if st.dp.enabled:
+                g_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_b, stream=self.stream, pool=g_a.pool(), capture_error_mode='thread_local'):
+                    st._optimise(cap.l_slt, cap.trainable, cap.train_light)
+                cap.graphs.append(g_b)
+        finally:
+            hip.capturing(False)
         # the optimisers' host halves ran inside the captures (step counts advanced, this step's scalars remembered): send the
         # scalars now, in front of the replay that executes the captured step
         st.sg_optimizer.graph_scalars.flush()

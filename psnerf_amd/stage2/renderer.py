@@ -336,12 +336,13 @@ class PSNetwork(nn.Module):
             self._vis_pack16_key = key
         return self._vis_pack16
 
-    def _visibility_pair_launch(self, pe_x, light_dir, light_vis_train):
-        """Issue the fused launch now, attach the autograd node later (ops.VisibilityPair.launch)."""
+    def _visibility_pair_launch(self, pe_x, light_dir, light_vis_train, live_count=None):
+        """Issue the fused launch now, attach the autograd node later (ops.VisibilityPair.launch).  live_count: the device-side
+        number of real rows of a padded surface list ('surface_count' of the batch)."""
         a = self._visibility_pair_args(pe_x, light_dir, light_vis_train)
         need = any(p.requires_grad for p in a[5])
         return a, ops.VisibilityPair.launch(a[0], a[1], a[2], a[3], a[4], [p.detach() for p in a[5]], need,
-                                            packed=self._visibility_prepack())
+                                            packed=self._visibility_prepack(), live_count=live_count)
 
     def _visibility_pair(self, pe_x, light_dir, light_vis_train, launched=None):
         """(vis [L*Ns,1], vis_train [V*Ns,1]) from one fused launch (ops.VisibilityPair)."""
@@ -417,7 +418,9 @@ class PSNetwork(nn.Module):
                     vis_bf16 = self._visibility_rows_x3(pe_x, pe_l0) if self.train_vis_bf16x6 else self._visibility_rows_bf16(pe_x, pe_l0)
                     vis_pair = self._visibility_pair_launch(pe_x, ld0[:0], lv0)
                 else:
-                    vis_pair = self._visibility_pair_launch(pe_x, ld0, lv0)
+                    # 'surface_count' (float32 [1] on the device, beside a 'surface_idx' padded to a fixed capacity -- hip.surface_index,
+                    # GraphedTrainStep(pad_to_pixels=True)): the gradient-free shading rows of the padding are not evaluated
+                    vis_pair = self._visibility_pair_launch(pe_x, ld0, lv0, live_count=input.get('surface_count'))
         on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
         if self.normal_mlp:  # renderer.py:127-143
             normal_pred = ones3()

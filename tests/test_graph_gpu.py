@@ -137,10 +137,43 @@ def test_surface_index_is_nonzero_padded_with_the_last_entry(cuda, n):
             assert torch.equal(inv, want)
 
 
-def test_padded_surface_list_gives_the_unpadded_step(cuda):
+@pytest.mark.parametrize('ns,live', [(1000, 517), (1024, 0), (1024, 1024), (4096, 3700), (640, 64)])
+def test_padded_visibility_launch_skips_only_padding_workgroups(cuda, ns, live):
+    """psn_mlp_infer_padded through ops.VisibilityPair.launch: with a device-side live count the shading rows (L groups of ns) of
+    workgroups that hold padding only are zeros, every other output and every dump of the supervision rows is bit-identical to
+    the plain launch."""
+    from psnerf_amd import ops
+    L, V = 5, 2
+    g = torch.Generator().manual_seed(ns + live)
+    pe_x = torch.randn(ns, 64, generator=g).to(cuda)
+    pe_l = torch.randn(L + V, 64, generator=g).to(cuda)
+    dims = [(256, 78)] + [(256, 256)] * 2 + [(256, 256 + 78)] + [(256, 256)] + [(1, 256)]
+    params = []
+    for o, i in dims:
+        params += [(torch.randn(o, i, generator=g) / i ** 0.5).to(cuda), (torch.randn(o, generator=g) * 0.1).to(cuda)]
+    c = torch.arange(39)
+    cols = torch.cat([c, 64 + c]).to(cuda)
+    ref, save_ref = ops.VisibilityPair.launch(pe_x, pe_l, L, cols, 2, params, True)
+    cnt = torch.tensor([float(live)], device=cuda)
+    out, save = ops.VisibilityPair.launch(pe_x, pe_l, L, cols, 2, params, True, live_count=cnt)
+    torch.cuda.synchronize()
+    r = torch.arange((L + V) * ns, device=cuda)
+    # a 64-row block of a shading light's group that lies behind the real rows is not evaluated (capacities that are no multiple
+    # of 64 take the plain launch: a block would straddle two lights)
+    dead = (r < L * ns) & (r % ns >= (live + 63) // 64 * 64) if ns % 64 == 0 else torch.zeros_like(r, dtype=torch.bool)
+    assert int(dead.sum()) == (L * (ns - (live + 63) // 64 * 64) if ns % 64 == 0 else 0)
+    assert bool((out[dead] == 0).all())
+    assert torch.equal(out[~dead], ref[~dead])
+    for a, b in zip(save, save_ref):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('with_count', [False, True])
+def test_padded_surface_list_gives_the_unpadded_step(cuda, with_count):
     """A surface-pixel list padded to the pixel count (dead rows = the last surface pixel repeated): the dense outputs of the
     forward are IDENTICAL to the unpadded step's, the losses too, and every gradient agrees to rounding (the dead rows add exact
-    zeros; split-K chunks fall differently)."""
+    zeros; split-K chunks fall differently).  with_count: the batch also carries the device-side surface count, with which the
+    visibility launch leaves the padding's shading rows out (zeros, dropped by the scatter)."""
     from psnerf_amd import hip
     res = {}
     for pad in (False, True):
@@ -149,7 +182,9 @@ def test_padded_surface_list_gives_the_unpadded_step(cuda):
         ns = int(inp['surface_mask'].sum())
         if pad:
             inp = dict(inp)
-            inp['surface_idx'] = hip.surface_index(inp['surface_mask'][0].contiguous(), 3000)[0]
+            inp['surface_idx'], cnt = hip.surface_index(inp['surface_mask'][0].contiguous(), 3000)
+            if with_count:
+                inp['surface_count'] = cnt
             nzp = torch.zeros(3000, 3, device=cuda)
             nzp[:ns] = nz['xyz']
             nz = {'xyz': nzp}
@@ -198,3 +233,36 @@ def test_one_graph_serves_batches_with_different_surface_counts(cuda):
     assert np.isfinite(lg).all()
     rel = np.abs(lg - le) / np.abs(le)
     assert rel[0] <= 1e-6 and rel.max() <= 2e-3, rel  # (one step from a common state: equal; then two fp32 trajectories)
+
+
+def test_pad_multiple_shares_a_graph_per_capacity(cuda):
+    """pad_multiple = 512: batches that bring their surface list along are padded to the next multiple of 512 (the count is known
+    on the host: the list's length); one graph per capacity, every step's loss equal to the eager, unpadded step's."""
+    from psnerf_amd.stage2.graph import GraphedTrainStep
+    N, L, V, n_it = 2560, 10, 4, 9
+    res = {}
+    caps = set()
+    for mode in ('eager', 'graph'):
+        step, NL = _make(cuda, 5001)
+        run = GraphedTrainStep(step, warmup=1, pad_multiple=512) if mode == 'graph' else step
+        losses = []
+        for it in range(n_it):
+            inp, gt = stage2_inputs(N, L, V, seed=500 + it, surface_frac=(0.55, 0.57, 0.75, 0.56, 0.76, 0.58, 0.74, 0.55, 0.77)[it])
+            inp['surface_idx'] = inp['surface_mask'][0].nonzero(as_tuple=True)[0]
+            ns = int(inp['surface_idx'].numel())
+            cap = -(-ns // 512) * 512
+            caps.add(cap)
+            l_slt = torch.randperm(NL, generator=torch.Generator().manual_seed(it))[:L].to(cuda)
+            nz = torch.zeros(cap, 3)
+            nz[:ns] = torch.randn(ns, 3, generator=torch.Generator().manual_seed(50 + it)) * 0.01
+            noise = {'xyz': (nz if mode == 'graph' else nz[:ns]).to(cuda)}
+            terms, _ = run.step({k: v.to(cuda) for k, v in inp.items()}, {k: v.to(cuda) for k, v in gt.items()}, l_slt, train_order=False, noise=noise)
+            losses.append(float(terms['total'].detach()))
+        res[mode] = losses
+        if mode == 'graph':
+            assert len(caps) == 2, caps
+            assert run.n_captures == 2 and run.n_eager == 2 and run.n_replays == n_it - 2, (run.n_captures, run.n_eager, run.n_replays)
+    le, lg = np.array(res['eager']), np.array(res['graph'])
+    assert np.isfinite(lg).all()
+    rel = np.abs(lg - le) / np.abs(le)
+    assert rel[0] <= 1e-6 and rel.max() <= 2e-3, rel
