@@ -419,7 +419,8 @@ int psn_surface_normals_bwd(const float* g, const unsigned char* hit, int64_t N,
 #define PSN_PAIR_SUMS_MAX_CHUNKS 2048
 int psn_pair_sums(const float* x, int V, int64_t Ns, int C, float* sx, float* sl_part, int* n_chunks, void* stream);
 /* The separable input-block weight gradients of the visibility network's backward (stage2/model/renderer.py:191-200, 251-262:
- * input row k = v Ns + n is [table(x_n) | table(l_v)]) for up to PSN_PAIR_GROUP_MAX input layers in two launches.  Per item,
+ * input row k = v Ns + n is [table(x_n) | table(l_v)]) for up to PSN_PAIR_GROUP_MAX input layers in two launches (three when the
+ * per-chunk partial sums are many: their reduction is then sliced over 32 blocks per output tile).  Per item,
  * with x = d z [V, Ns, C]:  sx [Ns, C] = sum_v x (the K = Ns operand of d W_x);  dWl [C, ld_w] (columns < n_pe written) =
  * (sum_n x[v])^T pe_l[v] summed over v, pe_l [V, ld_pe];  bias [C] = sum over v and n of x (NULL: not wanted).
  * workspace: psn_pair_sums_group_workspace(...) floats, 16-byte aligned.  Fixed summation order (deterministic). */

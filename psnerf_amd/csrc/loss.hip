@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void pair_sums_kernel(const float* __restrict_
 // ---- the separable input-block weight gradients of ops.VisibilityPair.backward for ALL input layers in two launches -----------
 // (were, per layer: pair_sums + a torch reduction of its partials + a [C, V] x [V, 64] GEMM, + a bias reduction: 7 launches)
 struct PairGroupArgs { PsnPairSumsItem it[PSN_PAIR_GROUP_MAX]; int V; int64_t Ns; int C; int rows_per_block; int chunks; float* part;
-                       const float* pe_l; int64_t ld_pe; int n_pe; int64_t ld_w; };
+                       const float* pe_l; int64_t ld_pe; int n_pe; int64_t ld_w;
+                       int slices; float* part2; };  // slices > 1: kernel B runs twice (chunk slices -> part2, then part2 -> results)
 // A: as pair_sums_kernel for item blockIdx.y, the four row lanes of a block combined through LDS: part [item][chunk][V][C]
 __global__ __launch_bounds__(256) void pair_group_sums_kernel(PairGroupArgs a) {
     const PsnPairSumsItem it = a.it[blockIdx.y];
@@ -199,17 +200,26 @@ __global__ __launch_bounds__(1024) void pair_group_final_kernel(PairGroupArgs a)
     const int cl = threadIdx.x & 63, v = threadIdx.x >> 6;  // v < 16
     __shared__ float dzl[PSN_PAIR_SUMS_MAX_V][64];
     __shared__ float pel[PSN_PAIR_SUMS_MAX_V][64];
+    // the chunk range of this block: everything, or -- first pass of the sliced form -- slice blockIdx.z of it.  (With one block
+    // per (item, column group) a thread walked ALL chunks: 1843 dependent 4-byte loads at Ns = 29487 -- 268 us on 8 blocks.)
+    int ch = 0, ch_end = a.chunks;
+    if (a.slices > 1) {
+        const int per = (a.chunks + a.slices - 1) / a.slices;
+        ch = blockIdx.z * per;
+        ch_end = min(a.chunks, ch + per);
+    }
     float s = 0.0f;
     if (v < V && c0 + cl < C) {
         const float* p = a.part + ((int64_t)blockIdx.y * a.chunks * V + v) * C + c0 + cl;
         const int64_t step = (int64_t)V * C;
-        int ch = 0;
-        for (; ch + 4 <= a.chunks; ch += 4) {
+        for (; ch + 4 <= ch_end; ch += 4) {
             const float t0 = p[(int64_t)ch * step], t1 = p[(int64_t)(ch + 1) * step], t2 = p[(int64_t)(ch + 2) * step], t3 = p[(int64_t)(ch + 3) * step];
             s += t0; s += t1; s += t2; s += t3;
         }
-        for (; ch < a.chunks; ++ch) s += p[(int64_t)ch * step];
+        for (; ch < ch_end; ++ch) s += p[(int64_t)ch * step];
+        if (a.slices > 1) a.part2[(((int64_t)blockIdx.y * a.slices + blockIdx.z) * V + v) * C + c0 + cl] = s;
     }
+    if (a.slices > 1) return;
     dzl[v][cl] = s;
     pel[v][cl] = (v < V && cl < a.n_pe) ? a.pe_l[(int64_t)v * a.ld_pe + cl] : 0.0f;
     __syncthreads();
@@ -426,11 +436,13 @@ extern "C" int psn_row_adam_dev(int n_items, const PsnRowAdamItem* items, const 
     return row_adam_impl(n_items, items, idx, n_idx, step_sizes_dev, stream);
 }
 
+constexpr int kPairSlices = 32;  // chunk slices of the final reduction when there are more than 128 chunks
+
 extern "C" int64_t psn_pair_sums_group_workspace(int n_items, int V, int64_t Ns, int C) {
     int rows = 16;
     int64_t chunks = (Ns + rows - 1) / rows;
     while (chunks > PSN_PAIR_SUMS_MAX_CHUNKS) { rows *= 2; chunks = (Ns + rows - 1) / rows; }
-    return (int64_t)n_items * (chunks > 0 ? chunks : 1) * V * C;
+    return (int64_t)n_items * ((chunks > 0 ? chunks : 1) + kPairSlices) * V * C;
 }
 
 extern "C" int psn_pair_sums_group(int n_items, const PsnPairSumsItem* items, int V, int64_t Ns, int C, const float* pe_l, int64_t ld_pe,
@@ -453,6 +465,14 @@ extern "C" int psn_pair_sums_group(int n_items, const PsnPairSumsItem* items, in
     if (chunks > 0) {
         hipLaunchKernelGGL(pair_group_sums_kernel, dim3((unsigned)chunks, n_items), dim3(256), 0, (hipStream_t)stream, a);
         PSN_CHECK_LAUNCH("pair_sums_group (sums)");
+    }
+    if (chunks > 128) {
+        // sliced: 32 blocks per (item, column group) add a slice of the chunks each (fixed order), the last launch adds the slices
+        a.slices = kPairSlices;
+        a.part2 = workspace + (int64_t)n_items * chunks * V * C;
+        hipLaunchKernelGGL(pair_group_final_kernel, dim3((unsigned)((C + 63) / 64), n_items, kPairSlices), dim3(1024), 0, (hipStream_t)stream, a);
+        PSN_CHECK_LAUNCH("pair_sums_group (slices)");
+        a.part = a.part2; a.chunks = kPairSlices; a.slices = 1; a.part2 = nullptr;
     }
     hipLaunchKernelGGL(pair_group_final_kernel, dim3((unsigned)((C + 63) / 64), n_items), dim3(1024), 0, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("pair_sums_group (final)");
