@@ -41,4 +41,11 @@ python3 $R/tools/strong_projection.py --graph --queue-ahead --steps 40 --out $O/
 python3 $R/tools/dbg/x3occ_probe.py 2>/dev/null | grep -v amdgpu > $O/x3occ.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps4 -o s4 -- python3 $R/tools/strong_projection.py --pixels 4096 --steps 30 --graph --no-profiler --out /tmp/ps4/p.json > /dev/null 2>&1
 cp $(find /tmp/ps4 -name '*kernel_stats*' | head -1) $O/strong4096_kernel_stats.csv
+# kernel timelines (start offset, duration, gap, queue per launch of one step): the replayed 4096-px rank shard and the eager 32768-px step
+for CASE in "4096 graph" "32768"; do
+    N=$(echo $CASE | tr ' ' '_')
+    rm -rf /tmp/tl_$N
+    rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$N -o t -- python3 $R/tools/dbg/trace_step.py $CASE > /dev/null 2>&1
+    python3 $R/tools/dbg/trace_step_analyse.py $(find /tmp/tl_$N -name '*kernel_trace.csv' | head -1) > $O/timeline_${N}.txt 2>&1
+done
 ls -la $O
