@@ -2,8 +2,9 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# a step starts at the light_rows_fwd kernel
-starts = [i for i, r in enumerate(rows) if 'light_rows_fwd' in r['Kernel_Name']]
+# a step starts at the marker kernel (default: light_rows_fwd, the first launch of a stage-2 step)
+marker = sys.argv[2] if len(sys.argv) > 2 else 'light_rows_fwd'
+starts = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
 a, b = starts[-3], starts[-2]
 step = rows[a:b]
 t0 = int(step[0]['Start_Timestamp'])
