@@ -87,6 +87,19 @@ def test_argument_validation_needs_no_gpu():
     rc = lib.psn_mlp_infer(ctypes.byref(m), dummy, dummy, None, 1, 1, None, 1, 1, None, None, None, 0, None, None, None, None, 0, None, None, 0,
                            None, 10, dummy, None)
     assert rc == -1 and b'n_out' in lib.psn_last_error()
+    # padded row sets (psn_mlp_infer_padded): a device-side count is required, the group length must be a multiple of the
+    # 64-row block and save_row0 a multiple of the group length -- checked on the host, before any launch
+    v = hip.PsnMlpDesc()
+    v.n_layers, v.n_out, v.in_kt_a, v.in_kt_b, v.init_stride = 2, 1, 2, 0, 0
+    v.layers[0].n_mt, v.layers[0].n_kt_in, v.layers[0].n_kt_act, v.layers[0].init_off, v.layers[0].b_off, v.layers[0].act = 8, 2, 0, -1, 0, hip.ACT_RELU
+    v.layers[1].n_mt, v.layers[1].n_kt_in, v.layers[1].n_kt_act, v.layers[1].init_off, v.layers[1].b_off = 1, 0, 8, -1, 256
+    args = (ctypes.byref(v), dummy, dummy, dummy, 1, 1000, None, 1, 1, None, None, None)
+    rc = lib.psn_mlp_infer_padded(*args, 5000, 7000, dummy, None, 1000, None)
+    assert rc == -1 and b'live_count' in lib.psn_last_error()
+    rc = lib.psn_mlp_infer_padded(*args, 5000, 7000, dummy, dummy, 1000, None)   # 1000 is no multiple of 64
+    assert rc == -1 and b'multiple of 64' in lib.psn_last_error()
+    rc = lib.psn_mlp_infer_padded(*args, 5000, 7000, dummy, dummy, 1024, None)   # save_row0 = 5000 is no multiple of 1024
+    assert rc == -1 and b'multiple of the period' in lib.psn_last_error()
 
 
 def test_split_rows_backward_is_the_slice_backward():
