@@ -506,6 +506,12 @@ typedef struct {
     int rows, cols;
 } PsnCopy2dItem;
 int psn_copy2d_group(int n_items, const PsnCopy2dItem* items, void* stream);
+/* Up to PSN_COPY_BYTES_MAX contiguous copies of any element type in ONE launch: a training batch (stage2/trainer.py:364-392: ~17
+ * tensors of floats, bools and indices) into the fixed input buffers of a captured HIP graph (one device-to-device copy each cost
+ * ~5 us of dependent-launch latency).  `aligned` is filled in by the library (both pointers 16-byte aligned). */
+#define PSN_COPY_BYTES_MAX 24
+typedef struct { const void* src; void* dst; int64_t n_bytes; int aligned; } PsnCopyBytesItem;
+int psn_copy_bytes_group(int n_items, const PsnCopyBytesItem* items, void* stream);
 int psn_mask_count(const unsigned char* mask_a, const unsigned char* mask_b, int64_t n, float* out, void* stream);
 /* psn_surface_index: idx[0 .. ns) = ascending positions of the set bytes of mask [n] (= surface_mask[0].nonzero(),
  *   stage2/model/renderer.py:125, without a host synchronisation), idx[ns .. cap) = idx[ns - 1]: a FIXED-size list whose

@@ -269,6 +269,45 @@ extern "C" int psn_copy2d_group(int n_items, const PsnCopy2dItem* items, void* s
     return PSN_OK;
 }
 
+// ---- up to PSN_COPY_BYTES_MAX contiguous copies of any element type in one launch (a batch -> the input buffers of a HIP graph) ----
+namespace psn {
+struct CopyBytesArgs { PsnCopyBytesItem it[PSN_COPY_BYTES_MAX]; int64_t start[PSN_COPY_BYTES_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void copy_bytes_group_kernel(CopyBytesArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int64_t)blockIdx.x >= a.start[i + 1]) ++i;
+    const PsnCopyBytesItem it = a.it[i];
+    const int64_t b = (int64_t)blockIdx.x - a.start[i];  // block of 256 threads x 16 bytes
+    const int64_t off = (b * 256 + threadIdx.x) * 16;
+    if (off >= it.n_bytes) return;
+    const char* s = reinterpret_cast<const char*>(it.src) + off;
+    char* d = reinterpret_cast<char*>(it.dst) + off;
+    if (it.aligned && off + 16 <= it.n_bytes) {
+        *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+    } else {
+        const int m = (int)(it.n_bytes - off < 16 ? it.n_bytes - off : 16);
+        for (int k = 0; k < m; ++k) d[k] = s[k];
+    }
+}
+}  // namespace psn
+
+extern "C" int psn_copy_bytes_group(int n_items, const PsnCopyBytesItem* items, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(items && n_items >= 1 && n_items <= PSN_COPY_BYTES_MAX, "copy_bytes_group: n_items=%d", n_items);
+    CopyBytesArgs a;
+    a.n = n_items;
+    a.start[0] = 0;
+    for (int i = 0; i < n_items; ++i) {
+        PSN_CHECK_ARG(items[i].src && items[i].dst && items[i].n_bytes >= 1, "copy_bytes_group: item %d", i);
+        a.it[i] = items[i];
+        a.it[i].aligned = ((((uintptr_t)items[i].src) | ((uintptr_t)items[i].dst)) & 15) == 0;
+        a.start[i + 1] = a.start[i] + (items[i].n_bytes + 4095) / 4096;
+    }
+    PSN_CHECK_ARG(a.start[n_items] < (1ll << 31), "copy_bytes_group: too many bytes");
+    hipLaunchKernelGGL(copy_bytes_group_kernel, dim3((unsigned)a.start[n_items]), dim3(256), 0, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("copy_bytes_group");
+    return PSN_OK;
+}
+
 // idx[0 .. ns) = the positions of the set bytes of mask [n] in ascending order, idx[ns .. cap) = idx[ns - 1] (0 when the mask is
 // empty), count[0] = ns as a float: nonzero() without its host synchronisation, into a FIXED-size list (graph replay).
 namespace psn {

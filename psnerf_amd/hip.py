@@ -80,6 +80,13 @@ class PsnCopy2dItem(ctypes.Structure):
 COPY2D_MAX = 24
 
 
+class PsnCopyBytesItem(ctypes.Structure):
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('n_bytes', i64), ('aligned', i32)]
+
+
+COPY_BYTES_MAX = 24
+
+
 class PsnAdamSeg(ctypes.Structure):
     _fields_ = [('offset', i64), ('grad_offset', i64), ('n', i64), ('neg_step_size', f32), ('bias_correction2_sqrt', f32)]
 
@@ -159,6 +166,7 @@ SIGNATURES = {
     'psn_surface_points': (i32, [c_f, c_f, c_f, c_f, i64, c_f, c_f, c_f, c_f, c_f]),
     'psn_stage1_targets': (i32, [c_f, i64, i32, i32, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, c_f, c_f, c_f, c_f, c_f]),
     'psn_copy2d_group': (i32, [i32, ctypes.c_void_p, c_f]),
+    'psn_copy_bytes_group': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_mask_count': (i32, [c_f, c_f, i64, c_f, c_f]),
     'psn_inverse_index': (i32, [c_f, i64, i64, c_f, c_f]),
     'psn_adam_flat': (i32, [c_f, c_f, c_f, c_f, i32, ctypes.c_void_p, f32, f32, f32, f32, c_f]),
@@ -376,6 +384,18 @@ def copy2d_group(pairs):
                 e.rows, e.cols, e.ld_src, e.ld_dst = src.shape[0], src.shape[1], src.stride(0), dst.stride(0)
             e.src, e.dst = src.data_ptr(), dst.data_ptr()
         _check(_lib.psn_copy2d_group(len(chunk), ctypes.addressof(arr), _stream()), 'copy2d_group')
+
+
+def copy_group(pairs):
+    """dst.copy_(src) for every (dst, src) pair of contiguous device tensors with equal dtype and element count, <= 24 per launch
+    (psn_copy_bytes_group): the batch of a step into the input buffers of a captured HIP graph in one launch."""
+    for c0 in range(0, len(pairs), COPY_BYTES_MAX):
+        chunk = pairs[c0:c0 + COPY_BYTES_MAX]
+        arr = (PsnCopyBytesItem * len(chunk))()
+        for e, (dst, src) in zip(arr, chunk):
+            assert dst.is_cuda and src.is_cuda and dst.dtype == src.dtype and dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+            e.src, e.dst, e.n_bytes = src.data_ptr(), dst.data_ptr(), dst.numel() * dst.element_size()
+        _check(_lib.psn_copy_bytes_group(len(chunk), ctypes.addressof(arr), _stream()), 'copy_bytes_group')
 
 
 def mask_count(mask_a, mask_b=None, out=None):

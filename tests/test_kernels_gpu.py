@@ -1120,3 +1120,21 @@ def test_pair_sums_group_vs_torch(cuda, V, Ns, n_items):
             assert_close(b.cpu(), dzl.sum(0).float().cpu(), 1e-5, 'bias')
         else:
             assert b is None
+
+
+def test_copy_group_copies_any_dtype_and_alignment(cuda):
+    """psn_copy_bytes_group: contiguous tensors of mixed element types, odd byte counts and unaligned views in one launch."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(0)
+    base = torch.randn(100000, generator=g).to(cuda)
+    srcs = [torch.randn(1, 4096, 3, generator=g).to(cuda), (torch.rand(1, 4097, generator=g) < 0.5).to(cuda), torch.randint(0, 1 << 40, (3001,), generator=g).to(cuda),
+            base[1:50002], torch.randn(96, 1234, 3, generator=g).to(cuda), torch.randint(0, 255, (13,), generator=g, dtype=torch.uint8).to(cuda),
+            torch.randn(1, generator=g).to(cuda)]
+    pad = torch.zeros(100001, device=cuda)
+    dsts = [torch.zeros_like(s) for s in srcs]
+    dsts[3] = pad[3:50004]  # (4-byte aligned only, both sides)
+    hip.copy_group(list(zip(dsts, srcs)) * 4)  # 28 items: two launches
+    torch.cuda.synchronize()
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+    assert float(pad[:3].abs().sum()) == 0.0 and float(pad[50004:].abs().sum()) == 0.0  # nothing written outside the views
