@@ -394,6 +394,33 @@ def strong_cfg4(device, dp, rank, world, steps=40):
     return res
 
 
+def guarded(fn, line, rank, timeout=240):
+    """fn() under a watchdog: if it has not returned after ``timeout`` seconds (a rank stuck in a collective cannot be interrupted),
+    rank 0 prints ``line`` with an error in place of the object and every rank leaves the process."""
+    import threading
+    lock, state = threading.Lock(), {'done': False}
+
+    def fire():
+        with lock:
+            if state['done']:
+                return
+            if rank == 0 and line is not None:
+                line['strong_cfg4'] = {'error': 'strong_cfg4 did not return within %d s at this world size; the headline and every other object of '
+                                                'this line were measured before it started' % timeout}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+    t = threading.Timer(timeout, fire)
+    t.daemon = True
+    t.start()
+    try:
+        return fn()
+    finally:
+        with lock:
+            state['done'] = True
+        t.cancel()
+
+
 def run_cfg4_child(timeout=900):
     """``python bench.py --cfg4-child`` as a child process; -> its strong_cfg4 dictionary, or {'error': ...}."""
     env = dict(os.environ)
@@ -608,82 +635,87 @@ def main():
             allreduce_ms = round(step.dp.time_allreduce(step.dp.allreduce_bytes // 4), 4)
     bucket_bytes = step.dp.allreduce_bytes
     cfg4 = cfg4_n1
-    if not args.no_extra and world > 1:
-        cfg4 = strong_cfg4(device, step.dp, rank, world)
 
     stage1 = None
     if world == 1 and not args.no_stage1:
         del step
         torch.cuda.empty_cache()
         stage1 = stage1_measure(device)
+    line = None
+    if rank == 0:
+        # dominant kernel: fused visibility MLP over (L + V) * Ns rows, one launch per step (the smaller launches of the
+        # same engine are the 128- / 64-wide BRDF / normal nets)
+        infer = [(r, a.elapsed_time(b)) for (name, r, a, b, _f) in events if name == 'mlp_infer']
+        top = max([r for r, _ in infer]) if infer else 0
+        durs = [t for r, t in infer if r == top]
+        roofline = None
+        if durs:
+            avg_ms = sum(durs) / len(durs)
+            algo = 2.0 * VIS_MACS * top / (avg_ms * 1e-3) / 1e12       # the reference's unfactorised formulation
+            issued = 2.0 * VIS_MACS_ISSUED * top / (avg_ms * 1e-3) / 1e12  # the flops of the algorithm this kernel runs
+            traffic = comp = busy = None
+            pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+            if os.path.exists(pmc) and px_local == N_PIXELS:
+                try:
+                    j = json.load(open(pmc))
+                    traffic, comp, busy = j.get('hbm_side_bytes_per_launch'), j.get('compulsory_bytes_per_launch'), j.get('mfma_busy_frac')
+                except Exception:
+                    traffic = None
+            roofline = {'bound': 'mfma', 'kernel': 'mlp_infer_kernel<false,16,0>', 'achieved': round(issued, 2),
+                        'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(issued / PEAK_F32_MFMA_TFLOPS, 4),
+                        'flops_per_row': 2 * VIS_MACS_ISSUED, 'rows_per_launch': top, 'avg_launch_ms': round(avg_ms, 3),
+                        'launches': len(durs), 'share_of_step': round(avg_ms / ms_per_step, 3),
+                        'algorithmic_flops_per_row': 2 * VIS_MACS, 'algorithmic_achieved': round(algo, 2),
+                        'algorithmic_frac': round(algo / PEAK_F32_MFMA_TFLOPS, 4),
+                        'traffic': traffic, 'algorithmic_bytes': comp,
+                        'traffic_over_algorithmic': round(traffic / comp, 2) if (traffic and comp) else None,
+                        'pmc_mfma_busy_frac': busy,
+                        'note': 'achieved = 2 x 462,848 MAC per row x rows / avg launch duration (HIP events, second pass): the two layers '
+                                'that read [pe(x) | pe(l)] start from per-point / per-light tables, W [pe(x) | pe(l)] = W_a pe(x) + W_b pe(l), '
+                                'computed once per point / light by separate small GEMMs (DESIGN.md 3).  algorithmic_* prices the '
+                                "reference's 523,520 MAC per row at the same duration.  traffic = 2 x FETCH_SIZE + WRITE_SIZE of the "
+                                'dispatch (rocprofv3 PMC, profiles/pmc_traffic.json; Infinity-Cache hits included), algorithmic_bytes = '
+                                'compulsory HBM bytes (tables and weights once, outputs, activation dumps of the V supervised rows); the '
+                                'ratio is re-read traffic of the init tables served by L2 / MALL on an MFMA-bound kernel'}
+        cpu = parity = None
+        if not args.no_cpu_baseline and world == 1:  # the CPU oracle is timed at N = 1 only (other ranks would idle behind it)
+            try:
+                parity = parity_check(device)
+            except Exception as e:  # noqa: BLE001
+                parity = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+            cpu = cpu_baseline()
+        line = {
+            'metric': 'ray-samples/sec (train step) on BEAR stage2', 'value': round(value, 1), 'unit': 'ray-samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'stage2 BEAR BRDF+light joint opt (BASELINE configs[2]): %d px/GPU (%d surface total), '
+                                   'L=96 shading lights, V=8 visibility lights, sgbasis RGB 9 lobes, visibility + vis_loss on, '
+                                   'train_fix phase 2, full step (fwd+loss+bwd+Adam+SparseAdam); the batch carries its V supervision '
+                                   'lights ready-made -- the per-step train.vis_plus draw of bear.conf:29 (stage2/trainer.py:384-392: one '
+                                   'np.random.choice + a two-index device gather, psnerf_amd.stage2.trainer.VisPlus) is NOT inside the timed '
+                                   'step, as BASELINE cfg 3 does not list it' % (px_local, ns_total),
+                       'pixels_per_gpu': px_local, 'surface_pixels_total': ns_total, 'lights': N_LIGHTS,
+                       'vis_lights': N_VIS, 'parallelism': 'pixel-dp%d' % world,
+                       'batch': "ViewSampler.batch layout: reference dictionary + 'surface_idx' (host-built index list of the surface mask)"},
+            'loss': round(float(terms['total'].detach()), 6),
+            'roofline': roofline, 'cpu_baseline': cpu, 'reference_dict': ref_dict, 'launches_per_step': launches,
+            'bf16x6_experiment': x6,
+            ('strong' if args.scaling == 'weak' else 'weak'): other,
+            'strong_cfg4': cfg4, 'parity': parity,
+            'allreduce_ms': allreduce_ms, 'allreduce_bytes': bucket_bytes if world > 1 else None,
+            'stage1': stage1,
+        }
+    if not args.no_extra and world > 1:
+        # The diagnostic object runs LAST, behind a watchdog: it captures HIP graphs around RCCL collectives on every rank, a path no
+        # multi-GPU node has exercised yet -- if it does not come back, rank 0 still prints the headline line (assembled above).
+        cfg4 = guarded(lambda: strong_cfg4(device, step.dp, rank, world), line, rank)
+        if line is not None:
+            line['strong_cfg4'] = cfg4
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()  # every rank leaves the group cleanly before rank 0 prints
     if rank != 0:
         return
-
-    # dominant kernel: fused visibility MLP over (L + V) * Ns rows, one launch per step (the smaller launches of the
-    # same engine are the 128- / 64-wide BRDF / normal nets)
-    infer = [(r, a.elapsed_time(b)) for (name, r, a, b, _f) in events if name == 'mlp_infer']
-    top = max([r for r, _ in infer]) if infer else 0
-    durs = [t for r, t in infer if r == top]
-    roofline = None
-    if durs:
-        avg_ms = sum(durs) / len(durs)
-        algo = 2.0 * VIS_MACS * top / (avg_ms * 1e-3) / 1e12       # the reference's unfactorised formulation
-        issued = 2.0 * VIS_MACS_ISSUED * top / (avg_ms * 1e-3) / 1e12  # the flops of the algorithm this kernel runs
-        traffic = comp = busy = None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc) and px_local == N_PIXELS:
-            try:
-                j = json.load(open(pmc))
-                traffic, comp, busy = j.get('hbm_side_bytes_per_launch'), j.get('compulsory_bytes_per_launch'), j.get('mfma_busy_frac')
-            except Exception:
-                traffic = None
-        roofline = {'bound': 'mfma', 'kernel': 'mlp_infer_kernel<false,16,0>', 'achieved': round(issued, 2),
-                    'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(issued / PEAK_F32_MFMA_TFLOPS, 4),
-                    'flops_per_row': 2 * VIS_MACS_ISSUED, 'rows_per_launch': top, 'avg_launch_ms': round(avg_ms, 3),
-                    'launches': len(durs), 'share_of_step': round(avg_ms / ms_per_step, 3),
-                    'algorithmic_flops_per_row': 2 * VIS_MACS, 'algorithmic_achieved': round(algo, 2),
-                    'algorithmic_frac': round(algo / PEAK_F32_MFMA_TFLOPS, 4),
-                    'traffic': traffic, 'algorithmic_bytes': comp,
-                    'traffic_over_algorithmic': round(traffic / comp, 2) if (traffic and comp) else None,
-                    'pmc_mfma_busy_frac': busy,
-                    'note': 'achieved = 2 x 462,848 MAC per row x rows / avg launch duration (HIP events, second pass): the two layers '
-                            'that read [pe(x) | pe(l)] start from per-point / per-light tables, W [pe(x) | pe(l)] = W_a pe(x) + W_b pe(l), '
-                            'computed once per point / light by separate small GEMMs (DESIGN.md 3).  algorithmic_* prices the '
-                            "reference's 523,520 MAC per row at the same duration.  traffic = 2 x FETCH_SIZE + WRITE_SIZE of the "
-                            'dispatch (rocprofv3 PMC, profiles/pmc_traffic.json; Infinity-Cache hits included), algorithmic_bytes = '
-                            'compulsory HBM bytes (tables and weights once, outputs, activation dumps of the V supervised rows); the '
-                            'ratio is re-read traffic of the init tables served by L2 / MALL on an MFMA-bound kernel'}
-    cpu = parity = None
-    if not args.no_cpu_baseline and world == 1:  # the CPU oracle is timed at N = 1 only (other ranks would idle behind it)
-        try:
-            parity = parity_check(device)
-        except Exception as e:  # noqa: BLE001
-            parity = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
-        cpu = cpu_baseline()
-    line = {
-        'metric': 'ray-samples/sec (train step) on BEAR stage2', 'value': round(value, 1), 'unit': 'ray-samples/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
-        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'stage2 BEAR BRDF+light joint opt (BASELINE configs[2]): %d px/GPU (%d surface total), '
-                               'L=96 shading lights, V=8 visibility lights, sgbasis RGB 9 lobes, visibility + vis_loss on, '
-                               'train_fix phase 2, full step (fwd+loss+bwd+Adam+SparseAdam); the batch carries its V supervision '
-                               'lights ready-made -- the per-step train.vis_plus draw of bear.conf:29 (stage2/trainer.py:384-392: one '
-                               'np.random.choice + a two-index device gather, psnerf_amd.stage2.trainer.VisPlus) is NOT inside the timed '
-                               'step, as BASELINE cfg 3 does not list it' % (px_local, ns_total),
-                   'pixels_per_gpu': px_local, 'surface_pixels_total': ns_total, 'lights': N_LIGHTS,
-                   'vis_lights': N_VIS, 'parallelism': 'pixel-dp%d' % world,
-                   'batch': "ViewSampler.batch layout: reference dictionary + 'surface_idx' (host-built index list of the surface mask)"},
-        'loss': round(float(terms['total'].detach()), 6),
-        'roofline': roofline, 'cpu_baseline': cpu, 'reference_dict': ref_dict, 'launches_per_step': launches,
-        'bf16x6_experiment': x6,
-        ('strong' if args.scaling == 'weak' else 'weak'): other,
-        'strong_cfg4': cfg4, 'parity': parity,
-        'allreduce_ms': allreduce_ms, 'allreduce_bytes': bucket_bytes if world > 1 else None,
-        'stage1': stage1,
-    }
     print(json.dumps(line), flush=True)
 
 

@@ -184,3 +184,21 @@ def test_integration_section_a_lines_run_against_psnerf_amd(tmp_path):
     assert isinstance(net, s2.PSNetwork) and loss.vis_weight == 1 and loss_n.normal_smooth_weight == 0.05
     sg_optimizer = torch.optim.Adam(net.parameters(), lr=conf.get_float('train.sg_learning_rate'))   # :115-116
     assert len(sg_optimizer.param_groups[0]['params']) == len(list(net.parameters()))
+
+
+def test_bench_watchdog_prints_the_headline_when_the_diagnostic_object_hangs():
+    """bench.guarded: strong_cfg4 at N > 1 (HIP graphs around RCCL collectives) runs behind a watchdog -- if it never returns, rank 0
+    prints the line it had assembled, with an error in place of the object, and the process leaves with exit code 0."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "bench.guarded(lambda: time.sleep(60), {'metric': 'm', 'value': 1.5, 'strong_cfg4': None}, 0, timeout=1)") % root
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=50)
+    assert r.returncode == 0, r.stderr[-500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['value'] == 1.5 and 'did not return' in line['strong_cfg4']['error']
+    # a rank other than 0 leaves silently; a function that returns in time is passed through
+    code2 = ("import sys, time; sys.path.insert(0, %r); import bench; "
+             "print(bench.guarded(lambda: 7, {'x': 1}, 0, timeout=5), flush=True); bench.guarded(lambda: time.sleep(60), {'x': 1}, 1, timeout=1)") % root
+    r = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, timeout=50)
+    assert r.returncode == 0 and r.stdout.strip() == '7', (r.stdout, r.stderr[-300:])
