@@ -184,7 +184,9 @@ enum {
     PSN_ACT_MUL_AUX = 4,       /* act = z * a1;                    second = z                               */
     PSN_ACT_MUL2 = 5,          /* act = z * a1;                    second = z * a2                          */
     PSN_ACT_SOFTPLUS_BWD = 6,  /* act = a1 z + 100 (1 - a1) a2     (softplus double-backward combine)        */
-    PSN_ACT_HEAD = 7           /* side output: z is dumped, the activations are left untouched              */
+    PSN_ACT_HEAD = 7,          /* side output: z is dumped, the activations are left untouched              */
+    PSN_ACT_RELU_BITS = 8      /* act = z * bit: RELU_MASK with the mask as sign bits -- a1 = [n_rows, 4] uint64 words written
+                                  by psn_mlp_infer_bits (bit 4 mt + r of word (row, g) = feature 16 mt + 4 g + r was > 0)    */
 };
 enum { PSN_OUT_NONE = 0, PSN_OUT_SIGMOID = 1, PSN_OUT_OCC = 2 /* sigmoid(-10 x), network.py:125 */ };
 
@@ -271,6 +273,16 @@ int psn_mlp_infer_padded(const PsnMlpDesc* desc, const float* packed_w, const fl
                          int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                          const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
                          int64_t n_rows, float* out, const float* live_count, int64_t live_period, void* stream);
+/* psn_mlp_infer, plain forward with activation dumps (stage2/model/renderer.py:251-262: the supervision rows of the visibility
+ * network, :127-143 / :163-189 the normal / BRDF networks), that ALSO leaves the sign bits of every dumped activation behind:
+ * save_bits_ptrs[l] [n_rows - save_row0, 4] uint64 (NULL per layer: none).  The ReLU-backward chain (PSN_ACT_RELU_BITS, the words
+ * passed as that layer's aux1 in mask_ptrs) reads 32 bytes per row and layer instead of the 1 KB activation row -- the same
+ * d z = d h * (h > 0), bit for bit.  live_count / live_period as for psn_mlp_infer_padded (NULL, 0: every row is real). */
+int psn_mlp_infer_bits(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
+                       int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
+                       const float* init_a, const float* init_b, float* const* save_ptrs,
+                       unsigned long long* const* save_bits_ptrs, int64_t save_row0, int64_t n_rows, float* out,
+                       const float* live_count, int64_t live_period, void* stream);
 
 /* Dense per-pixel outputs of the stage-2 model, stage2/model/renderer.py:145-152,204-264: dense [B, N, C] = fill
  * everywhere except dense[b, idx[r], c] = rows[(b Ns + r) row_stride + c col_stride] (light-major surface rows;

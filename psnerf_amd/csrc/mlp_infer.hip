@@ -83,6 +83,10 @@ struct InferArgs {
     // the all-padding 64-row blocks are not evaluated (zeros)
     const float* live_count;
     int64_t live_period;
+    // sign bits of the dumped activations (lean variant, 256-wide): save_bits[l] [n_rows - save_row0, 4] uint64 -- the word of
+    // (row, lane group g) holds bit 4 mt + r = (activation feature 16 mt + 4 g + r > 0); read back by PSN_ACT_RELU_BITS chains
+    // through mask[l], 32 bytes per row and layer instead of the 1 KB activation row
+    unsigned long long* save_bits[PSN_MLP_MAX_LAYERS];
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -251,7 +255,7 @@ __device__ __forceinline__ void st4(float* p, const floatx4& v) { *reinterpret_c
 template <int CODE, int NMT>
 __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&act)[NMT], const float* __restrict__ p1,
                                                  const float* __restrict__ p2, float* __restrict__ d1, float* __restrict__ d2,
-                                                 const uint32_t m1, const uint32_t m2) {
+                                                 const uint32_t m1, const uint32_t m2, const unsigned long long sign_bits = 0) {
     constexpr bool kNeed1 = CODE == PSN_ACT_RELU_MASK || CODE == PSN_ACT_MUL_AUX || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD;
     constexpr bool kNeed2 = CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD;
     constexpr bool kSecond = CODE == PSN_ACT_SOFTPLUS100 || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_MUL_AUX;
@@ -303,6 +307,8 @@ __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&
             o2[r] = z;
             if constexpr (CODE == PSN_ACT_RELU) o[r] = relu1(z);
             else if constexpr (CODE == PSN_ACT_RELU_MASK) o[r] = t1[mt][r] > 0.0f ? z : 0.0f;
+            else if constexpr (CODE == PSN_ACT_RELU_BITS)  // (compile-time bit position: one AND with a constant per element)
+                o[r] = (((4 * mt + r) < 32 ? (unsigned)sign_bits : (unsigned)(sign_bits >> 32)) & (1u << ((4 * mt + r) & 31))) != 0u ? z : 0.0f;
             else o[r] = z;
         }
         act[mt] = o;
@@ -317,7 +323,11 @@ __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&
 // Wait until this wave's LDS-DMA pieces have landed while leaving `stores` (0, NMT or 2 NMT) younger dump stores in flight.
 template <int NMT>
 __device__ __forceinline__ void wait_for_weights(int stores) {
-    if (stores == 2 * NMT) {
+    if (stores == NMT + 1) {  // a dump and its sign-bit word
+        if constexpr (NMT == 16) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+        else if constexpr (NMT == 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else if (stores == 2 * NMT) {
         if constexpr (NMT == 16) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else if constexpr (NMT == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -695,13 +705,24 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                 for (int mt = 0; mt < NMT; ++mt) act[mt] = acc[mt];
             }
             if (g.save[li] != nullptr) {
+                const bool bits = g.save_bits[li] != nullptr;
                 if (dump_row) {
                     float* dst = g.save[li] + (row - g.save_row0) * W + 4 * lg;
+                    // (sign bits: the dumped value is relu(z) or a softplus, > 0 exactly when it compares so; two 32-bit halves
+                    //  built tile by tile beside the stores -- formed as a block they cost the kernel 23 registers)
+                    unsigned w0 = 0u, w1 = 0u;
 #pragma unroll
-                    for (int mt = 0; mt < NMT; ++mt)
+                    for (int mt = 0; mt < NMT; ++mt) {
                         *reinterpret_cast<float4*>(dst + mt * 16) = make_float4(act[mt][0], act[mt][1], act[mt][2], act[mt][3]);
+                        if (bits) {
+                            unsigned t = (act[mt][0] > 0.0f ? 1u : 0u) | (act[mt][1] > 0.0f ? 2u : 0u) | (act[mt][2] > 0.0f ? 4u : 0u) | (act[mt][3] > 0.0f ? 8u : 0u);
+                            if (mt < 8) w0 |= t << (4 * mt); else w1 |= t << (4 * (mt - 8));
+                            asm volatile("" : "+v"(w0), "+v"(w1));
+                        }
+                    }
+                    if (bits) *reinterpret_cast<uint2*>(g.save_bits[li] + (row - g.save_row0) * 4 + lg) = make_uint2(w0, w1);
                 }
-                pending_dump = wave_dumps ? NMT : 0;
+                pending_dump = wave_dumps ? NMT + (bits ? 1 : 0) : 0;
                 pending_stages = wave_dumps ? 1 : 0;
             }
         } else
@@ -714,6 +735,10 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             const uint32_t m1 = g.save_tiles[li], m2 = g.save2_tiles[li];
 #define PSN_CASE(C) case C: chain_activation<C, NMT>(acc, act, p1, p2, d1, d2, m1, m2); break;
             switch (L.act) {
+                case PSN_ACT_RELU_BITS:  // mask[li] = the forward launch's sign-bit words [n_rows, 4] uint64 (save_bits)
+                    chain_activation<PSN_ACT_RELU_BITS, NMT>(acc, act, nullptr, nullptr, d1, d2, m1, m2,
+                                                             reinterpret_cast<const unsigned long long*>(g.mask[li])[rowc * 4 + lg]);
+                    break;
                 PSN_CASE(PSN_ACT_RELU)
                 PSN_CASE(PSN_ACT_SOFTPLUS100)
                 PSN_CASE(PSN_ACT_RELU_MASK)
@@ -1113,7 +1138,7 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
                           const float* const* mask_ptrs, const float* const* aux2_ptrs, float* const* save2_ptrs,
                           const float* act_init, int64_t act_init_rows, const float* rk_coef, const float* rk_basis, int rk_k,
                           const uint32_t* dump_tiles, int64_t n_rows, float* out, const float* live_count, int64_t live_period,
-                          void* stream) {
+                          unsigned long long* const* save_bits_ptrs, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG(desc && packed_w && packed_b && (out || desc->n_out == 0), "mlp_infer: null pointer");
     const PsnMlpDesc& d = *desc;
@@ -1168,9 +1193,9 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
                       "mlp_infer: aux / dump tensors must be 16-byte aligned");
         if (in_range) {
             const int act = d.layers[l].act;
-            const bool need1 = act == PSN_ACT_RELU_MASK || act == PSN_ACT_MUL_AUX || act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD;
+            const bool need1 = act == PSN_ACT_RELU_MASK || act == PSN_ACT_MUL_AUX || act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD || act == PSN_ACT_RELU_BITS;
             const bool need2 = act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD;
-            PSN_CHECK_ARG(act >= PSN_ACT_NONE && act <= PSN_ACT_HEAD, "mlp_infer: layer %d unknown activation %d", l, act);
+            PSN_CHECK_ARG(act >= PSN_ACT_NONE && act <= PSN_ACT_RELU_BITS, "mlp_infer: layer %d unknown activation %d", l, act);
             PSN_CHECK_ARG(!need1 || a.mask[l] != nullptr, "mlp_infer: layer %d needs aux operand 1", l);
             PSN_CHECK_ARG(!need2 || a.aux2[l] != nullptr, "mlp_infer: layer %d needs aux operand 2", l);
             PSN_CHECK_ARG(act != PSN_ACT_HEAD || a.save[l] != nullptr, "mlp_infer: a HEAD layer needs a dump tensor");
@@ -1195,6 +1220,11 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
     for (int l = 0; l < d.n_layers; ++l)
         chain = chain || d.layers[l].act > PSN_ACT_SOFTPLUS100 || a.save2[l] != nullptr || a.mask[l] != nullptr || a.aux2[l] != nullptr;
     PSN_CHECK_ARG(d.n_out <= 32 || (chain && hid == 8), "mlp_infer: 33..64 outputs are built for the 256-wide chain engine only (n_out=%d)", d.n_out);
+    for (int l = 0; l < PSN_MLP_MAX_LAYERS; ++l) {
+        a.save_bits[l] = (save_bits_ptrs != nullptr && l < (d.n_out > 0 ? d.n_layers - 1 : d.n_layers)) ? save_bits_ptrs[l] : nullptr;
+        PSN_CHECK_ARG(a.save_bits[l] == nullptr || (!chain && a.save[l] != nullptr && (((uintptr_t)a.save_bits[l]) & 7) == 0),
+                      "mlp_infer: sign-bit words (layer %d) go with an activation dump of a plain forward launch", l);
+    }
     PSN_CHECK_ARG(live_count == nullptr || (!chain && d.n_out >= 1 && live_period >= 64 && live_period % 64 == 0 && save_row0 >= 0 &&
                                             save_row0 % live_period == 0 && save_row0 <= n_rows),
                   "mlp_infer_padded: needs the lean variant, outputs, a period that is a multiple of 64 and save_row0 a multiple of the period (period=%lld save_row0=%lld)",
@@ -1231,7 +1261,22 @@ extern "C" int psn_mlp_infer(const PsnMlpDesc* desc, const float* packed_w, cons
                              const uint32_t* dump_tiles, int64_t n_rows, float* out, void* stream) {
     return mlp_infer_impl(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, init_a, init_b, save_ptrs, save_row0,
                           mask_ptrs, aux2_ptrs, save2_ptrs, act_init, act_init_rows, rk_coef, rk_basis, rk_k, dump_tiles, n_rows, out,
-                          nullptr, 0, stream);
+                          nullptr, 0, nullptr, stream);
+}
+
+// psn_mlp_infer, plain forward with activation dumps, that ALSO leaves the sign bits of every dumped activation behind:
+// save_bits_ptrs[l] [n_rows - save_row0, 4] uint64 (or NULL per layer), word (row, g) bit 4 mt + r = (feature 16 mt + 4 g + r of
+// the row's dumped activation > 0).  A ReLU-backward chain (PSN_ACT_RELU_BITS, the words passed as that layer's aux1) then reads
+// 32 bytes per row and layer instead of the activation row; live_count / live_period as for psn_mlp_infer_padded (NULL, 0: none).
+extern "C" int psn_mlp_infer_bits(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
+                                  int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
+                                  const float* init_a, const float* init_b, float* const* save_ptrs,
+                                  unsigned long long* const* save_bits_ptrs, int64_t save_row0, int64_t n_rows, float* out,
+                                  const float* live_count, int64_t live_period, void* stream) {
+    PSN_CHECK_ARG(save_ptrs != nullptr && save_bits_ptrs != nullptr, "mlp_infer_bits: dump and sign-bit pointer arrays are required");
+    return mlp_infer_impl(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, init_a, init_b, save_ptrs, save_row0,
+                          nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, n_rows, out, live_count, live_period,
+                          save_bits_ptrs, stream);
 }
 
 // psn_mlp_infer (lean variant: no chain operands) over a PADDED row set: the rows [0, save_row0) come in groups of
@@ -1245,7 +1290,7 @@ extern "C" int psn_mlp_infer_padded(const PsnMlpDesc* desc, const float* packed_
                                     int64_t n_rows, float* out, const float* live_count, int64_t live_period, void* stream) {
     PSN_CHECK_ARG(live_count != nullptr, "mlp_infer_padded: live_count is null");
     return mlp_infer_impl(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, init_a, init_b, save_ptrs, save_row0,
-                          nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, n_rows, out, live_count, live_period, stream);
+                          nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, n_rows, out, live_count, live_period, nullptr, stream);
 }
 
 // Lean evaluation of a 256-wide network whose input block is the positional encoding of a 3-vector (the stage-1 occupancy

@@ -41,7 +41,7 @@ class PackedMLP(object):
 
     def __call__(self, tab_a, n_rows, a_div=1, a_mod=None, tab_b=None, b_div=1, b_mod=1, out=None, save=None,
                  save_row0=0, mask=None, init_a_direct=None, aux2=None, save2=None, act_init=None, rank_init=None,
-                 save_tiles=None, save2_tiles=None, act_init_rows=None, live=None):
+                 save_tiles=None, save2_tiles=None, act_init_rows=None, live=None, save_bits=None):
         if a_mod is None:
             a_mod = tab_a.shape[0] if tab_a is not None else n_rows
         init_a = init_b = None
@@ -61,7 +61,7 @@ class PackedMLP(object):
                              tab_b if uses_in else None, b_div, b_mod, n_rows, out=out, init_a=init_a, init_b=init_b,
                              save=save, save_row0=save_row0, mask=mask, aux2=aux2, save2=save2, act_init=act_init,
                              macs_per_row=self.macs_per_row, rank_init=rank_init, save_tiles=save_tiles, save2_tiles=save2_tiles,
-                             act_init_rows=act_init_rows, live=live)
+                             act_init_rows=act_init_rows, live=live, save_bits=save_bits)
 
 
 def _pad_cols(w, n):
@@ -426,18 +426,21 @@ def pack_geo_occupancy(weights, biases, skips, d_pe):
     return pack_layers(layers, ka, 0, 1, hip.OUT_OCC, weights[0].device)
 
 
-def pack_relu_bwd(weights, skip_at, width=256):
+def pack_relu_bwd(weights, skip_at, width=256, bits=False):
     """Backward (d x) chain of a 256-wide ReLU MLP for the fused kernel: chain layer j computes
     d h_{l-1} = W_l[:, :256]^T d z_l for l = n-1-j (transposed weight packs, no bias), followed by the ReLU mask of
     the forward activation h_{l-1} (PSN_ACT_RELU_MASK, masks supplied at call time) and a dump of d z_{l-1}.
     Chain layer 0 has no weights: it starts from the caller's init table d h_{n-2} = g_out W_{n-1}.
-    Returns a PackedMLP whose call needs init_a_direct, mask=[h_{n-2}, ..., h_0], save=[dz_{n-2}, ..., dz_0]."""
+    Returns a PackedMLP whose call needs init_a_direct, mask=[h_{n-2}, ..., h_0], save=[dz_{n-2}, ..., dz_0].
+    bits: the masks are the sign-bit words of the forward launch (PSN_ACT_RELU_BITS; hip.mlp_infer save_bits) instead of the
+    activations themselves -- 32 bytes per row and layer instead of 4 x width."""
     n = len(weights)
     dev = weights[0].device
     zeros = _zeros(width, dev)
-    layers = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
+    act = hip.ACT_RELU_BITS if bits else hip.ACT_RELU_MASK
+    layers = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=act)]
     for l in range(n - 2, 0, -1):  # forward layers n-2 .. 1 -> their transposed [in(256), out(256)] blocks
-        layers.append(dict(w_act=Transposed(weights[l][:, :width]), bias=zeros, act=hip.ACT_RELU_MASK))
+        layers.append(dict(w_act=Transposed(weights[l][:, :width]), bias=zeros, act=act))
     return pack_layers(layers, 1, 0, 0, hip.OUT_NONE, dev, has_final=False, width=width)
 
 

@@ -27,7 +27,7 @@ MAX_LAYERS = 12
 (EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_SOFTPLUS, EPI_MUL_AUX, EPI_MUL_POS, EPI_BIAS_SIGMOID, EPI_ACCUM,
  EPI_MUL2, EPI_SOFTPLUS_BWD, EPI_MUL_AUX_RAW) = range(11)
 (ACT_NONE, ACT_RELU, ACT_SOFTPLUS100, ACT_RELU_MASK, ACT_MUL_AUX, ACT_MUL2, ACT_SOFTPLUS_BWD,
- ACT_HEAD) = range(8)
+ ACT_HEAD, ACT_RELU_BITS) = range(9)
 OUT_NONE, OUT_SIGMOID, OUT_OCC = range(3)
 
 
@@ -131,6 +131,8 @@ SIGNATURES = {
                             ctypes.POINTER(ctypes.c_uint32), i64, c_f, c_f]),
     'psn_mlp_infer_padded': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
                                    ctypes.POINTER(ctypes.c_void_p), i64, i64, c_f, c_f, i64, c_f]),
+    'psn_mlp_infer_bits': (i32, [ctypes.POINTER(PsnMlpDesc), c_f, c_f, c_f, i64, i64, c_f, i64, i64, c_f, c_f,
+                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), i64, i64, c_f, c_f, i64, c_f]),
     'psn_scatter_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_gather_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_gather_rows_valid': (i32, [i32, ctypes.c_void_p, c_f, c_f, i64, i64, c_f]),
@@ -230,6 +232,13 @@ def _ptr(t, name, allow_none=False):
         raise RuntimeError('%s: must be float32, got %s' % (name, t.dtype))
     if not t.is_contiguous():
         raise RuntimeError('%s: must be contiguous' % name)
+    return t.data_ptr()
+
+
+def _bits_ptr(t, name):
+    """Device pointer of a tensor of sign-bit words ([rows, 4] int64, contiguous)."""
+    if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == 4):
+        raise RuntimeError('%s: sign-bit words are a contiguous int64 [rows, 4] device tensor' % name)
     return t.data_ptr()
 
 
@@ -1079,13 +1088,15 @@ def mlp_pack_layers(plan):
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,
               init_b=None, save=None, save_row0=0, mask=None, aux2=None, save2=None, act_init=None, macs_per_row=None,
-              rank_init=None, save_tiles=None, save2_tiles=None, act_init_rows=None, live=None):
+              rank_init=None, save_tiles=None, save2_tiles=None, act_init_rows=None, live=None, save_bits=None):
     """save: list (one entry per hidden layer, None allowed) of [n_rows - save_row0, 256] tensors that receive the
     post-activation outputs of the rows >= save_row0.
     rank_init = (coef [n_rows, k], basis [k, init_stride]), k <= 4: rank-k init of the layers with init_off >= 0.
     act_init [act_init_rows (default n_rows), width]: initial activations; the rows behind them start from zeros.
     live = (count float32 [1] on the device, period): the rows [0, save_row0) are groups of `period` rows of which the first
-    count[0] are real (psn_mlp_infer_padded; plain forward launches only): all-padding workgroups write zeros and leave."""
+    count[0] are real (psn_mlp_infer_padded; plain forward launches only): all-padding workgroups write zeros and leave.
+    save_bits: list like ``save`` of int64 [n_rows - save_row0, 4] tensors (or None) that receive the sign bits of the dumped
+    activations (psn_mlp_infer_bits); a chain layer with ACT_RELU_BITS takes such a tensor as its ``mask`` entry."""
     tiles_arr = None
     if save_tiles is not None or save2_tiles is not None:  # per layer: bit mt = the 16-column tile mt of the dump is written
         tiles_arr = (ctypes.c_uint32 * (2 * MAX_LAYERS))(*([0xFFFFFFFF] * (2 * MAX_LAYERS)))
@@ -1112,7 +1123,7 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
         if lst is None:
             return None
         assert len(lst) == n, '%s: expected %d entries' % (name, n)
-        return (ctypes.c_void_p * n)(*[None if t is None else _ptr(t, name) for t in lst])
+        return (ctypes.c_void_p * n)(*[None if t is None else (_bits_ptr(t, name) if t.dtype == torch.int64 else _ptr(t, name)) for t in lst])
 
     mask_arr = ptr_array(mask, desc.n_layers, 'mask')
     aux2_arr = ptr_array(aux2, desc.n_layers, 'aux2')
@@ -1124,6 +1135,20 @@ def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod
     # 'mlp_infer' = the lean engine, 'mlp_chain' = the chain engine (same dispatch rule as psn_mlp_infer)
     chain = act_init is not None or rank_init is not None or tiles_arr is not None or mask is not None or aux2 is not None or save2 is not None or any(
         desc.layers[l].act > ACT_SOFTPLUS100 for l in range(desc.n_layers))
+    if save_bits is not None:
+        if chain or save is None:
+            raise RuntimeError('mlp_infer: sign-bit words go with the activation dumps of a plain forward launch')
+        assert len(save_bits) == n_hidden
+        for t, b in zip(save, save_bits):
+            assert b is None or (t is not None and b.shape == (t.shape[0], 4))
+        bits_arr = (ctypes.c_void_p * n_hidden)(*[None if t is None else _bits_ptr(t, 'save_bits') for t in save_bits])
+        cnt, period = live if live is not None else (None, 0)
+        with _Prof('mlp_infer', n_rows, None if macs_per_row is None else 2.0 * macs_per_row * n_rows):
+            _check(_lib.psn_mlp_infer_bits(ctypes.byref(desc), _ptr(packed_w, 'packed_w'), _ptr(packed_b, 'packed_b'),
+                                           _ptr(tab_a, 'tab_a', True), a_div, a_mod, _ptr(tab_b, 'tab_b', True), b_div, b_mod,
+                                           _ptr(init_a, 'init_a', True), _ptr(init_b, 'init_b', True), save_arr, bits_arr, save_row0, n_rows,
+                                           _ptr(out, 'out', True), None if cnt is None else cnt.data_ptr(), int(period), _stream()), 'mlp_infer_bits')
+        return out
     if live is not None:
         cnt, period = live
         if chain:

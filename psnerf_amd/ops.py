@@ -584,6 +584,17 @@ def mf_shade(light_dir, view, normal, albedo, rough, light_int, vis, f0):
 
 
 # --------------------------------------------------------------------------- visibility net: shading + supervision rows
+# ReLU-backward chains read the forward launch's SIGN BITS (32 bytes per row and layer, written beside the activation dumps:
+# psn_mlp_infer_bits / PSN_ACT_RELU_BITS) instead of re-reading the 1 KB activation rows as masks -- d z = d h * (h > 0) either
+# way, bit for bit; 16 operand loads per lane and layer fewer in the chain (each VMEM instruction of a stage costs the chain
+# about 1 %).  False: the activation rows themselves (PSN_ACT_RELU_MASK; A/B and tests).
+RELU_SIGN_BITS = True
+
+
+def _sign_bits(rows, n, device):
+    return [torch.empty(rows, 4, device=device, dtype=torch.int64) for _ in range(n)]
+
+
 class VisibilityPair(torch.autograd.Function):
     """stage-2 visibility_net on BOTH row groups of a training step in one fused launch:
          rows [0, L*Ns)          shading lights  (renderer.py:191-200; enter the loss detached, :197)
@@ -614,9 +625,11 @@ class VisibilityPair(torch.autograd.Function):
             if packed is None:
                 packed = fused.pack_relu_mlp(list(Ws), list(bs), din_half, din_half, skip_at)
             save = [torch.empty(V * Ns, 256, device=pe_x.device) for _ in range(n - 1)] if (need_grad and V > 0) else None
+            bits = _sign_bits(V * Ns, n - 1, pe_x.device) if (save is not None and RELU_SIGN_BITS) else None
             out = packed(pe_x, LV * Ns, a_div=1, a_mod=Ns, tab_b=pe_l, b_div=Ns, b_mod=LV, save=save, save_row0=n_shade * Ns,
-                         live=None if (live_count is None or Ns % 64 != 0) else (live_count, Ns))  # (64-row blocks must not straddle groups)
-        return out, save
+                         live=None if (live_count is None or Ns % 64 != 0) else (live_count, Ns),  # (64-row blocks must not straddle groups)
+                         save_bits=bits)
+        return out, (save, bits) if save is not None else None
 
     @staticmethod
     def forward(ctx, pe_x, pe_l, n_shade, in_cols, skip_at, pre, *params):
@@ -625,11 +638,11 @@ class VisibilityPair(torch.autograd.Function):
         V = LV - n_shade
         n = len(params) // 2
         need = any(ctx.needs_input_grad[6:])
-        out, save = pre if pre is not None else VisibilityPair.launch(pe_x, pe_l, n_shade, in_cols, skip_at, params, need)
-        if not need:
-            save = None
+        out, dumps = pre if pre is not None else VisibilityPair.launch(pe_x, pe_l, n_shade, in_cols, skip_at, params, need)
+        save, bits = dumps if (need and dumps is not None) else (None, None)
         if save is not None:
             ctx.save_for_backward(pe_x, pe_l[n_shade:], in_cols, *save, *params)
+        ctx.bits = bits  # (sign-bit words of the dumps, or None: plain tensors no gradient ever flows through)
         ctx.n, ctx.skip_at, ctx.V, ctx.saved = n, skip_at, V, save is not None
         # the standard column list [0 .. d) + [stride .. stride + d) (PSNetwork._cols): known without reading the device tensor
         ctx.contiguous_cols = bool(getattr(in_cols, '_psn_contiguous_pair', False))
@@ -657,11 +670,12 @@ class VisibilityPair(torch.autograd.Function):
         # last layer (out = 1): dW = g^T h ; d h_{n-2} = g w  (rank-1, feeds the fused backward chain)
         # d z_l = d h_l * relu'(h_l), d h_{l-1} = W_l[:, :256]^T d z_l for l = n-2 .. 0 in ONE register-resident
         # launch (transposed weight packs, activations re-read as masks, every d z_l dumped for the weight GEMMs)
-        chain = fused.pack_relu_bwd(list(Ws), ctx.skip_at)
+        bits = ctx.bits
+        chain = fused.pack_relu_bwd(list(Ws), ctx.skip_at, bits=bits is not None)
         DZ = [torch.empty(Q, 256, device=g.device) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
         # (the rank-1 init table d h_{n-2} = g w is formed inside the chain kernel: hip.mlp_infer rank_init)
         chain(None, Q, a_div=1, a_mod=Q, rank_init=(g.reshape(Q, 1), Ws[n - 1].reshape(1, -1).contiguous()),
-              mask=[H[n - 2 - j] for j in range(n - 1)], save=DZ, save_row0=0)
+              mask=[(bits if bits is not None else H)[n - 2 - j] for j in range(n - 1)], save=DZ, save_row0=0)
         # Every weight gradient in one grouped launch.  The input block [PE(x_n) | PE(l_v)] of row k = v Ns + n is never
         # expanded: its two halves are TABLES read as pe_x[k % Ns] and pe_lv[k // Ns] by the GEMM itself, side by side in
         # one 128-column product.
@@ -920,10 +934,12 @@ class FusedReluNet(torch.autograd.Function):
             packed = FusedReluNet.pack(Ws, bs, din, skip_at, final_sigmoid, width)
         need = any(ctx.needs_input_grad[6:])
         H = [torch.empty(Q, width, device=pe.device) for _ in range(n - 1)] if need else None
-        out = packed(pe, Q, save=H)
+        bits = _sign_bits(Q, n - 1, pe.device) if (need and RELU_SIGN_BITS) else None
+        out = packed(pe, Q, save=H, save_bits=bits)
         if need:
             ctx.save_for_backward(pe, out, *H, *Ws)
             ctx.meta = (n, din, skip_at, final_sigmoid, width)
+            ctx.bits = bits
         return out
 
     @staticmethod
@@ -937,13 +953,15 @@ class FusedReluNet(torch.autograd.Function):
         g = g.contiguous()
         if final_sigmoid:
             g = torch.ops.aten.sigmoid_backward(g, out)  # g * (1 - out) * out, one launch
-        chain = fused.pack_relu_bwd(list(Ws), skip_at, width=width)
+        bits = ctx.bits
+        chain = fused.pack_relu_bwd(list(Ws), skip_at, width=width, bits=bits is not None)
         DZ = [torch.empty(Q, width, device=dev) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
+        masks = [(bits if bits is not None else H)[n - 2 - j] for j in range(n - 1)]
         if Ws[n - 1].shape[0] <= 4:  # d h_{n-2} = g W_last as a rank-k init inside the kernel (albedo / normal nets: 3 outputs)
-            chain(None, Q, a_div=1, a_mod=Q, rank_init=(g, Ws[n - 1].contiguous()), mask=[H[n - 2 - j] for j in range(n - 1)], save=DZ)
+            chain(None, Q, a_div=1, a_mod=Q, rank_init=(g, Ws[n - 1].contiguous()), mask=masks, save=DZ)
         else:
             dh = hip.gemm(g, Ws[n - 1].contiguous())  # [Q, width]
-            chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh, mask=[H[n - 2 - j] for j in range(n - 1)], save=DZ)
+            chain(None, Q, a_div=1, a_mod=Q, init_a_direct=dh, mask=masks, save=DZ)
         x_in = pe[:, :din]
         items = [dict(A=g, B=H[n - 2], colsum=True)]
         where = [(n - 1, 'w')]

@@ -153,9 +153,9 @@ def test_padded_visibility_launch_skips_only_padding_workgroups(cuda, ns, live):
         params += [(torch.randn(o, i, generator=g) / i ** 0.5).to(cuda), (torch.randn(o, generator=g) * 0.1).to(cuda)]
     c = torch.arange(39)
     cols = torch.cat([c, 64 + c]).to(cuda)
-    ref, save_ref = ops.VisibilityPair.launch(pe_x, pe_l, L, cols, 2, params, True)
+    ref, (save_ref, bits_ref) = ops.VisibilityPair.launch(pe_x, pe_l, L, cols, 2, params, True)
     cnt = torch.tensor([float(live)], device=cuda)
-    out, save = ops.VisibilityPair.launch(pe_x, pe_l, L, cols, 2, params, True, live_count=cnt)
+    out, (save, bits) = ops.VisibilityPair.launch(pe_x, pe_l, L, cols, 2, params, True, live_count=cnt)
     torch.cuda.synchronize()
     r = torch.arange((L + V) * ns, device=cuda)
     # a 64-row block of a shading light's group that lies behind the real rows is not evaluated (capacities that are no multiple
@@ -164,8 +164,12 @@ def test_padded_visibility_launch_skips_only_padding_workgroups(cuda, ns, live):
     assert int(dead.sum()) == (L * (ns - (live + 63) // 64 * 64) if ns % 64 == 0 else 0)
     assert bool((out[dead] == 0).all())
     assert torch.equal(out[~dead], ref[~dead])
-    for a, b in zip(save, save_ref):
+    for a, b in zip(save + bits, save_ref + bits_ref):
         assert torch.equal(a, b)
+    # the sign-bit words beside the dumps: bit 4 mt + r of word (row, g) = (feature 16 mt + 4 g + r of the dumped activation > 0)
+    h = save[1].view(-1, 16, 4, 4)  # [row, mt, g, r]
+    want = ((h > 0).long() << (4 * torch.arange(16, device=cuda).view(1, 16, 1, 1) + torch.arange(4, device=cuda).view(1, 1, 1, 4))).sum(dim=(1, 3))
+    assert torch.equal(bits[1], want)
 
 
 @pytest.mark.parametrize('with_count', [False, True])

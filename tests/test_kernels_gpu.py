@@ -383,6 +383,19 @@ def test_fused_relu_net_widths(cuda, width):
     for l in range(5):
         assert_close(params[2 * l].grad.cpu(), Wd[l].grad, 2e-5, 'dW%d' % l)
         assert_close(params[2 * l + 1].grad.cpu(), bd[l].grad, 2e-5, 'db%d' % l)
+    # the backward chain on the forward's sign-bit words (the default, PSN_ACT_RELU_BITS) and on the activation rows as masks
+    # (PSN_ACT_RELU_MASK) are the same function: every gradient bit for bit
+    assert ops.RELU_SIGN_BITS
+    ops.RELU_SIGN_BITS = False
+    try:
+        p2 = [p.detach().clone().requires_grad_() for p in params]
+        out2 = ops.FusedReluNet.apply(pe, din, skip_at, True, width, None, *p2)
+        (out2 * c_out.to(cuda)).sum().backward()
+    finally:
+        ops.RELU_SIGN_BITS = True
+    assert torch.equal(out2, out)
+    for a, b in zip(p2, params):
+        assert torch.equal(a.grad, b.grad)
 
 
 def test_fused_geo_occupancy(cuda):
