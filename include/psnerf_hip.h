@@ -529,9 +529,10 @@ int psn_mask_count(const unsigned char* mask_a, const unsigned char* mask_b, int
  *   stage2/model/renderer.py:125, without a host synchronisation), idx[ns .. cap) = idx[ns - 1]: a FIXED-size list whose
  *   dead tail repeats the last surface pixel (0 for an empty mask); count[0] (may be NULL) = ns as a float.  A list longer than
  *   cap is truncated.  Kernels that read such a list treat entries behind the first of equal neighbours as dead rows
- *   (psn_gather_rows_valid); psn_inverse_index maps a pixel to the FIRST of equal entries. */
+ *   (psn_gather_rows_valid); psn_inverse_index maps a pixel to the FIRST of equal entries; count (device float [1], or NULL = ns):
+ *   only the first count[0] entries of idx are real -- an EMPTY mask then gives no pixel a row. */
 int psn_surface_index(const unsigned char* mask, int64_t n, int64_t cap, int64_t* idx, float* count, void* stream);
-int psn_inverse_index(const int64_t* idx, int64_t ns, int64_t n_pix, int* inv, void* stream);
+int psn_inverse_index(const int64_t* idx, int64_t ns, int64_t n_pix, int* inv, const float* count, void* stream);
 #define PSN_ADAM_MAX_SEGS 16
 typedef struct {
     int64_t offset, grad_offset, n;    /* elements [offset, offset + n) of param / exp_avg / exp_avg_sq, [grad_offset, ..+n) of grad */

@@ -226,9 +226,14 @@ __global__ __launch_bounds__(1024) void mask_count_kernel(const unsigned char* _
     }
 }
 // inv[p] = the position of pixel p in the ASCENDING list idx[0 .. ns), or -1: fill + arange + index_put in torch
-__global__ __launch_bounds__(256) void inverse_index_kernel(const int64_t* __restrict__ idx, int64_t ns, int64_t n_pix, int* __restrict__ inv) {
+__global__ __launch_bounds__(256) void inverse_index_kernel(const int64_t* __restrict__ idx, int64_t ns, int64_t n_pix, int* __restrict__ inv,
+                                                            const float* __restrict__ count) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pix) return;
+    if (count != nullptr) {  // a list padded to a fixed length: only its first count[0] entries are real (0: no pixel has a row)
+        const int64_t c = (int64_t)count[0];
+        ns = c < ns ? c : ns;
+    }
     int64_t lo = 0, hi = ns;  // first position with idx[pos] >= p
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -358,11 +363,11 @@ extern "C" int psn_mask_count(const unsigned char* mask_a, const unsigned char* 
     return PSN_OK;
 }
 
-extern "C" int psn_inverse_index(const int64_t* idx, int64_t ns, int64_t n_pix, int* inv, void* stream) {
+extern "C" int psn_inverse_index(const int64_t* idx, int64_t ns, int64_t n_pix, int* inv, const float* count, void* stream) {
     using namespace psn;
     PSN_CHECK_ARG((idx || ns == 0) && inv && ns >= 0 && n_pix >= 0 && ns < (1ll << 31), "inverse_index: bad arguments");
     if (n_pix == 0) return PSN_OK;
-    hipLaunchKernelGGL(inverse_index_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, ns, n_pix, inv);
+    hipLaunchKernelGGL(inverse_index_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, ns, n_pix, inv, count);
     PSN_CHECK_LAUNCH("inverse_index");
     return PSN_OK;
 }

@@ -170,7 +170,7 @@ SIGNATURES = {
     'psn_copy2d_group': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_copy_bytes_group': (i32, [i32, ctypes.c_void_p, c_f]),
     'psn_mask_count': (i32, [c_f, c_f, i64, c_f, c_f]),
-    'psn_inverse_index': (i32, [c_f, i64, i64, c_f, c_f]),
+    'psn_inverse_index': (i32, [c_f, i64, i64, c_f, c_f, c_f]),
     'psn_adam_flat': (i32, [c_f, c_f, c_f, c_f, i32, ctypes.c_void_p, f32, f32, f32, f32, c_f]),
     'psn_adam_flat_dev': (i32, [c_f, c_f, c_f, c_f, i32, ctypes.c_void_p, f32, f32, f32, f32, c_f, c_f]),
     'psn_weight_norm_fwd': (i32, [i32, ctypes.c_void_p, c_f]),
@@ -420,11 +420,14 @@ def mask_count(mask_a, mask_b=None, out=None):
     return out
 
 
-def inverse_index(idx, n_pixels):
-    """Pixel -> row map of an ascending index list: [n_pixels] int32, -1 where the pixel is not in idx (one launch)."""
+def inverse_index(idx, n_pixels, count=None):
+    """Pixel -> row map of an ascending index list: [n_pixels] int32, -1 where the pixel is not in idx (one launch).  count
+    (float32 [1] on the device): the list is padded to a fixed length and only its first count[0] entries are real."""
     assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 1
+    assert count is None or (count.is_cuda and count.dtype == torch.float32 and count.numel() == 1)
     inv = torch.empty(n_pixels, device=idx.device, dtype=torch.int32)
-    _check(_lib.psn_inverse_index(idx.data_ptr(), idx.numel(), n_pixels, inv.data_ptr(), _stream()), 'inverse_index')
+    _check(_lib.psn_inverse_index(idx.data_ptr(), idx.numel(), n_pixels, inv.data_ptr(), None if count is None else count.data_ptr(), _stream()),
+           'inverse_index')
     return inv
 
 

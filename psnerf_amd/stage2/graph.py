@@ -59,8 +59,8 @@ class GraphedTrainStep(object):
         psn_gather_rows_valid); the gradient-free shading rows among them -- 92 % of the rows of the BEAR step -- are not even
         evaluated (the visibility launch reads the count on the device, psn_mlp_infer_padded), the others are: (N - Ns) / Ns
         more rows in the small networks, the supervision rows, shading and losses, and split-K sums in a different order than
-        the unpadded step (equal to rounding, not bit for bit).  An EMPTY mask renders pixel 0 into the dense outputs (losses
-        and gradients are unaffected: they are masked).  ``pad_multiple`` = k > 0: for batches that bring their 'surface_idx'
+        the unpadded step (equal to rounding, not bit for bit).  An EMPTY mask gives no pixel a row (the pixel -> row map reads the
+        count too): dense outputs, losses and gradients are those of the eager step on the empty batch.  ``pad_multiple`` = k > 0: for batches that bring their 'surface_idx'
         along (handoff.ViewSampler, the benchmark: the count is then known on the HOST), the list is padded to the next
         multiple of k instead -- at most k - 1 dead rows, one graph per capacity that occurs (``max_graphs``)."""
         assert isinstance(step.sg_optimizer, FlatAdam) and isinstance(step.light_optimizer, RowSparseAdam) and step.FUSED_LOSSES, \

@@ -595,7 +595,7 @@ class PSNetwork(nn.Module):
         done = {}
         if with_rows:
             if idx.is_cuda and idx.dtype == torch.int64:
-                inv = hip.inverse_index(idx.contiguous(), n_pix)  # pixel -> surface row or -1, one launch (idx is ascending)
+                inv = hip.inverse_index(idx.contiguous(), n_pix, count=input.get('surface_count'))  # pixel -> surface row or -1, one launch (idx is ascending)
             else:
                 inv = torch.full((n_pix,), -1, dtype=torch.int32, device=device)
                 inv[idx] = torch.arange(ns, dtype=torch.int32, device=device)

@@ -130,11 +130,12 @@ def test_surface_index_is_nonzero_padded_with_the_last_entry(cuda, n):
         assert float(cnt) == float(k)
         assert torch.equal(idx[:k], ref)
         assert bool((idx[k:] == (ref[-1] if k else 0)).all())
+        want = torch.full((n,), -1, dtype=torch.int32, device=cuda)
+        want[ref] = torch.arange(k, dtype=torch.int32, device=cuda)
         if k:
-            inv = hip.inverse_index(idx, n)
-            want = torch.full((n,), -1, dtype=torch.int32, device=cuda)
-            want[ref] = torch.arange(k, dtype=torch.int32, device=cuda)
-            assert torch.equal(inv, want)
+            assert torch.equal(hip.inverse_index(idx, n), want)
+        # with the device-side count only the real entries map: an EMPTY mask gives no pixel a row (without it pixel 0 would get row 0)
+        assert torch.equal(hip.inverse_index(idx, n, count=cnt), want)
 
 
 @pytest.mark.parametrize('ns,live', [(1000, 517), (1024, 0), (1024, 1024), (4096, 3700), (640, 64)])
@@ -270,3 +271,35 @@ def test_pad_multiple_shares_a_graph_per_capacity(cuda):
     assert np.isfinite(lg).all()
     rel = np.abs(lg - le) / np.abs(le)
     assert rel[0] <= 1e-6 and rel.max() <= 2e-3, rel
+
+
+def test_padded_graph_with_an_empty_surface_mask(cuda):
+    """A batch WITHOUT surface pixels through the padded graph (the list is n x pixel 0, the count on the device is 0): no pixel
+    gets a row, so the dense outputs are the constant fills of the eager step on the same batch, and nothing is trained by it --
+    the parameters after the step equal those of the eager step."""
+    from psnerf_amd.stage2.graph import GraphedTrainStep
+    N, L, V = 2048, 8, 4
+    res = {}
+    for mode in ('eager', 'graph'):
+        step, NL = _make(cuda, 5001)
+        run = GraphedTrainStep(step, warmup=1, pad_to_pixels=True) if mode == 'graph' else step
+        for it in range(4):
+            inp, gt = stage2_inputs(N, L, V, seed=600 + it, surface_frac=(0.8, 0.7, 0.0, 0.75)[it])
+            if it == 2:
+                inp['object_mask'] = torch.zeros_like(inp['object_mask'])
+            l_slt = torch.randperm(NL, generator=torch.Generator().manual_seed(it))[:L].to(cuda)
+            ns = int(inp['surface_mask'].sum())
+            nz = torch.zeros(N, 3)
+            nz[:ns] = torch.randn(ns, 3, generator=torch.Generator().manual_seed(50 + it)) * 0.01
+            noise = {'xyz': (nz if mode == 'graph' else nz[:ns]).to(cuda)}
+            terms, out = run.step({k: v.to(cuda) for k, v in inp.items()}, {k: v.to(cuda) for k, v in gt.items()}, l_slt, train_order=False, noise=noise)
+            if it == 2:
+                res[mode] = ({k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}, float(terms['total'].detach()),
+                             {k: v.detach().clone() for k, v in step.model.state_dict().items()})
+        if mode == 'graph':
+            assert run.n_replays >= 2
+    (o_e, t_e, _), (o_g, t_g, _) = res['eager'], res['graph']
+    assert t_e == t_g == 0.0 or abs(t_e - t_g) <= 1e-7
+    for k in o_e:
+        if k in o_g and o_e[k].shape == o_g[k].shape:
+            assert torch.equal(o_e[k], o_g[k]), k
