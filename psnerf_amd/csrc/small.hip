@@ -214,7 +214,24 @@ __global__ __launch_bounds__(1024) void mask_count_kernel(const unsigned char* _
                                                           float* __restrict__ out) {
     __shared__ int part[16];
     int c = 0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) c += (a[i] != 0 && (b == nullptr || b[i] != 0)) ? 1 : 0;
+    int64_t done = 0;
+    if (((((uintptr_t)a) | ((uintptr_t)b)) & 7) == 0) {
+        // eight mask bytes per load (one byte per load and 32 dependent-latency iterations per thread took 28 us at 32768 pixels);
+        // high bit of every NON-ZERO byte: ((x & 0x7f..) + 0x7f..) | x
+        const unsigned long long lo7 = 0x7f7f7f7f7f7f7f7full, hi1 = 0x8080808080808080ull;
+        const int64_t n8 = n >> 3;
+        for (int64_t i = threadIdx.x; i < n8; i += 1024) {
+            const unsigned long long x = reinterpret_cast<const unsigned long long*>(a)[i];
+            unsigned long long m = (((x & lo7) + lo7) | x) & hi1;
+            if (b != nullptr) {
+                const unsigned long long y = reinterpret_cast<const unsigned long long*>(b)[i];
+                m &= (((y & lo7) + lo7) | y);
+            }
+            c += __popcll(m);
+        }
+        done = n8 << 3;
+    }
+    for (int64_t i = done + threadIdx.x; i < n; i += 1024) c += (a[i] != 0 && (b == nullptr || b[i] != 0)) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;

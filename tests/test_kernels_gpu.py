@@ -1106,6 +1106,11 @@ def test_mask_count_and_inverse_index_equal_torch(cuda, n):
     assert float(hip.mask_count(a, b)) == float((a & b).sum())
     assert float(hip.mask_count(a)) == float(a.sum())
     assert hip.mask_count(a, b).dtype == torch.float32 and hip.mask_count(a, b).shape == (1,)
+    if n > 9:  # unaligned views (the byte path) and masks whose true bytes are not 1 (a uint8 buffer viewed as bool)
+        assert float(hip.mask_count(a[1:], b[1:])) == float((a[1:] & b[1:]).sum())
+        raw = torch.randint(0, 256, (n,), generator=g, dtype=torch.uint8).to(cuda)
+        raw[::3] = 0
+        assert float(hip.mask_count(raw.view(torch.bool), a)) == float(((raw != 0) & a).sum())
     idx = a.nonzero(as_tuple=True)[0]
     inv = hip.inverse_index(idx, n)
     ref = torch.full((n,), -1, dtype=torch.int32, device=cuda)
