@@ -48,4 +48,8 @@ for CASE in "4096 graph" "32768"; do
     rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$N -o t -- python3 $R/tools/dbg/trace_step.py $CASE > /dev/null 2>&1
     python3 $R/tools/dbg/trace_step_analyse.py $(find /tmp/tl_$N -name '*kernel_trace.csv' | head -1) > $O/timeline_${N}.txt 2>&1
 done
+# stage 1: the rank shards of the ray-parallel step (4096 training rays over 1 / 2 / 4 / 8 ranks) on this one GPU
+for RAYS in 4096 2048 1024 512; do
+    python3 $R/tools/bench_stage1.py --rays $RAYS --steps 30 --warmup 5 2>/dev/null | tail -1
+done > $O/stage1_rank_shards.jsonl
 ls -la $O
