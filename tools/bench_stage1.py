@@ -16,7 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rays', type=int, default=4096)
     ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=5)  # (the first steps of a new shape are slow: allocator growth, pack and workspace caches)
     ap.add_argument('--cpu', action='store_true')
     ap.add_argument('--compact-secant', action='store_true', help='round-1 secant (A/B)')
     args = ap.parse_args()

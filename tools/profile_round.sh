@@ -12,7 +12,7 @@ mkdir -p "$O"
 export TMPDIR=/tmp
 cd /tmp
 python3 $R/bench.py > $O/bench_stage2.json 2> $O/bench_stage2.err
-python3 $R/tools/bench_stage1.py --steps 10 --warmup 3 > $O/bench_stage1.json 2> /dev/null
+python3 $R/tools/bench_stage1.py --steps 20 --warmup 5 > $O/bench_stage1.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps2 -o s2 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-stage1 --no-extra > /dev/null 2>&1
 cp $(find /tmp/ps2 -name '*kernel_stats*' | head -1) $O/bench_stage2_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps1 -o s1 -- python3 $R/tools/bench_stage1.py --steps 3 --warmup 1 > /dev/null 2>&1
