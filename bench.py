@@ -170,7 +170,7 @@ def cpu_baseline(n_pixels=4096, steps=3):
 
 
 # ----------------------------------------------------------------------------------------------- stage 1 (configs[1])
-def stage1_measure(device, steps=10, warmup=3, rays=4096):
+def stage1_measure(device, steps=10, warmup=5, rays=4096):
     """BASELINE configs[1]: stage-1 BEAR train step, 4096 rays x 128 samples (96 inner + 32 outer, it > 5000), 256 march
     steps + 8 secant, geometric-init weights.  Per-kernel numbers from HIP events on the launch stream."""
     import torch
@@ -188,6 +188,7 @@ def stage1_measure(device, steps=10, warmup=3, rays=4096):
     tr = Trainer(ren, FlatAdam(net.parameters(), lr=1e-4), cfg, device=device)
     for _ in range(warmup):
         tr.train_step(batch, it=it)
+    settle_gc()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -260,11 +261,22 @@ def stage1_measure(device, steps=10, warmup=3, rays=4096):
 
 
 # ----------------------------------------------------------------------------------------------- cfg 4 (strong scaling of cfg 3)
+def settle_gc():
+    """Full collection + gc.freeze() in front of a timed region: the interpreter's cyclic collector stays ON, but the ~270k objects
+    that exist by now (modules, torch, the model) move to the permanent generation, so that a generation-2 pass that happens to fall
+    into the region walks the step's own garbage only -- one such pass over everything was measured at 70 ms
+    (tools/dbg/gc_probe.py), three steps' worth of a 0.5-s region."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def time_steps(fn, steps, warmup, world, device):
     import torch
     import torch.distributed as dist
     for _ in range(warmup):
         fn()
+    settle_gc()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -515,6 +527,7 @@ def main():
         for _ in range(warmup):
             step.step(inp, gt, l_slt, train_order=False)
         hip.PROFILE_EVENTS = None
+        settle_gc()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -41,6 +41,9 @@ def main():
         batch_d = {k: v.to(dev) for k, v in batch.items()}
         for _ in range(args.warmup):
             terms = tr.train_step(batch_d, it=it)
+        import gc
+        gc.collect()
+        gc.freeze()  # (as bench.settle_gc: a generation-2 pass inside the timed region then walks the steps' own garbage only)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
