@@ -24,6 +24,12 @@ step = bench.make_step(dev)
 inp, gt = stage2_inputs(1024, 96, 8, seed=100, device=dev, with_surface_idx=True)
 l_slt = torch.arange(96, device=dev) + 288
 for _ in range(5): step.step(inp, gt, l_slt, train_order=False)
+if os.environ.get('FREEZE') == '1':
+    import gc
+    gc.collect(); gc.freeze()
+elif os.environ.get('FREEZE') == 'off':
+    import gc
+    gc.disable()
 torch.cuda.synchronize(); acc.clear()
 t0 = time.perf_counter()
 for _ in range(100): step.step(inp, gt, l_slt, train_order=False)

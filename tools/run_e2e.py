@@ -111,6 +111,10 @@ def main():
     s1_losses = []
     t0 = time.time()
     for it in range(args.s1_steps):
+        if it == 5:  # (a generation-2 pass of the cyclic collector over the whole process is ~70 ms)
+            import gc
+            gc.collect()
+            gc.freeze()
         terms = tr1.train_step(batches[it % args.views], it=it)
         s1_losses.append(float(terms['loss'].detach()))
     torch.cuda.synchronize()
@@ -199,6 +203,10 @@ def main():
     s2_losses, phases = [], []
     t0 = time.time()
     for it in range(args.s2_steps):
+        if it == 5:
+            import gc
+            gc.collect()
+            gc.freeze()
         if it == switch:
             step.cur_iter = 5000  # jump to the train_fix switch (trainer.py:485-513) instead of running 5000 iterations
         vidx, mi, gt, l_slt = ds.batch(it % args.views, device=dev)
