@@ -653,6 +653,16 @@ int psn_mlp_infer_x3_grouped(const PsnBf16Desc* desc, const uint16_t* packed_w, 
 int psn_mlp_infer_x3_occ(const PsnBf16Desc* desc, const uint16_t* packed_w, const uint16_t* bias_steps, const float* final_bias,
                          const float* points, int64_t n_rows, const long long* n_rows_dev, const int64_t* out_rows, int pe_octaves,
                          float pe_scale, int skip_layer, int pe_first, float* out, void* stream);
+/* The ray-march sweep of stage1/model/rendering.py:447-462 on the split-bf16 engine (opt-in experiment; psn_march_sweep is the exact
+ * form): occ [n_rays, n_steps] = sigmoid(-10 logit) at the points origin + dir (near (1 - u_m) + far u_m), formed and encoded in the
+ * kernel; a workgroup = 128 consecutive steps of one ray, block-major.  skip [n_rays] int32, zeroed by the caller (or NULL = every
+ * block is evaluated): the blocks behind a ray's first sign change are left out -- their entries stay unwritten, and nothing
+ * reads them (psn_first_crossing stops at the first crossing).  n_steps a multiple of 128; desc / packed_w / bias_steps /
+ * final_bias / skip_layer / pe_first as for psn_mlp_infer_x3_occ.  n_blocks (or NULL): counts the evaluated blocks. */
+int psn_march_sweep_x3(const PsnBf16Desc* desc, const uint16_t* packed_w, const uint16_t* bias_steps, const float* final_bias,
+                       const float* origin, const float* dir, const float* far, const float* u, const float* omu, float near,
+                       int64_t n_rays, int n_steps, float tau, int pe_octaves, float pe_scale, int skip_layer, int pe_first,
+                       int* skip, float* occ, unsigned long long* n_blocks, void* stream);
 
 
 /* ------------------------------------------------------------------------

@@ -48,6 +48,17 @@ struct X3Args {
     int pe_octaves; float pe_scale;
     int skip_layer;                // hidden layer whose input is cat[h, pe] / sqrt(2) (stage1/model/network.py:90-91), -1: none
     int pe_first;                  // first input feature of that layer that is a positional-encoding column (217)
+    // sweep form (psn_march_sweep_x3; stage1/model/rendering.py:447-462): the rows are (ray, step) pairs, a workgroup = 128
+    // consecutive steps of ONE ray, workgroups in block-major order; the point is formed in the prologue (n_steps > 0)
+    const float* ray_o;            // [n_rays][3]
+    const float* ray_d;            // [n_rays][3]
+    const float* far;              // [n_rays] sphere exit depth
+    const float* u;                // [n_steps] linspace(0, 1, n_steps)
+    const float* omu;              // [n_steps] 1 - u
+    float near, tau;
+    int n_steps;
+    int* skip;                     // [n_rays] or nullptr: INT_MAX - b = block b of the ray holds a sign change (lowest b wins), 0 = none
+    unsigned long long* n_blocks;  // optional: counts the evaluated 128-step blocks (measurement only)
 };
 
 constexpr int kX3Piece = 1024;
@@ -552,10 +563,26 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3p_kernel(X3Args g) {
     const int n_hidden = g.d.n_hidden;
     unsigned group = 0, tile = blockIdx.x;
     long long n_rows_eff = 0;
+    const bool sweep = OCC && g.n_steps > 0;
+    long long m_ray = 0;
+    int m_blk = 0;
     if constexpr (OCC) {
         n_rows_eff = g.n_rows;
-        if (g.n_rows_dev != nullptr) { const long long nd = *g.n_rows_dev; n_rows_eff = nd < n_rows_eff ? nd : n_rows_eff; }
-        if ((long long)blockIdx.x * (kX3Waves * 32) >= n_rows_eff) return;
+        if (sweep) {
+            // (ray, block) of this workgroup, block-major; a block BEHIND the lowest flagged block of its ray leaves here -- the flag was
+            // raised by a workgroup that may have run on another XCD (agent scope), see mlp_infer_kernel<.., 3>
+            const long long n_rays = g.n_rows / g.n_steps;
+            m_ray = (long long)blockIdx.x % n_rays;
+            m_blk = (int)((long long)blockIdx.x / n_rays);
+            if (m_blk > 0 && g.skip != nullptr) {
+                const int s = __hip_atomic_load(g.skip + m_ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (s != 0 && 0x7fffffff - s < m_blk) return;
+            }
+            if (g.n_blocks != nullptr && threadIdx.x == 0) atomicAdd(g.n_blocks, 1ull);
+        } else {
+            if (g.n_rows_dev != nullptr) { const long long nd = *g.n_rows_dev; n_rows_eff = nd < n_rows_eff ? nd : n_rows_eff; }
+            if ((long long)blockIdx.x * (kX3Waves * 32) >= n_rows_eff) return;
+        }
     } else {
         group = blockIdx.x / g.tiles_per_group;
         tile = blockIdx.x - group * g.tiles_per_group;
@@ -571,14 +598,22 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3p_kernel(X3Args g) {
     if (l1_bias) { x3_dma_piece(wptr, xsmem, first_bias, wave, lane, 12); x3_dma_piece(wptr, xsmem, first_bias, wave, lane, 13); }
     wptr += kX3StageBytes;
 
-    const unsigned n = tile * (unsigned)(kX3Waves * 32) + wave * 32 + ln;
+    const int m_step = m_blk * (kX3Waves * 32) + wave * 32 + ln;  // sweep: the step of this lane's row
+    const unsigned n = sweep ? (unsigned)(m_ray * g.n_steps + m_step) : tile * (unsigned)(kX3Waves * 32) + wave * 32 + ln;
     const bool valid = OCC ? (long long)n < n_rows_eff : n < g.rows_per_group;
     const unsigned row = OCC ? n : group * g.rows_per_group + n;
     const float* urow = OCC ? nullptr : g.U + (size_t)(valid ? n : g.rows_per_group - 1) * init_stride + 4 * lh;
     float* pe_row = reinterpret_cast<float*>(xsmem + 2 * kX3BufBytes) + (wave * 32 + ln) * kX3PeStride;
     if constexpr (OCC) {
         float q[3] = {0.f, 0.f, 0.f};
-        if (valid) { q[0] = g.points[(size_t)n * 3]; q[1] = g.points[(size_t)n * 3 + 1]; q[2] = g.points[(size_t)n * 3 + 2]; }
+        if (sweep) {
+            // sample_points_kernel (csrc/sample.hip), miss profile: d = near (1 - u) + far u, p = origin + dir d; products and sums
+            // rounded separately (-ffp-contract=off): the point has the bits of the table the two-launch path writes
+            const float d = g.near * g.omu[m_step] + g.far[m_ray] * g.u[m_step];
+            q[0] = g.ray_o[m_ray * 3 + 0] + g.ray_d[m_ray * 3 + 0] * d;
+            q[1] = g.ray_o[m_ray * 3 + 1] + g.ray_d[m_ray * 3 + 1] * d;
+            q[2] = g.ray_o[m_ray * 3 + 2] + g.ray_d[m_ray * 3 + 2] * d;
+        } else if (valid) { q[0] = g.points[(size_t)n * 3]; q[1] = g.points[(size_t)n * 3 + 1]; q[2] = g.points[(size_t)n * 3 + 2]; }
         const int n_pairs = 3 * g.pe_octaves, half = (n_pairs + 1) / 2;
         for (int pi = lh * half; pi < (lh == 0 ? half : n_pairs); ++pi) {
             const int f = pi / 3, c = pi - 3 * f;
@@ -718,6 +753,7 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3p_kernel(X3Args g) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bact[0][ks], c, 0, 0, 0);
         }
         const int n_out = g.d.n_out;
+        float occ0 = 0.0f;  // output 0 of this lane's row (lanes of the lower half)
         if (valid) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
@@ -728,6 +764,22 @@ __global__ __launch_bounds__(256, 1) void mlp_infer_x3p_kernel(X3Args g) {
                     else if (g.d.out_act == PSN_OUT_OCC) x = sigmoidf_(x * -10.0f);
                     const int64_t orow = (OCC && g.out_rows != nullptr) ? g.out_rows[row] : (int64_t)row;
                     g.out[orow * n_out + m] = x;
+                    if (v == 0) occ0 = x;
+                }
+            }
+        }
+        if constexpr (OCC) {
+            if (sweep && g.skip != nullptr) {
+                // val_m = occupancy - tau of the block's 128 steps through LDS (the encoding area: its rows were consumed by the skip
+                // layer long ago); a negative product of neighbours, or a ray that does not start in free space, decides the ray:
+                // its later blocks need not be evaluated (the semantics of mlp_infer_kernel<.., 3>, with 128-step blocks)
+                float* xch = reinterpret_cast<float*>(xsmem + 2 * kX3BufBytes);
+                __syncthreads();
+                if (lh == 0) xch[wave * 32 + ln] = occ0 - g.tau;
+                __syncthreads();
+                if (tid < kX3Waves * 32 - 1) {
+                    const bool hit = (xch[tid] * xch[tid + 1] < 0.0f) || (tid == 0 && m_blk == 0 && !(xch[0] < 0.0f));
+                    if (hit) __hip_atomic_fetch_max(g.skip + m_ray, 0x7fffffff - m_blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -885,5 +937,47 @@ extern "C" int psn_mlp_infer_x3_occ(const PsnBf16Desc* desc, const uint16_t* pac
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kX3Waves * 64), lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer_x3_occ");
+    return PSN_OK;
+}
+
+// The ray-march sweep of stage1/model/rendering.py:447-462 on the split-bf16 engine (opt-in experiment; psn_march_sweep is the
+// exact-fp32 form): occ [n_rays, n_steps] = sigmoid(-10 logit) of the points origin + dir (near (1 - u_m) + far u_m), formed and
+// encoded in the kernel; a workgroup = 128 consecutive steps of one ray, block-major; skip [n_rays] int32 (zeroed by the caller,
+// or NULL: every block is evaluated): the blocks behind a ray's first sign change are left out (their entries stay unwritten --
+// nothing reads them: psn_first_crossing stops at the first crossing).  n_steps a multiple of 128.
+extern "C" int psn_march_sweep_x3(const PsnBf16Desc* desc, const uint16_t* packed_w, const uint16_t* bias_steps, const float* final_bias,
+                                  const float* origin, const float* dir, const float* far, const float* u, const float* omu, float near,
+                                  int64_t n_rays, int n_steps, float tau, int pe_octaves, float pe_scale, int skip_layer, int pe_first,
+                                  int* skip, float* occ, unsigned long long* n_blocks, void* stream) {
+    using namespace psn;
+    PSN_CHECK_ARG(desc && packed_w && bias_steps && final_bias && origin && dir && far && u && omu && occ, "march_sweep_x3: null pointer");
+    const PsnBf16Desc& d = *desc;
+    PSN_CHECK_ARG(d.n_hidden >= 2 && d.n_hidden <= PSN_MLP_MAX_LAYERS && d.n_out == 1 && d.out_act == PSN_OUT_OCC, "march_sweep_x3: the occupancy network (one output, OCC)");
+    PSN_CHECK_ARG(pe_octaves >= 0 && 3 + 6 * pe_octaves <= kX3PeStride, "march_sweep_x3: %d octaves do not fit %d encoding columns", pe_octaves, kX3PeStride);
+    PSN_CHECK_ARG(skip_layer < d.n_hidden && (skip_layer < 1 || (pe_first >= 192 && pe_first + 3 + 6 * pe_octaves <= 256)), "march_sweep_x3: skip_layer=%d pe_first=%d", skip_layer, pe_first);
+    PSN_CHECK_ARG(n_steps >= 128 && n_steps % (kX3Waves * 32) == 0 && n_rays >= 0 && n_rays * (int64_t)n_steps < (1ll << 31),
+                  "march_sweep_x3: n_steps=%d must be a multiple of 128, rays x steps < 2^31", n_steps);
+    PSN_CHECK_ARG(x3_pipelined(), "march_sweep_x3: built for the pipelined kernel only (PSN_X3_PIPE=0 is set)");
+    if (n_rays == 0) return PSN_OK;
+    X3Args a = {};
+    a.d = d;
+    a.w = reinterpret_cast<const unsigned char*>(packed_w);
+    a.bias = reinterpret_cast<const unsigned char*>(bias_steps);
+    a.final_bias = final_bias;
+    a.n_rows = n_rays * (int64_t)n_steps;
+    a.pe_octaves = pe_octaves; a.pe_scale = pe_scale; a.skip_layer = skip_layer < 1 ? -1 : skip_layer; a.pe_first = pe_first;
+    a.out = occ;
+    a.ray_o = origin; a.ray_d = dir; a.far = far; a.u = u; a.omu = omu; a.near = near; a.tau = tau; a.n_steps = n_steps;
+    a.skip = skip; a.n_blocks = n_blocks;
+    const int64_t blocks = n_rays * (n_steps / (kX3Waves * 32));
+    const size_t lds_bytes = 2 * kX3BufBytes + kX3PeBytes;
+    const auto kern = &mlp_infer_x3p_kernel<true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+        set_error("march_sweep_x3: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+        return PSN_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kX3Waves * 64), lds_bytes, (hipStream_t)stream, a);
+    PSN_CHECK_LAUNCH("march_sweep_x3");
     return PSN_OK;
 }

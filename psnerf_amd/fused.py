@@ -555,6 +555,11 @@ class PackedX3Occ(object):
         self.desc, self.w, self.bias_steps, self.final_bias = desc, w, bias_steps, final_bias
         self.skip_layer, self.pe_first, self.macs_per_row = skip_layer, pe_first, macs_per_row
 
+    def march_sweep(self, origin, direction, far, u, omu, near, n_steps, tau, pe_octaves, pe_scale, early_exit=True):
+        """The ray-march sweep (hip.march_sweep_x3): points generated and encoded in the kernel, 128-step blocks with early exit."""
+        return hip.march_sweep_x3(self.desc, self.w, self.bias_steps, self.final_bias, origin, direction, far, u, omu, near, n_steps, tau,
+                                  pe_octaves, pe_scale, self.skip_layer, self.pe_first, early_exit=early_exit, macs_per_row=self.macs_per_row)
+
     def on_points(self, points, pe_octaves, pe_scale, out=None, n_rows_dev=None, out_rows=None):
         return hip.mlp_infer_x3_occ(self.desc, self.w, self.bias_steps, self.final_bias, points, pe_octaves, pe_scale,
                                     self.skip_layer, self.pe_first, out=out, n_rows_dev=n_rows_dev, out_rows=out_rows,

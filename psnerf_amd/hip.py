@@ -183,6 +183,8 @@ SIGNATURES = {
     'psn_x3_pack_bias': (i32, [c_f, i64, c_f, c_f]),
     'psn_mlp_infer_x3_grouped': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, c_f, i64, c_f, i64, c_f, c_f]),
     'psn_mlp_infer_x3_occ': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, c_f, i64, c_f, c_f, i32, f32, i32, i32, c_f, c_f]),
+    'psn_march_sweep_x3': (i32, [ctypes.POINTER(PsnBf16Desc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, i64, i32, f32, i32, f32, i32, i32,
+                                 c_f, c_f, c_f, c_f]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library out of date: fail loudly
@@ -1398,3 +1400,27 @@ def mf_shade_bwd(light_dir, view, normal, albedo, rough, light_int, light_int_sc
                                  _ptr(d_vis, 'd_vis', True), _ptr(d_ldir, 'd_ldir'), _ptr(d_lint, 'd_lint', True),
                                  ws.data_ptr(), _stream()), 'mf_shade_bwd')
     return d_albedo, d_rough, d_normal, d_vis, d_ldir, d_lint
+
+
+def march_sweep_x3(desc, packed_w, bias_steps, final_bias, origin, direction, far, u, omu, near, n_steps, tau, pe_octaves, pe_scale,
+                   skip_layer, pe_first, early_exit=True, macs_per_row=None):
+    """hip.march_sweep on the split-bf16 engine (psn_march_sweep_x3; opt-in experiment): occupancy of the n_steps sweep points of
+    every ray -> (occ [N, n_steps], skip flags [N] int32 or None); blocks of 128 steps behind a ray's first sign change are not
+    evaluated when early_exit (their entries are uninitialised).  n_steps a multiple of 128."""
+    N = origin.shape[0]
+    assert origin.shape == (N, 3) and direction.shape == (N, 3) and far.shape == (N,) and u.numel() == n_steps == omu.numel()
+    for t, nm in ((packed_w, 'packed_w'), (bias_steps, 'bias_steps')):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+            raise RuntimeError('%s: must be a contiguous bfloat16 HIP tensor' % nm)
+    occ = torch.empty(N, n_steps, device=origin.device, dtype=torch.float32)
+    skip = torch.zeros(N, device=origin.device, dtype=torch.int32) if early_exit else None
+    if N == 0:
+        return occ, skip
+    count = torch.zeros(1, device=origin.device, dtype=torch.int64) if PROFILE_EVENTS is not None else None
+    with _Prof('march_sweep_x3', N * n_steps, None if (macs_per_row is None or count is None) else (count, 2.0 * macs_per_row * 128)):
+        _check(_lib.psn_march_sweep_x3(ctypes.byref(desc), packed_w.data_ptr(), bias_steps.data_ptr(), _ptr(final_bias, 'final_bias'),
+                                       _ptr(origin, 'origin'), _ptr(direction, 'direction'), _ptr(far, 'far'), _ptr(u, 'u'), _ptr(omu, 'omu'),
+                                       float(near), N, int(n_steps), float(tau), int(pe_octaves), float(pe_scale), int(skip_layer), int(pe_first),
+                                       None if skip is None else skip.data_ptr(), occ.data_ptr(), None if count is None else count.data_ptr(),
+                                       _stream()), 'march_sweep_x3')
+    return occ, skip

@@ -138,9 +138,16 @@ class Renderer(nn.Module):
             far = sphere_intersection(ray0[:, 0], ray_direction, r=rad)[0][..., 1].contiguous()
         u = self._u(n_steps, dev)
         m = self.model
-        if (self.FUSED_SWEEP and not clip and n_steps % 64 == 0 and ray0.is_cuda and hasattr(m, '_occupancy_packed')
-                and m._hidden_is_256() and getattr(m, 'inference_precision', 'fp32') != 'bf16x6'):
-            # (with the opt-in split-bf16 engine the sweep takes the two-launch form below: self._occ -> model.occupancy)
+        x3 = getattr(m, 'inference_precision', 'fp32') == 'bf16x6'
+        if (self.FUSED_SWEEP and x3 and not clip and n_steps % 128 == 0 and ray0.is_cuda and hasattr(m, '_occupancy_packed_x3')
+                and m._hidden_is_256() and not torch.is_grad_enabled()):
+            # opt-in split-bf16 engine: the same one-launch sweep (points formed in the kernel, early exit per 128-step block)
+            occ, _ = m._occupancy_packed_x3().march_sweep(ray0.reshape(-1, 3).contiguous(), ray_direction.reshape(-1, 3).contiguous(),
+                                                          far.reshape(-1), u[0], u[1], float(depth_range[0]), n_steps, tau, m.octaves_pe,
+                                                          1.0 / m.rescale, early_exit=self.EARLY_EXIT)
+        elif (self.FUSED_SWEEP and not clip and n_steps % 64 == 0 and ray0.is_cuda and hasattr(m, '_occupancy_packed')
+                and m._hidden_is_256() and not x3):
+            # (with the opt-in split-bf16 engine and a step count that is no multiple of 128 the sweep takes the two-launch form below)
             # one launch: sweep points generated and encoded in the occupancy kernel, a workgroup = 64 consecutive steps of
             # one ray, and the blocks behind a ray's first sign change are not evaluated (psn_march_sweep; the reference's
             # result depends on nothing behind it, rendering.py:472-504)

@@ -742,6 +742,68 @@ def test_x3_occupancy_indirect_form_and_gradient_paths_stay_exact(cuda):
         net.inference_precision = 'fp32'
 
 
+@pytest.mark.parametrize('n_steps,n', [(256, 333), (512, 200), (128, 70), (256, 4096)])
+def test_x3_march_sweep_equals_the_two_launch_form_and_exits_early(cuda, n_steps, n):
+    """psn_march_sweep_x3 (the sweep of rendering.py:447-462 on the split-bf16 engine: points formed and encoded in the kernel, a
+    workgroup = 128 steps of one ray, blocks behind a ray's first sign change not evaluated) against the two-launch form on the SAME
+    engine (psn_sample_points + psn_mlp_infer_x3_occ): identical occupancies where both evaluate, identical brackets / masks /
+    refined depths; the flag records the lowest block with a sign change."""
+    from psnerf_amd import hip
+    from psnerf_amd.stage1.rendering import camera_origin, pixel_rays
+    from psnerf_amd.synthetic import stage1_camera
+    cfg, net, ren = _renderer(cuda)
+    net.inference_precision = 'bf16x6'
+    try:
+        h, w = 48, 64
+        K, c2w, S = stage1_camera(cfg, h=h, w=w)
+        gen = torch.Generator().manual_seed(n_steps + n)
+        pix = torch.stack([torch.randint(0, w, (n,), generator=gen).float(), torch.randint(0, h, (n,), generator=gen).float()], -1)[None].to(cuda)
+        cam = camera_origin(n, c2w.to(cuda))
+        rays = pixel_rays(pix, K.to(cuda), c2w.to(cuda))
+        rays = rays / rays.norm(2, 2).unsqueeze(-1)
+        args = (cam, rays, 0.5, [n_steps, n_steps + 1], ren.depth_range, cfg['rendering']['radius'], False)
+        with torch.no_grad():
+            ren.FUSED_SWEEP = False
+            st_ref = ren._march_launch(*args)  # sample_points + the x3 engine on the point tensor
+            d_ref = ren._march_finish(st_ref, 8)
+            ren.FUSED_SWEEP, ren.EARLY_EXIT = True, False
+            st_dense = ren._march_launch(*args)
+            ren.EARLY_EXIT = True
+            st = ren._march_launch(*args)
+            d = ren._march_finish(st, 8)
+            pk = net._occupancy_packed_x3()
+            u = ren._u(n_steps, cuda)
+            far = st['far'].reshape(-1)
+            o3, d3 = cam.reshape(-1, 3).contiguous(), rays.reshape(-1, 3).contiguous()
+            occ_dense, _ = pk.march_sweep(o3, d3, far, u[0], u[1], float(ren.depth_range[0]), n_steps, 0.5, net.octaves_pe, 1.0 / net.rescale, early_exit=False)
+            p_prop = torch.empty(n, n_steps, 3, device=cuda)
+            hip.sample_points(o3, d3, far, p_prop, False, float(ren.depth_range[0]), u)
+            occ_two = pk.on_points(p_prop.reshape(-1, 3), net.octaves_pe, 1.0 / net.rescale).view(n, n_steps)
+            occ_early, skip = pk.march_sweep(o3, d3, far, u[0], u[1], float(ren.depth_range[0]), n_steps, 0.5, net.octaves_pe, 1.0 / net.rescale, early_exit=True)
+    finally:
+        ren.FUSED_SWEEP = ren.EARLY_EXIT = True
+        net.inference_precision = 'fp32'
+    assert torch.equal(occ_dense, occ_two)
+    for key in ('bracket', 'flags'):
+        assert torch.equal(st_ref[key], st_dense[key]) and torch.equal(st_ref[key], st[key]), key
+    assert torch.equal(d_ref, d)
+    hits = (st['flags'] & 1).bool()
+    assert int(hits.sum()) > 10 and int((~hits).sum()) > 10
+    val = occ_dense - 0.5
+    neg = (val[:, :-1] * val[:, 1:]) < 0
+    first = torch.where(neg.any(1), neg.float().argmax(1), torch.full((n,), n_steps - 2, device=cuda, dtype=torch.long))
+    cols = torch.arange(n_steps, device=cuda)[None]
+    needed = cols <= (first[:, None] + 1)
+    needed &= (val[:, :1] < 0) | (cols < 128)
+    assert torch.equal(occ_early[needed], occ_dense[needed])
+    in_block = neg.any(1) & ((first % 128) != 127)
+    assert bool((skip[in_block] != 0).all())
+    free_start = in_block & (val[:, 0] < 0)
+    assert torch.equal((0x7fffffff - skip[free_start]).long(), first[free_start] // 128)
+    if n_steps > 128:
+        assert int((skip != 0).sum()) > 0
+
+
 def test_x3_occupancy_engine_passes_the_march_and_light_visibility_goldens(cuda):
     """Gates of the opt-in engine: with inference_precision = 'bf16x6' the ray march of the golden case
     classifies every ray as the reference does (hit / miss / starts-inside masks EQUAL), the refined depths and the

@@ -56,6 +56,20 @@ for tag, pix, M in (('train_M256_random_pixels', pix_train, 256), ('shape_extrac
             out[name + '_ms'] = round(ms, 3)
         hit = (ref['flags'] & 1).bool()
         out['hit_fraction'] = round(float(hit.float().mean()), 3)
+        # opt-in split-bf16 engine (inference_precision = 'bf16x6'): the same three forms, 128-step blocks
+        net.inference_precision = 'bf16x6'
+        ref6 = None
+        for name, fused, early in (('bf16x6_two_launch_dense', False, False), ('bf16x6_fused_dense', True, False), ('bf16x6_fused_early_exit', True, True)):
+            ren.FUSED_SWEEP, ren.EARLY_EXIT = fused, early
+            ms, st = timeit(lambda: ren._march_launch(*args))
+            if ref6 is None:
+                ref6 = st
+            else:
+                assert torch.equal(ref6['bracket'], st['bracket']) and torch.equal(ref6['flags'], st['flags']), name
+            out[name + '_ms'] = round(ms, 3)
+        out['bf16x6_masks_equal_fp32'] = bool(torch.equal(ref6['flags'], ref['flags']))
+        net.inference_precision = 'fp32'
+        ren.FUSED_SWEEP = ren.EARLY_EXIT = True
     res[tag] = out
     print(tag, out, flush=True)
 print(json.dumps(res))
