@@ -62,7 +62,8 @@ class GraphedTrainStep(object):
         the unpadded step (equal to rounding, not bit for bit).  An EMPTY mask gives no pixel a row (the pixel -> row map reads the
         count too): dense outputs, losses and gradients are those of the eager step on the empty batch.  ``pad_multiple`` = k > 0: for batches that bring their 'surface_idx'
         along (handoff.ViewSampler, the benchmark: the count is then known on the HOST), the list is padded to the next
-        multiple of k instead -- at most k - 1 dead rows, one graph per capacity that occurs (``max_graphs``)."""
+        multiple of k instead -- at most k - 1 dead rows, one graph per capacity that occurs (``max_graphs``).  With either padding an
+        injected ``noise`` (tests; training draws it on the device) has the PADDED row count."""
         assert isinstance(step.sg_optimizer, FlatAdam) and isinstance(step.light_optimizer, RowSparseAdam) and step.FUSED_LOSSES, \
             'GraphedTrainStep needs the device-resident step (FlatAdam, RowSparseAdam, fused losses)'
         self.step_obj, self.warmup, self.max_graphs = step, int(warmup), int(max_graphs)
