@@ -257,6 +257,28 @@ def stage1_measure(device, steps=10, warmup=5, rays=4096):
                          'frac': round(by / ms * 1e-6 / PEAK_HBM_GBS, 4), 'us_per_launch': round(ms / len(cp) * 1e3, 1),
                          'note': '4096 rays = 10-19 MB per launch: launch/latency-bound at this size; the HBM roofline of '
                                  'the kernel is measured at 2M rays by tools/bench_composite.py (profiles/)'}
+    # EXPERIMENT, never the stage-1 number above: the gradient-free ray march of the step (rendering.py:410-523 runs under no_grad)
+    # on the split-bf16 occupancy engine (psn_march_sweep_x3); every differentiated launch stays exact f32
+    try:
+        net.inference_precision = 'bf16x6'
+        for _ in range(3):
+            tr.train_step(batch, it=it)
+        settle_gc()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            terms6 = tr.train_step(batch, it=it)
+        torch.cuda.synchronize()
+        dt6 = (time.perf_counter() - t0) / steps
+        out['bf16x6_experiment'] = {'value': round(rays * S / dt6, 1), 'unit': 'ray-samples/s', 'ms_per_step': round(dt6 * 1e3, 3), 'steps': steps,
+                                    'loss': round(float(terms6['loss'].detach()), 6),
+                                    'dtype': 'f32 emulated on the bf16 matrix pipe (3 x bf16 split operands, 6 partial products, f32 accumulate)',
+                                    'scope': "NeuralNetwork.inference_precision = 'bf16x6': the ray-march sweep only (gradient-free); the secant root "
+                                             'finder, the render forward, both backward passes and the weight gradients: exact f32'}
+    except Exception as e:  # noqa: BLE001
+        out['bf16x6_experiment'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+    finally:
+        net.inference_precision = 'fp32'
     return out
 
 
