@@ -151,7 +151,7 @@ def bear_conf(**overrides):
     c = {
         'train': dict(render_model='sgbasis', nbasis=9, specular_rgb=True, visibility=True,
                       vis_loss=True, light_vis_detach=True, vis_rgb_detach=True, normal_mlp=True,
-                      normal_joint=True, shape_pregen=True),
+                      normal_joint=True, shape_pregen=True, light_inten_train=True),  # (bear.conf:17; absent in bunny / armadillo.conf)
         'brdf': dict(net=dict(n_freqs_xyz=10, mlp_width=128, mlp_depth=4, mlp_skip_at=2, xyz_jitter_std=0.01),
                      sgnet=dict(mlp_width=64, mlp_depth=2, mlp_skip_at=-1),
                      fresnel_f0=0.05, light_intensity=2.0),
@@ -418,7 +418,10 @@ class TrainStep(object):
     train_fix schedule (trainer.py:485-513), without datasets/checkpoints/plots.
 
     ``light_para`` [n_lights_total,3] and ``light_inten_para`` [n_lights_total,1]
-    are sparse embeddings optimised with SparseAdam (trainer.py:126-168)."""
+    are sparse embeddings optimised with SparseAdam (trainer.py:126-168); the intensity
+    table exists only under ``train.light_inten_train`` (trainer.py:38,154-163: the synthetic
+    objects' configurations leave it out and the model then uses its scalar
+    brdf.light_intensity, renderer.py:202)."""
 
     def __init__(self, model, conf, n_lights_total, light_init, lr=5e-4, light_lr=5e-4, light_inten_lr=1e-3,
                  milestones=(), gamma=0.5, loss_kwargs=None, normal_loss_kwargs=None, vis_plus=None):
@@ -440,11 +443,15 @@ class TrainStep(object):
         self.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.sg_optimizer, list(milestones), gamma=gamma)
         self.light_para = nn.Embedding(n_lights_total, 3, sparse=True)
         self.light_para.weight.data.copy_(light_init)
+        self.light_inten_train = conf.get_bool('train.light_inten_train', default=False)  # trainer.py:38
         self.light_inten_para = nn.Embedding(n_lights_total, 1, sparse=True)
         nn.init.constant_(self.light_inten_para.weight, model.light_int)
-        self.light_optimizer = torch.optim.SparseAdam(
-            [{'params': list(self.light_para.parameters())},
-             {'params': list(self.light_inten_para.parameters()), 'lr': light_inten_lr}], lr=light_lr)
+        groups = [{'params': list(self.light_para.parameters())}]
+        if self.light_inten_train:  # trainer.py:154-163
+            groups.append({'params': list(self.light_inten_para.parameters()), 'lr': light_inten_lr})
+        else:
+            self.light_inten_para.requires_grad_(False)  # (kept as a constant table: never read by the step)
+        self.light_optimizer = torch.optim.SparseAdam(groups, lr=light_lr)
         self.light_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.light_optimizer, list(milestones),
                                                                     gamma=gamma)
         self.cur_iter = 0
@@ -460,21 +467,24 @@ class TrainStep(object):
             self.model.albedo_net.eval().requires_grad_(False)
             self.model.rough_net.eval().requires_grad_(False)
             self.light_para.requires_grad_(False)
-            self.light_inten_para.requires_grad_(False)
+            if self.light_inten_train:  # trainer.py:502-503
+                self.light_inten_para.requires_grad_(False)
         elif self.cur_iter == 5000:
             (self.loss.sg_rgb_weight, self.loss.albedo_smooth_weight,
              self.loss.rough_smooth_weight, self.loss.vis_weight) = self._ori
             self.model.albedo_net.train().requires_grad_(True)
             self.model.rough_net.train().requires_grad_(True)
             self.light_para.requires_grad_(True)
-            self.light_inten_para.requires_grad_(True)
+            if self.light_inten_train:  # trainer.py:513-514
+                self.light_inten_para.requires_grad_(True)
 
     def step(self, model_input, ground_truth, l_slt, train_order=True, noise=None, vidx=None):
         if train_order:
             self.train_fix()
         model_input = dict(model_input)
         model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
-        model_input['light_intensity'] = self.light_inten_para(l_slt)
+        if self.light_inten_train:  # trainer.py:378-379
+            model_input['light_intensity'] = self.light_inten_para(l_slt)
         if self.vis_plus is not None and vidx is not None:
             # trainer.py:377 is overwritten by :384-392 when train.vis_plus is set
             vp = self.vis_plus

@@ -70,7 +70,9 @@ def save_stage2(step, checkpoints_path, epoch):
     os.makedirs(d, exist_ok=True)
     for fn in (str(epoch) + '.pth', 'latest.pth'):
         torch.save({'epoch': epoch, 'light_state_dict': step.light_para.state_dict(),
-                    'light_inten_state_dict': step.light_inten_para.state_dict()}, os.path.join(d, fn))
+                    # (trainer.py:250,254: the table's state, or -- intensities not trained -- the model's scalar)
+                    'light_inten_state_dict': step.light_inten_para.state_dict() if getattr(step, 'light_inten_train', True)
+                    else step.model.light_int}, os.path.join(d, fn))
 
 
 def load_stage2(step, checkpoints_path, checkpoint='latest', map_location=None):

@@ -75,13 +75,20 @@ class TrainStep(object):
         # dense gradients + RowSparseAdam = SparseAdam's update of the touched rows without coalesce() (optim.py)
         self.light_para = nn.Embedding(n_lights_total, 3, sparse=False).to(device)
         self.light_para.weight.data.copy_(light_init)
+        # the per-light intensity table is trained only under train.light_inten_train (stage2/trainer.py:38,154-163; the
+        # DiLiGenT-MV objects set it, the synthetic bunny / armadillo configurations do not: the model then shades with its scalar
+        # brdf.light_intensity, renderer.py:202).  The table itself always exists (checkpoint layout); untrained it is a constant
+        # that the step never reads.
+        self.light_inten_train = conf.get_bool('train.light_inten_train', default=False)
         self.light_inten_para = nn.Embedding(n_lights_total, 1, sparse=False).to(device)
         nn.init.constant_(self.light_inten_para.weight, model.light_int)
         lr_l = conf.get_float('train.light_learning_rate', default=5e-4)
-        self.light_optimizer = RowSparseAdam(
-            [{'params': list(self.light_para.parameters())},
-             {'params': list(self.light_inten_para.parameters()),
-              'lr': conf.get_float('train.light_inten_lr', default=lr_l)}], lr=lr_l)
+        groups = [{'params': list(self.light_para.parameters())}]
+        if self.light_inten_train:
+            groups.append({'params': list(self.light_inten_para.parameters()), 'lr': conf.get_float('train.light_inten_lr', default=lr_l)})
+        else:
+            self.light_inten_para.requires_grad_(False)
+        self.light_optimizer = RowSparseAdam(groups, lr=lr_l)
         self.light_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.light_optimizer, list(milestones), gamma=gamma)
         self.cur_iter = 0
 
@@ -96,14 +103,16 @@ class TrainStep(object):
             self.model.albedo_net.eval().requires_grad_(False)
             self.model.rough_net.eval().requires_grad_(False)
             self.light_para.requires_grad_(False)
-            self.light_inten_para.requires_grad_(False)
+            if self.light_inten_train:  # trainer.py:502-503
+                self.light_inten_para.requires_grad_(False)
         elif self.cur_iter == 5000:
             (self.loss.sg_rgb_weight, self.loss.albedo_smooth_weight,
              self.loss.rough_smooth_weight, self.loss.vis_weight) = self._ori
             self.model.albedo_net.train().requires_grad_(True)
             self.model.rough_net.train().requires_grad_(True)
             self.light_para.requires_grad_(True)
-            self.light_inten_para.requires_grad_(True)
+            if self.light_inten_train:  # trainer.py:513-514
+                self.light_inten_para.requires_grad_(True)
 
     def step(self, model_input, ground_truth, l_slt, train_order=True, noise=None, vidx=None):
         """One optimisation step on (this rank's pixel slice of) a batch.  ``l_slt`` are the rows of the
@@ -150,11 +159,14 @@ class TrainStep(object):
         model_input = dict(model_input)
         if l_slt.is_cuda and self.light_para.weight.is_cuda:
             # both table lookups + the normalisation in one launch (one more for the dense table gradients in backward)
-            model_input['light_direction'], model_input['light_intensity'] = ops.LightRows.apply(
-                self.light_para.weight, self.light_inten_para.weight, l_slt.long())
+            d_, i_ = ops.LightRows.apply(self.light_para.weight, self.light_inten_para.weight, l_slt.long())
+            model_input['light_direction'] = d_
+            if self.light_inten_train:  # (trainer.py:378-379; otherwise the model's scalar light_int)
+                model_input['light_intensity'] = i_
         else:
             model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
-            model_input['light_intensity'] = self.light_inten_para(l_slt)
+            if self.light_inten_train:
+                model_input['light_intensity'] = self.light_inten_para(l_slt)
         if 'light_vis_train' not in model_input:
             if l_slt.is_cuda and self.light_vis_table.is_cuda:
                 from .. import hip
@@ -190,7 +202,7 @@ class TrainStep(object):
         trainable = None
         if self.dp.enabled:
             trainable = [p for p in self.model.parameters() if p.requires_grad] \
-                + ([self.light_para.weight, self.light_inten_para.weight] if train_light else [])
+                + (([self.light_para.weight] + ([self.light_inten_para.weight] if self.light_inten_train else [])) if train_light else [])
             # every .grad dropped; gather_grads collects what autograd hands over into the flat bucket (one multi-tensor copy)
             self.dp.prepare_grads(list(self.model.parameters()) + [self.light_para.weight, self.light_inten_para.weight])
         else:

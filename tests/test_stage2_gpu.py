@@ -428,24 +428,28 @@ def test_surface_idx_from_the_data_pipeline(cuda):
     assert bool(torch.isfinite(t1['total']))
 
 
-@pytest.mark.parametrize('vis_plus', [False, True])
-def test_train_step_vs_reference_trainer_run(cuda, vis_plus):
+@pytest.mark.parametrize('vis_plus,inten_train', [(False, True), (True, True), (False, False)])
+def test_train_step_vs_reference_trainer_run(cuda, vis_plus, inten_train):
     """a24 against the reference's OWN trainer: tests/golden/stage2_trainer.npz holds six iterations of TrainRunner.run
     (stage2/trainer.py:355-410,462-464) across the train_fix switch at iteration 5000 (:485-513), produced by calling the
     reference's methods on a duck-typed runner (tools/gen_golden.py trainer).  The HIP TrainStep replays them: loss terms of
     every iteration, final light tables, final parameters (Adam: an element whose gradient sits at the fp32 noise floor may
-    step the other way, so the maximum is bounded by 2 lr per step and the bulk must agree tightly)."""
+    step the other way, so the maximum is bounded by 2 lr per step and the bulk must agree tightly).  inten_train=False: the run
+    of stage2_trainer_nointen.npz -- train.light_inten_train off as in armadillo.conf / bunny.conf (BASELINE configs[4]): no
+    intensity table is trained or read, the model shades with its scalar brdf.light_intensity."""
     import psnerf_amd.stage2 as s2
     from tests.test_oracle_golden import _trainer_golden_steps
 
-    def make(sd, NL, light_init, tables):
+    def make(sd, NL, light_init, tables, over=None):
         from psnerf_amd.stage2.trainer import VisPlus
-        net = s2.PSNetwork(s2.bear_conf())
+        conf = s2.bear_conf(**(over or {}))
+        net = s2.PSNetwork(conf)
         net.load_state_dict(sd)
         net.to(cuda)
         vp = VisPlus(tables['views'], tables['view_light'], tables['vnum'], cuda) if tables is not None else None
-        return s2.TrainStep(net, s2.bear_conf(), NL, light_init.to(cuda), cuda, vis_plus=vp)
-    g, names, logs, step = _trainer_golden_steps(make, dev=cuda, vis_plus=vis_plus)
+        return s2.TrainStep(net, conf, NL, light_init.to(cuda), cuda, vis_plus=vp)
+    g, names, logs, step = _trainer_golden_steps(make, dev=cuda, vis_plus=vis_plus, inten_train=inten_train)
+    assert step.light_inten_train == inten_train and len(step.light_optimizer.param_groups) == (2 if inten_train else 1)
     for i in range(6):
         assert_close(float(logs[i]['total'].detach()), float(g['total'][i]), 1e-4 if i == 0 else 1e-3, 'it %d total' % (4998 + i), atol=0.0)
         for k, v in zip(names, g['loss_vals'][i]):

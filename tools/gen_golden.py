@@ -658,13 +658,15 @@ def gen_stage2():
 
 
 # ---------------------------------------------------------------------------
-def gen_trainer(vis_plus=False):
+def gen_trainer(vis_plus=False, inten_train=True):
     """stage2/trainer.py: the reference's OWN TrainRunner.run / train_fix (the step body :355-410,462-464 and the schedule
     :485-513) driven for six iterations across the iteration-5000 switch.  The module imports with empty placeholders for
     the third-party packages this image lacks (pyhocon, tensorboardX, imageio, cv2, skimage, plotly, GPUtil, trimesh: none is
     touched by the step body; likewise torchvision, which utils/plots.py imports), and ``run`` is called on a duck-typed ``self`` that carries exactly the attributes the loop
     reads: a list as the data loader, the reference's model / loss classes, torch's Adam / SparseAdam as trainer.py:126-168
-    constructs them.  No reference edits.  Writes tests/golden/stage2_trainer.npz."""
+    constructs them.  No reference edits.  Writes tests/golden/stage2_trainer.npz (vis_plus: stage2_trainer_visplus.npz;
+    inten_train=False -- train.light_inten_train absent, as in bunny.conf / armadillo.conf: no intensity table, the model shades with
+    its scalar brdf.light_intensity, trainer.py:38,154-163,378-379 -- stage2_trainer_nointen.npz)."""
     import tempfile
     import types
     from oracle import stage2 as o2
@@ -687,7 +689,7 @@ def gen_trainer(vis_plus=False):
     from model.renderer import PSNetwork as RPS
     from model.loss import MainLoss as RMain, NormalLoss as RNormal
 
-    conf = o2.bear_conf(**{'train.vis_train_num': 5})
+    conf = o2.bear_conf(**{'train.vis_train_num': 5, 'train.light_inten_train': bool(inten_train)})
     sd = stage2_state_dict(conf, seed=41)
     N, L, V, NL = 360, 4, 3, 12
     light_slt = [list(range(5)), list(range(7))]          # two views with 5 and 7 lights: rows 0..4 and 5..11 of the tables
@@ -739,7 +741,7 @@ def gen_trainer(vis_plus=False):
     ns.model = rnet
     ns.loss = Recorder(RMain(loss_type='L1', sg_rgb_weight=1.0, albedo_smooth_weight=0.05, rough_smooth_weight=0.01, vis_weight=1))
     ns.loss_n = Recorder(RNormal(1, 0.05))
-    ns.normal_train, ns.multi_light, ns.light_train, ns.light_inten_train = True, True, True, True
+    ns.normal_train, ns.multi_light, ns.light_train, ns.light_inten_train = True, True, True, bool(inten_train)
     ns.visibility, ns.vis_loss, ns.vis_plus, ns.ana_fixlight, ns.light_decay, ns.train_order = True, True, bool(vis_plus), False, False, True
     ns.vis_plus_light = {'view_%02d' % (v + 1): vp_light[v].numpy().tolist() for v in range(2)}      # vis_plus/light_dir.json
     ns.vis_plus_all = {'view_%02d' % (v + 1): vp_vis[v].numpy().reshape(P, 30, 30) for v in range(2)}   # vis_plus/view_XX.npy
@@ -749,11 +751,14 @@ def gen_trainer(vis_plus=False):
     ns.light_para = torch.nn.Embedding(NL, 3, sparse=True)
     ns.light_para.weight.data.copy_(torch.cat(light_init, dim=0))
     ns.light_vis_train = [li.clone() for li in light_init]
-    ns.light_inten_para = torch.nn.Embedding(NL, 1, sparse=True)
-    torch.nn.init.constant_(ns.light_inten_para.weight, rnet.light_int)
-    ns.light_optimizer = torch.optim.SparseAdam(
-        [{'params': list(ns.light_para.parameters())},
-         {'params': list(ns.light_inten_para.parameters()), 'lr': 1e-3}], lr=5e-4)
+    if inten_train:
+        ns.light_inten_para = torch.nn.Embedding(NL, 1, sparse=True)
+        torch.nn.init.constant_(ns.light_inten_para.weight, rnet.light_int)
+        ns.light_optimizer = torch.optim.SparseAdam(
+            [{'params': list(ns.light_para.parameters())},
+             {'params': list(ns.light_inten_para.parameters()), 'lr': 1e-3}], lr=5e-4)
+    else:  # trainer.py:154-163: no table, no parameter group; the run must never touch the attribute
+        ns.light_optimizer = torch.optim.SparseAdam([{'params': list(ns.light_para.parameters())}], lr=5e-4)
     ns.light_scheduler = None
     class Loader(object):   # a DataLoader hands out fresh dictionaries every epoch (the loop edits them in place, trainer.py:365-367)
         def __len__(self):
@@ -826,7 +831,10 @@ def gen_trainer(vis_plus=False):
         d = (rsd[k] - osd[k]).abs()
         assert float(d.max()) <= 2 * 6 * 5e-4 + 1e-6 and float(d.mean()) <= 2e-5, (k, float(d.max()), float(d.mean()))
     check('trainer light table', ostep.light_para.weight.detach(), ns.light_para.weight.detach(), 1e-3)
-    check('trainer light intensity', ostep.light_inten_para.weight.detach(), ns.light_inten_para.weight.detach(), 1e-3)
+    if inten_train:
+        check('trainer light intensity', ostep.light_inten_para.weight.detach(), ns.light_inten_para.weight.detach(), 1e-3)
+    else:
+        assert not hasattr(ns, 'light_inten_para') and float((ostep.light_inten_para.weight.detach() - rnet.light_int).abs().max()) == 0.0
     moved = (sd['albedo_net.linears.0.weight'] - rsd['albedo_net.linears.0.weight']).abs().max()
     assert float(moved) > 0, 'the BRDF nets must have started training at iteration 5000'
     lk = sorted(keys)
@@ -836,7 +844,7 @@ def gen_trainer(vis_plus=False):
                      vp_light=np.stack([np_(x) for x in vp_light]), vp_vis=np.stack([np_(x) for x in vp_vis]).astype(np.uint8),
                      view_vis0=np_(view_vis[0]).astype(np.uint8), view_vis1=np_(view_vis[1]).astype(np.uint8))
     np.savez_compressed(
-        os.path.join(GOLDEN, 'stage2_trainer_visplus.npz' if vis_plus else 'stage2_trainer.npz'), **extra,
+        os.path.join(GOLDEN, 'stage2_trainer_visplus.npz' if vis_plus else ('stage2_trainer.npz' if inten_train else 'stage2_trainer_nointen.npz')), **extra,
         sd_digest=state_dict_digest(sd), N=N, L=L, V=V, NL=NL, input_seeds=np.array([200, 201, 202]), light_split=np.array([len(l) for l in light_slt]),
         light_init=np_(torch.cat(light_init, dim=0)), l_slt=np.stack([np_(x) for x in l_slts]), first_iter=4998,
         noise0=np_(noises[0]), noise1=np_(noises[1]), noise2=np_(noises[2]), noise3=np_(noises[3]), noise4=np_(noises[4]), noise5=np_(noises[5]),
@@ -845,11 +853,12 @@ def gen_trainer(vis_plus=False):
         loss_names=np.array(lk + ['normal_loss']),
         loss_vals=np.array([[(np.nan if ns.loss.log[i][k] is None else ns.loss.log[i][k]) for k in lk] + [ns.loss_n.log[i]['normal_loss']]
                             for i in range(6)]),  # nan = the reference returned None (term switched off)
-        light_para=np_(ns.light_para.weight.detach()), light_inten_para=np_(ns.light_inten_para.weight.detach()),
+        light_para=np_(ns.light_para.weight.detach()),
+        light_inten_para=np_(ns.light_inten_para.weight.detach()) if inten_train else np.full((NL, 1), rnet.light_int, dtype=np.float32),
         # final parameters: the first 2048 elements of every tensor (element-level check) + whole-tensor digests
         param_names=np.array(sorted(rsd)), param_norms=grad_digest(rsd)[1], param_projs=grad_digest(rsd)[2],
         **{('p_' + k): np_(v.reshape(-1)[:2048]) for k, v in rsd.items()})
-    print('stage2 trainer golden written (vis_plus=%s)' % vis_plus)
+    print('stage2 trainer golden written (vis_plus=%s, inten_train=%s)' % (vis_plus, inten_train))
 
 
 def gen_configs():
@@ -916,6 +925,7 @@ if __name__ == '__main__':
     elif what == 'trainer':
         gen_trainer(False)
         gen_trainer(True)
+        gen_trainer(False, inten_train=False)
     elif what == 'stage1':
         gen_stage1()
     elif what == 'stage2':

@@ -184,7 +184,7 @@ def main():
     assert min(n_surf) > 0, 'stage-1 surface is empty in some view'
 
     # ------------------------------------------------------------------ stage 2 (a19-a24)
-    conf = s2.bear_conf(**{'brdf.light_intensity': 4.0, 'train.light_bs': args.light_bs,
+    conf = s2.bear_conf(**{'brdf.light_intensity': 4.0, 'train.light_inten_train': False, 'train.light_bs': args.light_bs,
                            'train.vis_train_num': args.vis_train_num})
     torch.manual_seed(43)
     net2 = s2.PSNetwork(conf).to(dev)
