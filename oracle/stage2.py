@@ -151,7 +151,7 @@ def bear_conf(**overrides):
     c = {
         'train': dict(render_model='sgbasis', nbasis=9, specular_rgb=True, visibility=True,
                       vis_loss=True, light_vis_detach=True, vis_rgb_detach=True, normal_mlp=True,
-                      normal_joint=True, shape_pregen=True, light_inten_train=True),  # (bear.conf:17; absent in bunny / armadillo.conf)
+                      normal_joint=True, shape_pregen=True, light_inten_train=True, light_decay=True),  # (bear.conf:17,21; the former is absent in bunny / armadillo.conf)
         'brdf': dict(net=dict(n_freqs_xyz=10, mlp_width=128, mlp_depth=4, mlp_skip_at=2, xyz_jitter_std=0.01),
                      sgnet=dict(mlp_width=64, mlp_depth=2, mlp_skip_at=-1),
                      fresnel_f0=0.05, light_intensity=2.0),
@@ -444,6 +444,7 @@ class TrainStep(object):
         self.light_para = nn.Embedding(n_lights_total, 3, sparse=True)
         self.light_para.weight.data.copy_(light_init)
         self.light_inten_train = conf.get_bool('train.light_inten_train', default=False)  # trainer.py:38
+        self.light_decay = conf.get_bool('train.light_decay', default=False)  # trainer.py:40: without it the light tables keep their lr
         self.light_inten_para = nn.Embedding(n_lights_total, 1, sparse=True)
         nn.init.constant_(self.light_inten_para.weight, model.light_int)
         groups = [{'params': list(self.light_para.parameters())}]
@@ -511,7 +512,7 @@ class TrainStep(object):
             self.light_optimizer.step()
         self.cur_iter += 1
         self.sg_scheduler.step()
-        if train_light:
+        if train_light and self.light_decay:  # trainer.py:463-464
             self.light_scheduler.step()
         terms = dict(terms)
         terms['total'] = loss

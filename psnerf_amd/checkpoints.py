@@ -65,7 +65,8 @@ def save_stage2(step, checkpoints_path, epoch):
     os.makedirs(d, exist_ok=True)
     for fn in (str(epoch) + '.pth', 'latest.pth'):
         torch.save({'epoch': epoch, 'optimizer_light_state_dict': step.light_optimizer.state_dict(),
-                    'scheduler_light_state_dict': step.light_scheduler.state_dict()}, os.path.join(d, fn))
+                    'scheduler_light_state_dict': step.light_scheduler.state_dict() if getattr(step, 'light_decay', True) else None},
+                   os.path.join(d, fn))  # (trainer.py:241: None without train.light_decay)
     d = os.path.join(checkpoints_path, 'LightParameters')
     os.makedirs(d, exist_ok=True)
     for fn in (str(epoch) + '.pth', 'latest.pth'):

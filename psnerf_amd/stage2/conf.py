@@ -127,7 +127,7 @@ def bear_conf(**overrides):
         'train': Conf(render_model='sgbasis', nbasis=9, specular_rgb=True, visibility=True, vis_loss=True,
                       light_vis_detach=True, vis_rgb_detach=True, normal_mlp=True, normal_joint=True,
                       shape_pregen=True, light_bs=10, vis_train_num=8, vis_plus=True, train_order=True, light_train=True,
-                      multi_light=True, light_inten_train=True, num_pixels=8192, sg_learning_rate=5e-4,
+                      multi_light=True, light_inten_train=True, light_decay=True, num_pixels=8192, sg_learning_rate=5e-4,
                       sg_sched_milestones=[200, 400, 600, 800, 1000],
                       light_learning_rate=5e-4, light_inten_lr=1e-3, sg_sched_factor=0.5),
         'loss': Conf(sg_rgb_weight=1.0, loss_type='L1', albedo_smooth_weight=0.05, rough_smooth_weight=0.01,

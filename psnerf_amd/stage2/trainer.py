@@ -80,6 +80,7 @@ class TrainStep(object):
         # brdf.light_intensity, renderer.py:202).  The table itself always exists (checkpoint layout); untrained it is a constant
         # that the step never reads.
         self.light_inten_train = conf.get_bool('train.light_inten_train', default=False)
+        self.light_decay = conf.get_bool('train.light_decay', default=False)  # trainer.py:40,463-464: whether the light tables' lr follows the milestones
         self.light_inten_para = nn.Embedding(n_lights_total, 1, sparse=False).to(device)
         nn.init.constant_(self.light_inten_para.weight, model.light_int)
         lr_l = conf.get_float('train.light_learning_rate', default=5e-4)
@@ -241,7 +242,7 @@ class TrainStep(object):
     def _advance(self, train_light):
         self.cur_iter += 1
         self.sg_scheduler.step()
-        if train_light:
+        if train_light and self.light_decay:
             self.light_scheduler.step()
 
 
