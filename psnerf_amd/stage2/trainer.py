@@ -79,6 +79,15 @@ class TrainStep(object):
         # DiLiGenT-MV objects set it, the synthetic bunny / armadillo configurations do not: the model then shades with its scalar
         # brdf.light_intensity, renderer.py:202).  The table itself always exists (checkpoint layout); untrained it is a constant
         # that the step never reads.
+        # switches of stage2/trainer.py:36-50 that none of the seven shipped configurations uses and this step does not implement:
+        # refuse them instead of training something else than the configuration says
+        if not conf.get_bool('train.light_train', default=True):
+            raise NotImplementedError('train.light_train = False (ground-truth lights, trainer.py:36,126,368) is not implemented: every '
+                                      'shipped configuration trains the light tables')
+        if conf.get_bool('train.ana_fixlight', default=False):
+            raise NotImplementedError('train.ana_fixlight (trainer.py:41,510) is not implemented')
+        if conf.get_bool('train.visibility', default=False) and not conf.get_bool('train.vis_loss', default=True):
+            raise NotImplementedError('train.visibility without train.vis_loss (trainer.py:50,498-499) is not implemented')
         self.light_inten_train = conf.get_bool('train.light_inten_train', default=False)
         self.light_decay = conf.get_bool('train.light_decay', default=False)  # trainer.py:40,463-464: whether the light tables' lr follows the milestones
         self.light_inten_para = nn.Embedding(n_lights_total, 1, sparse=False).to(device)

@@ -202,3 +202,22 @@ def test_bench_watchdog_prints_the_headline_when_the_diagnostic_object_hangs():
              "print(bench.guarded(lambda: 7, {'x': 1}, 0, timeout=5), flush=True); bench.guarded(lambda: time.sleep(60), {'x': 1}, 1, timeout=1)") % root
     r = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, timeout=50)
     assert r.returncode == 0 and r.stdout.strip() == '7', (r.stdout, r.stderr[-300:])
+
+
+def test_train_step_refuses_switches_it_does_not_implement():
+    """stage2/trainer.py:36-50 has switches that no shipped configuration uses (ground-truth lights, ana_fixlight, visibility
+    without its loss): the product's TrainStep raises on them instead of silently training something else; the two that DO vary
+    between the shipped configurations -- train.light_inten_train (off for bunny / armadillo) and train.light_decay -- are read."""
+    import torch
+    import psnerf_amd.stage2 as s2
+    li = torch.nn.functional.normalize(torch.randn(6, 3), dim=-1)
+    for over in ({'train.light_train': False}, {'train.ana_fixlight': True}, {'train.vis_loss': False}):
+        conf = s2.bear_conf(**over)
+        with pytest.raises(NotImplementedError):
+            s2.TrainStep(s2.PSNetwork(conf), conf, 6, li, torch.device('cpu'))
+    for obj, inten in (('bear', True), ('reading', True), ('armadillo', False), ('bunny', False)):
+        from psnerf_amd.stage2.conf import object_conf
+        conf = object_conf(obj)
+        st = s2.TrainStep(s2.PSNetwork(conf), conf, 6, li, torch.device('cpu'))
+        assert st.light_inten_train == inten and st.light_decay and len(st.light_optimizer.param_groups) == (2 if inten else 1), obj
+        assert st.light_inten_para.weight.requires_grad == inten
