@@ -44,6 +44,17 @@ class VisPlus(object):
         return lights[sidx], vis[sidx[:, None], sampling_idx.to(self.device).long()[None, :]]
 
 
+def scheduler_milestones(conf, n_views):
+    """The iteration milestones of both learning-rate schedulers as stage2/trainer.py:118-121 derives them: the configuration's
+    ``train.sg_sched_milestones`` count EPOCHS of the multi-light data set; one epoch is n_views items, and with ``train.multi_light``
+    every item is visited ``train.light_bs`` times as often.  -> list of iterations for ``TrainStep(..., milestones=...)``."""
+    ms = list(conf.get_list('train.sg_sched_milestones', default=[]))
+    ms = [int(m) * int(n_views) for m in ms]
+    if conf.get_bool('train.multi_light', default=False):
+        ms = [m * conf.get_int('train.light_bs') for m in ms]
+    return ms
+
+
 class TrainStep(object):
     FUSED_LOSSES = True  # False: evaluate MainLoss / NormalLoss with the torch formulation (cross-check, other loss types)
 

@@ -221,3 +221,13 @@ def test_train_step_refuses_switches_it_does_not_implement():
         st = s2.TrainStep(s2.PSNetwork(conf), conf, 6, li, torch.device('cpu'))
         assert st.light_inten_train == inten and st.light_decay and len(st.light_optimizer.param_groups) == (2 if inten else 1), obj
         assert st.light_inten_para.weight.requires_grad == inten
+
+
+def test_scheduler_milestones_follow_the_reference_scaling():
+    """stage2/trainer.py:118-121: milestones = epochs x len(dataset) (x light_bs under multi_light)."""
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.stage2.trainer import scheduler_milestones
+    conf = s2.bear_conf()
+    assert scheduler_milestones(conf, 20) == [m * 20 * 10 for m in (200, 400, 600, 800, 1000)]
+    assert scheduler_milestones(s2.bear_conf(**{'train.multi_light': False}), 20) == [m * 20 for m in (200, 400, 600, 800, 1000)]
+    assert scheduler_milestones(s2.bear_conf(**{'train.sg_sched_milestones': []}), 20) == []
