@@ -82,6 +82,16 @@ class GraphedTrainStep(object):
         assert not (self.pad_multiple and agree is not None), 'pad_multiple is for single-process jobs; data-parallel jobs use pad_to_pixels'
         self.n_replays = self.n_eager = self.n_captures = 0
 
+    def reset(self):
+        """Drop every captured graph (the next steps of each signature run eagerly and are captured again).  Call it after anything
+        that REPLACES tensors the captured launches address -- ``checkpoints.load_stage2`` (optimiser state is re-created by
+        ``load_state_dict``), ``model.to(...)``, a new optimiser: a graph holds raw addresses, not tensors."""
+        self._captured.clear()
+        self._seen.clear()
+        for opt in (self.step_obj.sg_optimizer, self.step_obj.light_optimizer):
+            if hasattr(opt, '_graph_plan'):
+                opt._graph_plan = None
+
     # ---- signature of a step -------------------------------------------------------------------------------------------
     def _key(self, model_input, ground_truth, l_slt, noise):
         st = self.step_obj

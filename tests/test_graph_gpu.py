@@ -303,3 +303,29 @@ def test_padded_graph_with_an_empty_surface_mask(cuda):
     for k in o_e:
         if k in o_g and o_e[k].shape == o_g[k].shape:
             assert torch.equal(o_e[k], o_g[k]), k
+
+
+def test_reset_drops_the_graphs_and_training_continues_identically(cuda):
+    """GraphedTrainStep.reset() (what a caller does after load_stage2 / anything that replaces tensors the captured launches
+    address): the next steps run eagerly and are captured again; the trajectory stays the eager one, bit for bit."""
+    from psnerf_amd.stage2.graph import GraphedTrainStep
+    N, L, V, n_it = 1500, 8, 4, 10
+    res = {}
+    for mode in ('eager', 'graph'):
+        step, NL = _make(cuda, 5001)
+        batches = _batches(n_it, N, L, V, NL, cuda)
+        run = GraphedTrainStep(step, warmup=1) if mode == 'graph' else step
+        losses = []
+        for i, (inp, gt, l_slt, nz) in enumerate(batches):
+            if mode == 'graph' and i == 5:
+                assert run.n_captures == 1
+                run.reset()
+            terms, _ = run.step(inp, gt, l_slt, train_order=True, noise=nz)
+            losses.append(terms['total'].detach().reshape(()).clone())
+        torch.cuda.synchronize()
+        if mode == 'graph':
+            assert run.n_captures == 2 and run.n_eager == 2 and run.n_replays == n_it - 2, (run.n_captures, run.n_eager, run.n_replays)
+        res[mode] = (torch.stack(losses).cpu(), _state(step))
+    assert torch.equal(res['eager'][0], res['graph'][0])
+    for k in res['eager'][1]:
+        assert torch.equal(res['eager'][1][k], res['graph'][1][k]), k
