@@ -29,6 +29,28 @@ def to_hw(x, h, w):
     return x.reshape(w, h, -1).permute(1, 0, 2)
 
 
+def sample_vis_plus_dirs(world_mat, vnum=256, semisphere=False, rnum=10000, rng=None):
+    """The extra visibility-supervision directions of a view as stage1/shape_extract.py:117-129 draws them: ``rnum`` isotropic
+    unit vectors (np.random.normal, normalised), with ``semisphere`` only those facing the camera ((v . view_dir) < 0, view_dir =
+    world_mat[0, :3, 2]), thinned to ``vnum`` by farthest-point sampling with a random start.  The reference calls torch_cluster's
+    ``fps`` for the last step; this is the same greedy farthest-first selection on the host (the start index comes from ``rng``,
+    so the SET of directions is not bit-pinned to torch_cluster's -- any well-spread set serves: the directions are stored beside
+    the maps in vis_plus/light_dir.json).  -> float32 tensor [vnum, 3]."""
+    rng = rng if rng is not None else np.random
+    view_dir = np.asarray(world_mat[0, :3, 2].detach().cpu() if torch.is_tensor(world_mat) else world_mat[0, :3, 2], dtype=np.float64)
+    vec = rng.normal(size=(rnum, 3))
+    unit = vec / np.linalg.norm(vec, axis=-1, keepdims=True)
+    if semisphere:
+        unit = unit[(unit * view_dir).sum(-1) < 0]
+    assert unit.shape[0] >= vnum, 'sample_vis_plus_dirs: fewer candidates than directions asked for'
+    chosen = [int(rng.randint(unit.shape[0]))]
+    dist = np.full(unit.shape[0], np.inf)
+    for _ in range(vnum - 1):
+        dist = np.minimum(dist, ((unit - unit[chosen[-1]]) ** 2).sum(-1))
+        chosen.append(int(dist.argmax()))
+    return torch.from_numpy(unit[chosen]).float()
+
+
 @torch.no_grad()
 def export_view(renderer, camera_mat, world_mat, scale_mat, h, w, out_dir, view_id, light_dir=None, vis_plus_dir=None,
                 chunk=32000, it=100000):

@@ -231,3 +231,23 @@ def test_scheduler_milestones_follow_the_reference_scaling():
     assert scheduler_milestones(conf, 20) == [m * 20 * 10 for m in (200, 400, 600, 800, 1000)]
     assert scheduler_milestones(s2.bear_conf(**{'train.multi_light': False}), 20) == [m * 20 for m in (200, 400, 600, 800, 1000)]
     assert scheduler_milestones(s2.bear_conf(**{'train.sg_sched_milestones': []}), 20) == []
+
+
+def test_vis_plus_directions_are_spread_unit_vectors_facing_the_camera():
+    """handoff.sample_vis_plus_dirs (stage1/shape_extract.py:117-129): unit vectors, the requested count, hemisphere filter,
+    farthest-point spread (the closest pair is far wider apart than in a random subset of the same size)."""
+    import numpy as np
+    import torch
+    from psnerf_amd import handoff
+    wm = torch.eye(4)[None]
+    d = handoff.sample_vis_plus_dirs(wm, vnum=64, semisphere=True, rng=np.random.RandomState(3))
+    assert d.shape == (64, 3) and d.dtype == torch.float32
+    assert torch.allclose(d.norm(dim=-1), torch.ones(64), atol=1e-6)
+    assert bool((d[:, 2] < 0).all())  # view_dir = world_mat[0, :3, 2] = +z: only directions with a negative z component
+    gram = d @ d.t() - 2 * torch.eye(64)
+    rs = np.random.RandomState(4)
+    v = rs.normal(size=(2000, 3)); v = v / np.linalg.norm(v, axis=-1, keepdims=True); v = v[v[:, 2] < 0][:64]
+    gram_r = torch.from_numpy(v @ v.T).float() - 2 * torch.eye(64)
+    assert float(gram.max()) < float(gram_r.max()) - 0.02   # largest cosine between two different directions: smaller = better spread
+    full = handoff.sample_vis_plus_dirs(wm, vnum=256, rng=np.random.RandomState(5))
+    assert full.shape == (256, 3) and bool((full[:, 2] > 0).any()) and bool((full[:, 2] < 0).any())
