@@ -87,6 +87,7 @@ struct InferArgs {
     // (row, lane group g) holds bit 4 mt + r = (activation feature 16 mt + 4 g + r > 0); read back by PSN_ACT_RELU_BITS chains
     // through mask[l], 32 bytes per row and layer instead of the 1 KB activation row
     unsigned long long* save_bits[PSN_MLP_MAX_LAYERS];
+    int tb_lds;  // lean variant: 1 = a workgroup whose rows share one B-table row reads that init row through LDS (A/B: PSN_TB_LDS=0)
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -495,6 +496,23 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     };
 
     for (int i = tid; i < g.n_bias; i += kWaves * 64) bias_lds[i] = g.b[i];  // visible after the first stage barrier
+    // The B-side init row (stage 2: T[l] = W_b pe(l) + b of the workgroup's light) is the SAME for all 64 rows of a workgroup that
+    // does not straddle two B rows: it then goes through LDS (behind the biases, when there is room) instead of 16 global loads per
+    // lane and init layer -- a VMEM instruction in an MFMA wave costs about as much as an MFMA whether it hits L2 or not.
+    const float* tb_lds = nullptr;
+    if constexpr (!CHAIN && SRC == 0) {
+        if (g.init_b != nullptr && g.tb_lds != 0 && g.n_bias + g.d.init_stride <= PSN_MLP_MAX_LAYERS * 256) {
+            const int64_t r_first = blk_ * (kWaves * 16), r_last_ = r_first + kWaves * 16 - 1;
+            const int64_t r_last = r_last_ < n_rows_eff ? r_last_ : n_rows_eff - 1;
+            const int64_t ib0 = (r_first / g.b_div) % g.b_mod;
+            if (ib0 == (r_last / g.b_div) % g.b_mod) {  // (uniform over the workgroup)
+                float* dst = bias_lds + PSN_MLP_MAX_LAYERS * 256 - g.d.init_stride;
+                const float* src = g.init_b + ib0 * (int64_t)g.d.init_stride;
+                for (int i = tid; i < g.d.init_stride; i += kWaves * 64) dst[i] = src[i];
+                tb_lds = dst;
+            }
+        }
+    }
 
     floatx4 act[NMT];
     floatx4 acc[NMT];
@@ -612,7 +630,16 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                         acc[mt][3] += u.w;
                     }
                 }
-                if (init_b_row != nullptr) {
+                if (tb_lds != nullptr) {  // (written before the `li == 0` barrier above, like the biases)
+#pragma unroll
+                    for (int mt = 0; mt < NMT; ++mt) {
+                        const float4 u = *reinterpret_cast<const float4*>(tb_lds + L.init_off + mt * 16 + 4 * lg);
+                        acc[mt][0] += u.x;
+                        acc[mt][1] += u.y;
+                        acc[mt][2] += u.z;
+                        acc[mt][3] += u.w;
+                    }
+                } else if (init_b_row != nullptr) {
 #pragma unroll
                     for (int mt = 0; mt < NMT; ++mt) {
                         float4 u = *reinterpret_cast<const float4*>(init_b_row + L.init_off + mt * 16 + 4 * lg);
@@ -1230,6 +1257,10 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
                   "mlp_infer_padded: needs the lean variant, outputs, a period that is a multiple of 64 and save_row0 a multiple of the period (period=%lld save_row0=%lld)",
                   (long long)live_period, (long long)save_row0);
     a.live_count = live_count; a.live_period = live_period > 0 ? live_period : 1;
+    {
+        static const int tb = [] { const char* e = getenv("PSN_TB_LDS"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
+        a.tb_lds = tb;
+    }
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
     const dim3 grid((unsigned)blocks), block(kWaves * 64);
     hipStream_t st = (hipStream_t)stream;
