@@ -430,7 +430,8 @@ def strong_cfg4(device, dp, rank, world, steps=40):
 
 def guarded(fn, line, rank, timeout=240):
     """fn() under a watchdog: if it has not returned after ``timeout`` seconds (a rank stuck in a collective cannot be interrupted),
-    rank 0 prints ``line`` with an error in place of the object and every rank leaves the process."""
+    rank 0 prints ``line`` with an error in place of the object and every rank leaves the process with exit code 3: a run that
+    hung (RCCL, graph capture) must not look like a success to the launcher, even though the headline line was printed."""
     import threading
     lock, state = threading.Lock(), {'done': False}
 
@@ -442,7 +443,7 @@ def guarded(fn, line, rank, timeout=240):
                 line['strong_cfg4'] = {'error': 'strong_cfg4 did not return within %d s at this world size; the headline and every other object of '
                                                 'this line were measured before it started' % timeout}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
 
     t = threading.Timer(timeout, fire)
     t.daemon = True

@@ -151,7 +151,7 @@ def bear_conf(**overrides):
     c = {
         'train': dict(render_model='sgbasis', nbasis=9, specular_rgb=True, visibility=True,
                       vis_loss=True, light_vis_detach=True, vis_rgb_detach=True, normal_mlp=True,
-                      normal_joint=True, shape_pregen=True, light_inten_train=True, light_decay=True),  # (bear.conf:17,21; the former is absent in bunny / armadillo.conf)
+                      normal_joint=True, shape_pregen=True, light_train=True, light_inten_train=True, light_decay=True),  # (bear.conf:13,17,21; light_inten_train is absent in bunny / armadillo.conf)
         'brdf': dict(net=dict(n_freqs_xyz=10, mlp_width=128, mlp_depth=4, mlp_skip_at=2, xyz_jitter_std=0.01),
                      sgnet=dict(mlp_width=64, mlp_depth=2, mlp_skip_at=-1),
                      fresnel_f0=0.05, light_intensity=2.0),
@@ -441,9 +441,17 @@ class TrainStep(object):
         self.loss_n = NormalLoss(**nk)
         self.sg_optimizer = torch.optim.Adam(model.parameters(), lr=lr)
         self.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.sg_optimizer, list(milestones), gamma=gamma)
+        # the switches of trainer.py:36-50 with the reference's defaults
+        self.light_train = conf.get_bool('train.light_train', default=False)      # :36 estimated (trained) lights, or the data set's as given
+        self.ana_fixlight = conf.get_bool('train.ana_fixlight', default=False)    # :41 light tables stay frozen after iteration 5000
+        self.visibility = conf.get_bool('train.visibility', default=False)        # :49
+        self.vis_loss = self.visibility and conf.get_bool('train.vis_loss', default=False)  # :50
+        self.normal_train = conf.get_bool('train.normal_mlp', default=False) and conf.get_bool('train.normal_joint', default=False)  # :42-44
         self.light_para = nn.Embedding(n_lights_total, 3, sparse=True)
         self.light_para.weight.data.copy_(light_init)
-        self.light_inten_train = conf.get_bool('train.light_inten_train', default=False)  # trainer.py:38
+        if not self.light_train:  # trainer.py:126: no table, no optimiser; kept here as a frozen constant the step never reads
+            self.light_para.requires_grad_(False)
+        self.light_inten_train = self.light_train and conf.get_bool('train.light_inten_train', default=False)  # trainer.py:38,154
         self.light_decay = conf.get_bool('train.light_decay', default=False)  # trainer.py:40: without it the light tables keep their lr
         self.light_inten_para = nn.Embedding(n_lights_total, 1, sparse=True)
         nn.init.constant_(self.light_inten_para.weight, model.light_int)
@@ -467,25 +475,30 @@ class TrainStep(object):
             self.loss.vis_weight = 10
             self.model.albedo_net.eval().requires_grad_(False)
             self.model.rough_net.eval().requires_grad_(False)
-            self.light_para.requires_grad_(False)
-            if self.light_inten_train:  # trainer.py:502-503
-                self.light_inten_para.requires_grad_(False)
+            if self.visibility and not self.vis_loss:  # trainer.py:498-499 (never released again)
+                self.model.visibility_net.eval().requires_grad_(False)
+            if self.light_train:  # trainer.py:500-503
+                self.light_para.requires_grad_(False)
+                if self.light_inten_train:
+                    self.light_inten_para.requires_grad_(False)
         elif self.cur_iter == 5000:
             (self.loss.sg_rgb_weight, self.loss.albedo_smooth_weight,
              self.loss.rough_smooth_weight, self.loss.vis_weight) = self._ori
             self.model.albedo_net.train().requires_grad_(True)
             self.model.rough_net.train().requires_grad_(True)
-            self.light_para.requires_grad_(True)
-            if self.light_inten_train:  # trainer.py:513-514
-                self.light_inten_para.requires_grad_(True)
+            if not self.ana_fixlight and self.light_train:  # trainer.py:510-513
+                self.light_para.requires_grad_(True)
+                if self.light_inten_train:
+                    self.light_inten_para.requires_grad_(True)
 
     def step(self, model_input, ground_truth, l_slt, train_order=True, noise=None, vidx=None):
         if train_order:
             self.train_fix()
         model_input = dict(model_input)
-        model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
-        if self.light_inten_train:  # trainer.py:378-379
-            model_input['light_intensity'] = self.light_inten_para(l_slt)
+        if self.light_train:  # trainer.py:368-379; otherwise the batch's own 'light_direction' is used as given
+            model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
+            if self.light_inten_train:  # trainer.py:378-379
+                model_input['light_intensity'] = self.light_inten_para(l_slt)
         if self.vis_plus is not None and vidx is not None:
             # trainer.py:377 is overwritten by :384-392 when train.vis_plus is set
             vp = self.vis_plus
@@ -495,13 +508,16 @@ class TrainStep(object):
             model_input['light_vis_train'] = light_plus[sidx]                                       # :390
             assert light_plus.shape[0] == vis_plus_v.shape[0]                                       # :391
             model_input['vis_train_gt'] = vis_plus_v[sidx][:, model_input['sampling_idx'][0]]       # :392
-        elif 'light_vis_train' not in model_input:
+        elif self.light_train and 'light_vis_train' not in model_input:
             model_input['light_vis_train'] = F.normalize(self.light_vis_train_all[l_slt], p=2, dim=-1)  # :377
         out = self.model(model_input, noise=noise)
         terms = self.loss(out, ground_truth, model_input)
         loss = terms['loss']
-        terms_n = self.loss_n(out)
-        loss = loss + terms_n['loss']
+        if self.normal_train:  # trainer.py:397-399
+            terms_n = self.loss_n(out)
+            loss = loss + terms_n['loss']
+        else:
+            terms_n = {'loss': None, 'normal_loss': None, 'normal_smooth_loss': None}
         self.sg_optimizer.zero_grad()
         train_light = self.light_para.weight.requires_grad
         if train_light:

@@ -43,7 +43,8 @@ def sample_vis_plus_dirs(world_mat, vnum=256, semisphere=False, rnum=10000, rng=
     if semisphere:
         unit = unit[(unit * view_dir).sum(-1) < 0]
     assert unit.shape[0] >= vnum, 'sample_vis_plus_dirs: fewer candidates than directions asked for'
-    chosen = [int(rng.randint(unit.shape[0]))]
+    # (np.random / RandomState draw with randint; a numpy Generator -- np.random.default_rng() -- only has integers)
+    chosen = [int((rng.integers if hasattr(rng, 'integers') else rng.randint)(unit.shape[0]))]
     dist = np.full(unit.shape[0], np.inf)
     for _ in range(vnum - 1):
         dist = np.minimum(dist, ((unit - unit[chosen[-1]]) ** 2).sum(-1))
@@ -193,6 +194,10 @@ class ViewSampler(object):
         1, the per-light ones (rgb [L,n,3], light_direction [L,3], visibility [L,n]) do not, and ``l_slt`` = the rows of
         the concatenated per-view light tables (sum of the preceding views' light counts + lidx)."""
         _, sample, gt = self[idx]
+        if 'visibility' not in sample:
+            # trainer.py:366 strips the batch dimension of model_input['visibility'] under multi_light unconditionally: a data set
+            # built without train.vis_loss (dataset.py:168-169) fails there with this KeyError
+            raise KeyError('visibility')
         mi = {}
         for k, v in sample.items():
             if k in ('light_direction', 'visibility', 'lidx'):

@@ -55,11 +55,13 @@ class StepScalars(object):
 class RowSparseAdam(torch.optim.Optimizer):
     graph_scalars = None  # a StepScalars: the fused launch reads its step sizes from device memory (HIP-graph replay)
 
-    def graph_advance(self):
+    def graph_advance(self, plan=None):
         """The host half of one REPLAYED step: the step counts of the tables of the captured launch advance and the step
-        sizes of this step go to the device (the device half is the replayed psn_row_adam_dev launch)."""
+        sizes of this step go to the device (the device half is the replayed psn_row_adam_dev launch).  ``plan``: the
+        (table, group) list the captured launch was built from -- a graph keeps the one of ITS capture (stage2/graph.py);
+        the optimiser's own ``_graph_plan`` is that of the LAST fused step of any signature."""
         vals = []
-        for p, group in self._graph_plan:
+        for p, group in (self._graph_plan if plan is None else plan):
             state = self.state[p]
             state['step'] = int(state['step']) + 1
             t, (b1, b2) = int(state['step']), group['betas']
@@ -86,7 +88,9 @@ class RowSparseAdam(torch.optim.Optimizer):
                     state['exp_avg_sq'] = torch.zeros_like(p)
                 t = int(state['step']) + 1
                 items.append((p, state, b1, b2, group['eps'], group['lr'] * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)))
-        if not items or len(items) > 4:
+        if not items:
+            return None  # no table has a gradient (a batch without a surface pixel): nothing to do, in any formulation
+        if len(items) > 4:
             return False
         for p, state, *_ in items:
             state['step'] = int(state['step']) + 1
@@ -110,9 +114,15 @@ class RowSparseAdam(torch.optim.Optimizer):
     def step(self, rows=None):
         """rows: 1-D index tensor of the table rows used by this step (duplicates allowed).  Required when the
         gradients are dense (nn.Embedding(sparse=False)); with sparse gradients the rows are their indices."""
-        if rows is not None and rows.is_cuda and self._fused_step(rows):
+        if rows is not None and rows.is_cuda:
+            fused = self._fused_step(rows)
+            if fused or fused is None:
+                return
+        if not any(p.grad is not None for group in self.param_groups for p in group['params']):
             return
-        assert self.graph_scalars is None, 'RowSparseAdam: only the fused launch can be replayed from a graph'
+        # (an EAGER step may take the torch formulation beside live graphs -- its step sizes are host scalars; a capture may not)
+        assert not (self.graph_scalars is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()), \
+            'RowSparseAdam: only the fused launch can be captured into a graph'
 
         for group in self.param_groups:
             beta1, beta2 = group['betas']
@@ -192,12 +202,14 @@ class FlatAdam(torch.optim.Optimizer):
         self.graph_scalars = None  # a StepScalars: the launches read (neg_step, bc2_sqrt) of every range from device memory
         self._graph_plan = None
 
-    def graph_advance(self):
+    def graph_advance(self, plan=None):
         """The host half of one REPLAYED step: the step counts of the parameters of the captured launches advance and this
-        step's scalars go to the device (the device half are the replayed gather + psn_adam_flat_dev launches)."""
+        step's scalars go to the device (the device half are the replayed gather + psn_adam_flat_dev launches).  ``plan``:
+        the (group, members, range representatives) list of the capture that is replayed (stage2/graph.py snapshots it per
+        graph; ``_graph_plan`` itself is overwritten by every step of any other signature)."""
         import math
         vals = []
-        for group, params, reps in self._graph_plan:
+        for group, params, reps in (self._graph_plan if plan is None else plan):
             b1, b2 = group['betas']
             for p in params:
                 self.state[p]['step'] += 1
@@ -348,7 +360,8 @@ class FlatAdam(torch.optim.Optimizer):
                         segs.append((o, go, n, neg_step, bc2s))
                         reps.append(p)
                     continue
-                assert self.graph_scalars is None, 'FlatAdam: a gradient outside the flat layout cannot be replayed from a graph'
+                assert not (self.graph_scalars is not None and torch.cuda.is_current_stream_capturing()), \
+                    'FlatAdam: a gradient outside the flat layout cannot be captured into a graph'
                 # torch's formulation for whatever is not in the flat layout
                 m, v = st['exp_avg'], st['exp_avg_sq']
                 m.lerp_(g, 1 - b1)

@@ -12,6 +12,11 @@ eager step's arithmetic, bit for bit:
   * every further call copies the batch into the captured input buffers (skipped for tensors that already ARE those
     buffers: a data pipeline can write into ``.buffers`` directly) and replays.
 
+ALIASING: a replayed step returns the graph's STATIC output tensors (``terms``, ``out``): the next replay of the same
+signature overwrites them in place (the eager step returns fresh tensors).  Read what you need (``float(t)``, ``.clone()``)
+before the next ``.step``; ``GraphedTrainStep(..., clone_terms=True)`` returns detached clones of the scalar loss terms
+(one multi-tensor copy per step) for callers that keep them across steps.
+
 What stays on the host per replayed step: train_fix, the iteration / scheduler bookkeeping, the optimisers' step counts and
 their step-dependent scalars (bias corrections x learning rate), which the Adam / SparseAdam launches read from DEVICE memory
 (``optim.StepScalars``, psn_adam_flat_dev / psn_row_adam_dev) so that the captured launches never change; the vis_plus draw
@@ -38,13 +43,14 @@ class _Captured(object):
         self.terms = self.out = None
         self.trainable = None
         self.train_light = False
+        self.sg_plan = self.light_plan = None  # the optimisers' host-side plans of this capture (optim.*.graph_advance)
 
 
 class GraphedTrainStep(object):
     SKIP_PADDING = True  # pad_to_pixels: hand the device-side surface count to the model (False: the padding rows are evaluated; A/B)
 
     def __init__(self, step, warmup=2, max_graphs=8, overlap_small_nets=None, adopt_inputs=False, agree=None, pad_to_pixels=False,
-                 pad_multiple=0):
+                 pad_multiple=0, clone_terms=False):
         """``overlap_small_nets``: None keeps the model's setting; False captures a single-stream graph (0.04 ms of host
         time per replay instead of ~2.5 ms, at the price of the side-stream overlap).  ``adopt_inputs``: the tensors of the
         batch that is captured BECOME the graph's input buffers (no clones): for a caller that keeps refilling the same
@@ -81,6 +87,7 @@ class GraphedTrainStep(object):
         #  rank's own surface count would let one rank capture while another replays: such jobs pad to the pixel count)
         assert not (self.pad_multiple and agree is not None), 'pad_multiple is for single-process jobs; data-parallel jobs use pad_to_pixels'
         self.n_replays = self.n_eager = self.n_captures = 0
+        self.clone_terms = bool(clone_terms)
 
     def reset(self):
         """Drop every captured graph (the next steps of each signature run eagerly and are captured again).  Call it after anything
@@ -159,14 +166,23 @@ class GraphedTrainStep(object):
         else:
             first = False
             self._load(cap, model_input, ground_truth, l_slt, noise)
-            st.sg_optimizer.graph_advance()
+            # the plans of THIS graph's capture: eager steps / captures of other signatures in between overwrite the
+            # optimisers' own ``_graph_plan`` (another gradient set, another range layout -- or none at all for a batch
+            # without a surface pixel), and a replay must advance the step counts its launches were built from
+            st.sg_optimizer.graph_advance(cap.sg_plan)
             if cap.train_light:
-                st.light_optimizer.graph_advance()
+                st.light_optimizer.graph_advance(cap.light_plan)
         self._replay(cap)
         if not first:
             st.model.invalidate_packs(trainable_only=True)  # (the captured step re-packs; an eager step that follows must too)
         st._advance(cap.train_light)
         self.n_replays += 1
+        if self.clone_terms:
+            keys = [k for k, v in cap.terms.items() if torch.is_tensor(v)]
+            fresh = torch._foreach_add([cap.terms[k].detach() for k in keys], 0.0)  # one multi-tensor launch
+            terms = dict(cap.terms)
+            terms.update(zip(keys, fresh))
+            return terms, cap.out
         return cap.terms, cap.out
 
     def _eager(self, model_input, ground_truth, l_slt, noise):
@@ -239,6 +255,8 @@ class GraphedTrainStep(object):
         # scalars now, in front of the replay that executes the captured step
         st.sg_optimizer.graph_scalars.flush()
         st.light_optimizer.graph_scalars.flush()
+        cap.sg_plan = list(st.sg_optimizer._graph_plan or [])
+        cap.light_plan = list(st.light_optimizer._graph_plan or []) if cap.train_light else []
         self._captured[key] = cap
         self.n_captures += 1
         return cap

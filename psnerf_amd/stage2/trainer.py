@@ -86,20 +86,29 @@ class TrainStep(object):
         # dense gradients + RowSparseAdam = SparseAdam's update of the touched rows without coalesce() (optim.py)
         self.light_para = nn.Embedding(n_lights_total, 3, sparse=False).to(device)
         self.light_para.weight.data.copy_(light_init)
+        # the switches of stage2/trainer.py:36-50, read with the REFERENCE's defaults (all False: a configuration that leaves a key
+        # out trains what the reference would train; the seven shipped configurations set light_train / visibility / vis_loss):
+        #   train.light_train = False  -> no light tables: the batch's own 'light_direction' is used as given, no 'light_vis_train'
+        #                                 is injected (the visibility loss then supervises the L shading rows, loss.py:86-87), no
+        #                                 SparseAdam step (trainer.py:126,368,403-408).  The tables below still exist, frozen and unread.
+        #   train.ana_fixlight         -> the light tables stay frozen after the iteration-5000 switch (trainer.py:510)
+        #   train.visibility without train.vis_loss -> the visibility net is frozen at iteration 0 and never released (trainer.py:498-499)
+        #   train.normal_mlp and train.normal_joint -> NormalLoss is part of the step (trainer.py:42-44,397-399)
+        self.light_train = conf.get_bool('train.light_train', default=False)
+        self.ana_fixlight = conf.get_bool('train.ana_fixlight', default=False)
+        self.visibility = conf.get_bool('train.visibility', default=False)
+        self.vis_loss = self.visibility and conf.get_bool('train.vis_loss', default=False)
+        self.normal_train = conf.get_bool('train.normal_mlp', default=False) and conf.get_bool('train.normal_joint', default=False)
+        if vis_plus is not None and not self.light_train:
+            # trainer.py:388 concatenates self.light_vis_train, which exists only under light_train (:149): the reference raises here too
+            raise AttributeError("train.vis_plus needs train.light_train (the per-view initial light estimates 'light_vis_train', trainer.py:149,388)")
         # the per-light intensity table is trained only under train.light_inten_train (stage2/trainer.py:38,154-163; the
         # DiLiGenT-MV objects set it, the synthetic bunny / armadillo configurations do not: the model then shades with its scalar
         # brdf.light_intensity, renderer.py:202).  The table itself always exists (checkpoint layout); untrained it is a constant
         # that the step never reads.
-        # switches of stage2/trainer.py:36-50 that none of the seven shipped configurations uses and this step does not implement:
-        # refuse them instead of training something else than the configuration says
-        if not conf.get_bool('train.light_train', default=True):
-            raise NotImplementedError('train.light_train = False (ground-truth lights, trainer.py:36,126,368) is not implemented: every '
-                                      'shipped configuration trains the light tables')
-        if conf.get_bool('train.ana_fixlight', default=False):
-            raise NotImplementedError('train.ana_fixlight (trainer.py:41,510) is not implemented')
-        if conf.get_bool('train.visibility', default=False) and not conf.get_bool('train.vis_loss', default=True):
-            raise NotImplementedError('train.visibility without train.vis_loss (trainer.py:50,498-499) is not implemented')
-        self.light_inten_train = conf.get_bool('train.light_inten_train', default=False)
+        self.light_inten_train = self.light_train and conf.get_bool('train.light_inten_train', default=False)
+        if not self.light_train:
+            self.light_para.requires_grad_(False)
         self.light_decay = conf.get_bool('train.light_decay', default=False)  # trainer.py:40,463-464: whether the light tables' lr follows the milestones
         self.light_inten_para = nn.Embedding(n_lights_total, 1, sparse=False).to(device)
         nn.init.constant_(self.light_inten_para.weight, model.light_int)
@@ -123,17 +132,21 @@ class TrainStep(object):
             self.loss.vis_weight = 10
             self.model.albedo_net.eval().requires_grad_(False)
             self.model.rough_net.eval().requires_grad_(False)
-            self.light_para.requires_grad_(False)
-            if self.light_inten_train:  # trainer.py:502-503
-                self.light_inten_para.requires_grad_(False)
+            if self.visibility and not self.vis_loss:  # trainer.py:498-499 (there is no release at iteration 5000)
+                self.model.visibility_net.eval().requires_grad_(False)
+            if self.light_train:  # trainer.py:500-503
+                self.light_para.requires_grad_(False)
+                if self.light_inten_train:
+                    self.light_inten_para.requires_grad_(False)
         elif self.cur_iter == 5000:
             (self.loss.sg_rgb_weight, self.loss.albedo_smooth_weight,
              self.loss.rough_smooth_weight, self.loss.vis_weight) = self._ori
             self.model.albedo_net.train().requires_grad_(True)
             self.model.rough_net.train().requires_grad_(True)
-            self.light_para.requires_grad_(True)
-            if self.light_inten_train:  # trainer.py:513-514
-                self.light_inten_para.requires_grad_(True)
+            if not self.ana_fixlight and self.light_train:  # trainer.py:510-513
+                self.light_para.requires_grad_(True)
+                if self.light_inten_train:
+                    self.light_inten_para.requires_grad_(True)
 
     def step(self, model_input, ground_truth, l_slt, train_order=True, noise=None, vidx=None):
         """One optimisation step on (this rank's pixel slice of) a batch.  ``l_slt`` are the rows of the
@@ -178,7 +191,9 @@ class TrainStep(object):
         ``count``: the (global) masked-pixel count as a device tensor [1] when the caller has already formed it (graph replay
         under data parallelism: the count's all-reduce stays outside the captured graph)."""
         model_input = dict(model_input)
-        if l_slt.is_cuda and self.light_para.weight.is_cuda:
+        if not self.light_train:
+            pass  # ground-truth lights: 'light_direction' (and the model's scalar intensity) as the batch brings them (trainer.py:368)
+        elif l_slt.is_cuda and self.light_para.weight.is_cuda:
             # both table lookups + the normalisation in one launch (one more for the dense table gradients in backward)
             d_, i_ = ops.LightRows.apply(self.light_para.weight, self.light_inten_para.weight, l_slt.long())
             model_input['light_direction'] = d_
@@ -188,7 +203,7 @@ class TrainStep(object):
             model_input['light_direction'] = F.normalize(self.light_para(l_slt), p=2, dim=-1)
             if self.light_inten_train:
                 model_input['light_intensity'] = self.light_inten_para(l_slt)
-        if 'light_vis_train' not in model_input:
+        if self.light_train and 'light_vis_train' not in model_input:
             if l_slt.is_cuda and self.light_vis_table.is_cuda:
                 from .. import hip
                 model_input['light_vis_train'] = hip.light_rows_fwd(self.light_vis_table.contiguous(), None, l_slt.long().contiguous())[0]
@@ -209,12 +224,17 @@ class TrainStep(object):
         else:
             count = self.dp.global_count(sm & om)
         out = self.model(model_input, noise=noise)
-        fl = fused_losses(self.loss, self.loss_n, out, ground_truth, model_input, count) if self.FUSED_LOSSES else None
+        fl = fused_losses(self.loss, self.loss_n, out, ground_truth, model_input, count) if (self.FUSED_LOSSES and self.normal_train) else None
         if fl is None and torch.is_tensor(count):
             count = int(count.item())
         if fl is not None:  # both loss modules in two launches forward / one backward (csrc/loss.hip)
             loss, terms, terms_n = fl
             terms = dict(terms)
+        elif not self.normal_train:
+            # trainer.py:397-399: without a jointly trained normal net the step has MainLoss only (no shipped configuration; torch formulation)
+            terms = dict(self.loss(out, ground_truth, model_input, count=count))
+            terms_n = {'loss': None, 'normal_loss': None, 'normal_smooth_loss': None}
+            loss = terms['loss']
         else:
             terms = dict(self.loss(out, ground_truth, model_input, count=count))
             terms_n = self.loss_n(out, count=count)

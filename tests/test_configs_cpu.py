@@ -188,33 +188,49 @@ def test_integration_section_a_lines_run_against_psnerf_amd(tmp_path):
 
 def test_bench_watchdog_prints_the_headline_when_the_diagnostic_object_hangs():
     """bench.guarded: strong_cfg4 at N > 1 (HIP graphs around RCCL collectives) runs behind a watchdog -- if it never returns, rank 0
-    prints the line it had assembled, with an error in place of the object, and the process leaves with exit code 0."""
+    prints the line it had assembled, with an error in place of the object, and the process leaves with exit code 3 (a hung run is not a success)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, time; sys.path.insert(0, %r); import bench; "
             "bench.guarded(lambda: time.sleep(60), {'metric': 'm', 'value': 1.5, 'strong_cfg4': None}, 0, timeout=1)") % root
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=50)
-    assert r.returncode == 0, r.stderr[-500:]
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['value'] == 1.5 and 'did not return' in line['strong_cfg4']['error']
     # a rank other than 0 leaves silently; a function that returns in time is passed through
     code2 = ("import sys, time; sys.path.insert(0, %r); import bench; "
              "print(bench.guarded(lambda: 7, {'x': 1}, 0, timeout=5), flush=True); bench.guarded(lambda: time.sleep(60), {'x': 1}, 1, timeout=1)") % root
     r = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, timeout=50)
-    assert r.returncode == 0 and r.stdout.strip() == '7', (r.stdout, r.stderr[-300:])
+    assert r.returncode == 3 and r.stdout.strip() == '7', (r.stdout, r.stderr[-300:])
 
 
-def test_train_step_refuses_switches_it_does_not_implement():
-    """stage2/trainer.py:36-50 has switches that no shipped configuration uses (ground-truth lights, ana_fixlight, visibility
-    without its loss): the product's TrainStep raises on them instead of silently training something else; the two that DO vary
-    between the shipped configurations -- train.light_inten_train (off for bunny / armadillo) and train.light_decay -- are read."""
+def test_train_step_reads_the_trainer_switches_with_the_reference_defaults():
+    """stage2/trainer.py:36-50: train.light_train / train.ana_fixlight / train.visibility / train.vis_loss default to False in the
+    reference; a configuration that leaves them out must train what the reference would (no light tables, no visibility loss).
+    The switches are implemented (goldens: tests/golden/stage2_trainer_{gtlight,fixlight,novisloss}.npz); train.vis_plus without
+    train.light_train fails like the reference (trainer.py:149,388: 'light_vis_train' does not exist there).  The two switches that
+    vary between the shipped configurations -- train.light_inten_train (off for bunny / armadillo) and train.light_decay -- are read."""
     import torch
     import psnerf_amd.stage2 as s2
     li = torch.nn.functional.normalize(torch.randn(6, 3), dim=-1)
-    for over in ({'train.light_train': False}, {'train.ana_fixlight': True}, {'train.vis_loss': False}):
-        conf = s2.bear_conf(**over)
-        with pytest.raises(NotImplementedError):
-            s2.TrainStep(s2.PSNetwork(conf), conf, 6, li, torch.device('cpu'))
+    conf = s2.bear_conf()
+    for k in ('light_train', 'vis_loss', 'ana_fixlight'):
+        conf['train'].pop(k, None)
+    st = s2.TrainStep(s2.PSNetwork(conf), conf, 6, li, torch.device('cpu'))
+    assert not st.light_train and not st.vis_loss and st.visibility and not st.ana_fixlight and not st.light_inten_train
+    assert not st.light_para.weight.requires_grad
+    st.train_fix()   # iteration 0: without the loss the visibility net is frozen (trainer.py:498-499) ...
+    assert not any(q.requires_grad for q in st.model.visibility_net.parameters())
+    st.cur_iter = 5000
+    st.train_fix()   # ... and never released; the tables of a run without light_train stay frozen as well
+    assert not any(q.requires_grad for q in st.model.visibility_net.parameters()) and not st.light_para.weight.requires_grad
+    conf = s2.bear_conf(**{'train.ana_fixlight': True})
+    st = s2.TrainStep(s2.PSNetwork(conf), conf, 6, li, torch.device('cpu'))
+    st.train_fix(); st.cur_iter = 5000; st.train_fix()
+    assert st.light_train and not st.light_para.weight.requires_grad and all(q.requires_grad for q in st.model.albedo_net.parameters())
+    conf = s2.bear_conf(**{'train.light_train': False})
+    with pytest.raises(AttributeError):
+        s2.TrainStep(s2.PSNetwork(conf), conf, 6, li, torch.device('cpu'), vis_plus=object())
     for obj, inten in (('bear', True), ('reading', True), ('armadillo', False), ('bunny', False)):
         from psnerf_amd.stage2.conf import object_conf
         conf = object_conf(obj)

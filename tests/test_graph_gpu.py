@@ -97,6 +97,42 @@ def test_graphed_step_is_bit_identical_to_eager(cuda, start_iter, overlap):
     assert torch.equal(o_e, o_g)
 
 
+def test_alternating_signatures_and_an_empty_batch_keep_every_graph_on_its_own_plan(cuda):
+    """Two batch geometries (different pixel counts -> two graphs with different surface counts) replayed alternately, with an
+    UNPADDED batch without a single surface pixel in between (its loss has no graph: every .grad is None, both optimisers have
+    nothing to do -- and must neither crash beside live graphs nor wipe the host-side plans the replays advance their step counts
+    and step sizes from; optim.*.graph_advance(plan), one plan snapshot per capture).  Against the eager step: bit for bit."""
+    from psnerf_amd.stage2.graph import GraphedTrainStep
+    res = {}
+    for mode in ('eager', 'graph'):
+        step, NL = _make(cuda, 5001)
+        big = _batches(6, 3000, 12, 4, NL, cuda)
+        small = _batches(6, 1700, 12, 4, NL, cuda)
+        e_inp, e_gt, e_l, _ = _batches(1, 1700, 12, 4, NL, cuda)[0]
+        e_inp = dict(e_inp)
+        e_inp['surface_mask'] = torch.zeros_like(e_inp['surface_mask'])
+        e_inp['surface_idx'] = e_inp['surface_idx'][:0]
+        order = [big[0], small[0], big[1], small[1], big[2], small[2], (e_inp, e_gt, e_l, None), big[3], small[3],
+                 (e_inp, e_gt, e_l, None), small[4], big[4], big[5], small[5]]
+        run = GraphedTrainStep(step, warmup=2) if mode == 'graph' else step
+        losses = []
+        for inp, gt, l_slt, nz in order:
+            terms, out = run.step(inp, gt, l_slt, train_order=True, noise=nz)
+            losses.append(terms['total'].detach().reshape(()).clone())
+        torch.cuda.synchronize()
+        if mode == 'graph':
+            # the empty batch is a third signature: it runs eagerly both times (warm-up count 2), the two real ones are captured
+            assert run.n_captures == 2 and run.n_eager == 6 and run.n_replays == len(order) - 6, (run.n_captures, run.n_eager, run.n_replays)
+        res[mode] = (torch.stack(losses).cpu(), _state(step))
+    (l_e, s_e), (l_g, s_g) = res['eager'], res['graph']
+    assert torch.isfinite(l_e).all() and torch.equal(l_e, l_g), (l_e - l_g).abs().max()
+    for k in s_e:
+        assert torch.equal(s_e[k], s_g[k]), k
+    # the step counts advanced with the steps that HAD gradients only: 12 of the 14
+    steps = [float(v) for k, v in s_g.items() if k.startswith('__opt_sg_') and k.endswith('_step')]
+    assert steps and all(v == 12.0 for v in steps), steps
+
+
 def test_graphed_step_draws_fresh_jitter_noise_every_replay(cuda):
     """Without injected noise the model draws the xyz jitter on the device (renderer.py:212): under replay the generator's
     offset must advance, i.e. two replays of the same batch see different jitter and therefore different smoothness terms."""

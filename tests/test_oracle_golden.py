@@ -307,14 +307,21 @@ def test_stage2_psnetwork_normal_jitter():
     assert_close(projs, g['grad_projs'], 1e-4, 'grad projs')
 
 
-def _trainer_golden_steps(make_step, dev='cpu', vis_plus=False, inten_train=True):
+def _trainer_golden_steps(make_step, dev='cpu', vis_plus=False, inten_train=True, variant=None):
     """Replay tests/golden/stage2_trainer[_visplus].npz -- six iterations of the reference's OWN TrainRunner.run across the
     iteration-5000 train_fix switch, without / with the train.vis_plus supervision draw -- through a TrainStep built by
     ``make_step(sd, NL, light_init, tables)``; tables = None or the vis_plus tables (per view: 'vis_plus' [P, hw],
     'vis_plus_light' [P, 3], 'visibility' [L_v, hw]; + the per-view initial light estimates and vnum)."""
     # inten_train=False: stage2_trainer_nointen.npz -- train.light_inten_train off as in bunny.conf / armadillo.conf (no intensity
     # table: trainer.py:38,154-163,378-379); make_step then receives the configuration as a fifth argument
-    g = load('stage2_trainer_visplus.npz' if vis_plus else ('stage2_trainer.npz' if inten_train else 'stage2_trainer_nointen.npz'))
+    # variant: 'gtlight' / 'fixlight' / 'novisloss' -- the trainer switches no shipped configuration uses (tools/gen_golden.py
+    # TRAINER_VARIANTS: train.light_train off, train.ana_fixlight, train.visibility without train.vis_loss in the single-light layout);
+    # the fixture carries its configuration overrides, make_step receives them as the fifth argument
+    import json
+    g = load('stage2_trainer_%s.npz' % variant if variant else
+             ('stage2_trainer_visplus.npz' if vis_plus else ('stage2_trainer.npz' if inten_train else 'stage2_trainer_nointen.npz')))
+    over = json.loads(str(g['overrides'])) if variant else ({} if inten_train else {'train.light_inten_train': False})
+    multi_light = bool(over.get('train.multi_light', True))
     conf = o2.bear_conf()
     sd = stage2_state_dict(conf, seed=41)
     assert state_dict_digest(sd) == str(g['sd_digest'])
@@ -327,7 +334,7 @@ def _trainer_golden_steps(make_step, dev='cpu', vis_plus=False, inten_train=True
                  for v in range(2)]
         tables = dict(views=views, view_light=[light_init[:n0], light_init[n0:]], vnum=int(g['vnum']))
         np.random.seed(int(g['np_seed']))
-    step = make_step(sd, NL, light_init, tables) if inten_train else make_step(sd, NL, light_init, tables, {'train.light_inten_train': False})
+    step = make_step(sd, NL, light_init, tables, over) if over else make_step(sd, NL, light_init, tables)
     step.cur_iter = 0
     step.train_fix()                       # trainer.py:486-504: the state iteration 0 leaves behind
     step.cur_iter = int(g['first_iter'])
@@ -336,6 +343,8 @@ def _trainer_golden_steps(make_step, dev='cpu', vis_plus=False, inten_train=True
     for i in range(6):
         inp, gt = stage2_inputs(N, L, V, seed=int(g['input_seeds'][i % 3]))
         inp = {k: v.to(dev) for k, v in inp.items() if k not in ('light_intensity', 'light_vis_train', 'vis_train_gt')}
+        if not multi_light:
+            inp.pop('visibility')  # a data set built without train.vis_loss has none (dataset.py:168-169)
         vidx = None
         if vis_plus:
             vidx = int(g['views'][i % 3])
@@ -346,12 +355,14 @@ def _trainer_golden_steps(make_step, dev='cpu', vis_plus=False, inten_train=True
     return g, names, logs, step
 
 
-@pytest.mark.parametrize('vis_plus,inten_train', [(False, True), (True, True), (False, False)])
-def test_train_step_reproduces_the_reference_trainer_run(vis_plus, inten_train):
+@pytest.mark.parametrize('vis_plus,inten_train,variant', [(False, True, None), (True, True, None), (False, False, None),
+                                                          (False, True, 'gtlight'), (False, True, 'fixlight'), (False, True, 'novisloss')])
+def test_train_step_reproduces_the_reference_trainer_run(vis_plus, inten_train, variant):
     """a24: the oracle's TrainStep against the reference's own TrainRunner.run / train_fix (stage2/trainer.py:355-410,
     462-464, 485-513), six iterations across the switch at iteration 5000 (two with the BRDF nets and the light tables frozen
     and vis_weight 10, four with everything training), without and with the train.vis_plus draw (:384-392): every loss term of
-    every iteration, the final light tables and the final network parameters."""
+    every iteration, the final light tables and the final network parameters.  The variants run the same six iterations under the
+    trainer switches of stage2/trainer.py:36-50 that no shipped configuration uses (each fixture = the reference's own run)."""
     def make(sd, NL, light_init, tables, over=None):
         conf = o2.bear_conf(**(over or {}))
         net = o2.PSNetwork(conf)
@@ -361,8 +372,10 @@ def test_train_step_reproduces_the_reference_trainer_run(vis_plus, inten_train):
             vp = dict(light=[v['vis_plus_light'] for v in tables['views']], vis=[v['vis_plus'] for v in tables['views']],
                       view_light=tables['view_light'], view_vis=[v['visibility'] for v in tables['views']], vnum=tables['vnum'])
         return o2.TrainStep(net, conf, NL, light_init, vis_plus=vp)
-    g, names, logs, step = _trainer_golden_steps(make, vis_plus=vis_plus, inten_train=inten_train)
-    assert step.light_inten_train == inten_train and len(step.light_optimizer.param_groups) == (2 if inten_train else 1)
+    g, names, logs, step = _trainer_golden_steps(make, vis_plus=vis_plus, inten_train=inten_train, variant=variant)
+    assert step.light_inten_train == (inten_train and variant != 'gtlight')
+    assert len(step.light_optimizer.param_groups) == (2 if step.light_inten_train else 1)
+    assert ('vis_loss' in names) == (variant != 'novisloss')
     for i in range(6):
         for k, v in zip(names, g['loss_vals'][i]):
             if np.isnan(v):

@@ -428,15 +428,20 @@ def test_surface_idx_from_the_data_pipeline(cuda):
     assert bool(torch.isfinite(t1['total']))
 
 
-@pytest.mark.parametrize('vis_plus,inten_train', [(False, True), (True, True), (False, False)])
-def test_train_step_vs_reference_trainer_run(cuda, vis_plus, inten_train):
+@pytest.mark.parametrize('vis_plus,inten_train,variant', [(False, True, None), (True, True, None), (False, False, None),
+                                                          (False, True, 'gtlight'), (False, True, 'fixlight'), (False, True, 'novisloss')])
+def test_train_step_vs_reference_trainer_run(cuda, vis_plus, inten_train, variant):
     """a24 against the reference's OWN trainer: tests/golden/stage2_trainer.npz holds six iterations of TrainRunner.run
     (stage2/trainer.py:355-410,462-464) across the train_fix switch at iteration 5000 (:485-513), produced by calling the
     reference's methods on a duck-typed runner (tools/gen_golden.py trainer).  The HIP TrainStep replays them: loss terms of
     every iteration, final light tables, final parameters (Adam: an element whose gradient sits at the fp32 noise floor may
     step the other way, so the maximum is bounded by 2 lr per step and the bulk must agree tightly).  inten_train=False: the run
     of stage2_trainer_nointen.npz -- train.light_inten_train off as in armadillo.conf / bunny.conf (BASELINE configs[4]): no
-    intensity table is trained or read, the model shades with its scalar brdf.light_intensity."""
+    intensity table is trained or read, the model shades with its scalar brdf.light_intensity.  variant: the trainer switches of
+    stage2/trainer.py:36-50 no shipped configuration uses -- 'gtlight' train.light_train off (the batch's lights as given, no
+    tables, visibility loss on the L shading rows), 'fixlight' train.ana_fixlight (tables frozen behind the switch), 'novisloss'
+    train.visibility without train.vis_loss (visibility net frozen for good; single-light layout) -- each against the reference's
+    own TrainRunner.run under that switch (tests/golden/stage2_trainer_<variant>.npz)."""
     import psnerf_amd.stage2 as s2
     from tests.test_oracle_golden import _trainer_golden_steps
 
@@ -448,8 +453,8 @@ def test_train_step_vs_reference_trainer_run(cuda, vis_plus, inten_train):
         net.to(cuda)
         vp = VisPlus(tables['views'], tables['view_light'], tables['vnum'], cuda) if tables is not None else None
         return s2.TrainStep(net, conf, NL, light_init.to(cuda), cuda, vis_plus=vp)
-    g, names, logs, step = _trainer_golden_steps(make, dev=cuda, vis_plus=vis_plus, inten_train=inten_train)
-    assert step.light_inten_train == inten_train and len(step.light_optimizer.param_groups) == (2 if inten_train else 1)
+    g, names, logs, step = _trainer_golden_steps(make, dev=cuda, vis_plus=vis_plus, inten_train=inten_train, variant=variant)
+    assert step.light_inten_train == (inten_train and variant != 'gtlight')
     for i in range(6):
         assert_close(float(logs[i]['total'].detach()), float(g['total'][i]), 1e-4 if i == 0 else 1e-3, 'it %d total' % (4998 + i), atol=0.0)
         for k, v in zip(names, g['loss_vals'][i]):
@@ -461,7 +466,10 @@ def test_train_step_vs_reference_trainer_run(cuda, vis_plus, inten_train):
             else:
                 assert_close(float(got.detach()), float(v), 1e-4 if i == 0 else 1e-3, 'it %d %s' % (4998 + i, k), atol=0.0)
     # phase switch happened: BRDF nets and light tables train from iteration 5000 on
-    assert step.loss.sg_rgb_weight == 1.0 and step.light_para.weight.requires_grad
+    assert step.loss.sg_rgb_weight == 1.0 and step.light_para.weight.requires_grad == (variant not in ('gtlight', 'fixlight'))
+    assert any(q.requires_grad for q in step.model.visibility_net.parameters()) == (variant != 'novisloss')
+    if variant in ('gtlight', 'fixlight'):  # the tables never moved
+        assert torch.equal(step.light_para.weight.detach().cpu(), torch.from_numpy(g['light_init']))
     lr, lr_int, n_light_steps = 5e-4, 1e-3, 4
     d = (step.light_para.weight.detach().cpu() - torch.from_numpy(g['light_para'])).abs()
     assert float(d.max()) <= 2 * n_light_steps * lr + 1e-6 and float(d.mean()) <= 2e-5, (float(d.max()), float(d.mean()))

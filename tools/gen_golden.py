@@ -8,6 +8,7 @@ Usage:  python tools/gen_golden.py stage1 | stage2 | trainer | configs | all
 Weights are not stored for full-width nets: tests regenerate them from seeds
 (tests/helpers.py) and compare the sha256 stored in the fixture.
 """
+import json
 import os
 import subprocess
 import sys
@@ -658,7 +659,21 @@ def gen_stage2():
 
 
 # ---------------------------------------------------------------------------
-def gen_trainer(vis_plus=False, inten_train=True):
+TRAINER_VARIANTS = {   # fixture name -> the switches of stage2/trainer.py:36-50 that differ from bear.conf
+    None: {},
+    'gtlight': {'train.light_train': False},      # ground-truth lights: no tables, no SparseAdam, vis loss on the L shading rows
+    'fixlight': {'train.ana_fixlight': True},     # the light tables stay frozen behind the iteration-5000 switch
+    'novisloss': {'train.vis_loss': False, 'train.multi_light': False},  # visibility net frozen at iteration 0; single-light layout
+}                                                  # (under multi_light the reference fails at trainer.py:366 with KeyError 'visibility')
+
+
+def trainer_fixture_name(vis_plus=False, inten_train=True, variant=None):
+    if variant is not None:
+        return 'stage2_trainer_%s.npz' % variant
+    return 'stage2_trainer_visplus.npz' if vis_plus else ('stage2_trainer.npz' if inten_train else 'stage2_trainer_nointen.npz')
+
+
+def gen_trainer(vis_plus=False, inten_train=True, variant=None):
     """stage2/trainer.py: the reference's OWN TrainRunner.run / train_fix (the step body :355-410,462-464 and the schedule
     :485-513) driven for six iterations across the iteration-5000 switch.  The module imports with empty placeholders for
     the third-party packages this image lacks (pyhocon, tensorboardX, imageio, cv2, skimage, plotly, GPUtil, trimesh: none is
@@ -666,7 +681,8 @@ def gen_trainer(vis_plus=False, inten_train=True):
     reads: a list as the data loader, the reference's model / loss classes, torch's Adam / SparseAdam as trainer.py:126-168
     constructs them.  No reference edits.  Writes tests/golden/stage2_trainer.npz (vis_plus: stage2_trainer_visplus.npz;
     inten_train=False -- train.light_inten_train absent, as in bunny.conf / armadillo.conf: no intensity table, the model shades with
-    its scalar brdf.light_intensity, trainer.py:38,154-163,378-379 -- stage2_trainer_nointen.npz)."""
+    its scalar brdf.light_intensity, trainer.py:38,154-163,378-379 -- stage2_trainer_nointen.npz).  ``variant``: one of
+    TRAINER_VARIANTS -- the trainer switches no shipped configuration uses (stage2_trainer_<variant>.npz)."""
     import tempfile
     import types
     from oracle import stage2 as o2
@@ -689,10 +705,15 @@ def gen_trainer(vis_plus=False, inten_train=True):
     from model.renderer import PSNetwork as RPS
     from model.loss import MainLoss as RMain, NormalLoss as RNormal
 
-    conf = o2.bear_conf(**{'train.vis_train_num': 5, 'train.light_inten_train': bool(inten_train)})
+    over = dict(TRAINER_VARIANTS[variant])
+    multi_light = bool(over.get('train.multi_light', True))
+    light_train = bool(over.get('train.light_train', True))
+    conf = o2.bear_conf(**{'train.vis_train_num': 5, 'train.light_inten_train': bool(inten_train), **over})
     sd = stage2_state_dict(conf, seed=41)
     N, L, V, NL = 360, 4, 3, 12
     light_slt = [list(range(5)), list(range(7))]          # two views with 5 and 7 lights: rows 0..4 and 5..11 of the tables
+    if not multi_light:   # one light per view (dataset.py:141-147): the tables have one row per view, l_slt = [view] (trainer.py:375)
+        L, NL, light_slt = 1, 2, [[0], [0]]
     g = torch.Generator().manual_seed(17)
     light_init = [torch.nn.functional.normalize(torch.randn(len(ls), 3, generator=g), dim=-1) * 1.3 for ls in light_slt]  # un-normalised on purpose
     batches = []
@@ -701,10 +722,14 @@ def gen_trainer(vis_plus=False, inten_train=True):
         view = b % 2
         lidx = torch.randperm(len(light_slt[view]), generator=g)[:L]
         mi = {k: inp[k] for k in ('intrinsics', 'uv', 'pose', 'object_mask', 'surface_mask', 'points', 'normal')}
-        mi['light_direction'] = inp['light_direction'][None]          # collated: batch dimension (trainer.py:366 strips it)
-        mi['visibility'] = inp['visibility'][None]
-        mi['lidx'] = lidx[None]
-        batches.append((torch.tensor([view]), mi, {'rgb': gt['rgb'][None]}))
+        if multi_light:
+            mi['light_direction'] = inp['light_direction'][None]          # collated: batch dimension (trainer.py:366 strips it)
+            mi['visibility'] = inp['visibility'][None]
+            mi['lidx'] = lidx[None]
+            batches.append((torch.tensor([view]), mi, {'rgb': gt['rgb'][None]}))
+        else:   # single-light items: light_direction [3] -> collated [1,3], rgb [N,3] -> [1,N,3]; no 'visibility' without vis_loss (dataset.py:168)
+            mi['light_direction'] = inp['light_direction']
+            batches.append((torch.tensor([view]), mi, {'rgb': gt['rgb']}))
 
     # train.vis_plus (trainer.py:209-214, 384-392): per view P extra directions with their stage-1 visibility maps over the WHOLE
     # view (hw pixels) + the view's own lights / visibility; every step draws vnum of the P + L_v rows with np.random.choice
@@ -741,17 +766,23 @@ def gen_trainer(vis_plus=False, inten_train=True):
     ns.model = rnet
     ns.loss = Recorder(RMain(loss_type='L1', sg_rgb_weight=1.0, albedo_smooth_weight=0.05, rough_smooth_weight=0.01, vis_weight=1))
     ns.loss_n = Recorder(RNormal(1, 0.05))
-    ns.normal_train, ns.multi_light, ns.light_train, ns.light_inten_train = True, True, True, bool(inten_train)
-    ns.visibility, ns.vis_loss, ns.vis_plus, ns.ana_fixlight, ns.light_decay, ns.train_order = True, True, bool(vis_plus), False, False, True
+    ns.normal_train, ns.multi_light, ns.light_train, ns.light_inten_train = True, multi_light, light_train, bool(inten_train) and light_train
+    ns.visibility, ns.vis_loss, ns.vis_plus, ns.ana_fixlight, ns.light_decay, ns.train_order = \
+        True, bool(over.get('train.vis_loss', True)), bool(vis_plus), bool(over.get('train.ana_fixlight', False)), False, True
     ns.vis_plus_light = {'view_%02d' % (v + 1): vp_light[v].numpy().tolist() for v in range(2)}      # vis_plus/light_dir.json
     ns.vis_plus_all = {'view_%02d' % (v + 1): vp_vis[v].numpy().reshape(P, 30, 30) for v in range(2)}   # vis_plus/view_XX.npy
     # learning rates of stage2/confs/bear.conf:19-20,48-50 (the milestones lie beyond these iterations)
     ns.sg_optimizer = torch.optim.Adam(rnet.parameters(), lr=5e-4)
     ns.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(ns.sg_optimizer, [], gamma=0.5)
-    ns.light_para = torch.nn.Embedding(NL, 3, sparse=True)
-    ns.light_para.weight.data.copy_(torch.cat(light_init, dim=0))
-    ns.light_vis_train = [li.clone() for li in light_init]
-    if inten_train:
+    if not multi_light:
+        light_init = [li[:1] for li in light_init]
+    if light_train:   # (trainer.py:126-168; without it the runner has none of these attributes and the loop must never touch them)
+        ns.light_para = torch.nn.Embedding(NL, 3, sparse=True)
+        ns.light_para.weight.data.copy_(torch.cat(light_init, dim=0))
+        ns.light_vis_train = [li.clone() for li in light_init]
+    if not light_train:
+        pass
+    elif inten_train:
         ns.light_inten_para = torch.nn.Embedding(NL, 1, sparse=True)
         torch.nn.init.constant_(ns.light_inten_para.weight, rnet.light_int)
         ns.light_optimizer = torch.optim.SparseAdam(
@@ -781,8 +812,8 @@ def gen_trainer(vis_plus=False, inten_train=True):
     # the state train_fix left at iteration 0 (trainer.py:486-504), produced by the reference's own method
     ns.cur_iter = 0
     RT.TrainRunner.train_fix(ns)
-    assert ns.loss.vis_weight == 10 and ns.loss.sg_rgb_weight == 0 and not ns.light_para.weight.requires_grad \
-        and not any(q.requires_grad for q in rnet.albedo_net.parameters()) and any(q.requires_grad for q in rnet.visibility_net.parameters())
+    assert ns.loss.vis_weight == 10 and ns.loss.sg_rgb_weight == 0 and not (light_train and ns.light_para.weight.requires_grad) \
+        and not any(q.requires_grad for q in rnet.albedo_net.parameters()) and any(q.requires_grad for q in rnet.visibility_net.parameters()) == ns.vis_loss
     seed = 91
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -790,7 +821,9 @@ def gen_trainer(vis_plus=False, inten_train=True):
     with contextlib.redirect_stdout(io.StringIO()):
         RT.TrainRunner.run(ns)
     assert ns.cur_iter == 5004 and len(ns.loss.log) == 6
-    assert ns.loss.sg_rgb_weight == 1.0 and ns.light_para.weight.requires_grad and all(q.requires_grad for q in rnet.albedo_net.parameters())
+    assert ns.loss.sg_rgb_weight == 1.0 and all(q.requires_grad for q in rnet.albedo_net.parameters())
+    assert (not light_train) or ns.light_para.weight.requires_grad == (not ns.ana_fixlight)
+    assert any(q.requires_grad for q in rnet.visibility_net.parameters()) == ns.vis_loss   # (frozen for good without the loss, trainer.py:498-499)
 
     # the draws of the six forward passes (renderer.py:212: one torch.normal per step; normal jitter is off in bear.conf)
     torch.manual_seed(seed)
@@ -810,11 +843,13 @@ def gen_trainer(vis_plus=False, inten_train=True):
     for i in range(6):
         idx, mi, gt = batches[i % 3]
         view = int(idx[0])
-        l_slt = sum(accu[:view]) + mi['lidx'][0]
+        l_slt = (sum(accu[:view]) + mi['lidx'][0]) if multi_light else torch.tensor([view])   # trainer.py:370-375
         l_slts.append(l_slt)
         inp_o = {k: v for k, v in mi.items() if k not in ('lidx', 'vidx', 'vidx_ori')}
-        inp_o['light_direction'], inp_o['visibility'] = mi['light_direction'][0], mi['visibility'][0]
-        t, _ = ostep.step(inp_o, {'rgb': gt['rgb'][0]}, l_slt, train_order=True, noise={'xyz': noises[i]}, vidx=view if vis_plus else None)
+        if multi_light:
+            inp_o['light_direction'], inp_o['visibility'] = mi['light_direction'][0], mi['visibility'][0]
+        t, _ = ostep.step(inp_o, {'rgb': gt['rgb'][0] if multi_light else gt['rgb']}, l_slt, train_order=True, noise={'xyz': noises[i]},
+                          vidx=view if vis_plus else None)
         olog.append(t)
     keys = sorted(ns.loss.log[0])
     assert ns.loss.log[0]['albedo_smooth_loss'] is None and ns.loss.log[3]['albedo_smooth_loss'] is not None  # weight 0 before 5000
@@ -825,13 +860,21 @@ def gen_trainer(vis_plus=False, inten_train=True):
                 continue
             check('trainer it %d %s' % (4998 + i, k), float(olog[i][k]), ns.loss.log[i][k], 2e-6)
         check('trainer it %d normal_loss' % (4998 + i), float(olog[i]['normal_loss']), ns.loss_n.log[i]['normal_loss'], 2e-6)
+        assert ('vis_loss' in ns.loss.log[i]) == ns.vis_loss
     rsd, osd = rnet.state_dict(), onet.state_dict()
     # after Adam steps an element whose gradient sits at the fp32 noise floor may step the other way (|delta| <= 2 lr per step)
     for k in rsd:
         d = (rsd[k] - osd[k]).abs()
         assert float(d.max()) <= 2 * 6 * 5e-4 + 1e-6 and float(d.mean()) <= 2e-5, (k, float(d.max()), float(d.mean()))
-    check('trainer light table', ostep.light_para.weight.detach(), ns.light_para.weight.detach(), 1e-3)
-    if inten_train:
+    if light_train:
+        check('trainer light table', ostep.light_para.weight.detach(), ns.light_para.weight.detach(), 1e-3)
+        if ns.ana_fixlight:
+            assert float((ns.light_para.weight.detach() - torch.cat(light_init, dim=0)).abs().max()) == 0.0
+    else:
+        assert not hasattr(ns, 'light_para') and float((ostep.light_para.weight.detach() - torch.cat(light_init, dim=0)).abs().max()) == 0.0
+    if not light_train:
+        pass
+    elif inten_train:
         check('trainer light intensity', ostep.light_inten_para.weight.detach(), ns.light_inten_para.weight.detach(), 1e-3)
     else:
         assert not hasattr(ns, 'light_inten_para') and float((ostep.light_inten_para.weight.detach() - rnet.light_int).abs().max()) == 0.0
@@ -844,8 +887,9 @@ def gen_trainer(vis_plus=False, inten_train=True):
                      vp_light=np.stack([np_(x) for x in vp_light]), vp_vis=np.stack([np_(x) for x in vp_vis]).astype(np.uint8),
                      view_vis0=np_(view_vis[0]).astype(np.uint8), view_vis1=np_(view_vis[1]).astype(np.uint8))
     np.savez_compressed(
-        os.path.join(GOLDEN, 'stage2_trainer_visplus.npz' if vis_plus else ('stage2_trainer.npz' if inten_train else 'stage2_trainer_nointen.npz')), **extra,
+        os.path.join(GOLDEN, trainer_fixture_name(vis_plus, inten_train, variant)), **extra,
         sd_digest=state_dict_digest(sd), N=N, L=L, V=V, NL=NL, input_seeds=np.array([200, 201, 202]), light_split=np.array([len(l) for l in light_slt]),
+        **({} if variant is None else dict(variant=str(variant), overrides=json.dumps(over))),
         light_init=np_(torch.cat(light_init, dim=0)), l_slt=np.stack([np_(x) for x in l_slts]), first_iter=4998,
         noise0=np_(noises[0]), noise1=np_(noises[1]), noise2=np_(noises[2]), noise3=np_(noises[3]), noise4=np_(noises[4]), noise5=np_(noises[5]),
         # 'total' = what trainer.py:396-399 backpropagates (and, `loss += ...` being in place, what loss_output['loss'] holds afterwards)
@@ -853,12 +897,12 @@ def gen_trainer(vis_plus=False, inten_train=True):
         loss_names=np.array(lk + ['normal_loss']),
         loss_vals=np.array([[(np.nan if ns.loss.log[i][k] is None else ns.loss.log[i][k]) for k in lk] + [ns.loss_n.log[i]['normal_loss']]
                             for i in range(6)]),  # nan = the reference returned None (term switched off)
-        light_para=np_(ns.light_para.weight.detach()),
-        light_inten_para=np_(ns.light_inten_para.weight.detach()) if inten_train else np.full((NL, 1), rnet.light_int, dtype=np.float32),
+        light_para=np_(ns.light_para.weight.detach()) if light_train else np_(torch.cat(light_init, dim=0)),
+        light_inten_para=np_(ns.light_inten_para.weight.detach()) if (inten_train and light_train) else np.full((NL, 1), rnet.light_int, dtype=np.float32),
         # final parameters: the first 2048 elements of every tensor (element-level check) + whole-tensor digests
         param_names=np.array(sorted(rsd)), param_norms=grad_digest(rsd)[1], param_projs=grad_digest(rsd)[2],
         **{('p_' + k): np_(v.reshape(-1)[:2048]) for k, v in rsd.items()})
-    print('stage2 trainer golden written (vis_plus=%s, inten_train=%s)' % (vis_plus, inten_train))
+    print('stage2 trainer golden written (vis_plus=%s, inten_train=%s, variant=%s)' % (vis_plus, inten_train, variant))
 
 
 def gen_configs():
@@ -926,6 +970,8 @@ if __name__ == '__main__':
         gen_trainer(False)
         gen_trainer(True)
         gen_trainer(False, inten_train=False)
+        for variant in ('gtlight', 'fixlight', 'novisloss'):
+            gen_trainer(variant=variant)
     elif what == 'stage1':
         gen_stage1()
     elif what == 'stage2':
