@@ -533,6 +533,32 @@ int psn_mask_count(const unsigned char* mask_a, const unsigned char* mask_b, int
  *   only the first count[0] entries of idx are real -- an EMPTY mask then gives no pixel a row. */
 int psn_surface_index(const unsigned char* mask, int64_t n, int64_t cap, int64_t* idx, float* count, void* stream);
 int psn_inverse_index(const int64_t* idx, int64_t ns, int64_t n_pix, int* inv, const float* count, void* stream);
+/* psn_view_batch: ONE training batch of stage 2 gathered on the device from view tables that stay resident in HBM -- replaces the
+ * host-side item construction of stage2/datasets/dataset.py:137-199 (light subset :149-151 -> rgb = imgs[view][lidx] * object_mask
+ * :172; pixel subset :182-195 -> every per-pixel tensor indexed with sampling_idx), the un-batching of stage2/trainer.py:364-367 and
+ * the vis_plus selection of stage2/trainer.py:384-392 (vis_train_gt = vis_plus_v[sidx][:, sampling_idx]) + the upload of the batch.
+ * Only the drawn INDEX lists (lidx, pix, vidx: device int64) are per-step inputs; a data-parallel rank passes its slice of pix.
+ *   images [n_view_lights, hw, 3] of image_type 0 = float32 | 1 = uint8 | 2 = uint16; integer images are decoded through lut
+ *     ([256] / [65536] floats = value / 255 exactly as the reference's numpy division forms it, dataset.py:121);
+ *   object_mask / surface_mask [hw] bytes, points / normal [hw, 3], visibility [n_view_lights, hw], vis_plus [n_rows, hw],
+ *     light_direction [n_view_lights, 3] floats;
+ *   pix [n] pixel indices, or NULL = the identity range pix0 .. pix0 + n (a test-split item, dataset.py:182 not taken); width = image
+ *     width (uv = (pix % width, pix / width) as floats, dataset.py:138-140).
+ * Outputs (any may be NULL = not produced; all contiguous): rgb [n_lights, n, 3]; object_mask_out / surface_mask_out [n] bytes;
+ * uv [n, 2]; points_out / normal_out [n, 3]; visibility_out [n_lights, n]; vis_train_gt [n_vis, n]; sampling_idx_out [n] int64;
+ * light_direction_out [n_lights, 3] = light_direction[lidx]. */
+typedef struct {
+    const void* images; int image_type; const float* lut;
+    const unsigned char* object_mask; const unsigned char* surface_mask;
+    const float* points; const float* normal; const float* visibility; const float* vis_plus; const float* light_direction;
+    int64_t hw; int width;
+    const int64_t* lidx; int n_lights;
+    const int64_t* pix; int64_t pix0; int64_t n;
+    const int64_t* vidx; int n_vis;
+    float* rgb; unsigned char* object_mask_out; unsigned char* surface_mask_out; float* uv; float* points_out; float* normal_out;
+    float* visibility_out; float* vis_train_gt; int64_t* sampling_idx_out; float* light_direction_out;
+} PsnViewBatch;
+int psn_view_batch(const PsnViewBatch* b, void* stream);
 #define PSN_ADAM_MAX_SEGS 16
 typedef struct {
     int64_t offset, grad_offset, n;    /* elements [offset, offset + n) of param / exp_avg / exp_avg_sq, [grad_offset, ..+n) of grad */

@@ -216,3 +216,316 @@ class ViewSampler(object):
             gt = {k: v.to(device) for k, v in gt.items()}
             l_slt = l_slt.to(device)
         return idx, mi, gt, l_slt
+
+    def change_sampling_idx(self, sampling_size):
+        """dataset.py:219-226: the per-epoch pixel subset when train.sample_in_mask is off (python's ``random.sample``; with
+        sample_in_mask every item draws its own subset and this one is only a size)."""
+        import random
+        if sampling_size == -1:
+            self.sampling_idx = None
+        else:
+            self.sampling_idx = torch.tensor(random.sample(range(self.total_pixels), sampling_size)).long()
+
+
+class _Draw(object):
+    """The host-side random draws of one item, in the reference's order (lights, pixels, vis_plus rows)."""
+    __slots__ = ('idx', 'lidx', 'pix', 'vis_rows')
+
+    def __init__(self, idx, lidx, pix, vis_rows):
+        self.idx, self.lidx, self.pix, self.vis_rows = idx, lidx, pix, vis_rows
+
+
+class DeviceViews(object):
+    """``ViewSampler`` with the views RESIDENT IN HBM and the batch assembled on the device.
+
+    The reference builds every training item on the host (stage2/datasets/dataset.py:137-199: ``imgs[view][lidx] * mask`` =
+    light_bs x h*w x 3 floats materialised per iteration, then every per-pixel tensor indexed with the drawn pixel list) and
+    uploads the whole batch (trainer.py:381-382); at BEAR shapes that is 0.3 - 1.8 s of host time per 25 ms GPU step.  Here
+    every per-view table -- images (uint8 / uint16 as decoded when every value is k / 255, else float32), object / surface
+    masks, stage-1 points, normals, visibility maps, the vis_plus tables of ``VisPlus`` -- is uploaded ONCE (20 views x 96
+    lights x 612 x 512: 1.8 GB as uint8, 7.2 GB as float32, of 288 GB), and a step consists of
+
+      * ``draw(idx)``   -- the random draws, on the host, from the same ``np.random`` stream in the reference's order: the light
+                           subset (dataset.py:149-151), the in-mask pixel subset (:182-185), the vis_plus rows (trainer.py:389);
+      * ``assemble(d)`` -- ONE small host -> device copy of the drawn index lists (pinned, asynchronous) and ONE gather launch
+                           (csrc/views.hip psn_view_batch) that writes the batch; under data parallelism (``dp``) a rank gathers only
+                           ITS ``slice_bounds`` share of the drawn pixel list, and the index list of its surface pixels comes from
+                           the host copy of the view's surface mask (no nonzero(), no synchronisation).
+
+    ``batch(idx)`` = both; the result equals ``ViewSampler.batch(idx, device)`` (``dp.shard_stage2`` of it under data parallelism)
+    bit for bit, with 'light_vis_train' / 'vis_train_gt' of the vis_plus draw already in the dictionary when a ``VisPlus`` table
+    is attached (``TrainStep.step`` is then called WITHOUT ``vidx``: the draw has been made here).  ``loader(order)`` runs draws and gathers of the next items in a worker thread on a side
+    stream, so that the ~7 ms a 280k-pixel ``np.random.choice`` takes (numpy releases the GIL inside it) never sits in front of a step."""
+
+    def __init__(self, views, images, object_masks, light_direction, poses, intrinsics, light_bs, device, n_pixels=None,
+                 sample_in_mask=True, vis_loss=True, split='train', gt_normal=None, rng=None, dp=None, vis_plus=None,
+                 image_store='auto'):
+        from . import hip
+        self.hip = hip
+        self.device = torch.device(device)
+        dev = self.device
+        self.light_bs, self.n_pixels, self.sample_in_mask = int(light_bs), n_pixels, sample_in_mask
+        self.vis_loss, self.split = vis_loss, split
+        self.rng = rng if rng is not None else np.random
+        self.dp, self.vis_plus = dp, vis_plus
+        self.img_res = list(views[0]['img_res'])
+        self.total_pixels = self.img_res[0] * self.img_res[1]
+        hw = self.total_pixels
+        self.sampling_idx = None if n_pixels is None else torch.zeros(n_pixels, dtype=torch.long)
+        self.n_lights = [int(ld.shape[0]) for ld in light_direction]
+        self.light_offset = np.concatenate([[0], np.cumsum(self.n_lights)]).astype(np.int64)
+        # value tables of integer images: (float32) k / 255. exactly as numpy forms it in dataset.py:121
+        self._lut = {}
+        self.tables, self.pick, self.surf_host = [], [], []
+        for v, view in enumerate(views):
+            img = images[v]
+            img = torch.as_tensor(img) if not torch.is_tensor(img) else img
+            img = self._store(img.reshape(img.shape[0], hw, 3), image_store)
+            om = torch.as_tensor(object_masks[v]).reshape(hw).bool()
+            sm = view['surface_mask'].reshape(hw).bool()
+            t = {'images': img.to(dev).contiguous(), 'width': self.img_res[1],
+                 'object_mask': om.to(dev).contiguous(), 'surface_mask': sm.to(dev).contiguous(),
+                 'points': view['points'].reshape(hw, 3).float().to(dev).contiguous(),
+                 'normal': view['normal'].reshape(hw, 3).float().to(dev).contiguous(),
+                 'light_direction': torch.as_tensor(light_direction[v]).float().to(dev).contiguous()}
+            if img.dtype != torch.float32:
+                t['lut'] = self._value_table(img.dtype)
+            if vis_loss:
+                t['visibility'] = view['visibility'].reshape(-1, hw).float().to(dev).contiguous()
+            if vis_plus is not None:
+                t['vis_plus'] = vis_plus.vis[v].contiguous()
+                t['vis_plus_light'] = vis_plus.lights[v].contiguous()
+            self.tables.append(t)
+            self.pick.append(np.arange(hw)[om.cpu().numpy()])  # dataset.py:184 (fixed per view: cached)
+            self.surf_host.append(sm.cpu().numpy())
+        self.poses = [torch.as_tensor(p).float().reshape(1, 4, 4).to(dev) for p in poses]
+        self.intrinsics = torch.as_tensor(intrinsics).float().reshape(1, *torch.as_tensor(intrinsics).shape[-2:]).to(dev)
+        self.vidx_dev = [torch.tensor(v, device=dev) for v in range(len(views))]
+        self.gt_normal = None if gt_normal is None else [torch.as_tensor(g).float().reshape(1, hw, 3).to(dev) for g in gt_normal]
+        self._pinned = {}   # staging rows of the index lists (one ring per thread)
+        self.host_seconds = {'draw': 0.0, 'assemble': 0.0, 'items': 0}
+
+    # ---- storage ----------------------------------------------------------------------------------------------------------
+    def _value_table(self, dtype):
+        if dtype not in self._lut:
+            n = 256 if dtype == torch.uint8 else 65536
+            self._lut[dtype] = torch.from_numpy(np.arange(n).astype(np.float32) / 255.).to(self.device)
+        return self._lut[dtype]
+
+    @staticmethod
+    def _store(img, image_store):
+        """Integer images stay as decoded; float images are stored as uint8 when EVERY value is exactly (float32) k / 255. (what
+        dataset.py:121 makes of an 8-bit PNG) and image_store allows it -- the gathered batch is bit-identical either way."""
+        if img.dtype in (torch.uint8, torch.uint16):
+            return img
+        img = img.float()
+        if image_store == 'float32':
+            return img
+        lut = torch.from_numpy(np.arange(256).astype(np.float32) / 255.)
+        k = (img * 255.0).round().clamp_(0, 255).to(torch.uint8)
+        if bool((lut[k.long()] == img).all()):
+            return k
+        assert image_store == 'auto', 'DeviceViews: the images are not 8-bit values / 255 (image_store=%r)' % (image_store,)
+        return img
+
+    def __len__(self):
+        return len(self.tables)
+
+    def change_sampling_idx(self, sampling_size):
+        import random
+        if sampling_size == -1:
+            self.sampling_idx = None
+        else:
+            self.sampling_idx = torch.tensor(random.sample(range(self.total_pixels), sampling_size)).long()
+
+    def resident_bytes(self):
+        return sum(t.numel() * t.element_size() for tab in self.tables for t in tab.values() if torch.is_tensor(t))
+
+    # ---- host half: the draws ----------------------------------------------------------------------------------------------
+    def draw(self, idx):
+        import time
+        t0 = time.perf_counter()
+        idx = int(idx)
+        n_l = self.n_lights[idx]
+        if self.split == 'train' and n_l >= self.light_bs:
+            lidx = self.rng.choice(np.arange(n_l), self.light_bs, replace=False).astype(np.int64)   # dataset.py:149
+        else:
+            lidx = np.arange(n_l, dtype=np.int64)
+        pix = None
+        if self.sampling_idx is not None:
+            if self.sample_in_mask:
+                pick = self.pick[idx]
+                pix = self.rng.choice(pick, min(self.sampling_idx.shape[0], pick.shape[0]), replace=False).astype(np.int64)  # :184-185
+                self.sampling_idx = torch.from_numpy(pix)
+            else:
+                pix = self.sampling_idx.numpy().astype(np.int64)
+        rows = None
+        if self.vis_plus is not None:
+            rows = self.rng.choice(np.arange(self.tables[idx]['vis_plus'].shape[0]), self.vis_plus.vnum, replace=False).astype(np.int64)  # trainer.py:389
+        self.host_seconds['draw'] += time.perf_counter() - t0
+        return _Draw(idx, lidx, pix, rows)
+
+    # ---- device half: index upload + one gather launch ----------------------------------------------------------------------
+    def _staging(self, n_words):
+        import threading
+        key = threading.get_ident()
+        ring = self._pinned.get(key)
+        if ring is None or ring['buf'].shape[1] < n_words:
+            ring = self._pinned[key] = {'buf': torch.empty(8, max(n_words, 1024), dtype=torch.int64).pin_memory(), 'ev': [None] * 8, 'turn': 0}
+        k = ring['turn'] % 8
+        ring['turn'] += 1
+        if ring['ev'][k] is not None:
+            ring['ev'][k].synchronize()   # the copy that last read this row (8 items ago) has long completed
+        return ring, k
+
+    def assemble(self, d, out=None):
+        """(idx, model_input, ground_truth, l_slt) of the draw ``d`` on the device; ``out``: preallocated outputs (loader slots)."""
+        import time
+        t0 = time.perf_counter()
+        hip, dev, tab = self.hip, self.device, self.tables[d.idx]
+        n_all = self.total_pixels if d.pix is None else int(d.pix.shape[0])
+        lo, hi = (0, n_all) if (self.dp is None or not self.dp.enabled) else self.dp.slice_bounds(n_all)
+        n = hi - lo
+        pix = None if d.pix is None else d.pix[lo:hi]
+        surf = np.flatnonzero(self.surf_host[d.idx][lo:hi] if pix is None else self.surf_host[d.idx][pix]).astype(np.int64)
+        L, V, ns = int(d.lidx.shape[0]), (0 if d.vis_rows is None else int(d.vis_rows.shape[0])), int(surf.shape[0])
+        n_pix_words = 0 if pix is None else n
+        words = 2 * L + V + n_pix_words + ns
+        ring, k = self._staging(words)
+        row = ring['buf'][k].numpy()
+        row[0:L] = d.lidx
+        row[L:2 * L] = self.light_offset[d.idx] + d.lidx        # l_slt: rows of the concatenated light tables (trainer.py:370-373)
+        o = 2 * L
+        if V:
+            row[o:o + V] = d.vis_rows
+        o += V
+        if pix is not None:
+            row[o:o + n] = pix
+        row[o + n_pix_words:o + n_pix_words + ns] = surf
+        if out is None:
+            out = self.alloc_outputs(L, n, V)
+        idx_dev = out['_index'][:words]
+        idx_dev.copy_(ring['buf'][k, :words], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring['ev'][k] = ev
+        lidx_dev, l_slt = idx_dev[0:L], idx_dev[L:2 * L]
+        rows_dev = idx_dev[2 * L:2 * L + V] if V else None
+        pix_dev = idx_dev[o:o + n] if pix is not None else None
+        surf_dev = idx_dev[o + n_pix_words:o + n_pix_words + ns]
+        g = {'rgb': out['rgb'][:L * n * 3].view(L, n, 3), 'object_mask': out['object_mask'][:n], 'surface_mask': out['surface_mask'][:n],
+             'uv': out['uv'][:n * 2].view(n, 2), 'points': out['points'][:n * 3].view(n, 3), 'normal': out['normal'][:n * 3].view(n, 3),
+             'light_direction': out['light_direction'][:L * 3].view(L, 3)}
+        if self.vis_loss:
+            g['visibility'] = out['visibility'][:L * n].view(L, n)
+        if V:
+            g['vis_train_gt'] = out['vis_train_gt'][:V * n].view(V, n)
+        hip.view_batch(tab, lidx_dev, pix_dev, n, g, pix0=lo, vidx=rows_dev)
+        mi = {'object_mask': g['object_mask'][None], 'uv': g['uv'][None], 'vidx': self.vidx_dev[d.idx][None], 'intrinsics': self.intrinsics,
+              'lidx': lidx_dev, 'normal': g['normal'][None], 'points': g['points'][None], 'surface_mask': g['surface_mask'][None],
+              'light_direction': g['light_direction'], 'pose': self.poses[d.idx], 'surface_idx': surf_dev}
+        if self.gt_normal is not None:
+            mi['gt_normal'] = self.gt_normal[d.idx]
+        if self.vis_loss:
+            mi['visibility'] = g['visibility']
+        if pix is not None:
+            mi['sampling_idx'] = pix_dev[None]
+        if V:
+            mi['light_vis_train'] = torch.index_select(tab['vis_plus_light'], 0, rows_dev, out=out['light_vis_train'][:V * 3].view(V, 3))  # trainer.py:390
+            mi['vis_train_gt'] = g['vis_train_gt']                                              # trainer.py:392
+        self.host_seconds['assemble'] += time.perf_counter() - t0
+        self.host_seconds['items'] += 1
+        return d.idx, mi, {'rgb': g['rgb']}, l_slt
+
+    def alloc_outputs(self, L, n, V):
+        dev = self.device
+        f = lambda m: torch.empty(max(int(m), 1), device=dev, dtype=torch.float32)
+        return {'rgb': f(L * n * 3), 'object_mask': torch.empty(max(n, 1), device=dev, dtype=torch.bool),
+                'surface_mask': torch.empty(max(n, 1), device=dev, dtype=torch.bool), 'uv': f(n * 2), 'points': f(n * 3), 'normal': f(n * 3),
+                'light_direction': f(L * 3), 'visibility': f(L * n if self.vis_loss else 1), 'vis_train_gt': f(V * n), 'light_vis_train': f(V * 3),
+                '_index': torch.empty(2 * L + V + 2 * n + 16, device=dev, dtype=torch.int64)}
+
+    def batch(self, idx, device=None):
+        """ViewSampler.batch's signature (``device`` is this store's)."""
+        assert device is None or torch.device(device) == self.device
+        return self.assemble(self.draw(idx))
+
+    # ---- prefetching loader ---------------------------------------------------------------------------------------------------
+    def loader(self, order, depth=2):
+        """Iterator over ``batch(idx) for idx in order`` whose draws and gathers run up to ``depth`` items AHEAD in a worker thread on
+        a side stream (the draws stay in ``order``: one thread, one np.random stream).  The tensors of an item live in one of
+        depth + 2 fixed slots and stay valid until the NEXT item is fetched: consume (or copy -- GraphedTrainStep copies into its
+        own static buffers) an item before asking for the next."""
+        return _Prefetcher(self, order, depth)
+
+
+class _Prefetcher(object):
+    def __init__(self, store, order, depth):
+        import queue
+        import threading
+        self.store, self.order = store, list(int(i) for i in order)
+        self.n_slots = int(depth) + 2
+        self.side = torch.cuda.Stream(device=store.device)
+        self.free, self.ready = queue.Queue(), queue.Queue(maxsize=max(1, int(depth)))
+        self.slots = [None] * self.n_slots
+        self.released = [None] * self.n_slots   # event recorded by the consumer behind the last step that read slot k
+        for k in range(self.n_slots):
+            self.free.put(k)
+        self.current = None
+        self.error = None
+        self.consumer_wait = 0.0
+        self.thread = threading.Thread(target=self._work, daemon=True)
+        self.thread.start()
+
+    def _work(self):
+        st = self.store
+        try:
+            torch.cuda.set_device(st.device)   # a new thread starts on device 0
+            for idx in self.order:
+                d = st.draw(idx)
+                k = self.free.get()
+                if k is None:
+                    return
+                n_all = st.total_pixels if d.pix is None else int(d.pix.shape[0])
+                lo, hi = (0, n_all) if (st.dp is None or not st.dp.enabled) else st.dp.slice_bounds(n_all)
+                L, V = int(d.lidx.shape[0]), (0 if d.vis_rows is None else int(d.vis_rows.shape[0]))
+                need = (L, hi - lo, V)
+                with torch.cuda.stream(self.side):
+                    if self.slots[k] is None or self.slots[k][0] != need:
+                        self.slots[k] = (need, st.alloc_outputs(*need))
+                    if self.released[k] is not None:
+                        self.side.wait_event(self.released[k])
+                    item = st.assemble(d, out=self.slots[k][1])
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                self.ready.put((k, ev, item))
+            self.ready.put(None)
+        except BaseException as e:  # noqa: BLE001 (handed to the consumer)
+            self.error = e
+            self.ready.put(None)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        import time
+        if self.current is not None:   # the step on the previous item has been enqueued: its slot may be rewritten behind it
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.store.device))
+            self.released[self.current] = ev
+            self.free.put(self.current)
+            self.current = None
+        t0 = time.perf_counter()
+        got = self.ready.get()
+        self.consumer_wait += time.perf_counter() - t0
+        if got is None:
+            if self.error is not None:
+                raise self.error
+            raise StopIteration
+        k, ev, item = got
+        torch.cuda.current_stream(self.store.device).wait_event(ev)
+        self.current = k
+        return item
+
+    def close(self):
+        self.free.put(None)

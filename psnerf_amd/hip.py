@@ -94,6 +94,20 @@ class PsnAdamSeg(ctypes.Structure):
 ADAM_MAX_SEGS = 16
 
 
+class PsnViewBatch(ctypes.Structure):
+    _fields_ = [('images', ctypes.c_void_p), ('image_type', i32), ('lut', ctypes.c_void_p),
+                ('object_mask', ctypes.c_void_p), ('surface_mask', ctypes.c_void_p),
+                ('points', ctypes.c_void_p), ('normal', ctypes.c_void_p), ('visibility', ctypes.c_void_p), ('vis_plus', ctypes.c_void_p),
+                ('light_direction', ctypes.c_void_p),
+                ('hw', i64), ('width', i32),
+                ('lidx', ctypes.c_void_p), ('n_lights', i32),
+                ('pix', ctypes.c_void_p), ('pix0', i64), ('n', i64),
+                ('vidx', ctypes.c_void_p), ('n_vis', i32),
+                ('rgb', ctypes.c_void_p), ('object_mask_out', ctypes.c_void_p), ('surface_mask_out', ctypes.c_void_p), ('uv', ctypes.c_void_p),
+                ('points_out', ctypes.c_void_p), ('normal_out', ctypes.c_void_p), ('visibility_out', ctypes.c_void_p),
+                ('vis_train_gt', ctypes.c_void_p), ('sampling_idx_out', ctypes.c_void_p), ('light_direction_out', ctypes.c_void_p)]
+
+
 class PsnRowAdamItem(ctypes.Structure):
     _fields_ = [('param', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p), ('exp_avg_sq', ctypes.c_void_p),
                 ('rows', i64), ('cols', i32), ('one_minus_beta1', f32), ('one_minus_beta2', f32), ('eps', f32), ('step_size', f32)]
@@ -137,6 +151,7 @@ SIGNATURES = {
     'psn_gather_rows': (i32, [i32, ctypes.c_void_p, c_f, i64, i64, c_f]),
     'psn_gather_rows_valid': (i32, [i32, ctypes.c_void_p, c_f, c_f, i64, i64, c_f]),
     'psn_surface_index': (i32, [c_f, i64, i64, c_f, c_f, c_f]),
+    'psn_view_batch': (i32, [ctypes.c_void_p, c_f]),
     'psn_secant_step': (i32, [c_f, f32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, c_f]),
     'psn_first_crossing': (i32, [c_f, c_f, c_f, c_f, f32, f32, i64, i32, c_f, c_f, c_f]),
     'psn_stage2_loss_fwd': (i32, [c_f, c_f, i32, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, i64, i32, c_f, c_f, c_f,
@@ -459,6 +474,59 @@ def surface_index(mask, capacity):
     count = torch.empty(1, device=mask.device, dtype=torch.float32)
     _check(_lib.psn_surface_index(mask.data_ptr(), mask.numel(), int(capacity), idx.data_ptr(), count.data_ptr(), _stream()), 'surface_index')
     return idx, count
+
+
+IMAGE_TYPES = {torch.float32: 0, torch.uint8: 1, torch.uint16: 2}
+
+
+def view_batch(tables, lidx, pix, n, out, pix0=0, vidx=None):
+    """One stage-2 training batch gathered from the resident tables of a view (psn_view_batch; one launch, no allocation).
+    ``tables``: dict of contiguous device tensors -- 'images' [Lv, hw, 3] (float32 / uint8 / uint16), 'lut' (integer images),
+    'object_mask' / 'surface_mask' [hw] bool, 'points' / 'normal' [hw, 3], optional 'visibility' [Lv, hw], 'vis_plus' [R, hw],
+    'light_direction' [Lv, 3]; 'width'.  ``lidx`` [L] / ``pix`` [n] (or None: the range pix0 .. pix0 + n) / ``vidx`` [V]: device int64.
+    ``out``: dict of preallocated contiguous outputs, any subset of 'rgb' [L, n, 3], 'object_mask' / 'surface_mask' [n] bool,
+    'uv' [n, 2], 'points' / 'normal' [n, 3], 'visibility' [L, n], 'vis_train_gt' [V, n], 'sampling_idx' [n] int64,
+    'light_direction' [L, 3]."""
+    b = PsnViewBatch()
+    img = tables['images']
+    assert img.is_cuda and img.is_contiguous() and img.dtype in IMAGE_TYPES and img.dim() == 3 and img.shape[2] == 3
+    hw = img.shape[1]
+    b.images, b.image_type, b.hw, b.width = img.data_ptr(), IMAGE_TYPES[img.dtype], hw, int(tables['width'])
+    if b.image_type:
+        lut = tables['lut']
+        assert lut.is_cuda and lut.dtype == torch.float32 and lut.is_contiguous() and lut.numel() == (256 if b.image_type == 1 else 65536)
+        b.lut = lut.data_ptr()
+
+    def table(key, shape_tail, dtype):
+        t = tables.get(key)
+        if t is None:
+            return None
+        assert t.is_cuda and t.is_contiguous() and t.dtype == dtype and tuple(t.shape[-len(shape_tail):]) == shape_tail, key
+        return t.data_ptr()
+    b.object_mask, b.surface_mask = table('object_mask', (hw,), torch.bool), table('surface_mask', (hw,), torch.bool)
+    b.points, b.normal = table('points', (hw, 3), torch.float32), table('normal', (hw, 3), torch.float32)
+    b.visibility, b.vis_plus = table('visibility', (hw,), torch.float32), table('vis_plus', (hw,), torch.float32)
+    b.light_direction = table('light_direction', (3,), torch.float32)
+    L = 0 if lidx is None else int(lidx.numel())
+    for t_ in (lidx, pix, vidx):
+        assert t_ is None or (t_.is_cuda and t_.dtype == torch.int64 and t_.is_contiguous() and t_.dim() == 1)
+    assert pix is None or pix.numel() == n
+    b.lidx, b.n_lights = (None if lidx is None else lidx.data_ptr()), L
+    b.pix, b.pix0, b.n = (None if pix is None else pix.data_ptr()), int(pix0), int(n)
+    V = 0 if (vidx is None or 'vis_train_gt' not in out) else int(vidx.numel())
+    b.vidx, b.n_vis = (vidx.data_ptr() if V else None), V
+    want = {'rgb': ((L, n, 3), torch.float32), 'object_mask': ((n,), torch.bool), 'surface_mask': ((n,), torch.bool),
+            'uv': ((n, 2), torch.float32), 'points': ((n, 3), torch.float32), 'normal': ((n, 3), torch.float32),
+            'visibility': ((L, n), torch.float32), 'vis_train_gt': ((V, n), torch.float32), 'sampling_idx': ((n,), torch.int64),
+            'light_direction': ((L, 3), torch.float32)}
+    field = {'object_mask': 'object_mask_out', 'surface_mask': 'surface_mask_out', 'points': 'points_out', 'normal': 'normal_out',
+             'visibility': 'visibility_out', 'sampling_idx': 'sampling_idx_out', 'light_direction': 'light_direction_out'}
+    for k, t in out.items():
+        shape, dt = want[k]
+        assert t.is_cuda and t.is_contiguous() and t.dtype == dt and t.numel() == int(torch.Size(shape).numel()), (k, tuple(t.shape), shape)
+        setattr(b, field.get(k, k), t.data_ptr())
+    _check(_lib.psn_view_batch(ctypes.addressof(b), _stream()), 'view_batch')
+    return out
 
 
 def gather_rows(specs, dense_grads, idx, n_pixels, n_surf, inv=None):

@@ -145,3 +145,85 @@ def render_envmap(model, model_input, env_light, light_h=16, light_batch=64, pix
             model._eval_outputs = None
     rgb = rgb_sum.clamp(0, 1)
     return (rgb, vis_sum / n_lights) if visibility else rgb
+
+
+def eval_lights(light_direction, lidx, light_para=None, light_inten_para=None, light_offset=0):
+    """The lights of one light batch of a test view as evaluate() forms them (eval.py:338-345): the data set's directions of the
+    view, or -- for a model trained with ``train.light_train`` on all views (``light_para`` given) -- the optimised table rows
+    ``light_offset + lidx`` normalised (+ the optimised intensities when ``light_inten_para`` is given).
+    -> (light_direction [l, 3], light_intensity [l, 1] | None)."""
+    if light_para is None:
+        return light_direction[lidx], None
+    w = light_para.weight if hasattr(light_para, 'weight') else light_para
+    l_slt = (int(light_offset) + lidx).to(w.device)
+    inten = None
+    if light_inten_para is not None:
+        wi = light_inten_para.weight if hasattr(light_inten_para, 'weight') else light_inten_para
+        inten = wi.detach()[l_slt]
+    return F.normalize(w.detach()[l_slt], p=2, dim=-1), inten
+
+
+def edit_material(color=None, basis=None, edit_albedo=True, edit_specular=False, rng=None):
+    """The material edit of eval.py:121-139: ``albedo_new`` float32 [3] from a '#rrggbb' colour (each channel / 5 / 255; without a
+    colour three np.random draws from range(128), / 255) and ``basis_new`` = the index of the single spherical-Gaussian lobe that
+    keeps a weight (2^basis / 100, renderer.py:177-183; without an index one np.random draw from range(9)).
+    -> (albedo_new | None, basis_new | None, name) -- ``name`` is the reference's output sub-directory."""
+    rng = rng if rng is not None else np.random
+    albedo_new, basis_new, name = None, None, ''
+    if edit_albedo:
+        if color is None:
+            albedo_new = rng.choice(range(128), size=3)
+            name += '#{:02x}{:02x}{:02x}'.format(*list(albedo_new))
+        else:
+            albedo_new = np.array([int(color.lstrip('#')[i:i + 2], 16) for i in (0, 2, 4)]).astype(np.float32) / 5.
+            name = color
+        albedo_new = (albedo_new / 255.).astype(np.float32)
+    if edit_specular:
+        basis_new = int(rng.choice(range(9))) if basis is None else int(basis)
+        name = 'sg%d' % (basis_new + 1) if name == '' else name + '_sg%d' % (basis_new + 1)
+    return albedo_new, basis_new, name
+
+
+@torch.no_grad()
+def render_view(model, model_input, light_direction, light_intensity=None, light_batch=64, pixel_chunk=None, albedo_new=None,
+                basis_new=None):
+    """The test-view render of evaluate() (eval.py:314-417; with ``albedo_new`` / ``basis_new`` the material-edit loop :233-312):
+    the view under ITS OWN lights in batches of ``light_batch``, pixels in chunks through split_input / merge_output
+    (``pixel_chunk`` None = the whole image in one piece: the fused kernels keep no [N, 256] activations in HBM, the reference
+    needs 1024-pixel chunks), and the per-view maps the reference writes to disk, as float32 arrays over the N pixels:
+
+        'rgb' [L, N, 3] clipped (:371)         'rough' [L, N, 3] (sgbasis: the specular colour per light; microfacet: [N, 3], :372-375)
+        'mask' [N] bool (:382)                 'normal' [N, 3] (normal_pred with a normal net, else the stage-1 normals) x mask (:394-395)
+        'albedo' [N, 3] clipped (:400)         'visibility' [L, N, 3] clipped (:406; only for a model with a visibility net)
+
+    model_input: the item of eval.py:327-337 (uv [1,N,2] x-major grid, intrinsics, pose, object_mask, normal, points, surface_mask).
+    light_direction [L, 3] (see eval_lights), light_intensity [L, 1] or None (the model's scalar)."""
+    n_pix = model_input['uv'].shape[1]
+    sg = getattr(model, 'render_model', 'sgbasis') == 'sgbasis'
+    rgb_all, rough_all, vis_all = [], [], []
+    last = None
+    chunks = [dict(model_input)] if pixel_chunk is None else split_input(model_input, n_pix, pixel_chunk)
+    for l0 in range(0, light_direction.shape[0], light_batch):
+        res = []
+        for s in chunks:
+            s = dict(s)
+            s['light_direction'] = light_direction[l0:l0 + light_batch]
+            if light_intensity is not None:
+                s['light_intensity'] = light_intensity[l0:l0 + light_batch]
+            out = model(s, albedo_new=albedo_new, basis_new=basis_new)
+            res.append({k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
+        last = merge_output(res, n_pix, 1) if len(res) > 1 else {k: (v.reshape(-1) if v.dim() < 3 else v.reshape(-1, v.shape[-1])) for k, v in res[0].items()}
+        rgb_all.append(last['sg_rgb_values'].reshape(-1, n_pix, 3))
+        rough_all.append(last['sg_specular_rgb_values'].reshape(-1, n_pix, 3))
+        if 'visibility' in last:
+            vis_all.append(last['visibility'].reshape(-1, n_pix, 3))
+    mask = last['network_object_mask'].reshape(n_pix).bool()
+    normal = last['normal_pred'] if getattr(model, 'normal_mlp', False) else last['normal_values']
+    maps = {'rgb': torch.cat(rgb_all, 0).clamp(0, 1),
+            'rough': torch.cat(rough_all, 0) if sg else rough_all[-1][0],
+            'mask': mask,
+            'normal': normal.reshape(n_pix, 3) * mask[:, None].float(),
+            'albedo': last['sg_diffuse_albedo_values'].reshape(n_pix, 3).clamp(0, 1)}
+    if vis_all:
+        maps['visibility'] = torch.cat(vis_all, 0).clamp(0, 1)
+    return maps

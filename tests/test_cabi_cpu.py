@@ -37,6 +37,23 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(hip.PsnWnItem) == 64                  # 6 pointers + 2 x int32 + float, padded to 8
 
 
+def test_view_batch_struct_layout_against_the_c_compiler(tmp_path):
+    """PsnViewBatch (the descriptor of the on-device batch assembly, psn_view_batch) mixes pointers, int64 and int fields: its
+    ctypes mirror is compared with what gcc makes of include/psnerf_hip.h, field by field."""
+    import os, subprocess
+    from psnerf_amd import hip
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [f[0] for f in hip.PsnViewBatch._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "psnerf_hip.h"\nint main(void) {\n  printf("%zu\\n", sizeof(PsnViewBatch));\n'
+                   + ''.join('  printf("%%zu\\n", offsetof(PsnViewBatch, %s));\n' % f for f in fields) + '  return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == ctypes.sizeof(hip.PsnViewBatch)
+    assert got[1:] == [getattr(hip.PsnViewBatch, f).offset for f in fields]
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only check')
 def test_product_path_fails_loudly_without_gpu():
     """CPU tensors must be rejected -- there is no eager/CPU fallback behind the ops."""
@@ -100,6 +117,19 @@ def test_argument_validation_needs_no_gpu():
     assert rc == -1 and b'multiple of 64' in lib.psn_last_error()
     rc = lib.psn_mlp_infer_padded(*args, 5000, 7000, dummy, dummy, 1024, None)   # save_row0 = 5000 is no multiple of 1024
     assert rc == -1 and b'multiple of the period' in lib.psn_last_error()
+    # on-device batch assembly: descriptor checked on the host
+    rc = lib.psn_view_batch(None, None)
+    assert rc == -1 and b'null' in lib.psn_last_error()
+    vb = hip.PsnViewBatch()
+    vb.hw, vb.width, vb.n, vb.n_lights, vb.image_type = 100, 10, 8, 2, 3
+    rc = lib.psn_view_batch(ctypes.addressof(vb), None)
+    assert rc == -1 and b'image_type' in lib.psn_last_error()
+    vb.image_type, vb.images, vb.rgb, vb.lidx = 1, 64, 64, 64
+    rc = lib.psn_view_batch(ctypes.addressof(vb), None)
+    assert rc == -1 and b'value table' in lib.psn_last_error()
+    vb.lut, vb.object_mask, vb.pix0 = 64, 64, 96      # identity range 96 .. 104 of a 100-pixel view
+    rc = lib.psn_view_batch(ctypes.addressof(vb), None)
+    assert rc == -1 and b'outside the view' in lib.psn_last_error()
 
 
 def test_split_rows_backward_is_the_slice_backward():

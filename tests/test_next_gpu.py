@@ -169,3 +169,144 @@ def test_envmap_relight_vs_reference_pieces(cuda):
     assert_close(vis.cpu().reshape(hr, wr, 3), g['visibility'], 1e-4, 'light-averaged visibility', atol=1e-5)
     rgb6 = relight.render_envmap(net, base, g['env'], light_h=int(g['light_h']), light_batch=32, precision='bf16x6')
     assert_close(rgb6.cpu().reshape(hr, wr, 3), g['rgb'], 1e-4, 'relit rgb (bf16x6 experiment)', atol=ATOL_UNIT)
+
+
+def _toy_views(n_views=2, h=40, w=52, P=6, seed=0, u8=True):
+    """Views in the hand-off layout (handoff.load_view) + per-light images; u8: images are 8-bit values / 255 (a decoded PNG)."""
+    g = torch.Generator().manual_seed(seed)
+    Ls = [12, 9, 10][:n_views]
+    views, init, imgs, omasks, ldirs, poses = [], [], [], [], [], []
+    for L in Ls:
+        views.append({'points': torch.randn(1, h * w, 3, generator=g), 'normal': torch.randn(1, h * w, 3, generator=g),
+                      'surface_mask': torch.rand(1, h * w, generator=g) > 0.3, 'visibility': torch.rand(L, h * w, generator=g),
+                      'vis_plus': torch.rand(P, h * w, generator=g), 'vis_plus_light': torch.randn(P, 3, generator=g), 'img_res': [h, w]})
+        init.append(torch.randn(L, 3, generator=g) * 2.0)
+        if u8:
+            k = torch.randint(0, 256, (L, h * w, 3), generator=g)
+            imgs.append(torch.from_numpy(k.numpy().astype(np.float32) / 255.))   # dataset.py:121
+        else:
+            imgs.append(torch.rand(L, h * w, 3, generator=g))
+        omasks.append(torch.rand(h * w, generator=g) > 0.2)
+        ldirs.append(torch.randn(L, 3, generator=g))
+        poses.append(torch.randn(4, 4, generator=g))
+    return views, init, imgs, omasks, ldirs, poses, torch.randn(4, 4, generator=g)
+
+
+def _same_batch(a, b):
+    (ia, ma, ga, la), (ib, mb, gb, lb) = a, b
+    assert ia == ib and sorted(ma) == sorted(mb), (sorted(ma), sorted(mb))
+    for k in ma:
+        x, y = ma[k], mb[k]
+        assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x.cpu(), y.cpu()), k
+    assert sorted(ga) == sorted(gb) == ['rgb'] and ga['rgb'].shape == gb['rgb'].shape and torch.equal(ga['rgb'].cpu(), gb['rgb'].cpu())
+    assert la.dtype == lb.dtype and torch.equal(la.cpu(), lb.cpu())
+
+
+@pytest.mark.parametrize('u8,n_pixels,vis_plus', [(True, 700, True), (False, 700, False), (True, None, False), (True, 5000, True)])
+def test_device_views_batch_equals_the_host_sampler_bit_for_bit(cuda, u8, n_pixels, vis_plus):
+    """handoff.DeviceViews (views resident in HBM, draws on the host in the reference's order, ONE gather launch: psn_view_batch)
+    against handoff.ViewSampler.batch (stage2/datasets/dataset.py:137-199 + trainer.py:364-392 on the host) from the same np.random
+    seed: every key, shape, dtype and value of model_input / ground_truth / l_slt over several items of alternating views, the
+    vis_plus selection included; 8-bit images are stored as uint8 and decoded through the k / 255 table (bit-identical); n_pixels
+    None = a test-split item (all pixels, all lights); 5000 > in-mask pixels = the min() of dataset.py:185."""
+    from psnerf_amd.handoff import DeviceViews, ViewSampler
+    from psnerf_amd.stage2.trainer import VisPlus
+    views, init, imgs, omasks, ldirs, poses, K = _toy_views(u8=u8)
+    split = 'train' if n_pixels is not None else 'test'
+    vp_h = VisPlus(views, init, 5, 'cpu') if vis_plus else None
+    vp_d = VisPlus(views, init, 5, cuda) if vis_plus else None
+    host = ViewSampler(views, imgs, omasks, ldirs, poses, K, light_bs=4, n_pixels=n_pixels, split=split)
+    store = DeviceViews(views, imgs, omasks, ldirs, poses, K, light_bs=4, device=cuda, n_pixels=n_pixels, split=split, vis_plus=vp_d)
+    assert (store.tables[0]['images'].dtype == torch.uint8) == u8
+    order = [0, 1, 1, 0, 1]
+    np.random.seed(11)
+    want = []
+    for v in order:
+        idx, mi, gt, l_slt = host.batch(v, device=cuda)
+        if vis_plus:
+            mi['light_vis_train'], mi['vis_train_gt'] = (t.to(cuda) for t in vp_h.select(idx, mi['sampling_idx'][0].cpu()))
+        want.append((idx, mi, gt, l_slt))
+    np.random.seed(11)
+    got = [store.batch(v) for v in order]
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        _same_batch(a, b)
+    # the prefetching loader (worker thread, side stream, ring of fixed slots) hands out the same items in the same order
+    # (a fresh store: like the reference's data set the sampler is stateful -- min(len(sampling_idx), in-mask pixels), dataset.py:185)
+    store = DeviceViews(views, imgs, omasks, ldirs, poses, K, light_bs=4, device=cuda, n_pixels=n_pixels, split=split, vis_plus=vp_d)
+    np.random.seed(11)
+    for b, item in zip(want, store.loader(order, depth=2)):
+        torch.cuda.synchronize()
+        _same_batch(item, b)
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_device_views_rank_slice_equals_the_sharded_host_batch(cuda, world):
+    """Under data parallelism every rank draws the same lists (same np.random seed) and gathers only ITS slice_bounds share of the
+    pixel list: DeviceViews(dp=rank r).batch == DataParallel.shard_stage2(ViewSampler.batch) of rank r for every rank; the shares
+    tile the full batch; the surface-pixel list of a shard comes from the host copy of the mask (== nonzero of the shard's mask)."""
+    from psnerf_amd.dist import DataParallel
+    from psnerf_amd.handoff import DeviceViews, ViewSampler
+    from psnerf_amd.stage2.trainer import VisPlus
+    views, init, imgs, omasks, ldirs, poses, K = _toy_views()
+    n_px = 1001   # not a multiple of the world size: the last rank's share is shorter
+    host = ViewSampler(views, imgs, omasks, ldirs, poses, K, light_bs=5, n_pixels=n_px)
+    vp_h, vp_d = VisPlus(views, init, 4, 'cpu'), VisPlus(views, init, 4, cuda)
+    np.random.seed(5)
+    idx, mi, gt, l_slt = host.batch(1, device=cuda)
+    mi['light_vis_train'], mi['vis_train_gt'] = (t.to(cuda) for t in vp_h.select(idx, mi['sampling_idx'][0].cpu()))
+    seen = 0
+    for r in range(world):
+        dp = DataParallel.__new__(DataParallel)
+        dp.enabled, dp.world, dp.rank = True, world, r
+        store = DeviceViews(views, imgs, omasks, ldirs, poses, K, light_bs=5, device=cuda, n_pixels=n_px, dp=dp, vis_plus=vp_d)
+        np.random.seed(5)
+        got = store.batch(1)
+        mi_r, gt_r = dp.shard_stage2(mi, gt)
+        _same_batch(got, (idx, mi_r, gt_r, l_slt))
+        assert torch.equal(got[1]['surface_idx'], got[1]['surface_mask'][0].nonzero(as_tuple=True)[0])
+        seen += got[1]['uv'].shape[1]
+    assert seen == n_px
+
+
+def test_train_step_on_device_views_equals_the_step_on_the_host_sampler(cuda):
+    """Three optimisation steps fed by DeviceViews.loader (vis_plus draw made by the store) against the same steps fed by
+    ViewSampler.batch + TrainStep's own vis_plus draw: identical losses and parameters -- the device-resident pipeline changes where
+    the batch is assembled, not what is trained."""
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.handoff import DeviceViews, ViewSampler
+    from psnerf_amd.stage2.trainer import VisPlus
+    views, init, imgs, omasks, ldirs, poses, K = _toy_views()
+    for v, p in zip(views, poses):   # a real camera: look-at poses and BEAR-like intrinsics from the synthetic batch
+        inp, _ = stage2_inputs(40 * 52, 1, 1, seed=1, h=40, w=52)
+        v['points'], v['normal'] = inp['points'], inp['normal']
+    inp, _ = stage2_inputs(40 * 52, 1, 1, seed=1, h=40, w=52)
+    poses, K = [inp['pose'][0]] * len(views), inp['intrinsics'][0]
+    n_total = sum(l.shape[0] for l in ldirs)
+    res = {}
+    for mode in ('host', 'device'):
+        conf = s2.bear_conf(**{'train.light_bs': 4, 'train.vis_train_num': 5})
+        net = s2.PSNetwork(conf)
+        net.load_state_dict(stage2_state_dict(conf, seed=3))
+        net.to(cuda)
+        vp = VisPlus(views, init, 5, cuda)
+        step = s2.TrainStep(net, conf, n_total, torch.cat(init).to(cuda), cuda, vis_plus=vp if mode == 'host' else None)
+        step.cur_iter = 5000
+        step._ori = (1.0, 0.05, 0.01, 1)
+        step.train_fix()
+        np.random.seed(21)
+        torch.manual_seed(21)
+        order, losses = [0, 1, 0], []
+        if mode == 'host':
+            ds = ViewSampler(views, imgs, omasks, ldirs, poses, K, light_bs=4, n_pixels=600)
+            feed = (ds.batch(v, device=cuda) for v in order)
+        else:
+            feed = DeviceViews(views, imgs, omasks, ldirs, poses, K, light_bs=4, device=cuda, n_pixels=600, vis_plus=vp).loader(order)
+        for vidx, mi, gt, l_slt in feed:
+            terms, _ = step.step(mi, gt, l_slt, train_order=False, vidx=vidx if mode == 'host' else None)
+            losses.append(float(terms['total']))
+        res[mode] = (losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, step.light_para.weight.detach().cpu().clone())
+    assert res['host'][0] == res['device'][0], (res['host'][0], res['device'][0])
+    for k in res['host'][1]:
+        assert torch.equal(res['host'][1][k], res['device'][1][k]), k
+    assert torch.equal(res['host'][2], res['device'][2])
