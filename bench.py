@@ -282,6 +282,106 @@ def stage1_measure(device, steps=10, warmup=5, rays=4096):
     return out
 
 
+def _stage1_cfg1(rays=512):
+    """BASELINE configs[0]: stage1 BUNNY synthetic, 1 view, 512 rays x 64 samples (bunny.yaml: near 2, far 6, it = 0 -> 64 interval
+    samples), 256 march steps + 8 secant; geometric-init weights, a 512 x 612 synthetic view."""
+    import torch
+    from psnerf_amd.synthetic import stage1_batch, stage1_cfg
+    cfg = stage1_cfg('bunny', **{'training.n_training_points': rays})
+    batch = stage1_batch(cfg, h=512, w=612, seed=0)
+    g = torch.Generator().manual_seed(5)
+    pix = torch.stack([torch.randint(0, 612, (rays,), generator=g).float(), torch.randint(0, 512, (rays,), generator=g).float()], -1)[None]
+    return cfg, batch, pix, g
+
+
+def stage1_cpu_baseline(steps=2):
+    """BASELINE.md section 3 for stage 1 = BASELINE configs[0] itself: the oracle's Trainer.train_step (port of
+    stage1/model/training.py:46-60 -- march, render forward, loss, double backward, Adam) on the host cores at 512 rays x 64 samples.
+    Thread count swept on a 128-ray sample over {1, 8, 16, 32, 64}; the best count then runs the 512-ray step (1 warm-up + ``steps``
+    timed, minimum); one thread (what the stage-2 trainer of the reference pins; stage 1 does not pin) is reported beside it."""
+    import torch
+    from oracle import stage1 as o1
+
+    def run(rays, n_timed):
+        cfg, batch, pix, _ = _stage1_cfg1(rays)
+        torch.manual_seed(42)
+        net = o1.NeuralNetwork(cfg)
+        tr = o1.Trainer(o1.Renderer(net, cfg), torch.optim.Adam(net.parameters(), lr=1e-4), cfg)
+        tr.train_step(batch, it=0, pix=pix)
+        best = None
+        for _ in range(n_timed):
+            t0 = time.time()
+            tr.train_step(batch, it=0, pix=pix)
+            dt = time.time() - t0
+            best = dt if best is None else min(best, dt)
+        return best
+    nproc = os.cpu_count() or 1
+    t_all = torch.get_num_threads()
+    sweep = {}
+    try:
+        for th in sorted({t for t in (1, 8, 16, 32, 64) if t <= nproc}):
+            torch.set_num_threads(th)
+            sweep[th] = 128 * 64 / run(128, 1)
+        best_th = max(sweep, key=sweep.get)
+        torch.set_num_threads(best_th)
+        dt = run(512, steps)
+    finally:
+        torch.set_num_threads(t_all)
+    return {'value': 512 * 64 / dt, 'unit': 'ray-samples/s', 'cores': best_th, 'kind': 'port', 'host_cores': nproc,
+            'sample': 'oracle/stage1.py Trainer.train_step at BASELINE configs[0] (bunny, 512 rays x 64 samples, 256 march steps + 8 secant), '
+                      'min of %d timed steps after 1 warm-up, %.2f s/step, %d threads = the best of the sweep' % (steps, dt, best_th),
+            'thread_sweep_128rays': {str(k): round(v, 1) for k, v in sorted(sweep.items())},
+            'single_thread': {'value': sweep.get(1), 'cores': 1, 'sample': '128 rays x 64 samples, 1 timed step after 1 warm-up'}}
+
+
+def stage1_parity(device):
+    """The metric's "PSNR parity" for stage 1 at BASELINE configs[0]: ONE full train step of the oracle (CPU) and of the HIP path from
+    the same weights on the same 512 rays with the same injected draws (hit / miss jitter, neighbour offsets): rendered rgb, loss
+    terms, PSNR against the synthetic ground truth, parameters after the Adam step."""
+    import math
+    import torch
+    from oracle import stage1 as o1  # checker only
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    cfg, batch, pix, g = _stage1_cfg1(512)
+    torch.manual_seed(42)
+    onet = o1.NeuralNetwork(cfg)
+    net = NeuralNetwork(cfg)
+    net.load_state_dict(onet.state_dict())
+    oren, ren = o1.Renderer(onet, cfg), Renderer(net, cfg, device=device)
+    otr = o1.Trainer(oren, torch.optim.Adam(onet.parameters(), lr=1e-4), cfg)
+    tr = Trainer(ren, torch.optim.Adam(net.parameters(), lr=1e-4), cfg, device=device)
+    with torch.no_grad():  # the hit count decides the shapes of the draws (rendering.py:139,163,204): a dry march of the oracle
+        dry = oren(pix, batch['img.camera_mat'], batch['img.world_mat'], batch['img.scale_mat'], 'unisurf', add_noise=False, eval_=True, it=0)
+    n_hit = int(dry['mask_pred'].sum())
+    noise = {'miss': torch.rand(1, 512 - n_hit, 64, generator=g), 'hit': torch.rand(1, n_hit, 64, generator=g), 'nbr': torch.rand(n_hit, 3, generator=g)}
+    cap = {}
+    h1 = oren.register_forward_hook(lambda m, i, o: cap.__setitem__('o', o))
+    h2 = ren.register_forward_hook(lambda m, i, o: cap.__setitem__('p', o))
+    try:
+        ot = otr.train_step(batch, it=0, pix=pix, noise=noise)
+        pt = tr.train_step({k: v.to(device) for k, v in batch.items()}, it=0, pix=pix, noise={k: v.to(device) for k, v in noise.items()})
+    finally:
+        h1.remove(); h2.remove()
+    a, b = cap['p']['rgb'].detach().cpu().double().reshape(-1, 3), cap['o']['rgb'].detach().double().reshape(-1, 3)
+    same_mask = bool(torch.equal(cap['p']['mask_pred'].cpu(), cap['o']['mask_pred']))
+    from oracle.stage1 import gather_pixels
+    gt = gather_pixels(batch['img'], pix).double().reshape(-1, 3)
+    psnr = lambda x: -10.0 * math.log10(float(((x - gt) ** 2).mean()))
+    ratio = (a - b).abs() / (1e-4 * b.abs() + 1e-6)
+    lo, lh = float(ot['loss'].detach()), float(pt['loss'].detach())
+    pd = max(float((p.detach().cpu() - q.detach()).abs().max()) for p, q in zip(net.parameters(), onet.parameters()))
+    return {'sample': 'BASELINE configs[0]: bunny, 512 rays (%d hit) x 64 samples, 256 march steps + 8 secant, it = 0, one full step, same weights / '
+                      'pixels / jitter draws' % n_hit,
+            'hit_masks_equal': same_mask, 'rgb_max_rel_err': float((a - b).abs().max() / b.abs().max()),
+            'rgb_worst_over_bound': round(float(ratio.max()), 3), 'rgb_frac_beyond_bound': float((ratio > 1).double().mean()),
+            'bound': '1e-4 |ref| + 1e-6 elementwise', 'loss_hip': lh, 'loss_oracle': lo, 'loss_rel_err': abs(lh - lo) / abs(lo),
+            'loss_terms_rel_err': {k: (abs(float(pt[k].detach()) - float(ot[k].detach())) / max(abs(float(ot[k].detach())), 1e-12)) for k in ot if ot[k] is not None},
+            'psnr_hip_db': round(psnr(a), 5), 'psnr_oracle_db': round(psnr(b), 5), 'psnr_diff_db': round(psnr(a) - psnr(b), 6),
+            'max_param_diff_after_step': pd,
+            'fixture': 'tests/golden/stage1_unisurf_cfg1.npz (the reference\'s own Renderer.unisurf + Loss + backward at 512 x 64) is checked by '
+                       'tests/test_stage1_gpu.py::test_unisurf_golden[cfg1]; 200-step horizon: tests/test_convergence_gpu.py'}
+
+
 # ----------------------------------------------------------------------------------------------- cfg 4 (strong scaling of cfg 3)
 def settle_gc():
     """Full collection + gc.freeze() in front of a timed region: the interpreter's cyclic collector stays ON, but the ~270k objects
@@ -677,6 +777,12 @@ def main():
         del step
         torch.cuda.empty_cache()
         stage1 = stage1_measure(device)
+        if not args.no_cpu_baseline:  # BASELINE configs[0] = the stage-1 CPU case: oracle timing + one-step parity at 512 rays x 64 samples
+            for key, fn in (('parity', lambda: stage1_parity(device)), ('cpu_baseline', stage1_cpu_baseline)):
+                try:
+                    stage1[key] = fn()
+                except Exception as e:  # noqa: BLE001
+                    stage1[key] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     line = None
     if rank == 0:
         # dominant kernel: fused visibility MLP over (L + V) * Ns rows, one launch per step (the smaller launches of the

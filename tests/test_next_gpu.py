@@ -310,3 +310,26 @@ def test_train_step_on_device_views_equals_the_step_on_the_host_sampler(cuda):
     for k in res['host'][1]:
         assert torch.equal(res['host'][1][k], res['device'][1][k]), k
     assert torch.equal(res['host'][2], res['device'][2])
+
+
+@pytest.mark.parametrize('edit', [False, True])
+def test_render_view_vs_reference_pieces(cuda, edit):
+    """f1: relight.render_view on the HIP model against tests/golden/stage2_eval_view.npz -- the test-view render of
+    stage2/eval.py:314-417 (rgb / rough / mask / normal / albedo / visibility maps of a view under its own optimised lights, light
+    batches x 1024-pixel chunks) and the material-edit loop (:233-312) assembled from the reference's own pieces."""
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.stage2 import relight
+    from tests.test_oracle_golden import _eval_view_case
+    g, net, mi, ld, li = _eval_view_case(s2.PSNetwork, s2.bear_conf, dev=cuda)
+    kw, tag = {}, 'view_'
+    if edit:
+        an, bn, _ = relight.edit_material(color=str(g['color']), basis=int(g['basis']), edit_albedo=True, edit_specular=True)
+        kw, tag = {'albedo_new': an, 'basis_new': bn}, 'edit_'
+    hv, wv = (int(v) for v in g['hw'])
+    for chunk, lb in ((1024, int(g['light_batch'])), (None, 64)):
+        maps = relight.render_view(net, mi, ld, li, light_batch=lb, pixel_chunk=chunk, **kw)
+        for k in ('rgb', 'rough', 'visibility'):
+            assert_close(maps[k].reshape(-1, hv, wv, 3).cpu(), g[tag + k], 1e-4, k, atol=ATOL_UNIT)
+        for k in ('normal', 'albedo'):
+            assert_close(maps[k].reshape(hv, wv, 3).cpu(), g[tag + k], 1e-4, k, atol=ATOL_UNIT)
+        assert np.array_equal(maps['mask'].reshape(hv, wv).cpu().numpy(), g[tag + 'mask'].astype(bool))

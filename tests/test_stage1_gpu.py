@@ -113,10 +113,13 @@ def test_march_and_light_visibility_golden(cuda):
     assert_close(lv, g['light_vis'], 1e-4, 'light visibility', atol=ATOL_UNIT)
 
 
-@pytest.mark.parametrize('it', [0, 6000])
-def test_unisurf_golden(cuda, it):
+@pytest.mark.parametrize('tag', ['it0', 'it6000', 'cfg1'])
+def test_unisurf_golden(cuda, tag):
+    """G6 against the reference's own Renderer.unisurf + Loss + backward ('cfg1': 512 rays x 64 samples, 256 march steps = the
+    scale of BASELINE configs[0])."""
     from psnerf_amd.stage1 import Loss
-    g = np.load(os.path.join(GOLDEN, 'stage1_unisurf_it%d.npz' % it))
+    g = np.load(os.path.join(GOLDEN, 'stage1_unisurf_%s.npz' % tag))
+    it = int(g['it'])
     cfg, net, ren = _renderer(cuda)
     noise = {'miss': T(g['nz_miss'], cuda), 'hit': T(g['nz_hit'], cuda), 'nbr': T(g['nz_nbr'], cuda)}
     out = ren(T(g['pix'], cuda), T(g['K'], cuda), T(g['c2w'], cuda), torch.eye(4, device=cuda)[None], 'unisurf',

@@ -171,10 +171,15 @@ def gen_stage1():
                         light_vis=np_(lv_ref), hw=np.array([h, w]))
 
     batch = stage1_batch(cfg, h=h, w=w, seed=2)
-    for it in (0, 6000):
+    pix96 = pix
+    g1 = torch.Generator().manual_seed(19)
+    pix512 = torch.stack([torch.randint(0, w, (512,), generator=g1).float(), torch.randint(0, h, (512,), generator=g1).float()], -1)[None]
+    # 'cfg1' = SURVEY 8(c) G6 at the scale of BASELINE configs[0]: bunny.yaml, 512 rays x 64 samples (it = 0), 256 march steps
+    for it, pix, tag in ((0, pix96, 'it0'), (6000, pix96, 'it6000'), (0, pix512, 'cfg1')):
+        N = pix.shape[1]
         for net in (rnet, onet):
             net.zero_grad()
-        seed = 100 + it
+        seed = 100 + it + (7 if tag == 'cfg1' else 0)
         torch.manual_seed(seed)
         out_r = rren(pix, K, c2w, S_, 'unisurf', add_noise=True, eval_=False, it=it)
         # capture the draws by replaying the RNG stream in the reference's order
@@ -191,7 +196,8 @@ def gen_stage1():
         out_o = oren(pix, K, c2w, S_, 'unisurf', add_noise=True, eval_=False, it=it, noise=noise)
         assert torch.equal(out_o['mask_pred'], mask)
         for k in ('rgb', 'normal_pred', 'acc_map'):
-            check('unisurf it=%d %s' % (it, k), out_o[k], out_r[k], 2e-6)
+            # (512 rays: the worst of 512 normalised gradients sits at 5e-6 -- different row blocking of the same GEMMs)
+            check('unisurf %s %s' % (tag, k), out_o[k], out_r[k], 2e-6 if tag != 'cfg1' else 1e-5)
         # diff_norm = |n - n'| of two nearly equal unit normals: cancellation, so the
         # meaningful scale is the normals' (1.0), not max(diff_norm)
         dn_err = float((out_o['diff_norm'] - out_r['diff_norm']).abs().max())
@@ -215,7 +221,7 @@ def gen_stage1():
         check('unisurf it=%d grad norms' % it, onorms, norms, 2e-5)
         check('unisurf it=%d grad projs' % it, oprojs, projs, 1e-4)
         np.savez_compressed(
-            os.path.join(GOLDEN, 'stage1_unisurf_it%d.npz' % it), sd_digest=state_dict_digest(sd),
+            os.path.join(GOLDEN, 'stage1_unisurf_%s.npz' % tag), sd_digest=state_dict_digest(sd),
             pix=np_(pix), K=np_(K), c2w=np_(c2w), hw=np.array([h, w]), it=it,
             nz_miss=np_(nz_miss), nz_hit=np_(nz_hit), nz_nbr=np_(nz_nbr),
             rgb=np_(out_r['rgb']), mask_pred=np_(mask), diff_norm=np_(out_r['diff_norm']),
@@ -223,6 +229,7 @@ def gen_stage1():
             rgb_gt=np_(rgb_gt), normal_gt=np_(ngt), norm_mask=np_(nmask),
             loss_names=np.array(sorted(tr.keys())), loss_vals=np.array([float(tr[k]) for k in sorted(tr.keys())]),
             grad_names=np.array(names), grad_norms=norms, grad_projs=projs)
+    pix, N = pix96, 96
     # --- Renderer.shape_extract (rendering.py:297-376) as stage1/shape_extract.py:112-139 calls it: a chunk of the INT64
     #     x-major arange_pixels grid, 512 march steps, normals with tflag=False, shadow-ray visibility per 96-light batch
     from model.common import arange_pixels as r_arange
@@ -484,6 +491,74 @@ def gen_stage2():
     check('relight visibility', oo['visibility'].mean(0).reshape(hr, wr, 3), vis_ref, 2e-6)
     np.savez_compressed(os.path.join(GOLDEN, 'stage2_relight.npz'), sd_digest=state_dict_digest(sd_r), hw=np.array([hr, wr]), light_h=lh_r,
                         input_seed=3, uv=np_(uv_r), env=env_r, rgb=rgb_ref.astype(np.float32), visibility=vis_ref.astype(np.float32))
+
+    # ---- test-view render of evaluate() (stage2/eval.py:314-417) and its material-edit variant (:233-312), re-assembled from the
+    #      reference's OWN pieces in the order eval.py runs them: PSNetwork (eval mode, jitter 0 as :47-48 sets it), the optimised light
+    #      tables of a model trained with train.light_train on all views (:338-345), general.split_input / merge_output per light batch
+    conf_v = o2.bear_conf(**{'brdf.net.xyz_jitter_std': 0, 'normal.net.xyz_jitter_std': 0})
+    sd_v = stage2_state_dict(conf_v, seed=14)
+    rnet_v = RPS(conf_v)
+    rnet_v.load_state_dict(sd_v)
+    rnet_v.eval()
+    hv, wv, Lv, lbatch_v, NLv, off_v = 36, 34, 5, 2, 9, 3          # 1224 pixels = two chunks of general.py's 1024
+    inp_v, _ = stage2_inputs(hv * wv, 1, 1, seed=4, h=hv, w=wv)
+    uv_v = np.mgrid[0:hv, 0:wv].astype(np.int32)                    # eval.py:320-322
+    uv_v = torch.from_numpy(np.flip(uv_v, axis=0).copy()).float().reshape(2, -1).transpose(1, 0)
+    gv = torch.Generator().manual_seed(15)
+    light_para_v = torch.nn.Embedding(NLv, 3, sparse=True).eval().requires_grad_(False)
+    light_para_v.weight.data.copy_(torch.nn.functional.normalize(inp_v['pose'][0, :3, 3][None] + 8.0 * torch.randn(NLv, 3, generator=gv), dim=-1) * 1.7)
+    light_inten_v = torch.nn.Embedding(NLv, 1, sparse=True).eval().requires_grad_(False)
+    light_inten_v.weight.data.copy_(1.5 + torch.rand(NLv, 1, generator=gv))
+    lidx_v = torch.arange(Lv).long()
+
+    def eval_view(albedo_new=None, basis_new=None):
+        mi_v = {'object_mask': torch.ones(1, hv * wv), 'uv': uv_v[None], 'intrinsics': inp_v['intrinsics'], 'lidx': lidx_v, 'pose': inp_v['pose'],
+                'normal': torch.ones(1, hv * wv, 3), 'points': inp_v['points'], 'surface_mask': inp_v['surface_mask']}
+        rgb_all, vis_all, rough_all = [], [], []
+        with torch.no_grad():
+            for lstart in range(0, Lv, lbatch_v):                   # eval.py:339-363
+                lend = min(Lv, lstart + lbatch_v)
+                l_slt = off_v + lidx_v[lstart:lend]
+                mi_v['light_direction'] = torch.nn.functional.normalize(light_para_v(l_slt), p=2, dim=-1)
+                mi_v['light_intensity'] = light_inten_v(l_slt)
+                res = []
+                for sp in RGEN.split_input(mi_v, hv * wv):
+                    out = rnet_v(sp, albedo_new=albedo_new, basis_new=basis_new) if (albedo_new is not None or basis_new is not None) else rnet_v(sp)
+                    res.append({k: out[k].detach() for k in out})
+                mo = RGEN.merge_output(res, hv * wv, 1)
+                rgb_all.append(np_(mo['sg_rgb_values'].reshape(-1, hv, wv, 3)))
+                rough_all.append(np_(mo['sg_specular_rgb_values'].reshape(-1, hv, wv, 3)))
+                vis_all.append(np_(mo['visibility'].reshape(-1, hv, wv, 3)))
+        rmask = np_(mo['network_object_mask'].reshape(hv, wv))      # :382
+        return {'rgb': np.concatenate(rgb_all, 0).clip(0, 1), 'rough': np.concatenate(rough_all, 0), 'mask': rmask,
+                'normal': np_(mo['normal_pred'].reshape(hv, wv, 3)) * rmask[..., None],          # :394-395
+                'albedo': np_(mo['sg_diffuse_albedo_values'].reshape(hv, wv, 3)).clip(0, 1),      # :400
+                'visibility': np.concatenate(vis_all, 0).clip(0, 1)}                              # :406
+    ref_v = eval_view()
+    color_v, basis_v = '#4080c0', 3
+    albedo_new_v = (np.array([int(color_v.lstrip('#')[i:i + 2], 16) for i in (0, 2, 4)]).astype(np.float32) / 5. / 255.).astype(np.float32)  # :127-130
+    ref_e = eval_view(albedo_new=albedo_new_v, basis_new=basis_v)
+    from psnerf_amd.stage2 import relight as prl2
+    an, bn, name = prl2.edit_material(color=color_v, basis=basis_v, edit_albedo=True, edit_specular=True)
+    assert np.array_equal(an, albedo_new_v) and bn == basis_v and name == '#4080c0_sg4'
+    # the oracle network under the product's loop (relight.render_view) == the reference's pieces
+    onet_v = o2.PSNetwork(conf_v)
+    onet_v.load_state_dict(sd_v)
+    onet_v.eval()
+    mi_o = {'object_mask': torch.ones(1, hv * wv, dtype=torch.bool), 'uv': uv_v[None], 'intrinsics': inp_v['intrinsics'], 'pose': inp_v['pose'],
+            'normal': torch.ones(1, hv * wv, 3), 'points': inp_v['points'], 'surface_mask': inp_v['surface_mask']}
+    ld_o, li_o = prl2.eval_lights(None, lidx_v, light_para_v, light_inten_v, light_offset=off_v)
+    for tag, ref_maps, kw in (('view', ref_v, {}), ('edit', ref_e, {'albedo_new': albedo_new_v, 'basis_new': basis_v})):
+        got = prl2.render_view(onet_v, mi_o, ld_o, li_o, light_batch=lbatch_v, pixel_chunk=1024, **kw)
+        for k in ('rgb', 'rough', 'visibility'):
+            check('eval %s %s' % (tag, k), got[k].reshape(-1, hv, wv, 3), ref_maps[k], 2e-6)
+        for k in ('normal', 'albedo'):
+            check('eval %s %s' % (tag, k), got[k].reshape(hv, wv, 3), ref_maps[k], 2e-6)
+        assert np.array_equal(np_(got['mask']).reshape(hv, wv), ref_maps['mask'].astype(bool))
+    np.savez_compressed(os.path.join(GOLDEN, 'stage2_eval_view.npz'), sd_digest=state_dict_digest(sd_v), hw=np.array([hv, wv]), input_seed=4,
+                        uv=np_(uv_v), light_para=np_(light_para_v.weight), light_inten=np_(light_inten_v.weight), lidx=np_(lidx_v), light_offset=off_v,
+                        light_batch=lbatch_v, color=color_v, basis=basis_v,
+                        **{('view_' + k): v.astype(np.float32) for k, v in ref_v.items()}, **{('edit_' + k): v.astype(np.float32) for k, v in ref_e.items()})
 
     # ---- normal jitter > 0 (renderer.py:133-140; bear.conf has 0): TWO torch.normal draws, normal jitter first
     conf_j = o2.bear_conf(**{'normal.net.xyz_jitter_std': 0.02})
