@@ -344,7 +344,7 @@ class DeviceViews(object):
     # ---- host half: the draws ----------------------------------------------------------------------------------------------
     def draw(self, idx):
         import time
-        t0 = time.perf_counter()
+        t0 = time.thread_time()   # CPU time of the calling thread: waits (slots, events) are back-pressure, not host work
         idx = int(idx)
         n_l = self.n_lights[idx]
         if self.split == 'train' and n_l >= self.light_bs:
@@ -362,7 +362,7 @@ class DeviceViews(object):
         rows = None
         if self.vis_plus is not None:
             rows = self.rng.choice(np.arange(self.tables[idx]['vis_plus'].shape[0]), self.vis_plus.vnum, replace=False).astype(np.int64)  # trainer.py:389
-        self.host_seconds['draw'] += time.perf_counter() - t0
+        self.host_seconds['draw'] += time.thread_time() - t0
         return _Draw(idx, lidx, pix, rows)
 
     # ---- device half: index upload + one gather launch ----------------------------------------------------------------------
@@ -381,7 +381,7 @@ class DeviceViews(object):
     def assemble(self, d, out=None):
         """(idx, model_input, ground_truth, l_slt) of the draw ``d`` on the device; ``out``: preallocated outputs (loader slots)."""
         import time
-        t0 = time.perf_counter()
+        t0 = time.thread_time()
         hip, dev, tab = self.hip, self.device, self.tables[d.idx]
         n_all = self.total_pixels if d.pix is None else int(d.pix.shape[0])
         lo, hi = (0, n_all) if (self.dp is None or not self.dp.enabled) else self.dp.slice_bounds(n_all)
@@ -433,7 +433,7 @@ class DeviceViews(object):
         if V:
             mi['light_vis_train'] = torch.index_select(tab['vis_plus_light'], 0, rows_dev, out=out['light_vis_train'][:V * 3].view(V, 3))  # trainer.py:390
             mi['vis_train_gt'] = g['vis_train_gt']                                              # trainer.py:392
-        self.host_seconds['assemble'] += time.perf_counter() - t0
+        self.host_seconds['assemble'] += time.thread_time() - t0
         self.host_seconds['items'] += 1
         return d.idx, mi, {'rgb': g['rgb']}, l_slt
 
