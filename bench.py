@@ -169,6 +169,61 @@ def cpu_baseline(n_pixels=4096, steps=3):
             'single_thread': {'value': sweep.get(1), 'cores': 1, 'sample': '1024 px, min of 2 timed steps after 1 warm-up'}}
 
 
+# ----------------------------------------------------------------------------------------------- the data pipeline in the loop
+def sampler_in_loop(device, step, steps=60, warmup=8):
+    """The headline's step fed by the product's data pipeline instead of a resident batch: two BEAR-shaped views (612 x 512, 96
+    lights each, ~90 %% of the pixels in the object mask) resident in HBM (handoff.DeviceViews: images as uint8, masks, stage-1 points /
+    normals / visibility maps, the vis_plus tables), every step a fresh draw of light_bs = 96 lights and %d in-mask pixels in the reference's np.random
+    order (stage2/datasets/dataset.py:149-151,182-185), ONE gather launch, prefetched by a worker thread.  -> sustained ms/step.""" % N_PIXELS
+    import numpy as np
+    import torch
+    from psnerf_amd import handoff
+    h, w, L = 512, 612, N_LIGHTS
+    g = torch.Generator().manual_seed(7)
+    views, images, omasks, lights, poses = [], [], [], [], []
+    from psnerf_amd.synthetic import stage2_inputs
+    for v in range(2):
+        inp, _ = stage2_inputs(h * w, L, N_VIS, seed=300 + v, h=h, w=w)
+        views.append({'points': inp['points'], 'normal': inp['normal'], 'surface_mask': inp['surface_mask'],
+                      'visibility': inp['visibility'], 'img_res': [h, w],
+                      # train.vis_plus (bear.conf:29): 256 extra supervision directions per view with their stage-1 visibility maps
+                      'vis_plus': (torch.rand(256, h * w, generator=g) < 0.7).float(),
+                      'vis_plus_light': torch.nn.functional.normalize(torch.randn(256, 3, generator=g), dim=-1)})
+        images.append(torch.randint(0, 256, (L, h * w, 3), generator=g, dtype=torch.uint8))   # decoded 8-bit PNGs
+        omasks.append(inp['object_mask'][0])
+        lights.append(inp['light_direction'])
+        poses.append(inp['pose'][0])
+    from psnerf_amd.stage2.trainer import VisPlus
+    vp = VisPlus(views, lights, N_VIS, device)
+    store = handoff.DeviceViews(views, images, omasks, lights, poses, inp['intrinsics'][0], L, device, n_pixels=N_PIXELS, vis_plus=vp)
+    del images
+    np.random.seed(0)
+    order = [i % 2 for i in range(steps + warmup)]
+    t0 = None
+    feed = store.loader(order, depth=3)
+    for it, (vidx, mi, gt, l_slt) in enumerate(feed):
+        if it == warmup:
+            settle_gc()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        # (l_slt = rows of a 2-view table; the step's light tables hold N_LIGHTS_TOTAL rows)
+        terms, _ = step.step(mi, gt, l_slt, train_order=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ns = int(mi['surface_idx'].numel())
+    hs = store.host_seconds
+    return {'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'warmup': warmup, 'value': round(ns * L / dt, 1), 'unit': 'ray-samples/s',
+            'surface_pixels_last_batch': ns, 'resident_view_bytes': store.resident_bytes(), 'image_store': 'uint8',
+            'host_cpu_ms_per_item': {'draw': round(1e3 * hs['draw'] / hs['items'], 3), 'assemble': round(1e3 * hs['assemble'] / hs['items'], 3)},
+            'training_thread_wait_ms_per_item': round(1e3 * feed.consumer_wait / (steps + warmup), 3),
+            'batch': 'handoff.DeviceViews.loader: a different batch every step -- fresh light, pixel and vis_plus draws (V = %d of 256 + 96 '
+                     'supervision directions, stage2/trainer.py:384-392), assembled on the device' % N_VIS,
+            'note': 'compare VALUE with the headline (resident batch): in-mask sampling gives more surface pixels per batch than the headline batch, '
+                    'so ms_per_step differ by the row count; host_cpu_ms counts thread CPU time incl. the spin of event waits (back-pressure: the '
+                    'worker stays a bounded number of items ahead of the GPU); tools/run_e2e.py --full has the loop with HIP graphs '
+                    '(profiles/r05*_e2e_full.json)'}
+
+
 # ----------------------------------------------------------------------------------------------- stage 1 (configs[1])
 def stage1_measure(device, steps=10, warmup=5, rays=4096):
     """BASELINE configs[1]: stage-1 BEAR train step, 4096 rays x 128 samples (96 inner + 32 outer, it > 5000), 256 march
@@ -755,6 +810,13 @@ def main():
     del inp, gt
     ms_per_step = dt / args.steps * 1e3
     value = ns_total * N_LIGHTS / (dt / args.steps)
+    in_loop = None
+    if not args.no_extra and world == 1:
+        try:
+            in_loop = sampler_in_loop(device, step)
+            in_loop['value_over_headline'] = round(in_loop['value'] / value, 4)
+        except Exception as e:  # noqa: BLE001
+            in_loop = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
     other = None
     allreduce_ms = None
@@ -841,7 +903,7 @@ def main():
                        'batch': "ViewSampler.batch layout: reference dictionary + 'surface_idx' (host-built index list of the surface mask)"},
             'loss': round(float(terms['total'].detach()), 6),
             'roofline': roofline, 'cpu_baseline': cpu, 'reference_dict': ref_dict, 'launches_per_step': launches,
-            'bf16x6_experiment': x6,
+            'bf16x6_experiment': x6, 'sampler_in_loop': in_loop,
             ('strong' if args.scaling == 'weak' else 'weak'): other,
             'strong_cfg4': cfg4, 'parity': parity,
             'allreduce_ms': allreduce_ms, 'allreduce_bytes': bucket_bytes if world > 1 else None,
