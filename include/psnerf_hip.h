@@ -185,8 +185,13 @@ enum {
     PSN_ACT_MUL2 = 5,          /* act = z * a1;                    second = z * a2                          */
     PSN_ACT_SOFTPLUS_BWD = 6,  /* act = a1 z + 100 (1 - a1) a2     (softplus double-backward combine)        */
     PSN_ACT_HEAD = 7,          /* side output: z is dumped, the activations are left untouched              */
-    PSN_ACT_RELU_BITS = 8      /* act = z * bit: RELU_MASK with the mask as sign bits -- a1 = [n_rows, 4] uint64 words written
+    PSN_ACT_RELU_BITS = 8,     /* act = z * bit: RELU_MASK with the mask as sign bits -- a1 = [n_rows, 4] uint64 words written
                                   by psn_mlp_infer_bits (bit 4 mt + r of word (row, g) = feature 16 mt + 4 g + r was > 0)    */
+    /* single-dump forms of the softplus chains (stage1/model/network.py:85-120): a1 = the dumped softplus OUTPUT a of the forward
+       layer; s = sigmoid(100 z) = 1 - exp(-100 a) is re-formed in the kernel (a < 0, impossible for a softplus, gives s = 0) */
+    PSN_ACT_MUL_AUX_A = 9,     /* act = z * s(a1);                 second = z                               */
+    PSN_ACT_MUL2_A = 10,       /* act = z * s(a1);                 second = z * a2                          */
+    PSN_ACT_SOFTPLUS_BWD_A = 11 /* act = s(a1) z + 100 (1 - s(a1)) a2                                        */
 };
 enum { PSN_OUT_NONE = 0, PSN_OUT_SIGMOID = 1, PSN_OUT_OCC = 2 /* sigmoid(-10 x), network.py:125 */ };
 

@@ -253,10 +253,17 @@ __device__ __forceinline__ void st4(float* p, const floatx4& v) { *reinterpret_c
 // tile 0, tile mt is 16 floats further.  All operand loads of the layer are issued back to back (one exposed
 // latency per layer instead of one per tile) and all dump stores are issued at the end, where they complete under
 // the next layer's MFMAs.  p1 / p2 are non-null whenever CODE needs them (validated on the host).
-template <int CODE, int NMT>
+template <int CODE, int NMT, bool FROMA = false>
 __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&act)[NMT], const float* __restrict__ p1,
                                                  const float* __restrict__ p2, float* __restrict__ d1, float* __restrict__ d2,
                                                  const uint32_t m1, const uint32_t m2, const unsigned long long sign_bits = 0) {
+    // *_A codes (single-dump experiment): a1 is the dumped softplus OUTPUT a = softplus_100(z) of the forward layer instead of its
+    // sigmoid; s = sigmoid(100 z) = 1 - exp(-100 a) (and 1 - s = exp(-100 a)) is re-formed here, so the value pass writes one
+    // tensor per layer instead of two.  a < 0 cannot come from a softplus: such columns (the encoding half of the skip layer's
+    // [a | pe] input tile) are clamped to s = 0 -- their products meet zero weight rows, but must stay finite.
+    // (a separate INSTANTIATION of the kernel, FROMA: as further cases of the one kernel the three programs pushed the 256-register
+    //  chain kernel into 92 spilled registers -- for every chain, not only theirs)
+    constexpr bool kFromA = FROMA && (CODE == PSN_ACT_MUL_AUX || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD);
     constexpr bool kNeed1 = CODE == PSN_ACT_RELU_MASK || CODE == PSN_ACT_MUL_AUX || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD;
     constexpr bool kNeed2 = CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD;
     constexpr bool kSecond = CODE == PSN_ACT_SOFTPLUS100 || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_MUL_AUX;
@@ -294,7 +301,11 @@ __device__ __forceinline__ void chain_activation(floatx4 (&acc)[NMT], floatx4 (&
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x2 z = {acc[mt][2 * h], acc[mt][2 * h + 1]};
-                const f32x2 a1 = {t1[mt][2 * h], t1[mt][2 * h + 1]};
+                f32x2 a1 = {t1[mt][2 * h], t1[mt][2 * h + 1]};
+                if constexpr (kFromA) {  // s = 1 - exp(-100 a), in place of the operand (no further live value)
+                    const f32x2 t = a1 * (-100.0f * 1.44269502162933349609375f);
+                    a1 = 1.0f - f32x2{__builtin_amdgcn_exp2f(fminf(t.x, 0.0f)), __builtin_amdgcn_exp2f(fminf(t.y, 0.0f))};
+                }
                 f32x2 a, b = z;
                 if constexpr (CODE == PSN_ACT_MUL_AUX) a = z * a1;
                 else if constexpr (CODE == PSN_ACT_MUL2) { a = z * a1; b = z * f32x2{t2[mt][2 * h], t2[mt][2 * h + 1]}; }
@@ -361,7 +372,9 @@ __device__ __forceinline__ void wait_for_weights(int stores) {
 // hint: only pairs inside one block are examined, whoever misses it evaluates values that nothing reads.
 // TRIM: some layer reads one activation k-tile fewer than the width (a separate instantiation: the conditional last stage costs
 // the untrimmed visibility launch 0.7 %).
-template <bool CHAIN, int NMT, int SRC = 0, bool TRIM = false>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
+// FROMA (chain variant): the MUL_AUX / MUL2 / SOFTPLUS_BWD programs take the dumped softplus OUTPUT as a1 and re-form the sigmoid
+// (single-dump experiment, PSN_ACT_*_A on the host side).
+template <bool CHAIN, int NMT, int SRC = 0, bool TRIM = false, bool FROMA = false>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
 __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     constexpr int W = 16 * NMT;
     // LDS-DMA flavour (common.h lds_dma_16): asm pieces + explicit scheduling regions for the lean variant (exact lgkmcnt
@@ -760,7 +773,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             float* d2 = (g.save2[li] != nullptr && dump_row) ? g.save2[li] + (row - g.save_row0) * W + 4 * lg : nullptr;
             // one straight-line body per code (operand loads batched up front, results stored tile by tile)
             const uint32_t m1 = g.save_tiles[li], m2 = g.save2_tiles[li];
-#define PSN_CASE(C) case C: chain_activation<C, NMT>(acc, act, p1, p2, d1, d2, m1, m2); break;
+#define PSN_CASE(C) case C: chain_activation<C, NMT, FROMA>(acc, act, p1, p2, d1, d2, m1, m2); break;
             switch (L.act) {
                 case PSN_ACT_RELU_BITS:  // mask[li] = the forward launch's sign-bit words [n_rows, 4] uint64 (save_bits)
                     chain_activation<PSN_ACT_RELU_BITS, NMT>(acc, act, nullptr, nullptr, d1, d2, m1, m2,
@@ -1220,13 +1233,14 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
                       "mlp_infer: aux / dump tensors must be 16-byte aligned");
         if (in_range) {
             const int act = d.layers[l].act;
-            const bool need1 = act == PSN_ACT_RELU_MASK || act == PSN_ACT_MUL_AUX || act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD || act == PSN_ACT_RELU_BITS;
-            const bool need2 = act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD;
-            PSN_CHECK_ARG(act >= PSN_ACT_NONE && act <= PSN_ACT_RELU_BITS, "mlp_infer: layer %d unknown activation %d", l, act);
+            const bool need1 = act == PSN_ACT_RELU_MASK || act == PSN_ACT_MUL_AUX || act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD || act == PSN_ACT_RELU_BITS ||
+                               act == PSN_ACT_MUL_AUX_A || act == PSN_ACT_MUL2_A || act == PSN_ACT_SOFTPLUS_BWD_A;
+            const bool need2 = act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD || act == PSN_ACT_MUL2_A || act == PSN_ACT_SOFTPLUS_BWD_A;
+            PSN_CHECK_ARG(act >= PSN_ACT_NONE && act <= PSN_ACT_SOFTPLUS_BWD_A, "mlp_infer: layer %d unknown activation %d", l, act);
             PSN_CHECK_ARG(!need1 || a.mask[l] != nullptr, "mlp_infer: layer %d needs aux operand 1", l);
             PSN_CHECK_ARG(!need2 || a.aux2[l] != nullptr, "mlp_infer: layer %d needs aux operand 2", l);
             PSN_CHECK_ARG(act != PSN_ACT_HEAD || a.save[l] != nullptr, "mlp_infer: a HEAD layer needs a dump tensor");
-            const bool second = act == PSN_ACT_SOFTPLUS100 || act == PSN_ACT_MUL_AUX || act == PSN_ACT_MUL2;
+            const bool second = act == PSN_ACT_SOFTPLUS100 || act == PSN_ACT_MUL_AUX || act == PSN_ACT_MUL2 || act == PSN_ACT_MUL_AUX_A || act == PSN_ACT_MUL2_A;
             PSN_CHECK_ARG(a.save2[l] == nullptr || second, "mlp_infer: layer %d (activation %d) has no second value to dump", l, act);
         }
     }
@@ -1267,7 +1281,21 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
     bool trim = false;
     for (int l = 0; l < d.n_layers; ++l) trim = trim || (d.layers[l].n_kt_act > 0 && d.layers[l].n_kt_act < hid);
     PSN_CHECK_ARG(!trim || hid == 8, "mlp_infer: n_kt_act = n_mt - 1 is built for the 256-wide networks only");
-    if (trim) {
+    // single-dump programs (PSN_ACT_*_A): the FROMA instantiation of the 256-wide chain kernel runs their base programs on a1 = the
+    // softplus output; a launch uses either the _A codes or their base codes, never both
+    bool from_a = false, base_mul = false;
+    for (int l = 0; l < d.n_layers; ++l) {
+        int& act = a.d.layers[l].act;
+        if (act == PSN_ACT_MUL_AUX_A || act == PSN_ACT_MUL2_A || act == PSN_ACT_SOFTPLUS_BWD_A) {
+            from_a = true;
+            act = act == PSN_ACT_MUL_AUX_A ? PSN_ACT_MUL_AUX : act == PSN_ACT_MUL2_A ? PSN_ACT_MUL2 : PSN_ACT_SOFTPLUS_BWD;
+        } else if (act == PSN_ACT_MUL_AUX || act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD) base_mul = true;
+    }
+    PSN_CHECK_ARG(!from_a || (hid == 8 && chain && !base_mul), "mlp_infer: the single-dump programs (PSN_ACT_*_A) exist for the 256-wide chain engine and do not mix with their base programs");
+    if (from_a) {
+        if (trim) hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, true, true>), grid, block, lds_bytes, st, a);
+        else hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, false, true>), grid, block, lds_bytes, st, a);
+    } else if (trim) {
         if (chain) hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, true>), grid, block, lds_bytes, st, a);
         else hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 0, true>), grid, block, lds_bytes, st, a);
     } else if (hid == 8) {

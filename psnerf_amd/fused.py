@@ -449,10 +449,14 @@ def _t(w):
     return Transposed(w)
 
 
-def pack_geo_chains(weights, biases, skips, d_pe):
+def pack_geo_chains(weights, biases, skips, d_pe, single_dump=False):
     """The four fused chains of ops.GeoFieldFused for the 256-wide softplus geometry network
     (stage1/model/network.py:85-120); ``weights`` are the EFFECTIVE dense matrices with the 1/sqrt(2) of the skip
-    layer already folded in.  Returns dict(fwd, sweep, sweep_bwd, value_bwd, value_bwd_nosweep) of PackedMLP."""
+    layer already folded in.  Returns dict(fwd, sweep, sweep_bwd, value_bwd, value_bwd_nosweep) of PackedMLP.
+    ``single_dump`` (experiment, ops.GEO_SINGLE_DUMP): the consumer chains take the dumped softplus outputs A_l where they took the
+    dumped sigmoids S_l and re-form s = 1 - exp(-100 a) in their activation programs; the value pass then dumps one tensor per layer."""
+    mul_aux, mul2, sp_bwd = ((hip.ACT_MUL_AUX_A, hip.ACT_MUL2_A, hip.ACT_SOFTPLUS_BWD_A) if single_dump else
+                             (hip.ACT_MUL_AUX, hip.ACT_MUL2, hip.ACT_SOFTPLUS_BWD))
     n = len(weights)
     assert len(skips) == 1 and weights[1].shape[1] == 256 and weights[n - 1].shape[0] == 257
     sk = skips[0]
@@ -477,9 +481,9 @@ def pack_geo_chains(weights, biases, skips, d_pe):
     fwd = pack_layers(layers, ka, 0, 1, hip.OUT_NONE, dev)
 
     # F2: reverse sweep r_l = (r_{l+1} * s_l) W_l, starting from row 0 of the last layer (init table with one row)
-    layers = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=hip.ACT_MUL_AUX)]
+    layers = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=mul_aux)]
     for l in range(n - 2, 0, -1):
-        layers.append(dict(w_act=_t(W[l]), bias=zeros, act=hip.ACT_MUL_AUX))
+        layers.append(dict(w_act=_t(W[l]), bias=zeros, act=mul_aux))
     # ... and ends with r_0 = u_0 W_0 (256 -> d_pe encoding columns) as a 64-output FINAL layer: 4 output tiles instead of the 16
     # of a hidden-type layer, the [Q, d_pe] result written densely
     layers.append(dict(w_act=_t(W[0]), bias=_zeros(64, dev), act=hip.ACT_NONE))
@@ -487,7 +491,7 @@ def pack_geo_chains(weights, biases, skips, d_pe):
     sweep = pack_layers(layers, ka, 0, d_pe, hip.OUT_NONE, dev)
 
     # B1: adjoint of the sweep: du_l = dR_l W_l^T ; dR_{l+1} = du_l * s_l ; dS_l = du_l * R_{l+1}
-    layers = [dict(bias=zeros, act=hip.ACT_MUL2, **fwd_in(l)) for l in range(n - 1)]
+    layers = [dict(bias=zeros, act=mul2, **fwd_in(l)) for l in range(n - 1)]
     sweep_bwd = pack_layers(layers, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
 
     # B2: adjoint of the value pass: da_l = W_l^T dz_l ; dz_{l-1} = s (da + 100 dS (1 - s))   [or s * da without sweep]
@@ -497,8 +501,8 @@ def pack_geo_chains(weights, biases, skips, d_pe):
             ls.append(dict(w_act=_t(W[l]), bias=zeros, act=act))
         return pack_layers(ls, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
 
-    return dict(fwd=fwd, sweep=sweep, sweep_bwd=sweep_bwd, value_bwd=value_bwd(hip.ACT_SOFTPLUS_BWD),
-                value_bwd_nosweep=value_bwd(hip.ACT_MUL_AUX), d_a=d_a)
+    return dict(fwd=fwd, sweep=sweep, sweep_bwd=sweep_bwd, value_bwd=value_bwd(sp_bwd),
+                value_bwd_nosweep=value_bwd(mul_aux), d_a=d_a, single_dump=bool(single_dump))
 
 
 def pack_app_chains(weights, biases, d_x):

@@ -27,7 +27,7 @@ MAX_LAYERS = 12
 (EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_SOFTPLUS, EPI_MUL_AUX, EPI_MUL_POS, EPI_BIAS_SIGMOID, EPI_ACCUM,
  EPI_MUL2, EPI_SOFTPLUS_BWD, EPI_MUL_AUX_RAW) = range(11)
 (ACT_NONE, ACT_RELU, ACT_SOFTPLUS100, ACT_RELU_MASK, ACT_MUL_AUX, ACT_MUL2, ACT_SOFTPLUS_BWD,
- ACT_HEAD, ACT_RELU_BITS) = range(9)
+ ACT_HEAD, ACT_RELU_BITS, ACT_MUL_AUX_A, ACT_MUL2_A, ACT_SOFTPLUS_BWD_A) = range(12)
 OUT_NONE, OUT_SIGMOID, OUT_OCC = range(3)
 
 

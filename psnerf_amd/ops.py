@@ -736,6 +736,17 @@ class VisibilityPair(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- stage-1 geometry field, fused chains
+# One dump per softplus layer (round 5): the value pass writes A_l = softplus_100(z_l) only; the three consumer
+# chains re-form sigmoid(100 z_l) = 1 - exp(-100 A_l) in their activation programs (PSN_ACT_*_A: a separate instantiation of the
+# chain kernel -- as extra cases of the one kernel they spilled 92 registers).  Measured at 262,144 points (profiles/r05a_*single_dump*):
+# F1 writes 2.42 GB instead of 4.58 GB and takes 6 % fewer cycles, F2 / B1 / B2 pay 1.2 - 2.3 % for the exponentials (+25 M vector
+# instructions each); chains -0.3 % cycles, the configs[1] step -0.2 .. -0.45 ms (43.8 -> 43.5 ms), eight [Q, 256] tensors (4.3 GB at
+# 524k render samples) are no longer allocated.  Results differ in the last bits (gradients 6e-7 relative).  PSN_GEO_SINGLE_DUMP=0
+# restores the two-dump chains (A/B: tools/dbg/ab_single_dump.py).
+import os as _os
+GEO_SINGLE_DUMP = _os.environ.get('PSN_GEO_SINGLE_DUMP', '1') == '1'
+
+
 class GeoFieldFused(torch.autograd.Function):
     """Same function as GeoField (occupancy logit, 256 features and d logit / d p of the stage-1 geometry MLP, with a
     hand-derived backward through both the value pass and the gradient sweep), but every layer-to-layer chain runs
@@ -763,9 +774,11 @@ class GeoFieldFused(torch.autograd.Function):
         sk = skips[0]
         pe = hip.pe_encode(p, n_octaves, 64, scale)  # [Q,64] xin table (39 real columns)
         A = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]   # A[l] = softplus output of layer l = input of l+1
-        S = [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]
+        single = bool(chains.get('single_dump'))
+        # single-dump experiment (GEO_SINGLE_DUMP): the sigmoids are not dumped, the consumer chains re-form them from A
+        S = A if single else [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]
         feat = torch.empty(Q, 256, device=dev)
-        logit = chains['fwd'](pe, Q, save=A + [feat], save2=S + [None, None])
+        logit = chains['fwd'](pe, Q, save=A + [feat], save2=None if single else S + [None, None])
         A[sk - 1][:, d_a:] = pe[:, :d_pe]  # the skip layer's input is [a (217) | pe (39)]: complete the dumped tile
         grad = None
         U = R = None
@@ -787,7 +800,7 @@ class GeoFieldFused(torch.autograd.Function):
             grad = hip.pe_encode_bwd(p, r0, n_octaves, scale, add=r_sk[:, d_a:d_a + d_pe])
         if any(ctx.needs_input_grad):
             ctx.meta = (n, sk, d_pe, d_a, n_octaves, scale, with_grad, chains, feat_rows)
-            keep = [p, pe] + Ws + A + S
+            keep = [p, pe] + Ws + A + ([] if single else S)
             if with_grad:
                 keep += U
             ctx.save_for_backward(*keep)
@@ -803,7 +816,8 @@ class GeoFieldFused(torch.autograd.Function):
         p, pe = sv[0], sv[1]
         Ws = sv[2:2 + n]
         A = sv[2 + n:2 + 2 * n - 1]
-        S = sv[2 + 2 * n - 1:2 + 3 * n - 2]
+        single = bool(chains.get('single_dump'))
+        S = A if single else sv[2 + 2 * n - 1:2 + 3 * n - 2]
         Q, dev = p.shape[0], p.device
         sweep = with_grad and d_grad is not None
         d_logit = torch.zeros(Q, 1, device=dev) if d_logit is None else d_logit.contiguous()
@@ -814,7 +828,7 @@ class GeoFieldFused(torch.autograd.Function):
 
         E = None
         if sweep:
-            base = 2 + 3 * n - 2
+            base = 2 + (2 if single else 3) * n - (1 if single else 2)
             U = sv[base:base + n - 1]
             dd_pe = hip.pe_encode_jvp(p, d_grad.contiguous(), n_octaves, 64, scale)  # adjoint of d_pe, [Q,64]
             dR = [dd_pe] + [torch.empty(Q, 256, device=dev) for _ in range(n - 1)]   # dR[l], l = 0..n-1

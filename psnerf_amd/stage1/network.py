@@ -143,7 +143,7 @@ class NeuralNetwork(nn.Module):
         key = self._params_key()
         if self._chains is None or self._chains_key != key:
             with torch.no_grad():
-                self._chains = fused.pack_geo_chains(params[0::2], params[1::2], self.skips, self.d_pe)
+                self._chains = fused.pack_geo_chains(params[0::2], params[1::2], self.skips, self.d_pe, single_dump=ops.GEO_SINGLE_DUMP)
             self._chains_key = key
         return self._chains
 

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from psnerf_amd import hip, ops, fused
 
-Q = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+Q = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 262144
+SINGLE = 'single' in sys.argv  # the single-dump experiment (ops.GEO_SINGLE_DUMP): consumer chains re-form the sigmoid from A
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 dims_in = [39, 256, 256, 256, 256, 256, 256, 256, 256]
@@ -13,7 +14,7 @@ params = []
 for i, o in zip(dims_in, dims_out):
     params += [(torch.randn(o, i, device=dev) * (1.4 / i ** 0.5)).requires_grad_(), (torch.randn(o, device=dev) * 0.01).requires_grad_()]
 p = (torch.rand(Q, 3, device=dev) - 0.5).requires_grad_()
-chains = fused.pack_geo_chains(params[0::2], params[1::2], [4], 39)
+chains = fused.pack_geo_chains(params[0::2], params[1::2], [4], 39, single_dump=SINGLE)
 names = ['F1 value', 'F2 sweep', 'B1 sweep-adj', 'B2 value-adj']
 macs = [39 * 256 + 6 * 65536 + 256 * 217 + 256 * 256 + 2 * 65536 + 256, 7 * 65536 + 256 * 64, 64 * 256 + 7 * 65536 + 64 * 256, 8 * 65536]
 for it in range(3):
@@ -34,7 +35,7 @@ for it in range(3):
             print('%-14s %7.3f ms  %6.1f TF/s (padded-256 MACs)' % (n, ms, 2.0 * m * rows / ms / 1e9))
         print('forward %.3f ms  backward %.3f ms' % (e0.elapsed_time(e1), e1.elapsed_time(e2)))
 
-if os.environ.get('CHAINS_ONLY'):
+if os.environ.get('CHAINS_ONLY') or SINGLE or 'chains-only' in sys.argv:
     sys.exit(0)
 # ---- where does the value chain's time go?  same launch with fewer dumps
 pe = hip.pe_encode(p.detach(), 6, 64, 1.0)
