@@ -131,6 +131,13 @@ typedef struct {
 } PsnGemmTnItem;
 int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
                         int64_t workspace_floats, void* stream);
+/* psn_gemm_tn_grouped with the 256 x 256-tile products (128 < M, N <= 256: the hidden-layer weight gradients of
+ * stage1/model/network.py:85-106 and of the stage-2 visibility net) evaluated on the bf16 matrix pipe with split operands --
+ * every fp32 element as three bf16 pieces, six partial products per multiply, fp32 accumulation ("bf16x6"): fp32-class results,
+ * HBM-bound instead of MFMA-bound.  EXPERIMENT for BASELINE configs[4]'s bf16 path; every other product of the group takes the
+ * exact fp32 kernels of psn_gemm_tn_grouped.  Same arguments, same workspace size. */
+int psn_gemm_tn_grouped_x3(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
+                        int64_t workspace_floats, void* stream);
 
 /* column sums: out[j, n] (+)= sum_m w[m, j] X[m, n] for n_w <= 4 weight columns (row_weight [M, n_w], row stride ldw), or
  * plain column sums out[n] (+)= sum_m X[m, n] with row_weight = NULL, n_w = 0 -- bias gradients, and with weights the

@@ -646,6 +646,203 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_grouped_kernel(GroupedArgs 
         }
 }
 
+// ---- the same product on the bf16 matrix pipe with split operands ("bf16x6"; EXPERIMENT, never the default) ------------
+// dW = dZ^T X for 128 < M, N <= 256 with every fp32 operand element as the exact sum of three bf16 numbers (x = hi + mid + lo,
+// 8 + 8 + 8 significant bits, round-to-nearest pieces) and a product as the six partial products of weight >= 2^-16,
+//     lo hi + hi lo + mid mid + mid hi + hi mid + hi hi   (fp32 accumulation, smallest terms first),
+// i.e. fp32-class results (relative error of a product ~2^-22) at 16 / 6 = 2.7x the fp32-MFMA rate.  At that rate the kernel is
+// HBM-bound: per 16-row k-tile a workgroup reads 32 KB and issues 4 x 96 v_mfma_f32_32x32x16_bf16 (3072 matrix cycles per wave,
+// 1.28 us), which asks ~6.4 TB/s of the chip -- so the job is to read every operand row exactly once (one 256 x 256 tile per
+// workgroup, as above) and to keep two k-tiles of rows in flight per CU.
+// Both operands are K-major in memory ([K][256] rows) while the MFMA wants 8 consecutive k per lane for its m / n: a thread stages
+// the 4 x 4 block (k = 4 wave + j, m = lane + 64 e) of a tile, splits it and writes, per m and plane, the four k as one 8-byte
+// LDS word into a [256 m][16 k] bf16 plane with 48-byte rows (fragment reads: one conflict-free ds_read_b128 per 32 x 16 operand
+// tile and plane; the staging writes are 2-way conflicted).  2 x (2 operands x 3 planes x 12 KB) = 144 KB of LDS, one workgroup per CU.
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gbf16x2 __attribute__((ext_vector_type(2)));
+typedef float gfloatx2 __attribute__((ext_vector_type(2)));
+#ifndef X3_SCHED
+#define X3_SCHED 1
+#endif
+#ifndef X3_DO_MFMA   // (timing-only builds of tools/dbg: which part of a step the kernel waits for)
+#define X3_DO_MFMA 1
+#define X3_DO_STAGE 1
+#define X3_DO_FETCH 1
+#endif
+#ifndef X3_PRODUCTS  // (timing-only: fewer than the six partial products)
+#define X3_PRODUCTS 6
+#endif
+constexpr int XK = 16, X_ROW = 48, X_PLANE = T256 * X_ROW, X_OPND = 3 * X_PLANE, X_BUF = 2 * X_OPND;  // bytes
+__device__ __forceinline__ int x3g_cvt2(float a, float b) {
+    gfloatx2 f;
+    f[0] = a; f[1] = b;
+    return __builtin_bit_cast(int, __builtin_convertvector(f, gbf16x2));  // v_cvt_pk_bf16_f32 (round to nearest even): a in the low half
+}
+__device__ __forceinline__ void x3g_split2(float a, float b, int& hi, int& mid, int& lo) {
+    hi = x3g_cvt2(a, b);
+    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & (int)0xFFFF0000);
+    mid = x3g_cvt2(ra, rb);
+    lo = x3g_cvt2(ra - __builtin_bit_cast(float, mid << 16), rb - __builtin_bit_cast(float, mid & (int)0xFFFF0000));
+}
+// Eight waves, TWO per SIMD (measured with four waves of 128 x 128 each, one per SIMD: the vector / LDS / memory work of a step
+// and its MFMAs add up exactly -- 2.85 ms + 0.67 ms per partial product at K = 537k x 16 products -- a wave's own MFMAs do not
+// hide its other instructions; a second wave on the SIMD does): wave (wr, wc) owns 128 x 64 of the tile (4 x 2 MFMA tiles, 128
+// accumulator registers) and stages the 4 x 2 block (k = 4 (wave & 3) + j, m = lane + 64 (2 (wave >> 2) + e)) of every k-tile.
+__global__ __launch_bounds__(512, 1) void gemm_tn256_x3_grouped_kernel(GroupedArgs gg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsx[];  // 2 x {A planes hi/mid/lo, B planes hi/mid/lo}
+    int gi = 0;
+    while (gi + 1 < gg.n && (int64_t)blockIdx.x >= gg.block_start[gi + 1]) ++gi;
+    const GemmArgs g = gg.g[gi];
+    const int split = (int)((int64_t)blockIdx.x - gg.block_start[gi]);
+    if (split >= g.split_k) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int kb = wave & 3, half = wave >> 2;
+    const int li = lane & 31, lh = lane >> 5;
+    const bool seg2 = split >= g.seg_splits;
+    const float* Ap = seg2 ? g.A2 : g.A;
+    const float* Bp = seg2 ? g.B2 : g.B;
+    const int64_t lda = seg2 ? g.lda2 : g.lda, ldb = seg2 ? g.ldb2 : g.ldb;
+    const int k_begin = (seg2 ? split - g.seg_splits : split) * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int nt = (k_end - k_begin + XK - 1) / XK;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+    // staging registers: two k-tiles in flight (tile u lives in set (u + 1) & 1); [e][j]: column lane + 64 (2 half + e), k row 4 kb + j
+    float ra[2][2][4], rb[2][2][4];
+    int ca[2], cb[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {  // columns behind M / N are read from clamped (in-bounds) addresses: they only meet outputs that are not stored
+        ca[e] = min(lane + 64 * (2 * half + e), (int)g.M - 1);
+        cb[e] = min(lane + 64 * (2 * half + e), g.N - 1);
+    }
+    const bool do_cs = g.colsum != nullptr && !seg2;
+    float cs[2] = {0.f, 0.f};
+    auto fetch = [&](int t, float (&va)[2][4], float (&vb)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kc = min(k_begin + t * XK + 4 * kb + j, k_end - 1);  // wave-uniform row
+            const float* arow = Ap + (int64_t)kc * lda;
+            const float* brow = Bp + (int64_t)kc * ldb;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { va[e][j] = arow[ca[e]]; vb[e][j] = brow[cb[e]]; }
+        }
+    };
+    auto stage = [&](int t, int buf, float (&va)[2][4], float (&vb)[2][4]) __attribute__((always_inline)) {
+        // rows behind k_end are clamped duplicates: zeroed here (both operands: 0 x finite)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool kin = k_begin + t * XK + 4 * kb + j < k_end;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { va[e][j] = kin ? va[e][j] : 0.f; vb[e][j] = kin ? vb[e][j] : 0.f; }
+        }
+        // (always summed, stored only when asked for: a branch here would cut the step's scheduling region in two)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) cs[e] += (va[e][0] + va[e][1]) + (va[e][2] + va[e][3]);
+        unsigned char* base = ldsx + buf * X_BUF;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int h0, m0, l0, h1, m1, l1;
+            x3g_split2(va[e][0], va[e][1], h0, m0, l0);
+            x3g_split2(va[e][2], va[e][3], h1, m1, l1);
+            unsigned char* d = base + (lane + 64 * (2 * half + e)) * X_ROW + kb * 8;
+            *reinterpret_cast<int2*>(d) = make_int2(h0, h1);
+            *reinterpret_cast<int2*>(d + X_PLANE) = make_int2(m0, m1);
+            *reinterpret_cast<int2*>(d + 2 * X_PLANE) = make_int2(l0, l1);
+            x3g_split2(vb[e][0], vb[e][1], h0, m0, l0);
+            x3g_split2(vb[e][2], vb[e][3], h1, m1, l1);
+            d += X_OPND;
+            *reinterpret_cast<int2*>(d) = make_int2(h0, h1);
+            *reinterpret_cast<int2*>(d + X_PLANE) = make_int2(m0, m1);
+            *reinterpret_cast<int2*>(d + 2 * X_PLANE) = make_int2(l0, l1);
+        }
+    };
+    auto multiply = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* abase = ldsx + buf * X_BUF + (wr * 128 + li) * X_ROW + lh * 16;
+        const unsigned char* bbase = ldsx + buf * X_BUF + X_OPND + (wc * 64 + li) * X_ROW + lh * 16;
+        gbf16x8 fa[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[i][p] = *reinterpret_cast<const gbf16x8*>(abase + i * 32 * X_ROW + p * X_PLANE);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            gbf16x8 fb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const gbf16x8*>(bbase + n * 32 * X_ROW + p * X_PLANE);
+            // six partial products, smallest first; consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (X3_PRODUCTS > 5) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[0], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (X3_PRODUCTS > 4) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[2], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (X3_PRODUCTS > 3) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[1], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (X3_PRODUCTS > 2) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[0], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (X3_PRODUCTS > 1) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[1], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[0], acc[i][n], 0, 0, 0);
+        }
+    };
+    // prologue: tile 0 into buffer 0, tiles 1 and 2 in flight
+    fetch(0, ra[0], rb[0]);
+    stage(0, 0, ra[0], rb[0]);
+    fetch(1, ra[0], rb[0]);
+    fetch(2, ra[1], rb[1]);
+    __syncthreads();
+    // step t: multiply tile t (buffer t & 1); split tile t + 1 (register set t & 1) into the other buffer; request tile t + 3 into that set
+    // (measured: the two waves of a SIMD running the halves of a step in OPPOSITE order -- one multiplies while the other splits --
+    //  is slower, 6.27 against 5.66 ms; the time of a step is the SUM of its matrix and its vector / memory work however they are
+    //  arranged, 2.45 ms + 0.67 ms per partial product at 8.6 G rows x columns: the chip is power-bound on this kernel, so an
+    //  arrangement changes nothing and only fewer joules per product would)
+#define X3_STEP(T, S)                                       \
+    {                                                       \
+        if (X3_DO_MFMA) multiply((T) & 1);                  \
+        if (X3_DO_STAGE) stage((T) + 1, ((T) + 1) & 1, ra[S], rb[S]); \
+        if (X3_DO_FETCH) fetch((T) + 3, ra[S], rb[S]);      \
+        lds_barrier();                                      \
+    }
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+        X3_STEP(t, 0)
+        X3_STEP(t + 1, 1)
+    }
+    if (t < nt) X3_STEP(t, 0)
+#undef X3_STEP
+    __syncthreads();
+    if (do_cs) {  // thread (kb, half, lane) summed columns lane + 64 (2 half + e) over its k rows: reduce over the 4 k-row groups
+        float* red = reinterpret_cast<float*>(ldsx);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) red[kb * 256 + lane + 64 * (2 * half + e)] = cs[e];
+        __syncthreads();
+        if (tid < 256) {
+            const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+            if (tid < g.M) g.colsum[(int64_t)split * g.M + tid] = v;
+        }
+    }
+    // partial tile -> workspace.  Lane (li, lh) holds C[wr*128 + i*32 + (r&3) + 8*(r>>2) + 4*lh][wc*64 + n*32 + li].
+    float* Cw = g.C + (int64_t)split * g.split_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = wc * 64 + n * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.M && col < g.N) Cw[(int64_t)row * g.N + col] = acc[i][n][r];
+            }
+        }
+}
+
 // ---- weight gradients of an input block: 256 x (<= 64) outputs, ONE tile per workgroup ------------------------------
 // dW_in = dZ^T X_in with a narrow X_in (the 39 / 33 encoding columns that enter layer 0 of the stage-1 networks,
 // stage1/model/network.py:85-106): HBM-bound -- per k-row 1 KB of dZ against 2 x 256 x 64 MACs -- so the job is to read
@@ -1072,8 +1269,18 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
     return PSN_OK;
 }
 
+static int gemm_tn_grouped_impl(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
+                                int64_t workspace_floats, void* stream, bool x3);
 extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
                                    int64_t workspace_floats, void* stream) {
+    return gemm_tn_grouped_impl(n_items, items, K, split_k, workspace, workspace_floats, stream, false);
+}
+extern "C" int psn_gemm_tn_grouped_x3(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
+                                      int64_t workspace_floats, void* stream) {
+    return gemm_tn_grouped_impl(n_items, items, K, split_k, workspace, workspace_floats, stream, true);
+}
+static int gemm_tn_grouped_impl(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
+                                int64_t workspace_floats, void* stream, bool x3) {
     using namespace psn;
     PSN_CHECK_ARG(items && n_items >= 1 && n_items <= kMaxGroup, "gemm_tn_grouped: n_items=%d (1..%d)", n_items, kMaxGroup);
     PSN_CHECK_ARG(K > 0 && K < (1ll << 31) && workspace, "gemm_tn_grouped: bad K or null workspace");
@@ -1182,7 +1389,8 @@ extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int6
     PSN_CHECK_ARG(blocks < (1ll << 31) && blocks_big < (1ll << 31) && blocks_tall < (1ll << 31), "gemm_tn_grouped: too many blocks");
     hipStream_t st = (hipStream_t)stream;
     if (gb.n > 0) {
-        hipLaunchKernelGGL(gemm_tn256_grouped_kernel, dim3((unsigned)blocks_big), dim3(256), T256_BUF * 2 * sizeof(float), st, gb);
+        if (x3) hipLaunchKernelGGL(gemm_tn256_x3_grouped_kernel, dim3((unsigned)blocks_big), dim3(512), 2 * X_BUF, st, gb);
+        else hipLaunchKernelGGL(gemm_tn256_grouped_kernel, dim3((unsigned)blocks_big), dim3(256), T256_BUF * 2 * sizeof(float), st, gb);
         PSN_CHECK_LAUNCH("gemm_tn_grouped (256 x 256 tiles)");
     }
     if (gt.n > 0) {

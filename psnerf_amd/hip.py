@@ -128,6 +128,7 @@ SIGNATURES = {
     'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, c_f, i64,
                        i32, c_f, c_f, c_f]),
     'psn_gemm_tn_grouped': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
+    'psn_gemm_tn_grouped_x3': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
     'psn_colsum': (i32, [c_f, c_f, i32, i64, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_sample_points': (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f]),
     'psn_sample_points_flagged': (i32, [c_f, c_f, c_f, c_f, c_f, i64, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f]),
@@ -1026,7 +1027,31 @@ def _tn_is_tall(it):
             and _tn_aligned(it['A']) and _tn_aligned(it['B']) and _tn_aligned(it.get('A2')) and _tn_aligned(it.get('B2')))
 
 
-def gemm_tn_grouped(items, split_k=None):
+# EXPERIMENT (BASELINE configs[4] bf16 path): the 256 x 256-tile weight gradients on the bf16 matrix pipe with split operands
+# (psn_gemm_tn_grouped_x3).  Process-wide switch for A/B runs and the labelled bench objects; never on by default.
+WGRAD_X3 = os.environ.get('PSN_WGRAD_X3', '0') == '1'
+
+
+class wgrad_precision(object):
+    """``with hip.wgrad_precision('bf16x6'):`` -- the 256 x 256-tile weight-gradient products issued inside take the split-bf16
+    kernel (psn_gemm_tn_grouped_x3); 'fp32' = the exact kernel.  Wrap the BACKWARD pass (that is where the products are issued)."""
+
+    def __init__(self, mode):
+        assert mode in ('fp32', 'bf16x6'), mode
+        self.mode = mode
+
+    def __enter__(self):
+        global WGRAD_X3
+        self.saved, WGRAD_X3 = WGRAD_X3, self.mode == 'bf16x6'
+        return self
+
+    def __exit__(self, *exc):
+        global WGRAD_X3
+        WGRAD_X3 = self.saved
+        return False
+
+
+def gemm_tn_grouped(items, split_k=None, x3=None):
     """Weight gradients of one backward pass in one launch.  items: list of dicts with A [K,M], B [K,N] (row-major
     views, row stride allowed), optional A2 / B2 (second product summed into the same result), optional out [M,N]
     (+ accumulate=True) and colsum (True -> the column sums of A are returned too).  Returns [(C, colsum or None)].
@@ -1108,9 +1133,10 @@ def gemm_tn_grouped(items, split_k=None):
             keep.append((C, cs))
         ws = workspace(need, dev)
         flops = sum(2.0 * (arr[i].k_rows or K) * arr[i].M * arr[i].N * (2 if chunk[i].get('A2') is not None else 1) for i in range(len(chunk)))
+        use_x3 = WGRAD_X3 if x3 is None else bool(x3)
         with _Prof('gemm_tn_grouped', flops):
-            _check(_lib.psn_gemm_tn_grouped(len(chunk), ctypes.addressof(arr), K, split_k, ws.data_ptr(), ws.numel(), _stream()),
-                   'gemm_tn_grouped')
+            _check((_lib.psn_gemm_tn_grouped_x3 if use_x3 else _lib.psn_gemm_tn_grouped)(
+                len(chunk), ctypes.addressof(arr), K, split_k, ws.data_ptr(), ws.numel(), _stream()), 'gemm_tn_grouped')
         res += keep
     return res
 

@@ -43,6 +43,8 @@ class Trainer(object):
         # training forward without host synchronisation (Renderer._unisurf_sync_free); a caller that injects noise or
         # needs the reference-shaped out_dict (compact diff_norm) gets the reference-shaped path
         self.sync_free = bool(kwargs.get('sync_free', True))
+        # EXPERIMENT (BASELINE configs[4] bf16 path): the 256 x 256 weight gradients on the bf16 matrix pipe with split operands
+        self.wgrad_bf16x6 = bool(cfg.get('wgrad_bf16x6', False))
 
     def train_step(self, data, it=None, pix=None, noise=None):
         self.model.train()
@@ -56,7 +58,8 @@ class Trainer(object):
             self.optimizer.zero_grad()
         terms = self.compute_loss(data, it=it, pix=pix, noise=noise)
         if terms['loss'].requires_grad:
-            terms['loss'].backward()
+            with hip.wgrad_precision('bf16x6' if self.wgrad_bf16x6 else ('bf16x6' if hip.WGRAD_X3 else 'fp32')):
+                terms['loss'].backward()
         if self.dp.enabled:
             self.dp.allreduce_grads(trainable)
         self.optimizer.step()

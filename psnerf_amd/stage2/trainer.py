@@ -106,6 +106,9 @@ class TrainStep(object):
         # DiLiGenT-MV objects set it, the synthetic bunny / armadillo configurations do not: the model then shades with its scalar
         # brdf.light_intensity, renderer.py:202).  The table itself always exists (checkpoint layout); untrained it is a constant
         # that the step never reads.
+        # EXPERIMENT (BASELINE configs[4] bf16 path; off unless the configuration asks): the 256 x 256 weight gradients of the visibility
+        # net on the bf16 matrix pipe with split operands (hip.wgrad_precision; fp32-class results, tests/test_bf16_gpu.py)
+        self.wgrad_bf16x6 = conf.get_bool('train.wgrad_bf16x6', default=False)
         self.light_inten_train = self.light_train and conf.get_bool('train.light_inten_train', default=False)
         if not self.light_train:
             self.light_para.requires_grad_(False)
@@ -258,7 +261,12 @@ class TrainStep(object):
             seed = getattr(self, '_grad_seed', None)
             if seed is None or seed.device != loss.device or seed.shape != loss.shape:
                 seed = self._grad_seed = torch.ones_like(loss)
-            loss.backward(seed)
+            if self.wgrad_bf16x6:
+                from .. import hip
+                with hip.wgrad_precision('bf16x6'):
+                    loss.backward(seed)
+            else:
+                loss.backward(seed)
         # (a rank whose pixel slice has no surface pixel gets constants from the model: its loss has no graph, it skips
         # backward and contributes the zero-filled bucket, so the other ranks never wait for a collective it left out)
         if self.dp.enabled:

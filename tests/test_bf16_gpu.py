@@ -326,3 +326,89 @@ def test_relight_bf16x6_matches_fp32_render(cuda):
     d6 = float((res['bf16x6'] - res['fp32']).abs().max())
     d1 = float((res['bf16'] - res['fp32']).abs().max())
     assert d6 < 5e-6 and d1 > 20 * d6, (d6, d1)
+
+
+@pytest.mark.parametrize('K,M,N,seg2', [(40000, 256, 256, True), (7001, 217, 256, False), (33333, 256, 200, True), (300, 256, 256, False),
+                                        (65536, 129, 131, False)])
+def test_split_bf16_weight_gradient_gemm_has_fp32_class_accuracy(cuda, K, M, N, seg2):
+    """psn_gemm_tn_grouped_x3 (the 256 x 256-tile weight-gradient products dW = dZ^T X (+ U^T dR) of stage1/model/network.py:85-106
+    on the bf16 matrix pipe: three bf16 planes per operand, six partial products, fp32 accumulation) against float64: the error
+    of the exact fp32 kernel on the same operands is the yardstick (the split kernel may not be more than 1.5x worse), and both
+    stay below 2e-6 relative; ragged K (clamped + zeroed tail rows), narrow operands as column slices of 256-wide dumps, the
+    second product segment, the column sums (bias gradients)."""
+    from psnerf_amd import hip
+    g = torch.Generator().manual_seed(K + M)
+    its = []
+    for _ in range(2):
+        it = dict(A=(torch.randn(K, 256, generator=g) * 0.3).to(cuda)[:, :M], B=(torch.randn(K, 256, generator=g).abs() * 0.1).to(cuda)[:, :N], colsum=True)
+        if seg2:
+            it['A2'], it['B2'] = torch.randn(K, 256, generator=g).to(cuda)[:, :M], (torch.randn(K, 256, generator=g) * 0.05).to(cuda)[:, :N]
+        its.append(it)
+    ref = []
+    for it in its:
+        r = it['A'].double().t() @ it['B'].double()
+        if seg2:
+            r = r + it['A2'].double().t() @ it['B2'].double()
+        ref.append((r, it['A'].double().sum(0)))
+    err = {}
+    for name, x3 in (('fp32', False), ('bf16x6', True)):
+        res = hip.gemm_tn_grouped(its, x3=x3)
+        err[name] = (max(float((c.double() - r).abs().max() / r.abs().max()) for (c, _), (r, _) in zip(res, ref)),
+                     max(float((s_.double() - rs).abs().max() / rs.abs().max()) for (_, s_), (_, rs) in zip(res, ref)))
+    assert err['bf16x6'][0] <= max(1.5 * err['fp32'][0], 5e-7) and err['bf16x6'][0] < 2e-6, err
+    assert err['bf16x6'][1] < 2e-6, err
+    with hip.wgrad_precision('bf16x6'):   # the process-wide switch routes the same call
+        res2 = hip.gemm_tn_grouped(its)
+    res = hip.gemm_tn_grouped(its, x3=True)
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(res, res2)) and hip.WGRAD_X3 is False
+
+
+def test_wgrad_bf16x6_passes_the_parameter_gradient_gate(cuda):
+    """The split-bf16 weight-gradient kernel inside the stage-2 step (conf train.wgrad_bf16x6) and the stage-1 step (cfg
+    training.wgrad_bf16x6): every parameter gradient within the 1e-3 bound of the exact path's parity gate against the oracle
+    (stage 2, N = 3000 x V = 8 supervised rows) and within 2e-5 of the exact-fp32 HIP step (stage 1: one full train step from the same
+    weights, draws injected) -- and the switch really changes which kernel runs (some gradient differs in its last bits)."""
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd import hip
+    from oracle import stage2 as o2
+    from tests.helpers import assert_close
+    from tests.test_stage2_gpu import _run
+    sd = stage2_state_dict(o2.bear_conf(), seed=5)   # (the weights of the exact path's gate, test_train_vis_bf16x6_passes_...)
+    onet = o2.PSNetwork(o2.bear_conf())
+    onet.load_state_dict(sd)
+    N, L, V = 3000, 5, 8
+    inp, gt = stage2_inputs(N, L, V, seed=N)
+    ns = int(inp['surface_mask'].sum())
+    nz = torch.randn(ns, 3, generator=torch.Generator().manual_seed(1)) * 0.01
+    _, _, o_g = _run(onet, o2.MainLoss, o2.NormalLoss, inp, gt, 2, nz, 'cpu')
+    grads = {}
+    for mode in ('fp32', 'bf16x6'):
+        net = s2.PSNetwork(s2.bear_conf())
+        net.load_state_dict(sd)
+        net.to(cuda)
+        with hip.wgrad_precision(mode):
+            grads[mode] = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, 2, nz, cuda)[2]
+    for k in o_g:
+        assert_close(grads['bf16x6'][k].cpu(), o_g[k], 1e-3, 'grad ' + k)
+    vis = [k for k in o_g if k.startswith('visibility_net') and k.endswith('weight') and tuple(o_g[k].shape) == (256, 256)]
+    assert vis and any(not torch.equal(grads['bf16x6'][k], grads['fp32'][k]) for k in vis)
+    # stage 1: one train step, exact vs split weight gradients
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.synthetic import stage1_batch
+    from tests.helpers import stage1_cfg, stage1_state_dict
+    res = {}
+    for flag in (False, True):
+        cfg = stage1_cfg('bunny', **{'training.n_training_points': 256, 'training.wgrad_bf16x6': flag})
+        net = NeuralNetwork(cfg)
+        net.load_state_dict(stage1_state_dict(cfg, seed=21))
+        tr = Trainer(Renderer(net, cfg, device=cuda), torch.optim.SGD(net.parameters(), lr=0.0), cfg, device=cuda)
+        assert tr.wgrad_bf16x6 is flag
+        batch = {k: v.to(cuda) for k, v in stage1_batch(cfg, h=48, w=64, seed=4).items()}
+        gen = torch.Generator().manual_seed(5)
+        pix = torch.stack([torch.randint(0, 64, (256,), generator=gen).float(), torch.randint(0, 48, (256,), generator=gen).float()], -1)[None]
+        noise = {'full': torch.rand(256, 64, generator=gen).to(cuda), 'nbr_full': torch.rand(256, 3, generator=gen).to(cuda)}
+        terms = tr.train_step(batch, it=1500, pix=pix, noise=noise)
+        res[flag] = (float(terms['loss'].detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    assert res[True][0] == res[False][0]
+    worst = max(float((res[True][1][k] - res[False][1][k]).abs().max() / res[False][1][k].abs().max().clamp_min(1e-20)) for k in res[False][1])
+    assert 0.0 < worst <= 2e-5, worst

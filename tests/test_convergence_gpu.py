@@ -131,7 +131,16 @@ def _stage2_draws(views, n_steps, seed=6):
     return [torch.randn(int(views[it % len(views)][0]['surface_mask'].sum()), 3, generator=g) * 0.01 for it in range(n_steps)]
 
 
-def test_stage2_300_steps_synchronised_windows(cuda):
+@pytest.fixture(params=['fp32', 'bf16x6'])
+def wgrad(request):
+    """The synchronised-window tests run twice: with the exact fp32 weight-gradient kernel and with the split-bf16 experiment
+    (psn_gemm_tn_grouped_x3 through hip.wgrad_precision) -- the same bounds hold for both."""
+    from psnerf_amd import hip
+    with hip.wgrad_precision(request.param):
+        yield request.param
+
+
+def test_stage2_300_steps_synchronised_windows(cuda, wgrad):
     import psnerf_amd.stage2 as s2
     n_steps, W = int(os.environ.get('PSN_CONVERGENCE_STEPS', 300)), 10
     views, light_init, L, NL = _stage2_scene()
@@ -241,7 +250,7 @@ def test_stage2_300_steps_free_running_within_reference_spread(cuda):
     assert abs(lh[-50:].mean() - tails[0]) <= 0.01 * tails[0] + 2.0 * tail_spread, (lh[-50:].mean(), tails)
 
 
-def test_stage1_200_steps_synchronised_windows(cuda):
+def test_stage1_200_steps_synchronised_windows(cuda, wgrad):
     from oracle import stage1 as o1
     from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
     from psnerf_amd.stage1.rendering import sync_free_noise_for_reference
