@@ -6,7 +6,7 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 from psnerf_amd.synthetic import stage1_cfg, stage1_batch
 from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
-cfg = stage1_cfg('bear', **{'rendering.num_points_in': 96, 'rendering.num_points_out': 32, 'training.n_training_points': 4096})
+cfg = stage1_cfg('bear', **{'rendering.num_points_in': 96, 'rendering.num_points_out': 32, 'training.n_training_points': int(os.environ.get('RAYS', '4096'))})
 batch = stage1_batch(cfg, h=512, w=612, seed=0)
 dev = torch.device('cuda:0')
 torch.manual_seed(42)
