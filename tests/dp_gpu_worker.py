@@ -171,6 +171,68 @@ def _stage1(rank, dev, checks):
         checks['stage1 sync-free param after 2 steps ' + k] = (float((a - b).abs().max().cpu()), 2 * 2 * 1e-4 + 1e-6)
 
 
+def _device_views(rank, dev, checks):
+    """The training loop as tools/run_e2e.py runs it under data parallelism: every rank draws the same index lists (same np.random
+    seed), GATHERS ONLY ITS PIXEL SLICE from the views resident in HBM (handoff.DeviceViews(dp=...), prefetching loader) and steps;
+    rank 0 then runs the same three steps single-rank on the whole batches: first-step gradients (all-reduced) == single-rank
+    gradients, parameters and light tables after three steps within Adam's sign-flip bound."""
+    import numpy as np
+    import torch
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd import dist as pdist
+    from psnerf_amd.handoff import DeviceViews
+    from psnerf_amd.stage2.trainer import VisPlus
+    from psnerf_amd.synthetic import stage2_inputs
+    from tests.helpers import stage2_state_dict
+    from tests.test_next_gpu import _toy_views
+    from oracle import stage2 as o2
+    views, init, imgs, omasks, ldirs, poses, K = _toy_views()
+    for v in views:   # a real camera and surface geometry
+        inp, _ = stage2_inputs(40 * 52, 1, 1, seed=1, h=40, w=52)
+        v['points'], v['normal'] = inp['points'], inp['normal']
+    poses, K = [inp['pose'][0]] * len(views), inp['intrinsics'][0]
+    n_total = sum(l.shape[0] for l in ldirs)
+    conf = s2.bear_conf(**{'train.light_bs': 4, 'train.vis_train_num': 5, 'brdf.net.xyz_jitter_std': 0.0})  # (no jitter: no per-row device draws to slice)
+    sd = stage2_state_dict(o2.bear_conf(), seed=5)
+    order, n_px = [0, 1, 0], 601   # ranks get 301 and 300 pixels
+
+    def loop(dp):
+        net = s2.PSNetwork(conf)
+        net.load_state_dict(sd)
+        net.to(dev)
+        st = s2.TrainStep(net, conf, n_total, torch.cat(init).to(dev), dev, dp=dp)
+        st.cur_iter = 5001
+        store = DeviceViews(views, imgs, omasks, ldirs, poses, K, 4, dev, n_pixels=n_px, dp=dp, vis_plus=VisPlus(views, init, 5, dev))
+        np.random.seed(31)
+        first, n_seen = None, 0
+        for vidx, mi, gt, l_slt in store.loader(order, depth=2):
+            n_seen += mi['uv'].shape[1]
+            st.step(mi, gt, l_slt, train_order=False)
+            if first is None:
+                first = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+                first['__light_dir'] = st.light_para.weight.grad.detach().clone()
+        torch.cuda.synchronize()
+        return net, st, first, n_seen
+
+    dp = pdist.DataParallel(dev)
+    net, st, g_dp, n_seen = loop(dp)
+    lo, hi = dp.slice_bounds(n_px)
+    assert n_seen == len(order) * (hi - lo), (n_seen, lo, hi)   # a rank never assembled more than its slice
+    if rank != 0:
+        return
+    single = pdist.DataParallel(dev)
+    single.enabled, single.world, single.rank = False, 1, 0
+    net1, st1, g_1, n1 = loop(single)
+    assert n1 == len(order) * n_px and sorted(g_dp) == sorted(g_1)
+    for k in g_1:
+        checks['device views: first-step grad ' + k] = (_err(g_dp[k], g_1[k]), TOL_GRAD)
+    for (k, a), (_, b) in zip(net.state_dict().items(), net1.state_dict().items()):
+        d = (a - b).abs()
+        checks['device views: param after 3 steps (max) ' + k] = (float(d.max().cpu()), 3 * 2 * 5e-4 + 1e-6)
+        checks['device views: param after 3 steps (mean) ' + k] = (float(d.mean().cpu()), 3e-5)
+    checks['device views: light table after 3 steps'] = (float((st.light_para.weight - st1.light_para.weight).abs().max().cpu()), 3 * 2 * 5e-4 + 1e-6)
+
+
 def run(rank, port, out_path):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(WORLD))
@@ -187,6 +249,8 @@ def run(rank, port, out_path):
         _stage2(rank, dev, checks)
         dist.barrier()
         _stage1(rank, dev, checks)
+        dist.barrier()
+        _device_views(rank, dev, checks)
         dist.barrier()
     except Exception as e:  # report instead of hanging the peer
         import traceback
