@@ -1,5 +1,5 @@
 """Stage-1 renderer with the reference's ``Renderer`` interface (stage1/model/rendering.py:9-555,
-minus the phong preview, which is out of scope -- SURVEY 2).
+incl. the phong preview).
 
 Kernel mapping: every occupancy query without a graph (ray-march sweep, secant refinement, shadow-ray light
 visibility) goes through the register-resident occupancy engine -- the sweep as one launch over all N x M points, the
@@ -92,7 +92,7 @@ class Renderer(nn.Module):
             return self.shape_extract(pixels, camera_mat, world_mat, scale_mat, it=it, visibility=visibility,
                                       light_dir=light_dir)
         if rendering_technique == 'phong_renderer':
-            raise NotImplementedError('phong_renderer is a visualisation preview (out of scope, SURVEY 2)')
+            return self.phong_renderer(pixels, camera_mat, world_mat, scale_mat)
         raise ValueError('Choose unisurf or shape_extract')
 
     def _u(self, n, dev):
@@ -471,6 +471,27 @@ class Renderer(nn.Module):
                 vis[obj_mask[None].expand_as(vis)] = torch.cat(chunks, dim=0)
             out['visibility'] = vis
         return out
+
+    # ---- stage1/model/rendering.py:228-293 -------------------------------------------------------
+    @torch.no_grad()
+    def phong_renderer(self, pixels, camera_mat, world_mat, scale_mat):
+        """The shaded preview of the current shape (rendering.py:228-293; what training.py:62-118 renders for its image grids):
+        the 512-step march + root finder of shape_extract, unit normals grad / |grad| at the surface points (no epsilon, :282), one
+        light at the camera (:240-241), rgb = min(0.3 + 0.7 max(n . l, 0), 1) on the surface and 1 elsewhere."""
+        B, N, _ = pixels.shape
+        dev = pixels.device
+        self.model.eval()
+        cam, rays, dists, obj_mask, points = self._surface(pixels, camera_mat, world_mat, 512)
+        cam_o = cam.reshape(-1, 3)[0]
+        light = (cam_o / cam_o.norm(2)).unsqueeze(1)
+        rgb = torch.ones(B * N, 3, device=dev)
+        surf = points[obj_mask]
+        if len(surf) > 0:
+            g = torch.cat([self.model.gradient(ps, tflag=False)[:, 0, :] for ps in torch.split(surf, 1000000, dim=0)], 0)
+            n = g / g.norm(2, 1, keepdim=True)
+            diffuse = (n * light[:, 0]).sum(-1, keepdim=True).clamp_min(0).repeat(1, 3) * 0.7   # (a [Ns,3] x [3,1] product without a library GEMM)
+            rgb[obj_mask] = (0.3 + diffuse).clamp_max(1.0)
+        return {'rgb': rgb.reshape(B, -1, 3)}
 
     # ---- stage1/model/rendering.py:378-408 -------------------------------------------------------
     @torch.no_grad()

@@ -117,6 +117,17 @@ def test_shape_extract_vs_reference():
         assert_close(out[k], g[k], 1e-5, k)
 
 
+def test_phong_renderer_vs_reference():
+    """Renderer.phong_renderer (rendering.py:228-293), the third rendering_technique: fixture = the reference's own method."""
+    g = load('stage1_phong.npz')
+    cfg, net, ren = _stage1_renderer()
+    assert state_dict_digest(net.state_dict()) == str(g['sd_digest'])
+    out = ren(T(g['pix']).float(), T(g['K']), T(g['c2w']), torch.eye(4)[None], 'phong_renderer')
+    assert sorted(out) == ['rgb']
+    assert_close(out['rgb'], g['rgb'], 1e-5, 'rgb')
+    assert np.array_equal((out['rgb'].numpy() == 1).all(-1), (g['rgb'] == 1).all(-1))
+
+
 def test_arange_pixels_is_x_major_int64():
     p = o1.arange_pixels((3, 4))
     assert p.dtype == torch.int64 and p.shape == (1, 12, 2)

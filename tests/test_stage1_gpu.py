@@ -370,6 +370,20 @@ def test_shape_extract_golden(cuda):
     assert_close(out['visibility'].cpu(), g['visibility'], 1e-4, 'visibility', atol=ATOL_UNIT)
 
 
+def test_phong_renderer_golden(cuda):
+    """Renderer.forward(..., 'phong_renderer') (rendering.py:228-293: the third rendering_technique, the shaded preview of
+    training.py:62-118) against the reference's own method (tests/golden/stage1_phong.npz): background pixels exactly 1, surface
+    pixels 0.3 + 0.7 max(n . l, 0) with the normal of a root-found point (its floor: ATOL_NORMAL x 0.7)."""
+    g = np.load(os.path.join(GOLDEN, 'stage1_phong.npz'))
+    cfg, net, ren = _renderer(cuda)
+    assert state_dict_digest(stage1_state_dict(cfg, seed=11)) == str(g['sd_digest'])
+    out = ren(T(g['pix'], cuda).float(), T(g['K'], cuda), T(g['c2w'], cuda), torch.eye(4, device=cuda)[None], 'phong_renderer')
+    assert sorted(out) == ['rgb'] and out['rgb'].shape == g['rgb'].shape
+    bg = (g['rgb'] == 1).all(-1)
+    assert np.array_equal((out['rgb'].cpu().numpy() == 1).all(-1), bg) and 10 < int((~bg).sum()) < 200
+    assert_close(out['rgb'].cpu(), g['rgb'], 1e-4, 'rgb', atol=ATOL_NORMAL)
+
+
 @pytest.mark.parametrize('tag', sorted(COMPUTE_LOSS_CASES))
 def test_compute_loss_golden(cuda, tag):
     """Trainer.compute_loss against the reference's OWN Trainer (tests/golden/stage1_compute_loss.npz): training mode with

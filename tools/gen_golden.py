@@ -245,6 +245,15 @@ def gen_stage1():
     assert torch.equal(se_r['mask'], se_o['mask']) and 10 < int(se_r['mask'].sum()) < 200
     for k in ('normal', 'points', 'visibility'):
         check('shape_extract %s' % k, se_o[k], se_r[k], 5e-6)
+    # --- Renderer.phong_renderer (rendering.py:228-293): the shaded preview of training.py:62-118, the third value of
+    #     rendering_technique -- same 200-pixel chunk, the reference's own method
+    with torch.no_grad():
+        ph_r = rren(chunk.float(), Ks, c2ws, Ss, 'phong_renderer')
+    ph_o = oren(chunk.float(), Ks, c2ws, Ss, 'phong_renderer')
+    assert 10 < int((ph_r['rgb'] < 1).all(-1).sum()) < 200
+    check('phong rgb', ph_o['rgb'], ph_r['rgb'], 5e-6)
+    np.savez_compressed(os.path.join(GOLDEN, 'stage1_phong.npz'), sd_digest=state_dict_digest(sd), hw=np.array([hs, ws]),
+                        pix=np_(chunk), K=np_(Ks), c2w=np_(c2ws), rgb=np_(ph_r['rgb']))
     rnet.train(); onet.train()  # shape_extract leaves the model in eval mode (rendering.py:311); no effect on these modules
     np.savez_compressed(os.path.join(GOLDEN, 'stage1_shape_extract.npz'), sd_digest=state_dict_digest(sd), hw=np.array([hs, ws]),
                         pix=np_(chunk), K=np_(Ks), c2w=np_(c2ws), ldir=np_(ldir_s), mask=np_(se_r['mask']),
