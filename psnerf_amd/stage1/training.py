@@ -72,6 +72,59 @@ class Trainer(object):
             net.prepack(occupancy=True)  # the next step's ray march starts with this pack: queue it behind the backward
         return terms
 
+    @torch.no_grad()
+    def render_visdata(self, data_loader, it, out_render_path, chunk=65536):
+        """The periodic image grid of stage1/train.py (stage1/model/training.py:62-118): for the first two items of ``data_loader``
+        the panels [input image | rendered rgb | predicted normal (camera frame, /2 + 0.5) | (with a normal map: its normals | the
+        angular error / 45 deg through the 'jet' colour map on mask | mask_pred) | mask_pred | acc | phong preview] side by side, items
+        stacked vertically, written as an RGB image to ``out_render_path`` (PIL) and returned as a uint8 array [H, W, 3].
+        Whole images are rendered through 'unisurf' (eval_) and 'phong_renderer' on the int64 x-major pixel grid in chunks of
+        ``chunk`` pixels (the reference: 1024; per-pixel results do not depend on the chunking)."""
+        from ..handoff import arange_pixels, to_hw
+        from ..metrics import MAE
+        to_img = lambda x: (np.asarray(x).astype(np.float32).clip(0, 1) * 255).astype(np.uint8)
+        to_np = lambda x: x.detach().cpu().numpy()
+        self.model.eval()
+        rows = []
+        for di, data in enumerate(data_loader):
+            if di >= 2:
+                break
+            (img, mask, world_mat, camera_mat, scale_mat, img_idx, normal, norm_mask, mask_valid) = self.process_data_dict(data)
+            h, w = img.shape[-2:]
+            ploc = arange_pixels(h, w, self.device)
+            panels = [to_img(to_np(img))[0].transpose(1, 2, 0)]
+            outs = [self.model(px, camera_mat, world_mat, scale_mat, 'unisurf', add_noise=False, eval_=True, it=it)
+                    for px in torch.split(ploc, int(chunk), dim=1)]
+            rgb_pred = to_np(to_hw(torch.cat([o['rgb'] for o in outs], dim=1), h, w))
+            panels.append(to_img(rgb_pred))
+            mask_pred = to_np(to_hw(torch.cat([o['mask_pred'] for o in outs], dim=0), h, w)).repeat(3, axis=-1)
+            norm_pred = to_np(to_hw(torch.cat([o['normal_pred'] for o in outs], dim=1), h, w))
+            norm_pred = np.einsum('ij,hwi->hwj', to_np(world_mat)[0, :3, :3] * np.array([[1, -1, -1]]), norm_pred)   # training.py:92
+            panels.append(to_img(norm_pred / 2. + 0.5))
+            if normal is not None:
+                n_gt = to_np(normal[0].permute(1, 2, 0))
+                panels.append(to_img(n_gt / 2. + 0.5))
+                error = MAE(norm_pred, n_gt.clip(-1, 1))[1] / 45
+                try:
+                    import matplotlib.pyplot as plt
+                    cm = plt.get_cmap('jet')
+                except Exception:  # noqa: BLE001  (matplotlib is the reference's dependency for this one panel: grey levels without it)
+                    cm = lambda e: np.repeat(np.asarray(e)[..., None], 4, axis=-1)
+                panels.append(to_img(cm(error.clip(0, 1) * (to_np(mask.bool())[0, 0] | mask_pred[..., 0]))[..., :3]))
+            panels.append(to_img(mask_pred))
+            mask_acc = to_np(to_hw(torch.cat([o['acc_map'] for o in outs], dim=1), h, w)).repeat(3, axis=-1)
+            panels.append(to_img(mask_acc))
+            phong = torch.cat([self.model(px, camera_mat, world_mat, scale_mat, 'phong_renderer', add_noise=False, eval_=True, it=it)['rgb']
+                               for px in torch.split(ploc, int(chunk), dim=1)], dim=1)
+            panels.append(to_img(to_np(to_hw(phong, h, w))))
+            rows.append(np.concatenate(panels, axis=-2))
+        grid = np.concatenate(rows, axis=0).astype(np.uint8)
+        if out_render_path is not None:
+            from PIL import Image
+            Image.fromarray(grid).convert('RGB').save(out_render_path)
+        self.model.train()
+        return grid
+
     def process_data_dict(self, data):
         """stage1/model/training.py:120-139: the tensors of a data-loader item on the trainer's device, in the reference's
         order (img, mask_img, world_mat, camera_mat, scale_mat, img_idx, normal, norm_mask, mask_valid); absent masks are

@@ -384,6 +384,31 @@ def test_phong_renderer_golden(cuda):
     assert_close(out['rgb'].cpu(), g['rgb'], 1e-4, 'rgb', atol=ATOL_NORMAL)
 
 
+def test_render_visdata_golden(cuda, tmp_path):
+    """Trainer.render_visdata (stage1/model/training.py:62-118: the periodic image grid -- input | rgb | normal | normal map | angular
+    error | mask | acc | phong preview, two items) against the image the reference's OWN method wrote (tests/golden/
+    stage1_visdata.npz; uint8): rendered in ONE chunk here against the reference's 1024-pixel chunks.  A quantised 8-bit panel can
+    differ by one level where a value sits on a rounding edge, and a silhouette pixel may flip: >= 99 % of the values within one
+    level, mean absolute difference < 0.5 levels; the file is written and holds the returned array."""
+    from PIL import Image
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.synthetic import stage1_batch
+    g = np.load(os.path.join(GOLDEN, 'stage1_visdata.npz'))
+    cfg, net, ren = _renderer(cuda)
+    assert state_dict_digest(stage1_state_dict(cfg, seed=11)) == str(g['sd_digest'])
+    hv, wv = (int(v) for v in g['hw'])
+    items = [stage1_batch(cfg, h=hv, w=wv, seed=int(s_)) for s_ in g['seeds']]
+    tr = Trainer(ren, None, cfg, device=cuda)
+    out = tmp_path / 'vis.png'
+    grid = tr.render_visdata(items, int(g['it']), str(out))
+    assert grid.dtype == np.uint8 and grid.shape == g['grid'].shape == (2 * hv, 8 * wv, 3)
+    assert np.array_equal(np.array(Image.open(str(out))), grid)
+    d = np.abs(grid.astype(np.int32) - g['grid'].astype(np.int32))
+    assert float((d <= 1).mean()) >= 0.99 and float(d.mean()) < 0.5, (float((d <= 1).mean()), float(d.mean()), int(d.max()))
+    assert np.array_equal(grid[:, :wv], g['grid'][:, :wv])   # the input-image panel is data: exact
+    assert net.training   # render_visdata leaves the model in training mode (training.py:117)
+
+
 @pytest.mark.parametrize('tag', sorted(COMPUTE_LOSS_CASES))
 def test_compute_loss_golden(cuda, tag):
     """Trainer.compute_loss against the reference's OWN Trainer (tests/golden/stage1_compute_loss.npz): training mode with

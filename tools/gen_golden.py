@@ -254,6 +254,20 @@ def gen_stage1():
     check('phong rgb', ph_o['rgb'], ph_r['rgb'], 5e-6)
     np.savez_compressed(os.path.join(GOLDEN, 'stage1_phong.npz'), sd_digest=state_dict_digest(sd), hw=np.array([hs, ws]),
                         pix=np_(chunk), K=np_(Ks), c2w=np_(c2ws), rgb=np_(ph_r['rgb']))
+    # --- Trainer.render_visdata (training.py:62-118): the periodic image grid of stage1/train.py -- the reference's OWN method on two
+    #     small synthetic items (unisurf eval + phong preview over whole images in its 1024-pixel chunks, PIL output read back)
+    import tempfile
+    from PIL import Image
+    hv_, wv_ = 20, 24
+    vis_items = [stage1_batch(cfg, h=hv_, w=wv_, seed=s_) for s_ in (31, 32)]
+    rtr_v = rmdl.Trainer(rren, None, cfg, device=torch.device('cpu'))
+    png = os.path.join(tempfile.mkdtemp(), 'vis.png')
+    rtr_v.render_visdata(vis_items, 1500, png)
+    grid_ref = np.array(Image.open(png))
+    assert grid_ref.shape == (2 * hv_, 8 * wv_, 3) and grid_ref.dtype == np.uint8   # 8 panels per item (a normal map is present)
+    np.savez_compressed(os.path.join(GOLDEN, 'stage1_visdata.npz'), sd_digest=state_dict_digest(sd), hw=np.array([hv_, wv_]),
+                        seeds=np.array([31, 32]), it=1500, grid=grid_ref)
+    rnet.train(); onet.train()
     rnet.train(); onet.train()  # shape_extract leaves the model in eval mode (rendering.py:311); no effect on these modules
     np.savez_compressed(os.path.join(GOLDEN, 'stage1_shape_extract.npz'), sd_digest=state_dict_digest(sd), hw=np.array([hs, ws]),
                         pix=np_(chunk), K=np_(Ks), c2w=np_(c2ws), ldir=np_(ldir_s), mask=np_(se_r['mask']),
