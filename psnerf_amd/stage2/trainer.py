@@ -301,3 +301,36 @@ def psnr(img1, img2, mask=None):
         img1, img2 = torch.masked_select(img1, m).view(-1, 3), torch.masked_select(img2, m).view(-1, 3)
     mse = ((img1 - img2) ** 2).mean()
     return 100.0 if mse == 0 else float(-10.0 * torch.log10(mse))
+
+
+def mae_error(img1, img2, mask=None, normalize=True):
+    """stage2/trainer.py:257-266: mean angular error in degrees between two normal sets [N,3] (masked), and the per-pixel errors."""
+    if mask is not None:
+        m = mask.to(torch.bool)[:, None]
+        img1, img2 = torch.masked_select(img1, m).view(-1, 3), torch.masked_select(img2, m).view(-1, 3)
+    if normalize:
+        img1, img2 = F.normalize(img1, dim=-1), F.normalize(img2, dim=-1)
+    err = torch.acos((img1 * img2).sum(-1).clamp(-1, 1)) * 180.0 / np.pi
+    return err.mean(), err
+
+
+@torch.no_grad()
+def validate_view(model, model_input, rgb_gt, pixel_chunk=None):
+    """The validation half of TrainRunner.plot_to_disk (stage2/trainer.py:278-326; the plotting half, utils/plots.py, is file output):
+    one view under ONE light rendered whole (``pixel_chunk`` None; the reference: 1024-pixel chunks through split_input /
+    merge_output) -> {'psnr': PSNR of sg_rgb_values over network_object_mask & object_mask (:312-313), 'normal_MAE' and the
+    'normal_mae' error map when the model has a normal net and the input carries 'gt_normal' (:315-320), 'outputs': the merged
+    model outputs}.  ``rgb_gt`` [N, 3] (the picked light's image), ``model_input['light_direction']`` [1, 3]."""
+    from .relight import merge_output, split_input
+    n = model_input['uv'].shape[1]
+    chunks = [model_input] if pixel_chunk is None else split_input(model_input, n, pixel_chunk)
+    res = [{k: v.detach() for k, v in model(s).items() if torch.is_tensor(v)} for s in chunks]
+    out = merge_output(res, n, 1) if len(res) > 1 else {k: (v.reshape(-1) if v.dim() < 3 else v.reshape(-1, v.shape[-1])) for k, v in res[0].items()}
+    mask = torch.logical_and(out['network_object_mask'], out['object_mask'])
+    rep = {'psnr': psnr(rgb_gt.to(out['sg_rgb_values'].device), out['sg_rgb_values'], mask), 'outputs': out}
+    if 'normal_pred' in out and 'gt_normal' in model_input:
+        mae, err = mae_error(model_input['gt_normal'][0], out['normal_pred'], mask)
+        emap = torch.zeros_like(out['normal_pred'][..., 0])
+        emap[mask] = err
+        rep['normal_MAE'], rep['normal_mae'] = float(mae), emap
+    return rep

@@ -333,3 +333,36 @@ def test_render_view_vs_reference_pieces(cuda, edit):
         for k in ('normal', 'albedo'):
             assert_close(maps[k].reshape(hv, wv, 3).cpu(), g[tag + k], 1e-4, k, atol=ATOL_UNIT)
         assert np.array_equal(maps['mask'].reshape(hv, wv).cpu().numpy(), g[tag + 'mask'].astype(bool))
+
+
+def test_validate_view_vs_oracle(cuda):
+    """stage2.trainer.validate_view = the validation half of TrainRunner.plot_to_disk (stage2/trainer.py:257-326): PSNR over the
+    masked pixels and the normal MAE of one view under one light, whole image and in 1024-pixel chunks, against the same formulas on
+    the oracle's outputs."""
+    import math
+    import psnerf_amd.stage2 as s2
+    from psnerf_amd.stage2.trainer import validate_view
+    from oracle import stage2 as o2
+    conf = o2.bear_conf(**{'brdf.net.xyz_jitter_std': 0})
+    sd = stage2_state_dict(conf, seed=12)
+    onet = o2.PSNetwork(conf)
+    onet.load_state_dict(sd)
+    onet.eval()
+    net = s2.PSNetwork(s2.bear_conf(**{'brdf.net.xyz_jitter_std': 0}))
+    net.load_state_dict(sd)
+    net.to(cuda).eval()
+    N = 2300
+    inp, gt = stage2_inputs(N, 1, 1, seed=9)
+    inp = {k: v for k, v in inp.items() if k not in ('light_vis_train', 'vis_train_gt', 'light_intensity')}
+    inp['gt_normal'] = torch.nn.functional.normalize(torch.randn(1, N, 3, generator=torch.Generator().manual_seed(2)), dim=-1)
+    with torch.no_grad():
+        oo = onet(inp)
+    m = (oo['network_object_mask'] & oo['object_mask'])[0]
+    mse = float(((oo['sg_rgb_values'][0][m] - gt['rgb'][0][m]) ** 2).mean())
+    cosn = (torch.nn.functional.normalize(oo['normal_pred'][0][m], dim=-1) * inp['gt_normal'][0][m]).sum(-1).clamp(-1, 1)
+    want_psnr, want_mae = -10.0 * math.log10(mse), float(torch.rad2deg(torch.acos(cosn)).mean())
+    inp_d = {k: v.to(cuda) for k, v in inp.items()}
+    for chunk in (None, 1024):
+        rep = validate_view(net, inp_d, gt['rgb'][0].to(cuda), pixel_chunk=chunk)
+        assert abs(rep['psnr'] - want_psnr) < 1e-3 and abs(rep['normal_MAE'] - want_mae) < 2e-3, (rep['psnr'], want_psnr, rep['normal_MAE'], want_mae)
+        assert rep['normal_mae'].shape == (N,) and float(rep['normal_mae'][~m.to(cuda)].abs().max()) == 0.0
