@@ -473,6 +473,7 @@ class _Prefetcher(object):
             self.free.put(k)
         self.current = None
         self.error = None
+        self.stop = False
         self.consumer_wait = 0.0
         self.thread = threading.Thread(target=self._work, daemon=True)
         self.thread.start()
@@ -481,11 +482,20 @@ class _Prefetcher(object):
         st = self.store
         try:
             torch.cuda.set_device(st.device)   # a new thread starts on device 0
+            import queue
+
+            def blocking(fn, *a):   # a queue operation that gives up when the consumer has closed the loader
+                while not self.stop:
+                    try:
+                        return fn(*a, timeout=0.2)
+                    except (queue.Empty, queue.Full):
+                        continue
+                raise StopIteration
             for idx in self.order:
-                d = st.draw(idx)
-                k = self.free.get()
-                if k is None:
+                if self.stop:
                     return
+                d = st.draw(idx)
+                k = blocking(self.free.get)
                 n_all = st.total_pixels if d.pix is None else int(d.pix.shape[0])
                 lo, hi = (0, n_all) if (st.dp is None or not st.dp.enabled) else st.dp.slice_bounds(n_all)
                 L, V = int(d.lidx.shape[0]), (0 if d.vis_rows is None else int(d.vis_rows.shape[0]))
@@ -498,11 +508,16 @@ class _Prefetcher(object):
                     item = st.assemble(d, out=self.slots[k][1])
                     ev = torch.cuda.Event()
                     ev.record(self.side)
-                self.ready.put((k, ev, item))
-            self.ready.put(None)
+                blocking(self.ready.put, (k, ev, item))
+            blocking(self.ready.put, None)
+        except StopIteration:
+            return
         except BaseException as e:  # noqa: BLE001 (handed to the consumer)
             self.error = e
-            self.ready.put(None)
+            try:
+                self.ready.put(None, timeout=1.0)
+            except Exception:  # noqa: BLE001
+                pass
 
     def __iter__(self):
         return self
@@ -528,4 +543,9 @@ class _Prefetcher(object):
         return item
 
     def close(self):
-        self.free.put(None)
+        """Stop the worker (a consumer that leaves the loop early: the draws made ahead are lost -- re-seed to resume in step)."""
+        self.stop = True
+        self.thread.join(timeout=5.0)
+
+    def __del__(self):
+        self.stop = True

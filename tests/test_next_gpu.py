@@ -238,6 +238,11 @@ def test_device_views_batch_equals_the_host_sampler_bit_for_bit(cuda, u8, n_pixe
     for b, item in zip(want, store.loader(order, depth=2)):
         torch.cuda.synchronize()
         _same_batch(item, b)
+    # a consumer that leaves early stops the worker thread (it would otherwise wait for a free slot for ever)
+    early = store.loader(order * 20, depth=2)
+    next(early)
+    early.close()
+    assert not early.thread.is_alive()
 
 
 @pytest.mark.parametrize('world', [2, 8])
