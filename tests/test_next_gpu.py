@@ -371,3 +371,25 @@ def test_validate_view_vs_oracle(cuda):
         rep = validate_view(net, inp_d, gt['rgb'][0].to(cuda), pixel_chunk=chunk)
         assert abs(rep['psnr'] - want_psnr) < 1e-3 and abs(rep['normal_MAE'] - want_mae) < 2e-3, (rep['psnr'], want_psnr, rep['normal_MAE'], want_mae)
         assert rep['normal_mae'].shape == (N,) and float(rep['normal_mae'][~m.to(cuda)].abs().max()) == 0.0
+
+
+def test_device_views_decodes_16_bit_images_like_the_reference(cuda):
+    """16-bit PNGs (imageio gives uint16; stage2/datasets/dataset.py:121 divides by 255. all the same: values up to 257): DeviceViews
+    keeps the uint16 planes resident and decodes through the 65536-entry (float32) k / 255. table -- the batch equals the host sampler's
+    on the float images bit for bit."""
+    from psnerf_amd.handoff import DeviceViews, ViewSampler
+    views, init, imgs, omasks, ldirs, poses, K = _toy_views()
+    g = torch.Generator().manual_seed(9)
+    k16 = [torch.randint(0, 65536, tuple(i.shape), generator=g).to(torch.int32) for i in imgs]
+    imgs_f = [torch.from_numpy(k.numpy().astype(np.float32) / 255.) for k in k16]
+    imgs_u16 = [torch.from_numpy(k.numpy().astype(np.uint16)) for k in k16]
+    host = ViewSampler(views, imgs_f, omasks, ldirs, poses, K, light_bs=4, n_pixels=500)
+    store = DeviceViews(views, imgs_u16, omasks, ldirs, poses, K, light_bs=4, device=cuda, n_pixels=500)
+    assert store.tables[0]['images'].dtype == torch.uint16 and store.tables[0]['lut'].numel() == 65536
+    np.random.seed(3)
+    want = [host.batch(v, device=cuda) for v in (1, 0)]
+    np.random.seed(3)
+    got = [store.batch(v) for v in (1, 0)]
+    for a, b in zip(got, want):
+        _same_batch(a, b)
+    assert float(got[0][2]['rgb'].max()) > 200.0   # (values / 255 of a 16-bit image, not clipped)
