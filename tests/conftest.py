@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 DP_RESULT = os.path.join(ROOT, 'gpurun_out', 'dp_gpu_result.json')
 NCCL_RESULT = os.path.join(ROOT, 'gpurun_out', 'nccl_gpu_result.json')
 BENCH2_RESULT = os.path.join(ROOT, 'gpurun_out', 'bench2_gpu_result.json')
+E2E2_RESULT = os.path.join(ROOT, 'gpurun_out', 'e2e2_gpu_result.json')
 # one stamp per pytest process, whichever module instance of this file asks (pytest may import it under two names)
 SESSION_STAMP = os.environ.setdefault('PSN_TEST_SESSION', '%d-%d' % (os.getpid(), int(__import__('time').time())))
 
@@ -30,7 +31,7 @@ def pytest_collection_modifyitems(session, config, items):
     if config.getoption('collectonly'):
         return
     jobs = [(res, worker) for key, res, worker in (('test_dp_gpu', DP_RESULT, 'dp_gpu_worker.py'), ('test_nccl_gpu', NCCL_RESULT, 'nccl_gpu_worker.py'),
-                                   ('test_bench_multirank_gpu', BENCH2_RESULT, 'bench2_gpu_worker.py'))
+                                   ('test_bench_multirank_gpu', BENCH2_RESULT, 'bench2_gpu_worker.py'), ('test_e2e_dp_gpu', E2E2_RESULT, 'e2e2_gpu_worker.py'))
             if any(key in it.nodeid for it in items)]
     if not jobs:
         return

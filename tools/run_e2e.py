@@ -80,6 +80,8 @@ def main():
                     help='second stage-2 leg at the shipped shapes (light_bs 10, all in-mask pixels): iterations run with the REAL train_fix '
                          'schedule from iteration 0 (>= 5000 to cross the switch); 0 = skip')
     ap.add_argument('--json-out', default=None, help='also write the JSON line to this file')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend under torchrun (default nccl = RCCL; gloo for dry runs on one GPU)')
+    ap.add_argument('--single-device', action='store_true', help='dry run: every rank uses cuda:0')
     ap.add_argument('--occ-precision', choices=('fp32', 'bf16x6'), default='fp32',
                     help="gradient-free occupancy queries of shape_extract (ray march sweep, shadow rays): 'bf16x6' = the opt-in "
                          'split-bf16 engine; the hand-off is then ALSO extracted with the exact engine and compared')
@@ -104,7 +106,9 @@ def main():
     from psnerf_amd.stage2 import relight
     from psnerf_amd.stage2.trainer import VisPlus
 
-    rank, local, world = pdist.init_from_env()
+    rank, local, world = pdist.init_from_env(backend=args.backend, set_device=not args.single_device)
+    if args.single_device:
+        local = 0
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     torch.manual_seed(42)
@@ -151,7 +155,10 @@ def main():
         s1_losses.append(terms['loss'].detach().clone())   # (read after the loop: no host synchronisation per step)
     torch.cuda.synchronize()
     t_s1 = time.time() - t0
-    s1_losses = [float(x) for x in torch.stack(s1_losses).cpu()]
+    s1_hist = torch.stack(s1_losses)
+    if world > 1:   # a rank's loss is ITS share (local sums over the global denominators): the job's loss is the sum over ranks
+        torch.distributed.all_reduce(s1_hist)
+    s1_losses = [float(x) for x in s1_hist.cpu()]
     assert all(np.isfinite(s1_losses)), s1_losses
     k = max(2, args.s1_steps // 5)
     assert np.mean(s1_losses[-k:]) < np.mean(s1_losses[:k]), ('stage-1 loss did not decrease', s1_losses[:k], s1_losses[-k:])
@@ -241,7 +248,13 @@ def main():
         runner = step
         if args.graph:
             from psnerf_amd.stage2.graph import GraphedTrainStep
-            runner = GraphedTrainStep(step, warmup=2, pad_to_pixels=True)
+            agree = None
+            if step.dp.enabled:   # every rank replays or every rank raises (a capture that fails on one rank must not strand the others)
+                def agree(ok):
+                    t = torch.tensor([1 if ok else 0], device=dev)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+                    return bool(t.item())
+            runner = GraphedTrainStep(step, warmup=2, pad_to_pixels=True, agree=agree)
         order = [it % args.views for it in range(n_steps)]
         if on_device:
             store = handoff.DeviceViews(views, images, omasks, lights, poses, K[0], light_bs, dev, n_pixels=n_pixels, dp=step.dp, vis_plus=vp)
@@ -291,7 +304,10 @@ def main():
             runner.step(mi, gt, l_slt, train_order=True)
         torch.cuda.synchronize()
         resident = k_res / (time.time() - t0)
-        losses = [float(x) for x in torch.stack(hist).cpu()]
+        hist_t = torch.stack(hist)
+        if step.dp.enabled:   # (a rank's loss is its share of the global loss)
+            torch.distributed.all_reduce(hist_t)
+        losses = [float(x) for x in hist_t.cpu()]
         assert all(np.isfinite(losses)), losses[:10]
         sw = switch if not real_schedule else min(5000, n_steps)
         k = max(2, min(sw, n_steps - sw if n_steps > sw else sw) // 4)
