@@ -131,6 +131,10 @@ typedef struct {
 } PsnGemmTnItem;
 int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
                         int64_t workspace_floats, void* stream);
+/* Partial products per multiply of the psn_gemm_tn_grouped_x3 launches that follow: 6 (default; three bf16 pieces per operand,
+ * fp32-class), 3 (two pieces: hi hi + hi mid + mid hi, ~16 significant bits) or 1 (plain bf16 operands, fp32 accumulation -- the
+ * "bf16 MFMA path" of BASELINE configs[4] in its literal sense).  Process-wide; returns the previous value. */
+int psn_gemm_tn_x3_set_products(int n_products);
 /* psn_gemm_tn_grouped with the 256 x 256-tile products (128 < M, N <= 256: the hidden-layer weight gradients of
  * stage1/model/network.py:85-106 and of the stage-2 visibility net) evaluated on the bf16 matrix pipe with split operands --
  * every fp32 element as three bf16 pieces, six partial products per multiply, fp32 accumulation ("bf16x6"): fp32-class results,

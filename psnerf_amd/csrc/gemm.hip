@@ -669,9 +669,6 @@ typedef float gfloatx2 __attribute__((ext_vector_type(2)));
 #define X3_DO_STAGE 1
 #define X3_DO_FETCH 1
 #endif
-#ifndef X3_PRODUCTS  // (timing-only: fewer than the six partial products)
-#define X3_PRODUCTS 6
-#endif
 constexpr int XK = 16, X_ROW = 48, X_PLANE = T256 * X_ROW, X_OPND = 3 * X_PLANE, X_BUF = 2 * X_OPND;  // bytes
 __device__ __forceinline__ int x3g_cvt2(float a, float b) {
     gfloatx2 f;
@@ -688,7 +685,11 @@ __device__ __forceinline__ void x3g_split2(float a, float b, int& hi, int& mid, 
 // and its MFMAs add up exactly -- 2.85 ms + 0.67 ms per partial product at K = 537k x 16 products -- a wave's own MFMAs do not
 // hide its other instructions; a second wave on the SIMD does): wave (wr, wc) owns 128 x 64 of the tile (4 x 2 MFMA tiles, 128
 // accumulator registers) and stages the 4 x 2 block (k = 4 (wave & 3) + j, m = lane + 64 (2 (wave >> 2) + e)) of every k-tile.
+// NP = partial products per multiply: 6 (three pieces per operand: fp32-class), 3 (two pieces: hi hi + hi mid + mid hi, ~16 significant
+// bits) or 1 (plain bf16 operands, fp32 accumulation).  Pieces that no product reads are neither formed nor written.
+template <int NP>
 __global__ __launch_bounds__(512, 1) void gemm_tn256_x3_grouped_kernel(GroupedArgs gg) {
+    constexpr int NPL = NP == 6 ? 3 : NP == 3 ? 2 : 1;  // planes per operand
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsx[];  // 2 x {A planes hi/mid/lo, B planes hi/mid/lo}
     int gi = 0;
     while (gi + 1 < gg.n && (int64_t)blockIdx.x >= gg.block_start[gi + 1]) ++gi;
@@ -754,40 +755,44 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_x3_grouped_kernel(GroupedAr
             x3g_split2(va[e][2], va[e][3], h1, m1, l1);
             unsigned char* d = base + (lane + 64 * (2 * half + e)) * X_ROW + kb * 8;
             *reinterpret_cast<int2*>(d) = make_int2(h0, h1);
-            *reinterpret_cast<int2*>(d + X_PLANE) = make_int2(m0, m1);
-            *reinterpret_cast<int2*>(d + 2 * X_PLANE) = make_int2(l0, l1);
+            if constexpr (NPL >= 2) *reinterpret_cast<int2*>(d + X_PLANE) = make_int2(m0, m1);
+            if constexpr (NPL >= 3) *reinterpret_cast<int2*>(d + 2 * X_PLANE) = make_int2(l0, l1);
             x3g_split2(vb[e][0], vb[e][1], h0, m0, l0);
             x3g_split2(vb[e][2], vb[e][3], h1, m1, l1);
             d += X_OPND;
             *reinterpret_cast<int2*>(d) = make_int2(h0, h1);
-            *reinterpret_cast<int2*>(d + X_PLANE) = make_int2(m0, m1);
-            *reinterpret_cast<int2*>(d + 2 * X_PLANE) = make_int2(l0, l1);
+            if constexpr (NPL >= 2) *reinterpret_cast<int2*>(d + X_PLANE) = make_int2(m0, m1);
+            if constexpr (NPL >= 3) *reinterpret_cast<int2*>(d + 2 * X_PLANE) = make_int2(l0, l1);
         }
     };
     auto multiply = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* abase = ldsx + buf * X_BUF + (wr * 128 + li) * X_ROW + lh * 16;
         const unsigned char* bbase = ldsx + buf * X_BUF + X_OPND + (wc * 64 + li) * X_ROW + lh * 16;
-        gbf16x8 fa[4][3];
+        gbf16x8 fa[4][NPL];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) fa[i][p] = *reinterpret_cast<const gbf16x8*>(abase + i * 32 * X_ROW + p * X_PLANE);
+            for (int p = 0; p < NPL; ++p) fa[i][p] = *reinterpret_cast<const gbf16x8*>(abase + i * 32 * X_ROW + p * X_PLANE);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            gbf16x8 fb[3];
+            gbf16x8 fb[NPL];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const gbf16x8*>(bbase + n * 32 * X_ROW + p * X_PLANE);
-            // six partial products, smallest first; consecutive MFMAs go to different accumulators
+            for (int p = 0; p < NPL; ++p) fb[p] = *reinterpret_cast<const gbf16x8*>(bbase + n * 32 * X_ROW + p * X_PLANE);
+            // the partial products, smallest first; consecutive MFMAs go to different accumulators
+            if constexpr (NP == 6) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (X3_PRODUCTS > 5) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[0], acc[i][n], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[0], acc[i][n], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (X3_PRODUCTS > 4) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[2], acc[i][n], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[2], acc[i][n], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (X3_PRODUCTS > 3) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[1], acc[i][n], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[1], acc[i][n], 0, 0, 0);
+            }
+            if constexpr (NP >= 3) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (X3_PRODUCTS > 2) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[0], acc[i][n], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[0], acc[i][n], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (X3_PRODUCTS > 1) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[1], acc[i][n], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[1], acc[i][n], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[0], acc[i][n], 0, 0, 0);
         }
@@ -1271,6 +1276,13 @@ extern "C" int psn_gemm(int trans_a, int trans_b, int64_t M, int N, int K, const
 
 static int gemm_tn_grouped_impl(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
                                 int64_t workspace_floats, void* stream, bool x3);
+// partial products per multiply of psn_gemm_tn_grouped_x3: 6 (default: fp32-class), 3 (~16 significant bits), 1 (plain bf16 operands)
+static int g_x3_products = 6;
+extern "C" int psn_gemm_tn_x3_set_products(int n_products) {
+    const int prev = g_x3_products;
+    if (n_products == 6 || n_products == 3 || n_products == 1) g_x3_products = n_products;
+    return prev;
+}
 extern "C" int psn_gemm_tn_grouped(int n_items, const PsnGemmTnItem* items, int64_t K, int split_k, float* workspace,
                                    int64_t workspace_floats, void* stream) {
     return gemm_tn_grouped_impl(n_items, items, K, split_k, workspace, workspace_floats, stream, false);
@@ -1389,7 +1401,9 @@ static int gemm_tn_grouped_impl(int n_items, const PsnGemmTnItem* items, int64_t
     PSN_CHECK_ARG(blocks < (1ll << 31) && blocks_big < (1ll << 31) && blocks_tall < (1ll << 31), "gemm_tn_grouped: too many blocks");
     hipStream_t st = (hipStream_t)stream;
     if (gb.n > 0) {
-        if (x3) hipLaunchKernelGGL(gemm_tn256_x3_grouped_kernel, dim3((unsigned)blocks_big), dim3(512), 2 * X_BUF, st, gb);
+        if (x3 && g_x3_products == 6) hipLaunchKernelGGL(gemm_tn256_x3_grouped_kernel<6>, dim3((unsigned)blocks_big), dim3(512), 2 * X_BUF, st, gb);
+        else if (x3 && g_x3_products == 3) hipLaunchKernelGGL(gemm_tn256_x3_grouped_kernel<3>, dim3((unsigned)blocks_big), dim3(512), 2 * X_BUF, st, gb);
+        else if (x3) hipLaunchKernelGGL(gemm_tn256_x3_grouped_kernel<1>, dim3((unsigned)blocks_big), dim3(512), 2 * X_BUF, st, gb);
         else hipLaunchKernelGGL(gemm_tn256_grouped_kernel, dim3((unsigned)blocks_big), dim3(256), T256_BUF * 2 * sizeof(float), st, gb);
         PSN_CHECK_LAUNCH("gemm_tn_grouped (256 x 256 tiles)");
     }

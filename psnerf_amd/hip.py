@@ -128,6 +128,7 @@ SIGNATURES = {
     'psn_gemm': (i32, [i32, i32, i64, i32, i32, c_f, i64, c_f, i64, c_f, i64, c_f, i32, c_f, i64, c_f, i64, c_f, i64,
                        i32, c_f, c_f, c_f]),
     'psn_gemm_tn_grouped': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
+    'psn_gemm_tn_x3_set_products': (i32, [i32]),
     'psn_gemm_tn_grouped_x3': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
     'psn_colsum': (i32, [c_f, c_f, i32, i64, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_sample_points': (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f]),
@@ -1033,21 +1034,28 @@ WGRAD_X3 = os.environ.get('PSN_WGRAD_X3', '0') == '1'
 
 
 class wgrad_precision(object):
-    """``with hip.wgrad_precision('bf16x6'):`` -- the 256 x 256-tile weight-gradient products issued inside take the split-bf16
-    kernel (psn_gemm_tn_grouped_x3); 'fp32' = the exact kernel.  Wrap the BACKWARD pass (that is where the products are issued)."""
+    """``with hip.wgrad_precision(mode):`` -- the 256 x 256-tile weight-gradient products issued inside take
+    'fp32'   the exact kernel (v_mfma_f32_32x32x2_f32);
+    'bf16x6' the split-bf16 kernel with three pieces per operand and six partial products (fp32-class results);
+    'bf16x3' two pieces, three partial products (~16 significant bits);
+    'bf16'   plain bf16 operands, fp32 accumulation.
+    Wrap the BACKWARD pass (that is where the products are issued)."""
+    PRODUCTS = {'bf16x6': 6, 'bf16x3': 3, 'bf16': 1}
 
     def __init__(self, mode):
-        assert mode in ('fp32', 'bf16x6'), mode
+        assert mode in ('fp32', 'bf16x6', 'bf16x3', 'bf16'), mode
         self.mode = mode
 
     def __enter__(self):
         global WGRAD_X3
-        self.saved, WGRAD_X3 = WGRAD_X3, self.mode == 'bf16x6'
+        self.saved, WGRAD_X3 = WGRAD_X3, self.mode != 'fp32'
+        self.saved_products = _lib.psn_gemm_tn_x3_set_products(self.PRODUCTS.get(self.mode, 6))
         return self
 
     def __exit__(self, *exc):
         global WGRAD_X3
         WGRAD_X3 = self.saved
+        _lib.psn_gemm_tn_x3_set_products(self.saved_products)
         return False
 
 

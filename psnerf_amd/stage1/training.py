@@ -45,6 +45,7 @@ class Trainer(object):
         self.sync_free = bool(kwargs.get('sync_free', True))
         # EXPERIMENT (BASELINE configs[4] bf16 path): the 256 x 256 weight gradients on the bf16 matrix pipe with split operands
         self.wgrad_bf16x6 = bool(cfg.get('wgrad_bf16x6', False))
+        self.wgrad_mode = cfg.get('wgrad_precision', 'bf16x6' if self.wgrad_bf16x6 else None)   # 'bf16x6' | 'bf16x3' | 'bf16' | None = the process-wide setting
 
     def train_step(self, data, it=None, pix=None, noise=None):
         self.model.train()
@@ -58,7 +59,10 @@ class Trainer(object):
             self.optimizer.zero_grad()
         terms = self.compute_loss(data, it=it, pix=pix, noise=noise)
         if terms['loss'].requires_grad:
-            with hip.wgrad_precision('bf16x6' if self.wgrad_bf16x6 else ('bf16x6' if hip.WGRAD_X3 else 'fp32')):
+            if self.wgrad_mode is not None:
+                with hip.wgrad_precision(self.wgrad_mode):
+                    terms['loss'].backward()
+            else:
                 terms['loss'].backward()
         if self.dp.enabled:
             self.dp.allreduce_grads(trainable)

@@ -109,6 +109,9 @@ class TrainStep(object):
         # EXPERIMENT (BASELINE configs[4] bf16 path; off unless the configuration asks): the 256 x 256 weight gradients of the visibility
         # net on the bf16 matrix pipe with split operands (hip.wgrad_precision; fp32-class results, tests/test_bf16_gpu.py)
         self.wgrad_bf16x6 = conf.get_bool('train.wgrad_bf16x6', default=False)
+        # ('train.wgrad_precision' = 'bf16x6' | 'bf16x3' | 'bf16' selects the number of partial products; the flag above = 'bf16x6')
+        self.wgrad_mode = conf.get_string('train.wgrad_precision', default='bf16x6' if self.wgrad_bf16x6 else 'fp32')
+        self.wgrad_bf16x6 = self.wgrad_mode != 'fp32'
         self.light_inten_train = self.light_train and conf.get_bool('train.light_inten_train', default=False)
         if not self.light_train:
             self.light_para.requires_grad_(False)
@@ -263,7 +266,7 @@ class TrainStep(object):
                 seed = self._grad_seed = torch.ones_like(loss)
             if self.wgrad_bf16x6:
                 from .. import hip
-                with hip.wgrad_precision('bf16x6'):
+                with hip.wgrad_precision(self.wgrad_mode):
                     loss.backward(seed)
             else:
                 loss.backward(seed)

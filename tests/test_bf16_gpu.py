@@ -361,6 +361,16 @@ def test_split_bf16_weight_gradient_gemm_has_fp32_class_accuracy(cuda, K, M, N, 
         res2 = hip.gemm_tn_grouped(its)
     res = hip.gemm_tn_grouped(its, x3=True)
     assert all(torch.equal(a[0], b[0]) for a, b in zip(res, res2)) and hip.WGRAD_X3 is False
+    # fewer partial products (psn_gemm_tn_x3_set_products): 3 = two pieces per operand (~16 significant bits), 1 = plain bf16
+    # operands; the column sums stay fp32 sums of the fp32 rows in every mode; the setting is restored on exit
+    for mode, lo, hi in (('bf16x3', 2e-6, 2e-5), ('bf16', 3e-4, 8e-3)):
+        with hip.wgrad_precision(mode):
+            resm = hip.gemm_tn_grouped(its)
+        e = max(float((c.double() - r).abs().max() / r.abs().max()) for (c, _), (r, _) in zip(resm, ref))
+        es = max(float((s_.double() - rs).abs().max() / rs.abs().max()) for (_, s_), (_, rs) in zip(resm, ref))
+        assert lo < e < hi and es < 2e-6, (mode, e, es)
+    res3 = hip.gemm_tn_grouped(its, x3=True)
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(res, res3))
 
 
 def test_wgrad_bf16x6_passes_the_parameter_gradient_gate(cuda):
@@ -382,7 +392,7 @@ def test_wgrad_bf16x6_passes_the_parameter_gradient_gate(cuda):
     nz = torch.randn(ns, 3, generator=torch.Generator().manual_seed(1)) * 0.01
     _, _, o_g = _run(onet, o2.MainLoss, o2.NormalLoss, inp, gt, 2, nz, 'cpu')
     grads = {}
-    for mode in ('fp32', 'bf16x6'):
+    for mode in ('fp32', 'bf16x6', 'bf16x3'):
         net = s2.PSNetwork(s2.bear_conf())
         net.load_state_dict(sd)
         net.to(cuda)
@@ -390,6 +400,7 @@ def test_wgrad_bf16x6_passes_the_parameter_gradient_gate(cuda):
             grads[mode] = _run(net, s2.MainLoss, s2.NormalLoss, inp, gt, 2, nz, cuda)[2]
     for k in o_g:
         assert_close(grads['bf16x6'][k].cpu(), o_g[k], 1e-3, 'grad ' + k)
+        assert_close(grads['bf16x3'][k].cpu(), o_g[k], 1e-3, 'grad (three products) ' + k)
     vis = [k for k in o_g if k.startswith('visibility_net') and k.endswith('weight') and tuple(o_g[k].shape) == (256, 256)]
     assert vis and any(not torch.equal(grads['bf16x6'][k], grads['fp32'][k]) for k in vis)
     # stage 1: one train step, exact vs split weight gradients

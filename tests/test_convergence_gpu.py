@@ -131,7 +131,7 @@ def _stage2_draws(views, n_steps, seed=6):
     return [torch.randn(int(views[it % len(views)][0]['surface_mask'].sum()), 3, generator=g) * 0.01 for it in range(n_steps)]
 
 
-@pytest.fixture(params=['fp32', 'bf16x6'])
+@pytest.fixture(params=['fp32', 'bf16x6', 'bf16x3'])
 def wgrad(request):
     """The synchronised-window tests run twice: with the exact fp32 weight-gradient kernel and with the split-bf16 experiment
     (psn_gemm_tn_grouped_x3 through hip.wgrad_precision) -- the same bounds hold for both."""

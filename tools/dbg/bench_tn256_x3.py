@@ -31,8 +31,9 @@ acc = {}
 for (M, N) in ((256, 256), (217, 256), (256, 200)):
     its = items(40000, 2, True, M, N)  # (views of 256-wide tensors: lda = 256, the 256 x 256-tile path)
     ref = [(it['A'].double().t() @ it['B'].double() + it['A2'].double().t() @ it['B2'].double(), it['A'].double().sum(0)) for it in its]
-    for name, x3 in (('fp32', False), ('bf16x6', True)):
-        res = hip.gemm_tn_grouped(its, x3=x3)
+    for name in ('fp32', 'bf16x6', 'bf16x3', 'bf16'):
+        with hip.wgrad_precision(name):
+            res = hip.gemm_tn_grouped(its)
         e = max(float((c.double() - r).abs().max() / r.abs().max()) for (c, _), (r, _) in zip(res, ref))
         ec = max(float((s.double() - rs).abs().max() / rs.abs().max()) for (_, s), (_, rs) in zip(res, ref))
         acc['%s M=%d N=%d' % (name, M, N)] = {'max_rel_err_vs_float64': e, 'colsum_max_rel_err': ec}
@@ -41,11 +42,12 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 537000
 its = items(K, 8, True)
 flops = 2.0 * K * 256 * 256 * 16
 bytes_ = 16 * K * 1024 * 2.0
-for name, x3 in (('fp32', False), ('bf16x6', True), ('fp32', False), ('bf16x6', True)):
-    ms = timeit(lambda: hip.gemm_tn_grouped(its, x3=x3))
+for name in ('fp32', 'bf16x6', 'bf16x3', 'bf16') * 2:
+    with hip.wgrad_precision(name):
+        ms = timeit(lambda: hip.gemm_tn_grouped(its))
     r = rep.setdefault(name, {'ms': []})
     r['ms'].append(round(ms, 3))
-for name in ('fp32', 'bf16x6'):
+for name in ('fp32', 'bf16x6', 'bf16x3', 'bf16'):
     ms = min(rep[name]['ms'])
     rep[name].update({'best_ms': ms, 'tflops_fp32_equivalent': round(flops / ms / 1e9, 1), 'operand_TB_per_s': round(bytes_ / ms / 1e9, 2)})
 rep['K'] = K
