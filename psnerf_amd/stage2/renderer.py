@@ -409,7 +409,7 @@ class PSNetwork(nn.Module):
                     # encodings, the optimiser step of the previous iteration), not for the visibility kernel
                     side = self._side.get(device)
                     if side is None:
-                        side = self._side[device] = torch.cuda.Stream(device=device)  # (a high-priority stream measured the same: +-0.05 ms/step)
+                        side = self._side[device] = torch.cuda.Stream(device=device)  # (a high-priority stream: +-0.05 ms/step at 32768 px; round 5 at 4096 px: 3.76 -> 3.78 ms, 32768 px eager 25.1 -> 27.1 ms)
                     side.wait_stream(torch.cuda.current_stream(device))
                 if self.train_vis_bf16 or self.train_vis_bf16x6:
                     # opt-in (train.vis_bf16 / train.vis_bf16x6): the L shading rows enter the loss detached (renderer.py:197),
@@ -429,15 +429,27 @@ class PSNetwork(nn.Module):
                 cols_n = self._cols(self.n_freqs_n, device)
                 # (the encoding of the surface points is shared with the visibility / BRDF networks when the octave counts agree)
                 pe_n = (lambda: pe_x) if (pe_x is not None and self.n_freqs_n == self.n_freqs) else (lambda: self._pe(surf, self.n_freqs_n))
-                normal_s = self._memo('normal', input, lambda: ops.normalize_rows(self.normal_net(pe_n(), cols_n)))
-                normal_pred = scatter(normal_pred, normal_s)
-                if self.normal_jitter_std > 0:
+                if self.normal_jitter_std > 0 and torch.is_grad_enabled():
+                    # base and jittered evaluation (renderer.py:127-143) in the same launches, as the BRDF networks below: rows
+                    # [0, Ns) = PE(x), rows [Ns, 2 Ns) = PE(x + noise).  Row-wise identical results; one forward launch, one
+                    # backward chain and one weight-gradient launch instead of two each (they are latency-bound at Ns rows)
                     nz = noise.get('normal')
                     if nz is None:
                         nz = torch.empty_like(surf).normal_(0.0, self.normal_jitter_std)  # = torch.normal(0, std) without its host-side std >= 0 check (one launch)
-                    nj = self._memo('normal_jitter', input, lambda: ops.normalize_rows(
-                        self.normal_net(self._pe(surf + nz, self.n_freqs_n), cols_n)))
+                    pe_both_n = torch.cat([pe_n(), self._pe(surf + nz, self.n_freqs_n)], dim=0)
+                    normal_s, nj = ops.SplitRows.apply(ops.normalize_rows(self.normal_net(pe_both_n, cols_n)), ns)
+                    normal_pred = scatter(normal_pred, normal_s)
                     out_n['normal_jitter'] = scatter(ones3(), nj)
+                else:
+                    normal_s = self._memo('normal', input, lambda: ops.normalize_rows(self.normal_net(pe_n(), cols_n)))
+                    normal_pred = scatter(normal_pred, normal_s)
+                    if self.normal_jitter_std > 0:
+                        nz = noise.get('normal')
+                        if nz is None:
+                            nz = torch.empty_like(surf).normal_(0.0, self.normal_jitter_std)
+                        nj = self._memo('normal_jitter', input, lambda: ops.normalize_rows(
+                            self.normal_net(self._pe(surf + nz, self.n_freqs_n), cols_n)))
+                        out_n['normal_jitter'] = scatter(ones3(), nj)
             out_n['normal_pred'] = normal_pred
 
         sg = self.render_model == 'sgbasis'
