@@ -343,6 +343,30 @@ def stage1_measure(device, steps=10, warmup=5, rays=4096):
                     terms_m = tr.train_step(batch, it=it)
                 torch.cuda.synchronize()
                 dts[mode] = ((time.perf_counter() - t0) / steps, round(float(terms_m['loss'].detach()), 6))
+        # ... and the matrix work of the four geometry chains and the two appearance chains as three bf16 partial products
+        # (ops.chain_precision('bf16x3')) beside the three-product weight gradients: every MFMA of the step on the bf16 pipe
+        # except the (latency-bound) root finder
+        from psnerf_amd import ops
+        with ops.chain_precision('bf16x3'), hip.wgrad_precision('bf16x3'):
+            for _ in range(3):
+                tr.train_step(batch, it=it)
+            settle_gc()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                terms_c = tr.train_step(batch, it=it)
+            torch.cuda.synchronize()
+            dtc = (time.perf_counter() - t0) / steps
+        net.invalidate_packs()
+        out['bf16x3_chains_experiment'] = {
+            'value': round(rays * S / dtc, 1), 'unit': 'ray-samples/s', 'ms_per_step': round(dtc * 1e3, 3), 'steps': steps,
+            'loss': round(float(terms_c['loss'].detach()), 6),
+            'dtype': 'f32 emulated on the bf16 matrix pipe: 2 x bf16 split operands, 3 partial products, f32 accumulate (~16 significant bits); '
+                     'ray-march sweep: 3 x bf16, 6 products',
+            'scope': "ops.chain_precision('bf16x3') + hip.wgrad_precision('bf16x3') + inference_precision 'bf16x6': value pass, gradient sweep, "
+                     'their adjoints, the appearance chains (activation programs, dumps, epilogues f32), the 256 x 256 weight gradients and the '
+                     'ray-march sweep; root finder, composite, losses, Adam: exact f32.  Gates: tests/test_bf16_gpu.py (parameter gradients vs '
+                     'the exact step), tests/test_convergence_gpu.py (synchronised windows)'}
         dt7, loss7 = dts['bf16x6']
         out['bf16x6_wgrad_experiment'] = {'value': round(rays * S / dt7, 1), 'unit': 'ray-samples/s', 'ms_per_step': round(dt7 * 1e3, 3), 'steps': steps,
                                           'loss': loss7,
@@ -833,6 +857,15 @@ def main():
             x6['with_wgrad_bf16x6'] = {'value': round(ns5 * N_LIGHTS / (dt5 / k4), 1), 'ms_per_step': round(dt5 / k4 * 1e3, 3),
                                        'loss': round(float(terms5['total'].detach()), 6),
                                        'scope': 'as above + psn_gemm_tn_grouped_x3 for the 256 x 256 weight-gradient products of visibility_net'}
+            from psnerf_amd import ops
+            with hip.wgrad_precision('bf16x3'), ops.chain_precision('bf16x3'):
+                # + the backward chains of the 256-wide networks (V supervised rows, normal / albedo nets) and the weight gradients
+                # as three bf16 partial products: every large MFMA stream of the step except the V rows' forward on the bf16 pipe
+                dt6_, ns6_, terms6_ = timed(inp, gt, k4, 3)
+            x6['with_chains_wgrad_bf16x3'] = {'value': round(ns6_ * N_LIGHTS / (dt6_ / k4), 1), 'ms_per_step': round(dt6_ / k4 * 1e3, 3),
+                                              'loss': round(float(terms6_['total'].detach()), 6),
+                                              'scope': "shading rows bf16x6 + ops.chain_precision('bf16x3') + hip.wgrad_precision('bf16x3') "
+                                                       '(2 x bf16 split operands, 3 partial products, ~16 significant bits; gates: tests/test_bf16_gpu.py)'}
             if xk:
                 rows_x, ms_x = xk[0][0], sum(t for _, t in xk) / len(xk)
                 eq = 2.0 * VIS_MACS * rows_x / (ms_x * 1e-3) / 1e12

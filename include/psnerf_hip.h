@@ -206,6 +206,14 @@ enum {
 };
 enum { PSN_OUT_NONE = 0, PSN_OUT_SIGMOID = 1, PSN_OUT_OCC = 2 /* sigmoid(-10 x), network.py:125 */ };
 
+/* Weight-stage formats.  PSN_W_F32: fp32 fragments of v_mfma_f32_16x16x4_f32 (exact; every parity-gated path).  PSN_W_BF16X2
+ * (opt-in experiment, BASELINE configs[4] "bf16 MFMA path"): the same 32 KB stage geometry [k-tile][2][16-row tile][64 lanes][16 B],
+ * the two halves being the bf16 heads and the bf16 remainders (x = hi + mid + O(2^-16 x)) of the lane's eight weights of the
+ * k-tile; the chain engine multiplies hi hi + hi mid + mid hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the matrix
+ * work of stage1/model/network.py:85-120 (value pass, gradient sweep and their adjoints) and :98-106 on the bf16 pipe,
+ * activation programs, dumps and epilogues unchanged (fp32). */
+enum { PSN_W_F32 = 0, PSN_W_BF16X2 = 1 };
+
 typedef struct {
     int n_kt_in;   /* 32-wide K tiles taken from the input-feature registers (0..4) */
     int n_kt_act;  /* 32-wide K tiles taken from the previous layer's activations: 0, the hidden n_mt, or n_mt - 1 when the
@@ -225,6 +233,8 @@ typedef struct {
     int in_kt_a;  /* K tiles (of 32 floats) per row of feature table A (1..4) */
     int in_kt_b;  /* K tiles per row of table B (0 = unused); in_kt_a + in_kt_b <= 4 */
     int init_stride; /* floats per row of the init tables (multiple of the hidden width), 0 if no layer uses init_off */
+    int w_format; /* PSN_W_F32, or PSN_W_BF16X2 (experiment; psn_mlp_infer chain launches of the 256-wide networks only): every block
+                     with n_mt >= 2 is packed as two bf16 planes and multiplied as three bf16 partial products, see PsnPackItem.format */
     PsnMlpLayer layers[PSN_MLP_MAX_LAYERS];
 } PsnMlpDesc;
 
@@ -243,6 +253,7 @@ typedef struct {
     float* dst;
     int64_t ldw;
     int rows, cols, transpose, n_mt, k_tiles;
+    int format; /* PSN_W_F32 or PSN_W_BF16X2 (same size and geometry, see above) */
 } PsnPackItem;
 int psn_mlp_pack_layers(int n_items, const PsnPackItem* items, void* stream);
 

@@ -204,6 +204,79 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx
     }
 }
 
+// ---- split-bf16 form of a stage (experiment, PsnMlpDesc.w_format = PSN_W_BF16X2; chain launches of the 256-wide networks) ----
+// The stage holds the SAME 32-feature k-tile in the same [2][NMT][64 lanes][16 B] geometry, but the two halves are PLANES instead of
+// k-halves: plane 0 = the bf16 heads of the lane's eight weights W[16 mt + i][32 kt + 16 (s / 4) + 4 g + s % 4], s = 0..7, plane 1 =
+// the bf16 of what the heads left (x = hi + mid + O(2^-16 x)).  v_mfma_f32_16x16x32_bf16 contracts 32 k per instruction with lane
+// group g supplying k-slots 8 g .. 8 g + 7 of both operands, and the slots above are exactly the eight activations the lane holds of
+// this k-tile (b0[0..3], b1[0..3]): the B operand is split in registers, nothing moves between lanes, and the C layout -- hence
+// every activation program, dump and epilogue -- is that of the fp32 instruction.  Three partial products per multiply
+// (hi hi + hi mid + mid hi, fp32 accumulation): 48 MFMAs of 16 cycles per k-tile instead of 128 of 32.
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
+typedef int cintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int chain_cvt2(float a, float b) {
+    f32x2 f = {a, b};
+    return __builtin_bit_cast(int, __builtin_convertvector(f, cbf16x2));  // v_cvt_pk_bf16_f32 (round to nearest even): a in the low half
+}
+__device__ __forceinline__ void chain_split(const floatx4& b0, const floatx4& b1, cbf16x8& hi, cbf16x8& mid) {
+    cintx4 h, m;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = q < 2 ? b0[2 * q] : b1[2 * q - 4], b = q < 2 ? b0[2 * q + 1] : b1[2 * q - 3];
+        h[q] = chain_cvt2(a, b);
+        m[q] = chain_cvt2(a - __builtin_bit_cast(float, h[q] << 16), b - __builtin_bit_cast(float, h[q] & (int)0xFFFF0000));
+    }
+    hi = __builtin_bit_cast(cbf16x8, h);
+    mid = __builtin_bit_cast(cbf16x8, m);
+}
+template <int NMT, int NACC, typename RequestNext>
+__device__ __forceinline__ void stage_compute_x3(floatx4 (&acc)[NACC], const floatx4& b0, const floatx4& b1,
+                                                 const float4* __restrict__ wl_, int lane, RequestNext request_next) {
+    const cbf16x8* wl = reinterpret_cast<const cbf16x8*>(wl_);
+    cbf16x8 bh, bm;
+    chain_split(b0, b1, bh, bm);
+    if constexpr (NMT >= 8) {
+        constexpr int GE = NMT / 8;  // groups of 8 output tiles per plane
+        constexpr int NG = 2 * GE;
+        cbf16x8 a[2][8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a[0][m] = wl[m * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < NMT / 2; ++j) request_next(j);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int p = g / GE, m0 = (g % GE) * 8;
+            if (g < NG - 1) {
+                const int p1 = (g + 1) / GE, m1 = ((g + 1) % GE) * 8;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) a[(g + 1) & 1][m] = wl[(p1 * NMT + m1 + m) * 64 + lane];
+            }
+            const cbf16x8(&ag)[8] = a[g & 1];
+            if (p == 0) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[m], bm, acc[m0 + m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[m], bh, acc[m0 + m], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NMT / 2; ++j) request_next(j);
+        cbf16x8 a[2][NMT];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) a[p][m] = wl[(p * NMT + m) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][m], bm, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][m], bh, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][m], bh, acc[m], 0, 0, 0);
+    }
+}
+
 // LDS-DMA one stage (NBLK x 1 KB) of packed weights; wave w moves the contiguous blocks [w NBLK/4, (w+1) NBLK/4): four
 // consecutive 1 KB pieces share one base (global address and M0) and differ in the instruction offset only
 // (compile-time trip count, no kernarg reloads inside the stage: an s_load there forces s_waitcnt lgkmcnt(0), which
@@ -374,8 +447,11 @@ __device__ __forceinline__ void wait_for_weights(int stores) {
 // the untrimmed visibility launch 0.7 %).
 // FROMA (chain variant): the MUL_AUX / MUL2 / SOFTPLUS_BWD programs take the dumped softplus OUTPUT as a1 and re-form the sigmoid
 // (single-dump experiment, PSN_ACT_*_A on the host side).
-template <bool CHAIN, int NMT, int SRC = 0, bool TRIM = false, bool FROMA = false>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
+// X3 (chain variant, NMT = 16): the weight stages hold two bf16 planes (PSN_W_BF16X2) and the matrix work runs as three bf16 partial
+// products (stage_compute_x3); the final layer of a launch with n_out <= 32 stays fp32 (its block is packed PSN_W_F32).
+template <bool CHAIN, int NMT, int SRC = 0, bool TRIM = false, bool FROMA = false, bool X3 = false>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
 __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
+    static_assert(!X3 || (CHAIN && NMT == 16 && SRC == 0), "split-bf16 stages: 256-wide chain launches only");
     constexpr int W = 16 * NMT;
     // LDS-DMA flavour (common.h lds_dma_16): asm pieces + explicit scheduling regions for the lean variant (exact lgkmcnt
     // waits: visibility launch +1.9 %, march sweep +4 %), the builtin + scheduling groups for the chain variant (its
@@ -576,7 +652,8 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         /* branch-free request (a branch would end the scheduling region the pieces are spread over): after the very \
            last stage the idle buffer receives a copy of the first one */                                   \
         const float* src_ = s_ + 1 < n_st ? wl_g + (int64_t)(s_ + 1) * stage_floats : (next_w != nullptr ? next_w : g.w); \
-        stage_compute<NMT, NMT, kAsmDma>(acc, B0, B1, wl, lane, [&](int j_) { stage_piece<2 * (NMT), kAsmDma>(src_, nxt, wave, lane, j_); }); \
+        if constexpr (X3) stage_compute_x3<NMT, NMT>(acc, B0, B1, wl, lane, [&](int j_) { stage_piece<2 * (NMT), kAsmDma>(src_, nxt, wave, lane, j_); }); \
+        else stage_compute<NMT, NMT, kAsmDma>(acc, B0, B1, wl, lane, [&](int j_) { stage_piece<2 * (NMT), kAsmDma>(src_, nxt, wave, lane, j_); }); \
         ++gstage;                                                                                           \
     }
 
@@ -815,13 +892,19 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
         stage_load<2 * NMT, kAsmDma>(g.w + L.w_off + kStageFloats, smem + ((gstage + 1) & 1) * kStageFloats, wave, lane);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) stage_compute<4, NMT, kAsmDma>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 512, lane, [](int) {});
+        for (int kt = 0; kt < 4; ++kt) {
+            if constexpr (X3) stage_compute_x3<4, NMT>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 512, lane, [](int) {});
+            else stage_compute<4, NMT, kAsmDma>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 512, lane, [](int) {});
+        }
         ++gstage;
         wait_for_weights<NMT>(0);
         asm volatile("s_barrier" ::: "memory");
         wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) stage_compute<4, NMT, kAsmDma>(acc, act[8 + 2 * kt], act[8 + 2 * kt + 1], wl + kt * 512, lane, [](int) {});
+        for (int kt = 0; kt < 4; ++kt) {
+            if constexpr (X3) stage_compute_x3<4, NMT>(acc, act[8 + 2 * kt], act[8 + 2 * kt + 1], wl + kt * 512, lane, [](int) {});
+            else stage_compute<4, NMT, kAsmDma>(acc, act[8 + 2 * kt], act[8 + 2 * kt + 1], wl + kt * 512, lane, [](int) {});
+        }
     } else if (g.d.n_out > 0) {  // final layer: 32 (padded) outputs = two 16-wide tiles; all 8 k-tiles arrive as ONE 32 KB stage
         const PsnMlpLayer L = g.d.layers[li];
         const float* bp = bias_lds + L.b_off;
@@ -1128,10 +1211,23 @@ __global__ __launch_bounds__(256) void mlp_pack_group_kernel(PackGroupArgs a) {
     const int kt = (int)(blk / per_stage);
     const int bi = (int)(blk % per_stage);
     const int half = bi / nmt16, mt = bi % nmt16;
-    const int r = 16 * mt + (lane & 15), k = 32 * kt + 16 * half + 4 * (lane >> 4) + c;
-    float v = 0.0f;
-    if (r < it.rows && k < it.cols) v = it.transpose ? it.W[(int64_t)k * it.ldw + r] : it.W[(int64_t)r * it.ldw + k];
-    it.dst[e] = v;
+    const int r = 16 * mt + (lane & 15);
+    auto w_at = [&](int k) {
+        float v = 0.0f;
+        if (r < it.rows && k < it.cols) v = it.transpose ? it.W[(int64_t)k * it.ldw + r] : it.W[(int64_t)r * it.ldw + k];
+        return v;
+    };
+    if (it.format == PSN_W_BF16X2) {
+        // word c of plane `half` of this lane's 16 bytes = k-slots 2 c, 2 c + 1 (stage_compute_x3): slot s <-> k = 32 kt + 16 (s / 4)
+        // + 4 g + s % 4; plane 0 = the bf16 heads (round to nearest even), plane 1 = the bf16 of the remainders
+        const int k0 = 32 * kt + 16 * (c >> 1) + 4 * (lane >> 4) + 2 * (c & 1);
+        const float v0 = w_at(k0), v1 = w_at(k0 + 1);
+        int w = chain_cvt2(v0, v1);
+        if (half == 1) w = chain_cvt2(v0 - __builtin_bit_cast(float, w << 16), v1 - __builtin_bit_cast(float, w & (int)0xFFFF0000));
+        reinterpret_cast<int*>(it.dst)[e] = w;
+        return;
+    }
+    it.dst[e] = w_at(32 * kt + 16 * half + 4 * (lane >> 4) + c);
 }
 
 }  // namespace psn
@@ -1145,6 +1241,7 @@ extern "C" int psn_mlp_pack_layers(int n_items, const PsnPackItem* items, void* 
     for (int i = 0; i < n_items; ++i) {
         const PsnPackItem& it = items[i];
         PSN_CHECK_ARG(it.W && it.dst, "mlp_pack_layers: item %d: null pointer", i);
+        PSN_CHECK_ARG(it.format == PSN_W_F32 || it.format == PSN_W_BF16X2, "mlp_pack_layers: item %d: unknown format %d", i, it.format);
         PSN_CHECK_ARG(it.n_mt >= 1 && it.n_mt <= 8 && it.k_tiles >= 1 && it.k_tiles <= 12, "mlp_pack_layers: item %d: n_mt=%d k_tiles=%d", i, it.n_mt, it.k_tiles);
         PSN_CHECK_ARG(it.rows >= 1 && it.rows <= it.n_mt * 32 && it.cols >= 1 && it.cols <= it.k_tiles * 32,
                       "mlp_pack_layers: item %d: %d x %d does not fit %d x %d", i, it.rows, it.cols, it.n_mt * 32, it.k_tiles * 32);
@@ -1292,7 +1389,18 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
         } else if (act == PSN_ACT_MUL_AUX || act == PSN_ACT_MUL2 || act == PSN_ACT_SOFTPLUS_BWD) base_mul = true;
     }
     PSN_CHECK_ARG(!from_a || (hid == 8 && chain && !base_mul), "mlp_infer: the single-dump programs (PSN_ACT_*_A) exist for the 256-wide chain engine and do not mix with their base programs");
-    if (from_a) {
+    const bool x3 = d.w_format == PSN_W_BF16X2;
+    PSN_CHECK_ARG(d.w_format == PSN_W_F32 || x3, "mlp_infer: unknown weight format %d", d.w_format);
+    PSN_CHECK_ARG(!x3 || (hid == 8 && chain), "mlp_infer: split-bf16 weight stages (PSN_W_BF16X2) are built for chain launches of the 256-wide networks only");
+    if (x3) {
+        if (from_a) {
+            if (trim) hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, true, true, true>), grid, block, lds_bytes, st, a);
+            else hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, false, true, true>), grid, block, lds_bytes, st, a);
+        } else {
+            if (trim) hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, true, false, true>), grid, block, lds_bytes, st, a);
+            else hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, false, false, true>), grid, block, lds_bytes, st, a);
+        }
+    } else if (from_a) {
         if (trim) hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, true, true>), grid, block, lds_bytes, st, a);
         else hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, false, true>), grid, block, lds_bytes, st, a);
     } else if (trim) {
@@ -1363,6 +1471,7 @@ static int mlp_infer_pe_impl(const PsnMlpDesc* desc, const float* packed_w, cons
     PSN_CHECK_ARG(desc && packed_w && packed_b && points && out, "mlp_infer_pe: null pointer");
     const PsnMlpDesc& d = *desc;
     PSN_CHECK_ARG(d.n_layers >= 2 && d.n_layers <= PSN_MLP_MAX_LAYERS && d.n_out >= 1 && d.n_out <= 32, "mlp_infer_pe: n_layers=%d n_out=%d", d.n_layers, d.n_out);
+    PSN_CHECK_ARG(d.w_format == PSN_W_F32, "mlp_infer_pe: fp32 weight stages only");
     PSN_CHECK_ARG(d.out_act >= PSN_OUT_NONE && d.out_act <= PSN_OUT_OCC, "mlp_infer_pe: out_act=%d", d.out_act);
     PSN_CHECK_ARG(d.in_kt_a == 2 && d.in_kt_b == 0 && 3 + 6 * pe_octaves <= 64 && pe_octaves >= 0,
                   "mlp_infer_pe: the input block is one 64-column positional encoding (in_kt_a = 2), got in_kt_a=%d octaves=%d", d.in_kt_a, pe_octaves);
@@ -1420,6 +1529,7 @@ extern "C" int psn_march_sweep(const PsnMlpDesc* desc, const float* packed_w, co
     const PsnMlpDesc& d = *desc;
     PSN_CHECK_ARG(d.n_layers >= 2 && d.n_layers <= PSN_MLP_MAX_LAYERS && d.n_out == 1 && d.out_act == PSN_OUT_OCC,
                   "march_sweep: expects an occupancy network (one output, PSN_OUT_OCC)");
+    PSN_CHECK_ARG(d.w_format == PSN_W_F32, "march_sweep: fp32 weight stages only");
     PSN_CHECK_ARG(d.in_kt_a == 2 && d.in_kt_b == 0 && 3 + 6 * pe_octaves <= 64 && pe_octaves >= 0,
                   "march_sweep: the input block is one 64-column positional encoding (in_kt_a = 2), got in_kt_a=%d octaves=%d", d.in_kt_a, pe_octaves);
     PSN_CHECK_ARG(d.layers[0].n_kt_in == 2 && d.layers[0].n_kt_act == 0, "march_sweep: layer 0 reads the encoding as k-tiles");
@@ -1459,6 +1569,7 @@ extern "C" int psn_root_find(const PsnMlpDesc* desc, const float* packed_w, cons
     const PsnMlpDesc& d = *desc;
     PSN_CHECK_ARG(d.n_layers >= 2 && d.n_layers <= PSN_MLP_MAX_LAYERS && d.n_out == 1 && d.out_act == PSN_OUT_OCC,
                   "root_find: expects an occupancy network (one output, PSN_OUT_OCC)");
+    PSN_CHECK_ARG(d.w_format == PSN_W_F32, "root_find: fp32 weight stages only");
     PSN_CHECK_ARG(d.in_kt_a == 2 && d.in_kt_b == 0 && 3 + 6 * pe_octaves <= 64 && pe_octaves >= 0,
                   "root_find: the input block is one 64-column positional encoding (in_kt_a = 2), got in_kt_a=%d octaves=%d", d.in_kt_a, pe_octaves);
     PSN_CHECK_ARG(d.layers[0].n_kt_in == 2 && d.layers[0].n_kt_act == 0 && d.layers[0].init_off < 0, "root_find: layer 0 reads the encoding as k-tiles");

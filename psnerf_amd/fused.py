@@ -113,7 +113,7 @@ def _src(w):
     return m, False, m.shape[0], m.shape[1]
 
 
-def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True, width=256, reuse=None):
+def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True, width=256, reuse=None, x3=False):
     """layers: list of dicts {w_in | init_a/init_b, w_act, bias, act}.
     w_in: [o, <=in_kt*32] consumed as MFMA k-tiles; init_a [o, in_kt_a*32] / init_b [o, in_kt_b*32]: the same
     block evaluated through precomputed tables instead.  Hidden layers have o <= width (zero padded; width = 256 or
@@ -122,13 +122,16 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     the padding, so no padded / concatenated / transposed copies are made on the way.
     reuse: the PackedMLP this call site built last time (same network, new parameter values): its zero-padded init-table
     buffers are written in place -- two slice copies per table instead of a pad (fill + copy) per block and a concatenation.
-    Only for packs that no launch in flight on ANOTHER stream still reads."""
-    assert width in (64, 128, 256)
+    Only for packs that no launch in flight on ANOTHER stream still reads.
+    x3 (experiment; chain launches of the 256-wide networks): the weight blocks as two bf16 planes (hip.W_BF16X2) for the split-bf16
+    form of the chain engine; the final layer of a pack with n_out <= 32 stays fp32."""
+    assert width in (64, 128, 256) and (not x3 or width == 256)
     hid = width // 32
     kin = in_kt_a + in_kt_b
     desc = hip.PsnMlpDesc()
     desc.n_layers = len(layers)
     desc.n_out, desc.out_act, desc.in_kt_a, desc.in_kt_b = n_out, out_act, in_kt_a, in_kt_b
+    desc.w_format = hip.W_BF16X2 if x3 else hip.W_F32
     assert len(layers) <= hip.MAX_LAYERS
     plan, biases = [], []
     init_wa, init_wb, init_bias = [], [], []
@@ -191,7 +194,8 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     for w, n_mt, k_tiles, o in plan:
         m, tr, r, c = _src(w)
         assert r <= n_mt * 32 and c <= k_tiles * 32, 'pack_layers: block %dx%d does not fit %dx%d' % (r, c, n_mt * 32, k_tiles * 32)
-        group.append((m if m.dtype == torch.float32 else m.float(), tr, n_mt, k_tiles, w_buf[o:o + n_mt * k_tiles * 1024]))
+        group.append((m if m.dtype == torch.float32 else m.float(), tr, n_mt, k_tiles, w_buf[o:o + n_mt * k_tiles * 1024],
+                      hip.W_BF16X2 if (x3 and n_mt >= 2) else hip.W_F32))
     hip.mlp_pack_layers(group)  # every block of the network in one launch
     desc.init_stride = width * len(init_wa) if direct_init_off is None else width
     if init_wa:
@@ -426,7 +430,7 @@ def pack_geo_occupancy(weights, biases, skips, d_pe):
     return pack_layers(layers, ka, 0, 1, hip.OUT_OCC, weights[0].device)
 
 
-def pack_relu_bwd(weights, skip_at, width=256, bits=False):
+def pack_relu_bwd(weights, skip_at, width=256, bits=False, x3=False):
     """Backward (d x) chain of a 256-wide ReLU MLP for the fused kernel: chain layer j computes
     d h_{l-1} = W_l[:, :256]^T d z_l for l = n-1-j (transposed weight packs, no bias), followed by the ReLU mask of
     the forward activation h_{l-1} (PSN_ACT_RELU_MASK, masks supplied at call time) and a dump of d z_{l-1}.
@@ -441,7 +445,7 @@ def pack_relu_bwd(weights, skip_at, width=256, bits=False):
     layers = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=act)]
     for l in range(n - 2, 0, -1):  # forward layers n-2 .. 1 -> their transposed [in(256), out(256)] blocks
         layers.append(dict(w_act=Transposed(weights[l][:, :width]), bias=zeros, act=act))
-    return pack_layers(layers, 1, 0, 0, hip.OUT_NONE, dev, has_final=False, width=width)
+    return pack_layers(layers, 1, 0, 0, hip.OUT_NONE, dev, has_final=False, width=width, x3=x3 and width == 256)
 
 
 # --------------------------------------------------------------------------- stage-1 geometry-field chains
@@ -449,12 +453,13 @@ def _t(w):
     return Transposed(w)
 
 
-def pack_geo_chains(weights, biases, skips, d_pe, single_dump=False):
+def pack_geo_chains(weights, biases, skips, d_pe, single_dump=False, x3=False):
     """The four fused chains of ops.GeoFieldFused for the 256-wide softplus geometry network
     (stage1/model/network.py:85-120); ``weights`` are the EFFECTIVE dense matrices with the 1/sqrt(2) of the skip
     layer already folded in.  Returns dict(fwd, sweep, sweep_bwd, value_bwd, value_bwd_nosweep) of PackedMLP.
     ``single_dump`` (experiment, ops.GEO_SINGLE_DUMP): the consumer chains take the dumped softplus outputs A_l where they took the
-    dumped sigmoids S_l and re-form s = 1 - exp(-100 a) in their activation programs; the value pass then dumps one tensor per layer."""
+    dumped sigmoids S_l and re-form s = 1 - exp(-100 a) in their activation programs; the value pass then dumps one tensor per layer.
+    ``x3`` (experiment, ops.CHAIN_X3): the four chains' matrix work as three bf16 partial products (pack_layers x3)."""
     mul_aux, mul2, sp_bwd = ((hip.ACT_MUL_AUX_A, hip.ACT_MUL2_A, hip.ACT_SOFTPLUS_BWD_A) if single_dump else
                              (hip.ACT_MUL_AUX, hip.ACT_MUL2, hip.ACT_SOFTPLUS_BWD))
     n = len(weights)
@@ -478,7 +483,7 @@ def pack_geo_chains(weights, biases, skips, d_pe, single_dump=False):
     layers = [dict(bias=b[l], act=hip.ACT_SOFTPLUS100, **fwd_in(l)) for l in range(n - 1)]
     layers.append(dict(w_in=None, w_act=W[n - 1][1:], bias=b[n - 1][1:], act=hip.ACT_HEAD))
     layers.append(dict(w_in=None, w_act=W[n - 1][:1], bias=b[n - 1][:1], act=hip.ACT_NONE))
-    fwd = pack_layers(layers, ka, 0, 1, hip.OUT_NONE, dev)
+    fwd = pack_layers(layers, ka, 0, 1, hip.OUT_NONE, dev, x3=x3)
 
     # F2: reverse sweep r_l = (r_{l+1} * s_l) W_l, starting from row 0 of the last layer (init table with one row)
     layers = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=mul_aux)]
@@ -488,24 +493,24 @@ def pack_geo_chains(weights, biases, skips, d_pe, single_dump=False):
     # of a hidden-type layer, the [Q, d_pe] result written densely
     layers.append(dict(w_act=_t(W[0]), bias=_zeros(64, dev), act=hip.ACT_NONE))
     assert 32 < d_pe <= 64
-    sweep = pack_layers(layers, ka, 0, d_pe, hip.OUT_NONE, dev)
+    sweep = pack_layers(layers, ka, 0, d_pe, hip.OUT_NONE, dev, x3=x3)
 
     # B1: adjoint of the sweep: du_l = dR_l W_l^T ; dR_{l+1} = du_l * s_l ; dS_l = du_l * R_{l+1}
     layers = [dict(bias=zeros, act=mul2, **fwd_in(l)) for l in range(n - 1)]
-    sweep_bwd = pack_layers(layers, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
+    sweep_bwd = pack_layers(layers, ka, 0, 0, hip.OUT_NONE, dev, has_final=False, x3=x3)
 
     # B2: adjoint of the value pass: da_l = W_l^T dz_l ; dz_{l-1} = s (da + 100 dS (1 - s))   [or s * da without sweep]
     def value_bwd(act):
         ls = [dict(init_a=DIRECT_INIT, init_b=None, w_act=_t(W[n - 1][1:]), bias=zeros, act=act)]
         for l in range(n - 2, 0, -1):
             ls.append(dict(w_act=_t(W[l]), bias=zeros, act=act))
-        return pack_layers(ls, ka, 0, 0, hip.OUT_NONE, dev, has_final=False)
+        return pack_layers(ls, ka, 0, 0, hip.OUT_NONE, dev, has_final=False, x3=x3)
 
     return dict(fwd=fwd, sweep=sweep, sweep_bwd=sweep_bwd, value_bwd=value_bwd(sp_bwd),
                 value_bwd_nosweep=value_bwd(mul_aux), d_a=d_a, single_dump=bool(single_dump))
 
 
-def pack_app_chains(weights, biases, d_x):
+def pack_app_chains(weights, biases, d_x, x3=False):
     """stage1 appearance network (stage1/model/network.py:98-106, 128-138): ReLU MLP [d_x + 256] -> 256 x (n-1) -> 3
     whose input is cat[x (points, view encoding, normal: d_x <= 64 columns), 256 geometry features].  The features
     enter the first layer as the chain's initial activations (act_init), x as input-feature k-tiles.
@@ -522,6 +527,8 @@ def pack_app_chains(weights, biases, d_x):
     for l in range(1, n - 1):
         layers.append(dict(w_in=None, w_act=W[l], bias=b[l], act=hip.ACT_RELU))
     layers.append(dict(w_in=None, w_act=W[n - 1], bias=b[n - 1], act=hip.ACT_NONE))
+    # (x3: the backward chain only -- it is linear in its operand once the ReLU masks are fixed; a forward pass with 1e-5 errors
+    #  flips the units that sit at their kink and the first layers' gradients then differ by 2e-3 of their scale: measured)
     fwd = pack_layers(layers, ka, 0, W[n - 1].shape[0], hip.OUT_NONE, dev)
     ls = [dict(init_a=DIRECT_INIT, init_b=None, w_act=None, bias=zeros, act=hip.ACT_RELU_MASK)]
     for l in range(n - 2, 0, -1):
@@ -530,7 +537,7 @@ def pack_app_chains(weights, biases, d_x):
     # final layer of the backward chain: d normal = d z_0 W_0[:, d_x-3:d_x] (the HEAD layer leaves d z_0 in the
     # activation registers), so the [Q, 256] x [256, 3] product needs no pass over the dumped d z_0
     ls.append(dict(w_act=_t(W[0][:, d_x - 3:d_x]), bias=_zeros(32, dev), act=hip.ACT_NONE))
-    bwd = pack_layers(ls, ka, 0, 3, hip.OUT_NONE, dev)
+    bwd = pack_layers(ls, ka, 0, 3, hip.OUT_NONE, dev, x3=x3)
     return dict(fwd=fwd, bwd=bwd)
 
 

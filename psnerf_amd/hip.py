@@ -29,6 +29,7 @@ MAX_LAYERS = 12
 (ACT_NONE, ACT_RELU, ACT_SOFTPLUS100, ACT_RELU_MASK, ACT_MUL_AUX, ACT_MUL2, ACT_SOFTPLUS_BWD,
  ACT_HEAD, ACT_RELU_BITS, ACT_MUL_AUX_A, ACT_MUL2_A, ACT_SOFTPLUS_BWD_A) = range(12)
 OUT_NONE, OUT_SIGMOID, OUT_OCC = range(3)
+W_F32, W_BF16X2 = range(2)  # PsnMlpDesc.w_format / PsnPackItem.format
 
 
 class PsnMlpLayer(ctypes.Structure):
@@ -38,7 +39,7 @@ class PsnMlpLayer(ctypes.Structure):
 
 class PsnMlpDesc(ctypes.Structure):
     _fields_ = [('n_layers', i32), ('n_out', i32), ('out_act', i32), ('in_kt_a', i32), ('in_kt_b', i32),
-                ('init_stride', i32), ('layers', PsnMlpLayer * MAX_LAYERS)]
+                ('init_stride', i32), ('w_format', i32), ('layers', PsnMlpLayer * MAX_LAYERS)]
 
 
 class PsnBf16Desc(ctypes.Structure):
@@ -53,7 +54,7 @@ class PsnScatterItem(ctypes.Structure):
 
 class PsnPackItem(ctypes.Structure):
     _fields_ = [('W', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('ldw', i64), ('rows', i32), ('cols', i32),
-                ('transpose', i32), ('n_mt', i32), ('k_tiles', i32)]
+                ('transpose', i32), ('n_mt', i32), ('k_tiles', i32), ('format', i32)]
 
 
 class PsnWnItem(ctypes.Structure):
@@ -1180,11 +1181,13 @@ PACK_MAX_ITEMS = 24
 
 
 def mlp_pack_layers(plan):
-    """plan: list of (W, transpose, n_mt, k_tiles, dst) like mlp_pack_layer, packed in ONE launch per 24 blocks."""
+    """plan: list of (W, transpose, n_mt, k_tiles, dst[, format = W_F32]) like mlp_pack_layer, packed in ONE launch per 24 blocks."""
     for c0 in range(0, len(plan), PACK_MAX_ITEMS):
         chunk = plan[c0:c0 + PACK_MAX_ITEMS]
         arr = (PsnPackItem * len(chunk))()
-        for e, (W, transpose, n_mt, k_tiles, dst) in zip(arr, chunk):
+        for e, item in zip(arr, chunk):
+            W, transpose, n_mt, k_tiles, dst = item[:5]
+            e.format = item[5] if len(item) > 5 else W_F32
             assert W.dim() == 2 and W.stride(1) == 1 and W.is_cuda and W.dtype == torch.float32
             assert dst.is_contiguous() and dst.numel() == n_mt * k_tiles * 1024
             rows, cols = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])

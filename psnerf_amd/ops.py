@@ -671,7 +671,7 @@ class VisibilityPair(torch.autograd.Function):
         # d z_l = d h_l * relu'(h_l), d h_{l-1} = W_l[:, :256]^T d z_l for l = n-2 .. 0 in ONE register-resident
         # launch (transposed weight packs, activations re-read as masks, every d z_l dumped for the weight GEMMs)
         bits = ctx.bits
-        chain = fused.pack_relu_bwd(list(Ws), ctx.skip_at, bits=bits is not None)
+        chain = fused.pack_relu_bwd(list(Ws), ctx.skip_at, bits=bits is not None, x3=CHAIN_X3)
         DZ = [torch.empty(Q, 256, device=g.device) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
         # (the rank-1 init table d h_{n-2} = g w is formed inside the chain kernel: hip.mlp_infer rank_init)
         chain(None, Q, a_div=1, a_mod=Q, rank_init=(g.reshape(Q, 1), Ws[n - 1].reshape(1, -1).contiguous()),
@@ -745,6 +745,28 @@ class VisibilityPair(torch.autograd.Function):
 # restores the two-dump chains (A/B: tools/dbg/ab_single_dump.py).
 import os as _os
 GEO_SINGLE_DUMP = _os.environ.get('PSN_GEO_SINGLE_DUMP', '1') == '1'
+# Split-bf16 form of the stage-1 chains (experiment, never the headline; BASELINE configs[4] "bf16 MFMA path"): the four geometry
+# chains and the two appearance chains multiply on v_mfma_f32_16x16x32_bf16 -- every fp32 operand as two bf16 pieces, three partial
+# products, fp32 accumulation (csrc/mlp_infer.hip stage_compute_x3; PsnMlpDesc.w_format = PSN_W_BF16X2) -- while the activation
+# programs, dumps and epilogues stay fp32.  ``with ops.chain_precision('bf16x3'):`` around forward AND backward (the packs are
+# rebuilt when the mode changes).
+CHAIN_X3 = _os.environ.get('PSN_CHAIN_X3', '0') == '1'
+
+
+class chain_precision(object):
+    def __init__(self, mode):
+        assert mode in ('fp32', 'bf16x3'), mode
+        self.mode = mode
+
+    def __enter__(self):
+        global CHAIN_X3
+        self.saved, CHAIN_X3 = CHAIN_X3, self.mode == 'bf16x3'
+        return self
+
+    def __exit__(self, *exc):
+        global CHAIN_X3
+        CHAIN_X3 = self.saved
+        return False
 
 
 class GeoFieldFused(torch.autograd.Function):
@@ -968,7 +990,7 @@ class FusedReluNet(torch.autograd.Function):
         if final_sigmoid:
             g = torch.ops.aten.sigmoid_backward(g, out)  # g * (1 - out) * out, one launch
         bits = ctx.bits
-        chain = fused.pack_relu_bwd(list(Ws), skip_at, width=width, bits=bits is not None)
+        chain = fused.pack_relu_bwd(list(Ws), skip_at, width=width, bits=bits is not None, x3=CHAIN_X3)
         DZ = [torch.empty(Q, width, device=dev) for _ in range(n - 1)]  # DZ[j] = d z_{n-2-j}
         masks = [(bits if bits is not None else H)[n - 2 - j] for j in range(n - 1)]
         if Ws[n - 1].shape[0] <= 4:  # d h_{n-2} = g W_last as a rank-k init inside the kernel (albedo / normal nets: 3 outputs)

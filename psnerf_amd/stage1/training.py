@@ -1,10 +1,12 @@
 """Stage-1 train step with the reference's ``Trainer`` interface (stage1/model/training.py:20-60,
 120-198; visualisation is out of scope).  Under data parallelism every rank renders a slice of the
 sampled pixels of the same view and the gradients are summed with one flat-bucket all-reduce."""
+import contextlib
+
 import numpy as np
 import torch
 
-from .. import hip
+from .. import hip, ops
 from ..dist import DataParallel
 from ..optim import FlatAdam
 from .losses import Loss
@@ -46,6 +48,8 @@ class Trainer(object):
         # EXPERIMENT (BASELINE configs[4] bf16 path): the 256 x 256 weight gradients on the bf16 matrix pipe with split operands
         self.wgrad_bf16x6 = bool(cfg.get('wgrad_bf16x6', False))
         self.wgrad_mode = cfg.get('wgrad_precision', 'bf16x6' if self.wgrad_bf16x6 else None)   # 'bf16x6' | 'bf16x3' | 'bf16' | None = the process-wide setting
+        # ... and the matrix work of the geometry / appearance chains as three bf16 partial products (ops.chain_precision): 'bf16x3' | None
+        self.chain_mode = cfg.get('chain_precision', None)
 
     def train_step(self, data, it=None, pix=None, noise=None):
         self.model.train()
@@ -57,12 +61,13 @@ class Trainer(object):
             self.optimizer.attach_grads()  # grads dropped (no launch); step() gathers what autograd hands over with one multi-tensor copy
         else:
             self.optimizer.zero_grad()
-        terms = self.compute_loss(data, it=it, pix=pix, noise=noise)
-        if terms['loss'].requires_grad:
-            if self.wgrad_mode is not None:
-                with hip.wgrad_precision(self.wgrad_mode):
-                    terms['loss'].backward()
-            else:
+        with contextlib.ExitStack() as modes:
+            if self.chain_mode is not None:
+                modes.enter_context(ops.chain_precision(self.chain_mode))
+            terms = self.compute_loss(data, it=it, pix=pix, noise=noise)
+            if terms['loss'].requires_grad:
+                if self.wgrad_mode is not None:
+                    modes.enter_context(hip.wgrad_precision(self.wgrad_mode))
                 terms['loss'].backward()
         if self.dp.enabled:
             self.dp.allreduce_grads(trainable)

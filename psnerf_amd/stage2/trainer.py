@@ -112,6 +112,8 @@ class TrainStep(object):
         # ('train.wgrad_precision' = 'bf16x6' | 'bf16x3' | 'bf16' selects the number of partial products; the flag above = 'bf16x6')
         self.wgrad_mode = conf.get_string('train.wgrad_precision', default='bf16x6' if self.wgrad_bf16x6 else 'fp32')
         self.wgrad_bf16x6 = self.wgrad_mode != 'fp32'
+        self.chain_mode = conf.get_string('train.chain_precision', default='fp32')
+        assert self.chain_mode in ('fp32', 'bf16x3'), self.chain_mode
         self.light_inten_train = self.light_train and conf.get_bool('train.light_inten_train', default=False)
         if not self.light_train:
             self.light_para.requires_grad_(False)
@@ -193,6 +195,14 @@ class TrainStep(object):
         return model_input
 
     def _fwd_bwd(self, model_input, ground_truth, l_slt, noise=None, count=None):
+        if self.chain_mode != 'fp32':
+            # EXPERIMENT (conf train.chain_precision = 'bf16x3'): the backward chains of the 256-wide networks (the V supervised rows of
+            # visibility_net, the normal / albedo networks) as three bf16 partial products (ops.chain_precision)
+            with ops.chain_precision(self.chain_mode):
+                return self._fwd_bwd_exact(model_input, ground_truth, l_slt, noise, count)
+        return self._fwd_bwd_exact(model_input, ground_truth, l_slt, noise, count)
+
+    def _fwd_bwd_exact(self, model_input, ground_truth, l_slt, noise=None, count=None):
         """Forward, losses, backward; under data parallelism the gradients end up in the flat bucket (not yet reduced).
         ``count``: the (global) masked-pixel count as a device tensor [1] when the caller has already formed it (graph replay
         under data parallelism: the count's all-reduce stays outside the captured graph)."""

@@ -423,3 +423,112 @@ def test_wgrad_bf16x6_passes_the_parameter_gradient_gate(cuda):
     assert res[True][0] == res[False][0]
     worst = max(float((res[True][1][k] - res[False][1][k]).abs().max() / res[False][1][k].abs().max().clamp_min(1e-20)) for k in res[False][1])
     assert 0.0 < worst <= 2e-5, worst
+
+
+def test_chain_bf16x3_geometry_field_vs_exact_and_float64(cuda):
+    """The split-bf16 form of the chain engine (PsnMlpDesc.w_format = PSN_W_BF16X2, ops.chain_precision('bf16x3'): the matrix work of
+    stage1/model/network.py:85-120 -- value pass, gradient sweep and their two adjoints -- as three bf16 partial products on
+    v_mfma_f32_16x16x32_bf16, activation programs / dumps / epilogues in fp32) on the geometric-init BEAR network: outputs, the
+    field gradient and every parameter gradient of a double-backward objective against a float64 evaluation by torch autograd;
+    the exact chains on the same inputs are the yardstick.  Bounds: values 1e-4, gradients 1e-3 of the tensor's largest entry
+    (the parameter-gradient bound of the parity gate)."""
+    from psnerf_amd import fused, ops
+    from psnerf_amd.stage1 import NeuralNetwork
+    from tests.helpers import stage1_cfg, stage1_state_dict
+    cfg = stage1_cfg('bear')
+    net = NeuralNetwork(cfg)
+    net.load_state_dict(stage1_state_dict(cfg, seed=21))
+    net.to(cuda)
+    params = [p.detach().clone().requires_grad_() for p in net._geo_params()]
+    P64 = [p.detach().double().requires_grad_() for p in params]
+    Q = 3000
+    pts = ((torch.rand(Q, 3, generator=torch.Generator().manual_seed(3)) - 0.5) * 1.6).to(cuda)
+    octaves, skips, scale = net.octaves_pe, tuple(net.skips), 1.0 / net.rescale
+
+    def objective(logit, feat, grad):
+        return torch.sigmoid(logit * -10.0).sum() + feat.sum() * 0.1 + (grad * grad).sum()
+
+    def run(mode):
+        for p in params:
+            p.grad = None
+        with ops.chain_precision(mode):
+            chains = fused.pack_geo_chains(params[0::2], params[1::2], list(skips), net.d_pe, single_dump=ops.GEO_SINGLE_DUMP, x3=ops.CHAIN_X3)
+            logit, feat, grad = ops.GeoFieldFused.apply(pts, octaves, scale, skips, True, chains, None, *params)
+            objective(logit, feat, grad).backward()
+        return [logit.detach(), feat.detach(), grad.detach()] + [p.grad.clone() for p in params]
+
+    x = pts.double().requires_grad_()
+    xs = x * scale
+    pe = torch.cat([xs] + [f(xs * 2.0 ** k) for k in range(octaves) for f in (torch.sin, torch.cos)], -1)
+    h = pe
+    n = len(P64) // 2
+    for l in range(n):
+        if l in skips:
+            h = torch.cat([h, pe], -1)  # (effective weights: the 1 / sqrt(2) of network.py:90-91 is folded in)
+        h = h @ P64[2 * l].t() + P64[2 * l + 1]
+        if l < n - 1:
+            h = torch.nn.functional.softplus(h, beta=100)
+    g64 = torch.autograd.grad(h[:, :1].sum(), x, create_graph=True)[0]
+    objective(h[:, :1], h[:, 1:], g64).backward()
+    ref = [h[:, :1].detach(), h[:, 1:].detach(), g64.detach()] + [p.grad for p in P64]
+    err = {}
+    for mode in ('fp32', 'bf16x3'):
+        got = run(mode)
+        err[mode] = [float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(got, ref)]
+    print('values (logit, feat, grad) fp32 %s  bf16x3 %s' % (err['fp32'][:3], err['bf16x3'][:3]))
+    print('worst parameter gradient fp32 %.2e  bf16x3 %.2e' % (max(err['fp32'][3:]), max(err['bf16x3'][3:])))
+    assert max(err['fp32'][:2]) < 2e-5 and max(err['fp32'][2:]) < 1e-4, err['fp32']     # (the reference point: exact chains)
+    assert max(err['bf16x3'][:2]) < 1e-4, err['bf16x3'][:3]
+    assert max(err['bf16x3'][2:]) < 1e-3, err['bf16x3']
+    assert max(err['bf16x3'][3:]) > max(err['fp32'][3:])   # (the split form really ran)
+    # the fp32 entry points refuse the format
+    from psnerf_amd import hip
+    pk = fused.pack_geo_chains(params[0::2], params[1::2], list(skips), net.d_pe, x3=True)['fwd']
+    assert pk.desc.w_format == hip.W_BF16X2
+    with pytest.raises(RuntimeError, match='fp32 weight stages'):
+        pk.on_points(pts, octaves, scale)
+
+
+def test_chain_bf16x3_train_steps_vs_exact(cuda):
+    """cfg training.chain_precision = 'bf16x3' (stage 1) and conf train.chain_precision = 'bf16x3' (stage 2; the V-row and
+    normal / albedo backward chains): loss and every parameter gradient of one train step against the exact step on the same
+    inputs and draws, within the parity gate's parameter-gradient bound (1e-3 of the tensor's largest entry)."""
+    from psnerf_amd import stage2 as s2
+    from psnerf_amd.stage1 import NeuralNetwork, Renderer, Trainer
+    from psnerf_amd.synthetic import stage1_batch
+    from tests.helpers import stage1_cfg, stage1_state_dict
+    from tests.test_stage2_gpu import _run
+    res = {}
+    for mode in (None, 'bf16x3'):
+        cfg = stage1_cfg('bunny', **{'training.n_training_points': 256, 'training.chain_precision': mode})
+        net = NeuralNetwork(cfg)
+        net.load_state_dict(stage1_state_dict(cfg, seed=21))
+        tr = Trainer(Renderer(net, cfg, device=cuda), torch.optim.SGD(net.parameters(), lr=0.0), cfg, device=cuda)
+        assert tr.chain_mode == mode
+        batch = {k: v.to(cuda) for k, v in stage1_batch(cfg, h=48, w=64, seed=4).items()}
+        gen = torch.Generator().manual_seed(5)
+        pix = torch.stack([torch.randint(0, 64, (256,), generator=gen).float(), torch.randint(0, 48, (256,), generator=gen).float()], -1)[None]
+        noise = {'full': torch.rand(256, 64, generator=gen).to(cuda), 'nbr_full': torch.rand(256, 3, generator=gen).to(cuda)}
+        terms = tr.train_step(batch, it=1500, pix=pix, noise=noise)
+        res[mode] = (float(terms['loss'].detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    assert abs(res['bf16x3'][0] - res[None][0]) <= 1e-4 * abs(res[None][0]), (res['bf16x3'][0], res[None][0])
+    worst = max(float((res['bf16x3'][1][k] - res[None][1][k]).abs().max() / res[None][1][k].abs().max().clamp_min(1e-20)) for k in res[None][1])
+    print('stage 1: loss %.6f / %.6f, worst parameter gradient difference %.2e' % (res['bf16x3'][0], res[None][0], worst))
+    assert 0.0 < worst <= 1e-3, worst
+    # stage 2
+    sd = stage2_state_dict(s2.bear_conf(), seed=5)
+    N, L, V = 3000, 5, 8
+    inp, gt = stage2_inputs(N, L, V, seed=N)
+    ns = int(inp['surface_mask'].sum())
+    nz = torch.randn(ns, 3, generator=torch.Generator().manual_seed(1)) * 0.01
+    from psnerf_amd import ops
+    grads = {}
+    for mode in ('fp32', 'bf16x3'):
+        net2 = s2.PSNetwork(s2.bear_conf())
+        net2.load_state_dict(sd)
+        net2.to(cuda)
+        with ops.chain_precision(mode):
+            grads[mode] = _run(net2, s2.MainLoss, s2.NormalLoss, inp, gt, 2, nz, cuda)[2]
+    worst2 = max(float((grads['bf16x3'][k] - grads['fp32'][k]).abs().max() / grads['fp32'][k].abs().max().clamp_min(1e-20)) for k in grads['fp32'])
+    print('stage 2: worst parameter gradient difference %.2e' % worst2)
+    assert 0.0 < worst2 <= 1e-3, worst2

@@ -32,26 +32,30 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from psnerf_amd import hip
     assert ctypes.sizeof(hip.PsnMlpLayer) == 40
-    assert ctypes.sizeof(hip.PsnMlpDesc) == 24 + 12 * 40
+    assert ctypes.sizeof(hip.PsnMlpDesc) == 32 + 12 * 40       # 7 x int32 (w_format since round 5), padded to 8, + the layers
+    assert ctypes.sizeof(hip.PsnPackItem) == 48                # 2 pointers + int64 + 6 x int32 (format since round 5)
     assert ctypes.sizeof(hip.PsnBf16Desc) == 16 + 16          # 4 x int32 + uint8[PSN_MLP_MAX_LAYERS + 4]
     assert ctypes.sizeof(hip.PsnWnItem) == 64                  # 6 pointers + 2 x int32 + float, padded to 8
 
 
-def test_view_batch_struct_layout_against_the_c_compiler(tmp_path):
-    """PsnViewBatch (the descriptor of the on-device batch assembly, psn_view_batch) mixes pointers, int64 and int fields: its
-    ctypes mirror is compared with what gcc makes of include/psnerf_hip.h, field by field."""
+@pytest.mark.parametrize('struct', ['PsnViewBatch', 'PsnMlpDesc', 'PsnPackItem'])
+def test_struct_layout_against_the_c_compiler(tmp_path, struct):
+    """PsnViewBatch (the descriptor of the on-device batch assembly, psn_view_batch) mixes pointers, int64 and int fields, and
+    PsnMlpDesc / PsnPackItem grew a field in round 5 (the weight-stage format): the ctypes mirrors are compared with what gcc
+    makes of include/psnerf_hip.h, field by field."""
     import os, subprocess
     from psnerf_amd import hip
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    fields = [f[0] for f in hip.PsnViewBatch._fields_]
+    cls = getattr(hip, struct)
+    fields = [f[0] for f in cls._fields_]
     src = tmp_path / 'layout.c'
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "psnerf_hip.h"\nint main(void) {\n  printf("%zu\\n", sizeof(PsnViewBatch));\n'
-                   + ''.join('  printf("%%zu\\n", offsetof(PsnViewBatch, %s));\n' % f for f in fields) + '  return 0;\n}\n')
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "psnerf_hip.h"\nint main(void) {\n  printf("%%zu\\n", sizeof(%s));\n' % struct
+                   + ''.join('  printf("%%zu\\n", offsetof(%s, %s));\n' % (struct, f) for f in fields) + '  return 0;\n}\n')
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert got[0] == ctypes.sizeof(hip.PsnViewBatch)
-    assert got[1:] == [getattr(hip.PsnViewBatch, f).offset for f in fields]
+    assert got[0] == ctypes.sizeof(cls)
+    assert got[1:] == [getattr(cls, f).offset for f in fields]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only check')

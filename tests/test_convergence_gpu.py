@@ -131,13 +131,18 @@ def _stage2_draws(views, n_steps, seed=6):
     return [torch.randn(int(views[it % len(views)][0]['surface_mask'].sum()), 3, generator=g) * 0.01 for it in range(n_steps)]
 
 
-@pytest.fixture(params=['fp32', 'bf16x6', 'bf16x3'])
+@pytest.fixture(params=['fp32', 'bf16x6', 'bf16x3', 'chains_bf16x3'])
 def wgrad(request):
-    """The synchronised-window tests run twice: with the exact fp32 weight-gradient kernel and with the split-bf16 experiment
-    (psn_gemm_tn_grouped_x3 through hip.wgrad_precision) -- the same bounds hold for both."""
-    from psnerf_amd import hip
-    with hip.wgrad_precision(request.param):
-        yield request.param
+    """The synchronised-window tests run with the exact fp32 weight-gradient kernel, with the split-bf16 experiments
+    (psn_gemm_tn_grouped_x3 through hip.wgrad_precision: six / three partial products) and with the chains' matrix work on the
+    bf16 pipe as well (ops.chain_precision('bf16x3') beside the three-product weight gradients) -- the same bounds hold for all."""
+    from psnerf_amd import hip, ops
+    if request.param == 'chains_bf16x3':
+        with hip.wgrad_precision('bf16x3'), ops.chain_precision('bf16x3'):
+            yield request.param
+    else:
+        with hip.wgrad_precision(request.param):
+            yield request.param
 
 
 def test_stage2_300_steps_synchronised_windows(cuda, wgrad):
