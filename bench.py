@@ -347,6 +347,7 @@ def stage1_measure(device, steps=10, warmup=5, rays=4096):
         # (ops.chain_precision('bf16x3')) beside the three-product weight gradients: every MFMA of the step on the bf16 pipe
         # except the (latency-bound) root finder
         from psnerf_amd import ops
+        net.inference_precision = 'bf16x3'   # (the ray-march sweep through the exact engine's kernel on split-bf16 weight stages)
         with ops.chain_precision('bf16x3'), hip.wgrad_precision('bf16x3'):
             for _ in range(3):
                 tr.train_step(batch, it=it)
@@ -357,13 +358,13 @@ def stage1_measure(device, steps=10, warmup=5, rays=4096):
                 terms_c = tr.train_step(batch, it=it)
             torch.cuda.synchronize()
             dtc = (time.perf_counter() - t0) / steps
+        net.inference_precision = 'bf16x6'
         net.invalidate_packs()
         out['bf16x3_chains_experiment'] = {
             'value': round(rays * S / dtc, 1), 'unit': 'ray-samples/s', 'ms_per_step': round(dtc * 1e3, 3), 'steps': steps,
             'loss': round(float(terms_c['loss'].detach()), 6),
-            'dtype': 'f32 emulated on the bf16 matrix pipe: 2 x bf16 split operands, 3 partial products, f32 accumulate (~16 significant bits); '
-                     'ray-march sweep: 3 x bf16, 6 products',
-            'scope': "ops.chain_precision('bf16x3') + hip.wgrad_precision('bf16x3') + inference_precision 'bf16x6': value pass, gradient sweep, "
+            'dtype': 'f32 emulated on the bf16 matrix pipe: 2 x bf16 split operands, 3 partial products, f32 accumulate (~16 significant bits)',
+            'scope': "ops.chain_precision('bf16x3') + hip.wgrad_precision('bf16x3') + inference_precision 'bf16x3': value pass, gradient sweep, "
                      'their adjoints, the appearance chains (activation programs, dumps, epilogues f32), the 256 x 256 weight gradients and the '
                      'ray-march sweep; root finder, composite, losses, Adam: exact f32.  Gates: tests/test_bf16_gpu.py (parameter gradients vs '
                      'the exact step), tests/test_convergence_gpu.py (synchronised windows)'}
@@ -866,6 +867,24 @@ def main():
                                               'loss': round(float(terms6_['total'].detach()), 6),
                                               'scope': "shading rows bf16x6 + ops.chain_precision('bf16x3') + hip.wgrad_precision('bf16x3') "
                                                        '(2 x bf16 split operands, 3 partial products, ~16 significant bits; gates: tests/test_bf16_gpu.py)'}
+            step.model.train_vis_bf16x6, step.model.train_vis_bf16x3 = False, True
+            try:
+                with hip.wgrad_precision('bf16x3'), ops.chain_precision('bf16x3'):
+                    # the shading rows through the exact engine's own kernel on split-bf16 weight stages (PSN_W_BF16X2, three products)
+                    dt7_, ns7_, terms7_ = timed(inp, gt, k4, 3)
+                    ev7 = instrumented(inp, gt, 5)
+                lk = [(r, a.elapsed_time(b)) for (name, r, a, b, _f) in ev7 if name == 'mlp_infer' and r >= 1000000]
+                x6['all_bf16x3'] = {'value': round(ns7_ * N_LIGHTS / (dt7_ / k4), 1), 'ms_per_step': round(dt7_ / k4 * 1e3, 3),
+                                    'loss': round(float(terms7_['total'].detach()), 6),
+                                    'dtype': 'f32 emulated on the bf16 matrix pipe: 2 x bf16 split operands, 3 partial products, f32 accumulate (~16 significant bits)',
+                                    'scope': "conf train.vis_bf16x3 (shading rows: mlp_infer_kernel on PSN_W_BF16X2 stages) + ops.chain_precision('bf16x3') + "
+                                             "hip.wgrad_precision('bf16x3'); the V rows' forward, the 128-wide network, shading, losses, Adam: exact f32.  "
+                                             'Gates: tests/test_bf16_gpu.py (the exact path\'s oracle gate; parameter gradients; convergence windows)'}
+                if lk:
+                    x6['all_bf16x3']['shading_rows_kernel'] = {'rows_per_launch': lk[0][0], 'avg_launch_ms': round(sum(t for _, t in lk) / len(lk), 3),
+                                                               'f32_equivalent_tflops': round(2.0 * VIS_MACS * lk[0][0] / (sum(t for _, t in lk) / len(lk) * 1e-3) / 1e12, 1)}
+            finally:
+                step.model.train_vis_bf16x6, step.model.train_vis_bf16x3 = True, False
             if xk:
                 rows_x, ms_x = xk[0][0], sum(t for _, t in xk) / len(xk)
                 eq = 2.0 * VIS_MACS * rows_x / (ms_x * 1e-3) / 1e12

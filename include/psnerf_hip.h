@@ -233,8 +233,9 @@ typedef struct {
     int in_kt_a;  /* K tiles (of 32 floats) per row of feature table A (1..4) */
     int in_kt_b;  /* K tiles per row of table B (0 = unused); in_kt_a + in_kt_b <= 4 */
     int init_stride; /* floats per row of the init tables (multiple of the hidden width), 0 if no layer uses init_off */
-    int w_format; /* PSN_W_F32, or PSN_W_BF16X2 (experiment; psn_mlp_infer chain launches of the 256-wide networks only): every block
-                     with n_mt >= 2 is packed as two bf16 planes and multiplied as three bf16 partial products, see PsnPackItem.format */
+    int w_format; /* PSN_W_F32, or PSN_W_BF16X2 (experiment; 256-wide networks through psn_mlp_infer* / psn_mlp_infer_pe* /
+                     psn_march_sweep, not psn_root_find): every block with n_mt >= 2 is packed as two bf16 planes and multiplied as
+                     three bf16 partial products, see PsnPackItem.format */
     PsnMlpLayer layers[PSN_MLP_MAX_LAYERS];
 } PsnMlpDesc;
 

@@ -447,11 +447,11 @@ __device__ __forceinline__ void wait_for_weights(int stores) {
 // the untrimmed visibility launch 0.7 %).
 // FROMA (chain variant): the MUL_AUX / MUL2 / SOFTPLUS_BWD programs take the dumped softplus OUTPUT as a1 and re-form the sigmoid
 // (single-dump experiment, PSN_ACT_*_A on the host side).
-// X3 (chain variant, NMT = 16): the weight stages hold two bf16 planes (PSN_W_BF16X2) and the matrix work runs as three bf16 partial
+// X3 (NMT = 16; chain launches, and the gradient-free lean launches SRC = 0 / 2 / 3): the weight stages hold two bf16 planes (PSN_W_BF16X2) and the matrix work runs as three bf16 partial
 // products (stage_compute_x3); the final layer of a launch with n_out <= 32 stays fp32 (its block is packed PSN_W_F32).
 template <bool CHAIN, int NMT, int SRC = 0, bool TRIM = false, bool FROMA = false, bool X3 = false>  // NMT = hidden width / 16: 16 (256-wide networks), 8 (128-wide) or 4 (64-wide)
 __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
-    static_assert(!X3 || (CHAIN && NMT == 16 && SRC == 0), "split-bf16 stages: 256-wide chain launches only");
+    static_assert(!X3 || (NMT == 16 && SRC != 1), "split-bf16 stages: 256-wide networks; the root finder stays fp32");
     constexpr int W = 16 * NMT;
     // LDS-DMA flavour (common.h lds_dma_16): asm pieces + explicit scheduling regions for the lean variant (exact lgkmcnt
     // waits: visibility launch +1.9 %, march sweep +4 %), the builtin + scheduling groups for the chain variant (its
@@ -1391,8 +1391,11 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
     PSN_CHECK_ARG(!from_a || (hid == 8 && chain && !base_mul), "mlp_infer: the single-dump programs (PSN_ACT_*_A) exist for the 256-wide chain engine and do not mix with their base programs");
     const bool x3 = d.w_format == PSN_W_BF16X2;
     PSN_CHECK_ARG(d.w_format == PSN_W_F32 || x3, "mlp_infer: unknown weight format %d", d.w_format);
-    PSN_CHECK_ARG(!x3 || (hid == 8 && chain), "mlp_infer: split-bf16 weight stages (PSN_W_BF16X2) are built for chain launches of the 256-wide networks only");
-    if (x3) {
+    PSN_CHECK_ARG(!x3 || hid == 8, "mlp_infer: split-bf16 weight stages (PSN_W_BF16X2) are built for the 256-wide networks only");
+    if (x3 && !chain) {
+        if (trim) hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 0, true, false, true>), grid, block, lds_bytes, st, a);
+        else hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 0, false, false, true>), grid, block, lds_bytes, st, a);
+    } else if (x3) {
         if (from_a) {
             if (trim) hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, true, true, true>), grid, block, lds_bytes, st, a);
             else hipLaunchKernelGGL((mlp_infer_kernel<true, 16, 0, false, true, true>), grid, block, lds_bytes, st, a);
@@ -1471,7 +1474,7 @@ static int mlp_infer_pe_impl(const PsnMlpDesc* desc, const float* packed_w, cons
     PSN_CHECK_ARG(desc && packed_w && packed_b && points && out, "mlp_infer_pe: null pointer");
     const PsnMlpDesc& d = *desc;
     PSN_CHECK_ARG(d.n_layers >= 2 && d.n_layers <= PSN_MLP_MAX_LAYERS && d.n_out >= 1 && d.n_out <= 32, "mlp_infer_pe: n_layers=%d n_out=%d", d.n_layers, d.n_out);
-    PSN_CHECK_ARG(d.w_format == PSN_W_F32, "mlp_infer_pe: fp32 weight stages only");
+    PSN_CHECK_ARG(d.w_format == PSN_W_F32 || d.w_format == PSN_W_BF16X2, "mlp_infer_pe: unknown weight format %d", d.w_format);
     PSN_CHECK_ARG(d.out_act >= PSN_OUT_NONE && d.out_act <= PSN_OUT_OCC, "mlp_infer_pe: out_act=%d", d.out_act);
     PSN_CHECK_ARG(d.in_kt_a == 2 && d.in_kt_b == 0 && 3 + 6 * pe_octaves <= 64 && pe_octaves >= 0,
                   "mlp_infer_pe: the input block is one 64-column positional encoding (in_kt_a = 2), got in_kt_a=%d octaves=%d", d.in_kt_a, pe_octaves);
@@ -1495,7 +1498,8 @@ static int mlp_infer_pe_impl(const PsnMlpDesc* desc, const float* packed_w, cons
     const int64_t blocks = (n_rows + kWaves * 16 - 1) / (kWaves * 16);
     PSN_CHECK_ARG(blocks < (1ll << 31), "mlp_infer_pe: too many rows");
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
-    hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 2, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    if (d.w_format == PSN_W_BF16X2) hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 2, true, false, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 2, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("mlp_infer_pe");
     return PSN_OK;
 }
@@ -1529,7 +1533,7 @@ extern "C" int psn_march_sweep(const PsnMlpDesc* desc, const float* packed_w, co
     const PsnMlpDesc& d = *desc;
     PSN_CHECK_ARG(d.n_layers >= 2 && d.n_layers <= PSN_MLP_MAX_LAYERS && d.n_out == 1 && d.out_act == PSN_OUT_OCC,
                   "march_sweep: expects an occupancy network (one output, PSN_OUT_OCC)");
-    PSN_CHECK_ARG(d.w_format == PSN_W_F32, "march_sweep: fp32 weight stages only");
+    PSN_CHECK_ARG(d.w_format == PSN_W_F32 || d.w_format == PSN_W_BF16X2, "march_sweep: unknown weight format %d", d.w_format);
     PSN_CHECK_ARG(d.in_kt_a == 2 && d.in_kt_b == 0 && 3 + 6 * pe_octaves <= 64 && pe_octaves >= 0,
                   "march_sweep: the input block is one 64-column positional encoding (in_kt_a = 2), got in_kt_a=%d octaves=%d", d.in_kt_a, pe_octaves);
     PSN_CHECK_ARG(d.layers[0].n_kt_in == 2 && d.layers[0].n_kt_act == 0, "march_sweep: layer 0 reads the encoding as k-tiles");
@@ -1554,7 +1558,8 @@ extern "C" int psn_march_sweep(const PsnMlpDesc* desc, const float* packed_w, co
     const int64_t blocks = n_rays * (n_steps / (kWaves * 16));
     PSN_CHECK_ARG(blocks < (1ll << 31), "march_sweep: too many rows");
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256 + kWaves * 16) * sizeof(float);
-    hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 3, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    if (d.w_format == PSN_W_BF16X2) hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 3, true, false, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 3, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
     PSN_CHECK_LAUNCH("march_sweep");
     return PSN_OK;
 }

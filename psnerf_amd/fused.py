@@ -231,7 +231,7 @@ def pack_layers(layers, in_kt_a, in_kt_b, n_out, out_act, device, has_final=True
     return pk
 
 
-def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, precompute=True, width=256, reuse=None):
+def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, precompute=True, width=256, reuse=None, x3=False):
     """stage2 Network / Normal_Network (stage2/model/renderer.py:17-49) of width 256: ReLU stack, the
     input is concatenated AFTER layer ``skip_at``.  Input row = [table A (din_a real cols, padded to
     a multiple of 32) | table B (din_b)].  precompute=True evaluates the input block of layer 0 and of the
@@ -262,7 +262,7 @@ def pack_relu_mlp(weights, biases, din_a, din_b, skip_at, out_act=hip.OUT_NONE, 
         else:
             layers.append(dict(w_act=W, bias=b, act=act))
     assert all(L['bias'].shape[0] == width for L in layers[:-1]), 'fused path: every hidden layer must have the given width'
-    return pack_layers(layers, ka, kb, weights[-1].shape[0], out_act, weights[0].device, width=width, reuse=reuse)
+    return pack_layers(layers, ka, kb, weights[-1].shape[0], out_act, weights[0].device, width=width, reuse=reuse, x3=x3)
 
 
 class PackedBf16(object):
@@ -405,7 +405,7 @@ def pack_relu_mlp_bf16_grouped(weights, biases, din_a, din_b, skip_at, out_act=h
     return PackedBf16Grouped(desc, buf, fb, wb_t.contiguous(), torch.cat(b_in).contiguous())
 
 
-def pack_geo_occupancy(weights, biases, skips, d_pe):
+def pack_geo_occupancy(weights, biases, skips, d_pe, x3=False):
     """stage1 occupancy-only network (stage1/model/network.py:85-95,124-125): softplus(beta=100)
     stack, before layer l in ``skips`` the input becomes cat[x, pe]/sqrt(2); only output row 0 of the
     last layer is evaluated, followed by sigmoid(-10 x).  Every query point is distinct, so the input
@@ -427,7 +427,7 @@ def pack_geo_occupancy(weights, biases, skips, d_pe):
             layers.append(dict(w_in=W[:, d_x:] * inv, w_act=W[:, :d_x] * inv, bias=b, act=act))
         else:
             layers.append(dict(w_in=None, w_act=W, bias=b, act=act))
-    return pack_layers(layers, ka, 0, 1, hip.OUT_OCC, weights[0].device)
+    return pack_layers(layers, ka, 0, 1, hip.OUT_OCC, weights[0].device, x3=x3)
 
 
 def pack_relu_bwd(weights, skip_at, width=256, bits=False, x3=False):

@@ -89,6 +89,8 @@ class NeuralNetwork(nn.Module):
         self.inference_precision = 'fp32'
         self._packed_x3 = None
         self._packed_x3_key = None
+        self._packed_b3 = None
+        self._packed_b3_key = None
         self._chains = None
         self._chains_key = None
         self._app_packed = None
@@ -195,8 +197,20 @@ class NeuralNetwork(nn.Module):
     def _occupancy_packed(self, allow_x3=False):
         """The packed occupancy network of the exact-fp32 engine; ``allow_x3``: callers that only use ``.on_points`` get the
         split-bf16 pack instead when the module's ``inference_precision`` is 'bf16x6' (opt-in, gradient-free queries)."""
-        if allow_x3 and getattr(self, 'inference_precision', 'fp32') == 'bf16x6' and not torch.is_grad_enabled():
+        prec = getattr(self, 'inference_precision', 'fp32')
+        if allow_x3 and prec == 'bf16x6' and not torch.is_grad_enabled():
             return self._occupancy_packed_x3()
+        if allow_x3 and prec == 'bf16x3' and not torch.is_grad_enabled():
+            # the exact engine's kernels on split-bf16 weight stages (two bf16 pieces per operand, three partial products:
+            # PsnMlpDesc.w_format = PSN_W_BF16X2; ~1e-5 relative) -- same call surface, the sweep included
+            key = self._params_key()
+            if getattr(self, '_packed_b3', None) is None or self._packed_b3_key != key:
+                with torch.no_grad():
+                    Ws = self._effective('lin', self.n_geo, [1.0] * self.n_geo)
+                    bs = [getattr(self, 'lin%d' % l).bias for l in range(self.n_geo)]
+                    self._packed_b3 = fused.pack_geo_occupancy(Ws, bs, self.skips, self.d_pe, x3=True)
+                self._packed_b3_key = key
+            return self._packed_b3
         key = self._params_key()
         if self._packed is None or self._packed_key != key:
             with torch.no_grad():

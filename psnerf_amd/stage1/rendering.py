@@ -151,7 +151,7 @@ class Renderer(nn.Module):
             # one launch: sweep points generated and encoded in the occupancy kernel, a workgroup = 64 consecutive steps of
             # one ray, and the blocks behind a ray's first sign change are not evaluated (psn_march_sweep; the reference's
             # result depends on nothing behind it, rendering.py:472-504)
-            packed = m._occupancy_packed()
+            packed = m._occupancy_packed(allow_x3=True)  # ('bf16x3': the same kernel on split-bf16 weight stages; otherwise the exact pack)
             occ, _ = hip.march_sweep(packed.desc, packed.w, packed.b, ray0.reshape(-1, 3).contiguous(),
                                      ray_direction.reshape(-1, 3).contiguous(), far.reshape(-1), u[0], u[1], float(depth_range[0]),
                                      n_steps, tau, m.octaves_pe, 1.0 / m.rescale, early_exit=self.EARLY_EXIT,

@@ -190,6 +190,9 @@ class PSNetwork(nn.Module):
         # i.e. fp32-class arithmetic -- every operand as three bf16 planes, six partial products per multiply -- on the bf16
         # matrix pipe.  inference_precision = 'bf16x6' selects it for gradient-free evaluations.
         self.train_vis_bf16x6 = conf.get_bool('train.vis_bf16x6', default=False)
+        # ... or through the exact engine's own kernel on split-bf16 weight stages (two bf16 pieces per operand, three partial
+        # products, ~1e-5 relative: PsnMlpDesc.w_format = PSN_W_BF16X2); inference_precision = 'bf16x3' for evaluations
+        self.train_vis_bf16x3 = conf.get_bool('train.vis_bf16x3', default=False)
         # The BRDF / normal networks of a training forward (and, through autograd, their backward) run on a side stream
         # beside the visibility launch (20 of the 27 ms of a step; it is issued first and needs none of their results):
         # Ns-row launches of 25 - 70 us each, latency-bound on their own, fill the gaps of the big launch instead of
@@ -249,6 +252,8 @@ class PSNetwork(nn.Module):
         net = self.visibility_net
         Ws, bs = net.weights()
         cols = self._cols(self.n_freqs, pe_x.device, pair=True)
+        if (fused_ok and net.width == 256 and self.inference_precision == 'bf16x3' and not torch.is_grad_enabled() and pe_x.is_cuda):
+            return self._visibility_rows_b3(pe_x, pe_l)
         if (fused_ok and net.width == 256 and self.inference_precision in ('bf16', 'bf16x6') and not torch.is_grad_enabled()
                 and len(Ws) <= 12 and pe_x.is_cuda):
             # opt-in bf16 MFMA engines (evaluation / relighting): plain bf16 (csrc/mlp_infer_bf16.hip) or the split form with
@@ -309,6 +314,21 @@ class PSNetwork(nn.Module):
                                                               hip.OUT_SIGMOID if net.final == 'sigmoid' else hip.OUT_NONE)
             self._vis_packx3_key = key
         return self._vis_packx3(pe_x.contiguous(), pe_l.contiguous())
+
+    @torch.no_grad()
+    def _visibility_rows_b3(self, pe_x, pe_l):
+        """Gradient-free visibility_net rows (light-major) through the exact engine's kernel on split-bf16 weight stages (experiment)."""
+        net = self.visibility_net
+        key = params_key(net.parameters(), getattr(self, '_pack_epoch', 0))
+        if getattr(self, '_vis_packb3_key', None) != key:
+            Ws, bs = net.weights()
+            half = 3 + 6 * self.n_freqs
+            self._vis_packb3 = fused.pack_relu_mlp(list(Ws), list(bs), half, half, net._skip_index(),
+                                                   out_act=hip.OUT_SIGMOID if net.final == 'sigmoid' else hip.OUT_NONE,
+                                                   reuse=getattr(self, '_vis_packb3', None), x3=True)
+            self._vis_packb3_key = key
+        ns, nl = pe_x.shape[0], pe_l.shape[0]
+        return self._vis_packb3(pe_x.contiguous(), nl * ns, a_div=1, a_mod=ns, tab_b=pe_l.contiguous(), b_div=ns, b_mod=nl)
 
     def _memo(self, tag, input, fn):
         """Light-independent intermediate of a gradient-free evaluation, computed once per (pixel set, weights) while a
@@ -411,11 +431,12 @@ class PSNetwork(nn.Module):
                     if side is None:
                         side = self._side[device] = torch.cuda.Stream(device=device)  # (a high-priority stream: +-0.05 ms/step at 32768 px; round 5 at 4096 px: 3.76 -> 3.78 ms, 32768 px eager 25.1 -> 27.1 ms)
                     side.wait_stream(torch.cuda.current_stream(device))
-                if self.train_vis_bf16 or self.train_vis_bf16x6:
+                if self.train_vis_bf16 or self.train_vis_bf16x6 or self.train_vis_bf16x3:
                     # opt-in (train.vis_bf16 / train.vis_bf16x6): the L shading rows enter the loss detached (renderer.py:197),
                     # so they can run on a bf16 engine; the V supervised rows stay on the exact fp32 path with their dumps
                     pe_l0 = self._pe(ld0.detach(), self.n_freqs)
-                    vis_bf16 = self._visibility_rows_x3(pe_x, pe_l0) if self.train_vis_bf16x6 else self._visibility_rows_bf16(pe_x, pe_l0)
+                    vis_bf16 = (self._visibility_rows_b3(pe_x, pe_l0) if self.train_vis_bf16x3 else
+                                self._visibility_rows_x3(pe_x, pe_l0) if self.train_vis_bf16x6 else self._visibility_rows_bf16(pe_x, pe_l0))
                     vis_pair = self._visibility_pair_launch(pe_x, ld0[:0], lv0)
                 else:
                     # 'surface_count' (float32 [1] on the device, beside a 'surface_idx' padded to a fixed capacity -- hip.surface_index,
