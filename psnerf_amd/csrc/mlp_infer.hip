@@ -230,7 +230,7 @@ __device__ __forceinline__ void chain_split(const floatx4& b0, const floatx4& b1
     hi = __builtin_bit_cast(cbf16x8, h);
     mid = __builtin_bit_cast(cbf16x8, m);
 }
-template <int NMT, int NACC, typename RequestNext>
+template <int NMT, int NACC, bool PIN, typename RequestNext>
 __device__ __forceinline__ void stage_compute_x3(floatx4 (&acc)[NACC], const floatx4& b0, const floatx4& b1,
                                                  const float4* __restrict__ wl_, int lane, RequestNext request_next) {
     const cbf16x8* wl = reinterpret_cast<const cbf16x8*>(wl_);
@@ -259,6 +259,22 @@ __device__ __forceinline__ void stage_compute_x3(floatx4 (&acc)[NACC], const flo
             }
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc[m0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ag[m], bh, acc[m0 + m], 0, 0, 0);
+            // PIN (chain launches: builtin LDS-DMA pieces, which the VMEM scheduling group matches; measured chains -2.7 %, the lean
+            // launch with its asm pieces +12 %, and with the fp32 stage's scheduling regions instead +-0: it is bound by the LDS reads): the order as in the fp32 stage -- the next group's 8 fragment reads (and, in group 0,
+            // the LDS-DMA pieces of the next stage) spread over this group's first 8 MFMAs
+            if constexpr (PIN) {
+            if (g < NG - 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (g == 0) __builtin_amdgcn_sched_group_barrier(0x020, NMT / 8, 0);
+                }
+                if (p == 0) __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            }
         }
     } else {
 #pragma unroll
@@ -652,7 +668,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         /* branch-free request (a branch would end the scheduling region the pieces are spread over): after the very \
            last stage the idle buffer receives a copy of the first one */                                   \
         const float* src_ = s_ + 1 < n_st ? wl_g + (int64_t)(s_ + 1) * stage_floats : (next_w != nullptr ? next_w : g.w); \
-        if constexpr (X3) stage_compute_x3<NMT, NMT>(acc, B0, B1, wl, lane, [&](int j_) { stage_piece<2 * (NMT), kAsmDma>(src_, nxt, wave, lane, j_); }); \
+        if constexpr (X3) stage_compute_x3<NMT, NMT, CHAIN>(acc, B0, B1, wl, lane, [&](int j_) { stage_piece<2 * (NMT), kAsmDma>(src_, nxt, wave, lane, j_); }); \
         else stage_compute<NMT, NMT, kAsmDma>(acc, B0, B1, wl, lane, [&](int j_) { stage_piece<2 * (NMT), kAsmDma>(src_, nxt, wave, lane, j_); }); \
         ++gstage;                                                                                           \
     }
@@ -893,7 +909,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         stage_load<2 * NMT, kAsmDma>(g.w + L.w_off + kStageFloats, smem + ((gstage + 1) & 1) * kStageFloats, wave, lane);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if constexpr (X3) stage_compute_x3<4, NMT>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 512, lane, [](int) {});
+            if constexpr (X3) stage_compute_x3<4, NMT, false>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 512, lane, [](int) {});
             else stage_compute<4, NMT, kAsmDma>(acc, act[2 * kt], act[2 * kt + 1], wl + kt * 512, lane, [](int) {});
         }
         ++gstage;
@@ -902,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if constexpr (X3) stage_compute_x3<4, NMT>(acc, act[8 + 2 * kt], act[8 + 2 * kt + 1], wl + kt * 512, lane, [](int) {});
+            if constexpr (X3) stage_compute_x3<4, NMT, false>(acc, act[8 + 2 * kt], act[8 + 2 * kt + 1], wl + kt * 512, lane, [](int) {});
             else stage_compute<4, NMT, kAsmDma>(acc, act[8 + 2 * kt], act[8 + 2 * kt + 1], wl + kt * 512, lane, [](int) {});
         }
     } else if (g.d.n_out > 0) {  // final layer: 32 (padded) outputs = two 16-wide tiles; all 8 k-tiles arrive as ONE 32 KB stage
