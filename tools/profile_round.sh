@@ -57,4 +57,7 @@ done > $O/stage1_rank_shards.jsonl
 python3 $R/tools/run_e2e.py --full --json-out $O/e2e_full.json > $O/e2e_full.log 2>&1
 python3 $R/tools/dbg/bench_tn256_x3.py 2>/dev/null | tail -1 > $O/tn256_x3.json
 python3 $R/tools/dbg/ab_single_dump.py 2>/dev/null | tail -1 > $O/ab_single_dump.json
+# split-bf16 weight stages (PSN_W_BF16X2): the four geometry chains and the shading-row launch, fp32 vs three partial products
+python3 $R/tools/dbg/ab_chain_x3.py 2>/dev/null | tail -1 > $O/ab_chain_x3.json
+python3 $R/tools/dbg/bench_lrow_x3.py 2>/dev/null | tail -1 > $O/lrow_x3.json
 ls -la $O
