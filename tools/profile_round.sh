@@ -55,6 +55,7 @@ done > $O/stage1_rank_shards.jsonl
 # round 5 additions: configs[4] at its stated size with the device sampler in the loop, the split-bf16 weight-gradient kernel, the
 # single-dump chains A/B
 python3 $R/tools/run_e2e.py --full --json-out $O/e2e_full.json > $O/e2e_full.log 2>&1
+python3 $R/tools/run_e2e.py --full --precision bf16x3 --json-out $O/e2e_full_bf16x3.json > $O/e2e_full_bf16x3.log 2>&1
 python3 $R/tools/dbg/bench_tn256_x3.py 2>/dev/null | tail -1 > $O/tn256_x3.json
 python3 $R/tools/dbg/ab_single_dump.py 2>/dev/null | tail -1 > $O/ab_single_dump.json
 # split-bf16 weight stages (PSN_W_BF16X2): the four geometry chains and the shading-row launch, fp32 vs three partial products

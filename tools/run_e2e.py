@@ -82,6 +82,11 @@ def main():
     ap.add_argument('--json-out', default=None, help='also write the JSON line to this file')
     ap.add_argument('--backend', default=None, help='torch.distributed backend under torchrun (default nccl = RCCL; gloo for dry runs on one GPU)')
     ap.add_argument('--single-device', action='store_true', help='dry run: every rank uses cuda:0')
+    ap.add_argument('--precision', choices=('fp32', 'bf16x3'), default='fp32',
+                    help="'bf16x3' = BASELINE configs[4]'s bf16 MFMA path as built here (EXPERIMENT): every large MFMA stream of both "
+                         'training loops on split-bf16 weight stages / split-bf16 weight gradients (three partial products, ~1e-5 '
+                         'relative): stage 1 training.chain_precision + wgrad_precision + the ray-march sweep, stage 2 train.vis_bf16x3 '
+                         '+ train.chain_precision + train.wgrad_precision; shape_extract, root finder, losses, optimisers: exact fp32')
     ap.add_argument('--occ-precision', choices=('fp32', 'bf16x6'), default='fp32',
                     help="gradient-free occupancy queries of shape_extract (ray march sweep, shadow rays): 'bf16x6' = the opt-in "
                          'split-bf16 engine; the hand-off is then ALSO extracted with the exact engine and compared')
@@ -117,7 +122,9 @@ def main():
     t_all = time.time()
 
     # ------------------------------------------------------------------ scene
+    x3 = args.precision == 'bf16x3'
     cfg = stage1_cfg('bunny', **{'training.n_training_points': args.rays, 'training.normal_loss': False,
+                                 **({'training.chain_precision': 'bf16x3', 'training.wgrad_precision': 'bf16x3'} if x3 else {}),
                                  **({'rendering.num_points_in': 96, 'rendering.num_points_out': 32} if args.full else {})})
     K, _, S = stage1_camera(cfg, h=h, w=w)
     g = torch.Generator().manual_seed(1)
@@ -145,6 +152,8 @@ def main():
         batches.append({'img': mean_img.to(dev), 'img.mask': omasks[v].reshape(1, h, w).float().to(dev),
                         'img.world_mat': poses[v][None].to(dev), 'img.camera_mat': K.to(dev), 'img.scale_mat': S.to(dev)})
     s1_losses = []
+    if x3:
+        net1.inference_precision = 'bf16x3'   # the ray-march sweep of the training steps
     t0 = time.time()
     for it in range(args.s1_steps):
         if it == 5:  # (a generation-2 pass of the cyclic collector over the whole process is ~70 ms)
@@ -155,6 +164,7 @@ def main():
         s1_losses.append(terms['loss'].detach().clone())   # (read after the loop: no host synchronisation per step)
     torch.cuda.synchronize()
     t_s1 = time.time() - t0
+    net1.inference_precision = 'fp32'   # (shape_extract below: exact)
     s1_hist = torch.stack(s1_losses)
     if world > 1:   # a rank's loss is ITS share (local sums over the global denominators): the job's loss is the sum over ranks
         torch.distributed.all_reduce(s1_hist)
@@ -237,7 +247,8 @@ def main():
         iteration 0 (the switch falls at 5000 as in trainer.py:485-513), else the iteration counter jumps to 5000 at step ``switch``.
         Returns (report, net, step, runner)."""
         conf = s2.bear_conf(**{'brdf.light_intensity': 4.0, 'train.light_inten_train': False, 'train.light_bs': light_bs,
-                               'train.vis_train_num': args.vis_train_num})
+                               'train.vis_train_num': args.vis_train_num,
+                               **({'train.vis_bf16x3': True, 'train.chain_precision': 'bf16x3', 'train.wgrad_precision': 'bf16x3'} if x3 else {})})
         torch.manual_seed(seed)
         np.random.seed(seed)
         net2 = s2.PSNetwork(conf).to(dev)
@@ -399,7 +410,7 @@ def main():
             'e2e': 'ok', 'n_gpus': world, 'image': [h, w], 'views': args.views, 'lights_per_view': args.lights,
             'surface_pixels': n_surf, 'stage1': {'steps': args.s1_steps, 'loss_first': s1_losses[0], 'loss_last': s1_losses[-1],
                                                  'seconds': round(t_s1, 2)},
-            'shape_extract_seconds': round(t_extract, 2), 'handoff_dir': out_dir, 'occ_bf16x6': occ_cmp,
+            'precision': args.precision, 'shape_extract_seconds': round(t_extract, 2), 'handoff_dir': out_dir, 'occ_bf16x6': occ_cmp,
             'stage2_graph': rep2.get('graph'),
             'stage2': dict(rep2, switch_at=switch), 'stage2_shipped_shapes': shipped, 'host_sampler_probe': host_probe,
             'relight': {'envmap': [lh, 2 * lh], 'psnr_fp32': round(p32, 4), 'psnr_bf16': round(p16, 4),
