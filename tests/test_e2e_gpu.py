@@ -13,19 +13,22 @@ from tests.helpers import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('occ,graph', [('fp32', False), ('bf16x6', False), ('fp32', True)])
-def test_end_to_end_small(cuda, tmp_path, capsys, monkeypatch, occ, graph):
+@pytest.mark.parametrize('occ,graph,precision', [('fp32', False, 'fp32'), ('bf16x6', False, 'fp32'), ('fp32', True, 'fp32'), ('fp32', True, 'bf16x3')])
+def test_end_to_end_small(cuda, tmp_path, capsys, monkeypatch, occ, graph, precision):
     spec = importlib.util.spec_from_file_location('run_e2e', os.path.join(ROOT, 'tools', 'run_e2e.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, 'argv', ['run_e2e.py', '--h', '40', '--w', '40', '--views', '2', '--lights', '5', '--light-bs', '3',
                                       '--vis-plus', '6', '--vis-train-num', '3', '--rays', '192', '--s1-steps', '24',
                                       '--s2-steps', '32', '--pixels', '600', '--envmap-h', '4', '--out', str(tmp_path / 'shape'),
-                                      '--occ-precision', occ] + (['--graph'] if graph else []))
+                                      '--occ-precision', occ, '--precision', precision] + (['--graph'] if graph else []))
     mod.main()
     line = [l for l in capsys.readouterr().out.splitlines() if l.startswith('{')][-1]
     res = json.loads(line)
-    assert res['e2e'] == 'ok' and min(res['surface_pixels']) > 0
+    assert res['e2e'] == 'ok' and min(res['surface_pixels']) > 0 and res['precision'] == precision
+    if precision == 'bf16x3':
+        # both training loops on the split-bf16 path (EXPERIMENT): the same chain and the same asserts inside run_e2e.py
+        assert res['stage1']['loss_last'] < res['stage1']['loss_first'] and res['stage2']['loss_phase2'][1] < res['stage2']['loss_phase1'][0]
     if graph:  # stage 2 replayed from HIP graphs inside the reference-shaped loop (vis_plus draw, in-mask sampling, train_fix switch)
         assert res['stage2_graph']['replays'] >= 16 and res['stage2_graph']['captures'] <= 4, res['stage2_graph']
     if occ == 'bf16x6':  # the hand-off of the opt-in split-bf16 occupancy engine against the exact extraction (gates in run_e2e.py)
