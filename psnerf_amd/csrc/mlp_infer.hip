@@ -204,7 +204,8 @@ __device__ __forceinline__ void stage_compute(floatx4 (&acc)[NACC], const floatx
     }
 }
 
-// ---- split-bf16 form of a stage (experiment, PsnMlpDesc.w_format = PSN_W_BF16X2; chain launches of the 256-wide networks) ----
+// ---- split-bf16 form of a stage (experiment, PsnMlpDesc.w_format = PSN_W_BF16X2; the 256-wide networks: chain launches and the
+// gradient-free lean / occupancy / sweep launches) ----
 // The stage holds the SAME 32-feature k-tile in the same [2][NMT][64 lanes][16 B] geometry, but the two halves are PLANES instead of
 // k-halves: plane 0 = the bf16 heads of the lane's eight weights W[16 mt + i][32 kt + 16 (s / 4) + 4 g + s % 4], s = 0..7, plane 1 =
 // the bf16 of what the heads left (x = hi + mid + O(2^-16 x)).  v_mfma_f32_16x16x32_bf16 contracts 32 k per instruction with lane
