@@ -891,8 +891,11 @@ def main():
                 x6['kernel'] = {'name': 'mlp_infer_x3_kernel', 'rows_per_launch': rows_x, 'avg_launch_ms': round(ms_x, 3),
                                 'f32_equivalent_tflops': round(eq, 1), 'vs_f32_mfma_peak': round(eq / PEAK_F32_MFMA_TFLOPS, 3),
                                 'bf16_tflops_issued': round(6 * eq, 1), 'bf16_peak': 2500.0, 'bf16_frac': round(6 * eq / 2500.0, 3)}
+        except Exception as e:  # noqa: BLE001  (an experiment must never cost the headline its line)
+            x6 = dict(x6 or {}, error='%s: %s' % (type(e).__name__, str(e)[:200]))
         finally:
             step.model.train_vis_bf16x6 = False
+            step.model.train_vis_bf16x3 = False
     del inp, gt
     ms_per_step = dt / args.steps * 1e3
     value = ns_total * N_LIGHTS / (dt / args.steps)
