@@ -5,7 +5,8 @@ import torch
 from psnerf_amd import hip, ops, fused
 
 Q = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 262144
-SINGLE = 'single' in sys.argv  # the single-dump experiment (ops.GEO_SINGLE_DUMP): consumer chains re-form the sigmoid from A
+X3 = 'x3' in sys.argv          # split-bf16 weight stages (PSN_W_BF16X2), on top of the single-dump chains
+SINGLE = 'single' in sys.argv or X3  # the single-dump experiment (ops.GEO_SINGLE_DUMP): consumer chains re-form the sigmoid from A
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 dims_in = [39, 256, 256, 256, 256, 256, 256, 256, 256]
@@ -14,7 +15,7 @@ params = []
 for i, o in zip(dims_in, dims_out):
     params += [(torch.randn(o, i, device=dev) * (1.4 / i ** 0.5)).requires_grad_(), (torch.randn(o, device=dev) * 0.01).requires_grad_()]
 p = (torch.rand(Q, 3, device=dev) - 0.5).requires_grad_()
-chains = fused.pack_geo_chains(params[0::2], params[1::2], [4], 39, single_dump=SINGLE)
+chains = fused.pack_geo_chains(params[0::2], params[1::2], [4], 39, single_dump=SINGLE, x3=X3)
 names = ['F1 value', 'F2 sweep', 'B1 sweep-adj', 'B2 value-adj']
 macs = [39 * 256 + 6 * 65536 + 256 * 217 + 256 * 256 + 2 * 65536 + 256, 7 * 65536 + 256 * 64, 64 * 256 + 7 * 65536 + 64 * 256, 8 * 65536]
 for it in range(3):

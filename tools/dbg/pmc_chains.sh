@@ -3,7 +3,7 @@
 # 262144 query points: HBM-side traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and matrix-pipe occupancy.
 # Writes gpurun_out/$1/pmc_chains.json (copied to profiles/ by hand).  rocprofv3 runs python3 directly (no wrapper).
 TAG=${1:-r02}
-MODE=${2:-chains-only}   # 'single' = the single-dump experiment; the JSON is then pmc_chains_single.json
+MODE=${2:-chains-only}   # 'single' = the single-dump experiment (JSON: pmc_chains_single.json); 'x3' = + split-bf16 weight stages (pmc_chains_x3.json)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -34,7 +34,7 @@ for i in (1, 2, 3):
             if int(r['Dispatch_Id']) == d:
                 res.setdefault(name, {})[r['Counter_Name']] = float(r['Counter_Value'])
 Q = 262144
-alg = {'F1 value pass': (0, 1 if sys.argv[2] == 'single' else 2), 'F2 sweep': (1, 2), 'B1 sweep adjoint': (2, 2), 'B2 value adjoint': (2, 1)}
+alg = {'F1 value pass': (0, 1 if sys.argv[2] in ('single', 'x3') else 2), 'F2 sweep': (1, 2), 'B1 sweep adjoint': (2, 2), 'B2 value adjoint': (2, 1)}
 for name, v in res.items():
     rd, wr = alg[name]
     v['algorithmic_read_bytes'] = rd * 8 * 1024 * Q
@@ -47,6 +47,6 @@ for name, v in res.items():
         v['mfma_busy_frac'] = round(v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (v['GRBM_GUI_ACTIVE'] / 8.0), 4)
 json.dump({'_comment': 'rocprofv3 --pmc (3 separate passes, --kernel-trace only) on tools/dbg/bench_chains.py, 262144 query points, '
            'third iteration; FETCH_SIZE / WRITE_SIZE in KB; read side doubled per MI355X_MICROARCH.md', 'rows': Q, 'chains': res},
-          open(os.path.join(out, 'pmc_chains_single.json' if sys.argv[2] == 'single' else 'pmc_chains.json'), 'w'), indent=1)
+          open(os.path.join(out, {'single': 'pmc_chains_single.json', 'x3': 'pmc_chains_x3.json'}.get(sys.argv[2], 'pmc_chains.json')), 'w'), indent=1)
 print(json.dumps(res, indent=1))
 PY
