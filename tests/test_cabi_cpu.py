@@ -102,6 +102,17 @@ def test_argument_validation_needs_no_gpu():
     m.in_kt_a = 2
     rc = lib.psn_mlp_infer_pe(ctypes.byref(m), dummy, dummy, dummy, 10, 11, 1.0, dummy, None)  # 3 + 6 * 11 > 64 columns
     assert rc == -1 and b'octaves' in lib.psn_last_error()
+    # weight-stage formats (PSN_W_F32 / PSN_W_BF16X2): unknown values are refused by the packer, by the in-kernel-encoding entry
+    # point and by the root finder (which has no split-bf16 form)
+    it = (hip.PsnPackItem * 1)()
+    it[0].W, it[0].dst, it[0].ldw = 64, 64, 256
+    it[0].rows, it[0].cols, it[0].transpose, it[0].n_mt, it[0].k_tiles, it[0].format = 256, 256, 0, 8, 8, 7
+    rc = lib.psn_mlp_pack_layers(1, ctypes.addressof(it), None)
+    assert rc == -1 and b'unknown format' in lib.psn_last_error()
+    m.w_format = 5
+    rc = lib.psn_mlp_infer_pe(ctypes.byref(m), dummy, dummy, dummy, 10, 6, 1.0, dummy, None)
+    assert rc == -1 and b'unknown weight format' in lib.psn_last_error()
+    m.w_format = hip.W_F32
     # 33..64 outputs exist for the 256-wide chain engine only; > 64 nowhere
     m.n_out = 65
     m.layers[0].init_off = m.layers[1].init_off = -1
