@@ -301,6 +301,13 @@ int psn_mlp_infer_padded(const PsnMlpDesc* desc, const float* packed_w, const fl
                          int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                          const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
                          int64_t n_rows, float* out, const float* live_count, int64_t live_period, void* stream);
+/* Workgroup order of the psn_mlp_infer* launches whose rows are (group, point) pairs, row = group * P + point with a_div = 1,
+ * b_div = a_mod = P, n_rows = P * b_mod -- the light-major row set of stage2/model/renderer.py:163,183-193.  1 (default): the
+ * 64-row blocks are visited point-tile-major with the group (light) running fastest and every XCD takes a contiguous eighth of
+ * that order, so that the workgroups resident at one time share a few point tiles and the per-point init table is read from
+ * the fabric once instead of once per light; 0: row order (the light-major sweep).  A row's result does not depend on the
+ * order (bit-identical outputs and dumps).  Process-wide; returns the previous value. */
+int psn_mlp_block_order(int point_major);
 /* psn_mlp_infer, plain forward with activation dumps (stage2/model/renderer.py:251-262: the supervision rows of the visibility
  * network, :127-143 / :163-189 the normal / BRDF networks), that ALSO leaves the sign bits of every dumped activation behind:
  * save_bits_ptrs[l] [n_rows - save_row0, 4] uint64 (NULL per layer: none).  The ReLU-backward chain (PSN_ACT_RELU_BITS, the words

@@ -29,6 +29,7 @@
 // visibility net): 0.96-0.97 of the dense fp32-MFMA peak algorithmic, matrix pipe 88 % busy at 2.30 GHz.
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace psn {
 
@@ -87,7 +88,12 @@ struct InferArgs {
     // (row, lane group g) holds bit 4 mt + r = (activation feature 16 mt + 4 g + r > 0); read back by PSN_ACT_RELU_BITS chains
     // through mask[l], 32 bytes per row and layer instead of the 1 KB activation row
     unsigned long long* save_bits[PSN_MLP_MAX_LAYERS];
-    int tb_lds;  // lean variant: 1 = a workgroup whose rows share one B-table row reads that init row through LDS (A/B: PSN_TB_LDS=0)
+    int tb_lds;  // lean variant: 1 = a workgroup whose rows share one B-table row reads that init row through LDS (A/B: PSN_TB_LDS=0)    // lean variant, SRC == 0, pair row sets row = group * pm_period + point (stage 2: group = light, renderer.py:163,183-193): the
+    // workgroups visit the 64-row blocks POINT-TILE-major with the group (light) running fastest, every XCD a contiguous share of
+    // that order -- the workgroups resident at one time then share a handful of point tiles, whose A-side init rows (U[Ns, 512],
+    // 60 MB at 29k points) stay in the XCD's L2 instead of being streamed from the fabric once per light.  0 = row order.
+    int64_t pm_period;
+    int pm_groups;
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -485,20 +491,42 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
         // psn_mlp_infer_padded: the rows [0, save_row0) are groups of live_period rows (64 | live_period, 64 | save_row0) of which
         // the first live_count[0] are real.  The hardware hands workgroup i to XCD i % 8, and the all-padding blocks sit at the END
         // of every group: skipped where they stand they all fall on the same XCDs while the others carry the full work (measured:
-        // the launch no faster than without the skip).  So the grid enumerates the REAL blocks first, in their order -- workgroup i
-        // is real block i % rb of group i / rb, then come the blocks behind save_row0 -- and the surplus workgroups at the END of
-        // the grid, one per all-padding block, write that block's zeros and leave.
+        // the launch no faster than without the skip).  So the grid enumerates the REAL blocks first -- row order: workgroup i
+        // is real block i % rb of group i / rb, then come the blocks behind save_row0; point-major order: see below -- and the
+        // surplus workgroups at the END of the grid, one per all-padding block, write that block's zeros and leave.
         if (g.live_count != nullptr) {
             const int64_t bpg = g.live_period / (kWaves * 16), groups = g.save_row0 / g.live_period;
             int64_t rb = ((int64_t)*g.live_count + kWaves * 16 - 1) / (kWaves * 16);
             rb = rb < bpg ? rb : bpg;
             const int64_t real = groups * rb, tail = (g.n_rows - g.save_row0 + kWaves * 16 - 1) / (kWaves * 16);
-            if (blk_ < real) {
+            int64_t first_surplus = real + tail;
+            bool mapped = false;
+            if (g.pm_period > 0) {
+                // point-major: tile pt of every group that has one (pt < rb: the shading groups and the dumped groups behind
+                // save_row0, pt >= rb: the dumped groups only, which are evaluated in full), the group running fastest; XCD x =
+                // workgroups x, x + 8, ... takes the x-th eighth of that order
+                const unsigned all = (unsigned)g.pm_groups, vg = all - (unsigned)groups;
+                const unsigned btot = (unsigned)(real + tail), per = (btot + 7u) / 8u;
+                first_surplus = 8 * (int64_t)per;
+                if (blk_ < first_surplus) {
+                    const unsigned v = ((unsigned)blk_ & 7u) * per + ((unsigned)blk_ >> 3);
+                    if (v >= btot) return;
+                    const unsigned head = (unsigned)rb * all;
+                    unsigned pt, l;
+                    if (v < head) { pt = v / all; l = v - pt * all; }
+                    else { const unsigned t = v - head, q = t / vg; pt = (unsigned)rb + q; l = (unsigned)groups + (t - q * vg); }
+                    blk_ = (int64_t)l * bpg + pt;
+                    mapped = true;
+                }
+            } else if (blk_ < real) {
                 blk_ = (blk_ / rb) * bpg + blk_ % rb;
+                mapped = true;
             } else if (blk_ < real + tail) {
                 blk_ = groups * bpg + (blk_ - real);
-            } else {
-                const int64_t s_ = blk_ - real - tail, db = bpg - rb;  // all-padding block s_ % db of group s_ / db
+                mapped = true;
+            }
+            if (!mapped) {
+                const int64_t s_ = blk_ - first_surplus, db = bpg - rb;  // all-padding block s_ % db of group s_ / db
                 if (db > 0 && s_ < groups * db) {
                     const int64_t r0 = ((s_ / db) * bpg + rb + s_ % db) * (kWaves * 16);
                     const int n_out = g.d.n_out;
@@ -506,6 +534,18 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
                 }
                 return;  // (uniform, before any barrier or LDS-DMA request)
             }
+        } else if (g.pm_period > 0) {
+            // point-major order of a row set whose groups need not be multiples of 64 rows: group l owns the blocks that START in
+            // it, fb(l) = ceil(l P / 64) .. fb(l + 1) - 1 -- nfull = P / 64 of them, plus one more for ceil(G r / 64) of the groups
+            // (r = P % 64; the i-th such group is floor(64 i / r)).  Order: tile 0 of every group, tile 1, ..., then the extra ones.
+            const unsigned btot = (unsigned)((g.n_rows + kWaves * 16 - 1) / (kWaves * 16)), per = (btot + 7u) / 8u;
+            const unsigned v = ((unsigned)blk_ & 7u) * per + ((unsigned)blk_ >> 3);
+            if (v >= btot) return;
+            const unsigned G = (unsigned)g.pm_groups, nfull = (unsigned)(g.pm_period / (kWaves * 16)), r = (unsigned)(g.pm_period % (kWaves * 16));
+            unsigned pt, l;
+            if (v < nfull * G) { pt = v / G; l = v - pt * G; }
+            else { pt = nfull; l = (unsigned)(((uint64_t)(v - nfull * G) * (kWaves * 16)) / r); }
+            blk_ = (int64_t)l * nfull + ((int64_t)l * r + kWaves * 16 - 1) / (kWaves * 16) + pt;
         }
     }
     int64_t row_ = blk_ * (kWaves * 16) + wave * 16 + lj;
@@ -1286,6 +1326,13 @@ extern "C" int psn_mlp_pack_layer(const float* W, int64_t ldw, int rows, int col
     return PSN_OK;
 }
 
+// Block order of the lean engine's pair row sets (InferArgs.pm_period): 1 = point-tile-major with the group (light) fastest, an
+// eighth of that order per XCD (default), 0 = row order.  The results do not depend on it (a row's arithmetic is its own).
+static std::atomic<int> g_point_major{[] { const char* e = getenv("PSN_POINT_MAJOR"); return (e != nullptr && e[0] == '0') ? 0 : 1; }()};
+extern "C" int psn_mlp_block_order(int point_major) {
+    return g_point_major.exchange(point_major != 0 ? 1 : 0, std::memory_order_relaxed);
+}
+
 static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                           int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                           const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
@@ -1388,6 +1435,15 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
     {
         static const int tb = [] { const char* e = getenv("PSN_TB_LDS"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
         a.tb_lds = tb;
+        // point-major block order (InferArgs.pm_period): pair row sets row = group * P + point of the lean engine (A/B: PSN_POINT_MAJOR=0)
+        const int pm = g_point_major.load(std::memory_order_relaxed);
+        const bool pair = !chain && a_div == 1 && (tab_b != nullptr || init_b != nullptr) && b_div == a_mod && b_div >= rows_per_block &&
+                          b_mod >= 2 && b_mod < (1 << 20) && n_rows == b_div * b_mod && blocks + 8 < (1ll << 31);
+        if (pm && pair && (live_count == nullptr || (live_period == b_div && (n_rows - save_row0) % live_period == 0))) {
+            a.pm_period = b_div;
+            a.pm_groups = (int)b_mod;
+            blocks = live_count != nullptr ? blocks + 7 : (blocks + 7) / 8 * 8;  // (an eighth of the order per XCD: the grid is rounded up)
+        }
     }
     const size_t lds_bytes = (2 * kStageFloats + PSN_MLP_MAX_LAYERS * 256) * sizeof(float);
     const dim3 grid((unsigned)blocks), block(kWaves * 64);

@@ -130,6 +130,7 @@ SIGNATURES = {
                        i32, c_f, c_f, c_f]),
     'psn_gemm_tn_grouped': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
     'psn_gemm_tn_x3_set_products': (i32, [i32]),
+    'psn_mlp_block_order': (i32, [i32]),
     'psn_gemm_tn_grouped_x3': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
     'psn_colsum': (i32, [c_f, c_f, i32, i64, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_sample_points': (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f]),
@@ -1194,6 +1195,23 @@ def mlp_pack_layers(plan):
             e.W, e.dst, e.ldw = W.data_ptr(), dst.data_ptr(), W.stride(0)
             e.rows, e.cols, e.transpose, e.n_mt, e.k_tiles = rows, cols, int(transpose), n_mt, k_tiles
         _check(_lib.psn_mlp_pack_layers(len(chunk), ctypes.addressof(arr), _stream()), 'mlp_pack_layers')
+
+
+class block_order(object):
+    """``with hip.block_order('row'):`` -- the lean engine's (group, point) row sets in row order instead of the default
+    point-tile-major order (psn_mlp_block_order; results are bit-identical, the order only decides what stays in L2)."""
+
+    def __init__(self, order):
+        assert order in ('point', 'row'), order
+        self.order = order
+
+    def __enter__(self):
+        self.saved = _lib.psn_mlp_block_order(1 if self.order == 'point' else 0)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.psn_mlp_block_order(self.saved)
+        return False
 
 
 def mlp_infer(desc, packed_w, packed_b, tab_a, a_div, a_mod, tab_b, b_div, b_mod, n_rows, out=None, init_a=None,

@@ -209,6 +209,38 @@ def test_padded_visibility_launch_skips_only_padding_workgroups(cuda, ns, live):
     assert torch.equal(bits[1], want)
 
 
+@pytest.mark.parametrize('ns,live,L,V', [(1000, None, 5, 2), (64, None, 3, 1), (4099, None, 13, 3), (29, None, 4, 2), (1024, 517, 5, 2),
+                                         (4096, 3700, 11, 3), (640, 64, 5, 2), (1024, 0, 5, 2), (1024, 1024, 9, 8)])
+def test_point_major_block_order_is_bit_identical_to_row_order(cuda, ns, live, L, V):
+    """psn_mlp_block_order: the (light, point) row set of the visibility launch visited point-tile-major (light fastest, an eighth
+    of the order per XCD) -- plain launches with group sizes that are no multiple of 64 (blocks straddle lights; groups shorter
+    than a block fall back to row order) and padded launches with a device-side live count.  Every output row, every dump and
+    every sign-bit word equals the row-order launch bit for bit (the row-order results stay alive, so the second launch cannot
+    inherit their memory, and the block it is likely to get is poisoned with NaN first: a block that was left out shows)."""
+    from psnerf_amd import ops, hip
+    g = torch.Generator().manual_seed(ns * 7 + L)
+    pe_x = torch.randn(ns, 64, generator=g).to(cuda)
+    pe_l = torch.randn(L + V, 64, generator=g).to(cuda)
+    dims = [(256, 78)] + [(256, 256)] * 2 + [(256, 256 + 78)] + [(256, 256)] + [(1, 256)]
+    params = []
+    for o, i in dims:
+        params += [(torch.randn(o, i, generator=g) / i ** 0.5).to(cuda), (torch.randn(o, generator=g) * 0.1).to(cuda)]
+    c = torch.arange(39)
+    cols = torch.cat([c, 64 + c]).to(cuda)
+    cnt = None if live is None else torch.tensor([float(live)], device=cuda)
+    res = {}
+    for order in ('row', 'point'):
+        poison = torch.full(((L + V) * ns, 1), float('nan'), device=cuda)
+        del poison
+        with hip.block_order(order):
+            out, (save, bits) = ops.VisibilityPair.launch(pe_x, pe_l, L, cols, 2, params, True, live_count=cnt)
+        torch.cuda.synchronize()
+        res[order] = [out] + save + bits
+    assert not bool(torch.isnan(res['point'][0]).any())
+    for a, b in zip(res['row'], res['point']):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('with_count', [False, True])
 def test_padded_surface_list_gives_the_unpadded_step(cuda, with_count):
     """A surface-pixel list padded to the pixel count (dead rows = the last surface pixel repeated): the dense outputs of the
