@@ -480,17 +480,17 @@ class _Prefetcher(object):
 
     def _work(self):
         st = self.store
+        import queue
+
+        def blocking(fn, *a):   # a queue operation that gives up when the consumer has closed the loader
+            while not self.stop:
+                try:
+                    return fn(*a, timeout=0.2)
+                except (queue.Empty, queue.Full):
+                    continue
+            raise StopIteration
         try:
             torch.cuda.set_device(st.device)   # a new thread starts on device 0
-            import queue
-
-            def blocking(fn, *a):   # a queue operation that gives up when the consumer has closed the loader
-                while not self.stop:
-                    try:
-                        return fn(*a, timeout=0.2)
-                    except (queue.Empty, queue.Full):
-                        continue
-                raise StopIteration
             for idx in self.order:
                 if self.stop:
                     return
@@ -513,10 +513,12 @@ class _Prefetcher(object):
         except StopIteration:
             return
         except BaseException as e:  # noqa: BLE001 (handed to the consumer)
+            # the error is set BEFORE the sentinel is offered and the consumer also polls it (and the thread's liveness) while it
+            # waits, so a full queue under a long step cannot hide it; the sentinel is offered until delivered or the loader closed
             self.error = e
             try:
-                self.ready.put(None, timeout=1.0)
-            except Exception:  # noqa: BLE001
+                blocking(self.ready.put, None)
+            except BaseException:  # noqa: BLE001 (closed meanwhile)
                 pass
 
     def __iter__(self):
@@ -530,10 +532,21 @@ class _Prefetcher(object):
             self.released[self.current] = ev
             self.free.put(self.current)
             self.current = None
+        import queue
         t0 = time.perf_counter()
-        got = self.ready.get()
+        while True:
+            try:
+                got = self.ready.get(timeout=0.2)
+                break
+            except queue.Empty:
+                # nothing ready: a worker that died (error or not) will never deliver -- do not block forever (under data
+                # parallelism the other ranks would be left inside their collectives)
+                if not self.thread.is_alive() and self.ready.empty():
+                    got = None
+                    break
         self.consumer_wait += time.perf_counter() - t0
         if got is None:
+            self.stop = True
             if self.error is not None:
                 raise self.error
             raise StopIteration
@@ -546,6 +559,13 @@ class _Prefetcher(object):
         """Stop the worker (a consumer that leaves the loop early: the draws made ahead are lost -- re-seed to resume in step)."""
         self.stop = True
         self.thread.join(timeout=5.0)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
         self.stop = True

@@ -89,7 +89,12 @@ class RowSparseAdam(torch.optim.Optimizer):
                 t = int(state['step']) + 1
                 items.append((p, state, b1, b2, group['eps'], group['lr'] * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)))
         if not items:
-            return None  # no table has a gradient (a batch without a surface pixel): nothing to do, in any formulation
+            # no table has a gradient (a batch without a surface pixel): nothing to do, in any formulation -- and no launch: a
+            # graph captured around this step must not inherit the plan of an earlier fused step (its replays would advance
+            # the tables' step counts without an update)
+            if self.graph_scalars is not None:
+                self._graph_plan = []
+            return None
         if len(items) > 4:
             return False
         for p, state, *_ in items:

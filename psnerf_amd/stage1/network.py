@@ -142,7 +142,7 @@ class NeuralNetwork(nn.Module):
     MAX_ROWS = 1 << 20  # rows per GeoField call: bounds the saved activations to ~50 GB of the 288 GB HBM
 
     def _geo_chains(self, params):
-        key = (self._params_key(), ops.CHAIN_X3)
+        key = (self._params_key(), ops.CHAIN_X3, ops.GEO_SINGLE_DUMP)  # (both are run-time switches: a toggle rebuilds the packs)
         if self._chains is None or self._chains_key != key:
             with torch.no_grad():
                 self._chains = fused.pack_geo_chains(params[0::2], params[1::2], self.skips, self.d_pe, single_dump=ops.GEO_SINGLE_DUMP,
@@ -254,7 +254,7 @@ class NeuralNetwork(nn.Module):
         return self._app(x)
 
     def _app_chains(self, Ws, bs, d_x):
-        key = (self._params_key(), ops.CHAIN_X3)
+        key = (self._params_key(), ops.CHAIN_X3, ops.GEO_SINGLE_DUMP)  # (both are run-time switches: a toggle rebuilds the packs)
         if self._app_packed is None or self._app_key != key:
             with torch.no_grad():
                 self._app_packed = fused.pack_app_chains(Ws, bs, d_x, x3=ops.CHAIN_X3)

@@ -232,12 +232,16 @@ class TrainStep(object):
         sm, om = model_input['surface_mask'], model_input['object_mask']
         if count is not None:
             pass
-        elif self.FUSED_LOSSES and sm.is_cuda:
+        elif self.FUSED_LOSSES and sm.is_cuda and self.normal_train:
             # the count stays on the device (all-reduced there under data parallelism): the fused loss kernels divide by
             # it, so the step has no host synchronisation of its own (the model's only one is the surface-pixel list,
             # and a batch may bring that along as 'surface_idx')
             count = self.dp.masked_count_tensor(sm, om)
         else:
+            # (the MainLoss-only configuration and CPU tensors: the torch loss formulation divides by a host value)
+            if sm.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('TrainStep: this configuration (no jointly trained normal net: train.normal_mlp / train.normal_joint off) takes the '
+                                   'torch loss formulation, whose mask count is a host value -- the step cannot be captured into a HIP graph; run it eagerly')
             count = self.dp.global_count(sm & om)
         out = self.model(model_input, noise=noise)
         fl = fused_losses(self.loss, self.loss_n, out, ground_truth, model_input, count) if (self.FUSED_LOSSES and self.normal_train) else None

@@ -133,6 +133,26 @@ def test_alternating_signatures_and_an_empty_batch_keep_every_graph_on_its_own_p
     assert steps and all(v == 12.0 for v in steps), steps
 
 
+def test_row_sparse_adam_without_gradient_leaves_no_plan_behind(cuda):
+    """a step in which no table has a gradient issues no launch; with graph scalars on, the plan a capture would
+    snapshot must then be EMPTY -- not the plan of an earlier fused step, whose replays would advance the tables' step counts
+    (and with them the Adam bias corrections of later real steps) without an update."""
+    from psnerf_amd.optim import RowSparseAdam, StepScalars
+    table = torch.nn.Parameter(torch.randn(12, 3, device=cuda))
+    opt = RowSparseAdam([table], lr=1e-2)
+    opt.graph_scalars = StepScalars(4, cuda)
+    rows = torch.tensor([1, 5, 5, 7], device=cuda)
+    table.grad = torch.zeros_like(table)
+    table.grad[rows] = 1.0
+    opt.step(rows)
+    assert len(opt._graph_plan) == 1 and int(opt.state[table]['step']) == 1
+    table.grad = None
+    opt.step(rows)
+    assert opt._graph_plan == [] and int(opt.state[table]['step']) == 1
+    opt.graph_advance(list(opt._graph_plan))   # what a replay of a graph captured around that step does: nothing
+    assert int(opt.state[table]['step']) == 1
+
+
 def test_graphed_step_draws_fresh_jitter_noise_every_replay(cuda):
     """Without injected noise the model draws the xyz jitter on the device (renderer.py:212): under replay the generator's
     offset must advance, i.e. two replays of the same batch see different jitter and therefore different smoothness terms."""

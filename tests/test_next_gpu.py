@@ -243,6 +243,17 @@ def test_device_views_batch_equals_the_host_sampler_bit_for_bit(cuda, u8, n_pixe
     next(early)
     early.close()
     assert not early.thread.is_alive()
+    # a worker that fails while the bounded queue is full and the consumer sits in a long step: the error reaches the
+    # consumer -- after the items made before it -- instead of leaving it blocked on an empty queue; `with` closes the loader
+    import time
+    with store.loader(list(order[:3]) + [10 ** 6] + list(order), depth=1) as bad:
+        next(bad)
+        time.sleep(1.5)
+        with pytest.raises(Exception) as ei:
+            for _ in range(10):
+                next(bad)
+        assert not isinstance(ei.value, StopIteration) and bad.error is ei.value
+    assert not bad.thread.is_alive()
 
 
 @pytest.mark.parametrize('world', [2, 8])

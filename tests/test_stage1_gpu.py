@@ -113,11 +113,15 @@ def test_march_and_light_visibility_golden(cuda):
     assert_close(lv, g['light_vis'], 1e-4, 'light visibility', atol=ATOL_UNIT)
 
 
-@pytest.mark.parametrize('tag', ['it0', 'it6000', 'cfg1'])
-def test_unisurf_golden(cuda, tag):
+@pytest.mark.parametrize('tag,dumps', [('it0', 'single'), ('it6000', 'single'), ('cfg1', 'single'), ('it6000', 'two')])
+def test_unisurf_golden(cuda, tag, dumps, monkeypatch):
     """G6 against the reference's own Renderer.unisurf + Loss + backward ('cfg1': 512 rays x 64 samples, 256 march steps = the
-    scale of BASELINE configs[0])."""
+    scale of BASELINE configs[0]).  dumps: the default geometry chains write ONE tensor per softplus layer (ops.GEO_SINGLE_DUMP,
+    the mode every other gate of this suite runs in); 'two' = the two-dump chains behind PSN_GEO_SINGLE_DUMP=0, same gates (the
+    switch is part of the network's pack key: toggling it at run time rebuilds the chains)."""
+    from psnerf_amd import ops
     from psnerf_amd.stage1 import Loss
+    monkeypatch.setattr(ops, 'GEO_SINGLE_DUMP', dumps == 'single')
     g = np.load(os.path.join(GOLDEN, 'stage1_unisurf_%s.npz' % tag))
     it = int(g['it'])
     cfg, net, ren = _renderer(cuda)
