@@ -53,14 +53,14 @@ def sample_vis_plus_dirs(world_mat, vnum=256, semisphere=False, rnum=10000, rng=
 
 
 @torch.no_grad()
-def export_view(renderer, camera_mat, world_mat, scale_mat, h, w, out_dir, view_id, light_dir=None, vis_plus_dir=None,
-                chunk=32000, it=100000):
-    """shape_extract.py:120-171 for one view.  ``light_dir`` [L,3] (view's calibrated/estimated lights);
-    ``vis_plus_dir`` [P,3] extra supervision directions."""
+def extract_view(renderer, camera_mat, world_mat, scale_mat, h, w, light_dir=None, vis_plus_dir=None, chunk=32000, it=100000):
+    """The extraction loop of shape_extract.py:120-147 for one view, before anything is written: the renderer's 'shape_extract'
+    over the x-major pixel list of the h x w image in chunks, shadow-ray visibility towards ``light_dir`` [L,3] followed by
+    ``vis_plus_dir`` [P,3].  Returns {'mask' [1, hw], 'normal' [1, hw, 3], 'points' [1, hw, 3], 'visibility' [L + P, hw] or None,
+    'pixels' [1, hw, 2]} on the renderer's device (pixel order = arange_pixels)."""
     dev = camera_mat.device
     p_loc = arange_pixels(h, w, dev).float()
     lights = light_dir
-    n_ori = 0 if light_dir is None else light_dir.shape[0]
     if light_dir is not None and vis_plus_dir is not None:
         lights = torch.cat([light_dir, vis_plus_dir], dim=0)
     masks, normals, points, vis = [], [], [], []
@@ -72,6 +72,21 @@ def export_view(renderer, camera_mat, world_mat, scale_mat, h, w, out_dir, view_
         points.append(out['points'])
         if lights is not None:
             vis.append(out['visibility'])
+    return {'mask': torch.cat(masks, dim=1), 'normal': torch.cat(normals, dim=1), 'points': torch.cat(points, dim=1),
+            'visibility': torch.cat(vis, dim=1) if lights is not None else None, 'pixels': p_loc}
+
+
+def export_view(renderer, camera_mat, world_mat, scale_mat, h, w, out_dir, view_id, light_dir=None, vis_plus_dir=None,
+                chunk=32000, it=100000, extracted=None):
+    """shape_extract.py:120-171 for one view.  ``light_dir`` [L,3] (view's calibrated/estimated lights);
+    ``vis_plus_dir`` [P,3] extra supervision directions.  ``extracted``: the result of extract_view for these arguments (a caller
+    that has it already), else it is computed here."""
+    lights = light_dir
+    n_ori = 0 if light_dir is None else light_dir.shape[0]
+    if light_dir is not None and vis_plus_dir is not None:
+        lights = torch.cat([light_dir, vis_plus_dir], dim=0)
+    ex = extracted if extracted is not None else extract_view(renderer, camera_mat, world_mat, scale_mat, h, w, light_dir, vis_plus_dir, chunk, it)
+    masks, normals, points, vis = [ex['mask']], [ex['normal']], [ex['points']], [ex['visibility']]
     name = 'view_{:02d}.npy'.format(view_id)
     for sub in ('points', 'normal', 'mask', 'visibility', 'vis_plus'):
         os.makedirs(os.path.join(out_dir, sub), exist_ok=True)

@@ -22,6 +22,47 @@ def _hit(name):
     HITS[name] += 1
 
 
+# Engine selection made loud.  Every place where a DEVICE tensor is about to leave the register-resident /
+# fused engines for a layer-wise GEMM sequence or a torch formulation -- an unsupported width, a shape or dtype predicate that
+# failed -- calls ``fallback(name, tensor, why)``: it is counted in FALLBACKS and, when STRICT is on (bench.py, tools/run_e2e.py,
+# the operating-point tests: ``with ops.strict():``; or PSN_STRICT=1), raises instead of silently taking the slow path.  CPU
+# tensors (module construction, checkpoint loading, the CPU test-suite) and switches a caller set deliberately
+# (MLP.FUSED = False, Renderer.FUSED_SWEEP = False, ... -- the A/B and cross-check paths of the tests) are not fallbacks.
+import os as _os0
+STRICT = _os0.environ.get('PSN_STRICT', '0') == '1'
+FALLBACKS = collections.Counter()
+
+
+def fallback(name, tensor=None, why=''):
+    if tensor is not None and not getattr(tensor, 'is_cuda', False):
+        return
+    FALLBACKS[name] += 1
+    if STRICT:
+        raise RuntimeError('psnerf_amd.ops.STRICT: %s left the fused engines on a device tensor%s' % (name, (' (' + why + ')') if why else ''))
+
+
+class strict(object):
+    """``with ops.strict():`` -- a device tensor that falls off the fused engines raises (ops.fallback) instead of falling back."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global STRICT
+        self.saved, STRICT = STRICT, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global STRICT
+        STRICT = self.saved
+        return False
+
+
+def reset_hits():
+    HITS.clear()
+    FALLBACKS.clear()
+
+
 def _rowsum_small(t):
     """Column sums [C] of a contiguous [Q, C] tensor with C <= 4 (bias gradients of 1- / 3-output heads).  torch's
     dim-0 reduction of such a shape is pathological (250 us for [524288, 3]); viewed as [Q C / 64 C, 64 C] it is a

@@ -155,6 +155,9 @@ class NeuralNetwork(nn.Module):
             return ops.GeoFieldFused.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad,
                                            chains, feat_rows, *params)
         assert feat_rows is None
+        if self.USE_FUSED_CHAINS:  # (False: the layer-wise cross-check of the tests)
+            ops.fallback('stage1 geometry network -> layer-wise GEMMs (ops.GeoField)', p_flat,
+                         'hidden widths / skips / feature size outside the fused chains')
         o, g = ops.GeoField.apply(p_flat, self.octaves_pe, 1.0 / self.rescale, tuple(self.skips), with_grad, *params)
         return o[:, :1], o[:, 1:], g
 
@@ -269,6 +272,8 @@ class NeuralNetwork(nn.Module):
         Ws, bs = self._app_params()
         if not (self.USE_FUSED_CHAINS and self.feat_size == 256 and d_x <= 64 and Ws[0].shape[0] == 256
                 and all(w.shape == (256, 256) for w in Ws[1:-1]) and self.n_app <= 10 and points.is_cuda):
+            if self.USE_FUSED_CHAINS:
+                ops.fallback('stage1 appearance network -> layer-wise GEMMs (ops.ReluMLP)', points, 'widths / input size outside the fused chains')
             v = view / torch.norm(view, dim=-1, keepdim=True)
             v_pe = ops.positional_encoding(v, self.octaves_pe_views)
             return self._app(torch.cat([points, v_pe, normal, feat], dim=-1))
@@ -301,6 +306,8 @@ class NeuralNetwork(nn.Module):
         if only_occupancy:
             if not torch.is_grad_enabled() and self.feat_size + 1 > 1 and self._hidden_is_256():
                 return self.occupancy(flat).reshape(*shp, 1)
+            if not torch.is_grad_enabled():
+                ops.fallback('stage1 occupancy queries -> geometry-network formulation', flat, 'hidden width is not 256')
             logit, _, _ = self._geo_parts(flat, False)
             return torch.sigmoid(logit * -10.0).reshape(*shp, 1)
         if ray_d is not None:

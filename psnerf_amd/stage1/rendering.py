@@ -152,11 +152,15 @@ class Renderer(nn.Module):
             # one ray, and the blocks behind a ray's first sign change are not evaluated (psn_march_sweep; the reference's
             # result depends on nothing behind it, rendering.py:472-504)
             packed = m._occupancy_packed(allow_x3=True)  # ('bf16x3': the same kernel on split-bf16 weight stages; otherwise the exact pack)
+            ops._hit('march_sweep')
             occ, _ = hip.march_sweep(packed.desc, packed.w, packed.b, ray0.reshape(-1, 3).contiguous(),
                                      ray_direction.reshape(-1, 3).contiguous(), far.reshape(-1), u[0], u[1], float(depth_range[0]),
                                      n_steps, tau, m.octaves_pe, 1.0 / m.rescale, early_exit=self.EARLY_EXIT,
                                      macs_per_row=getattr(packed, 'macs_per_row', None))
         else:
+            if self.FUSED_SWEEP:  # (False: the two-launch cross-check of the tests)
+                ops.fallback('stage1 ray-march sweep -> point table + occupancy launch', ray0,
+                             'n_steps %d (64 | n_steps needed), clip %s, hidden width' % (n_steps, bool(clip)))
             # sweep points ray0 + dir * (near (1 - t) + far t), t = linspace(0, 1, n_steps): one launch (csrc/sample.hip)
             p_prop = torch.empty(B * N, n_steps, 3, device=dev)
             hip.sample_points(ray0.reshape(-1, 3).contiguous(), ray_direction.reshape(-1, 3).contiguous(),
@@ -222,6 +226,7 @@ class Renderer(nn.Module):
     def _root_find(self, bracket, origin, direction, tau, n_iter):
         m = self.model
         packed = m._occupancy_packed()
+        ops._hit('root_find')
         return hip.root_find(packed.desc, packed.w, packed.b, origin, direction, bracket, tau, n_iter, m.octaves_pe,
                              1.0 / m.rescale)
 
@@ -232,6 +237,8 @@ class Renderer(nn.Module):
             # all iterations in one launch (psn_root_find)
             bracket = torch.stack([d_low, d_high, f_low, f_high]).float().contiguous()
             return self._root_find(bracket, ray0_masked.contiguous(), ray_direction_masked.contiguous(), tau, n_secant_steps)
+        if f_low.numel() > 0:
+            ops.fallback('stage1 secant -> one launch set per iteration', f_low, 'hidden width is not 256')
         d_pred = -f_low * (d_high - d_low) / (f_high - f_low) + d_low
         if d_pred.numel() == 0:
             return d_pred
@@ -518,8 +525,11 @@ class Renderer(nn.Module):
             if self.SHADOW_SYNC_FREE and hasattr(m, '_occupancy_packed') and m._hidden_is_256():
                 # the network runs over the compacted list straight away: its length stays on the device (workgroups behind it
                 # leave at once) and the occupancies are scattered to their (ray, step) slots by the kernel itself
+                ops._hit('shadow_indirect')
                 m._occupancy_packed(allow_x3=True).on_points(pts, m.octaves_pe, 1.0 / m.rescale, out=alpha, n_rows_dev=counter, out_rows=rows)
             else:
+                if self.SHADOW_SYNC_FREE:
+                    ops.fallback('stage1 shadow rays -> host-synchronised compaction', surf, 'hidden width is not 256')
                 n_in = int(counter.item())  # one host synchronisation per launch group
                 if n_in > 0:
                     alpha.index_copy_(0, rows[:n_in], self._occ(pts[:n_in]).reshape(-1))

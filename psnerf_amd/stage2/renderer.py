@@ -114,6 +114,8 @@ class MLP(nn.Module):
                 params += [W, b]
             return ops.FusedReluNet.apply(x_padded, self.din, self._skip_index(), self.final == 'sigmoid', self.width,
                                           self.prepack(), *params)
+        if self.FUSED:  # (FUSED = False is a caller's deliberate choice: the layer-wise cross-check of the tests)
+            ops.fallback('stage2.MLP -> layer-wise GEMMs', x_padded, 'width %d, %d layers, input %s' % (self.width, len(Ws), tuple(x_padded.shape)))
         return ops.relu_mlp(x_padded, in_cols, self._skip_index(), self.final == 'sigmoid', Ws, bs)
 
 
@@ -266,6 +268,8 @@ class PSNetwork(nn.Module):
             for W, b in zip(Ws, bs):
                 params += [W, b]
             return ops.FusedPairMLP.apply(pe_x, pe_l, cols, net._skip_index(), *params)
+        if fused_ok:
+            ops.fallback('stage2.visibility rows -> expanded [L Ns, 128] input', pe_x, 'visibility_net width %d' % net.width)
         ns, nl = pe_x.shape[0], pe_l.shape[0]
         x = torch.cat([pe_x.tile(nl, 1), pe_l.repeat_interleave(ns, dim=0)], dim=1)
         return net(x, cols)

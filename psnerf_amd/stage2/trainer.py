@@ -245,6 +245,8 @@ class TrainStep(object):
             count = self.dp.global_count(sm & om)
         out = self.model(model_input, noise=noise)
         fl = fused_losses(self.loss, self.loss_n, out, ground_truth, model_input, count) if (self.FUSED_LOSSES and self.normal_train) else None
+        if fl is None and self.FUSED_LOSSES and self.normal_train:
+            ops.fallback('stage2 losses -> torch formulation of MainLoss / NormalLoss', out['sg_rgb_values'], 'loss type or outputs outside csrc/loss.hip')
         if fl is None and torch.is_tensor(count):
             count = int(count.item())
         if fl is not None:  # both loss modules in two launches forward / one backward (csrc/loss.hip)
