@@ -20,8 +20,9 @@ Extra objects on the JSON line (all measured after the headline's timed region):
   roofline      dominant kernel (fused 256-wide visibility MLP, MFMA-bound), HIP events on the launch stream from a SECOND,
                 separately instrumented pass (the headline's timed region records nothing).  ``achieved`` / ``frac`` count the
                 flops the kernel's own algorithm needs (2 x 462,848 MAC per row: the two input-block layers are factorised into
-                per-point / per-light tables computed by separate small GEMMs), so frac <= 1; ``algorithmic_frac`` prices the
-                reference's unfactorised 523,520 MAC per row at the same duration and may pass 1
+                per-point / per-light tables computed by separate small GEMMs), so frac <= 1; ``reference_formulation`` states the
+                reference's unfactorised 523,520 MAC per row at the same duration as an equivalent throughput -- work
+                the kernel does not execute, hence no fraction of a peak
   reference_dict  the same step fed the reference's dictionary WITHOUT 'surface_idx' (the index list is then rebuilt from
                 the mask inside the timed step: one nonzero() = one host synchronisation per step)
   launches_per_step  device kernel launches of one steady-state step (torch.profiler), hand-written HIP vs torch-eager
@@ -141,7 +142,7 @@ def parity_check(device, n_pixels=4096):
             'horizon': 'one step here; 300 stage-2 / 200 stage-1 steps: tests/test_convergence_gpu.py (PSNR within 0.05 dB)'}
 
 
-def cpu_baseline(n_pixels=4096, steps=3):
+def cpu_baseline(n_pixels=4096, steps=3, all_core_workers=True):
     """The oracle (port of the reference's stage-2 step) on the host cores.  The thread count is swept on a 1024-pixel
     sample (1 warm-up + 2 timed steps each) over {1, 8, 16, 32, 64} (more threads than that only oversubscribe the eager
     CPU kernels: 256 threads measured 1.1 k ray-samples/s against 203 k with 16); the best count is then timed on a bounded
@@ -159,11 +160,17 @@ def cpu_baseline(n_pixels=4096, steps=3):
         best_th = max(sweep, key=sweep.get)
         torch.set_num_threads(best_th)
         ns, dt = _cpu_steps(n_pixels, steps)
-        # BASELINE.md section 3 also names "all cores": every host core as a torch thread only oversubscribes the eager CPU kernels of this
-        # size -- measured once in round 5 on the 256-core host (profiles/r05b_bench_stage2.json): 174 ray-samples/s, 64 s per 128-px step,
-        # against 243 k with 16 threads -- and two such steps would take two minutes of every bench run: not timed here; the sweep's best
-        # count IS the all-core baseline in the sense that matters (the fastest the host can run the port)
-        all_cores = {'value': 174.0, 'cores': 256, 'sample': 'round-5 measurement on a 256-core host, 128 px, 64 s/step (not re-timed per run)'} if nproc >= 128 else None
+        # BASELINE.md section 3 also names "all cores".  Every host core as a torch thread of ONE process only oversubscribes the
+        # eager CPU kernels of this size (round 5, 256-core host: 174 ray-samples/s at 256 threads against 243 k at 16), so the
+        # all-core figure is taken the way a host would actually be filled: P = cores / best_th independent worker processes of
+        # best_th threads each, every one running the same oracle step on its own 1024-pixel batch at the same time (pixel data
+        # parallelism without the gradient exchange -- an upper bound for the host); measured in THIS run, summed over the workers
+        all_cores = None
+        if all_core_workers:
+            try:
+                all_cores = _cpu_all_cores(best_th, nproc)
+            except Exception as e:  # noqa: BLE001
+                all_cores = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
     finally:
         torch.set_num_threads(t_all)
     return {'value': ns * N_LIGHTS / dt, 'unit': 'ray-samples/s', 'cores': best_th, 'kind': 'port', 'all_cores': all_cores,
@@ -172,6 +179,34 @@ def cpu_baseline(n_pixels=4096, steps=3):
             'host_cores': nproc,
             'thread_sweep_1024px': {str(k): round(v, 1) for k, v in sorted(sweep.items())},
             'single_thread': {'value': sweep.get(1), 'cores': 1, 'sample': '1024 px, min of 2 timed steps after 1 warm-up'}}
+
+
+def _cpu_all_cores(threads, nproc, n_pixels=1024, steps=2, max_workers=16):
+    """P worker processes x ``threads`` torch threads, all timing ``_cpu_steps(n_pixels, steps)`` concurrently (children of this
+    process that never touch the GPU: `bench.py --cpu-worker`); value = the sum of the workers' rates."""
+    import subprocess
+    P = max(1, min(max_workers, nproc // max(threads, 1)))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', '%d,%d,%d' % (n_pixels, steps, threads)]
+    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(P)]
+    rates = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=240)
+            rates.append(float(json.loads(out.strip().splitlines()[-1])['rate']))
+        except Exception:  # noqa: BLE001  (a worker that failed or timed out contributes nothing)
+            pr.kill()
+    return {'value': sum(rates), 'unit': 'ray-samples/s', 'cores': P * threads, 'workers': len(rates),
+            'sample': '%d concurrent worker processes x %d threads, each oracle/stage2.py TrainStep on its own %d-px batch (min of %d timed '
+                      'steps after 1 warm-up); the sum of their rates, no gradient exchange' % (P, threads, n_pixels, steps)}
+
+
+def cpu_worker(spec):
+    import torch
+    n_pixels, steps, threads = (int(x) for x in spec.split(','))
+    torch.set_num_threads(threads)
+    ns, dt = _cpu_steps(n_pixels, steps)
+    print(json.dumps({'rate': ns * N_LIGHTS / dt}), flush=True)
 
 
 # ----------------------------------------------------------------------------------------------- the data pipeline in the loop
@@ -403,7 +438,7 @@ def _stage1_cfg1(rays=512):
     return cfg, batch, pix, g
 
 
-def stage1_cpu_baseline(steps=2):
+def stage1_cpu_baseline(steps=3):
     """BASELINE.md section 3 for stage 1 = BASELINE configs[0] itself: the oracle's Trainer.train_step (port of
     stage1/model/training.py:46-60 -- march, render forward, loss, double backward, Adam) on the host cores at 512 rays x 64 samples.
     Thread count swept on a 128-ray sample over {1, 8, 16, 32, 64}; the best count then runs the 512-ray step (1 warm-up + ``steps``
@@ -715,8 +750,13 @@ def main():
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo for 1-GPU dry runs)')
     ap.add_argument('--single-device', action='store_true', help='dry run: every rank uses cuda:0')
     ap.add_argument('--cfg4-child', action='store_true', help=argparse.SUPPRESS)  # internal: the strong_cfg4 object in a process of its own
+    ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)  # internal: one worker of the all-core CPU baseline (never touches the GPU)
+    ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the all-core leg of the CPU baseline (P worker processes)')
     args = ap.parse_args()
 
+    if args.cpu_worker:
+        cpu_worker(args.cpu_worker)
+        return
     if args.gpus < 1:
         raise SystemExit('bench.py: --gpus must be >= 1')
     import torch  # (device_count() does not initialise the GPU on this image: the parent stays exec-safe)
@@ -740,8 +780,9 @@ def main():
         cfg4_n1 = run_cfg4_child()
 
     import torch.distributed as dist
-    from psnerf_amd import dist as pdist, hip
+    from psnerf_amd import dist as pdist, hip, ops as _ops
     from psnerf_amd.synthetic import stage2_inputs
+    _ops.STRICT = True   # a device tensor that falls off the fused engines raises instead of quietly taking a slower formulation
 
     rank, local, world = pdist.init_from_env(backend=args.backend, set_device=not args.single_device)
     if args.single_device:
@@ -958,25 +999,26 @@ def main():
                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(issued / PEAK_F32_MFMA_TFLOPS, 4),
                         'flops_per_row': 2 * VIS_MACS_ISSUED, 'rows_per_launch': top, 'avg_launch_ms': round(avg_ms, 3),
                         'launches': len(durs), 'share_of_step': round(avg_ms / ms_per_step, 3),
-                        'algorithmic_flops_per_row': 2 * VIS_MACS, 'algorithmic_achieved': round(algo, 2),
-                        'algorithmic_frac': round(algo / PEAK_F32_MFMA_TFLOPS, 4),
+                        'reference_formulation': {'flops_per_row': 2 * VIS_MACS, 'equivalent_tflops': round(algo, 2),
+                                                  'note': "the reference's unfactorised 523,520 MAC per row at this launch's duration: a "
+                                                          'throughput EQUIVALENT (work the kernel does not execute), not a roofline fraction'},
                         'traffic': traffic, 'algorithmic_bytes': comp,
                         'traffic_over_algorithmic': round(traffic / comp, 2) if (traffic and comp) else None,
                         'pmc_mfma_busy_frac': busy,
                         'note': 'achieved = 2 x 462,848 MAC per row x rows / avg launch duration (HIP events, second pass): the two layers '
                                 'that read [pe(x) | pe(l)] start from per-point / per-light tables, W [pe(x) | pe(l)] = W_a pe(x) + W_b pe(l), '
-                                'computed once per point / light by separate small GEMMs (DESIGN.md 3).  algorithmic_* prices the '
-                                "reference's 523,520 MAC per row at the same duration.  traffic = 2 x FETCH_SIZE + WRITE_SIZE of the "
+                                'computed once per point / light by separate small GEMMs (DESIGN.md 3).  traffic = 2 x FETCH_SIZE + WRITE_SIZE of the '
                                 'dispatch (rocprofv3 PMC, profiles/pmc_traffic.json; Infinity-Cache hits included), algorithmic_bytes = '
-                                'compulsory HBM bytes (tables and weights once, outputs, activation dumps of the V supervised rows); the '
-                                'ratio is re-read traffic of the init tables served by L2 / MALL on an MFMA-bound kernel'}
+                                'compulsory HBM bytes (tables and weights once, outputs, activation dumps of the V supervised rows).  '
+                                'Round 6: the workgroups visit the (light, point) row set point-tile-major (psn_mlp_block_order), so the '
+                                'per-point init table is read from the fabric once instead of once per light'}
         cpu = parity = None
         if not args.no_cpu_baseline and world == 1:  # the CPU oracle is timed at N = 1 only (other ranks would idle behind it)
             try:
                 parity = parity_check(device)
             except Exception as e:  # noqa: BLE001
                 parity = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
-            cpu = cpu_baseline()
+            cpu = cpu_baseline(all_core_workers=not args.no_cpu_all_cores)
         line = {
             'metric': 'ray-samples/sec (train step) on BEAR stage2', 'value': round(value, 1), 'unit': 'ray-samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
@@ -991,7 +1033,10 @@ def main():
                        'vis_lights': N_VIS, 'parallelism': 'pixel-dp%d' % world,
                        'batch': "ViewSampler.batch layout: reference dictionary + 'surface_idx' (host-built index list of the surface mask)"},
             'loss': round(float(terms['total'].detach()), 6),
-            'roofline': roofline, 'cpu_baseline': cpu, 'reference_dict': ref_dict, 'launches_per_step': launches,
+            'roofline': roofline, 'cpu_baseline': cpu,
+            'cpu_baseline_single_thread': cpu.get('single_thread') if cpu else None,   # (what the reference's trainer pins, stage2/trainer.py:23)
+            'cpu_baseline_all_cores': cpu.get('all_cores') if cpu else None,
+            'reference_dict': ref_dict, 'launches_per_step': launches,
             'bf16x6_experiment': x6, 'sampler_in_loop': in_loop,
             ('strong' if args.scaling == 'weak' else 'weak'): other,
             'strong_cfg4': cfg4, 'parity': parity,

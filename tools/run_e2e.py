@@ -108,7 +108,9 @@ def main():
     from psnerf_amd.optim import FlatAdam
     from psnerf_amd.synthetic import stage1_camera, stage1_cfg, look_at_pose
     import psnerf_amd.stage2 as s2
+    from psnerf_amd import ops as _ops
     from psnerf_amd.stage2 import relight
+    _ops.STRICT = True   # engine selection is loud: a fallback off the fused engines raises
     from psnerf_amd.stage2.trainer import VisPlus
 
     rank, local, world = pdist.init_from_env(backend=args.backend, set_device=not args.single_device)
