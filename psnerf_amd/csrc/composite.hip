@@ -327,6 +327,146 @@ __global__ __launch_bounds__(256) void composite_fwd_flat_kernel(const float* __
     }
 }
 
+// Forward with SEVERAL rays per wave (round 6): a ray occupies LPR = 16 (S <= 64) or 32 (S <= 128) lanes, a lane owns four
+// consecutive samples -- 16-byte accesses on alpha and the weights (1 KB contiguous per wave instruction over the wave's adjacent
+// rays), the transmittance scan is the 4-step DPP row scan (+ one row broadcast for LPR = 32) and the four ray sums are DPP row
+// reductions (quad permutes + mirrors: no LDS crossbar).  Measured at 2 M-4 M rays (tools/dbg/experiments/composite_variants.hip,
+// profiles/r06b_composite_variants_*.jsonl): S = 64: 5.07 TB/s against 4.7-4.8 for the one-ray-per-wave kernel (whose lanes hold one
+// sample each there), S = 96: 5.39 against 4.93; at S = 128 the blocked one-ray kernel stays ahead (4.95-5.1 against 4.7-4.8) and
+// keeps the launch.  A plain streaming kernel with the forward's byte mix (4 reads : 1 write, float4 per lane) reaches 4.8-5.2 TB/s
+// on the same box: that, not the 6.3 TB/s read-mostly figure, is the ceiling these kernels sit under.
+constexpr int kQuad1 = 0xB1, kQuad2 = 0x4E, kHalfMirror = 0x141, kMirror = 0x140;
+__device__ __forceinline__ float row_allsum(float v) {
+    v += dpp_from<kQuad1, 0xf>(0.0f, v);
+    v += dpp_from<kQuad2, 0xf>(0.0f, v);
+    v += dpp_from<kHalfMirror, 0xf>(0.0f, v);
+    v += dpp_from<kMirror, 0xf>(0.0f, v);
+    return v;
+}
+
+struct MRegs {
+    float a[4];
+    float c[12];
+};
+
+// MODE 0: temporal loads / stores, 1: non-temporal
+template <int LPR, int MODE>
+__device__ __forceinline__ void m_load(MRegs& r, const float* __restrict__ alpha, const float* __restrict__ rgb, int64_t ray, int S,
+                                       int sub, bool live) {
+    const int s0 = sub * 4;
+    if (live && s0 < S) {
+        const float* ap = alpha + ray * S + s0;
+        const float* cp = rgb + (ray * S + s0) * 3;
+        float4 t = MODE == 1 ? nt_load4(ap) : *reinterpret_cast<const float4*>(ap);
+        r.a[0] = t.x; r.a[1] = t.y; r.a[2] = t.z; r.a[3] = t.w;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float4 u = MODE == 1 ? nt_load4(cp + 4 * i) : *reinterpret_cast<const float4*>(cp + 4 * i);
+            r.c[4 * i] = u.x; r.c[4 * i + 1] = u.y; r.c[4 * i + 2] = u.z; r.c[4 * i + 3] = u.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.a[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r.c[i] = 0.0f;
+    }
+}
+
+template <int LPR, int MODE>
+__device__ __forceinline__ void m_ray(const MRegs& r, int64_t ray, int S, int white_bg, int lane, int sub, bool live,
+                                      float* __restrict__ weights, float* __restrict__ rgb_out, float* __restrict__ acc_out) {
+    const int s0 = sub * 4;
+    const bool in = s0 < S;
+    float p[5];
+    p[0] = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i + 1] = p[i] * (in ? (1.0f - r.a[i] + kEps) : 1.0f);
+    float incl = row_incl_prod(p[4]);
+    float pre;
+    if constexpr (LPR == 32) {
+        incl *= dpp_from<kRowBcast15, 0xa>(1.0f, incl);
+        pre = wave_prev(incl, 1.0f);
+        if ((lane & 31) == 0) pre = 1.0f;
+    } else {
+        pre = dpp_from<kRowShr1, 0xf>(1.0f, incl);
+    }
+    float w[4];
+    float acc = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        w[i] = r.a[i] * (pre * p[i]);
+        acc += w[i];
+        q0 += w[i] * r.c[3 * i];
+        q1 += w[i] * r.c[3 * i + 1];
+        q2 += w[i] * r.c[3 * i + 2];
+    }
+    if (weights != nullptr && live && in) {
+        float* wp = weights + ray * S + s0;
+        if (MODE == 1) nt_store4(wp, w[0], w[1], w[2], w[3]);
+        else *reinterpret_cast<float4*>(wp) = make_float4(w[0], w[1], w[2], w[3]);
+    }
+    acc = row_allsum(acc); q0 = row_allsum(q0); q1 = row_allsum(q1); q2 = row_allsum(q2);
+    if constexpr (LPR == 32) {
+        acc += dpp_from<kRowBcast15, 0xa>(0.0f, acc);
+        q0 += dpp_from<kRowBcast15, 0xa>(0.0f, q0);
+        q1 += dpp_from<kRowBcast15, 0xa>(0.0f, q1);
+        q2 += dpp_from<kRowBcast15, 0xa>(0.0f, q2);
+    }
+    if (live && sub == LPR - 1) {
+        const float bg = white_bg ? (1.0f - acc) : 0.0f;
+        acc_out[ray] = acc;
+        rgb_out[ray * 3 + 0] = q0 + bg;
+        rgb_out[ray * 3 + 1] = q1 + bg;
+        rgb_out[ray * 3 + 2] = q2 + bg;
+    }
+}
+
+template <int LPR, int MODE, int DEPTH>
+__global__ __launch_bounds__(256) void composite_fwd_multi_kernel(const float* __restrict__ alpha, const float* __restrict__ rgb,
+                                                                  int64_t n_rays, int S, int white_bg, float* __restrict__ weights,
+                                                                  float* __restrict__ rgb_out, float* __restrict__ acc_out) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (LPR - 1), rq = lane / LPR;
+    const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * RPW;
+    int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * RPW;
+    if (base >= n_rays) return;
+    if constexpr (DEPTH == 1) {
+        MRegs r0, r1;
+        m_load<LPR, MODE>(r0, alpha, rgb, base + rq, S, sub, base + rq < n_rays);
+        while (true) {
+            int64_t nxt = base + stride;
+            if (nxt < n_rays) m_load<LPR, MODE>(r1, alpha, rgb, nxt + rq, S, sub, nxt + rq < n_rays);
+            m_ray<LPR, MODE>(r0, base + rq, S, white_bg, lane, sub, base + rq < n_rays, weights, rgb_out, acc_out);
+            if (nxt >= n_rays) break;
+            base = nxt;
+            nxt = base + stride;
+            if (nxt < n_rays) m_load<LPR, MODE>(r0, alpha, rgb, nxt + rq, S, sub, nxt + rq < n_rays);
+            m_ray<LPR, MODE>(r1, base + rq, S, white_bg, lane, sub, base + rq < n_rays, weights, rgb_out, acc_out);
+            if (nxt >= n_rays) break;
+            base = nxt;
+        }
+    } else {  // two ray sets ahead (three register sets)
+        MRegs r0, r1, r2;
+        m_load<LPR, MODE>(r0, alpha, rgb, base + rq, S, sub, base + rq < n_rays);
+        if (base + stride < n_rays) m_load<LPR, MODE>(r1, alpha, rgb, base + stride + rq, S, sub, base + stride + rq < n_rays);
+        while (true) {
+            int64_t n2 = base + 2 * stride;
+            if (n2 < n_rays) m_load<LPR, MODE>(r2, alpha, rgb, n2 + rq, S, sub, n2 + rq < n_rays);
+            m_ray<LPR, MODE>(r0, base + rq, S, white_bg, lane, sub, base + rq < n_rays, weights, rgb_out, acc_out);
+            base += stride; if (base >= n_rays) break;
+            n2 = base + 2 * stride;
+            if (n2 < n_rays) m_load<LPR, MODE>(r0, alpha, rgb, n2 + rq, S, sub, n2 + rq < n_rays);
+            m_ray<LPR, MODE>(r1, base + rq, S, white_bg, lane, sub, base + rq < n_rays, weights, rgb_out, acc_out);
+            base += stride; if (base >= n_rays) break;
+            n2 = base + 2 * stride;
+            if (n2 < n_rays) m_load<LPR, MODE>(r1, alpha, rgb, n2 + rq, S, sub, n2 + rq < n_rays);
+            m_ray<LPR, MODE>(r2, base + rq, S, white_bg, lane, sub, base + rq < n_rays, weights, rgb_out, acc_out);
+            base += stride; if (base >= n_rays) break;
+        }
+    }
+}
+
 // Accumulated opacity only (shadow rays, stage1/model/rendering.py:405-406: no colours, no weights kept), S <= 128 and a
 // multiple of 16: FOUR rays per wave -- a ray occupies one DPP row of 16 lanes, a lane owns E = S / 16 consecutive samples
 // (16-byte loads), the transmittance scan is the 4-step row scan and the ray sum a 4-step row reduction.  With one ray
@@ -492,6 +632,21 @@ extern "C" int psn_composite_fwd(const float* alpha, const float* rgb, int64_t n
         hipLaunchKernelGGL(composite_fwd_flat_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, alpha, rgb, n_rays, n_samples,
                            white_bg, weights, rgb_out, acc_out);
         PSN_CHECK_LAUNCH("composite_fwd (flat layout)");
+        return PSN_OK;
+    }
+    if (rgb != nullptr && weights != nullptr && n_samples % 4 == 0 && n_samples < 128 &&
+        (((uintptr_t)alpha | (uintptr_t)rgb | (uintptr_t)weights) & 15) == 0) {
+        // several rays per wave, four samples per lane (S <= 64: 4 rays, non-temporal accesses; 64 < S < 128: 2 rays, temporal)
+        const int rpw = n_samples <= 64 ? 4 : 2;
+        int64_t blocks = (n_rays + kWavesPerBlock * rpw - 1) / (kWavesPerBlock * rpw);
+        if (n_samples <= 64) {
+            if (blocks > 256 * 8) blocks = 256 * 8;
+            hipLaunchKernelGGL((composite_fwd_multi_kernel<16, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, alpha, rgb, n_rays, n_samples, white_bg, weights, rgb_out, acc_out);
+        } else {
+            if (blocks > 256 * 16) blocks = 256 * 16;
+            hipLaunchKernelGGL((composite_fwd_multi_kernel<32, 0, 1>), dim3((unsigned)blocks), dim3(256), 0, st, alpha, rgb, n_rays, n_samples, white_bg, weights, rgb_out, acc_out);
+        }
+        PSN_CHECK_LAUNCH("composite_fwd (several rays per wave)");
         return PSN_OK;
     }
     int E = (n_samples + 63) / 64;
