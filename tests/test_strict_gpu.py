@@ -84,25 +84,24 @@ def test_stage2_train_step_of_every_shipped_config_takes_the_fused_engines(cuda,
 
 def test_strict_raises_where_the_default_falls_back(cuda):
     """A width the register-resident engines do not cover (192): by default the layer-wise HIP GEMMs run and the event is
-    counted; under ops.strict() the same call raises.  CPU tensors never count."""
+    counted; under ops.strict() the same call raises.  CPU tensors never count (ops.fallback ignores them)."""
     from psnerf_amd import ops
     from psnerf_amd.stage2.renderer import MLP
     torch.manual_seed(0)
-    m = MLP(39, 3, 192, 4, skip_at=(2,), final='sigmoid')
-    cols = torch.arange(39)
-    x = torch.randn(100, 64)
+    m = MLP(39, 3, 192, 4, skip_at=(2,), final='sigmoid').to(cuda)
+    cols = torch.arange(39, device=cuda)
+    x = torch.randn(100, 64, device=cuda)
     ops.reset_hits()
     with ops.strict():
-        y_cpu = m(x, cols)   # CPU tensors: the torch formulation, not a fallback
+        ops.fallback('a CPU tensor', torch.zeros(3), 'not a fallback')
     assert not ops.FALLBACKS
-    m.to(cuda)
     h0 = ops.HITS['ReluMLP']
-    y = m(x.to(cuda), cols.to(cuda))
-    assert sum(ops.FALLBACKS.values()) == 1 and ops.HITS['ReluMLP'] == h0 + 1
-    assert float((y.detach().cpu() - y_cpu.detach()).abs().max()) < 1e-5
+    y = m(x, cols)
+    assert sum(ops.FALLBACKS.values()) == 1 and ops.HITS['ReluMLP'] == h0 + 1 and y.shape == (100, 3)
     with ops.strict(), pytest.raises(RuntimeError, match='STRICT'):
-        m(x.to(cuda), cols.to(cuda))
+        m(x, cols)
     # a deliberate switch is not a fallback
     m.FUSED = False
     with ops.strict():
-        m(x.to(cuda), cols.to(cuda))
+        y2 = m(x, cols)
+    assert torch.equal(y, y2)
