@@ -94,7 +94,6 @@ struct InferArgs {
     // 60 MB at 29k points) stay in the XCD's L2 instead of being streamed from the fabric once per light.  0 = row order.
     int64_t pm_period;
     int pm_groups;
-    int phase_delay;  // chain variant (experiment, PSN_CHAIN_PHASE): the workgroups 256..511 -- the SECOND resident workgroup of every CU -- start this many x 1024 cycles late
 };
 
 constexpr int kStageFloats = 8192;  // 32 input features x 256 outputs = 32 KB
@@ -548,12 +547,6 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
             else { pt = nfull; l = (unsigned)(((uint64_t)(v - nfull * G) * (kWaves * 16)) / r); }
             blk_ = (int64_t)l * nfull + ((int64_t)l * r + kWaves * 16 - 1) / (kWaves * 16) + pt;
         }
-    }
-    if constexpr (CHAIN) {
-        // phase experiment: the two workgroups of a CU run the same period (8 weight stages of MFMAs, then the activation program with
-        // its operand loads and dumps); started together they want the matrix pipe at the same time and idle it at the same time
-        if (g.phase_delay > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-            for (int i = 0; i < g.phase_delay; ++i) __builtin_amdgcn_s_sleep(16);
     }
     int64_t row_ = blk_ * (kWaves * 16) + wave * 16 + lj;
     int64_t m_ray = 0;  // SRC == 3: this workgroup's ray and the step of this lane's row
@@ -1443,8 +1436,6 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
         static const int tb = [] { const char* e = getenv("PSN_TB_LDS"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
         a.tb_lds = tb;
         // point-major block order (InferArgs.pm_period): pair row sets row = group * P + point of the lean engine (A/B: PSN_POINT_MAJOR=0)
-        static const int phase = [] { const char* e = getenv("PSN_CHAIN_PHASE"); return e != nullptr ? atoi(e) : 0; }();
-        a.phase_delay = chain ? phase : 0;
         const int pm = g_point_major.load(std::memory_order_relaxed);
         const bool pair = !chain && a_div == 1 && (tab_b != nullptr || init_b != nullptr) && b_div == a_mod && b_div >= rows_per_block &&
                           b_mod >= 2 && b_mod < (1 << 20) && n_rows == b_div * b_mod && blocks + 8 < (1ll << 31);
