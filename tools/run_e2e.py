@@ -50,6 +50,14 @@ def sphere_scene(K, c2w, h, w, lights, radius=0.6, albedo=(0.7, 0.5, 0.3), inten
 
 
 def main():
+    """The chain under ops.STRICT: engine selection is loud (a fallback off the fused engines raises); restored on exit so that a
+    caller that runs main() in-process (tests/test_e2e_gpu.py) keeps its own setting."""
+    from psnerf_amd import ops as _ops
+    with _ops.strict():
+        _main()
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--h', type=int, default=48)
     ap.add_argument("--w", type=int, default=48)
@@ -108,9 +116,7 @@ def main():
     from psnerf_amd.optim import FlatAdam
     from psnerf_amd.synthetic import stage1_camera, stage1_cfg, look_at_pose
     import psnerf_amd.stage2 as s2
-    from psnerf_amd import ops as _ops
     from psnerf_amd.stage2 import relight
-    _ops.STRICT = True   # engine selection is loud: a fallback off the fused engines raises
     from psnerf_amd.stage2.trainer import VisPlus
 
     rank, local, world = pdist.init_from_env(backend=args.backend, set_device=not args.single_device)
