@@ -308,12 +308,6 @@ int psn_mlp_infer_padded(const PsnMlpDesc* desc, const float* packed_w, const fl
  * the fabric once instead of once per light; 0: row order (the light-major sweep).  A row's result does not depend on the
  * order (bit-identical outputs and dumps).  Process-wide; returns the previous value. */
 int psn_mlp_block_order(int point_major);
-/* Chain launches (psn_mlp_infer with activation programs) of the 256-wide fp32 engine -- the geometry / appearance chains of
- * stage1/model/network.py:85-120 and the ReLU backward chains of stage2/model/renderer.py:34-49: 1 (default) = a layer's
- * activation program (operand loads, element-wise code, dumps) runs tile pair by tile pair inside the NEXT layer's weight-stage
- * loop, so that the chain's memory traffic is spread over its matrix work; 0 = the classic form (program between two layers).
- * Bit-identical results.  Process-wide; returns the previous value. */
-int psn_mlp_chain_pipeline(int pipelined);
 /* psn_mlp_infer, plain forward with activation dumps (stage2/model/renderer.py:251-262: the supervision rows of the visibility
  * network, :127-143 / :163-189 the normal / BRDF networks), that ALSO leaves the sign bits of every dumped activation behind:
  * save_bits_ptrs[l] [n_rows - save_row0, 4] uint64 (NULL per layer: none).  The ReLU-backward chain (PSN_ACT_RELU_BITS, the words

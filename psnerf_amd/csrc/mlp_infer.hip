@@ -1053,429 +1053,6 @@ __global__ __launch_bounds__(256, 2) void mlp_infer_kernel(InferArgs g) {
     }
 }
 
-// ---- chain engine, PIPELINED activation programs (round 6) ------------------------------------------------------------------
-// The chain variant above runs a layer as [8 weight stages of MFMAs] [activation program: 16-32 operand loads, 1024 values, 16-32
-// dump stores]: all of the layer's operand and dump traffic (up to 64 KB per wave) is issued in one burst between two MFMA phases,
-// the dumps must have drained one stage later (vmcnt counts loads and stores in order and the next weight stage's LDS-DMA pieces are
-// younger than they are), and the loads' latency is exposed once per layer.  Counters (profiles/r05a_pmc_chains_single_dump.json):
-// the sweep adjoint moves 9 GB in 2.6 ms with the matrix pipe 62 % busy -- neither roof.
-// Here layer l's program is DEFERRED into layer l + 1's stage loop: the accumulators z_l stay in registers, and stage kt of layer
-// l + 1 first turns the two 16-feature tiles (2 kt, 2 kt + 1) of z_l into its B operands -- their operand tiles were requested one
-// stage earlier, their dumps are issued at once and drain under the stage's 128 MFMAs --, then requests the operand tiles of the
-// next pair.  Per stage and wave: 4 operand loads, 4 dump stores, 8 LDS-DMA pieces, one vmcnt(0); the memory traffic of a chain is
-// spread evenly over its matrix work instead of alternating with it.  Same arithmetic per element in the same order: results are
-// bit-identical to the classic chain kernel (tests/test_kernels_gpu.py).  HEAD layers and the final layers run classically.
-template <int CODE, bool FROMA>
-__device__ __forceinline__ void act_tile(const floatx4& z, const floatx4& t1, const floatx4& t2, const unsigned long long sign_bits,
-                                         const int mt, floatx4& o, floatx4& o2) {
-    constexpr bool kFromA = FROMA && (CODE == PSN_ACT_MUL_AUX || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD);
-    if constexpr (CODE == PSN_ACT_SOFTPLUS100) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f32x2 a, sg;
-            softplus100_pair<true>(f32x2{z[2 * h], z[2 * h + 1]}, a, sg);
-            o[2 * h] = a.x; o[2 * h + 1] = a.y; o2[2 * h] = sg.x; o2[2 * h + 1] = sg.y;
-        }
-    } else if constexpr (CODE == PSN_ACT_MUL_AUX || CODE == PSN_ACT_MUL2 || CODE == PSN_ACT_SOFTPLUS_BWD) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x2 zz = {z[2 * h], z[2 * h + 1]};
-            f32x2 a1 = {t1[2 * h], t1[2 * h + 1]};
-            if constexpr (kFromA) {
-                const f32x2 t = a1 * (-100.0f * 1.44269502162933349609375f);
-                a1 = 1.0f - f32x2{__builtin_amdgcn_exp2f(fminf(t.x, 0.0f)), __builtin_amdgcn_exp2f(fminf(t.y, 0.0f))};
-            }
-            f32x2 a, b = zz;
-            if constexpr (CODE == PSN_ACT_MUL_AUX) a = zz * a1;
-            else if constexpr (CODE == PSN_ACT_MUL2) { a = zz * a1; b = zz * f32x2{t2[2 * h], t2[2 * h + 1]}; }
-            else a = pk_fma(a1, zz, ((1.0f - a1) * 100.0f) * f32x2{t2[2 * h], t2[2 * h + 1]});
-            o[2 * h] = a.x; o[2 * h + 1] = a.y; o2[2 * h] = b.x; o2[2 * h + 1] = b.y;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = z[r];
-            o2[r] = v;
-            if constexpr (CODE == PSN_ACT_RELU) o[r] = relu1(v);
-            else if constexpr (CODE == PSN_ACT_RELU_MASK) o[r] = t1[r] > 0.0f ? v : 0.0f;
-            else if constexpr (CODE == PSN_ACT_RELU_BITS)
-                o[r] = (((4 * mt + r) < 32 ? (unsigned)sign_bits : (unsigned)(sign_bits >> 32)) & (1u << ((4 * mt + r) & 31))) != 0u ? v : 0.0f;
-            else o[r] = v;
-        }
-    }
-}
-
-// The deferred program of the previous layer: row offsets (floats) of this lane's 4-float group in the operand / dump tensors and the
-// (wave-uniform) tensor bases; a null base = no such operand / dump.
-struct PipeProg {
-    const float* p1; const float* p2; float* d1; float* d2;
-    uint32_t m1, m2;
-    unsigned long long bits;
-};
-
-template <bool TRIM, bool FROMA>
-__global__ __launch_bounds__(256, 2) void chain_pipe_kernel(InferArgs g) {
-    constexpr int NMT = 16, W = 256;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* bias_lds = smem + 2 * kStageFloats;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lj = lane & 15, lg = lane >> 4;
-    const int64_t row = (int64_t)blockIdx.x * (kWaves * 16) + wave * 16 + lj;
-    const int64_t rowc = row < g.n_rows ? row : g.n_rows - 1;
-    const int n_layers = g.d.n_layers;
-    {
-        const int l0 = (g.d.layers[0].n_kt_in + g.d.layers[0].n_kt_act > 0) ? 0 : 1;
-        stage_load<2 * NMT, false>(g.w + g.d.layers[l0].w_off, smem, wave, lane);
-    }
-    const int64_t ia = (rowc / g.a_div) % g.a_mod;
-    const int64_t ib = (rowc / g.b_div) % g.b_mod;
-    const float* init_a_row = g.init_a != nullptr ? g.init_a + ia * (int64_t)g.d.init_stride : nullptr;
-    const float* init_b_row = g.init_b != nullptr ? g.init_b + ib * (int64_t)g.d.init_stride : nullptr;
-    const float* pa = g.ta != nullptr ? g.ta + ia * (int64_t)(g.d.in_kt_a * 32) : nullptr;
-    const float* pb = (g.d.in_kt_b > 0 && g.tb != nullptr) ? g.tb + ib * (int64_t)(g.d.in_kt_b * 32) : nullptr;
-    auto load_xin = [&](floatx4 (&xin)[8]) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float* src = nullptr;
-            if (t < 2 * g.d.in_kt_a) src = pa != nullptr ? pa + t * 16 : nullptr;
-            else if (t < 2 * (g.d.in_kt_a + g.d.in_kt_b)) src = pb != nullptr ? pb + (t - 2 * g.d.in_kt_a) * 16 : nullptr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src != nullptr) v = *reinterpret_cast<const float4*>(src + 4 * lg);
-            xin[t][0] = v.x; xin[t][1] = v.y; xin[t][2] = v.z; xin[t][3] = v.w;
-        }
-    };
-    for (int i = tid; i < g.n_bias; i += kWaves * 64) bias_lds[i] = g.b[i];
-
-    floatx4 zq[NMT];   // pipelined layers: the pre-activation values z of the previous layer (or the initial activations); classic: activations
-    floatx4 acc[NMT];
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) zq[mt][r] = 0.f;
-    if (g.act_init != nullptr) {
-        const bool has_row = rowc < g.act_init_rows;
-        const float* ap = g.act_init + (has_row ? rowc : 0) * W + 4 * lg;
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) {
-            float4 t = *reinterpret_cast<const float4*>(ap + mt * 16);
-            zq[mt][0] = has_row ? t.x : 0.f; zq[mt][1] = has_row ? t.y : 0.f; zq[mt][2] = has_row ? t.z : 0.f; zq[mt][3] = has_row ? t.w : 0.f;
-        }
-    }
-    int gstage = 0;
-    const bool dump_row = row < g.n_rows && row >= g.save_row0;
-    const int64_t off_in = rowc * W + 4 * lg;                                   // this lane's group in an operand row
-    const int64_t off_out = (dump_row ? row - g.save_row0 : 0) * W + 4 * lg;     // ... in a dump row
-    const int n_hidden = g.d.n_out > 0 ? n_layers - 1 : n_layers;
-
-    // the deferred program: applied to zq tile pair by tile pair inside the next layer's stage loop
-    int code = PSN_ACT_NONE;
-    PipeProg pr = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0ull};
-    floatx4 t1a, t1b, t2a, t2b;  // operand tiles of the pair that is activated next
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { t1a[r] = 0.f; t1b[r] = 0.f; t2a[r] = 0.f; t2b[r] = 0.f; }
-
-#define PIPE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define PIPE_MMA(B0, B1, S_IDX)                                                                             \
-    {                                                                                                       \
-        asm volatile("s_barrier" ::: "memory");                                                             \
-        const int s_ = (S_IDX);                                                                             \
-        float* nxt = smem + ((gstage + 1) & 1) * kStageFloats;                                              \
-        const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);             \
-        const float* src_ = s_ + 1 < n_st ? wl_g + (int64_t)(s_ + 1) * stage_floats : (next_w != nullptr ? next_w : g.w); \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
-        stage_compute<NMT, NMT, false>(acc, B0, B1, wl, lane, [&](int j_) { stage_piece<2 * NMT, false>(src_, nxt, wave, lane, j_); }); \
-        ++gstage;                                                                                           \
-    }
-    // pair KT of the deferred program CODE: operands have landed (PIPE_WAIT), B operands b0 / b1, dumps issued, next pair requested
-#define PIPE_ACT(C, KT)                                                                                     \
-        case C:                                                                                             \
-            act_tile<C, FROMA>(zq[2 * (KT)], t1a, t2a, pr.bits, 2 * (KT), b0, s0);                            \
-            act_tile<C, FROMA>(zq[2 * (KT) + 1], t1b, t2b, pr.bits, 2 * (KT) + 1, b1, s1);                    \
-            break;
-    // (the program code is wave-uniform: ONE branch per stage around ~20-150 vector instructions; the MFMA stream behind it is
-    //  common code -- a switch around whole stage loops made the allocator spill ~2000 registers at the merges)
-#define PIPE_PAIR(KT)                                                                                       \
-        floatx4 b0, b1, s0, s1;                                                                             \
-        switch (code) {                                                                                     \
-            PIPE_ACT(PSN_ACT_RELU, KT)                                                                      \
-            PIPE_ACT(PSN_ACT_SOFTPLUS100, KT)                                                               \
-            PIPE_ACT(PSN_ACT_RELU_MASK, KT)                                                                 \
-            PIPE_ACT(PSN_ACT_MUL_AUX, KT)                                                                   \
-            PIPE_ACT(PSN_ACT_MUL2, KT)                                                                      \
-            PIPE_ACT(PSN_ACT_SOFTPLUS_BWD, KT)                                                              \
-            PIPE_ACT(PSN_ACT_RELU_BITS, KT)                                                                 \
-            default:                                                                                        \
-                act_tile<PSN_ACT_NONE, FROMA>(zq[2 * (KT)], t1a, t2a, pr.bits, 2 * (KT), b0, s0);             \
-                act_tile<PSN_ACT_NONE, FROMA>(zq[2 * (KT) + 1], t1b, t2b, pr.bits, 2 * (KT) + 1, b1, s1);     \
-                break;                                                                                      \
-        }                                                                                                   \
-        if (pr.d1 != nullptr && dump_row) {                                                                 \
-            if ((pr.m1 >> (2 * (KT))) & 1) st4(pr.d1 + off_out + (2 * (KT)) * 16, b0);                        \
-            if ((pr.m1 >> (2 * (KT) + 1)) & 1) st4(pr.d1 + off_out + (2 * (KT) + 1) * 16, b1);                \
-        }                                                                                                   \
-        if (pr.d2 != nullptr && dump_row) {                                                                 \
-            if ((pr.m2 >> (2 * (KT))) & 1) st4(pr.d2 + off_out + (2 * (KT)) * 16, s0);                        \
-            if ((pr.m2 >> (2 * (KT) + 1)) & 1) st4(pr.d2 + off_out + (2 * (KT) + 1) * 16, s1);                \
-        }                                                                                                   \
-        if ((KT) < NMT / 2 - 1) {                                                                           \
-            if (pr.p1 != nullptr) { t1a = ld4(pr.p1 + off_in + (2 * (KT) + 2) * 16); t1b = ld4(pr.p1 + off_in + (2 * (KT) + 3) * 16); } \
-            if (pr.p2 != nullptr) { t2a = ld4(pr.p2 + off_in + (2 * (KT) + 2) * 16); t2b = ld4(pr.p2 + off_in + (2 * (KT) + 3) * 16); } \
-        }
-
-    int li = 0;
-    // ---- pipelined layers: up to the first HEAD layer (or all hidden layers)
-    for (; li < n_hidden && g.d.layers[li].act != PSN_ACT_HEAD; ++li) {
-        const PsnMlpLayer L = g.d.layers[li];
-        const int n_st = L.n_kt_in + L.n_kt_act;
-        const int stage_floats = NMT * 512;
-        const float* wl_g = g.w + L.w_off;
-        const float* next_w = li + 1 < n_layers ? g.w + g.d.layers[li + 1].w_off : nullptr;
-        {  // bias -> accumulator init (as in mlp_infer_kernel)
-            const float* bp = bias_lds + L.b_off;
-            if (li == 0) __syncthreads();
-#pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) {
-                float4 bv = *reinterpret_cast<const float4*>(bp + mt * 16 + 4 * lg);
-                acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
-            }
-            if (L.init_off >= 0) {
-                if (init_a_row != nullptr) {
-#pragma unroll
-                    for (int mt = 0; mt < NMT; ++mt) {
-                        float4 u = *reinterpret_cast<const float4*>(init_a_row + L.init_off + mt * 16 + 4 * lg);
-                        acc[mt][0] += u.x; acc[mt][1] += u.y; acc[mt][2] += u.z; acc[mt][3] += u.w;
-                    }
-                }
-                if (init_b_row != nullptr) {
-#pragma unroll
-                    for (int mt = 0; mt < NMT; ++mt) {
-                        float4 u = *reinterpret_cast<const float4*>(init_b_row + L.init_off + mt * 16 + 4 * lg);
-                        acc[mt][0] += u.x; acc[mt][1] += u.y; acc[mt][2] += u.z; acc[mt][3] += u.w;
-                    }
-                }
-                if (g.rk_coef != nullptr) {
-                    for (int c = 0; c < g.rk_k; ++c) {
-                        const float cf = g.rk_coef[rowc * g.rk_k + c];
-                        const float* bp2 = g.rk_basis + (int64_t)c * g.d.init_stride + L.init_off + 4 * lg;
-#pragma unroll
-                        for (int mt = 0; mt < NMT; ++mt) {
-                            const float4 u = *reinterpret_cast<const float4*>(bp2 + mt * 16);
-                            acc[mt][0] = fmaf(cf, u.x, acc[mt][0]); acc[mt][1] = fmaf(cf, u.y, acc[mt][1]);
-                            acc[mt][2] = fmaf(cf, u.z, acc[mt][2]); acc[mt][3] = fmaf(cf, u.w, acc[mt][3]);
-                        }
-                    }
-                }
-            }
-        }
-        if (L.n_kt_act > 0) {
-#pragma unroll
-            for (int kt = 0; kt < NMT / 2 - 1; ++kt) {
-                PIPE_WAIT();
-                PIPE_PAIR(kt)
-                PIPE_MMA(b0, b1, kt)
-            }
-            {
-                PIPE_WAIT();
-                PIPE_PAIR(NMT / 2 - 1)
-                if (!TRIM || L.n_kt_act == NMT / 2) PIPE_MMA(b0, b1, NMT / 2 - 1)
-            }
-        }
-        if (L.n_kt_in > 0) {
-            floatx4 xin[8];
-            load_xin(xin);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                if (kt < L.n_kt_in) { PIPE_WAIT(); PIPE_MMA(xin[2 * kt], xin[2 * kt + 1], L.n_kt_act + kt) }
-            }
-        }
-        // defer this layer's program into the next layer's stage loop (or the block below): z stays in registers
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) zq[mt] = acc[mt];
-        code = L.act;
-        pr.p1 = (L.act == PSN_ACT_RELU_BITS) ? nullptr : g.mask[li];
-        pr.p2 = g.aux2[li];
-        pr.d1 = g.save[li];
-        pr.d2 = g.save2[li];
-        pr.m1 = g.save_tiles[li];
-        pr.m2 = g.save2_tiles[li];
-        if (L.act == PSN_ACT_RELU_BITS) pr.bits = reinterpret_cast<const unsigned long long*>(g.mask[li])[rowc * 4 + lg];
-        if (pr.p1 != nullptr) { t1a = ld4(pr.p1 + off_in); t1b = ld4(pr.p1 + off_in + 16); }
-        if (pr.p2 != nullptr) { t2a = ld4(pr.p2 + off_in); t2b = ld4(pr.p2 + off_in + 16); }
-    }
-    {
-        // the pending program in full (every tile): zq becomes the ACTIVATIONS that the remaining layers consume classically
-        PIPE_WAIT();
-        const float* q1 = pr.p1 != nullptr ? pr.p1 + off_in : nullptr;
-        const float* q2 = pr.p2 != nullptr ? pr.p2 + off_in : nullptr;
-        float* e1 = (pr.d1 != nullptr && dump_row) ? pr.d1 + off_out : nullptr;
-        float* e2 = (pr.d2 != nullptr && dump_row) ? pr.d2 + off_out : nullptr;
-#define PSN_CASE(C) case C: chain_activation<C, NMT, FROMA>(zq, zq, q1, q2, e1, e2, pr.m1, pr.m2); break;
-        switch (code) {
-            case PSN_ACT_RELU_BITS: chain_activation<PSN_ACT_RELU_BITS, NMT>(zq, zq, nullptr, nullptr, e1, e2, pr.m1, pr.m2, pr.bits); break;
-            PSN_CASE(PSN_ACT_RELU)
-            PSN_CASE(PSN_ACT_SOFTPLUS100)
-            PSN_CASE(PSN_ACT_RELU_MASK)
-            PSN_CASE(PSN_ACT_MUL_AUX)
-            PSN_CASE(PSN_ACT_MUL2)
-            PSN_CASE(PSN_ACT_SOFTPLUS_BWD)
-            default: chain_activation<PSN_ACT_NONE, NMT>(zq, zq, q1, q2, e1, e2, pr.m1, pr.m2); break;
-        }
-#undef PSN_CASE
-    }
-    // ---- classic layers: a HEAD layer and whatever hidden layers follow it (activation program between two layers)
-    for (; li < n_hidden; ++li) {
-        const PsnMlpLayer L = g.d.layers[li];
-        const int n_st = L.n_kt_in + L.n_kt_act;
-        const int stage_floats = NMT * 512;
-        const float* wl_g = g.w + L.w_off;
-        const float* next_w = li + 1 < n_layers ? g.w + g.d.layers[li + 1].w_off : nullptr;
-        {  // bias -> accumulator init (as in mlp_infer_kernel)
-            const float* bp = bias_lds + L.b_off;
-            if (li == 0) __syncthreads();
-#pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) {
-                float4 bv = *reinterpret_cast<const float4*>(bp + mt * 16 + 4 * lg);
-                acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
-            }
-            if (L.init_off >= 0) {
-                if (init_a_row != nullptr) {
-#pragma unroll
-                    for (int mt = 0; mt < NMT; ++mt) {
-                        float4 u = *reinterpret_cast<const float4*>(init_a_row + L.init_off + mt * 16 + 4 * lg);
-                        acc[mt][0] += u.x; acc[mt][1] += u.y; acc[mt][2] += u.z; acc[mt][3] += u.w;
-                    }
-                }
-                if (init_b_row != nullptr) {
-#pragma unroll
-                    for (int mt = 0; mt < NMT; ++mt) {
-                        float4 u = *reinterpret_cast<const float4*>(init_b_row + L.init_off + mt * 16 + 4 * lg);
-                        acc[mt][0] += u.x; acc[mt][1] += u.y; acc[mt][2] += u.z; acc[mt][3] += u.w;
-                    }
-                }
-                if (g.rk_coef != nullptr) {
-                    for (int c = 0; c < g.rk_k; ++c) {
-                        const float cf = g.rk_coef[rowc * g.rk_k + c];
-                        const float* bp2 = g.rk_basis + (int64_t)c * g.d.init_stride + L.init_off + 4 * lg;
-#pragma unroll
-                        for (int mt = 0; mt < NMT; ++mt) {
-                            const float4 u = *reinterpret_cast<const float4*>(bp2 + mt * 16);
-                            acc[mt][0] = fmaf(cf, u.x, acc[mt][0]); acc[mt][1] = fmaf(cf, u.y, acc[mt][1]);
-                            acc[mt][2] = fmaf(cf, u.z, acc[mt][2]); acc[mt][3] = fmaf(cf, u.w, acc[mt][3]);
-                        }
-                    }
-                }
-            }
-        }
-        if (L.n_kt_act > 0) {
-#pragma unroll
-            for (int kt = 0; kt < NMT / 2 - 1; ++kt) { PIPE_WAIT(); PIPE_MMA(zq[2 * kt], zq[2 * kt + 1], kt) }
-            if (!TRIM || L.n_kt_act == NMT / 2) { PIPE_WAIT(); PIPE_MMA(zq[NMT - 2], zq[NMT - 1], NMT / 2 - 1) }
-        }
-        if (L.n_kt_in > 0) {
-            floatx4 xin[8];
-            load_xin(xin);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                if (kt < L.n_kt_in) { PIPE_WAIT(); PIPE_MMA(xin[2 * kt], xin[2 * kt + 1], L.n_kt_act + kt) }
-            }
-        }
-        const float* q1 = g.mask[li] != nullptr ? g.mask[li] + off_in : nullptr;
-        const float* q2 = g.aux2[li] != nullptr ? g.aux2[li] + off_in : nullptr;
-        float* e1 = (g.save[li] != nullptr && dump_row) ? g.save[li] + off_out : nullptr;
-        float* e2 = (g.save2[li] != nullptr && dump_row) ? g.save2[li] + off_out : nullptr;
-        const uint32_t m1 = g.save_tiles[li], m2 = g.save2_tiles[li];
-#define PSN_CASE(C) case C: chain_activation<C, NMT, FROMA>(acc, zq, q1, q2, e1, e2, m1, m2); break;
-        switch (L.act) {
-            case PSN_ACT_RELU_BITS:
-                chain_activation<PSN_ACT_RELU_BITS, NMT>(acc, zq, nullptr, nullptr, e1, e2, m1, m2,
-                                                         reinterpret_cast<const unsigned long long*>(g.mask[li])[rowc * 4 + lg]);
-                break;
-            PSN_CASE(PSN_ACT_RELU)
-            PSN_CASE(PSN_ACT_SOFTPLUS100)
-            PSN_CASE(PSN_ACT_RELU_MASK)
-            PSN_CASE(PSN_ACT_MUL_AUX)
-            PSN_CASE(PSN_ACT_MUL2)
-            PSN_CASE(PSN_ACT_SOFTPLUS_BWD)
-            PSN_CASE(PSN_ACT_HEAD)
-            default: chain_activation<PSN_ACT_NONE, NMT>(acc, zq, q1, q2, e1, e2, m1, m2); break;
-        }
-#undef PSN_CASE
-    }
-#undef PIPE_ACT
-#undef PIPE_PAIR
-#undef PIPE_MMA
-    // ---- final layer(s): as in mlp_infer_kernel<true, 16> (zq = the activations)
-    const bool wide_final = g.d.n_out > 32;
-    if (wide_final) {
-        const PsnMlpLayer L = g.d.layers[li];
-        const float* bp = bias_lds + L.b_off;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            float4 bv = *reinterpret_cast<const float4*>(bp + mt * 16 + 4 * lg);
-            acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
-        }
-        PIPE_WAIT();
-        asm volatile("s_barrier" ::: "memory");
-        const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
-        stage_load<2 * NMT, false>(g.w + L.w_off + kStageFloats, smem + ((gstage + 1) & 1) * kStageFloats, wave, lane);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) stage_compute<4, NMT, false>(acc, zq[2 * kt], zq[2 * kt + 1], wl + kt * 512, lane, [](int) {});
-        ++gstage;
-        PIPE_WAIT();
-        asm volatile("s_barrier" ::: "memory");
-        wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) stage_compute<4, NMT, false>(acc, zq[8 + 2 * kt], zq[8 + 2 * kt + 1], wl + kt * 512, lane, [](int) {});
-    } else if (g.d.n_out > 0) {
-        const PsnMlpLayer L = g.d.layers[li];
-        const float* bp = bias_lds + L.b_off;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            float4 bv = *reinterpret_cast<const float4*>(bp + mt * 16 + 4 * lg);
-            acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
-        }
-        PIPE_WAIT();
-        __syncthreads();
-        const float4* wl = reinterpret_cast<const float4*>(smem + (gstage & 1) * kStageFloats);
-        if (g.d.n_out <= 16) {
-#pragma unroll
-            for (int kt = 0; kt < NMT / 2; ++kt) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float4 a = wl[kt * 256 + e * 128 + lane];
-                    const floatx4& bs = e ? zq[2 * kt + 1] : zq[2 * kt];
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bs[0], acc[0], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bs[1], acc[0], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bs[2], acc[0], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bs[3], acc[0], 0, 0, 0);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int kt = 0; kt < NMT / 2; ++kt) stage_compute<2, NMT, false>(acc, zq[2 * kt], zq[2 * kt + 1], wl + kt * 256, lane, [](int) {});
-        }
-    }
-#undef PIPE_WAIT
-    if (row < g.n_rows && g.d.n_out > 0) {
-        const int n_out = g.d.n_out;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * mt + 4 * lg + r;
-                if (f < n_out) {
-                    float v = acc[mt][r];
-                    if (g.d.out_act == PSN_OUT_SIGMOID) v = sigmoidf_(v);
-                    else if (g.d.out_act == PSN_OUT_OCC) v = sigmoidf_(v * -10.0f);
-                    g.out[row * n_out + f] = v;
-                }
-            }
-        }
-    }
-}
-
 // ---- fused secant root finder, feature-parallel form ---------------------------------------------------------------------
 // The row-parallel engine above needs one serial pass through the network per secant iteration whatever the ray count
 // (a wave owns 16 rays x all 256 outputs: 128 MFMAs = 4096 matrix-pipe cycles per weight stage and SIMD), and 4096 rays
@@ -1756,13 +1333,6 @@ extern "C" int psn_mlp_block_order(int point_major) {
     return g_point_major.exchange(point_major != 0 ? 1 : 0, std::memory_order_relaxed);
 }
 
-// Chain launches of the 256-wide fp32 engine: 1 = pipelined activation programs (chain_pipe_kernel, default), 0 = the classic
-// layer-by-layer form.  Bit-identical results.
-static std::atomic<int> g_chain_pipe{[] { const char* e = getenv("PSN_CHAIN_PIPE"); return (e != nullptr && e[0] == '0') ? 0 : 1; }()};
-extern "C" int psn_mlp_chain_pipeline(int pipelined) {
-    return g_chain_pipe.exchange(pipelined != 0 ? 1 : 0, std::memory_order_relaxed);
-}
-
 static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const float* packed_b, const float* tab_a,
                           int64_t a_div, int64_t a_mod, const float* tab_b, int64_t b_div, int64_t b_mod,
                           const float* init_a, const float* init_b, float* const* save_ptrs, int64_t save_row0,
@@ -1895,21 +1465,6 @@ static int mlp_infer_impl(const PsnMlpDesc* desc, const float* packed_w, const f
     const bool x3 = d.w_format == PSN_W_BF16X2;
     PSN_CHECK_ARG(d.w_format == PSN_W_F32 || x3, "mlp_infer: unknown weight format %d", d.w_format);
     PSN_CHECK_ARG(!x3 || hid == 8, "mlp_infer: split-bf16 weight stages (PSN_W_BF16X2) are built for the 256-wide networks only");
-    // pipelined activation programs (chain_pipe_kernel): fp32 weight stages, 256-wide, every hidden layer behind the first reads the
-    // previous layer's activations (so a deferred program always finds a stage loop to run in)
-    bool pipe = chain && hid == 8 && !x3 && g_chain_pipe.load(std::memory_order_relaxed) != 0 && live_count == nullptr && d.n_layers >= 2;
-    for (int l = 1; l < (d.n_out > 0 ? d.n_layers - 1 : d.n_layers); ++l) pipe = pipe && d.layers[l].n_kt_act >= hid - 1;
-    if (pipe) {
-        if (from_a) {
-            if (trim) hipLaunchKernelGGL((chain_pipe_kernel<true, true>), grid, block, lds_bytes, st, a);
-            else hipLaunchKernelGGL((chain_pipe_kernel<false, true>), grid, block, lds_bytes, st, a);
-        } else {
-            if (trim) hipLaunchKernelGGL((chain_pipe_kernel<true, false>), grid, block, lds_bytes, st, a);
-            else hipLaunchKernelGGL((chain_pipe_kernel<false, false>), grid, block, lds_bytes, st, a);
-        }
-        PSN_CHECK_LAUNCH("mlp_infer (pipelined chain)");
-        return PSN_OK;
-    }
     if (x3 && !chain) {
         if (trim) hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 0, true, false, true>), grid, block, lds_bytes, st, a);
         else hipLaunchKernelGGL((mlp_infer_kernel<false, 16, 0, false, false, true>), grid, block, lds_bytes, st, a);

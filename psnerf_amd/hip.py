@@ -131,7 +131,6 @@ SIGNATURES = {
     'psn_gemm_tn_grouped': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
     'psn_gemm_tn_x3_set_products': (i32, [i32]),
     'psn_mlp_block_order': (i32, [i32]),
-    'psn_mlp_chain_pipeline': (i32, [i32]),
     'psn_gemm_tn_grouped_x3': (i32, [i32, ctypes.c_void_p, i64, i32, c_f, i64, c_f]),
     'psn_colsum': (i32, [c_f, c_f, i32, i64, i64, i32, i64, c_f, i32, c_f, c_f]),
     'psn_sample_points': (i32, [c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, c_f]),
@@ -1196,22 +1195,6 @@ def mlp_pack_layers(plan):
             e.W, e.dst, e.ldw = W.data_ptr(), dst.data_ptr(), W.stride(0)
             e.rows, e.cols, e.transpose, e.n_mt, e.k_tiles = rows, cols, int(transpose), n_mt, k_tiles
         _check(_lib.psn_mlp_pack_layers(len(chunk), ctypes.addressof(arr), _stream()), 'mlp_pack_layers')
-
-
-class chain_pipeline(object):
-    """``with hip.chain_pipeline(False):`` -- chain launches in the classic layer-by-layer form instead of the pipelined activation
-    programs (psn_mlp_chain_pipeline; bit-identical results)."""
-
-    def __init__(self, on):
-        self.on = bool(on)
-
-    def __enter__(self):
-        self.saved = _lib.psn_mlp_chain_pipeline(1 if self.on else 0)
-        return self
-
-    def __exit__(self, *exc):
-        _lib.psn_mlp_chain_pipeline(self.saved)
-        return False
 
 
 class block_order(object):
