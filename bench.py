@@ -772,12 +772,20 @@ def main():
         torch.cuda.set_device(device)
         print('CFG4_JSON ' + json.dumps(strong_cfg4(device, None, 0, 1)), flush=True)
         return
+    wall = {}
+    t_mark = [time.perf_counter()]
+
+    def mark(name):   # wall seconds per leg of this run (reported as 'wall_s': what a driver's clock around the command is spent on)
+        now = time.perf_counter()
+        wall[name] = round(wall.get(name, 0.0) + now - t_mark[0], 2)
+        t_mark[0] = now
     cfg4_n1 = None
     if args.gpus == 1 and not args.no_extra and int(os.environ.get('WORLD_SIZE', '1')) == 1:
         # N = 1: the strong_cfg4 object needs a process group of its own (RCCL in a world of one rank) and captures HIP graphs
         # next to RCCL's watchdog thread -- it runs in a CHILD process, started HERE, before this process has touched the GPU
         # (nothing is ever exec'ed from a GPU-initialised process), so that nothing it does can take the headline line down
         cfg4_n1 = run_cfg4_child()
+        mark('strong_cfg4 (child process)')
 
     import torch.distributed as dist
     from psnerf_amd import dist as pdist, hip, ops as _ops
@@ -863,10 +871,13 @@ def main():
 
     head_batch, other_batch = (weak_batch, strong_batch) if args.scaling == 'weak' else (strong_batch, weak_batch)
     inp, gt = head_batch()
+    mark('imports, model, batch')
     dt, ns_total, terms = timed(inp, gt, args.steps, args.warmup)
+    mark('headline (warm-up + timed steps)')
     px_local = inp['uv'].shape[1]
     events = instrumented(inp, gt, min(args.steps, 10))
     launches = count_launches(inp, gt) if not args.no_extra else None
+    mark('instrumented pass + launch count')
     ref_dict = None
     if not args.no_extra and world == 1:
         # the drop-in number: the reference's own dictionary, no 'surface_idx' -- PSNetwork.forward then builds the index list
@@ -878,6 +889,7 @@ def main():
                     'steps': k3, 'warmup': 2, 'batch': "the reference's model_input keys only (stage2/model/renderer.py:110-125); the "
                     "surface index list is built inside the step"}
         del inp_ref
+    mark('reference_dict')
     x6 = None
     if not args.no_extra and world == 1:
         # EXPERIMENT, never the headline: the L shading rows (gradient-free: vis.detach(), renderer.py:197) on the split-bf16
@@ -938,6 +950,7 @@ def main():
             step.model.train_vis_bf16x6 = False
             step.model.train_vis_bf16x3 = False
     del inp, gt
+    mark('bf16 experiments')
     ms_per_step = dt / args.steps * 1e3
     value = ns_total * N_LIGHTS / (dt / args.steps)
     in_loop = None
@@ -948,6 +961,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             in_loop = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
+    mark('sampler_in_loop')
     other = None
     allreduce_ms = None
     if not args.no_extra:
@@ -964,6 +978,7 @@ def main():
     bucket_bytes = step.dp.allreduce_bytes
     cfg4 = cfg4_n1
 
+    mark('other scaling mode')
     stage1 = None
     if world == 1 and not args.no_stage1:
         del step
@@ -975,6 +990,7 @@ def main():
                     stage1[key] = fn()
                 except Exception as e:  # noqa: BLE001
                     stage1[key] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    mark('stage1 (step, parity, CPU baseline)')
     line = None
     if rank == 0:
         # dominant kernel: fused visibility MLP over (L + V) * Ns rows, one launch per step (the smaller launches of the
@@ -1019,6 +1035,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 parity = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
             cpu = cpu_baseline(all_core_workers=not args.no_cpu_all_cores)
+        mark('stage2 parity + CPU baseline')
         line = {
             'metric': 'ray-samples/sec (train step) on BEAR stage2', 'value': round(value, 1), 'unit': 'ray-samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
@@ -1042,6 +1059,7 @@ def main():
             'strong_cfg4': cfg4, 'parity': parity,
             'allreduce_ms': allreduce_ms, 'allreduce_bytes': bucket_bytes if world > 1 else None,
             'stage1': stage1,
+            'wall_s': wall,
         }
     if not args.no_extra and world > 1:
         # The diagnostic object runs LAST, behind a watchdog: it captures HIP graphs around RCCL collectives on every rank, a path no

@@ -19,6 +19,7 @@ MI355X mapping:
   * the dense [B, N, C] output dictionary -> one psn_scatter_rows launch (ops.ScatterRows).
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -555,6 +556,10 @@ class PSNetwork(nn.Module):
                            and (self.light_vis_detach or not (light_dir.requires_grad or lv.requires_grad)))
                 if pair_ok:
                     # shading rows and supervision rows in ONE fused launch (the latter dump their activations)
+                    # (round 6, measured and dropped: attaching this node BEHIND the shading node -- so that autograd queues the V-row
+                    #  chain and its 256 x 256 weight gradients first -- costs 0.23 ms at 4096 px (3.74 -> 3.97 ms replayed) and 0.45 ms
+                    #  at 32768 px: the weight-gradient launch holds every CU while the small networks' backward, the longer dependent
+                    #  chain, waits; profiles/r06d_ab_strong4096.jsonl)
                     if vis_bf16 is not None:
                         _none, vis_t_pre = self._visibility_pair(pe_x, light_dir[:0], lv, launched=vis_pair)
                         vis = vis_bf16
