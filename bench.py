@@ -144,7 +144,7 @@ def parity_check(device, n_pixels=4096):
 
 def cpu_baseline(n_pixels=4096, steps=3, all_core_workers=True):
     """The oracle (port of the reference's stage-2 step) on the host cores.  The thread count is swept on a 1024-pixel
-    sample (1 warm-up + 2 timed steps each) over {1, 8, 16, 32, 64} (more threads than that only oversubscribe the eager
+    sample (1 warm-up + 2 timed steps each) over {1, 8, 16, 32} (more threads than that only oversubscribe the eager
     CPU kernels: 256 threads measured 1.1 k ray-samples/s against 203 k with 16); the best count is then timed on a bounded
     4096-pixel sample of the same workload (min of 3 after 1 warm-up).  One thread is what the reference's own trainer
     pins (stage2/trainer.py:23) and is reported beside it."""
@@ -153,7 +153,7 @@ def cpu_baseline(n_pixels=4096, steps=3, all_core_workers=True):
     t_all = torch.get_num_threads()
     sweep = {}
     try:
-        for th in sorted({t for t in (1, 8, 16, 32, 64) if t <= nproc}):
+        for th in sorted({t for t in (1, 16, 32) if t <= nproc} | {min(8, nproc)}):   # (rounds 1-5 swept 1 / 8 / 16 / 32 / 64: the best was 16 on every 256-core box)
             torch.set_num_threads(th)
             ns1, dt1 = _cpu_steps(1024, 2)
             sweep[th] = ns1 * N_LIGHTS / dt1
@@ -181,7 +181,7 @@ def cpu_baseline(n_pixels=4096, steps=3, all_core_workers=True):
             'single_thread': {'value': sweep.get(1), 'cores': 1, 'sample': '1024 px, min of 2 timed steps after 1 warm-up'}}
 
 
-def _cpu_all_cores(threads, nproc, n_pixels=1024, steps=2, max_workers=16):
+def _cpu_all_cores(threads, nproc, n_pixels=512, steps=1, max_workers=16):
     """P worker processes x ``threads`` torch threads, all timing ``_cpu_steps(n_pixels, steps)`` concurrently (children of this
     process that never touch the GPU: `bench.py --cpu-worker`); value = the sum of the workers' rates."""
     import subprocess
@@ -441,7 +441,7 @@ def _stage1_cfg1(rays=512):
 def stage1_cpu_baseline(steps=3):
     """BASELINE.md section 3 for stage 1 = BASELINE configs[0] itself: the oracle's Trainer.train_step (port of
     stage1/model/training.py:46-60 -- march, render forward, loss, double backward, Adam) on the host cores at 512 rays x 64 samples.
-    Thread count swept on a 128-ray sample over {1, 8, 16, 32, 64}; the best count then runs the 512-ray step (1 warm-up + ``steps``
+    Thread count swept on a 128-ray sample over {1, 8, 16}; the best count then runs the 512-ray step (1 warm-up + ``steps``
     timed, minimum); one thread (what the stage-2 trainer of the reference pins; stage 1 does not pin) is reported beside it."""
     import torch
     from oracle import stage1 as o1
@@ -463,7 +463,7 @@ def stage1_cpu_baseline(steps=3):
     t_all = torch.get_num_threads()
     sweep = {}
     try:
-        for th in sorted({t for t in (1, 8, 16, 32, 64) if t <= nproc}):
+        for th in sorted({t for t in (1, 16) if t <= nproc} | {min(8, nproc)}):
             torch.set_num_threads(th)
             sweep[th] = 128 * 64 / run(128, 1)
         best_th = max(sweep, key=sweep.get)
