@@ -54,7 +54,9 @@ def main():
                 shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, name)))
     for name in ('march_sweep.json', 'bf16x6_kernel.json', 'bf16x6_kernel_zero_operands.json', 'tn256.txt', 'shadow_visibility.json',
                  'composite.json', 'pmc_x3.csv', 'strong_projection.json', 'x3occ.txt', 'strong4096_kernel_stats.csv',
-                 'timeline_4096_graph.txt', 'timeline_32768.txt', 'stage1_rank_shards.jsonl', 'e2e_full.json', 'e2e_full_bf16x3.json', 'tn256_x3.json', 'ab_single_dump.json', 'ab_chain_x3.json', 'lrow_x3.json'):
+                 'timeline_4096_graph.txt', 'timeline_32768.txt', 'stage1_rank_shards.jsonl', 'e2e_full.json', 'e2e_full_bf16x3.json', 'tn256_x3.json', 'ab_single_dump.json', 'ab_chain_x3.json', 'lrow_x3.json',
+                 'ab_block_order.json', 'pmc_block_order.json', 'composite_kernel_stats.csv', 'composite_pmc.json', 'composite_bench.json',
+                 'pmc_chains_single.json'):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, name)))

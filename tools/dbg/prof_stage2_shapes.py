@@ -21,9 +21,9 @@ for e in prof.key_averages(group_by_input_shape=True):
     t = getattr(e, 'self_device_time_total', None)
     if t is None:
         t = e.self_cuda_time_total
-    if e.key.startswith('aten::') and t >= 10:
+    if e.key.startswith('aten::') and t >= 1:
         rows.append((t, e.count, e.key, str(e.input_shapes)[:120]))
 rows.sort(reverse=True)
 print('total %.3f ms' % (sum(r[0] for r in rows) / 1e3))
-for t, c, k, sh in rows[:40]:
+for t, c, k, sh in rows[:60]:
     print('%8.1f us %3d  %-22s %s' % (t, c, k, sh))

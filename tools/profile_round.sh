@@ -61,4 +61,10 @@ python3 $R/tools/dbg/ab_single_dump.py 2>/dev/null | tail -1 > $O/ab_single_dump
 # split-bf16 weight stages (PSN_W_BF16X2): the four geometry chains and the shading-row launch, fp32 vs three partial products
 python3 $R/tools/dbg/ab_chain_x3.py 2>/dev/null | tail -1 > $O/ab_chain_x3.json
 python3 $R/tools/dbg/bench_lrow_x3.py 2>/dev/null | tail -1 > $O/lrow_x3.json
+# round 6 additions: the visibility launch per workgroup order (times + PMC traffic), the composite kernels under rocprofv3 at a
+# size where they are HBM-bound (kernel stats + FETCH_SIZE / WRITE_SIZE), the geometry chains' counters
+python3 $R/tools/ab_block_order.py 2>/dev/null | tail -1 > $O/ab_block_order.json
+bash $R/tools/pmc_block_order.sh $TAG > /dev/null 2>&1
+bash $R/tools/prof_composite.sh $TAG > /dev/null 2>&1
+bash $R/tools/dbg/pmc_chains.sh $TAG single > /dev/null 2>&1
 ls -la $O
