@@ -85,6 +85,7 @@ def main():
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo for 1-GPU dry runs)')
     ap.add_argument('--single-device', action='store_true', help='dry run: every rank uses cuda:0')
     ap.add_argument('--cfg4-child', action='store_true', help=argparse.SUPPRESS)  # internal: the strong_cfg4 object in a process of its own
+    ap.add_argument('--cfg4-graph', action='store_true', help='N > 1: also capture / replay HIP graphs in the strong_cfg4 diagnostic (default: its eager step only)')
     ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)  # internal: one worker of the all-core CPU baseline (never touches the GPU)
     ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the all-core leg of the CPU baseline (P worker processes)')
     args = ap.parse_args()
@@ -399,7 +400,7 @@ def main():
     if not args.no_extra and world > 1:
         # The diagnostic object runs LAST, behind a watchdog: it captures HIP graphs around RCCL collectives on every rank, a path no
         # multi-GPU node has exercised yet -- if it does not come back, rank 0 still prints the headline line (assembled above).
-        cfg4 = guarded(lambda: strong_cfg4(device, step.dp, rank, world), line, rank)
+        cfg4 = guarded(lambda: strong_cfg4(device, step.dp, rank, world, graph_at_n=args.cfg4_graph or os.environ.get('PSN_BENCH_CFG4_GRAPH') == '1'), line, rank)
         if line is not None:
             line['strong_cfg4'] = cfg4
     if world > 1:

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     out_path = sys.argv[1]
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--backend', 'gloo', '--single-device',
-           '--no-stage1', '--no-cpu-baseline', '--pixels', '4096']
+           '--no-stage1', '--no-cpu-baseline', '--pixels', '4096', '--cfg4-graph']   # (--cfg4-graph: the N > 1 graph capture of the diagnostic is opt-in)
     res = {'ok': False, 'cmd': ' '.join(cmd)}
     try:
         p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
