@@ -253,6 +253,67 @@ def test_sync_free_training_forward_matches_reference_shaped_path(cuda, monkeypa
             assert_close(g1[k].cpu(), g0[k].cpu(), 1e-4, 'grad %s it%d' % (k, it))
 
 
+@pytest.mark.parametrize('case', ['all_miss', 'all_hit'])
+def test_sync_free_forward_on_batches_without_hits_or_without_misses_vs_oracle(cuda, case):
+    """Edge cases of the training forward (rendering.py:84-108: the hit / miss split): a batch in which EVERY ray misses the object
+    (the hit group of the reference is empty: no surface points, no normals, diff_norm of zero rows, grad_loss = 0) and one in which
+    every ray hits (the miss group is empty).  The sync-free forward has no groups -- one flagged launch over all rays, masked
+    normals, device-side counts -- and must still give the oracle's outputs, loss terms and parameter gradients."""
+    from oracle import stage1 as o1
+    from psnerf_amd.stage1 import Loss, NeuralNetwork, Renderer
+    from psnerf_amd.stage1.rendering import sync_free_noise_for_reference
+    from psnerf_amd.synthetic import stage1_camera
+    cfg = stage1_cfg('bunny')
+    sd = stage1_state_dict(cfg, seed=11)
+    h, w = 48, 64
+    K, c2w, S = stage1_camera(cfg, h=h, w=w)
+    onet = o1.NeuralNetwork(cfg)
+    onet.load_state_dict(sd)
+    oren = o1.Renderer(onet, cfg)
+    # classify every pixel once with the oracle, then draw the batch from one class only
+    ys, xs = torch.meshgrid(torch.arange(0, h, 2).float(), torch.arange(0, w, 2).float(), indexing='ij')   # (every second pixel: 768 rays on the CPU)
+    grid = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1)[None]
+    with torch.no_grad():
+        mask_all = oren(grid, K, c2w, S, 'unisurf', add_noise=False, eval_=True, it=100)['mask_pred']
+    pool = grid[0][mask_all if case == 'all_hit' else ~mask_all]
+    assert pool.shape[0] >= 96, (case, pool.shape)
+    gen = torch.Generator().manual_seed(7)
+    n = 96
+    pix = pool[torch.randperm(pool.shape[0], generator=gen)[:n]][None]
+    rgb_gt = torch.rand(1, n, 3, generator=gen)
+    ngt = torch.nn.functional.normalize(torch.randn(1, n, 3, generator=gen), dim=-1)
+    nmask = torch.rand(1, n, generator=gen) > 0.3
+    it = 100
+    noise = {'full': torch.rand(n, 64, generator=gen), 'nbr_full': torch.rand(n, 3, generator=gen)}
+    net = NeuralNetwork(cfg)
+    net.load_state_dict(sd)
+    ren = Renderer(net, cfg, device=cuda)
+    ren.sync_free = True
+    out = ren(pix.to(cuda), K.to(cuda), c2w.to(cuda), S.to(cuda), 'unisurf', add_noise=True, eval_=False, it=it,
+              noise={k: v.to(cuda) for k, v in noise.items()})
+    hit = out['mask_pred'].cpu()
+    assert int(hit.sum()) == (n if case == 'all_hit' else 0)
+    o = oren(pix, K, c2w, S, 'unisurf', add_noise=True, eval_=False, it=it, noise=sync_free_noise_for_reference(noise, hit))
+    assert torch.equal(o['mask_pred'], hit)
+    for k in ('rgb', 'normal_pred', 'acc_map'):
+        assert_close(out[k].detach().cpu(), o[k].detach(), 1e-4, k, atol=ATOL_NORMAL if k == 'normal_pred' else ATOL_UNIT)
+    terms = Loss(1.0, 0.005, 0.05, 1.0, device=cuda)(out, rgb_gt.to(cuda), ngt.to(cuda), nmask.to(cuda))
+    oterms = o1.Loss(1.0, 0.005, 0.05, 1.0)(o, rgb_gt, ngt, nmask)
+    assert sorted(terms) == sorted(oterms)
+    for k in oterms:
+        assert_close(float(terms[k].detach()), float(oterms[k].detach()), 1e-3 if k == 'grad_loss' else 1e-4, k, atol=1e-12)
+    if case == 'all_miss':
+        assert float(terms['grad_loss'].detach()) == 0.0 and float(oterms['grad_loss']) == 0.0
+    terms['loss'].backward()
+    oterms['loss'].backward()
+    og = {k: v.grad for k, v in onet.named_parameters()}
+    for k, v in net.named_parameters():
+        if og[k] is None:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+        else:
+            assert_close(v.grad.cpu(), og[k], 1e-3, 'grad ' + k)
+
+
 @pytest.mark.parametrize('it', [100, 6000])
 def test_sync_free_forward_with_jitter_vs_oracle(cuda, it):
     """The forward the bench and the Trainer actually run -- Renderer._unisurf_sync_free: one flagged sampling launch, one
